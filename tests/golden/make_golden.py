@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory by running the UNMODIFIED reference.
+
+Run in the build container only (needs /root/reference; the GPU box has no reference):
+
+    python tests/golden/make_golden.py
+
+It imports the reference modules read-only (sys.dont_write_bytecode, a stub for the
+un-buildable `operators._ext.segment_reduction`) and stores small .npz
+files.  Parameters are drawn with `oracle.make_lanczosnet_params` (numpy RandomState ->
+reproducible on any machine) and loaded into the reference with `load_state_dict`, so
+full-size weights need not be committed — only a checksum.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('LANCZOS_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+class AttrDict(dict):
+  """EasyDict substitute: attribute access, AttributeError on missing keys (so the
+  reference's `hasattr(config.model, 'dropout')` probing works)."""
+
+  def __getattr__(self, k):
+    try:
+      v = self[k]
+    except KeyError:
+      raise AttributeError(k)
+    return AttrDict(v) if isinstance(v, dict) else v
+
+
+def import_reference():
+  for name in ('operators._ext', 'operators._ext.segment_reduction'):
+    sys.modules.setdefault(name, types.ModuleType(name))
+  sys.modules['operators._ext'].segment_reduction = sys.modules['operators._ext.segment_reduction']
+  if REF not in sys.path:
+    sys.path.insert(1, REF)
+  import model as ref_model  # noqa
+  import utils.data_helper as ref_dh  # noqa
+  import dataset.qm8 as ref_qm8  # noqa
+  return ref_model, ref_dh, ref_qm8
+
+
+def make_config(cfg, name='LanczosNet', general=False):
+  model = dict(name=name, short_diffusion_dist=cfg['short_diffusion_dist'],
+               long_diffusion_dist=cfg['long_diffusion_dist'], num_eig_vec=cfg['num_eig_vec'],
+               spectral_filter_kind=cfg['spectral_filter_kind'], input_dim=cfg['input_dim'],
+               hidden_dim=cfg['hidden_dim'], output_dim=cfg['output_dim'],
+               num_layer=cfg['num_layer'], loss='MSE')
+  if general:
+    dataset = dict(node_emb_dim=cfg['input_dim'], graph_emb_dim=cfg['output_dim'],
+                   num_edge_type=cfg['num_bond_type'])
+  else:
+    dataset = dict(num_atom=cfg['num_atom'], num_bond_type=cfg['num_bond_type'],
+                   data_path='/nonexistent')
+  return AttrDict(dict(seed=1234, dataset=dataset, model=model))
+
+
+def params_checksum(P):
+  return float(sum(float(np.abs(v.astype(np.float64)).sum()) for _, v in sorted(P.items())))
+
+
+def reference_preprocess(ref_dh, adjs_b, n):
+  """dataset/get_qm8_data.py:59-81 for one molecule (adjs_b: [N,N,E] padded)."""
+  adjs = adjs_b[:n, :n, :]
+  adj_simple = np.sum(adjs, axis=2)
+  _, _, L_list = ref_dh.get_multi_graph_laplacian_eigs(
+      adjs, graph_laplacian_type='L4', use_eigen_decomp=True, is_sym=True)
+  D, V, L4 = ref_dh.get_graph_laplacian_eigs(
+      adj_simple, graph_laplacian_type='L4', use_eigen_decomp=True, is_sym=True)
+  return dict(L_multi=np.stack(L_list, axis=2), L_simple_4=L4,
+              D_simple=D if D is not None else np.ones(n),
+              V_simple=V if V is not None else np.eye(n))
+
+
+def reference_collate(ref_qm8, config, mols, batch):
+  ds = ref_qm8.QM8Data(config, split='train')  # globs an empty dir; only collate_fn is used
+  items = []
+  for b, m in enumerate(mols):
+    n = int(batch['n_nodes'][b])
+    items.append(dict(node_feat=batch['node_feat'][b, :n], label=batch['label'][b:b + 1],
+                      L_multi=m['L_multi'], L_simple_4=m['L_simple_4'],
+                      D_simple=m['D_simple'], V_simple=m['V_simple']))
+  # dataset/qm8.py:254-259 calls np.expand_dims(x2d, axis=3); numpy < 1.18 clamped an
+  # out-of-range axis to ndim (-> [n,n,1]), numpy 2 raises.  Emulate the old numpy, leave
+  # the reference untouched.
+  real_expand = np.expand_dims
+  np.expand_dims = lambda a, axis: real_expand(a, min(axis, np.ndim(a)))
+  try:
+    return ds.collate_fn(items)
+  finally:
+    np.expand_dims = real_expand
+
+
+def main():
+  from oracle import make_lanczosnet_params, DEFAULT_QM8_CFG
+  from lanczosnet_amd.synthetic import draw_batch
+  ref_model, ref_dh, ref_qm8 = import_reference()
+  torch.set_num_threads(4)
+
+  # ---- 1. the reference's only fixture: the 6-node graph of utils/data_helper.py:297-299
+  adj6 = np.array([[0, 1, 0, 0, 1, 0], [1, 0, 1, 0, 1, 0], [0, 1, 0, 1, 0, 0],
+                   [0, 0, 1, 0, 1, 1], [1, 1, 0, 1, 0, 0],
+                   [0, 0, 0, 1, 0, 0]]).astype(np.float32)
+  out = dict(adj=adj6)
+  for t in ['L1', 'L2', 'L3', 'L4', 'L5', 'L6', 'L7']:
+    out[t] = ref_dh.get_laplacian(adj6, graph_laplacian_type=t)
+  e4, v4, _ = ref_dh.get_graph_laplacian_eigs(adj6, graph_laplacian_type='L4',
+                                              use_eigen_decomp=True, is_sym=True)
+  out['eigs_L4'], out['V_L4'] = e4, v4
+  e1, v1, _ = ref_dh.get_graph_laplacian_eigs(adj6, k=3, graph_laplacian_type='L1',
+                                              use_eigen_decomp=True, is_sym=True)
+  out['eigs_L1_k3'], out['V_L1_k3'] = e1, v1
+  np.savez_compressed(os.path.join(HERE, 'six_node.npz'), **out)
+
+  # ---- 2. preprocess + collate of a synthetic QM8-schema batch (R1, R2, R3)
+  cfg = dict(DEFAULT_QM8_CFG)
+  config = make_config(cfg)
+  batch = draw_batch(24, seed=11, n_min=3, n_max=26)  # includes n > K=20 and tiny molecules
+  mols = [reference_preprocess(ref_dh, batch['adjs'][b], int(batch['n_nodes'][b]))
+          for b in range(24)]
+  data = reference_collate(ref_qm8, config, mols, batch)
+  np.savez_compressed(
+      os.path.join(HERE, 'collate_batch.npz'), seed=11, batch_size=24, n_min=3, n_max=26,
+      n_nodes=batch['n_nodes'], L=data['L'].numpy(), D=data['D'].numpy(), V=data['V'].numpy(),
+      node_feat=data['node_feat'].numpy(), node_mask=data['node_mask'].numpy(),
+      label=data['label'].numpy(),
+      D_full=np.stack([np.pad(m['D_simple'], (0, 26 - len(m['D_simple']))) for m in mols]))
+
+  # ---- 3. LanczosNet forward, full QM8 config, weights from numpy seed 2024 (R7, R9, R10)
+  P = make_lanczosnet_params(cfg, seed=2024)
+  net = ref_model.LanczosNet(config).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  with torch.no_grad():
+    score, loss = net(data['node_feat'], data['L'], data['D'], data['V'],
+                      label=data['label'], mask=data['node_mask'].bool())
+  np.savez_compressed(os.path.join(HERE, 'lanczosnet_full.npz'), param_seed=2024,
+                      param_checksum=params_checksum(P), score=score.numpy(),
+                      loss=float(loss))
+
+  # ---- 4. small configs incl. short diffusion + non-MLP filters (branches :118-121, :164-169)
+  small = dict(num_atom=11, num_bond_type=2, short_diffusion_dist=[1, 3],
+               long_diffusion_dist=[2, 5], num_eig_vec=6, spectral_filter_kind='MLP',
+               input_dim=8, hidden_dim=[16, 12], output_dim=4, num_layer=2)
+  for tag, kind in (('mlp', 'MLP'), ('pow', 'None')):
+    c = dict(small, spectral_filter_kind=kind)
+    conf = make_config(c)
+    b2 = draw_batch(5, seed=5, n_min=3, n_max=9, num_atom=11, num_bond_type=2, num_label=4)
+    mols2 = [reference_preprocess(ref_dh, b2['adjs'][b], int(b2['n_nodes'][b])) for b in range(5)]
+    d2 = reference_collate(ref_qm8, conf, mols2, b2)
+    P2 = make_lanczosnet_params(c, seed=7)
+    net2 = ref_model.LanczosNet(conf).eval()
+    net2.load_state_dict({k: torch.from_numpy(v) for k, v in P2.items()})
+    with torch.no_grad():
+      s2 = net2(d2['node_feat'], d2['L'], d2['D'], d2['V'], mask=d2['node_mask'].bool())
+    np.savez_compressed(os.path.join(HERE, 'lanczosnet_small_%s.npz' % tag),
+                        cfg_json=np.array(repr(c)), param_seed=7, score=s2.numpy(),
+                        L=d2['L'].numpy(), D=d2['D'].numpy(), V=d2['V'].numpy(),
+                        node_feat=d2['node_feat'].numpy(), node_mask=d2['node_mask'].numpy())
+
+  # ---- 5. LanczosNetGeneral (R11), config/graph_lanczos_net.yaml shapes at reduced width
+  gen = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5],
+             num_eig_vec=8, spectral_filter_kind='MLP', input_dim=10, hidden_dim=[32, 32],
+             output_dim=2, num_layer=2, num_atom=0)
+  confg = make_config(gen, name='LanczosNetGeneral', general=True)
+  rs = np.random.RandomState(3)
+  Bg, Ng = 4, 12
+  Lg = np.zeros((Bg, Ng, Ng, 2), np.float32)
+  Dg = np.zeros((Bg, 8), np.float32)
+  Vg = np.zeros((Bg, Ng, 8), np.float32)
+  maskg = np.zeros((Bg, Ng), np.uint8)
+  for b in range(Bg):
+    n = int(rs.randint(6, Ng + 1))
+    a = (rs.rand(n, n) < 0.4).astype(np.float32)
+    a = np.triu(a, 1)
+    a = a + a.T
+    e, v, l4 = ref_dh.get_graph_laplacian_eigs(a, graph_laplacian_type='L4',
+                                               use_eigen_decomp=True, is_sym=True)
+    Lg[b, :n, :n, 0] = l4
+    Lg[b, :n, :n, 1] = l4
+    kk = min(8, n)
+    Dg[b, :kk] = e[:kk]
+    Vg[b, :n, :kk] = v[:, :kk]
+    maskg[b, :n] = 1
+  Xg = rs.randn(Bg, Ng, 10).astype(np.float32)
+  Pg = make_lanczosnet_params(gen, seed=9, general=True)
+  netg = ref_model.LanczosNetGeneral(confg).eval()
+  netg.load_state_dict({k: torch.from_numpy(v) for k, v in Pg.items()})
+  with torch.no_grad():
+    sg = netg(torch.from_numpy(Xg), torch.from_numpy(Lg), torch.from_numpy(Dg),
+              torch.from_numpy(Vg), mask=torch.from_numpy(maskg).bool())
+  np.savez_compressed(os.path.join(HERE, 'lanczosnet_general.npz'), cfg_json=np.array(repr(gen)),
+                      param_seed=9, node_feat=Xg, L=Lg, D=Dg, V=Vg, node_mask=maskg,
+                      score=sg.numpy())
+
+  # ---- 6. AdaLanczosNet._lanczos_layer and ._get_graph_laplacian (R4, R5), fixed start vector
+  ada_cfg = dict(cfg, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30],
+                 hidden_dim=[8], num_layer=1)  # tiny widths: only the two methods are exercised
+  conf_ada = make_config(ada_cfg, name='AdaLanczosNet')
+  # shrink the 4096-wide filter MLP so construction is cheap; not used below
+  ada = ref_model.AdaLanczosNet.__new__(ref_model.AdaLanczosNet)
+  torch.nn.Module.__init__(ada)
+  ada.num_eig_vec = 20
+  ada.use_reorthogonalization = True  # effective value in the reference
+  Lsim = data['L'][:, :, :, 0].clone()
+  Bn, Nn = Lsim.shape[0], Lsim.shape[1]
+  q1 = np.random.RandomState(77).randn(Bn, Nn, 1).astype(np.float32)
+  real_randn = torch.randn
+  try:
+    torch.randn = lambda *a, **k: torch.from_numpy(q1.copy())
+    with torch.no_grad():
+      T, Q = ada._lanczos_layer(Lsim, data['node_mask'])
+  finally:
+    torch.randn = real_randn
+  feat = torch.from_numpy(np.random.RandomState(78).randn(Bn, Nn, 5).astype(np.float32))
+  adj = (Lsim != 0).float()
+  with torch.no_grad():
+    Le = ada._get_graph_laplacian(feat, adj)
+    torch.randn = lambda *a, **k: torch.from_numpy(q1.copy())
+    try:
+      T2, Q2 = ada._lanczos_layer(Le, data['node_mask'])
+    finally:
+      torch.randn = real_randn
+  np.savez_compressed(os.path.join(HERE, 'ada_lanczos.npz'), A=Lsim.numpy(), q1=q1[:, :, 0],
+                      node_mask=data['node_mask'].numpy(), T=T.numpy(), Q=Q.numpy(),
+                      feat=feat.numpy(), adj=adj.numpy(), Le=Le.numpy(), T2=T2.numpy(),
+                      Q2=Q2.numpy())
+  print('golden fixtures written to', HERE)
+  for f in sorted(os.listdir(HERE)):
+    if f.endswith('.npz'):
+      print('  %-32s %8d B' % (f, os.path.getsize(os.path.join(HERE, f))))
+
+
+if __name__ == '__main__':
+  main()
