@@ -1,0 +1,148 @@
+/*
+ * lanczosnet_hip.h — C ABI of the MI355X (gfx950) LanczosNet hot path.
+ *
+ * The reference (lrjconan/LanczosNetwork) has no FFI in front of this path: the boundary
+ * is the Python nn.Module contract.  This header is what a binding for
+ * that path binds to; `lanczosnet_amd/_lib.py` is the ctypes binding, INTEGRATION.md shows
+ * the reference-side stub.  All pointers are DEVICE pointers unless the name ends in
+ * `_host`; all tensors are dense row-major float32 unless stated; `stream` is a
+ * hipStream_t (NULL = default stream).  Every entry point is asynchronous on `stream`,
+ * returns 0 on success and a negative LNZ_E* code on error (message via lnz_last_error()).
+ * Nothing here allocates device memory or synchronises the device.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference
+ * repository root).
+ */
+#ifndef LANCZOSNET_HIP_H_
+#define LANCZOSNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LNZ_ABI_VERSION 1
+#define LNZ_OK 0
+#define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
+#define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */
+#define LNZ_ENOTSUP (-3)  /* valid request outside the built range */
+
+#define LNZ_TILE 32       /* node tile: one v_mfma_f32_32x32x2_f32 tile per molecule */
+#define LNZ_MAX_CHANNELS 32
+
+typedef void* lnz_stream_t;
+
+int lnz_abi_version(void);
+const char* lnz_last_error(void);
+
+/* ---- R1: graph Laplacian ------------------------------------------------------------
+ * L4 = D^-1/2 (I + A) D^-1/2 for the simple graph (channel 0, A = sum_e A_e) and for every
+ * bond-type channel e (channel 1+e), written channels-last like the collate output.
+ * Replaces utils/data_helper.py:92-116,155-156 (normalize_adj / get_laplacian 'L4'),
+ * dataset/get_qm8_data.py:62-75 and the L part of dataset/qm8.py:225-262.
+ * adjs [B,N,N,E]; n_nodes [B] (rows/cols >= n are written as exact zeros); L [B,N,N,E+1].
+ * Arithmetic in fp64 (the reference builds L4 in float64), stored as float32. */
+int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B, int N, int E,
+                     float* L, lnz_stream_t stream);
+
+/* ---- R2 + R6: Lanczos tridiagonalisation -> tridiagonal eigensolve -> Ritz select ----
+ * Per molecule: full-length (m = n) Lanczos with twice-iterated classical Gram-Schmidt and
+ * restart on breakdown on the n x n leading block of A, implicit-shift QL on T with the
+ * rotations applied to Q (so the Ritz vectors V = Q*B come out directly), stable ordering
+ * by descending |lambda| (ties: ascending lambda), cut / zero-pad to K.  Produces exactly
+ * the (D, V) that utils/data_helper.py:197-223 (np.linalg.eigh + mergesort on -|eig|)
+ * followed by dataset/qm8.py:264-291 (pad rows to N, cut/pad to K, cast fp32) produce,
+ * up to the basis of degenerate eigenspaces and eigenvector sign.  fp64 arithmetic.
+ * A is addressed as A[b*stride_b + r*stride_r + c*stride_c] (elements) so channel 0 of a
+ * channels-last L [B,N,N,E+1] can be passed without a copy.  N <= 64.
+ * D [B,K], V [B,N,K].  info [B] (optional, may be NULL): number of Lanczos restarts. */
+int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                     const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
+                     int32_t* info, lnz_stream_t stream);
+
+/* ---- operand packing (MFMA fragment order) -------------------------------------------
+ * W [rows, cols] (leading dimension ld) -> Wp[rt][q][lane][u] =
+ *   W[32*rt + (lane&31)][8*q + 4*(lane>>5) + u], zero padded to rows%32==0, cols%8==0.
+ * One float4 per lane per (rt, q): the A- or B-operand stream of v_mfma_f32_32x32x2_f32
+ * for four consecutive k-steps.  Wp holds lnz_packed_rows_k8_size(rows, cols) floats. */
+int64_t lnz_packed_rows_k8_size(int rows, int cols);
+int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, float* Wp,
+                     lnz_stream_t stream);
+/* bias [rows] -> bp[rt][lane][r] = bias[32*rt + (r&3) + 8*(r>>2) + 4*(lane>>5)] (the C/D
+ * row of accumulator register r); holds 32*ceil(rows/32)*32 floats. */
+int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_stream_t stream);
+/* L [B,N,N,C] addressed by element strides -> Lp[b][c][g][lane][u] =
+ *   L[b][lane&31][8*g + 4*(lane>>5) + u][c], zero padded to the 32 x 32 tile (N <= 32).
+ * Replaces the per-slice `L[:, :, :, ii]` strided-view clones of model/lanczos_net.py:172-178. */
+int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                       int64_t stride_ch, int B, int N, int C, float* Lp, lnz_stream_t stream);
+
+/* ---- R7 (first half): per-eigenvalue spectral filter gains ----------------------------
+ * G[l][b][s][k] = MLP_l([D^p_1 .. D^p_S])_s for every conv layer l — the
+ * `spectral_filter[layer_idx]` Sequential (Linear S->128, ReLU, 128->128, ReLU, 128->128,
+ * ReLU, 128->S) of model/lanczos_net.py:48-60,110-113, with the powers of :146-149.
+ * mlp_pack: per layer, lnz_spectral_mlp_pack_size(S) floats written by
+ * lnz_pack_spectral_mlp().  dist_host: S integer exponents (host memory).
+ * kind 0 = 'MLP'; kind 1 = plain powers G = D^p (the non-MLP branch, :118-121; mlp_pack unused).
+ * D [B,K]; G [num_layer,B,S,K]. */
+int64_t lnz_spectral_mlp_pack_size(int S);
+int lnz_pack_spectral_mlp(const float* W0, const float* b0, const float* W2, const float* b2,
+                          const float* W4, const float* b4, const float* W6, const float* b6,
+                          int S, float* pack, lnz_stream_t stream);
+int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,
+                       int num_layer, int kind, const float* mlp_pack, float* G,
+                       lnz_stream_t stream);
+
+/* ---- R7 (second half) + R9 + R10: fused LanczosNet forward ------------------------------
+ * One workgroup per molecule runs the whole network on chip: embedding gather, then per conv
+ * layer  X' = relu( sum_c M_c X W_c^T + b )  with M_c in message order
+ *   short  : L[...,0]^p                       (model/lanczos_net.py:164-169)
+ *   long   : V diag(G[l,:,s,:]) V^T           (:114-117 + :172-174)
+ *   edge   : L[...,e], e = 0..E               (:177-178)
+ * evaluated as M_c (X W_c^T) so that `cat` (:180) and the [B,N,N,S] filter stack (:123) never
+ * exist, then the head  y = sigmoid(X w_a + b_a) * (X W_o^T + b_o)  (:185-188) and the masked
+ * mean over real nodes (:190-194).  fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.
+ * Also serves LanczosNetGeneral (model/lanczos_net_general.py:156): pass node_feat_f. */
+typedef struct lnz_forward_args {
+  int32_t B, N, K;            /* batch, padded node count (<= 32), eigen slots (<= 32)      */
+  int32_t num_layer;          /* conv layers, head excluded (<= 16)                          */
+  int32_t din0, dhid, dout;   /* input width (%8==0, <=128), hidden width (64|128), head P (<=31) */
+  int32_t n_short, n_long, n_edge;      /* channel counts (n_edge = E+1)                    */
+  int32_t short_dist[8];      /* powers p of the short channels                              */
+  const int64_t* node_feat;   /* [B,N] atom ids (embedding path) or NULL                     */
+  const float* node_feat_f;   /* [B,N,din0] float features (General path) or NULL           */
+  const float* embedding;     /* [num_atom, din0]                                            */
+  int32_t num_atom;
+  const uint8_t* mask;        /* [B,N] 1 = real node                                         */
+  const float* Lp;            /* lnz_pack_laplacian output, C = n_edge                       */
+  const float* V;             /* [B,N,K]                                                     */
+  const float* G;             /* [num_layer,B,n_long,K] from lnz_spectral_gains              */
+  const float* Wp;            /* packed conv weights: layer l at Wp + w_off[l]               */
+  const float* bias;          /* conv biases: layer l at bias + b_off[l], dhid floats        */
+  int64_t w_off[16];
+  int64_t b_off[16];
+  const float* Wp_head;       /* packed [32, dhid]: rows 0..P-1 = filter[-1], row P = att    */
+  const float* bias_head;     /* [32]: b_o (P), b_a, zeros                                   */
+  float* score;               /* [B,dout]                                                    */
+  float* state_out;           /* optional [B,32,dhid] final node state (debug/tests) or NULL */
+} lnz_forward_args;
+int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
+
+/* ---- R12: unsorted_segment_sum -----------------------------------------------------------
+ * out[b, ids[b,c], x] += data[b,c,x]  /  grad_data[b,c,x] = grad_out[b, ids[b,c], x].
+ * Replaces operators/src/cuda/segment_reduction.cu:39-69 (+ launchers :72-95) behind
+ * operators/functions/unsorted_segment_sum.py:8-44.  `out` must be pre-zeroed by the caller
+ * (as :25-26 does).  The output batch stride is num_segments*dim2 (the reference kernel's
+ * dim1*dim2 stride, :48, is only in-bounds when num_segments == dim1; identical there). */
+int lnz_unsorted_segment_sum_forward(const float* data, const int64_t* segment_ids, int B,
+                                     int dim1, int dim2, int num_segments, float* out,
+                                     lnz_stream_t stream);
+int lnz_unsorted_segment_sum_backward(const float* grad_out, const int64_t* segment_ids, int B,
+                                      int dim1, int dim2, int num_segments, float* grad_data,
+                                      lnz_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCZOSNET_HIP_H_ */

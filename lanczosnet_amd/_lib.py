@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI in include/lanczosnet_hip.h.
+
+The shared library is built in-tree (`lanczosnet_amd/csrc/liblanczosnet_hip.so`, see
+`__graft_entry__.build()` / `make -C lanczosnet_amd/csrc`).  There is NO fallback: if the
+library is missing or a symbol does not resolve, importing the product path fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'liblanczosnet_hip.so')
+
+LNZ_OK, LNZ_EINVAL, LNZ_ELAUNCH, LNZ_ENOTSUP = 0, -1, -2, -3
+ABI_VERSION = 1
+
+
+class LnzError(RuntimeError):
+  def __init__(self, code, msg):
+    super().__init__('lanczosnet_hip error %d: %s' % (code, msg))
+    self.code = code
+
+
+class NotSupported(LnzError, NotImplementedError):
+  pass
+
+
+class ForwardArgs(C.Structure):
+  """struct lnz_forward_args (include/lanczosnet_hip.h)."""
+  _fields_ = [
+      ('B', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+      ('num_layer', C.c_int32),
+      ('din0', C.c_int32), ('dhid', C.c_int32), ('dout', C.c_int32),
+      ('n_short', C.c_int32), ('n_long', C.c_int32), ('n_edge', C.c_int32),
+      ('short_dist', C.c_int32 * 8),
+      ('node_feat', C.c_void_p), ('node_feat_f', C.c_void_p), ('embedding', C.c_void_p),
+      ('num_atom', C.c_int32),
+      ('mask', C.c_void_p), ('Lp', C.c_void_p), ('V', C.c_void_p), ('G', C.c_void_p),
+      ('Wp', C.c_void_p), ('bias', C.c_void_p),
+      ('w_off', C.c_int64 * 16), ('b_off', C.c_int64 * 16),
+      ('Wp_head', C.c_void_p), ('bias_head', C.c_void_p),
+      ('score', C.c_void_p), ('state_out', C.c_void_p),
+  ]
+
+
+# name -> (restype, argtypes); every symbol include/lanczosnet_hip.h declares
+_P, _I, _L = C.c_void_p, C.c_int, C.c_int64
+SIGNATURES = {
+    'lnz_abi_version': (C.c_int, []),
+    'lnz_last_error': (C.c_char_p, []),
+    'lnz_laplacian_l4': (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
+    'lnz_lanczos_ritz': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'lnz_packed_rows_k8_size': (C.c_int64, [_I, _I]),
+    'lnz_pack_rows_k8': (C.c_int, [_P, _I, _I, _L, _P, _P]),
+    'lnz_pack_bias_rows': (C.c_int, [_P, _I, _P, _P]),
+    'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
+    'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),
+    'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),
+    'lnz_spectral_gains': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P]),
+    'lnz_lanczosnet_forward': (C.c_int, [C.POINTER(ForwardArgs), _P]),
+    'lnz_unsorted_segment_sum_forward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    'lnz_unsorted_segment_sum_backward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+  """Load (once) and type the shared library.  Raises ImportError if it is not built."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'lanczosnet_amd: HIP library not built: %s is missing. Build it with '
+        '`python -c "import __graft_entry__ as g; g.build()"` or '
+        '`make -C lanczosnet_amd/csrc` (needs hipcc, --offload-arch=gfx950). '
+        'There is no CPU fallback for this path.' % LIB_PATH)
+  lib = C.CDLL(LIB_PATH)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)  # AttributeError (loud) if the symbol is missing
+    fn.restype = res
+    fn.argtypes = args
+  ver = lib.lnz_abi_version()
+  if ver != ABI_VERSION:
+    raise ImportError('lanczosnet_amd: ABI version mismatch: library %d, binding %d (rebuild)' %
+                      (ver, ABI_VERSION))
+  _lib = lib
+  return lib
+
+
+def check(code):
+  if code == LNZ_OK:
+    return
+  msg = load().lnz_last_error().decode('utf-8', 'replace')
+  if code == LNZ_ENOTSUP:
+    raise NotSupported(code, msg)
+  raise LnzError(code, msg)

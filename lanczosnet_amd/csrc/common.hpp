@@ -1,0 +1,50 @@
+// Shared helpers for the gfx950 LanczosNet kernels.  CDNA4 only: wave = 64 lanes,
+// v_mfma_f32_32x32x2_f32 fragments as described in include/lanczosnet_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/lanczosnet_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace lnz {
+
+void set_error(const char* fmt, ...);
+
+#define LNZ_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      lnz::set_error(__VA_ARGS__);        \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LNZ_ELAUNCH;
+  }
+  return LNZ_OK;
+}
+
+// C/D row of accumulator register r for the lane half hh (= lane >> 5):
+//   row = (r & 3) + 8 * (r >> 2) + 4 * hh          (v_mfma_f32_32x32x2_f32, col = lane & 31)
+__host__ __device__ inline int cd_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ inline f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ inline f32x16 splat16(float v) {
+  f32x16 x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = v;
+  return x;
+}
+
+}  // namespace lnz

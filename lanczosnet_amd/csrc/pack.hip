@@ -1,0 +1,136 @@
+// Operand packing into v_mfma_f32_32x32x2_f32 fragment order, error state, ABI version.
+#include "common.hpp"
+
+namespace lnz {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace lnz
+
+extern "C" int lnz_abi_version(void) { return LNZ_ABI_VERSION; }
+extern "C" const char* lnz_last_error(void) { return lnz::g_err; }
+
+// ---------------------------------------------------------------------------------------
+// Wp[rt][q][lane][u] = W[32 rt + (lane & 31)][8 q + 4 (lane >> 5) + u]
+// One thread per output float4; the write side is perfectly coalesced (16 B per lane,
+// 1 KiB per wave), the read side walks 4 consecutive floats of one row.
+// ---------------------------------------------------------------------------------------
+__global__ void pack_rows_k8_kernel(const float* __restrict__ W, int rows, int cols, int64_t ld,
+                                    int RT, int Q, float4* __restrict__ Wp) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, q, lane)
+  int64_t total = (int64_t)RT * Q * 64;
+  if (idx >= total) return;
+  int lane = (int)(idx & 63);
+  int q = (int)((idx >> 6) % Q);
+  int rt = (int)((idx >> 6) / Q);
+  int row = 32 * rt + (lane & 31);
+  int col0 = 8 * q + 4 * (lane >> 5);
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int col = col0 + u;
+    v[u] = (row < rows && col < cols) ? W[(int64_t)row * ld + col] : 0.0f;
+  }
+  Wp[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int64_t lnz_packed_rows_k8_size(int rows, int cols) {
+  int64_t RT = (rows + 31) / 32, Q = (cols + 7) / 8;
+  return RT * Q * 64 * 4;
+}
+
+extern "C" int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, float* Wp,
+                                lnz_stream_t stream) {
+  LNZ_REQUIRE(W && Wp && rows > 0 && cols > 0 && ld >= cols, LNZ_EINVAL,
+              "lnz_pack_rows_k8: bad arguments (rows=%d cols=%d ld=%lld)", rows, cols,
+              (long long)ld);
+  int RT = (rows + 31) / 32, Q = (cols + 7) / 8;
+  int64_t total = (int64_t)RT * Q * 64;
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_rows_k8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, rows,
+                     cols, ld, RT, Q, (float4*)Wp);
+  return lnz::check_launch("lnz_pack_rows_k8");
+}
+
+// bp[rt][lane][r] = bias[32 rt + cd_row(r, lane >> 5)]
+__global__ void pack_bias_rows_kernel(const float* __restrict__ bias, int rows, int RT,
+                                      float* __restrict__ bp) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (rt, lane, r)
+  if (idx >= RT * 64 * 16) return;
+  int r = idx & 15;
+  int lane = (idx >> 4) & 63;
+  int rt = idx >> 10;
+  int row = 32 * rt + lnz::cd_row(r, lane >> 5);
+  bp[idx] = row < rows ? bias[row] : 0.0f;
+}
+
+extern "C" int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_stream_t stream) {
+  LNZ_REQUIRE(bias && bp && rows > 0, LNZ_EINVAL, "lnz_pack_bias_rows: bad arguments");
+  int RT = (rows + 31) / 32;
+  int total = RT * 64 * 16;
+  hipLaunchKernelGGL(pack_bias_rows_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, bias, rows, RT, bp);
+  return lnz::check_launch("lnz_pack_bias_rows");
+}
+
+// ---------------------------------------------------------------------------------------
+// Lp[b][c][g][lane][u] = L[b][lane & 31][8 g + 4 (lane >> 5) + u][c]   (zero beyond N)
+// The source is channels-last (stride_ch = 1 for the collate layout): a workgroup stages
+// one molecule's whole [N, N, C] block with fully coalesced reads into LDS, then writes
+// the C packed tiles with coalesced float4 stores — each HBM byte is touched once.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_laplacian_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    float4* __restrict__ Lp) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // [N*N*C], source order if dense
+  const int b = blockIdx.x;
+  const float* Lb = L + (int64_t)b * sb;
+  const bool dense_cl = (sch == 1 && sc == C && sr == (int64_t)N * C);
+  const int total = N * N * C;
+  if (dense_cl) {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) tile[i] = Lb[i];
+  } else {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      int c = i % C;
+      int m = (i / C) % N;
+      int r = i / (C * N);
+      tile[i] = Lb[r * sr + m * sc + c * sch];
+    }
+  }
+  __syncthreads();
+  // C * 4 * 64 float4 outputs
+  for (int o = threadIdx.x; o < C * 256; o += blockDim.x) {
+    int lane = o & 63;
+    int g = (o >> 6) & 3;
+    int c = o >> 8;
+    int row = lane & 31;
+    int col0 = 8 * g + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int col = col0 + u;
+      v[u] = (row < N && col < N) ? tile[(row * N + col) * C + c] : 0.0f;
+    }
+    Lp[((int64_t)b * C + c) * 256 + (o & 255)] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r,
+                                  int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                  float* Lp, lnz_stream_t stream) {
+  LNZ_REQUIRE(L && Lp && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS, LNZ_EINVAL,
+              "lnz_pack_laplacian: bad arguments (B=%d C=%d)", B, C);
+  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP,
+              "lnz_pack_laplacian: N=%d exceeds the %d-node tile built in this version", N,
+              LNZ_TILE);
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(lds <= 64 * 1024, LNZ_ENOTSUP,
+              "lnz_pack_laplacian: N*N*C*4 = %zu B exceeds the 64 KiB staging tile", lds);
+  hipLaunchKernelGGL(pack_laplacian_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, L,
+                     stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp);
+  return lnz::check_launch("lnz_pack_laplacian");
+}

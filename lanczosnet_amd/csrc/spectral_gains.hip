@@ -1,0 +1,218 @@
+// R7 (first half): per-eigenvalue spectral filter gains
+//   G[l][b][s][k] = MLP_l([D[b,k]^p_1, ..., D[b,k]^p_S])_s        model/lanczos_net.py:110-113,146-149
+//
+// The MLP (S -> 128 -> 128 -> 128 -> S, ReLU) is evaluated TRANSPOSED on the matrix cores:
+// one wavefront owns a tile of 32 eigenvalue rows (b,k); activations are H^T [features x 32 rows].
+//   H^T_{i+1} = relu(W_{i+1} H^T_i + b_{i+1})
+// With v_mfma_f32_32x32x2_f32 the C/D registers of one layer (lane = row column j, register r =
+// feature cd_row(r, lane>>5)) ARE the B operand of the next layer if the k-steps are taken in the
+// order k(r, hh) = cd_row(r, hh) — the weight (A operand) stream is pre-packed in exactly that
+// order by lnz_pack_rows_k8().  So the whole chain runs out of registers: no LDS, no barriers,
+// no transposes; HBM/L2 traffic is the packed weights (209 KB per layer) and 4 B in / 4*S B out
+// per row.  grid = (row tiles, conv layers): B*K/32 * L workgroups (4480 for B=1024) >> 256 CUs.
+#include "common.hpp"
+
+namespace {
+
+constexpr int HID = 128;           // hidden width of the reference's spectral_filter MLP
+constexpr int HT = HID / 32;       // 4 feature tiles
+constexpr int SMAX = 16;           // exponents supported (two k-halves of 8)
+// pack layout (floats) per conv layer
+constexpr int OFF_W0 = 0;                       // [HT][8][64]          A scalars of Linear(S->128)
+constexpr int OFF_B0 = OFF_W0 + HT * 8 * 64;    // [HT][64][16]
+constexpr int OFF_W2 = OFF_B0 + HT * 1024;      // rows_k8(128,128)
+constexpr int OFF_B2 = OFF_W2 + HT * 16 * 256;
+constexpr int OFF_W4 = OFF_B2 + HT * 1024;
+constexpr int OFF_B4 = OFF_W4 + HT * 16 * 256;
+constexpr int OFF_W6 = OFF_B4 + HT * 1024;      // rows_k8(32,128) (S rows zero padded to 32)
+constexpr int OFF_B6 = OFF_W6 + 16 * 256;       // [1][64][16]
+constexpr int PACK_SIZE = OFF_B6 + 1024;
+
+struct DistArr {
+  int32_t v[SMAX];
+};
+
+// W0p[ot][t][lane] = W0[32 ot + (lane&31)][8 (lane>>5) + t]  (zero beyond S)
+__global__ void pack_w0_kernel(const float* __restrict__ W0, int S, float* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= HT * 8 * 64) return;
+  int lane = idx & 63, t = (idx >> 6) & 7, ot = idx >> 9;
+  int f = 8 * (lane >> 5) + t;
+  out[idx] = f < S ? W0[(32 * ot + (lane & 31)) * S + f] : 0.0f;
+}
+
+__device__ inline float powi(float x, int p) {
+  // integer power in fp64, rounded once to fp32 (torch.pow(D, ii), model/lanczos_net.py:148,
+  // is a <= 1 ulp powf; this is the correctly rounded value)
+  double base = (double)x, acc = 1.0;
+  int e = p < 0 ? -p : p;
+  while (e) {
+    if (e & 1) acc *= base;
+    base *= base;
+    e >>= 1;
+  }
+  return (float)(p < 0 ? 1.0 / acc : acc);
+}
+
+__device__ inline f32x16 load_bias_frag(const float* __restrict__ bp, int lane) {
+  const float4* p = reinterpret_cast<const float4*>(bp) + lane * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 v = p[g];
+    acc[4 * g + 0] = v.x;
+    acc[4 * g + 1] = v.y;
+    acc[4 * g + 2] = v.z;
+    acc[4 * g + 3] = v.w;
+  }
+  return acc;
+}
+
+// out_tile += W[32 rows of tile ot_out][0..127] * Hin   (A = packed weights, B = Hin registers)
+__device__ inline f32x16 dense128(const float4* __restrict__ Wp_tile, const f32x16 (&Hin)[HT],
+                                  f32x16 acc, int lane) {
+#pragma unroll
+  for (int ti = 0; ti < HT; ++ti) {
+    float4 a[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) a[g] = Wp_tile[(ti * 4 + g) * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      acc = lnz::mfma32(a[g].x, Hin[ti][4 * g + 0], acc);
+      acc = lnz::mfma32(a[g].y, Hin[ti][4 * g + 1], acc);
+      acc = lnz::mfma32(a[g].z, Hin[ti][4 * g + 2], acc);
+      acc = lnz::mfma32(a[g].w, Hin[ti][4 * g + 3], acc);
+    }
+  }
+  return acc;
+}
+
+__device__ inline f32x16 relu16(f32x16 v) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.0f);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
+    const float* __restrict__ D, int R, int B, int K, DistArr dist, int S,
+    const float* __restrict__ mlp_pack, float* __restrict__ G) {
+  const int lane = threadIdx.x;
+  const int j = lane & 31, hh = lane >> 5;
+  const int l = blockIdx.y;
+  const int row = blockIdx.x * 32 + j;
+  const bool valid = row < R;
+  const float dval = valid ? D[row] : 0.0f;
+  const float* pk = mlp_pack + (int64_t)l * PACK_SIZE;
+
+  // features of this lane's k-half: f = 8 hh + t
+  float feat[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    float lo = t < S ? powi(dval, dist.v[t]) : 0.0f;
+    float hi = (8 + t) < S ? powi(dval, dist.v[8 + t]) : 0.0f;
+    feat[t] = hh ? hi : lo;
+  }
+  const int steps0 = S < 8 ? S : 8;
+
+  f32x16 h1[HT], h2[HT];
+  // Linear(S -> 128) + ReLU
+#pragma unroll
+  for (int ot = 0; ot < HT; ++ot) {
+    f32x16 acc = load_bias_frag(pk + OFF_B0 + ot * 1024, lane);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < steps0) acc = lnz::mfma32(pk[OFF_W0 + (ot * 8 + t) * 64 + lane], feat[t], acc);
+    }
+    h1[ot] = relu16(acc);
+  }
+  // Linear(128 -> 128) + ReLU, twice
+#pragma unroll
+  for (int ot = 0; ot < HT; ++ot) {
+    f32x16 acc = load_bias_frag(pk + OFF_B2 + ot * 1024, lane);
+    acc = dense128(reinterpret_cast<const float4*>(pk + OFF_W2) + ot * 16 * 64, h1, acc, lane);
+    h2[ot] = relu16(acc);
+  }
+#pragma unroll
+  for (int ot = 0; ot < HT; ++ot) {
+    f32x16 acc = load_bias_frag(pk + OFF_B4 + ot * 1024, lane);
+    acc = dense128(reinterpret_cast<const float4*>(pk + OFF_W4) + ot * 16 * 64, h2, acc, lane);
+    h1[ot] = relu16(acc);
+  }
+  // Linear(128 -> S), no activation
+  f32x16 acc = load_bias_frag(pk + OFF_B6, lane);
+  acc = dense128(reinterpret_cast<const float4*>(pk + OFF_W6), h1, acc, lane);
+
+  if (valid) {
+    const int b = row / K, k = row - b * K;
+    float* Gb = G + (((int64_t)l * B + b) * S) * K + k;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int s = lnz::cd_row(r, hh);
+      if (s < S) Gb[(int64_t)s * K] = acc[r];
+    }
+  }
+}
+
+// non-MLP branch (model/lanczos_net.py:118-121): G[l][b][s][k] = D[b,k]^p_s for every layer
+__global__ void spectral_gains_pow_kernel(const float* __restrict__ D, int B, int K, DistArr dist,
+                                          int S, int num_layer, float* __restrict__ G) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)num_layer * B * S * K;
+  if (idx >= total) return;
+  int k = (int)(idx % K);
+  int s = (int)((idx / K) % S);
+  int b = (int)((idx / ((int64_t)K * S)) % B);
+  G[idx] = powi(D[(int64_t)b * K + k], dist.v[s]);
+}
+
+}  // namespace
+
+extern "C" int64_t lnz_spectral_mlp_pack_size(int S) {
+  (void)S;
+  return PACK_SIZE;
+}
+
+extern "C" int lnz_pack_spectral_mlp(const float* W0, const float* b0, const float* W2,
+                                     const float* b2, const float* W4, const float* b4,
+                                     const float* W6, const float* b6, int S, float* pack,
+                                     lnz_stream_t stream) {
+  LNZ_REQUIRE(W0 && b0 && W2 && b2 && W4 && b4 && W6 && b6 && pack, LNZ_EINVAL,
+              "lnz_pack_spectral_mlp: null pointer");
+  LNZ_REQUIRE(S >= 1 && S <= SMAX, LNZ_ENOTSUP, "lnz_pack_spectral_mlp: S=%d not in 1..%d", S,
+              SMAX);
+  hipLaunchKernelGGL(pack_w0_kernel, dim3((HT * 8 * 64 + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, W0, S, pack + OFF_W0);
+  int rc = lnz::check_launch("lnz_pack_spectral_mlp(W0)");
+  if (rc) return rc;
+  if ((rc = lnz_pack_bias_rows(b0, HID, pack + OFF_B0, stream))) return rc;
+  if ((rc = lnz_pack_rows_k8(W2, HID, HID, HID, pack + OFF_W2, stream))) return rc;
+  if ((rc = lnz_pack_bias_rows(b2, HID, pack + OFF_B2, stream))) return rc;
+  if ((rc = lnz_pack_rows_k8(W4, HID, HID, HID, pack + OFF_W4, stream))) return rc;
+  if ((rc = lnz_pack_bias_rows(b4, HID, pack + OFF_B4, stream))) return rc;
+  if ((rc = lnz_pack_rows_k8(W6, S, HID, HID, pack + OFF_W6, stream))) return rc;
+  if ((rc = lnz_pack_bias_rows(b6, S, pack + OFF_B6, stream))) return rc;
+  return LNZ_OK;
+}
+
+extern "C" int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,
+                                  int num_layer, int kind, const float* mlp_pack, float* G,
+                                  lnz_stream_t stream) {
+  LNZ_REQUIRE(D && dist_host && G && B > 0 && K > 0 && num_layer > 0, LNZ_EINVAL,
+              "lnz_spectral_gains: bad arguments (B=%d K=%d L=%d)", B, K, num_layer);
+  LNZ_REQUIRE(S >= 1 && S <= SMAX, LNZ_ENOTSUP, "lnz_spectral_gains: S=%d not in 1..%d", S, SMAX);
+  DistArr dist;
+  for (int i = 0; i < SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 0) {
+    LNZ_REQUIRE(mlp_pack, LNZ_EINVAL, "lnz_spectral_gains: kind=MLP needs mlp_pack");
+    int R = B * K;
+    dim3 grid((R + 31) / 32, num_layer);
+    hipLaunchKernelGGL(spectral_gains_mlp_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
+                       mlp_pack, G);
+  } else {
+    int64_t total = (int64_t)num_layer * B * S * K;
+    hipLaunchKernelGGL(spectral_gains_pow_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
+                       s, D, B, K, dist, S, num_layer, G);
+  }
+  return lnz::check_launch("lnz_spectral_gains");
+}

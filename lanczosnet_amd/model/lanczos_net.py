@@ -1,0 +1,199 @@
+"""`LanczosNet` / `LanczosNetGeneral` nn.Modules backed by the gfx950 HIP path.
+
+Drop-in surface of reference `model/lanczos_net.py:13-199` and
+`model/lanczos_net_general.py:13-201`: same constructor config keys, same
+`forward(node_feat, L, D, V, label=None, mask=None)` signature and return convention, same
+`state_dict` keys (`filter.*`, `embedding.weight`, `spectral_filter.*.{0,2,4,6}.*`,
+`att_func.0.*`), same parameter creation and init order, so `torch.manual_seed(s)` yields
+the reference's weights and `utils/train_helper.py:28-32` checkpoints load unchanged.
+
+The forward itself is three HIP launches (Laplacian pack, spectral gains, fused network) on
+the current torch stream; parameters are re-packed into MFMA fragment order only when they
+change.  Forward only in this version: training through `loss.backward()`
+(runner/qm8_runner.py:247) raises — backward kernels are SURVEY.md §8(f) rank 2.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.data_helper import check_dist
+
+__all__ = ['LanczosNet', 'LanczosNetGeneral']
+
+_SPECTRAL_HIDDEN = 128  # model/lanczos_net.py:50-56
+
+
+def _opt(node, key, default):
+    return getattr(node, key) if hasattr(node, key) else default
+
+
+class _LanczosNetBase(nn.Module):
+    general = False
+
+    def __init__(self, config):
+        super().__init__()
+        m = config.model
+        self.config = config
+        self.input_dim = m.input_dim
+        self.hidden_dim = list(m.hidden_dim)
+        self.output_dim = m.output_dim
+        self.num_layer = m.num_layer
+        self._read_dataset(config.dataset)
+        self.dropout = _opt(m, 'dropout', 0.0)
+        self.short_diffusion_dist = check_dist(list(m.short_diffusion_dist))
+        self.long_diffusion_dist = check_dist(list(m.long_diffusion_dist))
+        self.max_short_diffusion_dist = max(self.short_diffusion_dist, default=None)
+        self.max_long_diffusion_dist = max(self.long_diffusion_dist, default=None)
+        self.num_scale_short = len(self.short_diffusion_dist)
+        self.num_scale_long = len(self.long_diffusion_dist)
+        self.num_eig_vec = m.num_eig_vec
+        self.spectral_filter_kind = m.spectral_filter_kind
+
+        widths = [self.input_dim] + self.hidden_dim + [self.output_dim]
+        n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
+        # creation order == reference (RNG parity): conv mixes, head, [embedding], spectral MLPs, gate
+        mixes = [nn.Linear(widths[t] * n_chan, widths[t + 1]) for t in range(self.num_layer)]
+        self.filter = nn.ModuleList(mixes + [nn.Linear(widths[-2], widths[-1])])
+        self._make_input_layer()
+        if self._has_mlp():
+            S, H = self.num_scale_long, _SPECTRAL_HIDDEN
+            self.spectral_filter = nn.ModuleList([
+                nn.Sequential(nn.Linear(S, H), nn.ReLU(), nn.Linear(H, H), nn.ReLU(),
+                              nn.Linear(H, H), nn.ReLU(), nn.Linear(H, S))
+                for _ in range(self.num_layer)])
+        self.att_func = nn.Sequential(nn.Linear(widths[-2], 1), nn.Sigmoid())
+
+        losses = {'CrossEntropy': nn.CrossEntropyLoss, 'MSE': nn.MSELoss, 'L1': nn.L1Loss}
+        if m.loss not in losses:
+            raise ValueError("Non-supported loss function!")
+        self.loss_func = losses[m.loss]()
+        self._init_param()
+        self._plan_cache = None
+
+    # -- configuration hooks ------------------------------------------------------------
+    def _read_dataset(self, ds):
+        self.num_atom = ds.num_atom
+        self.num_edgetype = ds.num_bond_type
+
+    def _make_input_layer(self):
+        self.embedding = nn.Embedding(self.num_atom, self.input_dim)
+
+    def _has_mlp(self):
+        return self.spectral_filter_kind == 'MLP' and self.num_scale_long > 0
+
+    def _init_param(self):
+        # model/lanczos_net.py:74-93: Xavier-uniform weights, zero biases; embedding keeps N(0,1)
+        groups = [list(self.filter), list(self.att_func)]
+        if self._has_mlp():
+            groups.append([f for seq in self.spectral_filter for f in seq])
+        for group in groups:
+            for layer in group:
+                if isinstance(layer, nn.Linear):
+                    nn.init.xavier_uniform_(layer.weight.data)
+                    if layer.bias is not None:
+                        layer.bias.data.zero_()
+
+    # -- packed-parameter plan ------------------------------------------------------------
+    def _param_signature(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+
+    def _check_supported(self):
+        if any(d == 'inf' for d in self.short_diffusion_dist + self.long_diffusion_dist):
+            raise NotImplementedError("diffusion distance 'inf' is not built in the HIP path")
+        hid = set(self.hidden_dim[:self.num_layer])
+        if len(hid) != 1 or next(iter(hid)) not in (64, 128):
+            raise NotImplementedError(
+                'HIP path is built for a uniform hidden width of 64 or 128, got %r' %
+                (self.hidden_dim,))
+        if self.input_dim % 8 or self.input_dim > 128:
+            raise NotImplementedError('input_dim must be a multiple of 8 and <= 128')
+
+    @torch.no_grad()
+    def _plan(self):
+        sig = self._param_signature()
+        if self._plan_cache is not None and self._plan_cache['sig'] == sig:
+            return self._plan_cache
+        self._check_supported()
+        dev = self.filter[0].weight.device
+        dhid = self.hidden_dim[0]
+        packs, biases, w_off, b_off, woff, boff = [], [], [], [], 0, 0
+        for t in range(self.num_layer):
+            wp = ops.pack_rows_k8(self.filter[t].weight)
+            packs.append(wp)
+            w_off.append(woff)
+            woff += wp.numel()
+            biases.append(self.filter[t].bias.detach().float())
+            b_off.append(boff)
+            boff += dhid
+        P = self.output_dim
+        head = torch.zeros((32, dhid), dtype=torch.float32, device=dev)
+        head[:P] = self.filter[-1].weight
+        head[P] = self.att_func[0].weight[0]
+        bias_head = torch.zeros((32,), dtype=torch.float32, device=dev)
+        bias_head[:P] = self.filter[-1].bias
+        bias_head[P] = self.att_func[0].bias[0]
+        plan = dict(sig=sig, num_layer=self.num_layer, din0=self.input_dim, dhid=dhid, dout=P,
+                    short=list(self.short_diffusion_dist), n_long=self.num_scale_long,
+                    n_edge=self.num_edgetype + 1,
+                    Wp=torch.cat(packs), bias=torch.cat(biases).contiguous(),
+                    w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
+                    bias_head=bias_head,
+                    embedding=None if self.general else self.embedding.weight.detach())
+        if self._has_mlp():
+            size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
+            buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)
+            for t, seq in enumerate(self.spectral_filter):
+                lins = [(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
+                ops.pack_spectral_mlp(lins, self.num_scale_long, out=buf[t])
+            plan['mlp_pack'] = buf
+        else:
+            plan['mlp_pack'] = None
+        self._plan_cache = plan
+        return plan
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward(self, node_feat, L, D, V, label=None, mask=None):
+        """Shapes as the reference docstring (model/lanczos_net.py:125-141): node_feat B x N
+        (long) [General: B x N x D float], L B x N x N x (E+1), D B x K, V B x N x K,
+        label B x P, mask B x N.  Returns score, or (score, loss) when `label` is given."""
+        if mask is None:
+            raise ValueError('LanczosNet.forward needs `mask` (model/lanczos_net.py:192)')
+        if not L.is_cuda:
+            raise RuntimeError('lanczosnet_amd.LanczosNet runs on the AMD GPU only: move the '
+                               'module and its inputs to cuda (no CPU fallback)')
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError('dropout > 0 in training mode is not built in the HIP path')
+        if torch.is_grad_enabled() and self.training and any(
+                p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                'lanczosnet_amd: backward kernels are not built yet (forward-only); call under '
+                'torch.no_grad() or model.eval()')
+        with torch.no_grad():
+            plan = self._plan()
+            Lp = ops.pack_laplacian(L if L.dtype == torch.float32 else L.float())
+            G = None
+            if self.num_scale_long > 0:
+                G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer,
+                                       plan['mlp_pack'])
+            score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+        if label is not None:
+            return score, self.loss_func(score, label)
+        return score
+
+
+class LanczosNet(_LanczosNetBase):
+    """QM8 model: integer atom ids through nn.Embedding (model/lanczos_net.py:44,154)."""
+
+
+class LanczosNetGeneral(_LanczosNetBase):
+    """Float node features, no embedding (model/lanczos_net_general.py:22-24,45-46,156)."""
+    general = True
+
+    def _read_dataset(self, ds):
+        self.node_emb_dim = ds.node_emb_dim
+        self.graph_emb_dim = ds.graph_emb_dim
+        self.num_edgetype = ds.num_edge_type
+
+    def _make_input_layer(self):
+        assert self.input_dim == self.node_emb_dim
+        assert self.output_dim == self.graph_emb_dim

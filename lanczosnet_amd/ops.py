@@ -1,0 +1,212 @@
+"""Torch-tensor front end of the C ABI (device memory + streams are torch's; the compute is the
+HIP library).  Every function requires CUDA(HIP) tensors and raises otherwise — no CPU path.
+
+Reference interfaces replaced (paths relative to the reference repo):
+  laplacian_l4        utils/data_helper.py:92-116,155-156 ; dataset/get_qm8_data.py:62-75
+  lanczos_ritz        utils/data_helper.py:197-223 (eigh + |lambda| sort) ; dataset/qm8.py:264-291
+  spectral_gains      model/lanczos_net.py:110-113,118-121,146-149
+  lanczosnet_forward  model/lanczos_net.py:114-117,154-194
+  unsorted_segment_sum operators/functions/unsorted_segment_sum.py:8-44
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*tensors):
+  for t in tensors:
+    if t is None:
+      continue
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+      raise RuntimeError(
+          'lanczosnet_amd: this path runs only on an AMD GPU (HIP); got a %s tensor. '
+          'There is no CPU fallback.' % (getattr(t, 'device', type(t)),))
+
+
+def _ptr(t):
+  return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32c(t):
+  return t.to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ R1
+def laplacian_l4(adjs, n_nodes):
+  """adjs [B,N,N,E] (bond-type adjacency, zero padded), n_nodes [B] -> L [B,N,N,E+1] float32."""
+  _need_cuda(adjs, n_nodes)
+  adjs = _f32c(adjs)
+  n_nodes = n_nodes.to(torch.int32).contiguous()
+  B, N, N2, E = adjs.shape
+  assert N == N2 and n_nodes.shape == (B,)
+  L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=adjs.device)
+  lib = _lib.load()
+  with torch.cuda.device(adjs.device):
+    _lib.check(lib.lnz_laplacian_l4(_ptr(adjs), _ptr(n_nodes), B, N, E, _ptr(L), _stream()))
+  return L
+
+
+# ------------------------------------------------------------------------------------- R2 + R6
+def lanczos_ritz(A, n_nodes, K, return_info=False):
+  """Batched Lanczos -> tridiagonal eigensolve -> Ritz select.
+
+  A: [B,N,N] float32 symmetric (any strides: pass `L[..., 0]` of a channels-last Laplacian
+  without copying).  n_nodes: [B] real node counts (rows/cols >= n are ignored).
+  Returns D [B,K], V [B,N,K] exactly like the collated `D`, `V` of dataset/qm8.py:264-291."""
+  _need_cuda(A, n_nodes)
+  assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
+  B, N, _ = A.shape
+  n_nodes = n_nodes.to(torch.int32).contiguous()
+  D = torch.empty((B, K), dtype=torch.float32, device=A.device)
+  V = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
+  info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
+  sb, sr, sc = A.stride()
+  lib = _lib.load()
+  with torch.cuda.device(A.device):
+    _lib.check(lib.lnz_lanczos_ritz(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D), _ptr(V),
+                                    _ptr(info), _stream()))
+  return (D, V, info) if return_info else (D, V)
+
+
+# ------------------------------------------------------------------------------------- packing
+def pack_rows_k8(W):
+  """[rows, cols] -> MFMA fragment order (see include/lanczosnet_hip.h)."""
+  _need_cuda(W)
+  W = _f32c(W)
+  rows, cols = W.shape
+  lib = _lib.load()
+  out = torch.empty((lib.lnz_packed_rows_k8_size(rows, cols),), dtype=torch.float32,
+                    device=W.device)
+  with torch.cuda.device(W.device):
+    _lib.check(lib.lnz_pack_rows_k8(_ptr(W), rows, cols, cols, _ptr(out), _stream()))
+  return out
+
+
+def pack_bias_rows(bias):
+  _need_cuda(bias)
+  bias = _f32c(bias)
+  rows = bias.shape[0]
+  out = torch.empty((((rows + 31) // 32) * 1024,), dtype=torch.float32, device=bias.device)
+  lib = _lib.load()
+  with torch.cuda.device(bias.device):
+    _lib.check(lib.lnz_pack_bias_rows(_ptr(bias), rows, _ptr(out), _stream()))
+  return out
+
+
+def pack_laplacian(L):
+  """L [B,N,N,C] float32 (any strides) -> Lp [B,C,4,64,4] fragment order, N <= 32."""
+  _need_cuda(L)
+  assert L.dim() == 4 and L.dtype == torch.float32
+  B, N, _, Cn = L.shape
+  Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=L.device)
+  sb, sr, sc, sch = L.stride()
+  lib = _lib.load()
+  with torch.cuda.device(L.device):
+    _lib.check(lib.lnz_pack_laplacian(_ptr(L), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _stream()))
+  return Lp
+
+
+def pack_spectral_mlp(linears, S, out=None):
+  """linears: 4 (weight, bias) pairs of one `spectral_filter[l]` Sequential -> packed buffer."""
+  lib = _lib.load()
+  size = lib.lnz_spectral_mlp_pack_size(S)
+  ws = []
+  for (w, b) in linears:
+    _need_cuda(w, b)
+    ws += [_f32c(w), _f32c(b)]
+  if out is None:
+    out = torch.empty((size,), dtype=torch.float32, device=ws[0].device)
+  with torch.cuda.device(ws[0].device):
+    _lib.check(lib.lnz_pack_spectral_mlp(*[_ptr(t) for t in ws], S, _ptr(out), _stream()))
+  return out
+
+
+# ------------------------------------------------------------------------------------------ R7
+def spectral_gains(D, dist, num_layer, mlp_pack=None):
+  """D [B,K] -> G [num_layer,B,S,K].  mlp_pack=None selects the plain-power branch."""
+  _need_cuda(D, mlp_pack)
+  D = _f32c(D)
+  B, K = D.shape
+  S = len(dist)
+  G = torch.empty((num_layer, B, S, K), dtype=torch.float32, device=D.device)
+  darr = (C.c_int32 * S)(*[int(x) for x in dist])
+  lib = _lib.load()
+  with torch.cuda.device(D.device):
+    _lib.check(lib.lnz_spectral_gains(_ptr(D), B, K, darr, S, num_layer,
+                                      0 if mlp_pack is not None else 1, _ptr(mlp_pack), _ptr(G),
+                                      _stream()))
+  return G
+
+
+def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
+  """Launch the fused forward.  `plan` is a dict made by LanczosNet._plan() holding the packed
+  parameters and the static sizes."""
+  _need_cuda(node_feat, Lp, V, G, mask)
+  B, N, K = V.shape
+  a = _lib.ForwardArgs()
+  a.B, a.N, a.K = B, N, K
+  a.num_layer = plan['num_layer']
+  a.din0, a.dhid, a.dout = plan['din0'], plan['dhid'], plan['dout']
+  a.n_short, a.n_long, a.n_edge = len(plan['short']), plan['n_long'], plan['n_edge']
+  for i, p in enumerate(plan['short']):
+    a.short_dist[i] = int(p)
+  if node_feat.dtype in (torch.int64,):
+    nf = node_feat.contiguous()
+    a.node_feat, a.node_feat_f = nf.data_ptr(), None
+    a.embedding = plan['embedding'].data_ptr()
+    a.num_atom = plan['embedding'].shape[0]
+  else:
+    nf = _f32c(node_feat)
+    a.node_feat, a.node_feat_f, a.embedding, a.num_atom = None, nf.data_ptr(), None, 0
+  mask_u8 = mask.to(torch.uint8).contiguous()
+  Vc = _f32c(V)
+  a.mask, a.Lp, a.V = mask_u8.data_ptr(), Lp.data_ptr(), Vc.data_ptr()
+  a.G = G.data_ptr() if G is not None else None
+  a.Wp, a.bias = plan['Wp'].data_ptr(), plan['bias'].data_ptr()
+  for i in range(plan['num_layer']):
+    a.w_off[i] = plan['w_off'][i]
+    a.b_off[i] = plan['b_off'][i]
+  a.Wp_head, a.bias_head = plan['Wp_head'].data_ptr(), plan['bias_head'].data_ptr()
+  score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
+  a.score = score.data_ptr()
+  state = None
+  if return_state:
+    state = torch.empty((B, 32, plan['dhid']), dtype=torch.float32, device=V.device)
+    a.state_out = state.data_ptr()
+  lib = _lib.load()
+  with torch.cuda.device(V.device):
+    _lib.check(lib.lnz_lanczosnet_forward(C.byref(a), _stream()))
+  return (score, state) if return_state else score
+
+
+# ----------------------------------------------------------------------------------------- R12
+def unsorted_segment_sum_forward(data, segment_ids, num_segments):
+  _need_cuda(data, segment_ids)
+  data = _f32c(data)
+  ids = segment_ids.to(torch.int64).contiguous()
+  B, D1, D2 = data.shape
+  out = torch.zeros((B, num_segments, D2), dtype=torch.float32, device=data.device)
+  lib = _lib.load()
+  with torch.cuda.device(data.device):
+    _lib.check(lib.lnz_unsorted_segment_sum_forward(_ptr(data), _ptr(ids), B, D1, D2,
+                                                    num_segments, _ptr(out), _stream()))
+  return out
+
+
+def unsorted_segment_sum_backward(grad_out, segment_ids, dim1):
+  _need_cuda(grad_out, segment_ids)
+  g = _f32c(grad_out)
+  ids = segment_ids.to(torch.int64).contiguous()
+  B, S, D2 = g.shape
+  out = torch.empty((B, dim1, D2), dtype=torch.float32, device=g.device)
+  lib = _lib.load()
+  with torch.cuda.device(g.device):
+    _lib.check(lib.lnz_unsorted_segment_sum_backward(_ptr(g), _ptr(ids), B, dim1, D2, S,
+                                                     _ptr(out), _stream()))
+  return out
