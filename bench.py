@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py — molecules/s of the LanczosNet forward hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of B synthetic QM8-schema molecules that
+is already resident in HBM (the channels-last Laplacian L, atom ids, mask):
+
+    pack L into MFMA fragment order                      (lnz_pack_laplacian)
+    Lanczos tridiagonalisation + QL eigensolve + select   (lnz_lanczos_ritz)      -> D, V
+    spectral filter gains, all 7 layers                   (lnz_spectral_gains)
+    fused 7-layer spectral conv + mix + head + readout    (lnz_lanczosnet_forward) -> score
+    [N > 1 ranks only] RCCL all-gather of the per-shard scores
+
+Workload = BASELINE.json configs[1]: QM8 LanczosNet, batch 1024 per GPU, N <= 32 dense L,
+K = 20, fp32, config/qm8_lanczos_net.yaml architecture.  Molecules are independent, so ranks
+shard the batch with no data-path collective (weak scaling, 1024 molecules per GPU).
+
+Prints ONE JSON line (rank 0).  See DESIGN.md §Measurement for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from lanczosnet_amd import ops  # noqa: E402
+from lanczosnet_amd.model import LanczosNet  # noqa: E402
+from lanczosnet_amd.synthetic import draw_batch  # noqa: E402
+from lanczosnet_amd.utils.arg_helper import make_model_config  # noqa: E402
+
+QM8_CFG = dict(num_atom=70, num_bond_type=6, short_diffusion_dist=[],
+               long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30], num_eig_vec=20,
+               spectral_filter_kind='MLP', input_dim=64, hidden_dim=[128] * 7, output_dim=16,
+               num_layer=7)
+
+# Algorithmic FLOPs per molecule of the fused forward kernel in the REFERENCE's association
+# (SURVEY.md §8d, N = 32 tile, K = 20, S = 8, E+1 = 7, 64 -> 128 x 7 -> 16):
+#   filter build S*2N^2K per layer, long S*2N^2 d, edge (E+1)*2N^2 d, mix 2N(15d)128, head 2N*128*17
+FWD_FLOP_PER_MOL = (7 * 8 * 2 * 32 * 32 * 20
+                    + 8 * 2 * 1024 * (64 + 6 * 128)
+                    + 7 * 2 * 1024 * (64 + 6 * 128)
+                    + 2 * 32 * 15 * 128 * (64 + 6 * 128)
+                    + 2 * 32 * 128 * 17)  # = 130,228,224
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(cfg, params, batch_size, reps):
+  """The oracle (numpy port of the reference pipeline) on the host cores, bounded sample."""
+  import oracle
+  batch = draw_batch(batch_size, seed=0)
+  B, N = batch['node_mask'].shape
+  L = np.zeros((B, N, N, 7), np.float32)
+  for b in range(B):
+    nb = int(batch['n_nodes'][b])
+    L[b, :nb, :nb] = oracle.laplacian_multi_l4(batch['adjs'][b, :nb, :nb])
+  times = []
+  for _ in range(reps):
+    t0 = time.perf_counter()
+    Dl, Vl = [], []
+    for b in range(B):  # (D, V) producer: utils/data_helper.py:197-223 per molecule
+      nb = int(batch['n_nodes'][b])
+      e, V = np.linalg.eigh(L[b, :nb, :nb, 0].astype(np.float64))
+      idx = np.argsort(-np.abs(e), kind='mergesort')
+      Dl.append(e[idx])
+      Vl.append(V[:, idx])
+    D, V = oracle.collate_eigs(Dl, Vl, N, cfg['num_eig_vec'])
+    oracle.lanczos_net_forward(params, cfg, batch['node_feat'], L, D, V, batch['node_mask'])
+    times.append(time.perf_counter() - t0)
+  return batch_size / min(times), times
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=10)
+  ap.add_argument('--batch', type=int, default=1024, help='molecules per GPU')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-reps', type=int, default=3)
+  args = ap.parse_args()
+
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  dev = torch.device('cuda', local_rank)
+  torch.cuda.set_device(dev)
+
+  import oracle  # parameters only (numpy RandomState draw); not on the measured path
+  cfg = dict(QM8_CFG)
+  params = oracle.make_lanczosnet_params(cfg, 1234)
+  net = LanczosNet(make_model_config(cfg)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+  net = net.to(dev)
+
+  B = args.batch
+  batch = draw_batch(B, seed=rank)  # config 3: seeds 0..7 per shard
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+  n_nodes = t(batch['n_nodes'])
+  node_feat, mask = t(batch['node_feat']), t(batch['node_mask'])
+  L = ops.laplacian_l4(t(batch['adjs']), n_nodes)  # dataset preprocessing, resident before timing
+  A = L[:, :, :, 0]
+  K = cfg['num_eig_vec']
+  plan = net._plan()
+  gathered = [torch.empty((B, cfg['output_dim']), device=dev) for _ in range(world)] if dist else None
+
+  ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(5)] for k in range(args.steps)}
+
+  def step(events=None):
+    if events:
+      events[0].record()
+    Lp = ops.pack_laplacian(L)
+    if events:
+      events[1].record()
+    D, V = ops.lanczos_ritz(A, n_nodes, K)
+    if events:
+      events[2].record()
+    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+    if events:
+      events[3].record()
+    score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+    if events:
+      events[4].record()
+    if dist:
+      dist.all_gather(gathered, score)
+    return score
+
+  with torch.no_grad():
+    for _ in range(args.warmup):
+      score = step()
+    torch.cuda.synchronize()
+    if dist:
+      dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+      score = step(ev[i])
+    torch.cuda.synchronize()
+    if dist:
+      dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+  if dist:
+    tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+  assert torch.isfinite(score).all()
+
+  names = ['pack_laplacian', 'lanczos_ritz', 'spectral_gains', 'lanczosnet_forward']
+  stage_ms = {nm: float(np.mean([ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)]))
+              for k, nm in enumerate(names)}
+
+  if rank == 0:
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    fwd_s = stage_ms['lanczosnet_forward'] * 1e-3
+    achieved = FWD_FLOP_PER_MOL * B / fwd_s / 1e12
+    traffic = None
+    prof = os.path.join(ROOT, 'profiles', 'pmc_forward_hbm_bytes.json')
+    if os.path.exists(prof) and B == 1024:
+      try:
+        traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+      except Exception:
+        traffic = None
+    out = {
+        'metric': 'molecules/sec LanczosNet forward, QM8 batch=1024',
+        'value': round(value, 1), 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
+                               'fp32, 7x128 layers, 1xMI355X per rank; step = pack L + Lanczos/QL '
+                               'Ritz pairs + spectral gains + fused forward' % (B, L.shape[1]),
+                   'global_batch': world * B, 'parallelism': 'dp%d (batch shards, score all-gather)'
+                   % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
+        'roofline': {'kernel': 'lanczosnet_forward_kernel<2>', 'bound': 'mfma',
+                     'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                     'traffic': traffic,
+                     'flops_per_launch': FWD_FLOP_PER_MOL * B,
+                     'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      torch.set_num_threads(os.cpu_count() or 1)
+      v, times = cpu_baseline(cfg, params, B, args.cpu_reps)
+      out['cpu_baseline'] = {'value': round(v, 1), 'unit': 'molecules/s',
+                             'cores': os.cpu_count(), 'kind': 'port',
+                             'sample': 'numpy oracle (eigh per molecule + LanczosNet forward), '
+                                       'B=%d, best of %d runs (%.2f s each)' %
+                                       (B, args.cpu_reps, min(times))}
+    print(json.dumps(out))
+  if dist:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

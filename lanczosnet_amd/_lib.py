@@ -75,6 +75,11 @@ def load():
         '`python -c "import __graft_entry__ as g; g.build()"` or '
         '`make -C lanczosnet_amd/csrc` (needs hipcc, --offload-arch=gfx950). '
         'There is no CPU fallback for this path.' % LIB_PATH)
+  # One HIP runtime per process: torch ships its own libamdhip64.so.7; importing torch first
+  # makes the dynamic loader resolve this library's DT_NEEDED libamdhip64.so.7 to that same,
+  # already-initialised runtime (otherwise /opt/rocm's copy is loaded beside it and sees no
+  # device / no torch stream).
+  import torch  # noqa: F401
   lib = C.CDLL(LIB_PATH)
   for name, (res, args) in SIGNATURES.items():
     fn = getattr(lib, name)  # AttributeError (loud) if the symbol is missing
