@@ -82,6 +82,8 @@ def main():
   ap.add_argument('--batch', type=int, default=1024, help='molecules per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-reps', type=int, default=3)
+  ap.add_argument('--zero-params', action='store_true',
+                  help='diagnostic only (power/DVFS probe): all-zero weights; never reported')
   args = ap.parse_args()
 
   rank = int(os.environ.get('RANK', '0'))
@@ -99,6 +101,8 @@ def main():
   import oracle  # parameters only (numpy RandomState draw); not on the measured path
   cfg = dict(QM8_CFG)
   params = oracle.make_lanczosnet_params(cfg, 1234)
+  if args.zero_params:
+    params = {k: np.zeros_like(v) for k, v in params.items()}
   net = LanczosNet(make_model_config(cfg)).eval()
   net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
   net = net.to(dev)

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'liblanczosnet_hip.so')
+# LANCZOSNET_HIP_LIB overrides the path (A/B builds of the same ABI); default = in-tree build
+LIB_PATH = os.environ.get('LANCZOSNET_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblanczosnet_hip.so')
 
 LNZ_OK, LNZ_EINVAL, LNZ_ELAUNCH, LNZ_ENOTSUP = 0, -1, -2, -3
 ABI_VERSION = 1

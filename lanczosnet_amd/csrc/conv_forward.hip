@@ -1,6 +1,6 @@
 // R7 (second half) + R9 + R10: the fused LanczosNet forward.
 //
-// One 128-thread workgroup (2 wavefronts) per molecule runs the WHOLE network on chip:
+// One workgroup (dhid/32 wavefronts) per PAIR of molecules runs the WHOLE network on chip:
 // embedding -> num_layer x [ X' = relu( sum_c M_c X W_c^T + b ) ] -> gated head -> masked mean.
 //
 // Per layer and message channel c two chained matrix-core GEMMs (v_mfma_f32_32x32x2_f32, exact
@@ -9,7 +9,8 @@
 //   GEMM1  Z_c [32 nodes x dhid] = X [32 x din] * W_c^T
 //          A = X from LDS (row-major, pitch 132 floats, one ds_read_b128 = 4 k-steps),
 //          B = W_c pre-packed in fragment order (one global_load_dwordx4 = 4 k-steps, L2 hits),
-//          wave w owns output-feature tiles [w*OTW, (w+1)*OTW).
+//          wave w owns output-feature tile w for both molecules: each weight fragment feeds
+//          2 x 4 MFMAs (the per-CU vector-memory path, not L2, limits a 1-molecule tiling).
 //   GEMM2  out += M_c [32 x 32] * Z_c
 //          B = the C/D registers of GEMM1 *as they are*: register r of lane (j, hh) holds
 //              Z_c[cd_row(r,hh)][j], which is exactly what k-step r needs when the contraction
@@ -29,7 +30,7 @@
 
 namespace {
 
-constexpr int NW = 2;        // wavefronts per molecule
+constexpr int MOLS = 2;      // molecules per workgroup; every wave works on both
 constexpr int PITCH = 132;   // LDS row pitch (floats): conflict-free ds_read_b128 A fragments
 constexpr int KHMAX = 16;    // eigen slots per lane half (K <= 32)
 
@@ -45,11 +46,12 @@ __device__ inline f32x16 frag_from4(const float4 (&v)[4]) {
   return f;
 }
 
-template <int OTW>
-__global__ __launch_bounds__(64 * NW) void lanczosnet_forward_kernel(const lnz_forward_args a) {
-  __shared__ __attribute__((aligned(16))) float Xs[2][32][PITCH];
+// NWV wavefronts per workgroup = dhid / 32: wave w owns output-feature tile w for BOTH molecules
+// of the workgroup, so every packed-weight fragment it loads feeds 2 x 4 MFMAs.
+template <int NWV, int KHT>
+__global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_forward_args a) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][MOLS][32][PITCH];
 
-  const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -57,37 +59,55 @@ __global__ __launch_bounds__(64 * NW) void lanczosnet_forward_kernel(const lnz_f
   const int N = a.N, K = a.K, B = a.B;
   const int dhid = a.dhid;
   const int C = a.n_short + a.n_long + a.n_edge;
-  const int OT = OTW * NW;  // dhid / 32
+  int mb[MOLS];  // molecule ids (an odd batch repeats the last molecule; its result is dropped)
+#pragma unroll
+  for (int m = 0; m < MOLS; ++m) {
+    int x = blockIdx.x * MOLS + m;
+    mb[m] = x < B ? x : B - 1;
+  }
 
   // ---- embedding gather (model/lanczos_net.py:154) / float features (lanczos_net_general.py:156)
   {
     const int d4 = a.din0 >> 2;
-    for (int idx = tid; idx < 32 * d4; idx += 64 * NW) {
-      int row = idx / d4, c4 = idx - row * d4;
+    for (int idx = tid; idx < MOLS * 32 * d4; idx += 64 * NWV) {
+      int m = idx / (32 * d4);
+      int rem = idx - m * 32 * d4;
+      int row = rem / d4, c4 = rem - row * d4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < N) {
         if (a.node_feat) {
-          int64_t id = a.node_feat[(int64_t)b * N + row];
+          int64_t id = a.node_feat[(int64_t)mb[m] * N + row];
           id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
           v = reinterpret_cast<const float4*>(a.embedding + id * a.din0)[c4];
         } else {
-          v = reinterpret_cast<const float4*>(a.node_feat_f + ((int64_t)b * N + row) * a.din0)[c4];
+          v = reinterpret_cast<const float4*>(a.node_feat_f + ((int64_t)mb[m] * N + row) * a.din0)[c4];
         }
       }
-      *reinterpret_cast<float4*>(&Xs[0][row][4 * c4]) = v;
+      *reinterpret_cast<float4*>(&Xs[0][m][row][4 * c4]) = v;
     }
   }
 
-  // ---- Ritz-vector fragments: vreg[t] = V[b][j][KH*hh + t]
+  // ---- Ritz-vector fragments: vreg[m][t] = V[mol m][j][KH*hh + t]
   const int KH = (K + 1) >> 1;
-  float vreg[KHMAX];
+  float vreg[MOLS][KHT];
 #pragma unroll
-  for (int t = 0; t < KHMAX; ++t) {
-    int k = KH * hh + t;
-    vreg[t] = (t < KH && k < K && j < N) ? a.V[((int64_t)b * N + j) * K + k] : 0.0f;
+  for (int m = 0; m < MOLS; ++m) {
+#pragma unroll
+    for (int t = 0; t < KHT; ++t) {
+      int k = KH * hh + t;
+      vreg[m][t] = (t < KH && k < K && j < N) ? a.V[((int64_t)mb[m] * N + j) * K + k] : 0.0f;
+    }
   }
   __syncthreads();
 
+#ifdef LNZ_PROFILE_PHASES
+  long long t_g1 = 0, t_g2 = 0, t_ep = 0, t_all = clock64();
+#define LNZ_T0 long long _t0 = clock64();
+#define LNZ_ACC(x) { long long _t1 = clock64(); x += _t1 - _t0; _t0 = _t1; }
+#else
+#define LNZ_T0
+#define LNZ_ACC(x)
+#endif
   int cur = 0;
   for (int l = 0; l < a.num_layer; ++l) {
     const int din = l == 0 ? a.din0 : dhid;
@@ -95,114 +115,181 @@ __global__ __launch_bounds__(64 * NW) void lanczosnet_forward_kernel(const lnz_f
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
     const float* __restrict__ bl = a.bias + a.b_off[l];
 
-    f32x16 out[OTW];
+    f32x16 out[MOLS];
+    {
+      const float bv = bl[32 * wave + j];
 #pragma unroll
-    for (int ot = 0; ot < OTW; ++ot) out[ot] = lnz::splat16(bl[32 * (wave * OTW + ot) + j]);
+      for (int m = 0; m < MOLS; ++m) out[m] = lnz::splat16(bv);
+    }
 
-    for (int c = 0; c < C; ++c) {
-      // ---------------- A operand of GEMM2: M_c fragments ----------------
-      f32x16 Mf;
-      const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
-      if (is_long) {
-        const int s = c - a.n_short;
-        const float* gp = a.G + (((int64_t)l * B + b) * a.n_long + s) * K;
-        f32x16 acc = lnz::splat16(0.0f);
+    // B-operand stream of this wave's feature tile: contiguous over g = c*Q + q for the whole
+    // layer, read through a 4-slot register ring with prefetch distance 3 steps.  One running
+    // pointer + immediate offsets; over-reads 3 steps past the layer (host keeps 3 KiB slack).
+    const int Gtot = C * Q;
+    const float4* __restrict__ wp = Wl + (int64_t)wave * Gtot * 64 + lane;
+    float4 ring[4];
 #pragma unroll
-        for (int t = 0; t < KHMAX; ++t) {
-          if (t < KH) {
-            int k = KH * hh + t;
-            float g = k < K ? gp[k] : 0.0f;
-            acc = lnz::mfma32(vreg[t] * g, vreg[t], acc);
-          }
+    for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
+    const float* xrow[MOLS];
+#pragma unroll
+    for (int m = 0; m < MOLS; ++m) xrow[m] = &Xs[cur][m][j][4 * hh];
+
+    // Operands of GEMM2 (per molecule, 16 registers: the 10 spectral gains g_s[k] of a long
+    // channel OR the four float4 Laplacian fragments of an edge/short channel) are fetched one
+    // channel ahead, right after the previous fragments are consumed and before that
+    // molecule's GEMM2 — so they have >= 16 MFMAs to land and are waited for together with the
+    // oldest ring slot at the next GEMM1 loop header.
+    float mop[MOLS][16];
+    auto fetch_m_operands = [&](int c, int m) {
+      const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
+      if (lng) {
+        const float* gp = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K;
+#pragma unroll
+        for (int t = 0; t < KHT; ++t) {
+          int k = KH * hh + t;
+          mop[m][t] = (t < KH && k < K) ? gp[k] : 0.0f;
         }
-        Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]
       } else {
         const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
-        const float4* lp = reinterpret_cast<const float4*>(a.Lp) + ((int64_t)b * a.n_edge + e) * 256;
-        float4 v[4];
+        const float4* lp =
+            reinterpret_cast<const float4*>(a.Lp) + ((int64_t)mb[m] * a.n_edge + e) * 256;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = lp[g * 64 + lane];
-        Mf = frag_from4(v);
-      }
-
-      // ---------------- GEMM1: Z = X W_c^T ----------------
-      f32x16 Z[OTW];
-#pragma unroll
-      for (int ot = 0; ot < OTW; ++ot) Z[ot] = lnz::splat16(0.0f);
-      const float4* __restrict__ wb[OTW];
-#pragma unroll
-      for (int ot = 0; ot < OTW; ++ot)
-        wb[ot] = Wl + ((int64_t)(wave * OTW + ot) * (C * Q) + (int64_t)c * Q) * 64 + lane;
-      const float* xrow = &Xs[cur][j][4 * hh];
-#pragma unroll 2
-      for (int q = 0; q < Q; ++q) {
-        float4 av = *reinterpret_cast<const float4*>(xrow + 8 * q);
-        float4 bv[OTW];
-#pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) bv[ot] = wb[ot][q * 64];
-#pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) Z[ot] = lnz::mfma32(av.x, bv[ot].x, Z[ot]);
-#pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) Z[ot] = lnz::mfma32(av.y, bv[ot].y, Z[ot]);
-#pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) Z[ot] = lnz::mfma32(av.z, bv[ot].z, Z[ot]);
-#pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) Z[ot] = lnz::mfma32(av.w, bv[ot].w, Z[ot]);
-      }
-
-      // ---------------- short diffusion: Z <- L_0^(p-1) Z ----------------
-      if (c < a.n_short) {
-        const int p = a.short_dist[c];
-        for (int rep = 1; rep < p; ++rep) {
-#pragma unroll
-          for (int ot = 0; ot < OTW; ++ot) {
-            f32x16 T = lnz::splat16(0.0f);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T = lnz::mfma32(Mf[r], Z[ot][r], T);
-            Z[ot] = T;
-          }
+        for (int g = 0; g < 4; ++g) {
+          float4 v = lp[g * 64 + lane];
+          mop[m][4 * g + 0] = v.x;
+          mop[m][4 * g + 1] = v.y;
+          mop[m][4 * g + 2] = v.z;
+          mop[m][4 * g + 3] = v.w;
         }
       }
+    };
+#pragma unroll
+    for (int m = 0; m < MOLS; ++m) fetch_m_operands(0, m);
 
-      // ---------------- GEMM2: out += M_c Z ----------------
+    for (int c = 0; c < C; ++c) {
+      const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
+
+      LNZ_T0
+      // ---------------- GEMM1: Z_m = X_m W_c^T ----------------
+      f32x16 Z[MOLS];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int m = 0; m < MOLS; ++m) Z[m] = lnz::splat16(0.0f);
+      const float* xq[MOLS];
+      float4 acur[MOLS];
 #pragma unroll
-        for (int ot = 0; ot < OTW; ++ot) out[ot] = lnz::mfma32(Mf[r], Z[ot][r], out[ot]);
+      for (int m = 0; m < MOLS; ++m) {
+        xq[m] = xrow[m];
+        acur[m] = *reinterpret_cast<const float4*>(xq[m]);
       }
+#pragma unroll 1
+      for (int q0 = 0; q0 < Q; q0 += 4) {
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+          ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
+          // next A fragments (the read one step past the channel's last is in-bounds, unused)
+          float4 anext[MOLS];
+#pragma unroll
+          for (int m = 0; m < MOLS; ++m)
+            anext[m] = *reinterpret_cast<const float4*>(xq[m] + 8 * (u4 + 1));
+          // keep the prefetches ahead of this step's MFMAs (hipcc otherwise sinks all loads of
+          // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
+          __builtin_amdgcn_sched_barrier(0);
+          const float4 bv = ring[u4];
+#pragma unroll
+          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MOLS; ++m) acur[m] = anext[m];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MOLS; ++m) xq[m] += 32;
+        wp += 4 * 64;
+      }
+
+      LNZ_ACC(t_g1)
+      // ---------------- per molecule: M_c fragments, next operands, GEMM2 ----------------
+#pragma unroll
+      for (int m = 0; m < MOLS; ++m) {
+        f32x16 Mf;
+        if (is_long) {
+          f32x16 acc = lnz::splat16(0.0f);
+#pragma unroll
+          for (int t = 0; t < KHT; ++t) {
+            if (t < KH) acc = lnz::mfma32(vreg[m][t] * mop[m][t], vreg[m][t], acc);
+          }
+          Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]  (symmetric)
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Mf[r] = mop[m][r];
+        }
+        if (c + 1 < C) fetch_m_operands(c + 1, m);
+
+        // short diffusion: Z <- L_0^(p-1) Z
+        if (c < a.n_short) {
+          const int p = a.short_dist[c];
+          for (int rep = 1; rep < p; ++rep) {
+            f32x16 T = lnz::splat16(0.0f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T = lnz::mfma32(Mf[r], Z[m][r], T);
+            Z[m] = T;
+          }
+        }
+        // GEMM2: out_m += M_c,m Z_m
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[m] = lnz::mfma32(Mf[r], Z[m][r], out[m]);
+      }
+      LNZ_ACC(t_g2)
     }
 
     // ---------------- epilogue: ReLU, X' -> LDS (other buffer), one barrier per layer -------
+    LNZ_T0
     const int nxt = cur ^ 1;
 #pragma unroll
-    for (int ot = 0; ot < OTW; ++ot) {
+    for (int m = 0; m < MOLS; ++m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Xs[nxt][lnz::cd_row(r, hh)][32 * (wave * OTW + ot) + j] = fmaxf(out[ot][r], 0.0f);
+        Xs[nxt][m][lnz::cd_row(r, hh)][32 * wave + j] = fmaxf(out[m][r], 0.0f);
     }
     __syncthreads();
     cur = nxt;
+    LNZ_ACC(t_ep)
   }
+#ifdef LNZ_PROFILE_PHASES
+  if (a.state_out && lane == 0 && blockIdx.x < 8) {
+    float* d = a.state_out + ((int64_t)B * 32 * dhid) + (blockIdx.x * 4 + wave) * 4;
+    d[0] = (float)t_g1; d[1] = (float)t_g2; d[2] = (float)t_ep; d[3] = (float)(clock64() - t_all);
+  }
+#endif
 
   // ---- optional debug/test output of the final node state
   if (a.state_out) {
-    float* so = a.state_out + (int64_t)b * 32 * dhid;
-    for (int idx = tid; idx < 32 * dhid; idx += 64 * NW) {
-      int row = idx / dhid, col = idx - row * dhid;
-      so[idx] = Xs[cur][row][col];
+    for (int idx = tid; idx < MOLS * 32 * dhid; idx += 64 * NWV) {
+      int m = idx / (32 * dhid);
+      int rem = idx - m * 32 * dhid;
+      int row = rem / dhid, col = rem - row * dhid;
+      if (blockIdx.x * MOLS + m < B)
+        a.state_out[((int64_t)mb[m] * 32 + row) * dhid + col] = Xs[cur][m][row][col];
     }
   }
 
-  // ---- head (model/lanczos_net.py:185-194): one 32-column tile = [W_o ; w_a ; 0], wave 0 only
-  if (wave == 0) {
+  // ---- head (model/lanczos_net.py:185-194): one 32-column tile = [W_o ; w_a ; 0];
+  //      wave m handles molecule m
+  if (wave < MOLS && blockIdx.x * MOLS + wave < B) {
+    const int m = wave;
     const int P = a.dout;
     f32x16 acc = lnz::splat16(a.bias_head[j]);
     const float4* wh = reinterpret_cast<const float4*>(a.Wp_head) + lane;
-    const float* xrow = &Xs[cur][j][4 * hh];
+    const float* xr = &Xs[cur][m][j][4 * hh];
     const int Q = dhid >> 3;
 #pragma unroll 2
     for (int q = 0; q < Q; ++q) {
-      float4 av = *reinterpret_cast<const float4*>(xrow + 8 * q);
+      float4 av = *reinterpret_cast<const float4*>(xr + 8 * q);
       float4 bv = wh[q * 64];
       acc = lnz::mfma32(av.x, bv.x, acc);
       acc = lnz::mfma32(av.y, bv.y, acc);
@@ -212,18 +299,19 @@ __global__ __launch_bounds__(64 * NW) void lanczosnet_forward_kernel(const lnz_f
     // acc[r] of lane (j,hh) = Y[cd_row(r,hh)][j]; the gate logit is column P of the same row
     float sum = 0.0f, cnt = 0.0f;
     const int src = 32 * hh + P;
+    const int64_t mol = mb[m];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float logit = __shfl(acc[r], src, 64);
       float gate = 1.0f / (1.0f + __expf(-logit));
       int row = lnz::cd_row(r, hh);
-      bool m = row < N && a.mask[(int64_t)b * N + row] != 0;
-      sum += m ? gate * acc[r] : 0.0f;
-      cnt += m ? 1.0f : 0.0f;
+      bool msk = row < N && a.mask[mol * N + row] != 0;
+      sum += msk ? gate * acc[r] : 0.0f;
+      cnt += msk ? 1.0f : 0.0f;
     }
     sum += __shfl_xor(sum, 32, 64);
     cnt += __shfl_xor(cnt, 32, 64);
-    if (hh == 0 && j < P) a.score[(int64_t)b * P + j] = sum / cnt;
+    if (hh == 0 && j < P) a.score[mol * P + j] = sum / cnt;
   }
 }
 
@@ -243,8 +331,9 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
               a.num_layer);
   LNZ_REQUIRE(a.dhid == 64 || a.dhid == 128, LNZ_ENOTSUP,
               "lnz_lanczosnet_forward: hidden width %d not in {64,128}", a.dhid);
-  LNZ_REQUIRE(a.din0 > 0 && a.din0 % 8 == 0 && a.din0 <= 128, LNZ_ENOTSUP,
-              "lnz_lanczosnet_forward: input width %d must be a multiple of 8, <= 128", a.din0);
+  LNZ_REQUIRE(a.din0 > 0 && a.din0 % 32 == 0 && a.din0 <= 128, LNZ_ENOTSUP,
+              "lnz_lanczosnet_forward: input width %d must be a multiple of 32, <= 128 "
+              "(zero-pad features and weight columns on the host)", a.din0);
   LNZ_REQUIRE(a.dout >= 1 && a.dout <= 31, LNZ_ENOTSUP,
               "lnz_lanczosnet_forward: output width %d not in 1..31", a.dout);
   LNZ_REQUIRE(a.n_short >= 0 && a.n_short <= 8 && a.n_long >= 0 && a.n_edge >= 1 &&
@@ -256,10 +345,16 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
               LNZ_EINVAL, "lnz_lanczosnet_forward: null tensor pointer");
   LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "lnz_lanczosnet_forward: G missing");
   hipStream_t s = (hipStream_t)stream;
-  if (a.dhid == 128) {
-    hipLaunchKernelGGL(lanczosnet_forward_kernel<2>, dim3(a.B), dim3(64 * NW), 0, s, a);
+  const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
+  const int grid = (a.B + MOLS - 1) / MOLS;
+  if (a.dhid == 128 && k20) {
+    hipLaunchKernelGGL((lanczosnet_forward_kernel<4, 10>), dim3(grid), dim3(256), 0, s, a);
+  } else if (a.dhid == 128) {
+    hipLaunchKernelGGL((lanczosnet_forward_kernel<4, KHMAX>), dim3(grid), dim3(256), 0, s, a);
+  } else if (k20) {
+    hipLaunchKernelGGL((lanczosnet_forward_kernel<2, 10>), dim3(grid), dim3(128), 0, s, a);
   } else {
-    hipLaunchKernelGGL(lanczosnet_forward_kernel<1>, dim3(a.B), dim3(64 * NW), 0, s, a);
+    hipLaunchKernelGGL((lanczosnet_forward_kernel<2, KHMAX>), dim3(grid), dim3(128), 0, s, a);
   }
   return lnz::check_launch("lnz_lanczosnet_forward");
 }

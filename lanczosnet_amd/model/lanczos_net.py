@@ -105,8 +105,8 @@ class _LanczosNetBase(nn.Module):
             raise NotImplementedError(
                 'HIP path is built for a uniform hidden width of 64 or 128, got %r' %
                 (self.hidden_dim,))
-        if self.input_dim % 8 or self.input_dim > 128:
-            raise NotImplementedError('input_dim must be a multiple of 8 and <= 128')
+        if self.input_dim > 128:
+            raise NotImplementedError('input_dim must be <= 128')
 
     @torch.no_grad()
     def _plan(self):
@@ -117,8 +117,17 @@ class _LanczosNetBase(nn.Module):
         dev = self.filter[0].weight.device
         dhid = self.hidden_dim[0]
         packs, biases, w_off, b_off, woff, boff = [], [], [], [], 0, 0
+        # the kernel consumes the input width in 32-column groups: zero-pad layer-0 weight
+        # columns (per message channel) and the embedding / feature columns to match
+        din0 = self.input_dim
+        din0p = (din0 + 31) // 32 * 32
+        n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
         for t in range(self.num_layer):
-            wp = ops.pack_rows_k8(self.filter[t].weight)
+            w = self.filter[t].weight
+            if t == 0 and din0p != din0:
+                w = torch.nn.functional.pad(w.view(dhid, n_chan, din0), (0, din0p - din0))
+                w = w.reshape(dhid, n_chan * din0p)
+            wp = ops.pack_rows_k8(w)
             packs.append(wp)
             w_off.append(woff)
             woff += wp.numel()
@@ -132,13 +141,20 @@ class _LanczosNetBase(nn.Module):
         bias_head = torch.zeros((32,), dtype=torch.float32, device=dev)
         bias_head[:P] = self.filter[-1].bias
         bias_head[P] = self.att_func[0].bias[0]
-        plan = dict(sig=sig, num_layer=self.num_layer, din0=self.input_dim, dhid=dhid, dout=P,
+        emb = None
+        if not self.general:
+            emb = torch.nn.functional.pad(self.embedding.weight.detach().float(),
+                                          (0, din0p - din0)).contiguous()
+        plan = dict(sig=sig, num_layer=self.num_layer, din0=din0p, din0_raw=din0, dhid=dhid,
+                    dout=P,
                     short=list(self.short_diffusion_dist), n_long=self.num_scale_long,
                     n_edge=self.num_edgetype + 1,
-                    Wp=torch.cat(packs), bias=torch.cat(biases).contiguous(),
+                    # + slack: the kernel's weight prefetch ring over-reads 3 steps (3 KiB)
+                    Wp=torch.cat(packs + [torch.zeros(1024, dtype=torch.float32, device=dev)]),
+                    bias=torch.cat(biases).contiguous(),
                     w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
                     bias_head=bias_head,
-                    embedding=None if self.general else self.embedding.weight.detach())
+                    embedding=emb)
         if self._has_mlp():
             size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
             buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)

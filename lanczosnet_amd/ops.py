@@ -162,7 +162,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
     a.embedding = plan['embedding'].data_ptr()
     a.num_atom = plan['embedding'].shape[0]
   else:
-    nf = _f32c(node_feat)
+    nf = node_feat.to(torch.float32)
+    if nf.shape[-1] != plan['din0']:  # zero-pad feature columns to the kernel's 32-column groups
+      assert nf.shape[-1] == plan['din0_raw']
+      nf = torch.nn.functional.pad(nf, (0, plan['din0'] - nf.shape[-1]))
+    nf = nf.contiguous()
     a.node_feat, a.node_feat_f, a.embedding, a.num_atom = None, nf.data_ptr(), None, 0
   mask_u8 = mask.to(torch.uint8).contiguous()
   Vc = _f32c(V)
