@@ -128,6 +128,9 @@ typedef struct lnz_forward_args {
   float* state_out;           /* optional [B,32,dhid] final node state (debug/tests) or NULL */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
+/* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
+ * its struct layout before the first call. */
+int64_t lnz_forward_args_size(void);
 
 /* ---- R12: unsorted_segment_sum -----------------------------------------------------------
  * out[b, ids[b,c], x] += data[b,c,x]  /  grad_data[b,c,x] = grad_out[b, ids[b,c], x].

@@ -58,6 +58,7 @@ SIGNATURES = {
     'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),
     'lnz_spectral_gains': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P]),
     'lnz_lanczosnet_forward': (C.c_int, [C.POINTER(ForwardArgs), _P]),
+    'lnz_forward_args_size': (C.c_int64, []),
     'lnz_unsorted_segment_sum_forward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'lnz_unsorted_segment_sum_backward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
 }
@@ -90,6 +91,9 @@ def load():
   if ver != ABI_VERSION:
     raise ImportError('lanczosnet_amd: ABI version mismatch: library %d, binding %d (rebuild)' %
                       (ver, ABI_VERSION))
+  if lib.lnz_forward_args_size() != C.sizeof(ForwardArgs):
+    raise ImportError('lanczosnet_amd: lnz_forward_args layout mismatch: library %d B, binding %d B'
+                      % (lib.lnz_forward_args_size(), C.sizeof(ForwardArgs)))
   _lib = lib
   return lib
 

@@ -317,6 +317,8 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
 
 }  // namespace
 
+extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
+
 extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream) {
   LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_forward: null args");
   const lnz_forward_args& a = *args;

@@ -1,0 +1,88 @@
+"""Multi-GPU sharding of the LanczosNet forward: one process per GPU, `torch.distributed`
+(backend `nccl` = RCCL over xGMI on ROCm; `gloo` in the CPU tests).
+
+Molecules are independent (every tensor of the collate output has the batch on dim 0 and no op
+mixes batch entries: dataset/qm8.py:71-90,262,289-291; model/lanczos_net.py:190-194), so the
+path shards with NO data-path collective: each rank runs the HIP pipeline on a contiguous
+dim-0 slice.  The only exchange is the result: one all-gather of the per-shard scores
+(64 KiB per rank at 1024 x 16 fp32 — latency bound, far below the 7 x ~153 GB/s xGMI links) and,
+when labels are given, one all-reduce of (sum of squared errors, count) so the loss is the
+size-weighted mean the single-process `MSELoss` would have produced (the reference's
+`nn.DataParallel`, runner/qm8_runner.py:62, gathers per-replica means instead, which is only
+correct for equal shards).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous dim-0 split of n items over `world` ranks; the first n % world ranks get one
+    extra item (same rule as torch.tensor_split)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def shard_batch(batch, rank=None, world=None):
+    """Slice every tensor of a collated batch (dict or tuple/list of tensors) on dim 0."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+
+    def cut(t):
+        if t is None:
+            return None
+        lo, hi = shard_bounds(t.shape[0], rank, world)
+        return t[lo:hi]
+
+    if isinstance(batch, dict):
+        return {k: cut(v) for k, v in batch.items()}
+    return type(batch)(cut(v) for v in batch)
+
+
+def all_gather_scores(local_score, n_global, group=None):
+    """Gather the per-shard scores [b_r, P] into the full [n_global, P] on every rank.
+    Shards may be uneven (sizes follow shard_bounds): shorter shards are zero-padded for the
+    collective and trimmed afterwards."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local_score
+    sizes = [shard_bounds(n_global, r, world)[1] - shard_bounds(n_global, r, world)[0]
+             for r in range(world)]
+    bmax = max(sizes)
+    P = local_score.shape[1]
+    send = local_score
+    if local_score.shape[0] != bmax:
+        send = torch.zeros((bmax, P), dtype=local_score.dtype, device=local_score.device)
+        send[:local_score.shape[0]] = local_score
+    out = torch.empty((world * bmax, P), dtype=local_score.dtype, device=local_score.device)
+    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    if all(s == bmax for s in sizes):
+        return out
+    return torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], dim=0)
+
+
+def global_mse(local_score, local_label, group=None):
+    """Size-weighted global mean squared error == MSELoss over the unsharded batch
+    (model/lanczos_net.py:66,197).  One all-reduce of two scalars."""
+    sse = ((local_score.double() - local_label.double()) ** 2).sum()
+    acc = torch.stack([sse, torch.tensor(float(local_score.numel()), dtype=torch.float64,
+                                         device=local_score.device)])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return (acc[0] / acc[1]).to(local_score.dtype)
+
+
+def forward_sharded(forward_fn, batch, n_global, label_key='label', group=None):
+    """Run `forward_fn(shard) -> score [b_r, P]` on this rank's slice of `batch` (already
+    sliced or sliced here when it still has n_global rows) and return (full_score, loss|None)."""
+    first = next(v for v in (batch.values() if isinstance(batch, dict) else batch)
+                 if v is not None)
+    shard = shard_batch(batch) if first.shape[0] == n_global and dist.get_world_size(group) > 1 \
+        else batch
+    local = forward_fn(shard)
+    full = all_gather_scores(local, n_global, group)
+    loss = None
+    if isinstance(shard, dict) and shard.get(label_key) is not None:
+        loss = global_mse(local, shard[label_key], group)
+    return full, loss

@@ -233,6 +233,17 @@ def main():
                       node_mask=data['node_mask'].numpy(), T=T.numpy(), Q=Q.numpy(),
                       feat=feat.numpy(), adj=adj.numpy(), Le=Le.numpy(), T2=T2.numpy(),
                       Q2=Q2.numpy())
+  # ---- 7. constructor / init RNG parity: reference LanczosNet under torch.manual_seed(1234)
+  torch.manual_seed(1234)
+  ref_net = ref_model.LanczosNet(make_config(dict(DEFAULT_QM8_CFG)))
+  sd = ref_net.state_dict()
+  keys = sorted(sd.keys())
+  np.savez_compressed(os.path.join(HERE, 'init_parity.npz'), keys=np.array(keys),
+                      shapes=np.array([repr(tuple(sd[k].shape)) for k in keys]),
+                      sums=np.array([float(sd[k].double().sum()) for k in keys]),
+                      first=np.array([float(sd[k].reshape(-1)[0]) for k in keys]),
+                      num_params=sum(int(v.numel()) for v in sd.values()),
+                      torch_version=np.array(torch.__version__))
   print('golden fixtures written to', HERE)
   for f in sorted(os.listdir(HERE)):
     if f.endswith('.npz'):

@@ -1,0 +1,93 @@
+"""world_size-2 (and 3, uneven) `gloo` tests of the N > 1 path on CPU: contiguous batch shards,
+score all-gather, size-weighted loss.  The per-shard forward is the numpy oracle here (tests may
+use it); on the GPU box the same driver code wraps the HIP forward (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from lanczosnet_amd import dist as lnz_dist
+
+CFG = dict(num_atom=11, num_bond_type=2, short_diffusion_dist=[], long_diffusion_dist=[1, 3],
+           num_eig_vec=6, spectral_filter_kind='MLP', input_dim=8, hidden_dim=[16, 16],
+           output_dim=4, num_layer=2)
+
+
+def _make_batch(B=7):
+  from lanczosnet_amd.synthetic import draw_batch
+  b = draw_batch(B, seed=3, n_min=3, n_max=9, num_atom=11, num_bond_type=2, num_label=4)
+  N = b['node_mask'].shape[1]
+  L = np.zeros((B, N, N, 3), np.float32)
+  Dl, Vl = [], []
+  for i in range(B):
+    n = int(b['n_nodes'][i])
+    L[i, :n, :n] = oracle.laplacian_multi_l4(b['adjs'][i, :n, :n])
+    e, V, _ = oracle.graph_laplacian_eigs(b['adjs'][i, :n, :n].sum(axis=2),
+                                          graph_laplacian_type='L4')
+    Dl.append(e)
+    Vl.append(V)
+  D, V = oracle.collate_eigs(Dl, Vl, N, 6)
+  return dict(node_feat=torch.from_numpy(b['node_feat']), L=torch.from_numpy(L),
+              D=torch.from_numpy(D), V=torch.from_numpy(V),
+              node_mask=torch.from_numpy(b['node_mask']), label=torch.from_numpy(b['label']))
+
+
+def _oracle_forward(P):
+  def fn(shard):
+    s = oracle.lanczos_net_forward(P, CFG, shard['node_feat'].numpy(), shard['L'].numpy(),
+                                   shard['D'].numpy(), shard['V'].numpy(),
+                                   shard['node_mask'].numpy())
+    return torch.from_numpy(s)
+  return fn
+
+
+def _worker(rank, world, port, out_dir):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    P = oracle.make_lanczosnet_params(CFG, 3)
+    batch = _make_batch()
+    n = batch['L'].shape[0]
+    full, loss = lnz_dist.forward_sharded(_oracle_forward(P), batch, n)
+    ref = _oracle_forward(P)(batch)
+    ref_loss = torch.mean((ref - batch['label']) ** 2)
+    ok = bool(torch.equal(full, ref)) and abs(float(loss) - float(ref_loss)) < 1e-6
+    lo, hi = lnz_dist.shard_bounds(n, rank, world)
+    np.save(os.path.join(out_dir, 'r%d.npy' % rank), np.array([ok, lo, hi], dtype=np.int64))
+  finally:
+    dist.destroy_process_group()
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_forward_matches_single_process(world, tmp_path):
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  covered = []
+  for r in range(world):
+    ok, lo, hi = np.load(tmp_path / ('r%d.npy' % r))
+    assert ok == 1
+    covered += list(range(lo, hi))
+  assert covered == list(range(7))  # shards tile the batch exactly once, in order
+
+
+def test_shard_bounds_properties():
+  for n in (0, 1, 7, 1024, 8191):
+    for world in (1, 2, 3, 8):
+      b = [lnz_dist.shard_bounds(n, r, world) for r in range(world)]
+      assert b[0][0] == 0 and b[-1][1] == n
+      assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+      sizes = [hi - lo for lo, hi in b]
+      assert max(sizes) - min(sizes) <= 1
