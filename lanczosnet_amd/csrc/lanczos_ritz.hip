@@ -119,6 +119,9 @@ __global__ __launch_bounds__(64) void lanczos_ritz_kernel(
   }
   __syncthreads();
 
+#ifdef LNZ_PROFILE_PHASES
+  long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
+#endif
   int nrestart = 0;
   if (n > 0) {
     // deterministic, strictly positive, non-symmetric start vector (any start works: restarts
@@ -191,6 +194,9 @@ __global__ __launch_bounds__(64) void lanczos_ritz_kernel(
     }
     __syncthreads();
 
+#ifdef LNZ_PROFILE_PHASES
+    tp1 = clock64();
+#endif
     // ---- implicit-shift QL on (dd, ee); rotations applied to rows of Z = Qt^T -----------
     // All lanes run the scalar recurrences redundantly on identical LDS values.
     double f = 0.0, tst1 = 0.0;
@@ -265,6 +271,9 @@ __global__ __launch_bounds__(64) void lanczos_ritz_kernel(
       __syncthreads();
     }
 
+#ifdef LNZ_PROFILE_PHASES
+    tp2 = clock64();
+#endif
     // ---- order by descending |lambda| (ties: ascending lambda, then index) --------------
     // = np.argsort(-|eig|, kind='mergesort') on eigh's ascending output
     //   (utils/data_helper.py:218-223)
@@ -306,6 +315,331 @@ __global__ __launch_bounds__(64) void lanczos_ritz_kernel(
     Vb[idx] = v;
   }
   if (info && lane == 0) info[b] = nrestart;
+#ifdef LNZ_PROFILE_PHASES
+  __syncthreads();
+  if (lane == 0) {
+    long long tp3 = clock64();
+    D[(int64_t)b * K + 0] = (float)(tp1 - tp0);
+    D[(int64_t)b * K + 1] = (float)(tp2 - tp1);
+    D[(int64_t)b * K + 2] = (float)(tp3 - tp2);
+    D[(int64_t)b * K + 3] = (float)n;
+  }
+#endif
+}
+
+
+// =========================================================================================
+// Fast path, N <= 32 (QM8): same algorithm, scheduled for latency.
+//   * lane = r + 32*h : both wave halves own node row r; every length-32 reduction is split
+//     into two 16-element halves (h = 0/1) held in REGISTERS (loaded with back-to-back
+//     ds_read_b128, one wait) and combined with one v_permlane32_swap pair — no LDS loop with a
+//     dependent load per element;
+//   * norm and SpMV share one broadcast of the residual:  beta = |w|, A q = (A w) / beta;
+//   * T's diagonal / off-diagonal live in lane registers during QL (uniform reads via
+//     v_readlane, writes by lane-select), and the rotated eigenvector row is carried in a
+//     register, so the LDS eigenvector update is off the scalar sqrt/rsqrt critical path.
+// =========================================================================================
+struct Ritz32Smem {
+  static constexpr int LD = 34;   // doubles per basis row: b128 row reads conflict free
+  double Qt[32 * LD];
+  double za[32];
+  double zb[32];
+  double ca[32];
+  double cb[32];
+  double dd[32];
+  int perm[32];
+  float sgn[32];
+};
+
+__device__ inline double xhalf_sum(double x) {
+  // x(lower half lane) + x(upper half lane), identical (bitwise) in both halves
+  unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  double a = __hiloint2double((int)rh[0], (int)rl[0]);  // lower-half value, in every lane
+  double b = __hiloint2double((int)rh[1], (int)rl[1]);  // upper-half value, in every lane
+  return a + b;
+}
+
+__device__ inline double readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ inline void load16(const double* p, double (&v)[16]) {
+  // p is 16-byte aligned: 8 x ds_read_b128
+#pragma unroll
+  for (int t = 0; t < 16; t += 2) {
+    double2 x = *reinterpret_cast<const double2*>(p + t);
+    v[t] = x.x;
+    v[t + 1] = x.y;
+  }
+}
+
+__device__ inline double dot16(const double (&a)[16], const double (&b)[16]) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int t = 0; t < 16; t += 4) {
+    s0 = fma(a[t], b[t], s0);
+    s1 = fma(a[t + 1], b[t + 1], s1);
+    s2 = fma(a[t + 2], b[t + 2], s2);
+    s3 = fma(a[t + 3], b[t + 3], s3);
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
+// x <- (I - Q Q^T)^2 x over all stored basis rows (rows not yet written are zero); returns the
+// accumulated coefficient on basis vector j.  r = lane & 31, h = lane >> 5.
+__device__ inline double cgs2_32(Ritz32Smem& sm, double& x, int j, int r, int h) {
+  constexpr int LD = Ritz32Smem::LD;
+  double qrow[16], qcol[16], v[16];
+  double coef = 0.0;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    double* zbuf = pass ? sm.zb : sm.za;
+    double* cbuf = pass ? sm.cb : sm.ca;
+    zbuf[r] = x;
+    __syncthreads();
+    load16(zbuf + 16 * h, v);
+    if (pass == 0) {
+      load16(&sm.Qt[r * LD + 16 * h], qrow);  // half of basis vector r
+#pragma unroll
+      for (int t = 0; t < 16; ++t) qcol[t] = sm.Qt[(16 * h + t) * LD + r];  // element r of vectors
+    }
+    double c = xhalf_sum(dot16(qrow, v));  // <q_r, x>
+    cbuf[r] = c;
+    coef += readlane_f64(c, j);
+    __syncthreads();
+    load16(cbuf + 16 * h, v);
+    x -= xhalf_sum(dot16(qcol, v));
+  }
+  return coef;
+}
+
+__global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
+    const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
+    const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
+    float* __restrict__ V, int32_t* __restrict__ info) {
+  constexpr int LD = Ritz32Smem::LD;
+  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  int n = n_nodes[b];
+  n = n < 0 ? 0 : (n > N ? N : n);
+  const int kk = K < n ? K : n;
+
+  // this lane's half row of A (fp64 registers), zero outside the n x n block
+  double arow[16];
+  {
+    const float* Ab = A + (int64_t)b * sb + (int64_t)r * sr;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      int c = 16 * h + t;
+      arow[t] = (r < n && c < n) ? (double)Ab[c * sc] : 0.0;
+    }
+  }
+  // zero the basis (rows beyond the current step must read as zero)
+  for (int idx = lane; idx < 32 * LD / 2; idx += 64)
+    reinterpret_cast<double2*>(sm.Qt)[idx] = make_double2(0.0, 0.0);
+  __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+  long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
+#endif
+
+  int nrestart = 0;
+  double dreg = 0.0, ereg = 0.0;  // lane r holds T[r][r], T[r][r+1]
+  if (n > 0) {
+    double w = 0.0;
+    if (r < n) {
+      unsigned hsh = (unsigned)(r + 1) * 2654435761u;
+      w = 1.0 + (double)((hsh >> 8) & 0xffff) * (1.0 / 65536.0);
+    }
+    bool fresh = true;  // w is a start/restart vector: its norm is not a coupling beta
+    for (int j = 0; j < n; ++j) {
+      double beta, u;
+      for (;;) {
+        // ---- one broadcast of w: beta = |w| and u = A w
+        sm.za[r] = w;
+        __syncthreads();
+        double v[16];
+        load16(sm.za + 16 * h, v);
+        double nn = xhalf_sum(dot16(v, v));
+        u = xhalf_sum(dot16(arow, v));
+        beta = sqrt(nn);
+        __syncthreads();
+        if (fresh || beta > kBreakdownTol) break;
+        // breakdown: span(q_0..q_{j-1}) is A-invariant -> restart from the unit vector with the
+        // largest residual against the basis; T[j-1][j] stays 0
+        ++nrestart;
+        double colsq[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) colsq[t] = sm.Qt[(16 * h + t) * LD + r];
+        double res = 1.0 - xhalf_sum(dot16(colsq, colsq));
+        sm.zb[r] = r < n ? res : -1.0;
+        __syncthreads();
+        int cand = 0;
+        double best = sm.zb[0];
+        for (int x = 1; x < n; ++x) {
+          double vv = sm.zb[x];
+          if (vv > best) {
+            best = vv;
+            cand = x;
+          }
+        }
+        __syncthreads();
+        w = (r == cand) ? 1.0 : 0.0;
+        (void)cgs2_32(sm, w, 0, r, h);
+        fresh = true;
+      }
+      if (!fresh && r == j - 1) ereg = beta;
+      fresh = false;
+      const double binv = 1.0 / beta;
+      const double q = w * binv;
+      double x = u * binv;  // A q
+      if (h == 0) sm.Qt[j * LD + r] = q;
+      // (the __syncthreads inside cgs2_32 orders this store before the basis reads)
+      const double alpha = cgs2_32(sm, x, j, r, h);
+      if (r == j) dreg = alpha;
+      w = x;
+    }
+    __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+    tp1 = clock64();
+#endif
+
+    // ---- implicit-shift QL (tql2 recurrences); d/e in lane registers, eigenvectors in Qt ----
+    double f = 0.0, tst1 = 0.0;
+    for (int l = 0; l < n; ++l) {
+      tst1 = fmax(tst1, fabs(readlane_f64(dreg, l)) + fabs(readlane_f64(ereg, l)));
+      const unsigned long long small =
+          __ballot(h == 0 && r >= l && r < n && (r == n - 1 || fabs(ereg) <= kEps * tst1));
+      const int m = __builtin_ctzll(small);
+      if (m > l) {
+        int iter = 0;
+        double el;
+        do {
+          ++iter;
+          double g = readlane_f64(dreg, l);
+          el = readlane_f64(ereg, l);
+          double p = (readlane_f64(dreg, l + 1) - g) / (2.0 * el);
+          double rr = sqrt(p * p + 1.0);
+          if (p < 0) rr = -rr;
+          const double dl = el / (p + rr);
+          const double dl1 = el * (p + rr);
+          const double hh = g - dl;
+          dreg = (r == l) ? dl : (r == l + 1) ? dl1 : (r >= l + 2 && r < n) ? dreg - hh : dreg;
+          f += hh;
+          p = readlane_f64(dreg, m);
+          double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+          const double el1 = readlane_f64(ereg, l + 1);
+          double carry = sm.Qt[m * LD + r];
+          double z0 = sm.Qt[(m - 1) * LD + r];
+          double ei = readlane_f64(ereg, m - 1);
+          double di = readlane_f64(dreg, m - 1);
+          for (int i = m - 1; i >= l; --i) {
+            // prefetch the next rotation's inputs: none of them is written by this rotation
+            const int ip = i > l ? i - 1 : l;
+            const double znext = sm.Qt[ip * LD + r];
+            const double ei_n = readlane_f64(ereg, ip);
+            const double di_n = readlane_f64(dreg, ip);
+            c3 = c2;
+            c2 = c;
+            s2 = s;
+            g = c * ei;
+            const double hp = c * p;
+            const double tt = fma(p, p, ei * ei);
+            const double num = fma(p, di, -(ei * g));  // (p d_i - e_i g): off the rsqrt chain
+            // 1/sqrt(tt): hardware seed + two Newton steps (tt is a normal double here:
+            // |e_i| > eps * tst1 for l <= i < m)
+            double y = __builtin_amdgcn_rsq(tt);
+            {
+              double hy = 0.5 * y;
+              double er = fma(-(tt * y), hy, 0.5);
+              y = fma(y, er, y);
+              hy = 0.5 * y;
+              er = fma(-(tt * y), hy, 0.5);
+              y = fma(y, er, y);
+            }
+            const double rad = tt * y;
+            const double e_next = s * rad;
+            s = ei * y;
+            c = p * y;
+            p = y * num;  // = c d_i - s g
+            const double d_next = hp + s * (c * g + s * di);
+            ereg = (r == i + 1) ? e_next : ereg;
+            dreg = (r == i + 1) ? d_next : dreg;
+            if (h == 0) sm.Qt[(i + 1) * LD + r] = s * z0 + c * carry;
+            carry = c * z0 - s * carry;
+            z0 = znext;
+            ei = ei_n;
+            di = di_n;
+          }
+          if (h == 0) sm.Qt[l * LD + r] = carry;
+          p = -s * s2 * c3 * el1 * readlane_f64(ereg, l) / dl1;
+          el = s * p;
+          ereg = (r == l) ? el : ereg;
+          dreg = (r == l) ? c * p : dreg;
+          __syncthreads();  // rows written by half 0 are re-read by both halves next sweep
+        } while (fabs(el) > kEps * tst1 && iter < 60);
+      }
+      dreg = (r == l) ? dreg + f : dreg;
+      ereg = (r == l) ? 0.0 : ereg;
+    }
+    if (h == 0) sm.dd[r] = dreg;
+    __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+    tp2 = clock64();
+#endif
+
+    // ---- order by descending |lambda| (ties: ascending lambda, then index) — see generic kernel
+    if (lane < n) {
+      double di = sm.dd[lane], ai = fabs(di);
+      int rank = 0;
+      for (int jj = 0; jj < n; ++jj) {
+        double dj = sm.dd[jj], aj = fabs(dj);
+        bool before = (aj > ai) || (aj == ai && (dj < di || (dj == di && jj < lane)));
+        rank += before ? 1 : 0;
+      }
+      sm.perm[rank] = lane;
+    }
+    __syncthreads();
+    if (lane < kk) {
+      const double* v = &sm.Qt[sm.perm[lane] * LD];
+      double best = 0.0;
+      float sg = 1.0f;
+      for (int x = 0; x < n; ++x) {
+        double av = fabs(v[x]);
+        if (av > best) {
+          best = av;
+          sg = v[x] < 0 ? -1.0f : 1.0f;
+        }
+      }
+      sm.sgn[lane] = sg;
+    }
+    __syncthreads();
+  }
+
+  for (int k = lane; k < K; k += 64) D[(int64_t)b * K + k] = k < kk ? (float)sm.dd[sm.perm[k]] : 0.0f;
+  float* Vb = V + (int64_t)b * N * K;
+  for (int idx = lane; idx < N * K; idx += 64) {
+    int rr = idx / K, k = idx - rr * K;
+    float v = 0.0f;
+    if (rr < n && k < kk) v = sm.sgn[k] * (float)sm.Qt[sm.perm[k] * LD + rr];
+    Vb[idx] = v;
+  }
+  if (info && lane == 0) info[b] = nrestart;
+#ifdef LNZ_PROFILE_PHASES
+  __syncthreads();
+  if (lane == 0) {
+    long long tp3 = clock64();
+    D[(int64_t)b * K + 0] = (float)(tp1 - tp0);
+    D[(int64_t)b * K + 1] = (float)(tp2 - tp1);
+    D[(int64_t)b * K + 2] = (float)(tp3 - tp2);
+    D[(int64_t)b * K + 3] = (float)n;
+  }
+#endif
 }
 
 }  // namespace
@@ -320,7 +654,7 @@ extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride
               N);
   hipStream_t s = (hipStream_t)stream;
   if (N <= 32) {
-    hipLaunchKernelGGL(lanczos_ritz_kernel<32>, dim3(B), dim3(64), 0, s, A, stride_b, stride_r,
+    hipLaunchKernelGGL(lanczos_ritz32_kernel, dim3(B), dim3(64), 0, s, A, stride_b, stride_r,
                        stride_c, n_nodes, N, K, D, V, info);
   } else {
     hipLaunchKernelGGL(lanczos_ritz_kernel<64>, dim3(B), dim3(64), 0, s, A, stride_b, stride_r,

@@ -1,0 +1,18 @@
+"""Diagnostic: clock64 phase times of lanczos_ritz_kernel (needs tools/libprobe_ritz.so)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from lanczosnet_amd import ops
+from lanczosnet_amd.synthetic import draw_batch
+b = draw_batch(1024, seed=0)
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+n = t(b['n_nodes']); L = ops.laplacian_l4(t(b['adjs']), n)
+for _ in range(3):
+  D, V, info = ops.lanczos_ritz(L[..., 0], n, 20, return_info=True)
+torch.cuda.synchronize()
+D = D.cpu().numpy(); info = info.cpu().numpy()
+print('n   count  lanczos   ql   out (kcycles, mean)   restarts(mean)')
+for nn in sorted(set(D[:, 3].astype(int))):
+  m = D[:, 3].astype(int) == nn
+  print('%2d %5d %8.1f %8.1f %6.1f   %.2f' % (nn, m.sum(), D[m, 0].mean() / 1e3, D[m, 1].mean() / 1e3, D[m, 2].mean() / 1e3, info[m].mean()))
+print('max total kcycles', (D[:, 0] + D[:, 1] + D[:, 2]).max() / 1e3)
