@@ -87,6 +87,19 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
     }
   }
 
+  // ---- rows of M_c beyond the last real node are zero (zero-padded Laplacian rows/cols, zero
+  //      rows of V): GEMM2 k-steps 4g..4g+3 only touch node rows 8g..8g+7, so a molecule with
+  //      n real nodes needs 4*ceil(n/8) of the 16 steps (wave-uniform per molecule).
+  int g2steps[MOLS];
+#pragma unroll
+  for (int m = 0; m < MOLS; ++m) {
+    int last = 0;
+    for (int i = lane; i < N; i += 64) last = a.mask[(int64_t)mb[m] * N + i] ? i + 1 : last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+    g2steps[m] = __builtin_amdgcn_readfirstlane(((last + 7) >> 3) * 4);
+  }
+
   // ---- Ritz-vector fragments: vreg[m][t] = V[mol m][j][KH*hh + t]
   const int KH = (K + 1) >> 1;
   float vreg[MOLS][KHT];
@@ -236,13 +249,22 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
           for (int rep = 1; rep < p; ++rep) {
             f32x16 T = lnz::splat16(0.0f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T = lnz::mfma32(Mf[r], Z[m][r], T);
+            for (int r = 0; r < 16; ++r) {
+              if (r < g2steps[m]) T = lnz::mfma32(Mf[r], Z[m][r], T);
+            }
             Z[m] = T;
           }
         }
         // GEMM2: out_m += M_c,m Z_m
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[m] = lnz::mfma32(Mf[r], Z[m][r], out[m]);
+        for (int r = 0; r < 16; r += 4) {
+          if (r < g2steps[m]) {
+            out[m] = lnz::mfma32(Mf[r + 0], Z[m][r + 0], out[m]);
+            out[m] = lnz::mfma32(Mf[r + 1], Z[m][r + 1], out[m]);
+            out[m] = lnz::mfma32(Mf[r + 2], Z[m][r + 2], out[m]);
+            out[m] = lnz::mfma32(Mf[r + 3], Z[m][r + 3], out[m]);
+          }
+        }
       }
       LNZ_ACC(t_g2)
     }

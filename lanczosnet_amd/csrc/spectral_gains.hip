@@ -17,16 +17,20 @@ namespace {
 constexpr int HID = 128;           // hidden width of the reference's spectral_filter MLP
 constexpr int HT = HID / 32;       // 4 feature tiles
 constexpr int SMAX = 16;           // exponents supported (two k-halves of 8)
-// pack layout (floats) per conv layer
+// pack layout (floats) per conv layer: scalars/biases first, then the three 128-wide weight
+// streams CONTIGUOUS (W2 | W4 | W6) so the kernel reads them as one prefetched stream, then slack
+// for the prefetch ring's over-read.
 constexpr int OFF_W0 = 0;                       // [HT][8][64]          A scalars of Linear(S->128)
 constexpr int OFF_B0 = OFF_W0 + HT * 8 * 64;    // [HT][64][16]
-constexpr int OFF_W2 = OFF_B0 + HT * 1024;      // rows_k8(128,128)
-constexpr int OFF_B2 = OFF_W2 + HT * 16 * 256;
-constexpr int OFF_W4 = OFF_B2 + HT * 1024;
-constexpr int OFF_B4 = OFF_W4 + HT * 16 * 256;
-constexpr int OFF_W6 = OFF_B4 + HT * 1024;      // rows_k8(32,128) (S rows zero padded to 32)
-constexpr int OFF_B6 = OFF_W6 + 16 * 256;       // [1][64][16]
-constexpr int PACK_SIZE = OFF_B6 + 1024;
+constexpr int OFF_B2 = OFF_B0 + HT * 1024;
+constexpr int OFF_B4 = OFF_B2 + HT * 1024;
+constexpr int OFF_B6 = OFF_B4 + HT * 1024;      // [1][64][16]
+constexpr int OFF_W2 = OFF_B6 + 1024;           // rows_k8(128,128): [HT][16][64] float4
+constexpr int OFF_W4 = OFF_W2 + HT * 16 * 256;
+constexpr int OFF_W6 = OFF_W4 + HT * 16 * 256;  // rows_k8(32,128) (S rows zero padded to 32)
+constexpr int RING = 8;                         // prefetch ring slots (distance RING-2 steps)
+constexpr int PACK_SIZE = OFF_W6 + 16 * 256 + RING * 256;
+constexpr int NSTEP = 2 * HT * 16 + 16;         // float4 steps of the W2|W4|W6 stream (144)
 
 struct DistArr {
   int32_t v[SMAX];
@@ -68,29 +72,32 @@ __device__ inline f32x16 load_bias_frag(const float* __restrict__ bp, int lane) 
   return acc;
 }
 
-// out_tile += W[32 rows of tile ot_out][0..127] * Hin   (A = packed weights, B = Hin registers)
-__device__ inline f32x16 dense128(const float4* __restrict__ Wp_tile, const f32x16 (&Hin)[HT],
-                                  f32x16 acc, int lane) {
+__device__ inline f32x16 relu_bias16(f32x16 v, f32x16 b) {
 #pragma unroll
-  for (int ti = 0; ti < HT; ++ti) {
-    float4 a[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) a[g] = Wp_tile[(ti * 4 + g) * 64 + lane];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      acc = lnz::mfma32(a[g].x, Hin[ti][4 * g + 0], acc);
-      acc = lnz::mfma32(a[g].y, Hin[ti][4 * g + 1], acc);
-      acc = lnz::mfma32(a[g].z, Hin[ti][4 * g + 2], acc);
-      acc = lnz::mfma32(a[g].w, Hin[ti][4 * g + 3], acc);
-    }
-  }
-  return acc;
+  for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i] + b[i], 0.0f);
+  return v;
 }
 
-__device__ inline f32x16 relu16(f32x16 v) {
+// One 32-row output tile of a 128-wide layer: 16 stream steps (4 MFMAs each).  F0 = index of the
+// tile's first step in the W2|W4|W6 stream (compile time => static ring slots / registers).
+template <int F0>
+__device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (&ring)[RING],
+                                    const f32x16 (&Hin)[HT]) {
+  f32x16 acc = lnz::splat16(0.0f);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.0f);
-  return v;
+  for (int q = 0; q < 16; ++q) {
+    constexpr int D = RING - 2;
+    ring[(F0 + q + D) % RING] = wstream[(F0 + q + D) * 64];  // over-read lands in the slack
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 a = ring[(F0 + q) % RING];
+    const int ti = q >> 2, g = q & 3;
+    acc = lnz::mfma32(a.x, Hin[ti][4 * g + 0], acc);
+    acc = lnz::mfma32(a.y, Hin[ti][4 * g + 1], acc);
+    acc = lnz::mfma32(a.z, Hin[ti][4 * g + 2], acc);
+    acc = lnz::mfma32(a.w, Hin[ti][4 * g + 3], acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
 }
 
 __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
@@ -104,7 +111,19 @@ __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
   const float dval = valid ? D[row] : 0.0f;
   const float* pk = mlp_pack + (int64_t)l * PACK_SIZE;
 
-  // features of this lane's k-half: f = 8 hh + t
+  // start the 128-wide weight stream right away: it is independent of the first layer
+  const float4* __restrict__ wstream = reinterpret_cast<const float4*>(pk + OFF_W2) + lane;
+  float4 ring[RING];
+#pragma unroll
+  for (int f = 0; f < RING - 2; ++f) ring[f] = wstream[f * 64];
+
+  // first-layer A scalars (32 per lane) and features of this lane's k-half: f = 8 hh + t
+  float w0[HT][8];
+#pragma unroll
+  for (int ot = 0; ot < HT; ++ot) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) w0[ot][t] = pk[OFF_W0 + (ot * 8 + t) * 64 + lane];
+  }
   float feat[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -118,37 +137,42 @@ __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
   // Linear(S -> 128) + ReLU
 #pragma unroll
   for (int ot = 0; ot < HT; ++ot) {
-    f32x16 acc = load_bias_frag(pk + OFF_B0 + ot * 1024, lane);
+    f32x16 acc = lnz::splat16(0.0f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      if (t < steps0) acc = lnz::mfma32(pk[OFF_W0 + (ot * 8 + t) * 64 + lane], feat[t], acc);
+      if (t < steps0) acc = lnz::mfma32(w0[ot][t], feat[t], acc);
     }
-    h1[ot] = relu16(acc);
+    h1[ot] = relu_bias16(acc, load_bias_frag(pk + OFF_B0 + ot * 1024, lane));
   }
-  // Linear(128 -> 128) + ReLU, twice
+  // Linear(128 -> 128) + ReLU, twice (stream steps 0..63 and 64..127)
+  {
+    f32x16 b0 = load_bias_frag(pk + OFF_B2 + 0 * 1024, lane);
+    f32x16 b1 = load_bias_frag(pk + OFF_B2 + 1 * 1024, lane);
+    h2[0] = relu_bias16(dense_tile<0>(wstream, ring, h1), b0);
+    b0 = load_bias_frag(pk + OFF_B2 + 2 * 1024, lane);
+    h2[1] = relu_bias16(dense_tile<16>(wstream, ring, h1), b1);
+    b1 = load_bias_frag(pk + OFF_B2 + 3 * 1024, lane);
+    h2[2] = relu_bias16(dense_tile<32>(wstream, ring, h1), b0);
+    b0 = load_bias_frag(pk + OFF_B4 + 0 * 1024, lane);
+    h2[3] = relu_bias16(dense_tile<48>(wstream, ring, h1), b1);
+    b1 = load_bias_frag(pk + OFF_B4 + 1 * 1024, lane);
+    h1[0] = relu_bias16(dense_tile<64>(wstream, ring, h2), b0);
+    b0 = load_bias_frag(pk + OFF_B4 + 2 * 1024, lane);
+    h1[1] = relu_bias16(dense_tile<80>(wstream, ring, h2), b1);
+    b1 = load_bias_frag(pk + OFF_B4 + 3 * 1024, lane);
+    h1[2] = relu_bias16(dense_tile<96>(wstream, ring, h2), b0);
+    b0 = load_bias_frag(pk + OFF_B6, lane);
+    h1[3] = relu_bias16(dense_tile<112>(wstream, ring, h2), b1);
+    // Linear(128 -> S), no activation (stream steps 128..143)
+    f32x16 acc = dense_tile<128>(wstream, ring, h1);
+    if (valid) {
+      const int b = row / K, k = row - b * K;
+      float* Gb = G + (((int64_t)l * B + b) * S) * K + k;
 #pragma unroll
-  for (int ot = 0; ot < HT; ++ot) {
-    f32x16 acc = load_bias_frag(pk + OFF_B2 + ot * 1024, lane);
-    acc = dense128(reinterpret_cast<const float4*>(pk + OFF_W2) + ot * 16 * 64, h1, acc, lane);
-    h2[ot] = relu16(acc);
-  }
-#pragma unroll
-  for (int ot = 0; ot < HT; ++ot) {
-    f32x16 acc = load_bias_frag(pk + OFF_B4 + ot * 1024, lane);
-    acc = dense128(reinterpret_cast<const float4*>(pk + OFF_W4) + ot * 16 * 64, h2, acc, lane);
-    h1[ot] = relu16(acc);
-  }
-  // Linear(128 -> S), no activation
-  f32x16 acc = load_bias_frag(pk + OFF_B6, lane);
-  acc = dense128(reinterpret_cast<const float4*>(pk + OFF_W6), h1, acc, lane);
-
-  if (valid) {
-    const int b = row / K, k = row - b * K;
-    float* Gb = G + (((int64_t)l * B + b) * S) * K + k;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int s = lnz::cd_row(r, hh);
-      if (s < S) Gb[(int64_t)s * K] = acc[r];
+      for (int r = 0; r < 16; ++r) {
+        int sidx = lnz::cd_row(r, hh);
+        if (sidx < S) Gb[(int64_t)sidx * K] = acc[r] + b0[r];
+      }
     }
   }
 }
