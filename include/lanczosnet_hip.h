@@ -114,10 +114,13 @@ typedef struct lnz_forward_args {
   const float* node_feat_f;   /* [B,N,din0] float features (General path) or NULL           */
   const float* embedding;     /* [num_atom, din0]                                            */
   int32_t num_atom;
+  int32_t filter_kind;        /* 0 = LanczosNet diagonal gains, 1 = AdaLanczosNet dense filters    */
   const uint8_t* mask;        /* [B,N] 1 = real node                                         */
   const float* Lp;            /* lnz_pack_laplacian output, C = n_edge                       */
   const float* V;             /* [B,N,K]                                                     */
-  const float* G;             /* [num_layer,B,n_long,K] from lnz_spectral_gains              */
+  const float* G;             /* filter_kind 0: [num_layer,B,n_long,K] from lnz_spectral_gains (V = Ritz
+                                 vectors); filter_kind 1: dense [num_layer,B,n_long,K,K] from
+                                 lnz_ada_symmetrize_filters (V = Lanczos basis Q): M = Q DD Q^T     */
   const float* Wp;            /* packed conv weights: layer l at Wp + w_off[l]               */
   const float* bias;          /* conv biases: layer l at bias + b_off[l], dhid floats        */
   int64_t w_off[16];
@@ -131,6 +134,33 @@ int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);
+
+/* ---- R4, R5, R8: AdaLanczosNet stages --------------------------------------------------------
+ * lnz_ada_graph_laplacian: Gaussian-kernel learned Laplacian of model/ada_lanczos_net.py:101-137
+ *   (dist2 over node embeddings, sigma2 = mean over all N^2 pairs, exp(-d2/sigma2) * adj,
+ *   D^-1/2 A D^-1/2 with the zero-row guard); adj = (L0 != 0) as :310-311.  Node features are either
+ *   embedding rows gathered by id (node_feat + embedding[num_atom, D]) or float rows node_feat_f
+ *   [B,N,D].  L0 addressed by element strides (pass L[...,0] of the channels-last Laplacian).
+ *   Le [B,N,N].
+ * lnz_ada_lanczos_layer: the in-model Lanczos layer of :139-247, reference exact: fp32,
+ *   T_it = min(N,K) steps, sequential Gram-Schmidt applied twice, breakdown mask beta < 1e-4, and
+ *   the three quirks of SURVEY.md F6 (alpha of the breakdown step zeroed; its Q column dropped;
+ *   NODE rows >= idx_mask zeroed).  q1 [B,N] is the raw start vector (the reference draws
+ *   torch.randn(B,N,1) on the CPU generator, :161).  mask [B,N] uint8 or NULL.  T [B,K,K], Q [B,N,K].
+ * lnz_ada_t_powers: T^p for the S exponents in dist_host by sequential TT = TT*T (:262-270),
+ *   written as torch.cat(T_list, dim=2): Tcat [B, K, S*K] (= the [B, K*K*S] MLP input).
+ * lnz_ada_symmetrize_filters: DD [B,K,K,S] (MLP output view, :274-275) ->
+ *   DDp [B,S,K,K] = (DD + DD^T)/2 (:278), the dense-filter operand of lnz_lanczosnet_forward. */
+int lnz_ada_graph_laplacian(const int64_t* node_feat, const float* embedding, int num_atom,
+                            const float* node_feat_f, int D, const float* L0, int64_t stride_b,
+                            int64_t stride_r, int64_t stride_c, int B, int N, float* Le,
+                            lnz_stream_t stream);
+int lnz_ada_lanczos_layer(const float* A, const uint8_t* mask, const float* q1, int B, int N,
+                          int K, float* T, float* Q, lnz_stream_t stream);
+int lnz_ada_t_powers(const float* T, int B, int K, const int32_t* dist_host, int S, float* Tcat,
+                     lnz_stream_t stream);
+int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, float* DDp,
+                               lnz_stream_t stream);
 
 /* ---- R12: unsorted_segment_sum -----------------------------------------------------------
  * out[b, ids[b,c], x] += data[b,c,x]  /  grad_data[b,c,x] = grad_out[b, ids[b,c], x].

@@ -34,7 +34,7 @@ class ForwardArgs(C.Structure):
       ('n_short', C.c_int32), ('n_long', C.c_int32), ('n_edge', C.c_int32),
       ('short_dist', C.c_int32 * 8),
       ('node_feat', C.c_void_p), ('node_feat_f', C.c_void_p), ('embedding', C.c_void_p),
-      ('num_atom', C.c_int32),
+      ('num_atom', C.c_int32), ('filter_kind', C.c_int32),
       ('mask', C.c_void_p), ('Lp', C.c_void_p), ('V', C.c_void_p), ('G', C.c_void_p),
       ('Wp', C.c_void_p), ('bias', C.c_void_p),
       ('w_off', C.c_int64 * 16), ('b_off', C.c_int64 * 16),
@@ -59,6 +59,10 @@ SIGNATURES = {
     'lnz_spectral_gains': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P]),
     'lnz_lanczosnet_forward': (C.c_int, [C.POINTER(ForwardArgs), _P]),
     'lnz_forward_args_size': (C.c_int64, []),
+    'lnz_ada_graph_laplacian': (C.c_int, [_P, _P, _I, _P, _I, _P, _L, _L, _L, _I, _I, _P, _P]),
+    'lnz_ada_lanczos_layer': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    'lnz_ada_t_powers': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _P, _P]),
+    'lnz_ada_symmetrize_filters': (C.c_int, [_P, _I, _I, _I, _P, _P]),
     'lnz_unsorted_segment_sum_forward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'lnz_unsorted_segment_sum_backward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
 }

@@ -1,0 +1,335 @@
+// AdaLanczosNet stages:
+//   lnz_ada_graph_laplacian   model/ada_lanczos_net.py:101-137  Gaussian-kernel learned Laplacian
+//   lnz_ada_lanczos_layer     model/ada_lanczos_net.py:139-247  in-model Lanczos layer, reference
+//                             exact ("ada_ref"): fp32, sequential Gram-Schmidt twice, the 1e-4
+//                             breakdown mask and the three quirks of SURVEY.md F6 / §A.3
+//   lnz_ada_t_powers          model/ada_lanczos_net.py:262-270  T^p by sequential TT = TT T
+//   lnz_ada_symmetrize_filters :276-278 (DD + DD^T)/2, relaid out [B,K,K,S] -> [B,S,K,K]
+#include "common.hpp"
+
+namespace {
+
+constexpr float kEpsF = 1.1920928955078125e-07f;  // np.finfo(np.float32).eps (ada_lanczos_net.py:8)
+
+// ---------------------------------------------------------------------------------------------
+// wave-wide sum, identical in every lane, fixed tree (deterministic): 4 DPP steps inside each
+// 16-lane row, then the 4 row totals via v_readlane.
+// ---------------------------------------------------------------------------------------------
+__device__ inline float dpp_add(float v, int ctrl_sel) {
+  int x = __float_as_int(v), y;
+  switch (ctrl_sel) {
+    case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+    case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false); break;   // quad_perm [2,3,0,1]
+    case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); break; // row_mirror
+  }
+  return v + __int_as_float(y);
+}
+
+__device__ inline float wave_sum(float v) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  v = dpp_add(v, 3);
+  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// R4: learned graph Laplacian.  One workgroup per molecule.
+//   dist2[i][j] = |x_j - x_i|^2 ; sigma2 = mean over ALL N^2 pairs (padded nodes included, as
+//   the reference) ; A = exp(-dist2 / sigma2) * adj ; D = (rowsum + [rowsum == 0])^-1/2 ; L = D A D
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ada_graph_laplacian_kernel(
+    const int64_t* __restrict__ node_feat, const float* __restrict__ embedding, int num_atom,
+    const float* __restrict__ Xf, int Dm, const float* __restrict__ L0, int64_t sb, int64_t sr,
+    int64_t sc, int N, float* __restrict__ Le) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X = smem;                  // [N][Dm]
+  float* d2 = X + N * Dm;           // [N][N]  -> later A
+  float* red = d2 + N * N;          // [256] partial sums / row scale
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int idx = tid; idx < N * Dm; idx += 256) {
+    int i = idx / Dm, f = idx - i * Dm;
+    float v;
+    if (node_feat) {
+      int64_t id = node_feat[(int64_t)b * N + i];
+      id = id < 0 ? 0 : (id >= num_atom ? num_atom - 1 : id);
+      v = embedding[id * Dm + f];
+    } else {
+      v = Xf[((int64_t)b * N + i) * Dm + f];
+    }
+    X[idx] = v;
+  }
+  __syncthreads();
+  double part = 0.0;
+  for (int p = tid; p < N * N; p += 256) {
+    int i = p / N, jn = p - i * N;
+    float s = 0.0f;
+    for (int f = 0; f < Dm; ++f) {
+      float df = X[jn * Dm + f] - X[i * Dm + f];
+      s = fmaf(df, df, s);
+    }
+    d2[p] = s;
+    part += (double)s;
+  }
+  // block reduction of the mean (fp64 accumulate, rounded once)
+  __shared__ double dred[256];
+  dred[tid] = part;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) dred[tid] += dred[tid + st];
+    __syncthreads();
+  }
+  const float sigma2 = (float)(dred[0] / (double)(N * N));
+  const float* Lb = L0 + (int64_t)b * sb;
+  for (int p = tid; p < N * N; p += 256) {
+    int i = p / N, jn = p - i * N;
+    float adj = Lb[i * sr + jn * sc] != 0.0f ? 1.0f : 0.0f;  // :310-311
+    d2[p] = expf(-d2[p] / sigma2) * adj;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    double rs = 0.0;
+    for (int jn = 0; jn < N; ++jn) rs += (double)d2[i * N + jn];
+    float rowsum = (float)rs;
+    float pad = rowsum == 0.0f ? 1.0f : 0.0f;
+    red[i] = 1.0f / sqrtf(rowsum + pad);  // 1 / (row_sum + pad).pow(0.5)
+  }
+  __syncthreads();
+  float* out = Le + (int64_t)b * N * N;
+  for (int p = tid; p < N * N; p += 256) {
+    int i = p / N, jn = p - i * N;
+    out[p] = (red[i] * d2[p]) * red[jn];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R5: reference-exact Lanczos layer.  One wavefront per molecule, lane = node row (N <= 64),
+// fp32.  A tile and the basis live in LDS; alpha / beta / MGS coefficients are wave reductions.
+// ---------------------------------------------------------------------------------------------
+template <int NMAX, int KMAX>
+__global__ __launch_bounds__(64) void ada_lanczos_layer_kernel(
+    const float* __restrict__ A, const uint8_t* __restrict__ mask, const float* __restrict__ q1,
+    int N, int K, float* __restrict__ T, float* __restrict__ Q) {
+  __shared__ float As[NMAX * (NMAX + 1)];
+  __shared__ float Qs[(KMAX + 2) * NMAX];  // Q[0] = 0, Q[1..Tit+1]
+  __shared__ float zb[NMAX];
+  __shared__ float alpha_s[KMAX + 1], beta_s[KMAX + 1], valid_s[KMAX + 1], qq_s[KMAX + 2];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int Tit = N < K ? N : K;
+  const float* Ab = A + (int64_t)b * N * N;
+  for (int idx = lane; idx < N * N; idx += 64) {
+    int r = idx / N, c = idx - r * N;
+    As[r * (NMAX + 1) + c] = Ab[idx];
+  }
+  const bool row = lane < N;
+  const float mk = (row && (mask == nullptr || mask[(int64_t)b * N + lane] != 0)) ? 1.0f : 0.0f;
+  float q = row ? q1[(int64_t)b * N + lane] * mk : 0.0f;  // :161-165
+  {
+    float nrm = sqrtf(wave_sum(q * q));
+    q = q / nrm;  // :167 (no EPS: an all-masked molecule is NaN in the reference too)
+  }
+  if (lane < NMAX) {
+    Qs[0 * NMAX + lane] = 0.0f;
+    Qs[1 * NMAX + lane] = q;
+  }
+  float q_prev = 0.0f, beta_prev = 0.0f, valid_prev = 1.0f;
+  const float nmask = wave_sum(mk);
+  __syncthreads();
+  for (int ii = 1; ii <= Tit; ++ii) {
+    if (lane < NMAX) zb[lane] = q;
+    __syncthreads();
+    float z = 0.0f;
+    if (row) {
+      const float* ar = &As[lane * (NMAX + 1)];
+      for (int c = 0; c < N; ++c) z = fmaf(ar[c], zb[c], z);  // :173
+    }
+    const float alpha = wave_sum(q * z);               // :174
+    z = z - alpha * q - beta_prev * q_prev;            // :175
+    if (ii > 1) {                                      // :177-189, use_reorthogonalization (F7)
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int jj = 1; jj < ii; ++jj) {
+          const float qj = lane < NMAX ? Qs[jj * NMAX + lane] : 0.0f;
+          const float num = wave_sum(z * qj);
+          z = z - num / (qq_s[jj] + kEpsF) * qj;
+        }
+      }
+    }
+    const float beta = sqrtf(wave_sum(z * z));         // :191
+    const float ok = beta >= 1.0e-4f ? 1.0f : 0.0f;    // :195
+    const float valid = (ii == 1) ? ok : valid_prev * ok;  // :196-199
+    const float qn = (z * valid) / (beta + kEpsF);     // :202
+    if (lane == 0) {
+      alpha_s[ii] = alpha;
+      beta_s[ii] = beta;
+      valid_s[ii] = valid;
+    }
+    const float qq_cur = wave_sum(q * q);              // <Q[ii], Q[ii]> for later projections
+    if (lane == 0) qq_s[ii] = qq_cur;
+    if (lane < NMAX) Qs[(ii + 1) * NMAX + lane] = qn;
+    q_prev = q;
+    q = qn;
+    beta_prev = beta;
+    valid_prev = valid;
+    __syncthreads();
+  }
+  // idx_mask = min(sum(valid), sum(mask))  (:209-211); valid[idx_mask:] = 0 (:213-215)
+  float vsum = 0.0f;
+  for (int ii = 1; ii <= Tit; ++ii) vsum += valid_s[ii];
+  int idx_mask = (int)vsum;
+  if (mask != nullptr) {
+    int nm = (int)nmask;
+    idx_mask = idx_mask < nm ? idx_mask : nm;
+  }
+  // T [K,K] (zero padded) = diag(alpha*valid) + offdiag(beta*valid[:-1])   (:218-226, quirk 1)
+  float* Tb = T + (int64_t)b * K * K;
+  for (int idx = lane; idx < K * K; idx += 64) {
+    int i = idx / K, jn = idx - i * K;
+    float v = 0.0f;
+    if (i < Tit && jn < Tit) {
+      auto vm = [&](int t0) { return (t0 < idx_mask) ? valid_s[t0 + 1] : 0.0f; };  // 0-based step
+      if (i == jn) v = alpha_s[i + 1] * vm(i);
+      else if (jn == i + 1 && i < Tit - 1) v = beta_s[i + 1] * vm(i);
+      else if (i == jn + 1 && jn < Tit - 1) v = beta_s[jn + 1] * vm(jn);
+    }
+    Tb[idx] = v;
+  }
+  // Q [N,K] = [q_1..q_Tit] * valid (per column, quirk 2); rows >= idx_mask zeroed (quirk 3)
+  float* Qb = Q + (int64_t)b * N * K;
+  for (int idx = lane; idx < N * K; idx += 64) {
+    int r = idx / K, k = idx - r * K;
+    float v = 0.0f;
+    if (k < Tit) {
+      float vmk = (k < idx_mask) ? valid_s[k + 1] : 0.0f;
+      float rowkeep = (idx_mask < N && r >= idx_mask) ? 0.0f : 1.0f;
+      v = Qs[(k + 1) * NMAX + r] * (vmk * rowkeep);  // Q * Q_mask (:237)
+    }
+    Qb[idx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R8 glue: T^p (sequential TT = TT T, fp32) -> Tcat [B, K, S*K] as torch.cat(T_list, dim=2)
+// ---------------------------------------------------------------------------------------------
+struct PowArr {
+  int32_t v[16];
+};
+
+__global__ __launch_bounds__(256) void ada_t_powers_kernel(const float* __restrict__ T, int K,
+                                                            PowArr dist, int S, int pmax,
+                                                            float* __restrict__ Tcat) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ts = smem;            // [K][K]
+  float* TT = Ts + K * K;      // current power
+  float* TN = TT + K * K;      // next
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < K * K; i += 256) {
+    float v = T[(int64_t)b * K * K + i];
+    Ts[i] = v;
+    TT[i] = v;
+  }
+  __syncthreads();
+  float* out = Tcat + (int64_t)b * K * S * K;
+  for (int ii = 1; ii <= pmax; ++ii) {
+    for (int s = 0; s < S; ++s) {
+      if (dist.v[s] == ii) {
+        for (int i = tid; i < K * K; i += 256) {
+          int r = i / K, c = i - r * K;
+          out[(int64_t)r * S * K + s * K + c] = TT[i];
+        }
+      }
+    }
+    if (ii == pmax) break;
+    for (int i = tid; i < K * K; i += 256) {
+      int r = i / K, c = i - r * K;
+      float acc = 0.0f;
+      for (int k = 0; k < K; ++k) acc = fmaf(TT[r * K + k], Ts[k * K + c], acc);
+      TN[i] = acc;
+    }
+    __syncthreads();
+    float* t = TT;
+    TT = TN;
+    TN = t;
+  }
+}
+
+// DDp[b][s][k1][k2] = 0.5 * (DD[b][k1][k2][s] + DD[b][k2][k1][s])
+__global__ void ada_symmetrize_kernel(const float* __restrict__ DD, int64_t total, int K, int S,
+                                      float* __restrict__ DDp) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int k2 = (int)(idx % K);
+  int k1 = (int)((idx / K) % K);
+  int s = (int)((idx / ((int64_t)K * K)) % S);
+  int64_t b = idx / ((int64_t)K * K * S);
+  const float* base = DD + b * K * K * S;
+  float x = base[((int64_t)k1 * K + k2) * S + s];
+  float y = base[((int64_t)k2 * K + k1) * S + s];
+  DDp[idx] = (x + y) * 0.5f;
+}
+
+}  // namespace
+
+extern "C" int lnz_ada_graph_laplacian(const int64_t* node_feat, const float* embedding,
+                                       int num_atom, const float* node_feat_f, int D,
+                                       const float* L0, int64_t stride_b, int64_t stride_r,
+                                       int64_t stride_c, int B, int N, float* Le,
+                                       lnz_stream_t stream) {
+  LNZ_REQUIRE(((node_feat && embedding && num_atom > 0) || node_feat_f) && L0 && Le && B > 0 &&
+                  N > 0 && D > 0,
+              LNZ_EINVAL, "lnz_ada_graph_laplacian: bad arguments (B=%d N=%d D=%d)", B, N, D);
+  size_t lds = ((size_t)N * D + (size_t)N * N + 256) * sizeof(float);
+  LNZ_REQUIRE(lds <= 60 * 1024, LNZ_ENOTSUP, "lnz_ada_graph_laplacian: N*D + N*N too large");
+  hipLaunchKernelGGL(ada_graph_laplacian_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream,
+                     node_feat, embedding, num_atom, node_feat_f, D, L0, stride_b, stride_r,
+                     stride_c, N, Le);
+  return lnz::check_launch("lnz_ada_graph_laplacian");
+}
+
+extern "C" int lnz_ada_lanczos_layer(const float* A, const uint8_t* mask, const float* q1, int B,
+                                     int N, int K, float* T, float* Q, lnz_stream_t stream) {
+  LNZ_REQUIRE(A && q1 && T && Q && B > 0 && N > 0 && K > 0, LNZ_EINVAL,
+              "lnz_ada_lanczos_layer: bad arguments (B=%d N=%d K=%d)", B, N, K);
+  LNZ_REQUIRE(N <= 64 && K <= 64, LNZ_ENOTSUP, "lnz_ada_lanczos_layer: N=%d, K=%d exceed 64", N, K);
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 32 && K <= 32) {
+    hipLaunchKernelGGL((ada_lanczos_layer_kernel<32, 32>), dim3(B), dim3(64), 0, s, A, mask, q1, N,
+                       K, T, Q);
+  } else {
+    hipLaunchKernelGGL((ada_lanczos_layer_kernel<64, 64>), dim3(B), dim3(64), 0, s, A, mask, q1, N,
+                       K, T, Q);
+  }
+  return lnz::check_launch("lnz_ada_lanczos_layer");
+}
+
+extern "C" int lnz_ada_t_powers(const float* T, int B, int K, const int32_t* dist_host, int S,
+                                float* Tcat, lnz_stream_t stream) {
+  LNZ_REQUIRE(T && dist_host && Tcat && B > 0 && K > 0 && S > 0, LNZ_EINVAL,
+              "lnz_ada_t_powers: bad arguments");
+  LNZ_REQUIRE(S <= 16 && K <= 64, LNZ_ENOTSUP, "lnz_ada_t_powers: S=%d K=%d out of range", S, K);
+  PowArr d;
+  int pmax = 0;
+  for (int i = 0; i < 16; ++i) {
+    d.v[i] = i < S ? dist_host[i] : -1;
+    if (i < S && dist_host[i] > pmax) pmax = dist_host[i];
+  }
+  LNZ_REQUIRE(pmax >= 1 && pmax <= 4096, LNZ_EINVAL, "lnz_ada_t_powers: bad exponents");
+  size_t lds = (size_t)3 * K * K * sizeof(float);
+  hipLaunchKernelGGL(ada_t_powers_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, K, d, S,
+                     pmax, Tcat);
+  return lnz::check_launch("lnz_ada_t_powers");
+}
+
+extern "C" int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, float* DDp,
+                                          lnz_stream_t stream) {
+  LNZ_REQUIRE(DD && DDp && B > 0 && K > 0 && S > 0, LNZ_EINVAL,
+              "lnz_ada_symmetrize_filters: bad arguments");
+  int64_t total = (int64_t)B * S * K * K;
+  hipLaunchKernelGGL(ada_symmetrize_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, DD, total, K, S, DDp);
+  return lnz::check_launch("lnz_ada_symmetrize_filters");
+}

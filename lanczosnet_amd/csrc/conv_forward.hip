@@ -48,7 +48,9 @@ __device__ inline f32x16 frag_from4(const float4 (&v)[4]) {
 
 // NWV wavefronts per workgroup = dhid / 32: wave w owns output-feature tile w for BOTH molecules
 // of the workgroup, so every packed-weight fragment it loads feeds 2 x 4 MFMAs.
-template <int NWV, int KHT>
+// FK = filter kind: 0 = diagonal gains on Ritz vectors (LanczosNet), 1 = dense K x K filters on
+// the Lanczos basis (AdaLanczosNet: M = Q DD Q^T, model/ada_lanczos_net.py:280-281).
+template <int NWV, int KHT, int FK>
 __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_forward_args a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][MOLS][32][PITCH];
 
@@ -100,15 +102,18 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
     g2steps[m] = __builtin_amdgcn_readfirstlane(((last + 7) >> 3) * 4);
   }
 
-  // ---- Ritz-vector fragments: vreg[m][t] = V[mol m][j][KH*hh + t]
+  // ---- basis fragments.  FK = 0: vreg[m][t] = V[mol m][j][KH*hh + t] (Ritz vectors, two k-halves)
+  //      FK = 1: vreg[m][r] = Q[mol m][j][cd_row(r,hh)] — the k-order that lets the same registers
+  //      serve as B operand of R = DD Q^T and as A operand of L_s = Q R.
   const int KH = (K + 1) >> 1;
   float vreg[MOLS][KHT];
 #pragma unroll
   for (int m = 0; m < MOLS; ++m) {
 #pragma unroll
     for (int t = 0; t < KHT; ++t) {
-      int k = KH * hh + t;
-      vreg[m][t] = (t < KH && k < K && j < N) ? a.V[((int64_t)mb[m] * N + j) * K + k] : 0.0f;
+      int k = FK ? lnz::cd_row(t, hh) : KH * hh + t;
+      bool ok = FK ? (k < K) : (t < KH && k < K);
+      vreg[m][t] = (ok && j < N) ? a.V[((int64_t)mb[m] * N + j) * K + k] : 0.0f;
     }
   }
   __syncthreads();
@@ -156,11 +161,21 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
     auto fetch_m_operands = [&](int c, int m) {
       const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
       if (lng) {
-        const float* gp = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K;
+        if (FK == 0) {
+          const float* gp = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K;
 #pragma unroll
-        for (int t = 0; t < KHT; ++t) {
-          int k = KH * hh + t;
-          mop[m][t] = (t < KH && k < K) ? gp[k] : 0.0f;
+          for (int t = 0; t < KHT; ++t) {
+            int k = KH * hh + t;
+            mop[m][t] = (t < KH && k < K) ? gp[k] : 0.0f;
+          }
+        } else {
+          // row j of the symmetric K x K filter DD_s, columns in cd_row order
+          const float* dp = a.G + ((((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K + j) * K;
+#pragma unroll
+          for (int t = 0; t < KHT; ++t) {
+            int k2 = lnz::cd_row(t, hh);
+            mop[m][t] = (j < K && k2 < K) ? dp[k2] : 0.0f;
+          }
         }
       } else {
         const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
@@ -232,9 +247,18 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
         f32x16 Mf;
         if (is_long) {
           f32x16 acc = lnz::splat16(0.0f);
+          if (FK == 0) {
 #pragma unroll
-          for (int t = 0; t < KHT; ++t) {
-            if (t < KH) acc = lnz::mfma32(vreg[m][t] * mop[m][t], vreg[m][t], acc);
+            for (int t = 0; t < KHT; ++t) {
+              if (t < KH) acc = lnz::mfma32(vreg[m][t] * mop[m][t], vreg[m][t], acc);
+            }
+          } else {
+            // R[k1][n] = sum_k2 DD[k1][k2] Q[n][k2]  then  L_s[i][n] = sum_k1 Q[i][k1] R[k1][n]
+            f32x16 R = lnz::splat16(0.0f);
+#pragma unroll
+            for (int t = 0; t < KHT; ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
+#pragma unroll
+            for (int t = 0; t < KHT; ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
           }
           Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]  (symmetric)
         } else {
@@ -369,16 +393,25 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
               LNZ_EINVAL, "lnz_lanczosnet_forward: null tensor pointer");
   LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "lnz_lanczosnet_forward: G missing");
   hipStream_t s = (hipStream_t)stream;
-  const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
   const int grid = (a.B + MOLS - 1) / MOLS;
-  if (a.dhid == 128 && k20) {
-    hipLaunchKernelGGL((lanczosnet_forward_kernel<4, 10>), dim3(grid), dim3(256), 0, s, a);
-  } else if (a.dhid == 128) {
-    hipLaunchKernelGGL((lanczosnet_forward_kernel<4, KHMAX>), dim3(grid), dim3(256), 0, s, a);
-  } else if (k20) {
-    hipLaunchKernelGGL((lanczosnet_forward_kernel<2, 10>), dim3(grid), dim3(128), 0, s, a);
+  LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL,
+              "lnz_lanczosnet_forward: filter_kind %d", a.filter_kind);
+#define LNZ_LAUNCH(NWV_, KHT_, FK_)                                                             \
+  hipLaunchKernelGGL((lanczosnet_forward_kernel<NWV_, KHT_, FK_>), dim3(grid), dim3(64 * NWV_), \
+                     0, s, a)
+  if (a.filter_kind == 0) {
+    const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
+    if (a.dhid == 128 && k20) LNZ_LAUNCH(4, 10, 0);
+    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 0);
+    else if (k20) LNZ_LAUNCH(2, 10, 0);
+    else LNZ_LAUNCH(2, KHMAX, 0);
   } else {
-    hipLaunchKernelGGL((lanczosnet_forward_kernel<2, KHMAX>), dim3(grid), dim3(128), 0, s, a);
+    const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
+    if (a.dhid == 128 && k24) LNZ_LAUNCH(4, 12, 1);
+    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 1);
+    else if (k24) LNZ_LAUNCH(2, 12, 1);
+    else LNZ_LAUNCH(2, KHMAX, 1);
   }
+#undef LNZ_LAUNCH
   return lnz::check_launch("lnz_lanczosnet_forward");
 }

@@ -1,3 +1,3 @@
-from .lanczos_net import LanczosNet, LanczosNetGeneral  # noqa: F401
+from .lanczos_net import LanczosNet, LanczosNetGeneral, AdaLanczosNet  # noqa: F401
 
-__all__ = ['LanczosNet', 'LanczosNetGeneral']
+__all__ = ['LanczosNet', 'LanczosNetGeneral', 'AdaLanczosNet']

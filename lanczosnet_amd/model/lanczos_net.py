@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import ops
 from ..utils.data_helper import check_dist
 
-__all__ = ['LanczosNet', 'LanczosNetGeneral']
+__all__ = ['LanczosNet', 'LanczosNetGeneral', 'AdaLanczosNet']
 
 _SPECTRAL_HIDDEN = 128  # model/lanczos_net.py:50-56
 
@@ -29,6 +29,11 @@ def _opt(node, key, default):
 
 class _LanczosNetBase(nn.Module):
     general = False
+    filter_kind = 0                      # 0: diagonal gains on Ritz vectors, 1: dense (Ada)
+    _spectral_hidden = _SPECTRAL_HIDDEN
+
+    def _spectral_io(self):
+        return self.num_scale_long
 
     def __init__(self, config):
         super().__init__()
@@ -49,6 +54,7 @@ class _LanczosNetBase(nn.Module):
         self.num_eig_vec = m.num_eig_vec
         self.spectral_filter_kind = m.spectral_filter_kind
 
+        self._override_dims()
         widths = [self.input_dim] + self.hidden_dim + [self.output_dim]
         n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
         # creation order == reference (RNG parity): conv mixes, head, [embedding], spectral MLPs, gate
@@ -56,10 +62,10 @@ class _LanczosNetBase(nn.Module):
         self.filter = nn.ModuleList(mixes + [nn.Linear(widths[-2], widths[-1])])
         self._make_input_layer()
         if self._has_mlp():
-            S, H = self.num_scale_long, _SPECTRAL_HIDDEN
+            fin, H = self._spectral_io(), self._spectral_hidden
             self.spectral_filter = nn.ModuleList([
-                nn.Sequential(nn.Linear(S, H), nn.ReLU(), nn.Linear(H, H), nn.ReLU(),
-                              nn.Linear(H, H), nn.ReLU(), nn.Linear(H, S))
+                nn.Sequential(nn.Linear(fin, H), nn.ReLU(), nn.Linear(H, H), nn.ReLU(),
+                              nn.Linear(H, H), nn.ReLU(), nn.Linear(H, fin))
                 for _ in range(self.num_layer)])
         self.att_func = nn.Sequential(nn.Linear(widths[-2], 1), nn.Sigmoid())
 
@@ -71,6 +77,23 @@ class _LanczosNetBase(nn.Module):
         self._plan_cache = None
 
     # -- configuration hooks ------------------------------------------------------------
+    def _override_dims(self):
+        pass
+
+    def _guard_forward(self, L, mask):
+        if mask is None:
+            raise ValueError('forward needs `mask` (model/lanczos_net.py:192)')
+        if not L.is_cuda:
+            raise RuntimeError('lanczosnet_amd models run on the AMD GPU only: move the '
+                               'module and its inputs to cuda (no CPU fallback)')
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError('dropout > 0 in training mode is not built in the HIP path')
+        if torch.is_grad_enabled() and self.training and any(
+                p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                'lanczosnet_amd: backward kernels are not built yet (forward-only); call under '
+                'torch.no_grad() or model.eval()')
+
     def _read_dataset(self, ds):
         self.num_atom = ds.num_atom
         self.num_edgetype = ds.num_bond_type
@@ -146,7 +169,7 @@ class _LanczosNetBase(nn.Module):
             emb = torch.nn.functional.pad(self.embedding.weight.detach().float(),
                                           (0, din0p - din0)).contiguous()
         plan = dict(sig=sig, num_layer=self.num_layer, din0=din0p, din0_raw=din0, dhid=dhid,
-                    dout=P,
+                    dout=P, filter_kind=self.filter_kind,
                     short=list(self.short_diffusion_dist), n_long=self.num_scale_long,
                     n_edge=self.num_edgetype + 1,
                     # + slack: the kernel's weight prefetch ring over-reads 3 steps (3 KiB)
@@ -155,7 +178,7 @@ class _LanczosNetBase(nn.Module):
                     w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
                     bias_head=bias_head,
                     embedding=emb)
-        if self._has_mlp():
+        if self._has_mlp() and self.filter_kind == 0:
             size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
             buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)
             for t, seq in enumerate(self.spectral_filter):
@@ -172,18 +195,7 @@ class _LanczosNetBase(nn.Module):
         """Shapes as the reference docstring (model/lanczos_net.py:125-141): node_feat B x N
         (long) [General: B x N x D float], L B x N x N x (E+1), D B x K, V B x N x K,
         label B x P, mask B x N.  Returns score, or (score, loss) when `label` is given."""
-        if mask is None:
-            raise ValueError('LanczosNet.forward needs `mask` (model/lanczos_net.py:192)')
-        if not L.is_cuda:
-            raise RuntimeError('lanczosnet_amd.LanczosNet runs on the AMD GPU only: move the '
-                               'module and its inputs to cuda (no CPU fallback)')
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError('dropout > 0 in training mode is not built in the HIP path')
-        if torch.is_grad_enabled() and self.training and any(
-                p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                'lanczosnet_amd: backward kernels are not built yet (forward-only); call under '
-                'torch.no_grad() or model.eval()')
+        self._guard_forward(L, mask)
         with torch.no_grad():
             plan = self._plan()
             Lp = ops.pack_laplacian(L if L.dtype == torch.float32 else L.float())
@@ -213,3 +225,57 @@ class LanczosNetGeneral(_LanczosNetBase):
     def _make_input_layer(self):
         assert self.input_dim == self.node_emb_dim
         assert self.output_dim == self.graph_emb_dim
+
+
+class AdaLanczosNet(_LanczosNetBase):
+    """Drop-in for reference `model/ada_lanczos_net.py:12-368`: learned Gaussian-kernel Laplacian
+    (:101-137) -> in-model Lanczos layer (:139-247) -> `Q MLP(T^k) Q^T` filters (:250-286) -> the
+    same conv / readout.  `forward(node_feat, L, label=None, mask=None)`.
+
+    HIP: Laplacian, Lanczos layer (reference exact incl. the quirks of SURVEY.md F6), T powers,
+    filter symmetrisation and the fused conv kernel (dense-filter variant).  The 2000-4096-4096-
+    4096-2000 filter MLPs (50 M parameters per layer, M = batch) are plain dense GEMMs and go to
+    hipBLASLt through `torch.nn.functional.linear`.  Like the reference (F7) the re-orthogonalisation
+    flag is effectively always on: `hasattr(config, 'use_reorthogonalization')` probes the TOP-LEVEL
+    config (:35-38)."""
+    filter_kind = 1
+    _spectral_hidden = 4096
+
+    def _spectral_io(self):
+        return self.num_eig_vec * self.num_eig_vec * self.num_scale_long
+
+    def _override_dims(self):
+        cfg = self.config
+        self.use_reorthogonalization = cfg.model.use_reorthogonalization if hasattr(
+            cfg, 'use_reorthogonalization') else True
+        self.use_power_iteration_cap = cfg.model.use_power_iteration_cap if hasattr(
+            cfg, 'use_power_iteration_cap') else True
+        if not self.use_reorthogonalization:
+            raise NotImplementedError('HIP Lanczos layer is built with re-orthogonalisation on '
+                                      '(the reference never turns it off, SURVEY.md F7)')
+        self.input_dim = self.num_atom  # model/ada_lanczos_net.py:40
+
+    def forward(self, node_feat, L, label=None, mask=None):
+        if mask is None:
+            mask = torch.ones(node_feat.shape[:2], dtype=torch.uint8, device=L.device)
+        self._guard_forward(L, mask)
+        if self.num_scale_long == 0:
+            raise NotImplementedError('AdaLanczosNet without long-diffusion scales is not built')
+        B, N = node_feat.shape[0], node_feat.shape[1]
+        K, S = self.num_eig_vec, self.num_scale_long
+        with torch.no_grad():
+            plan = self._plan()
+            Lf = L if L.dtype == torch.float32 else L.float()
+            # same RNG consumption as the reference: CPU generator, shape (B, N, 1) (:161)
+            q1 = torch.randn(B, N, 1).to(L.device)
+            Le = ops.ada_graph_laplacian(node_feat, self.embedding.weight, Lf[:, :, :, 0])
+            T, Q = ops.ada_lanczos_layer(Le, mask, q1, K)
+            tcat = ops.ada_t_powers(T, self.long_diffusion_dist).view(B, -1)
+            DDp = torch.empty((self.num_layer, B, S, K, K), dtype=torch.float32, device=L.device)
+            for t, seq in enumerate(self.spectral_filter):
+                ops.ada_symmetrize_filters(seq(tcat), K, S, out=DDp[t])  # hipBLASLt GEMMs
+            Lp = ops.pack_laplacian(Lf)
+            score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask)
+        if label is not None:
+            return score, self.loss_func(score, label)
+        return score

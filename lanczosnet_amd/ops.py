@@ -171,6 +171,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
   mask_u8 = mask.to(torch.uint8).contiguous()
   Vc = _f32c(V)
   a.mask, a.Lp, a.V = mask_u8.data_ptr(), Lp.data_ptr(), Vc.data_ptr()
+  a.filter_kind = int(plan.get('filter_kind', 0))
+  if G is not None:
+    want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if a.filter_kind == 1 else ())
+    assert tuple(G.shape) == want and G.is_contiguous() and G.dtype == torch.float32, \
+        (tuple(G.shape), want)
   a.G = G.data_ptr() if G is not None else None
   a.Wp, a.bias = plan['Wp'].data_ptr(), plan['bias'].data_ptr()
   for i in range(plan['num_layer']):
@@ -187,6 +192,73 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
   with torch.cuda.device(V.device):
     _lib.check(lib.lnz_lanczosnet_forward(C.byref(a), _stream()))
   return (score, state) if return_state else score
+
+
+# ------------------------------------------------------------------------------ R4, R5, R8 (Ada)
+def ada_graph_laplacian(node_feat, embedding, L0):
+  """Learned Laplacian (model/ada_lanczos_net.py:101-137).  node_feat: [B,N] int64 ids (with
+  `embedding` [num_atom, D]) or [B,N,D] float features (embedding=None).  L0: [B,N,N] view of the
+  simple-graph Laplacian (adjacency mask = L0 != 0, :310-311).  Returns Le [B,N,N]."""
+  _need_cuda(node_feat, embedding, L0)
+  B, N = L0.shape[0], L0.shape[1]
+  assert L0.dtype == torch.float32
+  Le = torch.empty((B, N, N), dtype=torch.float32, device=L0.device)
+  sb, sr, sc = L0.stride()
+  lib = _lib.load()
+  if node_feat.dtype == torch.int64:
+    emb = _f32c(embedding)
+    nf = node_feat.contiguous()
+    args = (_ptr(nf), _ptr(emb), emb.shape[0], C.c_void_p(0), emb.shape[1])
+  else:
+    nf = _f32c(node_feat)
+    args = (C.c_void_p(0), C.c_void_p(0), 0, _ptr(nf), nf.shape[2])
+  with torch.cuda.device(L0.device):
+    _lib.check(lib.lnz_ada_graph_laplacian(*args, _ptr(L0), sb, sr, sc, B, N, _ptr(Le), _stream()))
+  return Le
+
+
+def ada_lanczos_layer(A, mask, q1, K):
+  """Reference-exact in-model Lanczos layer (model/ada_lanczos_net.py:139-247).
+  A [B,N,N], mask [B,N] (or None), q1 [B,N] raw start vector -> T [B,K,K], Q [B,N,K]."""
+  _need_cuda(A, mask, q1)
+  A = _f32c(A)
+  B, N, _ = A.shape
+  q1 = _f32c(q1.reshape(B, N))
+  m = mask.to(torch.uint8).contiguous() if mask is not None else None
+  T = torch.empty((B, K, K), dtype=torch.float32, device=A.device)
+  Q = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
+  lib = _lib.load()
+  with torch.cuda.device(A.device):
+    _lib.check(lib.lnz_ada_lanczos_layer(_ptr(A), _ptr(m), _ptr(q1), B, N, K, _ptr(T), _ptr(Q),
+                                         _stream()))
+  return T, Q
+
+
+def ada_t_powers(T, dist):
+  """T [B,K,K] -> Tcat [B, K, S*K] = cat([T^p for p in dist], dim=2) (:262-270)."""
+  _need_cuda(T)
+  T = _f32c(T)
+  B, K, _ = T.shape
+  S = len(dist)
+  out = torch.empty((B, K, S * K), dtype=torch.float32, device=T.device)
+  darr = (C.c_int32 * S)(*[int(x) for x in dist])
+  lib = _lib.load()
+  with torch.cuda.device(T.device):
+    _lib.check(lib.lnz_ada_t_powers(_ptr(T), B, K, darr, S, _ptr(out), _stream()))
+  return out
+
+
+def ada_symmetrize_filters(DD, K, S, out=None):
+  """DD [B, K*K*S] (MLP output) -> DDp [B,S,K,K] = (DD + DD^T)/2 (:274-278)."""
+  _need_cuda(DD)
+  DD = _f32c(DD)
+  B = DD.shape[0]
+  if out is None:
+    out = torch.empty((B, S, K, K), dtype=torch.float32, device=DD.device)
+  lib = _lib.load()
+  with torch.cuda.device(DD.device):
+    _lib.check(lib.lnz_ada_symmetrize_filters(_ptr(DD), B, K, S, _ptr(out), _stream()))
+  return out
 
 
 # ----------------------------------------------------------------------------------------- R12

@@ -93,3 +93,105 @@ def ada_graph_laplacian(node_feat, adj_mask, dtype=np.float32):
   pad = (row_sum == 0.0).astype(dtype)  # :131-132
   Dm = 1.0 / np.power(row_sum + pad, dtype(0.5))  # :133-134
   return Dm * A * Dm.transpose(0, 2, 1)  # :135
+
+
+# ---------------------------------------------------------------------------------------------
+# Full AdaLanczosNet forward (model/ada_lanczos_net.py:250-368)
+# ---------------------------------------------------------------------------------------------
+ADA_HIDDEN = 4096  # model/ada_lanczos_net.py:56-62
+
+
+def make_ada_params(cfg, seed, mlp_hidden=ADA_HIDDEN, bias_scale=0.05):
+  """Deterministic parameters keyed like the reference AdaLanczosNet state_dict.
+  input_dim is overridden to num_atom (model/ada_lanczos_net.py:40)."""
+  rs = np.random.RandomState(seed)
+  K, S = cfg['num_eig_vec'], len(cfg['long_diffusion_dist'])
+  din = cfg['num_atom']
+  dim_list = [din] + list(cfg['hidden_dim']) + [cfg['output_dim']]
+  n_chan = len(cfg['short_diffusion_dist']) + S + cfg['num_bond_type'] + 1
+  P = {}
+
+  def lin(name, fan_out, fan_in):
+    a = np.sqrt(6.0 / (fan_in + fan_out))
+    P[name + '.weight'] = rs.uniform(-a, a, size=(fan_out, fan_in)).astype(np.float32)
+    P[name + '.bias'] = (bias_scale * rs.uniform(-1, 1, size=(fan_out,))).astype(np.float32)
+
+  for tt in range(cfg['num_layer']):
+    lin('filter.%d' % tt, dim_list[tt + 1], dim_list[tt] * n_chan)
+  lin('filter.%d' % cfg['num_layer'], dim_list[-1], dim_list[-2])
+  P['embedding.weight'] = rs.randn(cfg['num_atom'], din).astype(np.float32)
+  for tt in range(cfg['num_layer']):
+    lin('spectral_filter.%d.0' % tt, mlp_hidden, K * K * S)
+    lin('spectral_filter.%d.2' % tt, mlp_hidden, mlp_hidden)
+    lin('spectral_filter.%d.4' % tt, mlp_hidden, mlp_hidden)
+    lin('spectral_filter.%d.6' % tt, K * K * S, mlp_hidden)
+  lin('att_func.0', 1, dim_list[-2])
+  return P
+
+
+def ada_t_powers(T, dists, dtype=np.float32):
+  """T_list of model/ada_lanczos_net.py:262-270: sequential TT = TT @ T, collected at the
+  requested powers; returned concatenated on dim 2 ([B, K, S*K]) like `torch.cat(T_list, dim=2)`."""
+  T = np.asarray(T, dtype=dtype)
+  out, TT = [], T
+  for ii in range(1, max(dists) + 1):
+    if ii in dists:
+      out.append(TT)
+    TT = TT @ T
+  return np.concatenate(out, axis=2)
+
+
+def ada_spectral_filter_dd(P, cfg, T, layer_idx, dtype=np.float32):
+  """Symmetrised DD [B,K,K,S] of model/ada_lanczos_net.py:273-278."""
+  dists = list(cfg['long_diffusion_dist'])
+  B, K = T.shape[0], T.shape[1]
+  S = len(dists)
+  h = ada_t_powers(T, dists, dtype).reshape(B, -1)
+  pre = 'spectral_filter.%d.' % layer_idx
+  for ii in (0, 2, 4):
+    h = np.maximum(h @ P[pre + '%d.weight' % ii].T.astype(dtype) + P[pre + '%d.bias' % ii], 0)
+  h = h @ P[pre + '6.weight'].T.astype(dtype) + P[pre + '6.bias']
+  DD = h.reshape(B, K, K, S)
+  return (DD + DD.transpose(0, 2, 1, 3)) * dtype(0.5)
+
+
+def ada_lanczos_net_forward(P, cfg, node_feat, L, mask, q1, dtype=np.float32, TQ=None):
+  """score [B,P] of AdaLanczosNet (eval mode).  q1: raw start vector [B,N] (the reference draws
+  torch.randn(B,N,1) at :161).  TQ: optional precomputed (T, Q) to decouple stage tests."""
+  P = {k: np.asarray(v, dtype=dtype) for k, v in P.items()}
+  L = np.asarray(L, dtype=dtype)
+  B, N = L.shape[0], L.shape[1]
+  short = list(cfg['short_diffusion_dist'])
+  S = len(cfg['long_diffusion_dist'])
+  E1 = cfg['num_bond_type'] + 1
+  state = P['embedding.weight'][np.asarray(node_feat)]  # :306
+  if TQ is None:
+    adj = (L[:, :, :, 0] != 0).astype(dtype)  # :310-311
+    Le = ada_graph_laplacian(state, adj, dtype)  # :312
+    T, Q = ada_lanczos_layer(Le, mask, q1, cfg['num_eig_vec'], True, dtype)  # :315 (F7: reorth on)
+  else:
+    T, Q = (np.asarray(x, dtype=dtype) for x in TQ)
+  for tt in range(cfg['num_layer']):
+    msg = []
+    DD = ada_spectral_filter_dd(P, cfg, T, tt, dtype)
+    if short:  # :328-333
+      tmp = state
+      for ii in range(1, max(short) + 1):
+        tmp = L[:, :, :, 0] @ tmp
+        if ii in short:
+          msg.append(tmp)
+    for s in range(S):  # :280-281 + :336-338
+      Ls = Q @ DD[:, :, :, s] @ Q.transpose(0, 2, 1)
+      msg.append(Ls @ state)
+    for e in range(E1):  # :341-342
+      msg.append(L[:, :, :, e] @ state)
+    msg = np.concatenate(msg, axis=2).reshape(B * N, -1)
+    state = np.maximum(msg @ P['filter.%d.weight' % tt].T + P['filter.%d.bias' % tt], 0)
+    state = state.reshape(B, N, -1)
+  flat = state.reshape(B * N, -1)
+  nl = cfg['num_layer']
+  y = flat @ P['filter.%d.weight' % nl].T + P['filter.%d.bias' % nl]
+  att = 1.0 / (1.0 + np.exp(-(flat @ P['att_func.0.weight'].T + P['att_func.0.bias'])))
+  y = (att * y).reshape(B, N, -1)
+  m = np.asarray(mask).astype(bool)
+  return np.stack([y[b, m[b], :].mean(axis=0) for b in range(B)]).astype(dtype), (T, Q)

@@ -233,6 +233,28 @@ def main():
                       node_mask=data['node_mask'].numpy(), T=T.numpy(), Q=Q.numpy(),
                       feat=feat.numpy(), adj=adj.numpy(), Le=Le.numpy(), T2=T2.numpy(),
                       Q2=Q2.numpy())
+  # ---- 6b. full AdaLanczosNet forward (R4+R5+R8+conv), config/qm8_ada_lanczos_net.yaml shapes,
+  #          2 layers (each layer owns a 2000-4096-4096-4096-2000 MLP = 50M parameters)
+  from oracle import make_ada_params
+  ada2 = dict(cfg, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30],
+              hidden_dim=[128, 128], num_layer=2)
+  conf2 = make_config(ada2, name='AdaLanczosNet')
+  conf2['model']['use_reorthogonalization'] = False  # as in the yaml; ignored by the reference (F7)
+  Pa = make_ada_params(ada2, seed=31)
+  neta = ref_model.AdaLanczosNet(conf2).eval()
+  neta.load_state_dict({k: torch.from_numpy(v) for k, v in Pa.items()})
+  nb = 8
+  q1a = np.random.RandomState(79).randn(nb, Nn, 1).astype(np.float32)
+  torch.randn = lambda *a, **k: torch.from_numpy(q1a.copy())
+  try:
+    with torch.no_grad():
+      sa = neta(data['node_feat'][:nb], data['L'][:nb], mask=data['node_mask'][:nb].bool())
+  finally:
+    torch.randn = real_randn
+  np.savez_compressed(os.path.join(HERE, 'ada_full.npz'), cfg_json=np.array(repr(ada2)),
+                      param_seed=31, nb=nb, q1=q1a[:, :, 0], score=sa.numpy())
+  del neta, Pa
+
   # ---- 7. constructor / init RNG parity: reference LanczosNet under torch.manual_seed(1234)
   torch.manual_seed(1234)
   ref_net = ref_model.LanczosNet(make_config(dict(DEFAULT_QM8_CFG)))
