@@ -61,6 +61,21 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
                      const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                      int32_t* info, lnz_stream_t stream);
 
+/* ---- R2 + R6, large graphs (BASELINE config 5: N = 2048, K = 64) -------------------------------
+ * M-step Lanczos (full re-orthogonalisation, CGS2; stops early if the Krylov space becomes
+ * invariant) -> QL on the M x M tridiagonal -> Ritz vectors V = Q S, top-K by |theta|, zero
+ * padded.  The dense A (rows contiguous, 16-byte aligned, row stride stride_r, N %% 4 == 0,
+ * N <= 2048) is re-streamed from HBM every step: this is the HBM-bound regime of the path.
+ * The reference's counterpart is scipy.sparse.linalg.eigsh(L, k, which='LM')
+ * (utils/data_helper.py:205-208, ARPACK, implicitly restarted): converged leading pairs agree,
+ * unconverged ones are a different function — see oracle/lanczos_kstep.py.
+ * workspace: lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes of device memory (Krylov basis,
+ * fp64).  D [B,K], V [B,N,K]; info [B] (optional) = Lanczos steps actually taken. */
+int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N);
+int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B, int N,
+                           int M, int K, void* workspace, float* D, float* V, int32_t* info,
+                           lnz_stream_t stream);
+
 /* ---- operand packing (MFMA fragment order) -------------------------------------------
  * W [rows, cols] (leading dimension ld) -> Wp[rt][q][lane][u] =
  *   W[32*rt + (lane&31)][8*q + 4*(lane>>5) + u], zero padded to rows%32==0, cols%8==0.

@@ -1,0 +1,387 @@
+// R2 + R6 for LARGE graphs (BASELINE config 5: N = 2048, K = 64): M-step Lanczos with full
+// re-orthogonalisation -> QL on the M x M tridiagonal -> Ritz vectors V = Q S.  HBM BOUND.
+//
+// One 512-thread workgroup (8 wavefronts) per graph — 256 graphs fill the 256 CUs, each CU
+// streaming its own A at the per-CU HBM rate.  Per Lanczos step the dense A (4 N^2 bytes; 16.8 MB
+// at N = 2048, far beyond LDS/L2) is streamed ONCE:
+//   * lane l of every wave owns columns {256 s + 4 l .. +3 | s = 0..7}: its slice of q sits in 32
+//     fp64 REGISTERS for the whole step, so the inner loop has no LDS traffic at all;
+//   * wave v owns rows v, v+8, ...: 8 x global_load_dwordx4 per row (one fully coalesced 8 KiB
+//     row), two rows software-pipelined, fp64 FMAs, one DPP wave reduction per row.
+// The Krylov basis (M x N fp64 = 1 MB per graph) lives in a caller-provided HBM workspace: the
+// CGS2 dot products are "one wave per basis vector", the update is "thread owns rows".
+//
+// Algorithmic bytes per graph: M * 4 N^2 (A) + basis traffic ~ 4 * 8 N * M(M+1)/2
+// + 4 N K (V) : 1.074 GB + 0.133 GB + 0.5 MB at N = 2048, M = K = 64.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TPB = 512;
+constexpr int NWAVE = TPB / 64;
+constexpr int NCH = 8;          // 256-column chunks -> N <= 2048
+constexpr int MMAX = 64;        // Lanczos steps
+constexpr int ZLD = MMAX;      // QL accumulator rows (aliases the q/w vectors, dead by then)
+constexpr double kTol = 1e-8;
+constexpr double kEpsD = 2.220446049250313e-16;
+
+struct LargeSmem {
+  union {
+    struct {
+      double qs[NCH * 256];
+      double ws[NCH * 256];
+    };
+    double Zt[MMAX * ZLD];  // QL eigenvector accumulator, transposed: Zt[i][r] = S[r][i]
+  };
+  double dd[MMAX];
+  double ee[MMAX];
+  double cs[MMAX];
+  double red[NWAVE];
+  int perm[MMAX];
+  float sgn[MMAX];
+};
+
+__device__ inline double dpp_xadd_f64(double v, int sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v), l2, h2;
+  switch (sel) {
+    case 0:
+      l2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false);
+      h2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false);
+      break;
+    case 1:
+      l2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false);
+      h2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false);
+      break;
+    case 2:
+      l2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false);
+      h2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false);
+      break;
+    default:
+      l2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false);
+      h2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false);
+      break;
+  }
+  return v + __hiloint2double(h2, l2);
+}
+
+// wave-wide fp64 sum, identical in every lane, fixed tree
+__device__ inline double wave_sum_f64(double v) {
+  v = dpp_xadd_f64(v, 0);
+  v = dpp_xadd_f64(v, 1);
+  v = dpp_xadd_f64(v, 2);
+  v = dpp_xadd_f64(v, 3);
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * k);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * k);
+    r[k] = __hiloint2double(hi, lo);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+__device__ inline double block_sum(LargeSmem& sm, double part, int tid) {
+  double w = wave_sum_f64(part);
+  if ((tid & 63) == 0) sm.red[tid >> 6] = w;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < NWAVE; ++k) t += sm.red[k];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
+    const float* __restrict__ A, int64_t sb, int64_t sr, int N, int M, int K,
+    double* __restrict__ work, float* __restrict__ D, float* __restrict__ V,
+    int32_t* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) LargeSmem sm;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const float* Ab = A + (int64_t)b * sb;
+  double* Qg = work + (int64_t)b * MMAX * N;
+
+  // start vector (same hash as the small-graph kernel)
+  double part = 0.0;
+  for (int r = tid; r < NCH * 256; r += TPB) {
+    double w = 0.0;
+    if (r < N) {
+      unsigned hsh = (unsigned)(r + 1) * 2654435761u;
+      w = 1.0 + (double)((hsh >> 8) & 0xffff) * (1.0 / 65536.0);
+    }
+    sm.ws[r] = w;
+    part += w * w;
+  }
+  if (tid < MMAX) {
+    sm.dd[tid] = 0.0;
+    sm.ee[tid] = 0.0;
+  }
+  double nrm2 = block_sum(sm, part, tid);
+
+  int steps = 0;
+  for (int j = 0; j < M; ++j) {
+    const double nrm = sqrt(nrm2);
+    if (j > 0 && nrm <= kTol) break;  // invariant subspace reached: stop (slots stay zero)
+    if (j > 0 && tid == 0) sm.ee[j - 1] = nrm;
+    const double ninv = 1.0 / nrm;
+    for (int r = tid; r < NCH * 256; r += TPB) {
+      double q = sm.ws[r] * ninv;
+      sm.qs[r] = q;
+      if (r < N) Qg[(int64_t)j * N + r] = q;
+    }
+    __syncthreads();
+
+    // ---- SpMV: w = A q; q slice in registers, A streamed once ------------------------------
+    double qreg[NCH][4];
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      const double2* p = reinterpret_cast<const double2*>(&sm.qs[256 * s + 4 * lane]);
+      double2 x = p[0], y = p[1];
+      qreg[s][0] = x.x;
+      qreg[s][1] = x.y;
+      qreg[s][2] = y.x;
+      qreg[s][3] = y.y;
+    }
+    auto load_row = [&](int r, float4 (&a)[NCH]) {
+      const float* row = Ab + (int64_t)r * sr;
+#pragma unroll
+      for (int s = 0; s < NCH; ++s) {
+        int c0 = 256 * s + 4 * lane;
+        a[s] = (c0 < N) ? *reinterpret_cast<const float4*>(row + c0)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    auto dot_row = [&](const float4 (&a)[NCH]) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int s = 0; s < NCH; ++s) {
+        s0 = fma((double)a[s].x, qreg[s][0], s0);
+        s1 = fma((double)a[s].y, qreg[s][1], s1);
+        s2 = fma((double)a[s].z, qreg[s][2], s2);
+        s3 = fma((double)a[s].w, qreg[s][3], s3);
+      }
+      return (s0 + s1) + (s2 + s3);
+    };
+    {
+      float4 a0[NCH], a1[NCH];
+      int r = wave;
+      if (r < N) load_row(r, a0);
+      for (; r < N; r += 2 * NWAVE) {
+        const int r1 = r + NWAVE, r2 = r + 2 * NWAVE;
+        if (r1 < N) load_row(r1, a1);
+        double t0 = wave_sum_f64(dot_row(a0));
+        if (lane == 0) sm.ws[r] = t0;
+        if (r2 < N) load_row(r2, a0);
+        if (r1 < N) {
+          double t1 = wave_sum_f64(dot_row(a1));
+          if (lane == 0) sm.ws[r1] = t1;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- CGS2 against q_0..q_j -------------------------------------------------------------
+    double coef = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = wave; i <= j; i += NWAVE) {
+        const double* qi = Qg + (int64_t)i * N;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+          int c0 = 256 * s + 4 * lane;
+          if (c0 < N) {
+            const double2* g = reinterpret_cast<const double2*>(qi + c0);
+            const double2* w = reinterpret_cast<const double2*>(&sm.ws[c0]);
+            double2 g0 = g[0], g1 = g[1], w0 = w[0], w1 = w[1];
+            s0 = fma(g0.x, w0.x, s0);
+            s1 = fma(g0.y, w0.y, s1);
+            s0 = fma(g1.x, w1.x, s0);
+            s1 = fma(g1.y, w1.y, s1);
+          }
+        }
+        double c = wave_sum_f64(s0 + s1);
+        if (lane == 0) sm.cs[i] = c;
+      }
+      __syncthreads();
+      for (int r = tid; r < N; r += TPB) {
+        double acc0 = 0.0, acc1 = 0.0;
+        int i = 0;
+        for (; i + 1 <= j; i += 2) {
+          acc0 = fma(sm.cs[i], Qg[(int64_t)i * N + r], acc0);
+          acc1 = fma(sm.cs[i + 1], Qg[(int64_t)(i + 1) * N + r], acc1);
+        }
+        if (i <= j) acc0 = fma(sm.cs[i], Qg[(int64_t)i * N + r], acc0);
+        sm.ws[r] -= (acc0 + acc1);
+      }
+      coef += sm.cs[j];
+      __syncthreads();
+    }
+    if (tid == 0) sm.dd[j] = coef;
+    part = 0.0;
+    for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
+    nrm2 = block_sum(sm, part, tid);
+    steps = j + 1;
+  }
+  __syncthreads();
+
+  // ---- QL (tql2 recurrences) on the steps x steps tridiagonal; Zt starts as identity --------
+  const int n = steps;
+  for (int idx = tid; idx < MMAX * ZLD; idx += TPB) {
+    int i = idx / ZLD, r = idx - i * ZLD;
+    sm.Zt[idx] = (i == r) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  {
+    double f = 0.0, tst1 = 0.0;
+    for (int l = 0; l < n; ++l) {
+      tst1 = fmax(tst1, fabs(sm.dd[l]) + fabs(sm.ee[l]));
+      int m = l;
+      while (m < n - 1 && fabs(sm.ee[m]) > kEpsD * tst1) ++m;
+      if (m > l) {
+        int iter = 0;
+        double el;
+        do {
+          ++iter;
+          double g = sm.dd[l];
+          el = sm.ee[l];
+          double p = (sm.dd[l + 1] - g) / (2.0 * el);
+          double rr = sqrt(p * p + 1.0);
+          if (p < 0) rr = -rr;
+          const double dl = el / (p + rr);
+          const double dl1 = el * (p + rr);
+          const double hh = g - dl;
+          __syncthreads();
+          if (tid == 0) {
+            sm.dd[l] = dl;
+            sm.dd[l + 1] = dl1;
+          }
+          if (tid >= l + 2 && tid < n) sm.dd[tid] -= hh;
+          __syncthreads();
+          f += hh;
+          p = sm.dd[m];
+          double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+          const double el1 = sm.ee[l + 1];
+          double carry = tid < MMAX ? sm.Zt[m * ZLD + tid] : 0.0;
+          __syncthreads();
+          for (int i = m - 1; i >= l; --i) {
+            c3 = c2;
+            c2 = c;
+            s2 = s;
+            const double ei = sm.ee[i], di = sm.dd[i];
+            g = c * ei;
+            const double hp = c * p;
+            const double tt = fma(p, p, ei * ei);
+            const double rinv = rsqrt(tt);
+            const double rad = tt * rinv;
+            const double e_next = s * rad;
+            s = ei * rinv;
+            c = p * rinv;
+            p = c * di - s * g;
+            const double d_next = hp + s * (c * g + s * di);
+            __syncthreads();  // all threads have read ee[i], dd[i] (and ee[i+1] earlier)
+            if (tid == 0) {
+              sm.ee[i + 1] = e_next;
+              sm.dd[i + 1] = d_next;
+            }
+            if (tid < MMAX) {
+              const double z0 = sm.Zt[i * ZLD + tid];
+              sm.Zt[(i + 1) * ZLD + tid] = s * z0 + c * carry;
+              carry = c * z0 - s * carry;
+            }
+          }
+          if (tid < MMAX) sm.Zt[l * ZLD + tid] = carry;
+          __syncthreads();
+          p = -s * s2 * c3 * el1 * sm.ee[l] / dl1;
+          el = s * p;
+          __syncthreads();
+          if (tid == 0) {
+            sm.ee[l] = el;
+            sm.dd[l] = c * p;
+          }
+          __syncthreads();
+        } while (fabs(el) > kEpsD * tst1 && iter < 60);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        sm.dd[l] = sm.dd[l] + f;
+        sm.ee[l] = 0.0;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- order by descending |theta| (ties: ascending theta, then index) ----------------------
+  if (tid < n) {
+    double di = sm.dd[tid], ai = fabs(di);
+    int rank = 0;
+    for (int jj = 0; jj < n; ++jj) {
+      double dj = sm.dd[jj], aj = fabs(dj);
+      bool before = (aj > ai) || (aj == ai && (dj < di || (dj == di && jj < tid)));
+      rank += before ? 1 : 0;
+    }
+    sm.perm[rank] = tid;
+  }
+  __syncthreads();
+  const int kk = K < n ? K : n;
+  if (tid < kk) {  // sign: largest-magnitude coefficient of the Ritz vector in the Krylov basis > 0
+    const double* s = &sm.Zt[sm.perm[tid] * ZLD];
+    double best = 0.0;
+    float sg = 1.0f;
+    for (int x = 0; x < n; ++x) {
+      double av = fabs(s[x]);
+      if (av > best) {
+        best = av;
+        sg = s[x] < 0 ? -1.0f : 1.0f;
+      }
+    }
+    sm.sgn[tid] = sg;
+  }
+  __syncthreads();
+
+  // ---- D [K], V [N, K] = Q S -------------------------------------------------------------------
+  for (int k = tid; k < K; k += TPB) D[(int64_t)b * K + k] = k < kk ? (float)sm.dd[sm.perm[k]] : 0.0f;
+  float* Vb = V + (int64_t)b * N * K;
+  for (int r = tid; r < N; r += TPB) {
+    double qcol[MMAX];
+#pragma unroll
+    for (int i = 0; i < MMAX; ++i) qcol[i] = i < n ? Qg[(int64_t)i * N + r] : 0.0;
+    for (int k = 0; k < K; ++k) {
+      float out = 0.0f;
+      if (k < kk) {
+        const double* s = &sm.Zt[sm.perm[k] * ZLD];
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MMAX; i += 2) {
+          a0 = fma(qcol[i], s[i], a0);
+          a1 = fma(qcol[i + 1], s[i + 1], a1);
+        }
+        out = sm.sgn[k] * (float)(a0 + a1);
+      }
+      Vb[(int64_t)r * K + k] = out;
+    }
+  }
+  if (info && tid == 0) info[b] = steps;
+}
+
+}  // namespace
+
+extern "C" int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N) {
+  return (int64_t)B * MMAX * N * (int64_t)sizeof(double);
+}
+
+extern "C" int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B,
+                                      int N, int M, int K, void* workspace, float* D, float* V,
+                                      int32_t* info, lnz_stream_t stream) {
+  LNZ_REQUIRE(A && workspace && D && V && B > 0 && N > 0 && M > 0 && K > 0, LNZ_EINVAL,
+              "lnz_lanczos_ritz_large: bad arguments (B=%d N=%d M=%d K=%d)", B, N, M, K);
+  LNZ_REQUIRE(N <= NCH * 256 && M <= MMAX && K <= M, LNZ_ENOTSUP,
+              "lnz_lanczos_ritz_large: N=%d <= 2048, K=%d <= M=%d <= 64 required", N, K, M);
+  LNZ_REQUIRE(N % 4 == 0 && stride_r % 4 == 0 && stride_b % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(A) & 15) == 0,
+              LNZ_ENOTSUP,
+              "lnz_lanczos_ritz_large: rows must be contiguous, 16-byte aligned, N %% 4 == 0");
+  LNZ_REQUIRE(M <= N, LNZ_EINVAL, "lnz_lanczos_ritz_large: M=%d > N=%d", M, N);
+  hipLaunchKernelGGL(lanczos_ritz_large_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, A,
+                     stride_b, stride_r, N, M, K, (double*)workspace, D, V, info);
+  return lnz::check_launch("lnz_lanczos_ritz_large");
+}

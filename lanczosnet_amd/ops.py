@@ -74,6 +74,27 @@ def lanczos_ritz(A, n_nodes, K, return_info=False):
   return (D, V, info) if return_info else (D, V)
 
 
+def lanczos_ritz_large(A, M, K, workspace=None, return_info=False):
+  """M-step Lanczos Ritz pairs for large dense graphs (N <= 2048, rows contiguous).
+  A [B,N,N] float32 -> D [B,K], V [B,N,K].  `workspace`: optional reusable uint8 CUDA tensor of
+  lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes."""
+  _need_cuda(A, workspace)
+  assert A.dim() == 3 and A.dtype == torch.float32 and A.stride(2) == 1
+  B, N, _ = A.shape
+  lib = _lib.load()
+  need = lib.lnz_lanczos_ritz_large_workspace_bytes(B, N)
+  if workspace is None or workspace.numel() * workspace.element_size() < need:
+    workspace = torch.empty((need,), dtype=torch.uint8, device=A.device)
+  D = torch.empty((B, K), dtype=torch.float32, device=A.device)
+  V = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
+  info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
+  with torch.cuda.device(A.device):
+    _lib.check(lib.lnz_lanczos_ritz_large(_ptr(A), A.stride(0), A.stride(1), B, N, M, K,
+                                          _ptr(workspace), _ptr(D), _ptr(V), _ptr(info),
+                                          _stream()))
+  return (D, V, info) if return_info else (D, V)
+
+
 # ------------------------------------------------------------------------------------- packing
 def pack_rows_k8(W):
   """[rows, cols] -> MFMA fragment order (see include/lanczosnet_hip.h)."""

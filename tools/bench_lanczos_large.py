@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""HBM-roofline measurement of the large-graph Lanczos stage (BASELINE.json configs[4] shape:
+N = 2048, K = 64, batch 256).  Algorithmic bytes per graph: M * 4 N^2 for A
+re-streamed every step + basis traffic 4 * 8 N * M (M + 1) / 2 (fp64, two CGS passes, dots +
+update) + 4 N K for V.  Input graphs are drawn with torch on the GPU (generator, not the path)."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lanczosnet_amd import ops, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--nodes', type=int, default=2048)
+ap.add_argument('--steps', type=int, default=64)
+ap.add_argument('--reps', type=int, default=3)
+args = ap.parse_args()
+B, N, M = args.batch, args.nodes, args.steps
+g = torch.Generator(device='cuda'); g.manual_seed(0)
+A = torch.empty((B, N, N), dtype=torch.float32, device='cuda')
+for b in range(B):  # G(n, p = 0.01) + self loops, symmetric GCN normalisation (L4)
+  adj = (torch.rand((N, N), generator=g, device='cuda') < 0.01).float().triu(1)
+  adj = adj + adj.t() + torch.eye(N, device='cuda')
+  d = adj.sum(1).rsqrt()
+  A[b] = d[:, None] * adj * d[None, :]
+lib = _lib.load()
+ws = torch.empty((lib.lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ops.lanczos_ritz_large(A, M, M, workspace=ws)
+torch.cuda.synchronize()
+ts = []
+for _ in range(args.reps):
+  ev[0].record(); D, V, info = ops.lanczos_ritz_large(A, M, M, workspace=ws, return_info=True); ev[1].record()
+  torch.cuda.synchronize(); ts.append(ev[0].elapsed_time(ev[1]))
+t = min(ts) * 1e-3
+bytes_A = M * 4 * N * N
+bytes_Q = 4 * 8 * N * M * (M + 1) // 2
+bytes_V = 4 * N * M
+alg = B * (bytes_A + bytes_Q + bytes_V)
+print(json.dumps({'workload': 'lanczos_ritz_large B=%d N=%d M=K=%d fp32 A, fp64 arithmetic' % (B, N, M),
+                  'ms': round(t * 1e3, 3), 'graphs_per_s': round(B / t, 1),
+                  'algorithmic_GB': round(alg / 1e9, 2), 'achieved_GBps': round(alg / t / 1e9, 1),
+                  'A_only_GBps': round(B * bytes_A / t / 1e9, 1), 'peak_GBps': 8000,
+                  'frac_of_hbm_peak': round(alg / t / 8e12, 4), 'steps_taken_min': int(info.min()),
+                  'all_ms': [round(x, 2) for x in ts]}))
