@@ -255,6 +255,23 @@ def main():
                       param_seed=31, nb=nb, q1=q1a[:, :, 0], score=sa.numpy())
   del neta, Pa
 
+  # ---- 6c. MAE gate: the runner's weighted MAE (runner/qm8_runner.py:156-160:
+  #          |pred - label| * std, masked by label_weight, averaged) of the REFERENCE LanczosNet on a
+  #          QM8-schema surrogate test split, identical weights (numpy seed 2024)
+  bt = draw_batch(96, seed=101)
+  molst = [reference_preprocess(ref_dh, bt['adjs'][b], int(bt['n_nodes'][b])) for b in range(96)]
+  dt = reference_collate(ref_qm8, config, molst, bt)
+  rs_m = np.random.RandomState(5)
+  std = (0.05 + rs_m.rand(16)).astype(np.float32)          # QM8_meta.p 'std' stand-in
+  net = ref_model.LanczosNet(config).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  with torch.no_grad():
+    pred = net(dt['node_feat'], dt['L'], dt['D'], dt['V'], mask=dt['node_mask'].bool())
+  err = (pred - dt['label']).abs().numpy() * std[None, :]
+  np.savez_compressed(os.path.join(HERE, 'mae_gate.npz'), seed=101, batch_size=96, std=std,
+                      label=dt['label'].numpy(), mae=float(err.mean()),
+                      mae_per_target=err.mean(axis=0))
+
   # ---- 7. constructor / init RNG parity: reference LanczosNet under torch.manual_seed(1234)
   torch.manual_seed(1234)
   ref_net = ref_model.LanczosNet(make_config(dict(DEFAULT_QM8_CFG)))

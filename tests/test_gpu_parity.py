@@ -371,3 +371,25 @@ def test_full_size_properties_batch_1024():
                                    D[:16].cpu().numpy(), V[:16].cpu().numpy(),
                                    batch['node_mask'][:16], dtype=np.float64)
   assert rel_err(s1[:16].cpu().numpy(), ref) < 1e-5
+
+
+def test_mae_gate_vs_reference():
+  """BASELINE.md §1 MAE gate: reference-vs-ours on the same QM8-schema surrogate test split with
+  identical weights; runner MAE formula (runner/qm8_runner.py:156-160).  Target |dMAE| <= 0.05e-3.
+  The whole device pipeline is used: adjacency -> L4 -> Lanczos/QL Ritz pairs -> forward."""
+  from lanczosnet_amd import ops
+  g = load_golden('mae_gate.npz')
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  P = oracle.make_lanczosnet_params(cfg, 2024)
+  net = _model(cfg, P)
+  b = draw_batch(int(g['batch_size']), seed=int(g['seed']))
+  n = _t(b['n_nodes'])
+  L = ops.laplacian_l4(_t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, cfg['num_eig_vec'])
+  with torch.no_grad():
+    pred = net(_t(b['node_feat']), L, D, V, mask=_t(b['node_mask'])).cpu().numpy()
+  np.testing.assert_array_equal(b['label'], g['label'])
+  err = np.abs(pred - g['label']) * g['std'][None, :]
+  assert abs(float(err.mean()) - float(g['mae'])) < 0.05e-3
+  assert np.abs(err.mean(axis=0) - g['mae_per_target']).max() < 0.05e-3
+  print('MAE ours %.6f reference %.6f' % (err.mean(), float(g['mae'])))
