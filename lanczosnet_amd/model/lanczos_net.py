@@ -9,8 +9,10 @@ the reference's weights and `utils/train_helper.py:28-32` checkpoints load uncha
 
 The forward itself is three HIP launches (Laplacian pack, spectral gains, fused network) on
 the current torch stream; parameters are re-packed into MFMA fragment order only when they
-change.  Forward only in this version: training through `loss.backward()`
-(runner/qm8_runner.py:247) raises — backward kernels are SURVEY.md §8(f) rank 2.
+change.  Training through `loss.backward()` (runner/qm8_runner.py:247) works for LanczosNet /
+LanczosNetGeneral: the forward values are the HIP kernels', the parameter gradients come from an
+autograd recomputation in torch ops on the GPU (hand-written backward kernels are SURVEY.md §8(f)
+rank 2).
 """
 import torch
 import torch.nn as nn
@@ -88,11 +90,13 @@ class _LanczosNetBase(nn.Module):
                                'module and its inputs to cuda (no CPU fallback)')
         if self.training and self.dropout > 0.0:
             raise NotImplementedError('dropout > 0 in training mode is not built in the HIP path')
-        if torch.is_grad_enabled() and self.training and any(
-                p.requires_grad for p in self.parameters()):
+        if self._needs_grad() and self.filter_kind != 0:
             raise NotImplementedError(
-                'lanczosnet_amd: backward kernels are not built yet (forward-only); call under '
+                'lanczosnet_amd: AdaLanczosNet has no backward yet (forward-only); call under '
                 'torch.no_grad() or model.eval()')
+
+    def _needs_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def _read_dataset(self, ds):
         self.num_atom = ds.num_atom
@@ -191,22 +195,95 @@ class _LanczosNetBase(nn.Module):
         return plan
 
     # -- forward ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def _hip_forward(self, node_feat, L, D, V, mask):
+        plan = self._plan()
+        Lp = ops.pack_laplacian(L if L.dtype == torch.float32 else L.float())
+        G = None
+        if self.num_scale_long > 0:
+            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
+        return ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+
+    def _torch_forward(self, node_feat, L, D, V, mask):
+        """Differentiable torch restatement of the same math (device tensors, channel-major L,
+        `M_c (X W_c^T)` association) — used ONLY inside backward to obtain parameter gradients;
+        the values returned to the caller always come from the HIP kernels."""
+        B, N = L.shape[0], L.shape[1]
+        Lc = L.float().permute(0, 3, 1, 2).contiguous()          # [B, E+1, N, N]
+        Vf, Vt = V.float(), V.float().transpose(1, 2)
+        state = node_feat.float() if self.general else self.embedding(node_feat)
+        S = self.num_scale_long
+        if S > 0:
+            pows = torch.stack([torch.pow(D.float(), p) for p in self.long_diffusion_dist], dim=2)
+        for t in range(self.num_layer):
+            W, bias = self.filter[t].weight, self.filter[t].bias
+            d_in = state.shape[2]
+            Wc = W.view(W.shape[0], -1, d_in)                       # [dout, C, d_in]
+            Z = torch.einsum('bnd,ocd->bcno', state, Wc)             # X W_c^T  [B, C, N, dout]
+            out = bias.view(1, 1, -1).expand(B, N, -1)
+            c = 0
+            if self.num_scale_short > 0:
+                for p in self.short_diffusion_dist:
+                    z = Z[:, c]
+                    for _ in range(p):
+                        z = torch.bmm(Lc[:, 0], z)
+                    out = out + z
+                    c += 1
+            if S > 0:
+                G = pows if self.spectral_filter_kind != 'MLP' else \
+                    self.spectral_filter[t](pows.view(-1, S)).view(B, -1, S)   # [B, K, S]
+                for s_ in range(S):
+                    y = torch.bmm(Vt, Z[:, c])                                   # [B, K, dout]
+                    out = out + torch.bmm(Vf, G[:, :, s_].unsqueeze(2) * y)
+                    c += 1
+            for e in range(self.num_edgetype + 1):
+                out = out + torch.bmm(Lc[:, e], Z[:, c])
+                c += 1
+            state = torch.relu(out)
+        y = self.filter[-1](state)
+        att = self.att_func(state)
+        y = att * y
+        m = (mask != 0).float().unsqueeze(2)
+        return (y * m).sum(dim=1) / m.sum(dim=1)
     def forward(self, node_feat, L, D, V, label=None, mask=None):
         """Shapes as the reference docstring (model/lanczos_net.py:125-141): node_feat B x N
         (long) [General: B x N x D float], L B x N x N x (E+1), D B x K, V B x N x K,
         label B x P, mask B x N.  Returns score, or (score, loss) when `label` is given."""
         self._guard_forward(L, mask)
-        with torch.no_grad():
-            plan = self._plan()
-            Lp = ops.pack_laplacian(L if L.dtype == torch.float32 else L.float())
-            G = None
-            if self.num_scale_long > 0:
-                G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer,
-                                       plan['mlp_pack'])
-            score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+        if self._needs_grad():
+            # training (runner/qm8_runner.py:216-248): forward = HIP kernels, backward = autograd
+            # through a torch recomputation on the same device (_LanczosNetFunction)
+            score = _LanczosNetFunction.apply(self, node_feat, L, D, V, mask,
+                                              *[p for p in self.parameters()])
+        else:
+            score = self._hip_forward(node_feat, L, D, V, mask)
         if label is not None:
             return score, self.loss_func(score, label)
         return score
+
+
+class _LanczosNetFunction(torch.autograd.Function):
+    """forward: the fused HIP path.  backward: parameter gradients by autograd through
+    `_torch_forward` (inputs L, D, V, mask, node ids are data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, module, node_feat, L, D, V, mask, *params):
+        ctx.module = module
+        ctx.save_for_backward(node_feat, L, D, V, mask)
+        return module._hip_forward(node_feat, L, D, V, mask)
+
+    @staticmethod
+    def backward(ctx, grad_score):
+        module = ctx.module
+        node_feat, L, D, V, mask = ctx.saved_tensors
+        params = [p for p in module.parameters()]
+        with torch.enable_grad():
+            score = module._torch_forward(node_feat, L, D, V, mask)
+            need = [p for p in params if p.requires_grad]
+            grads = torch.autograd.grad(score, need, grad_score.contiguous(), allow_unused=True)
+        it = iter(grads)
+        out = [next(it) if p.requires_grad else None for p in params]
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class LanczosNet(_LanczosNetBase):

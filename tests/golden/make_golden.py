@@ -272,6 +272,23 @@ def main():
                       label=dt['label'].numpy(), mae=float(err.mean()),
                       mae_per_target=err.mean(axis=0))
 
+  # ---- 6d. training parity: reference loss.backward() parameter gradients (per-tensor sums,
+  #          abs-sums and a few entries), full config, first 12 molecules of the collate batch
+  netg = ref_model.LanczosNet(config).train()
+  netg.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  nb_g = 12
+  _, loss_g = netg(data['node_feat'][:nb_g], data['L'][:nb_g], data['D'][:nb_g], data['V'][:nb_g],
+                   label=data['label'][:nb_g], mask=data['node_mask'][:nb_g].bool())
+  loss_g.backward()
+  names = sorted(k for k, _ in netg.named_parameters())
+  gd = dict(netg.named_parameters())
+  np.savez_compressed(os.path.join(HERE, 'grad_parity.npz'), nb=nb_g, loss=float(loss_g),
+                      names=np.array(names),
+                      gsum=np.array([float(gd[k].grad.double().sum()) for k in names]),
+                      gabs=np.array([float(gd[k].grad.double().abs().sum()) for k in names]),
+                      gfirst=np.array([float(gd[k].grad.reshape(-1)[0]) for k in names]),
+                      gmax=np.array([float(gd[k].grad.abs().max()) for k in names]))
+
   # ---- 7. constructor / init RNG parity: reference LanczosNet under torch.manual_seed(1234)
   torch.manual_seed(1234)
   ref_net = ref_model.LanczosNet(make_config(dict(DEFAULT_QM8_CFG)))
