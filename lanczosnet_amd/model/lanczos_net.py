@@ -204,6 +204,74 @@ class _LanczosNetBase(nn.Module):
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
         return ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
 
+    @torch.no_grad()
+    def _large_graph_forward(self, node_feat, L, D, V, mask, gemm_dtype=None):
+        """Graphs beyond the 32-node MFMA tile (BASELINE config 5: N = 2048, K = 64).  The conv is
+        then plain batched dense GEMMs (`L_e (X W_e^T)` with N x N operands), which go to
+        hipBLASLt through torch.bmm; the spectral gains are the HIP kernel and the Ritz pairs come
+        from `lnz_lanczos_ritz_large`.  `gemm_dtype=torch.bfloat16` runs the edge-type GEMMs with
+        bf16 operands / fp32 accumulate (config 5's "bf16 MFMA filter GEMM"); default fp32."""
+        if self._needs_grad():
+            raise NotImplementedError('large-graph path is forward only')
+        B, N = L.shape[0], L.shape[1]
+        S = self.num_scale_long
+        plan_mlp = None
+        if self._has_mlp():
+            plan_mlp = self._plan_large()['mlp_pack']
+        G = None
+        if S > 0:
+            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan_mlp)  # [L,B,S,K]
+        Lc = L.permute(0, 3, 1, 2)                                   # channel-major view
+        if gemm_dtype is not None:
+            Lc = Lc.to(gemm_dtype)
+        Lc = Lc.contiguous()
+        Vf = V.float()
+        Vt = Vf.transpose(1, 2).contiguous()
+        state = node_feat.float() if self.general else self.embedding(node_feat)
+        for t in range(self.num_layer):
+            W, bias = self.filter[t].weight, self.filter[t].bias
+            d_in = state.shape[2]
+            Wc = W.view(W.shape[0], -1, d_in)
+            out = bias.view(1, 1, -1).expand(B, N, -1).clone()
+            c = 0
+            for p in self.short_diffusion_dist:
+                z = torch.matmul(state, Wc[:, c].t())
+                for _ in range(p):
+                    z = torch.bmm(Lc[:, 0].float(), z)
+                out += z
+                c += 1
+            for s_ in range(S):
+                z = torch.matmul(state, Wc[:, c].t())                # X W_s^T      [B,N,dout]
+                y = torch.bmm(Vt, z)                                  # V^T z        [B,K,dout]
+                out += torch.bmm(Vf, G[t, :, s_, :].unsqueeze(2) * y)
+                c += 1
+            for e in range(self.num_edgetype + 1):
+                z = torch.matmul(state, Wc[:, c].t())
+                if gemm_dtype is not None:
+                    out += torch.bmm(Lc[:, e], z.to(gemm_dtype)).float()
+                else:
+                    out += torch.bmm(Lc[:, e], z)
+                c += 1
+            state = torch.relu_(out)
+        y = self.filter[-1](state) * self.att_func(state)
+        m = (mask != 0).float().unsqueeze(2)
+        return (y * m).sum(dim=1) / m.sum(dim=1)
+
+    @torch.no_grad()
+    def _plan_large(self):
+        sig = self._param_signature()
+        cache = getattr(self, '_plan_large_cache', None)
+        if cache is not None and cache['sig'] == sig:
+            return cache
+        dev = self.filter[0].weight.device
+        size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
+        buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)
+        for t, seq in enumerate(self.spectral_filter):
+            lins = [(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
+            ops.pack_spectral_mlp(lins, self.num_scale_long, out=buf[t])
+        self._plan_large_cache = dict(sig=sig, mlp_pack=buf)
+        return self._plan_large_cache
+
     def _torch_forward(self, node_feat, L, D, V, mask):
         """Differentiable torch restatement of the same math (device tensors, channel-major L,
         `M_c (X W_c^T)` association) — used ONLY inside backward to obtain parameter gradients;
@@ -250,7 +318,9 @@ class _LanczosNetBase(nn.Module):
         (long) [General: B x N x D float], L B x N x N x (E+1), D B x K, V B x N x K,
         label B x P, mask B x N.  Returns score, or (score, loss) when `label` is given."""
         self._guard_forward(L, mask)
-        if self._needs_grad():
+        if L.shape[1] > 32:
+            score = self._large_graph_forward(node_feat, L, D, V, mask)
+        elif self._needs_grad():
             # training (runner/qm8_runner.py:216-248): forward = HIP kernels, backward = autograd
             # through a torch recomputation on the same device (_LanczosNetFunction)
             score = _LanczosNetFunction.apply(self, node_feat, L, D, V, mask,

@@ -58,3 +58,38 @@ def test_large_lanczos_early_stop_on_invariant_subspace():
   D = D.cpu().numpy()[0]
   assert abs(D[0] - 1.0) < 1e-6 and (D[1:] == 0).all()
   assert (V.cpu().numpy()[0][:, 1:] == 0).all()
+
+
+def test_large_graph_general_forward_matches_oracle():
+  """LanczosNetGeneral beyond the 32-node tile (config 5 regime, reduced size): device pipeline
+  (large Lanczos -> gains -> hipBLASLt conv) vs the fp64 oracle fed the SAME Ritz pairs."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNetGeneral
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
+             num_eig_vec=32, spectral_filter_kind='MLP', input_dim=10, hidden_dim=[128, 128, 128],
+             output_dim=2, num_layer=3, num_atom=0)
+  B, N, K = 3, 256, 32
+  A = _graphs(B, N, 8.0 / N, seed=7)
+  rs = np.random.RandomState(2)
+  X = rs.randn(B, N, 10).astype(np.float32)
+  mask = np.ones((B, N), np.uint8)
+  mask[1, 200:] = 0
+  L = np.stack([A, A], axis=3)  # E+1 = 2 channels (graph_data collate: simple + one edge type)
+  P = oracle.make_lanczosnet_params(cfg, 17, general=True)
+  net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  net = net.to(DEV)
+  Ld = torch.from_numpy(L).to(DEV)
+  D, V = ops.lanczos_ritz_large(Ld[:, :, :, 0].contiguous(), K, K)
+  with torch.no_grad():
+    score = net(torch.from_numpy(X).to(DEV), Ld, D, V, mask=torch.from_numpy(mask).to(DEV))
+    score_bf16 = net._large_graph_forward(torch.from_numpy(X).to(DEV), Ld, D, V,
+                                          torch.from_numpy(mask).to(DEV), gemm_dtype=torch.bfloat16)
+  ref = oracle.lanczos_net_forward(P, cfg, X, L, D.cpu().numpy(), V.cpu().numpy(), mask,
+                                   dtype=np.float64, general=True)
+  e = np.abs(score.cpu().numpy() - ref).max() / np.abs(ref).max()
+  eb = np.abs(score_bf16.cpu().numpy() - ref).max() / np.abs(ref).max()
+  print('large-graph forward rel err fp32 %.2e, bf16 edge GEMMs %.2e' % (e, eb))
+  assert e < 1e-5
+  assert eb < 2e-2  # bf16 operands: 8-bit mantissa (documented, opt-in)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4]: LanczosNetGeneral (config/graph_lanczos_net.yaml architecture),
+N = 2048 nodes, K = 64, batch 256, 1 x MI355X.  Lanczos (HIP, HBM bound) + gains (HIP) + conv
+(hipBLASLt batched GEMMs, fp32 or bf16 operands)."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import oracle
+from lanczosnet_amd import ops
+from lanczosnet_amd.model import LanczosNetGeneral
+from lanczosnet_amd.utils.arg_helper import make_model_config
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--nodes', type=int, default=2048)
+ap.add_argument('--reps', type=int, default=3)
+args = ap.parse_args()
+B, N, K = args.batch, args.nodes, 64
+cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
+           num_eig_vec=K, spectral_filter_kind='MLP', input_dim=10, hidden_dim=[128] * 7,
+           output_dim=2, num_layer=7, num_atom=0)
+torch.manual_seed(1234)
+net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval().cuda()
+g = torch.Generator(device='cuda'); g.manual_seed(0)
+L = torch.empty((B, N, N, 2), dtype=torch.float32, device='cuda')
+for b in range(B):
+  adj = (torch.rand((N, N), generator=g, device='cuda') < 0.01).float().triu(1)
+  adj = adj + adj.t() + torch.eye(N, device='cuda')
+  d = adj.sum(1).rsqrt()
+  A = d[:, None] * adj * d[None, :]
+  L[b, :, :, 0] = A
+  L[b, :, :, 1] = A
+X = torch.randn((B, N, 10), generator=g, device='cuda')
+mask = torch.ones((B, N), dtype=torch.uint8, device='cuda')
+A0 = L[:, :, :, 0].contiguous()
+ws = torch.empty((ops._lib.load().lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+res = {}
+for name, dt in (('fp32', None), ('bf16_edge_gemm', torch.bfloat16)):
+  best = None
+  for it in range(args.reps + 1):
+    ev[0].record()
+    D, V = ops.lanczos_ritz_large(A0, K, K, workspace=ws)
+    ev[1].record()
+    with torch.no_grad():
+      score = net._large_graph_forward(X, L, D, V, mask, gemm_dtype=dt)
+    ev[2].record()
+    torch.cuda.synchronize()
+    t = (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
+    if it > 0 and (best is None or sum(t) < sum(best)):
+      best = t
+  res[name] = {'lanczos_ms': round(best[0], 2), 'forward_ms': round(best[1], 2),
+               'graphs_per_s': round(B / (sum(best) * 1e-3), 1), 'finite': bool(torch.isfinite(score).all())}
+print(json.dumps({'workload': 'LanczosNetGeneral N=%d K=%d batch=%d' % (N, K, B), **res}))
