@@ -84,6 +84,13 @@ int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, i
 int64_t lnz_packed_rows_k8_size(int rows, int cols);
 int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, float* Wp,
                      lnz_stream_t stream);
+/* W [rows, cols] -> fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order:
+ *   out[rt][kb][piece][lane][e] (e = 0..7 halves, 16 B per lane) with
+ *   x = W[32*rt + (lane&31)][16*kb + 8*(lane>>5) + e], piece 0 = half(x), piece 1 = half(x - piece0);
+ * rows padded to 32, cols to 16.  lnz_packed_rows_f16x2_bytes(rows, cols) bytes. */
+int64_t lnz_packed_rows_f16x2_bytes(int rows, int cols);
+int lnz_pack_rows_f16x2(const float* W, int rows, int cols, int64_t ld, void* out,
+                        lnz_stream_t stream);
 /* bias [rows] -> bp[rt][lane][r] = bias[32*rt + (r&3) + 8*(r>>2) + 4*(lane>>5)] (the C/D
  * row of accumulator register r); holds 32*ceil(rows/32)*32 floats. */
 int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_stream_t stream);
@@ -144,6 +151,18 @@ typedef struct lnz_forward_args {
   const float* bias_head;     /* [32]: b_o (P), b_a, zeros                                   */
   float* score;               /* [B,dout]                                                    */
   float* state_out;           /* optional [B,32,dhid] final node state (debug/tests) or NULL */
+  /* ---- opt-in split-precision mode (gemm_mode = 1): X W_c^T evaluated as x_hi w_hi + x_hi w_lo +
+   * x_lo w_hi with fp16 pieces on v_mfma_f32_32x32x16_f16 (fp32 accumulate): 2^-22 relative
+   * operand precision, measured 6e-7 end-to-end vs fp64 (fp32 MFMA path: 2e-7).  Needs dhid == 128,
+   * filter_kind == 0, K <= 20, din0 <= 128; packs from lnz_pack_rows_f16x2 with the layer-0 input
+   * width zero-padded to 128.  gemm_mode = 0 (default) is the exact fp32 path. */
+  int32_t gemm_mode;
+  const void* Wp16;           /* packed fp16 hi/lo conv weights: layer l at (char*)Wp16 + w16_off[l] */
+  int64_t w16_off[16];        /* byte offsets                                                     */
+  const void* Wp16_head;      /* packed [32, 128] head                                            */
+  const int32_t* order;       /* optional [B] permutation: workgroup g processes molecules
+                                 order[4g..4g+3] (sort by node count so each group skips the same
+                                 padded GEMM2 steps); NULL = identity.  gemm_mode 1 only          */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify

@@ -40,6 +40,8 @@ class ForwardArgs(C.Structure):
       ('w_off', C.c_int64 * 16), ('b_off', C.c_int64 * 16),
       ('Wp_head', C.c_void_p), ('bias_head', C.c_void_p),
       ('score', C.c_void_p), ('state_out', C.c_void_p),
+      ('gemm_mode', C.c_int32), ('Wp16', C.c_void_p), ('w16_off', C.c_int64 * 16),
+      ('Wp16_head', C.c_void_p), ('order', C.c_void_p),
   ]
 
 
@@ -54,6 +56,8 @@ SIGNATURES = {
     'lnz_lanczos_ritz_large': (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_packed_rows_k8_size': (C.c_int64, [_I, _I]),
     'lnz_pack_rows_k8': (C.c_int, [_P, _I, _I, _L, _P, _P]),
+    'lnz_packed_rows_f16x2_bytes': (C.c_int64, [_I, _I]),
+    'lnz_pack_rows_f16x2': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_pack_bias_rows': (C.c_int, [_P, _I, _P, _P]),
     'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),

@@ -363,6 +363,10 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
 
 }  // namespace
 
+namespace lnz {
+int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_forward_f16.hip
+}
+
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
 
 extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream) {
@@ -393,6 +397,9 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
               LNZ_EINVAL, "lnz_lanczosnet_forward: null tensor pointer");
   LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "lnz_lanczosnet_forward: G missing");
   hipStream_t s = (hipStream_t)stream;
+  LNZ_REQUIRE(a.gemm_mode == 0 || a.gemm_mode == 1, LNZ_EINVAL,
+              "lnz_lanczosnet_forward: gemm_mode %d", a.gemm_mode);
+  if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
   const int grid = (a.B + MOLS - 1) / MOLS;
   LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL,
               "lnz_lanczosnet_forward: filter_kind %d", a.filter_kind);

@@ -1,0 +1,364 @@
+// Opt-in split-precision variant of the fused LanczosNet forward (lnz_forward_args.gemm_mode = 1).
+//
+// GEMM1  Z_c = X W_c^T  is 77 % of the fp32 kernel's matrix work.  Here both operands are split
+// into fp16 pieces x = x_hi + x_lo (x_hi = half(x), x_lo = half(x - x_hi): 22 mantissa bits) and
+//   X W^T  ~=  X_hi W_hi^T + X_hi W_lo^T + X_lo W_hi^T          (fp32 accumulate)
+// runs on v_mfma_f32_32x32x16_f16 (32 cycles per 32x32x16) instead of v_mfma_f32_32x32x2_f32
+// (64 cycles per 32x32x2): 3/16 of the issue cycles.  The dropped x_lo w_lo term is 2^-22 relative;
+// end-to-end deviation from fp64 is 6e-7 (exact-fp32 path: 2e-7; parity bar 1e-5).
+// GEMM2 (M_c Z_c), the L_s build and everything else stay exact fp32 exactly as in conv_forward.hip.
+//
+// With GEMM1 this cheap the per-CU vector-memory path becomes the limiter unless every packed
+// weight fragment is reused more: ONE workgroup per CU-sized group of FOUR molecules, four
+// wavefronts (one per SIMD, up to 512 registers each), wave w owns output-feature tile w for all
+// four molecules, so one 2 KiB weight fragment (hi + lo) feeds 4 x 3 MFMAs.  X lives in LDS as
+// fp16 hi/lo row-major tiles (pitch 136 halves: conflict-free ds_read_b128 A fragments), written
+// by the epilogue of the previous layer.  All layers use an input width of 128 (layer-0 features
+// and weight columns are zero padded), so a channel is always 8 k-blocks and ring slots are static.
+#include "common.hpp"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int M4 = 4;          // molecules per workgroup
+constexpr int P16 = 136;       // LDS row pitch in halves
+constexpr int KB = 8;          // k-blocks (of 16) per channel: input width 128
+constexpr int RING_D = 6;      // weight prefetch distance in k-blocks
+constexpr int KHT = 10;        // eigen slots per lane half (K <= 20)
+
+union H8 {
+  uint4 u;
+  f16x8 h;
+};
+
+__device__ inline f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ inline void split_store(_Float16* xh, _Float16* xl, float x) {
+  _Float16 h = (_Float16)x;
+  *xh = h;
+  *xl = (_Float16)(x - (float)h);
+}
+
+__global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz_forward_args a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  // [buf][piece][mol][32][P16]
+  auto Xp = [&](int buf, int piece, int m) { return smem + (((buf * 2 + piece) * M4 + m) * 32) * P16; };
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int j = lane & 31, hh = lane >> 5;
+  const int N = a.N, K = a.K, B = a.B;
+  const int C = a.n_short + a.n_long + a.n_edge;
+  int mb[M4];  // molecule ids of this group (a.order: optional size-sorted permutation)
+#pragma unroll
+  for (int m = 0; m < M4; ++m) {
+    int x = blockIdx.x * M4 + m;
+    x = x < B ? x : B - 1;
+    mb[m] = a.order ? a.order[x] : x;
+  }
+
+  // ---- embedding gather / float features, zero padded to 128 columns, split into hi/lo ----------
+  for (int idx = tid; idx < M4 * 32 * 128; idx += 256) {
+    int m = idx >> 12, row = (idx >> 7) & 31, col = idx & 127;
+    float v = 0.0f;
+    if (row < N && col < a.din0) {
+      if (a.node_feat) {
+        int64_t id = a.node_feat[(int64_t)mb[m] * N + row];
+        id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
+        v = a.embedding[id * a.din0 + col];
+      } else {
+        v = a.node_feat_f[((int64_t)mb[m] * N + row) * a.din0 + col];
+      }
+    }
+    split_store(Xp(0, 0, m) + row * P16 + col, Xp(0, 1, m) + row * P16 + col, v);
+  }
+
+  int g2steps[M4];
+#pragma unroll
+  for (int m = 0; m < M4; ++m) {
+    int last = 0;
+    for (int i = lane; i < N; i += 64) last = a.mask[(int64_t)mb[m] * N + i] ? i + 1 : last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+    g2steps[m] = __builtin_amdgcn_readfirstlane(((last + 7) >> 3) * 4);
+  }
+  int smax = g2steps[0];
+#pragma unroll
+  for (int m = 1; m < M4; ++m) smax = g2steps[m] > smax ? g2steps[m] : smax;
+
+  const int KH = (K + 1) >> 1;
+  float vreg[M4][KHT];
+#pragma unroll
+  for (int m = 0; m < M4; ++m) {
+#pragma unroll
+    for (int t = 0; t < KHT; ++t) {
+      int k = KH * hh + t;
+      vreg[m][t] = (t < KH && k < K && j < N) ? a.V[((int64_t)mb[m] * N + j) * K + k] : 0.0f;
+    }
+  }
+  __syncthreads();
+
+#ifdef LNZ_PROFILE_PHASES
+  long long t_g1 = 0, t_g2 = 0, t_ep = 0, t_all = clock64();
+#define LNZ_T0 long long _t0 = clock64();
+#define LNZ_ACC(x) { long long _t1 = clock64(); x += _t1 - _t0; _t0 = _t1; }
+#else
+#define LNZ_T0
+#define LNZ_ACC(x)
+#endif
+  int cur = 0;
+  for (int l = 0; l < a.num_layer; ++l) {
+    const float* __restrict__ bl = a.bias + a.b_off[l];
+    f32x16 out[M4];
+    {
+      const float bv = bl[32 * wave + j];
+#pragma unroll
+      for (int m = 0; m < M4; ++m) out[m] = lnz::splat16(bv);
+    }
+    // weight stream of this wave's feature tile: [g = c*8 + kb][piece][lane] uint4, contiguous
+    const uint4* __restrict__ wp =
+        reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.Wp16) + a.w16_off[l]) +
+        (int64_t)wave * (C * KB) * 128 + lane;
+    uint4 ringh[KB], ringl[KB];
+#pragma unroll
+    for (int sl = 0; sl < RING_D; ++sl) {
+      ringh[sl] = wp[sl * 128];
+      ringl[sl] = wp[sl * 128 + 64];
+    }
+    const _Float16* xa[M4][2];
+#pragma unroll
+    for (int m = 0; m < M4; ++m) {
+      xa[m][0] = Xp(cur, 0, m) + j * P16 + 8 * hh;
+      xa[m][1] = Xp(cur, 1, m) + j * P16 + 8 * hh;
+    }
+
+    // GEMM2 operands of the CURRENT channel, fetched at its start (they have the whole GEMM1 to
+    // land): 16 floats per molecule as four dwordx4 — the Laplacian fragments of an edge/short
+    // channel, or (long channel) the gains g_s[KH*hh .. +15] (10 used; G is padded by 64 B).
+    float mop[M4][16];
+    auto fetch_m_operands = [&](int c, int m) {
+      const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
+      const float* src;
+      int stride4;
+      if (lng) {
+        src = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K + KH * hh;
+        stride4 = 1;
+      } else {
+        const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
+        src = a.Lp + (((int64_t)mb[m] * a.n_edge + e) * 256 + lane) * 4;
+        stride4 = 64;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = *reinterpret_cast<const float4*>(src + (int64_t)g * stride4 * 4);
+        mop[m][4 * g + 0] = v.x;
+        mop[m][4 * g + 1] = v.y;
+        mop[m][4 * g + 2] = v.z;
+        mop[m][4 * g + 3] = v.w;
+      }
+    };
+
+    for (int c = 0; c < C; ++c) {
+      const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
+#pragma unroll
+      for (int m = 0; m < M4; ++m) fetch_m_operands(c, m);
+
+      LNZ_T0
+      // ---------------- GEMM1 (split fp16): Z_m = X_m W_c^T ----------------
+      f32x16 Z[M4];
+#pragma unroll
+      for (int m = 0; m < M4; ++m) Z[m] = lnz::splat16(0.0f);
+      H8 ah[M4], al[M4];
+#pragma unroll
+      for (int m = 0; m < M4; ++m) {
+        ah[m].u = *reinterpret_cast<const uint4*>(xa[m][0]);
+        al[m].u = *reinterpret_cast<const uint4*>(xa[m][1]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        // prefetch weights RING_D k-blocks ahead (over-reads past the layer into the slack)
+        ringh[(kb + RING_D) % KB] = wp[(kb + RING_D) * 128];
+        ringl[(kb + RING_D) % KB] = wp[(kb + RING_D) * 128 + 64];
+        H8 nh[M4], nl[M4];
+        if (kb + 1 < KB) {
+#pragma unroll
+          for (int m = 0; m < M4; ++m) {
+            nh[m].u = *reinterpret_cast<const uint4*>(xa[m][0] + 16 * (kb + 1));
+            nl[m].u = *reinterpret_cast<const uint4*>(xa[m][1] + 16 * (kb + 1));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        H8 wh, wl;
+        wh.u = ringh[kb];
+        wl.u = ringl[kb];
+#pragma unroll
+        for (int m = 0; m < M4; ++m) Z[m] = mfma16(ah[m].h, wh.h, Z[m]);
+#pragma unroll
+        for (int m = 0; m < M4; ++m) Z[m] = mfma16(ah[m].h, wl.h, Z[m]);
+#pragma unroll
+        for (int m = 0; m < M4; ++m) Z[m] = mfma16(al[m].h, wh.h, Z[m]);
+        if (kb + 1 < KB) {
+#pragma unroll
+          for (int m = 0; m < M4; ++m) {
+            ah[m] = nh[m];
+            al[m] = nl[m];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wp += KB * 128;
+
+      LNZ_ACC(t_g1)
+      // ---------------- M_c fragments for all four molecules (interleaved chains) --------------
+      f32x16 Mf[M4];
+      if (is_long) {
+#pragma unroll
+        for (int m = 0; m < M4; ++m) Mf[m] = lnz::splat16(0.0f);
+#pragma unroll
+        for (int t = 0; t < KHT; ++t) {
+          if (t < KH) {
+#pragma unroll
+            for (int m = 0; m < M4; ++m) {
+              const float g = (KH * hh + t < K) ? mop[m][t] : 0.0f;
+              Mf[m] = lnz::mfma32(vreg[m][t] * g, vreg[m][t], Mf[m]);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < M4; ++m) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Mf[m][r] = mop[m][r];
+        }
+      }
+      if (c < a.n_short) {  // short diffusion: Z <- L_0^(p-1) Z
+        const int p = a.short_dist[c];
+        for (int rep = 1; rep < p; ++rep) {
+          f32x16 T[M4];
+#pragma unroll
+          for (int m = 0; m < M4; ++m) T[m] = lnz::splat16(0.0f);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int m = 0; m < M4; ++m) T[m] = lnz::mfma32(Mf[m][r], Z[m][r], T[m]);
+          }
+#pragma unroll
+          for (int m = 0; m < M4; ++m) Z[m] = T[m];
+        }
+      }
+      // ---------------- GEMM2 (exact fp32): out_m += M_c,m Z_m, four chains interleaved --------
+      // k-steps 4g..4g+3 touch node rows 8g..8g+7 only; rows beyond the largest molecule of the
+      // group are zero padding, so the group needs smax (workgroup-uniform) of the 16 steps.
+#pragma unroll
+      for (int r4 = 0; r4 < 16; r4 += 4) {
+        if (r4 < smax) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int m = 0; m < M4; ++m)
+              out[m] = lnz::mfma32(Mf[m][r4 + u], Z[m][r4 + u], out[m]);
+          }
+        }
+      }
+      LNZ_ACC(t_g2)
+    }
+
+    // ---------------- epilogue: ReLU, split, X' -> LDS (other buffer), one barrier per layer ----
+    LNZ_T0
+    const int nxt = cur ^ 1;
+#pragma unroll
+    for (int m = 0; m < M4; ++m) {
+      _Float16* xh = Xp(nxt, 0, m) + 32 * wave + j;
+      _Float16* xl = Xp(nxt, 1, m) + 32 * wave + j;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = lnz::cd_row(r, hh);
+        split_store(xh + row * P16, xl + row * P16, fmaxf(out[m][r], 0.0f));
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+    LNZ_ACC(t_ep)
+  }
+#ifdef LNZ_PROFILE_PHASES
+  if (a.state_out && lane == 0 && blockIdx.x < 8) {
+    float* d = a.state_out + ((int64_t)B * 32 * 128) + (blockIdx.x * 4 + wave) * 4;
+    d[0] = (float)t_g1; d[1] = (float)t_g2; d[2] = (float)t_ep; d[3] = (float)(clock64() - t_all);
+  }
+#endif
+
+  if (a.state_out) {
+    for (int idx = tid; idx < M4 * 32 * 128; idx += 256) {
+      int m = idx >> 12, row = (idx >> 7) & 31, col = idx & 127;
+      if (blockIdx.x * M4 + m < B)
+        a.state_out[((int64_t)mb[m] * 32 + row) * 128 + col] =
+            (float)Xp(cur, 0, m)[row * P16 + col] + (float)Xp(cur, 1, m)[row * P16 + col];
+    }
+  }
+
+  // ---- head: wave m handles molecule m (split fp16 GEMM against the packed [32,128] head) ------
+  if (blockIdx.x * M4 + wave < B) {
+    const int m = wave;
+    const int P = a.dout;
+    f32x16 acc = lnz::splat16(a.bias_head[j]);
+    const uint4* wh = reinterpret_cast<const uint4*>(a.Wp16_head) + lane;
+    const _Float16* x0 = Xp(cur, 0, m) + j * P16 + 8 * hh;
+    const _Float16* x1 = Xp(cur, 1, m) + j * P16 + 8 * hh;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      H8 xh, xl, bh, blo;
+      xh.u = *reinterpret_cast<const uint4*>(x0 + 16 * kb);
+      xl.u = *reinterpret_cast<const uint4*>(x1 + 16 * kb);
+      bh.u = wh[kb * 128];
+      blo.u = wh[kb * 128 + 64];
+      acc = mfma16(xh.h, bh.h, acc);
+      acc = mfma16(xh.h, blo.h, acc);
+      acc = mfma16(xl.h, bh.h, acc);
+    }
+    float sum = 0.0f, cnt = 0.0f;
+    const int src = 32 * hh + P;
+    const int64_t mol = mb[m];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float logit = __shfl(acc[r], src, 64);
+      float gate = 1.0f / (1.0f + __expf(-logit));
+      int row = lnz::cd_row(r, hh);
+      bool msk = row < N && a.mask[mol * N + row] != 0;
+      sum += msk ? gate * acc[r] : 0.0f;
+      cnt += msk ? 1.0f : 0.0f;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    cnt += __shfl_xor(cnt, 32, 64);
+    if (hh == 0 && j < P) a.score[mol * P + j] = sum / cnt;
+  }
+}
+
+constexpr size_t kSmemBytes = (size_t)2 * 2 * M4 * 32 * P16 * sizeof(_Float16);  // 139,264 B
+
+}  // namespace
+
+namespace lnz {
+int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s) {
+  LNZ_REQUIRE(a.dhid == 128 && a.filter_kind == 0 && a.K <= 2 * KHT && a.din0 <= 128, LNZ_ENOTSUP,
+              "lnz_lanczosnet_forward(gemm_mode=1): needs dhid=128, filter_kind=0, K<=20, din0<=128");
+  LNZ_REQUIRE(a.Wp16 && a.Wp16_head, LNZ_EINVAL,
+              "lnz_lanczosnet_forward(gemm_mode=1): Wp16 / Wp16_head missing");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lanczosnet_forward_f16x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemBytes);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(max dynamic LDS %zu): %s", kSmemBytes, hipGetErrorString(e));
+      return LNZ_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int grid = (a.B + M4 - 1) / M4;
+  hipLaunchKernelGGL(lanczosnet_forward_f16x3_kernel, dim3(grid), dim3(256), kSmemBytes, s, a);
+  return check_launch("lnz_lanczosnet_forward(f16x3)");
+}
+}  // namespace lnz

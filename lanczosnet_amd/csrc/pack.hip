@@ -56,6 +56,54 @@ extern "C" int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, 
   return lnz::check_launch("lnz_pack_rows_k8");
 }
 
+// fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order (see header)
+__global__ void pack_rows_f16x2_kernel(const float* __restrict__ W, int rows, int cols, int64_t ld,
+                                       int RT, int KB, uint4* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kb, lane)
+  int64_t total = (int64_t)RT * KB * 64;
+  if (idx >= total) return;
+  int lane = (int)(idx & 63);
+  int kb = (int)((idx >> 6) % KB);
+  int rt = (int)((idx >> 6) / KB);
+  int row = 32 * rt + (lane & 31);
+  int col0 = 16 * kb + 8 * (lane >> 5);
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2) {
+    unsigned short h[2], l[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int col = col0 + 2 * e2 + u;
+      float x = (row < rows && col < cols) ? W[(int64_t)row * ld + col] : 0.0f;
+      _Float16 xh = (_Float16)x;
+      _Float16 xl = (_Float16)(x - (float)xh);
+      h[u] = __builtin_bit_cast(unsigned short, xh);
+      l[u] = __builtin_bit_cast(unsigned short, xl);
+    }
+    hi[e2] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+    lo[e2] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+  }
+  int64_t base = ((int64_t)rt * KB + kb) * 2 * 64;
+  out[base + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  out[base + 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+extern "C" int64_t lnz_packed_rows_f16x2_bytes(int rows, int cols) {
+  int64_t RT = (rows + 31) / 32, KB = (cols + 15) / 16;
+  return RT * KB * 2 * 64 * 16;
+}
+
+extern "C" int lnz_pack_rows_f16x2(const float* W, int rows, int cols, int64_t ld, void* out,
+                                   lnz_stream_t stream) {
+  LNZ_REQUIRE(W && out && rows > 0 && cols > 0 && ld >= cols, LNZ_EINVAL,
+              "lnz_pack_rows_f16x2: bad arguments (rows=%d cols=%d)", rows, cols);
+  int RT = (rows + 31) / 32, KB = (cols + 15) / 16;
+  int64_t total = (int64_t)RT * KB * 64;
+  hipLaunchKernelGGL(pack_rows_f16x2_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, W, rows, cols, ld, RT, KB, (uint4*)out);
+  return lnz::check_launch("lnz_pack_rows_f16x2");
+}
+
 // bp[rt][lane][r] = bias[32 rt + cd_row(r, lane >> 5)]
 __global__ void pack_bias_rows_kernel(const float* __restrict__ bias, int rows, int RT,
                                       float* __restrict__ bp) {

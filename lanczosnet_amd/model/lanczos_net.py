@@ -14,6 +14,8 @@ LanczosNetGeneral: the forward values are the HIP kernels', the parameter gradie
 autograd recomputation in torch ops on the GPU (hand-written backward kernels are SURVEY.md §8(f)
 rank 2).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -32,6 +34,9 @@ def _opt(node, key, default):
 class _LanczosNetBase(nn.Module):
     general = False
     filter_kind = 0                      # 0: diagonal gains on Ritz vectors, 1: dense (Ada)
+    # 'fp32' (default): exact fp32 MFMA.  'f16x3': opt-in split-precision GEMM1 (x_hi w_hi + x_hi w_lo
+    # + x_lo w_hi on fp16 MFMA, fp32 accumulate; 6e-7 vs fp64, parity bar 1e-5) — see DESIGN.md §4.7
+    gemm_mode = os.environ.get('LANCZOSNET_GEMM', 'fp32')
     _spectral_hidden = _SPECTRAL_HIDDEN
 
     def _spectral_io(self):
@@ -122,7 +127,8 @@ class _LanczosNetBase(nn.Module):
 
     # -- packed-parameter plan ------------------------------------------------------------
     def _param_signature(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        return (self.gemm_mode,) + tuple((p.data_ptr(), p._version, str(p.device))
+                                         for p in self.parameters())
 
     def _check_supported(self):
         if any(d == 'inf' for d in self.short_diffusion_dist + self.long_diffusion_dist):
@@ -182,6 +188,31 @@ class _LanczosNetBase(nn.Module):
                     w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
                     bias_head=bias_head,
                     embedding=emb)
+        plan['Wp16'] = None
+        if self.gemm_mode == 'f16x3':
+            if not (self.filter_kind == 0 and dhid == 128 and self.num_eig_vec <= 20):
+                raise NotImplementedError("gemm_mode='f16x3' is built for LanczosNet with hidden "
+                                          "width 128 and num_eig_vec <= 20")
+            packs16, w16_off, off = [], [], 0
+            for t in range(self.num_layer):
+                w = self.filter[t].weight
+                d_in = w.shape[1] // n_chan
+                if d_in != 128:  # every layer consumes 128 input columns: zero-pad layer 0
+                    w = torch.nn.functional.pad(w.view(dhid, n_chan, d_in), (0, 128 - d_in))
+                    w = w.reshape(dhid, n_chan * 128)
+                pk = ops.pack_rows_f16x2(w)
+                packs16.append(pk)
+                w16_off.append(off)
+                off += pk.numel()
+            packs16.append(torch.zeros(16384, dtype=torch.uint8, device=dev))  # prefetch slack
+            plan['Wp16'] = torch.cat(packs16)
+            plan['w16_off'] = w16_off
+            plan['Wp16_head'] = ops.pack_rows_f16x2(head)
+            plan['din0'] = din0  # this kernel pads columns itself
+            if emb is not None:
+                plan['embedding'] = self.embedding.weight.detach().float().contiguous()
+        elif self.gemm_mode != 'fp32':
+            raise ValueError("gemm_mode must be 'fp32' or 'f16x3'")
         if self._has_mlp() and self.filter_kind == 0:
             size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
             buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)

@@ -109,6 +109,19 @@ def pack_rows_k8(W):
   return out
 
 
+def pack_rows_f16x2(W):
+  """[rows, cols] -> fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order (uint8 buffer)."""
+  _need_cuda(W)
+  W = _f32c(W)
+  rows, cols = W.shape
+  lib = _lib.load()
+  out = torch.empty((lib.lnz_packed_rows_f16x2_bytes(rows, cols),), dtype=torch.uint8,
+                    device=W.device)
+  with torch.cuda.device(W.device):
+    _lib.check(lib.lnz_pack_rows_f16x2(_ptr(W), rows, cols, cols, _ptr(out), _stream()))
+  return out
+
+
 def pack_bias_rows(bias):
   _need_cuda(bias)
   bias = _f32c(bias)
@@ -155,7 +168,9 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None):
   D = _f32c(D)
   B, K = D.shape
   S = len(dist)
-  G = torch.empty((num_layer, B, S, K), dtype=torch.float32, device=D.device)
+  # + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
+  Gbuf = torch.empty((num_layer * B * S * K + 16,), dtype=torch.float32, device=D.device)
+  G = Gbuf[:num_layer * B * S * K].view(num_layer, B, S, K)
   darr = (C.c_int32 * S)(*[int(x) for x in dist])
   lib = _lib.load()
   with torch.cuda.device(D.device):
@@ -203,11 +218,19 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
     a.w_off[i] = plan['w_off'][i]
     a.b_off[i] = plan['b_off'][i]
   a.Wp_head, a.bias_head = plan['Wp_head'].data_ptr(), plan['bias_head'].data_ptr()
+  a.gemm_mode = 1 if plan.get('Wp16') is not None else 0
+  if a.gemm_mode == 1:
+    a.Wp16, a.Wp16_head = plan['Wp16'].data_ptr(), plan['Wp16_head'].data_ptr()
+    for i in range(plan['num_layer']):
+      a.w16_off[i] = plan['w16_off'][i]
+    # group molecules of similar size: every workgroup of 4 then skips the same padded k-steps
+    order = torch.argsort(mask_u8.sum(dim=1, dtype=torch.int32)).to(torch.int32).contiguous()
+    a.order = order.data_ptr()
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
   a.score = score.data_ptr()
   state = None
   if return_state:
-    state = torch.empty((B, 32, plan['dhid']), dtype=torch.float32, device=V.device)
+    state = torch.zeros((B, 32, plan['dhid']), dtype=torch.float32, device=V.device)
     a.state_out = state.data_ptr()
   lib = _lib.load()
   with torch.cuda.device(V.device):

@@ -422,3 +422,37 @@ def test_training_gradients_match_reference_autograd():
     net.eval()
     s2 = net(*args, mask=_t(c['node_mask'][:nb]))  # repacked weights after the update
   assert torch.isfinite(s2).all() and not torch.equal(s2, score.detach())
+
+
+def test_split_precision_f16x3_mode_meets_parity_bar():
+  """Opt-in gemm_mode='f16x3' (fp16 hi/lo split GEMM1 on v_mfma_f32_32x32x16_f16): same 1e-5 bar
+  against the reference fixture and the fp64 oracle; measured deviation is reported."""
+  g = load_golden('lanczosnet_full.npz')
+  c = load_golden('collate_batch.npz')
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  P = oracle.make_lanczosnet_params(cfg, int(g['param_seed']))
+  net = _model(cfg, P)
+  args = (_t(c['node_feat']), _t(c['L']), _t(c['D']), _t(c['V']))
+  with torch.no_grad():
+    exact = net(*args, mask=_t(c['node_mask'])).cpu().numpy()
+    net.gemm_mode = 'f16x3'
+    split = net(*args, mask=_t(c['node_mask'])).cpu().numpy()
+  s64, st64 = oracle.lanczos_net_forward(P, cfg, c['node_feat'], c['L'], c['D'], c['V'],
+                                         c['node_mask'], dtype=np.float64, return_state=True)
+  print('vs fp64: exact-fp32 %.2e, f16x3 split %.2e ; split vs reference fp32 %.2e' %
+        (rel_err(exact, s64), rel_err(split, s64), rel_err(split, g['score'])))
+  assert rel_err(split, s64) < 1e-5 and rel_err(split, g['score']) < 1e-5
+  # odd batch sizes (partial last group of 4), state output, padding invariance
+  from lanczosnet_amd import ops
+  plan = net._plan()
+  for nb in (1, 5, 6, 7):
+    Lp = ops.pack_laplacian(_t(c['L'][:nb]))
+    G = ops.spectral_gains(_t(c['D'][:nb]), cfg['long_diffusion_dist'], cfg['num_layer'],
+                           plan['mlp_pack'])
+    sc, state = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(c['V'][:nb]), G,
+                                       _t(c['node_mask'][:nb]), return_state=True)
+    assert rel_err(sc.cpu().numpy(), s64[:nb]) < 1e-5, nb
+    state = state.cpu().numpy()
+    for b in range(nb):
+      n = int(c['n_nodes'][b])
+      assert rel_err(state[b, :n], st64[b, :n]) < 1e-5, (nb, b)
