@@ -456,3 +456,18 @@ def test_split_precision_f16x3_mode_meets_parity_bar():
     for b in range(nb):
       n = int(c['n_nodes'][b])
       assert rel_err(state[b, :n], st64[b, :n]) < 1e-5, (nb, b)
+
+
+def test_device_collate_from_raw_adjacency():
+  from lanczosnet_amd.dataset import collate_adjacency
+  g = load_golden('collate_batch.npz')
+  b = draw_batch(int(g['batch_size']), seed=int(g['seed']), n_min=int(g['n_min']),
+                 n_max=int(g['n_max']))
+  items = [dict(adjs=b['adjs'][i, :int(n), :int(n)], node_feat=b['node_feat'][i, :int(n)],
+                label=b['label'][i:i + 1]) for i, n in enumerate(b['n_nodes'])]
+  out = collate_adjacency(items, 20, DEV)
+  np.testing.assert_array_equal(out['node_feat'].cpu().numpy(), g['node_feat'])
+  np.testing.assert_array_equal(out['node_mask'].cpu().numpy(), g['node_mask'])
+  assert np.abs(out['L'].cpu().numpy() - g['L']).max() < 1e-7
+  _check_ritz(out['D'].cpu().numpy(), out['V'].cpu().numpy(), g['D'], g['V'], g['n_nodes'],
+              g['D_full'])

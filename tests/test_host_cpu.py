@@ -131,3 +131,28 @@ def test_synthetic_batch_schema():
     assert a[i, n:].sum() == 0 and a[i, :, n:].sum() == 0
     assert b['node_mask'][i].sum() == n
     assert a[i].sum() / 2 >= n - 1  # spanning tree => connected
+
+
+def test_collate_preprocessed_matches_reference_collate():
+  """Host collate of reference-format items == the reference's collate_fn output (fixture)."""
+  import oracle
+  from lanczosnet_amd.dataset import collate_preprocessed
+  from lanczosnet_amd.synthetic import draw_batch
+  g = load_golden('collate_batch.npz')
+  b = draw_batch(int(g['batch_size']), seed=int(g['seed']), n_min=int(g['n_min']),
+                 n_max=int(g['n_max']))
+  items = []
+  for i in range(len(b['n_nodes'])):
+    n = int(b['n_nodes'][i])
+    adjs = b['adjs'][i, :n, :n]
+    Lm = oracle.laplacian_multi_l4(adjs)
+    e, V, _ = oracle.graph_laplacian_eigs(adjs.sum(axis=2), graph_laplacian_type='L4')
+    items.append(dict(node_feat=b['node_feat'][i, :n], label=b['label'][i:i + 1],
+                      L_multi=Lm[:, :, 1:], L_simple_4=Lm[:, :, 0], D_simple=e, V_simple=V))
+  out = collate_preprocessed(items, 20)
+  np.testing.assert_array_equal(out['node_feat'].numpy(), g['node_feat'])
+  np.testing.assert_array_equal(out['node_mask'].numpy(), g['node_mask'])
+  np.testing.assert_array_equal(out['label'].numpy(), g['label'])
+  np.testing.assert_allclose(out['L'].numpy(), g['L'], atol=1e-7)
+  np.testing.assert_allclose(out['D'].numpy(), g['D'], atol=1e-6)
+  assert out['V'].shape == g['V'].shape
