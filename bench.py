@@ -126,7 +126,7 @@ def main():
   def step(events=None):
     if events:
       events[0].record()
-    Lp = ops.pack_laplacian(L)
+    Lp = ops.pack_laplacian_for(plan, L)
     if events:
       events[1].record()
     D, V = ops.lanczos_ritz(A, n_nodes, K)
@@ -179,7 +179,7 @@ def main():
         s2 = step()
       torch.cuda.synchronize()
       el2 = time.perf_counter() - t1
-      Lp = ops.pack_laplacian(L)
+      Lp = ops.pack_laplacian_for(plan, L)
       D, V = ops.lanczos_ritz(A, n_nodes, K)
       G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
       e0.record()

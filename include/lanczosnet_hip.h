@@ -100,6 +100,12 @@ int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_stream_t stre
 int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                        int64_t stride_ch, int B, int N, int C, float* Lp, lnz_stream_t stream);
 
+/* Same tile split into fp16 hi/lo pieces for the split-precision GEMM2 (gemm_mode = 1):
+ * Lp16[b][c][blk][piece][lane][e] = L[b][lane&31][cd_row(8*blk+e, lane>>5)][c]; B*C*4096 bytes. */
+int lnz_pack_laplacian_f16x2(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                             int64_t stride_ch, int B, int N, int C, void* Lp16,
+                             lnz_stream_t stream);
+
 /* ---- R7 (first half): per-eigenvalue spectral filter gains ----------------------------
  * G[l][b][s][k] = MLP_l([D^p_1 .. D^p_S])_s for every conv layer l — the
  * `spectral_filter[layer_idx]` Sequential (Linear S->128, ReLU, 128->128, ReLU, 128->128,
@@ -160,6 +166,7 @@ typedef struct lnz_forward_args {
   const void* Wp16;           /* packed fp16 hi/lo conv weights: layer l at (char*)Wp16 + w16_off[l] */
   int64_t w16_off[16];        /* byte offsets                                                     */
   const void* Wp16_head;      /* packed [32, 128] head                                            */
+  const void* Lp16;           /* lnz_pack_laplacian_f16x2 output (gemm_mode 1; replaces Lp there)  */
   const int32_t* order;       /* optional [B] permutation: workgroup g processes molecules
                                  order[4g..4g+3] (sort by node count so each group skips the same
                                  padded GEMM2 steps); NULL = identity.  gemm_mode 1 only          */

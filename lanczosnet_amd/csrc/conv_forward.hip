@@ -393,7 +393,8 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
               LNZ_EINVAL, "lnz_lanczosnet_forward: bad channel counts");
   LNZ_REQUIRE((a.node_feat && a.embedding && a.num_atom > 0) || a.node_feat_f, LNZ_EINVAL,
               "lnz_lanczosnet_forward: need node_feat+embedding or node_feat_f");
-  LNZ_REQUIRE(a.mask && a.Lp && a.V && a.Wp && a.bias && a.Wp_head && a.bias_head && a.score,
+  LNZ_REQUIRE(a.mask && (a.Lp || (a.gemm_mode == 1 && a.Lp16)) && a.V && a.Wp && a.bias &&
+                  a.Wp_head && a.bias_head && a.score,
               LNZ_EINVAL, "lnz_lanczosnet_forward: null tensor pointer");
   LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "lnz_lanczosnet_forward: G missing");
   hipStream_t s = (hipStream_t)stream;

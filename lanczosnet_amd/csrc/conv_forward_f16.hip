@@ -6,7 +6,9 @@
 // runs on v_mfma_f32_32x32x16_f16 (32 cycles per 32x32x16) instead of v_mfma_f32_32x32x2_f32
 // (64 cycles per 32x32x2): 3/16 of the issue cycles.  The dropped x_lo w_lo term is 2^-22 relative;
 // end-to-end deviation from fp64 is 6e-7 (exact-fp32 path: 2e-7; parity bar 1e-5).
-// GEMM2 (M_c Z_c), the L_s build and everything else stay exact fp32 exactly as in conv_forward.hip.
+// GEMM2 (M_c Z_c) uses the same split (M_c pieces pre-split by lnz_pack_laplacian_f16x2 or split from
+// the L_s registers, Z_c split from the GEMM1 accumulators); the L_s build, the head accumulation and
+// everything else stay exact fp32.
 //
 // With GEMM1 this cheap the per-CU vector-memory path becomes the limiter unless every packed
 // weight fragment is reused more: ONE workgroup per CU-sized group of FOUR molecules, four
@@ -40,6 +42,17 @@ __device__ inline void split_store(_Float16* xh, _Float16* xl, float x) {
   _Float16 h = (_Float16)x;
   *xh = h;
   *xl = (_Float16)(x - (float)h);
+}
+
+// registers [8 blk, 8 blk + 8) of a C/D tile -> fp16 hi / lo operand vectors
+__device__ inline void split8(const f32x16& v, int blk, f16x8& h, f16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = v[8 * blk + e];
+    _Float16 xh = (_Float16)x;
+    h[e] = xh;
+    l[e] = (_Float16)(x - (float)xh);
+  }
 }
 
 __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz_forward_args a) {
@@ -148,8 +161,10 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
         src = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K + KH * hh;
         stride4 = 1;
       } else {
+        // [blk][piece][lane] uint4: g = 2 blk + piece
         const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
-        src = a.Lp + (((int64_t)mb[m] * a.n_edge + e) * 256 + lane) * 4;
+        src = reinterpret_cast<const float*>(a.Lp16) +
+              (((int64_t)mb[m] * a.n_edge + e) * 256 + lane) * 4;
         stride4 = 64;
       }
 #pragma unroll
@@ -213,55 +228,80 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
       wp += KB * 128;
 
       LNZ_ACC(t_g1)
-      // ---------------- M_c fragments for all four molecules (interleaved chains) --------------
-      f32x16 Mf[M4];
+      // ---------------- M_c operand pieces (A of GEMM2), per molecule and k-block --------------
+      // long: L_s = V diag(g_s) V^T by exact fp32 MFMAs (four chains interleaved), then split;
+      // edge/short: pre-split fragments from lnz_pack_laplacian_f16x2.
+      H8 mh[M4][2], ml[M4][2];
       if (is_long) {
+        f32x16 Ls[M4];
 #pragma unroll
-        for (int m = 0; m < M4; ++m) Mf[m] = lnz::splat16(0.0f);
+        for (int m = 0; m < M4; ++m) Ls[m] = lnz::splat16(0.0f);
 #pragma unroll
         for (int t = 0; t < KHT; ++t) {
           if (t < KH) {
 #pragma unroll
             for (int m = 0; m < M4; ++m) {
               const float g = (KH * hh + t < K) ? mop[m][t] : 0.0f;
-              Mf[m] = lnz::mfma32(vreg[m][t] * g, vreg[m][t], Mf[m]);
+              Ls[m] = lnz::mfma32(vreg[m][t] * g, vreg[m][t], Ls[m]);
             }
           }
+        }
+#pragma unroll
+        for (int m = 0; m < M4; ++m) {
+          split8(Ls[m], 0, mh[m][0].h, ml[m][0].h);
+          split8(Ls[m], 1, mh[m][1].h, ml[m][1].h);
         }
       } else {
 #pragma unroll
         for (int m = 0; m < M4; ++m) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Mf[m][r] = mop[m][r];
+          for (int blk = 0; blk < 2; ++blk) {
+            mh[m][blk].u = make_uint4(__float_as_uint(mop[m][8 * blk + 0]), __float_as_uint(mop[m][8 * blk + 1]),
+                                      __float_as_uint(mop[m][8 * blk + 2]), __float_as_uint(mop[m][8 * blk + 3]));
+            ml[m][blk].u = make_uint4(__float_as_uint(mop[m][8 * blk + 4]), __float_as_uint(mop[m][8 * blk + 5]),
+                                      __float_as_uint(mop[m][8 * blk + 6]), __float_as_uint(mop[m][8 * blk + 7]));
+          }
         }
       }
-      if (c < a.n_short) {  // short diffusion: Z <- L_0^(p-1) Z
+      // ---------------- GEMM2 (split fp16): out_m += M_c,m Z_m ---------------------------------
+      // k-block 0 covers node rows 0..15, block 1 rows 16..31 (skipped when the whole group has
+      // <= 16 nodes).  Short-diffusion channels first apply M = L_0 (p-1) more times to Z.
+      const int nblk = smax > 8 ? 2 : 1;
+      if (c < a.n_short) {  // Z <- L_0^(p-1) Z
         const int p = a.short_dist[c];
         for (int rep = 1; rep < p; ++rep) {
           f32x16 T[M4];
 #pragma unroll
           for (int m = 0; m < M4; ++m) T[m] = lnz::splat16(0.0f);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int blk = 0; blk < 2; ++blk) {
+            if (blk < nblk) {
 #pragma unroll
-            for (int m = 0; m < M4; ++m) T[m] = lnz::mfma32(Mf[m][r], Z[m][r], T[m]);
+              for (int m = 0; m < M4; ++m) {
+                H8 zh, zl;
+                split8(Z[m], blk, zh.h, zl.h);
+                T[m] = mfma16(mh[m][blk].h, zh.h, T[m]);
+                T[m] = mfma16(mh[m][blk].h, zl.h, T[m]);
+                T[m] = mfma16(ml[m][blk].h, zh.h, T[m]);
+              }
+            }
           }
 #pragma unroll
           for (int m = 0; m < M4; ++m) Z[m] = T[m];
         }
       }
-      // ---------------- GEMM2 (exact fp32): out_m += M_c,m Z_m, four chains interleaved --------
-      // k-steps 4g..4g+3 touch node rows 8g..8g+7 only; rows beyond the largest molecule of the
-      // group are zero padding, so the group needs smax (workgroup-uniform) of the 16 steps.
 #pragma unroll
-      for (int r4 = 0; r4 < 16; r4 += 4) {
-        if (r4 < smax) {
+      for (int blk = 0; blk < 2; ++blk) {
+        if (blk < nblk) {
+          H8 zh[M4], zl[M4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int m = 0; m < M4; ++m) split8(Z[m], blk, zh[m].h, zl[m].h);
 #pragma unroll
-            for (int m = 0; m < M4; ++m)
-              out[m] = lnz::mfma32(Mf[m][r4 + u], Z[m][r4 + u], out[m]);
-          }
+          for (int m = 0; m < M4; ++m) out[m] = mfma16(mh[m][blk].h, zh[m].h, out[m]);
+#pragma unroll
+          for (int m = 0; m < M4; ++m) out[m] = mfma16(mh[m][blk].h, zl[m].h, out[m]);
+#pragma unroll
+          for (int m = 0; m < M4; ++m) out[m] = mfma16(ml[m][blk].h, zh[m].h, out[m]);
         }
       }
       LNZ_ACC(t_g2)
@@ -345,8 +385,8 @@ namespace lnz {
 int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s) {
   LNZ_REQUIRE(a.dhid == 128 && a.filter_kind == 0 && a.K <= 2 * KHT && a.din0 <= 128, LNZ_ENOTSUP,
               "lnz_lanczosnet_forward(gemm_mode=1): needs dhid=128, filter_kind=0, K<=20, din0<=128");
-  LNZ_REQUIRE(a.Wp16 && a.Wp16_head, LNZ_EINVAL,
-              "lnz_lanczosnet_forward(gemm_mode=1): Wp16 / Wp16_head missing");
+  LNZ_REQUIRE(a.Wp16 && a.Wp16_head && a.Lp16, LNZ_EINVAL,
+              "lnz_lanczosnet_forward(gemm_mode=1): Wp16 / Wp16_head / Lp16 missing");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lanczosnet_forward_f16x3_kernel),

@@ -167,6 +167,63 @@ __global__ __launch_bounds__(256) void pack_laplacian_kernel(
   }
 }
 
+// Lp16[b][c][blk][piece][lane] (uint4 = 8 halves): element e = L[b][lane&31][cd_row(8 blk + e, lane>>5)][c]
+// split into fp16 hi / lo — the A operand of the split-precision GEMM2 (k-order = C/D register order).
+__global__ __launch_bounds__(256) void pack_laplacian_f16x2_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    uint4* __restrict__ Lp) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const int b = blockIdx.x;
+  const float* Lb = L + (int64_t)b * sb;
+  const bool dense_cl = (sch == 1 && sc == C && sr == (int64_t)N * C);
+  const int total = N * N * C;
+  if (dense_cl) {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) tile[i] = Lb[i];
+  } else {
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      int c = i % C, m = (i / C) % N, r = i / (C * N);
+      tile[i] = Lb[r * sr + m * sc + c * sch];
+    }
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < C * 2 * 64; o += blockDim.x) {  // (c, blk, lane)
+    int lane = o & 63, blk = (o >> 6) & 1, c = o >> 7;
+    int row = lane & 31, hh = lane >> 5;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      unsigned short h[2], l[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int col = lnz::cd_row(8 * blk + 2 * e2 + u, hh);
+        float x = (row < N && col < N) ? tile[(row * N + col) * C + c] : 0.0f;
+        _Float16 xh = (_Float16)x;
+        _Float16 xl = (_Float16)(x - (float)xh);
+        h[u] = __builtin_bit_cast(unsigned short, xh);
+        l[u] = __builtin_bit_cast(unsigned short, xl);
+      }
+      hi[e2] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+      lo[e2] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+    }
+    int64_t base = (((int64_t)b * C + c) * 2 + blk) * 2 * 64;
+    Lp[base + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    Lp[base + 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+extern "C" int lnz_pack_laplacian_f16x2(const float* L, int64_t stride_b, int64_t stride_r,
+                                        int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                        void* Lp, lnz_stream_t stream) {
+  LNZ_REQUIRE(L && Lp && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS, LNZ_EINVAL,
+              "lnz_pack_laplacian_f16x2: bad arguments (B=%d C=%d)", B, C);
+  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_pack_laplacian_f16x2: N=%d > %d", N, LNZ_TILE);
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(lds <= 64 * 1024, LNZ_ENOTSUP, "lnz_pack_laplacian_f16x2: tile too large");
+  hipLaunchKernelGGL(pack_laplacian_f16x2_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, L,
+                     stride_b, stride_r, stride_c, stride_ch, N, C, (uint4*)Lp);
+  return lnz::check_launch("lnz_pack_laplacian_f16x2");
+}
+
 extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r,
                                   int64_t stride_c, int64_t stride_ch, int B, int N, int C,
                                   float* Lp, lnz_stream_t stream) {

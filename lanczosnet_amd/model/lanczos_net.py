@@ -229,7 +229,7 @@ class _LanczosNetBase(nn.Module):
     @torch.no_grad()
     def _hip_forward(self, node_feat, L, D, V, mask):
         plan = self._plan()
-        Lp = ops.pack_laplacian(L if L.dtype == torch.float32 else L.float())
+        Lp = ops.pack_laplacian_for(plan, L)
         G = None
         if self.num_scale_long > 0:
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])

@@ -146,6 +146,27 @@ def pack_laplacian(L):
   return Lp
 
 
+def pack_laplacian_f16x2(L):
+  """L [B,N,N,C] -> fp16 hi/lo A fragments of the split-precision GEMM2 (uint8 buffer)."""
+  _need_cuda(L)
+  assert L.dim() == 4 and L.dtype == torch.float32
+  B, N, _, Cn = L.shape
+  out = torch.empty((B * Cn * 4096,), dtype=torch.uint8, device=L.device)
+  sb, sr, sc, sch = L.stride()
+  lib = _lib.load()
+  with torch.cuda.device(L.device):
+    _lib.check(lib.lnz_pack_laplacian_f16x2(_ptr(L), sb, sr, sc, sch, B, N, Cn, _ptr(out),
+                                            _stream()))
+  return out
+
+
+def pack_laplacian_for(plan, L):
+  """The Laplacian pack the fused forward expects for `plan` (fp32 fragments, or fp16 hi/lo
+  fragments when the plan was built with gemm_mode='f16x3')."""
+  Lf = L if L.dtype == torch.float32 else L.float()
+  return pack_laplacian_f16x2(Lf) if plan.get('Wp16') is not None else pack_laplacian(Lf)
+
+
 def pack_spectral_mlp(linears, S, out=None):
   """linears: 4 (weight, bias) pairs of one `spectral_filter[l]` Sequential -> packed buffer."""
   lib = _lib.load()
@@ -206,7 +227,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
     a.node_feat, a.node_feat_f, a.embedding, a.num_atom = None, nf.data_ptr(), None, 0
   mask_u8 = mask.to(torch.uint8).contiguous()
   Vc = _f32c(V)
-  a.mask, a.Lp, a.V = mask_u8.data_ptr(), Lp.data_ptr(), Vc.data_ptr()
+  a.mask, a.V = mask_u8.data_ptr(), Vc.data_ptr()
+  if Lp.dtype == torch.uint8:   # split-precision fragments (pack_laplacian_f16x2)
+    a.Lp, a.Lp16 = None, Lp.data_ptr()
+  else:
+    a.Lp, a.Lp16 = Lp.data_ptr(), None
   a.filter_kind = int(plan.get('filter_kind', 0))
   if G is not None:
     want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if a.filter_kind == 1 else ())
@@ -219,6 +244,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
     a.b_off[i] = plan['b_off'][i]
   a.Wp_head, a.bias_head = plan['Wp_head'].data_ptr(), plan['bias_head'].data_ptr()
   a.gemm_mode = 1 if plan.get('Wp16') is not None else 0
+  assert (a.gemm_mode == 1) == (Lp.dtype == torch.uint8), 'Lp pack does not match gemm_mode'
   if a.gemm_mode == 1:
     a.Wp16, a.Wp16_head = plan['Wp16'].data_ptr(), plan['Wp16_head'].data_ptr()
     for i in range(plan['num_layer']):

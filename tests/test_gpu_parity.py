@@ -446,7 +446,7 @@ def test_split_precision_f16x3_mode_meets_parity_bar():
   from lanczosnet_amd import ops
   plan = net._plan()
   for nb in (1, 5, 6, 7):
-    Lp = ops.pack_laplacian(_t(c['L'][:nb]))
+    Lp = ops.pack_laplacian_for(plan, _t(c['L'][:nb]))
     G = ops.spectral_gains(_t(c['D'][:nb]), cfg['long_diffusion_dist'], cfg['num_layer'],
                            plan['mlp_pack'])
     sc, state = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(c['V'][:nb]), G,
