@@ -15,6 +15,7 @@ autograd recomputation in torch ops on the GPU (hand-written backward kernels ar
 rank 2).
 """
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -130,16 +131,20 @@ class _LanczosNetBase(nn.Module):
         return (self.gemm_mode,) + tuple((p.data_ptr(), p._version, str(p.device))
                                          for p in self.parameters())
 
+    def _fused_supported(self):
+        """True when the fused MFMA kernel is built for this architecture (uniform hidden width
+        64 or 128, input width <= 128, head width <= 31)."""
+        hid = set(self.hidden_dim[:self.num_layer])
+        return (len(hid) == 1 and next(iter(hid)) in (64, 128) and self.input_dim <= 128
+                and self.output_dim <= 31)
+
     def _check_supported(self):
         if any(d == 'inf' for d in self.short_diffusion_dist + self.long_diffusion_dist):
             raise NotImplementedError("diffusion distance 'inf' is not built in the HIP path")
-        hid = set(self.hidden_dim[:self.num_layer])
-        if len(hid) != 1 or next(iter(hid)) not in (64, 128):
+        if not self._fused_supported():
             raise NotImplementedError(
-                'HIP path is built for a uniform hidden width of 64 or 128, got %r' %
-                (self.hidden_dim,))
-        if self.input_dim > 128:
-            raise NotImplementedError('input_dim must be <= 128')
+                'fused kernel is built for a uniform hidden width of 64 or 128, input width <= 128, '
+                'got hidden_dim=%r input_dim=%r' % (self.hidden_dim, self.input_dim))
 
     @torch.no_grad()
     def _plan(self):
@@ -349,7 +354,15 @@ class _LanczosNetBase(nn.Module):
         (long) [General: B x N x D float], L B x N x N x (E+1), D B x K, V B x N x K,
         label B x P, mask B x N.  Returns score, or (score, loss) when `label` is given."""
         self._guard_forward(L, mask)
-        if L.shape[1] > 32:
+        if any(d == 'inf' for d in self.short_diffusion_dist + self.long_diffusion_dist):
+            raise NotImplementedError("diffusion distance 'inf' is not built in the HIP path")
+        if L.shape[1] > 32 or not self._fused_supported():
+            if L.shape[1] <= 32 and not getattr(self, '_warned_library_path', False):
+                warnings.warn('lanczosnet_amd: hidden_dim=%r / input_dim=%r is outside the fused MFMA '
+                              'kernel (uniform width 64 or 128): using the device library-GEMM path '
+                              '(hipBLASLt conv + HIP spectral gains), which is slower'
+                              % (self.hidden_dim, self.input_dim))
+                self._warned_library_path = True
             score = self._large_graph_forward(node_feat, L, D, V, mask)
         elif self._needs_grad():
             # training (runner/qm8_runner.py:216-248): forward = HIP kernels, backward = autograd

@@ -17,7 +17,7 @@ for B in (1024,):
   t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
   n = t(b['n_nodes']); L = ops.laplacian_l4(t(b['adjs']), n)
   D, V = ops.lanczos_ritz(L[..., 0], n, 20)
-  plan = net._plan(); Lp = ops.pack_laplacian(L)
+  plan = net._plan(); Lp = ops.pack_laplacian_for(plan, L)
   G = ops.spectral_gains(D, cfg['long_diffusion_dist'], 7, plan['mlp_pack'])
   # state buffer with room for the phase record behind it
   import lanczosnet_amd.ops as o
