@@ -476,3 +476,33 @@ def test_device_collate_from_raw_adjacency():
   assert np.abs(out['L'].cpu().numpy() - g['L']).max() < 1e-7
   _check_ritz(out['D'].cpu().numpy(), out['V'].cpu().numpy(), g['D'], g['V'], g['n_nodes'],
               g['D_full'])
+
+
+@pytest.mark.parametrize('N,K,dh,B,short', [(32, 32, 128, 3, []), (32, 20, 128, 1, [2]), (5, 3, 64, 7, []),
+                                             (32, 24, 64, 2, [1, 2]), (17, 20, 128, 5, [])])
+def test_forward_edge_shapes(N, K, dh, B, short):
+  """Full 32-node tiles, K up to 32 (KHT=16 kernels), single molecule, tiny graphs, width 64,
+  short-diffusion powers — fused exact kernel vs the fp64 oracle."""
+  cfg = dict(num_atom=9, num_bond_type=3, short_diffusion_dist=short, long_diffusion_dist=[1, 2, 4],
+             num_eig_vec=K, spectral_filter_kind='MLP', input_dim=32, hidden_dim=[dh, dh],
+             output_dim=5, num_layer=2)
+  P = oracle.make_lanczosnet_params(cfg, 100 + N + K)
+  b = draw_batch(B, seed=N * 7 + K, n_min=max(1, N - 6), n_max=N, N=N, num_atom=9, num_bond_type=3,
+                 num_label=5)
+  L = np.zeros((B, N, N, 4), np.float32)
+  Dl, Vl = [], []
+  for i in range(B):
+    n = int(b['n_nodes'][i])
+    L[i, :n, :n] = oracle.laplacian_multi_l4(b['adjs'][i, :n, :n])
+    e, V, _ = oracle.graph_laplacian_eigs(b['adjs'][i, :n, :n].sum(axis=2), graph_laplacian_type='L4')
+    Dl.append(e); Vl.append(V)
+  D, V = oracle.collate_eigs(Dl, Vl, N, K)
+  ref = oracle.lanczos_net_forward(P, cfg, b['node_feat'], L, D, V, b['node_mask'], dtype=np.float64)
+  net = _model(cfg, P)
+  with torch.no_grad():
+    score = net(_t(b['node_feat']), _t(L), _t(D), _t(V), mask=_t(b['node_mask'])).cpu().numpy()
+  assert rel_err(score, ref) < 1e-5
+  # the device Ritz pairs for the same shapes (full tiles, n up to 32)
+  from lanczosnet_amd import ops
+  Dd, Vd = ops.lanczos_ritz(_t(L)[:, :, :, 0], _t(b['n_nodes']), K)
+  _check_ritz(Dd.cpu().numpy(), Vd.cpu().numpy(), D, V, b['n_nodes'], None, K=K)
