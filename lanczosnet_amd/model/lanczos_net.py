@@ -96,11 +96,6 @@ class _LanczosNetBase(nn.Module):
                                'module and its inputs to cuda (no CPU fallback)')
         if self.training and self.dropout > 0.0:
             raise NotImplementedError('dropout > 0 in training mode is not built in the HIP path')
-        if self._needs_grad() and self.filter_kind != 0:
-            raise NotImplementedError(
-                'lanczosnet_amd: AdaLanczosNet has no backward yet (forward-only); call under '
-                'torch.no_grad() or model.eval()')
-
     def _needs_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
@@ -452,13 +447,27 @@ class AdaLanczosNet(_LanczosNetBase):
         self._guard_forward(L, mask)
         if self.num_scale_long == 0:
             raise NotImplementedError('AdaLanczosNet without long-diffusion scales is not built')
+        if not self._fused_supported() or L.shape[1] > 32:
+            raise NotImplementedError('AdaLanczosNet HIP path needs hidden width 64/128 and N <= 32')
+        B, N = node_feat.shape[0], node_feat.shape[1]
+        # same RNG consumption as the reference: CPU generator, shape (B, N, 1) (:161)
+        q1 = torch.randn(B, N, 1).to(L.device)
+        if self._needs_grad():
+            score = _AdaLanczosNetFunction.apply(self, node_feat, L, mask, q1,
+                                                 *[p for p in self.parameters()])
+        else:
+            score = self._hip_forward_ada(node_feat, L, mask, q1)
+        if label is not None:
+            return score, self.loss_func(score, label)
+        return score
+
+    @torch.no_grad()
+    def _hip_forward_ada(self, node_feat, L, mask, q1):
         B, N = node_feat.shape[0], node_feat.shape[1]
         K, S = self.num_eig_vec, self.num_scale_long
         with torch.no_grad():
             plan = self._plan()
             Lf = L if L.dtype == torch.float32 else L.float()
-            # same RNG consumption as the reference: CPU generator, shape (B, N, 1) (:161)
-            q1 = torch.randn(B, N, 1).to(L.device)
             Le = ops.ada_graph_laplacian(node_feat, self.embedding.weight, Lf[:, :, :, 0])
             T, Q = ops.ada_lanczos_layer(Le, mask, q1, K)
             tcat = ops.ada_t_powers(T, self.long_diffusion_dist).view(B, -1)
@@ -466,7 +475,114 @@ class AdaLanczosNet(_LanczosNetBase):
             for t, seq in enumerate(self.spectral_filter):
                 ops.ada_symmetrize_filters(seq(tcat), K, S, out=DDp[t])  # hipBLASLt GEMMs
             Lp = ops.pack_laplacian(Lf)
-            score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask)
-        if label is not None:
-            return score, self.loss_func(score, label)
-        return score
+            return ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask)
+
+    def _torch_forward_ada(self, node_feat, L, mask, q1):
+        """Differentiable torch restatement (device tensors, batched, no Python loops over the
+        batch) of model/ada_lanczos_net.py:101-368 incl. the quirks of `_lanczos_layer` — used ONLY
+        inside backward; forward values always come from the HIP kernels."""
+        eps = 1.1920928955078125e-07
+        B, N = node_feat.shape
+        K, S = self.num_eig_vec, self.num_scale_long
+        Lf = L.float()
+        state = self.embedding(node_feat)
+        # learned Laplacian (:101-137)
+        adj = (Lf[:, :, :, 0] != 0).float()
+        diff = state.unsqueeze(1) - state.unsqueeze(2)          # [B, i, j, D] = x_j - x_i
+        dist2 = (diff * diff).sum(dim=3)
+        sigma2 = dist2.reshape(B, -1).mean(dim=1).view(B, 1, 1)
+        A = torch.exp(-dist2 / sigma2) * adj
+        row_sum = A.sum(dim=2, keepdim=True)
+        Dg = 1.0 / (row_sum + (row_sum == 0).float()).pow(0.5)
+        Le = Dg * A * Dg.transpose(1, 2)
+        # Lanczos layer (:139-247)
+        m = (mask != 0).float().unsqueeze(2)
+        Tit = min(N, K)
+        q = q1.float() * m
+        q = q / torch.norm(q, 2, dim=1, keepdim=True)
+        Qs, alphas, betas, valids = [torch.zeros_like(q), q], [], [torch.zeros(B, 1, 1, device=L.device)], []
+        for ii in range(1, Tit + 1):
+            z = torch.bmm(Le, Qs[ii])
+            alpha = (Qs[ii] * z).sum(dim=1, keepdim=True)
+            z = z - alpha * Qs[ii] - betas[ii - 1] * Qs[ii - 1]
+            if ii > 1:
+                for _ in range(2):
+                    for jj in range(1, ii):
+                        z = z - (z * Qs[jj]).sum(dim=1, keepdim=True) / (
+                            (Qs[jj] * Qs[jj]).sum(dim=1, keepdim=True) + eps) * Qs[jj]
+            beta = torch.norm(z, p=2, dim=1, keepdim=True)
+            ok = (beta >= 1.0e-4).float()
+            valids.append(ok if ii == 1 else valids[-1] * ok)
+            Qs.append((z * valids[-1]) / (beta + eps))
+            alphas.append(alpha)
+            betas.append(beta)
+        alpha = torch.cat(alphas, dim=1).squeeze(2)
+        beta = torch.cat(betas[1:-1], dim=1).squeeze(2) if Tit > 1 else alpha[:, :0]
+        valid = torch.cat(valids, dim=1).squeeze(2)
+        idx = torch.minimum(valid.sum(dim=1), m.squeeze(2).sum(dim=1)).long()
+        valid = valid * (torch.arange(Tit, device=L.device)[None, :] < idx[:, None]).float()
+        alpha = alpha * valid
+        beta = beta * valid[:, :-1]
+        T = torch.diag_embed(alpha) + torch.diag_embed(beta, offset=1) + torch.diag_embed(beta, offset=-1)
+        Q = torch.cat(Qs[1:-1], dim=2) * valid.unsqueeze(1)
+        Q = Q * (torch.arange(N, device=L.device)[None, :] < idx[:, None]).float().unsqueeze(2)
+        if Tit < K:
+            T = torch.nn.functional.pad(T, (0, K - Tit, 0, K - Tit))
+            Q = torch.nn.functional.pad(Q, (0, K - Tit))
+        # T powers (:262-270)
+        T_list, TT = [], T
+        for ii in range(1, self.max_long_diffusion_dist + 1):
+            if ii in self.long_diffusion_dist:
+                T_list.append(TT)
+            TT = torch.bmm(TT, T)
+        tcat = torch.cat(T_list, dim=2).view(B, -1)
+        Lc = Lf.permute(0, 3, 1, 2).contiguous()
+        Qt = Q.transpose(1, 2)
+        for t in range(self.num_layer):
+            DD = self.spectral_filter[t](tcat).view(B, K, K, S)
+            DD = (DD + DD.transpose(1, 2)) * 0.5
+            W, bias = self.filter[t].weight, self.filter[t].bias
+            d_in = state.shape[2]
+            Wc = W.view(W.shape[0], -1, d_in)
+            Z = torch.einsum('bnd,ocd->bcno', state, Wc)
+            out = bias.view(1, 1, -1).expand(B, N, -1)
+            c = 0
+            for p in self.short_diffusion_dist:
+                z = Z[:, c]
+                for _ in range(p):
+                    z = torch.bmm(Lc[:, 0], z)
+                out = out + z
+                c += 1
+            for s_ in range(S):
+                out = out + torch.bmm(Q, torch.bmm(DD[:, :, :, s_], torch.bmm(Qt, Z[:, c])))
+                c += 1
+            for e in range(self.num_edgetype + 1):
+                out = out + torch.bmm(Lc[:, e], Z[:, c])
+                c += 1
+            state = torch.relu(out)
+        y = self.filter[-1](state) * self.att_func(state)
+        return (y * m).sum(dim=1) / m.sum(dim=1)
+
+
+class _AdaLanczosNetFunction(torch.autograd.Function):
+    """forward: HIP kernels (+ hipBLASLt filter MLPs); backward: autograd through
+    `_torch_forward_ada` with the SAME start vector q1."""
+
+    @staticmethod
+    def forward(ctx, module, node_feat, L, mask, q1, *params):
+        ctx.module = module
+        ctx.save_for_backward(node_feat, L, mask, q1)
+        return module._hip_forward_ada(node_feat, L, mask, q1)
+
+    @staticmethod
+    def backward(ctx, grad_score):
+        module = ctx.module
+        node_feat, L, mask, q1 = ctx.saved_tensors
+        params = [p for p in module.parameters()]
+        with torch.enable_grad():
+            score = module._torch_forward_ada(node_feat, L, mask, q1)
+            need = [p for p in params if p.requires_grad]
+            grads = torch.autograd.grad(score, need, grad_score.contiguous(), allow_unused=True)
+        it = iter(grads)
+        out = [next(it) if p.requires_grad else None for p in params]
+        return (None, None, None, None, None) + tuple(out)

@@ -251,9 +251,23 @@ def main():
       sa = neta(data['node_feat'][:nb], data['L'][:nb], mask=data['node_mask'][:nb].bool())
   finally:
     torch.randn = real_randn
+  # training parity: reference loss.backward() gradient statistics (same start vector)
+  neta.train()
+  torch.randn = lambda *a, **k: torch.from_numpy(q1a.copy())
+  try:
+    _, la = neta(data['node_feat'][:nb], data['L'][:nb], label=data['label'][:nb],
+                 mask=data['node_mask'][:nb].bool())
+  finally:
+    torch.randn = real_randn
+  la.backward()
+  gda = dict(neta.named_parameters())
+  gnames = sorted(gda.keys())
   np.savez_compressed(os.path.join(HERE, 'ada_full.npz'), cfg_json=np.array(repr(ada2)),
-                      param_seed=31, nb=nb, q1=q1a[:, :, 0], score=sa.numpy())
-  del neta, Pa
+                      param_seed=31, nb=nb, q1=q1a[:, :, 0], score=sa.numpy(), loss=float(la),
+                      gnames=np.array(gnames),
+                      gsum=np.array([float(gda[k].grad.double().sum()) for k in gnames]),
+                      gabs=np.array([float(gda[k].grad.double().abs().sum()) for k in gnames]))
+  del neta, Pa, gda
 
   # ---- 6c. MAE gate: the runner's weighted MAE (runner/qm8_runner.py:156-160:
   #          |pred - label| * std, masked by label_weight, averaged) of the REFERENCE LanczosNet on a

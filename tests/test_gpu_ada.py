@@ -143,3 +143,35 @@ def test_ada_module_surface():
   assert {'embedding.weight', 'filter.0.weight', 'filter.1.bias', 'spectral_filter.0.0.weight',
           'spectral_filter.0.6.bias', 'att_func.0.weight'} <= keys
   assert net.state_dict()['spectral_filter.0.0.weight'].shape == (4096, 2000)
+
+
+def test_ada_training_gradients_match_reference_autograd():
+  """AdaLanczosNet loss.backward() (HIP forward + torch recomputation backward, same q1) against
+  the reference's parameter-gradient statistics (tests/golden/ada_full.npz)."""
+  g = load_golden('ada_full.npz')
+  c = load_golden('collate_batch.npz')
+  cfg = ast.literal_eval(str(g['cfg_json']))
+  nb = int(g['nb'])
+  P = oracle.make_ada_params(cfg, int(g['param_seed']))
+  net = _ada_model(cfg, P).train()
+  real_randn = torch.randn
+  q1 = torch.from_numpy(g['q1'][:, :, None].copy())
+  torch.randn = lambda *a, **k: q1.clone()
+  try:
+    score, loss = net(_t(c['node_feat'][:nb]), _t(c['L'][:nb]), label=_t(c['label'][:nb]),
+                      mask=_t(c['node_mask'][:nb]))
+  finally:
+    torch.randn = real_randn
+  assert abs(float(loss.detach()) - float(g['loss'])) < 5e-3 * abs(float(g['loss']))
+  loss.backward()
+  gd = dict(net.named_parameters())
+  worst = 0.0
+  for k, gs, ga in zip(g['gnames'], g['gsum'], g['gabs']):
+    gr = gd[str(k)].grad
+    assert gr is not None, k
+    # fp32 Lanczos noise floor (see the forward tests): gradients agree to ~1e-3 of their mass
+    e = abs(float(gr.double().abs().sum()) - float(ga)) / (float(ga) + 1e-12)
+    worst = max(worst, e)
+    assert e < 2e-2, (k, e)
+    assert abs(float(gr.double().sum()) - float(gs)) < 2e-2 * float(ga) + 1e-9, k
+  print('worst relative gradient-mass deviation %.2e' % worst)
