@@ -61,6 +61,13 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
                      const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                      int32_t* info, lnz_stream_t stream);
 
+/* ---- R6 standalone: batched symmetric tridiagonal eigensolver --------------------------------
+ * The step the reference leaves to LAPACK (inside np.linalg.eigh, utils/data_helper.py:201) /
+ * ARPACK (:208).  diag [B,M], offdiag [B,M-1] (fp64) -> R [B,M] ascending, Bm [B,M,M] with
+ * eigenvectors in columns.  Implicit-shift QL (tql2 recurrences), M <= 64. */
+int lnz_tridiag_eigh(const double* diag, const double* offdiag, int B, int M, double* R,
+                     double* Bm, lnz_stream_t stream);
+
 /* ---- R2 + R6, large graphs (BASELINE config 5: N = 2048, K = 64) -------------------------------
  * M-step Lanczos (full re-orthogonalisation, CGS2; stops early if the Krylov space becomes
  * invariant) -> QL on the M x M tridiagonal -> Ritz vectors V = Q S, top-K by |theta|, zero

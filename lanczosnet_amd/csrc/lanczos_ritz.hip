@@ -662,3 +662,117 @@ extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride
   }
   return lnz::check_launch("lnz_lanczos_ritz");
 }
+
+// ---------------------------------------------------------------------------------------------
+// R6 standalone: eigendecomposition of a batch of symmetric tridiagonal matrices (the step the
+// reference leaves to LAPACK / ARPACK).  One wavefront per matrix, M <= 64; same tql2 recurrences
+// as the fused kernels, eigenvectors accumulated from the identity.  Output ascending (LAPACK
+// convention): R [B,M], Bm [B,M,M] with columns = eigenvectors (Bm[b][i][k] = component i of k).
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void tridiag_eigh_kernel(const double* __restrict__ diag,
+                                                          const double* __restrict__ offd, int M,
+                                                          double* __restrict__ R,
+                                                          double* __restrict__ Bm) {
+  constexpr int NMAX = 64, LD = NMAX + 2;
+  __shared__ double Qt[NMAX * LD];
+  __shared__ double dd[NMAX], ee[NMAX];
+  __shared__ int perm[NMAX];
+  const int b = blockIdx.x, lane = threadIdx.x, n = M;
+  for (int idx = lane; idx < NMAX * LD; idx += 64) {
+    int i = idx / LD, r = idx - i * LD;
+    Qt[idx] = (i == r) ? 1.0 : 0.0;
+  }
+  dd[lane] = lane < n ? diag[(int64_t)b * M + lane] : 0.0;
+  ee[lane] = lane < n - 1 ? offd[(int64_t)b * (M - 1) + lane] : 0.0;
+  __syncthreads();
+  double f = 0.0, tst1 = 0.0;
+  for (int l = 0; l < n; ++l) {
+    tst1 = fmax(tst1, fabs(dd[l]) + fabs(ee[l]));
+    int m = l;
+    while (m < n - 1 && fabs(ee[m]) > kEps * tst1) ++m;
+    if (m > l) {
+      int iter = 0;
+      double el;
+      do {
+        ++iter;
+        double g = dd[l];
+        el = ee[l];
+        double p = (dd[l + 1] - g) / (2.0 * el);
+        double rr = sqrt(p * p + 1.0);
+        if (p < 0) rr = -rr;
+        const double dl = el / (p + rr), dl1 = el * (p + rr), hh = g - dl;
+        __syncthreads();
+        if (lane == 0) {
+          dd[l] = dl;
+          dd[l + 1] = dl1;
+        }
+        if (lane >= l + 2 && lane < n) dd[lane] -= hh;
+        __syncthreads();
+        f += hh;
+        p = dd[m];
+        double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+        const double el1 = ee[l + 1];
+        double carry = Qt[m * LD + lane];
+        for (int i = m - 1; i >= l; --i) {
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          const double ei = ee[i], di = dd[i];
+          g = c * ei;
+          const double hp = c * p;
+          const double tt = fma(p, p, ei * ei);
+          const double rinv = rsqrt(tt), rad = tt * rinv;
+          const double e_next = s * rad;
+          s = ei * rinv;
+          c = p * rinv;
+          p = c * di - s * g;
+          const double d_next = hp + s * (c * g + s * di);
+          ee[i + 1] = e_next;  // every lane stores the same value
+          dd[i + 1] = d_next;
+          const double z0 = Qt[i * LD + lane];
+          Qt[(i + 1) * LD + lane] = s * z0 + c * carry;
+          carry = c * z0 - s * carry;
+        }
+        Qt[l * LD + lane] = carry;
+        p = -s * s2 * c3 * el1 * ee[l] / dl1;
+        el = s * p;
+        __syncthreads();
+        if (lane == 0) {
+          ee[l] = el;
+          dd[l] = c * p;
+        }
+        __syncthreads();
+      } while (fabs(el) > kEps * tst1 && iter < 60);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      dd[l] = dd[l] + f;
+      ee[l] = 0.0;
+    }
+    __syncthreads();
+  }
+  if (lane < n) {  // ascending order
+    double di = dd[lane];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (dd[j] < di || (dd[j] == di && j < lane)) ? 1 : 0;
+    perm[rank] = lane;
+  }
+  __syncthreads();
+  if (lane < n) R[(int64_t)b * M + lane] = dd[perm[lane]];
+  for (int idx = lane; idx < n * n; idx += 64) {
+    int i = idx / n, k = idx - i * n;
+    Bm[(int64_t)b * M * M + idx] = Qt[perm[k] * LD + i];
+  }
+}
+}  // namespace
+
+extern "C" int lnz_tridiag_eigh(const double* diag, const double* offdiag, int B, int M, double* R,
+                                double* Bm, lnz_stream_t stream) {
+  LNZ_REQUIRE(diag && R && Bm && B > 0 && M > 0 && (offdiag || M == 1), LNZ_EINVAL,
+              "lnz_tridiag_eigh: bad arguments (B=%d M=%d)", B, M);
+  LNZ_REQUIRE(M <= 64, LNZ_ENOTSUP, "lnz_tridiag_eigh: M=%d > 64", M);
+  hipLaunchKernelGGL(tridiag_eigh_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, diag, offdiag,
+                     M, R, Bm);
+  return lnz::check_launch("lnz_tridiag_eigh");
+}

@@ -74,6 +74,21 @@ def lanczos_ritz(A, n_nodes, K, return_info=False):
   return (D, V, info) if return_info else (D, V)
 
 
+def tridiag_eigh(diag, offdiag):
+  """Batched symmetric tridiagonal eigensolver: diag [B,M], offdiag [B,M-1] (float64)
+  -> R [B,M] ascending, Bm [B,M,M] (columns = eigenvectors), like numpy.linalg.eigh."""
+  _need_cuda(diag, offdiag)
+  d = diag.to(torch.float64).contiguous()
+  e = offdiag.to(torch.float64).contiguous()
+  B, M = d.shape
+  R = torch.empty((B, M), dtype=torch.float64, device=d.device)
+  Bm = torch.empty((B, M, M), dtype=torch.float64, device=d.device)
+  lib = _lib.load()
+  with torch.cuda.device(d.device):
+    _lib.check(lib.lnz_tridiag_eigh(_ptr(d), _ptr(e), B, M, _ptr(R), _ptr(Bm), _stream()))
+  return R, Bm
+
+
 def lanczos_ritz_large(A, M, K, workspace=None, return_info=False):
   """M-step Lanczos Ritz pairs for large dense graphs (N <= 2048, rows contiguous).
   A [B,N,N] float32 -> D [B,K], V [B,N,K].  `workspace`: optional reusable uint8 CUDA tensor of

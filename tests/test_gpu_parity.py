@@ -506,3 +506,26 @@ def test_forward_edge_shapes(N, K, dh, B, short):
   from lanczosnet_amd import ops
   Dd, Vd = ops.lanczos_ritz(_t(L)[:, :, :, 0], _t(b['n_nodes']), K)
   _check_ritz(Dd.cpu().numpy(), Vd.cpu().numpy(), D, V, b['n_nodes'], None, K=K)
+
+
+@pytest.mark.parametrize('M', [1, 2, 7, 20, 33, 64])
+def test_tridiag_eigh_standalone(M):
+  """R6: tridiagonal eigensolve vs numpy.linalg.eigh(T) in fp64: eigenvalues 1e-12,
+  |T B - B diag(R)| and |B^T B - I| at fp64 round-off; includes zero off-diagonals (split blocks)."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(M)
+  B = 9
+  d = rs.randn(B, M)
+  e = rs.randn(B, max(M - 1, 0))
+  if M > 3:
+    e[0, M // 2] = 0.0          # reducible: two blocks
+    e[1, :] = 1e-3 * e[1, :]    # nearly diagonal
+    d[2, :] = 0.5               # constant diagonal
+  R, Bm = ops.tridiag_eigh(_t(d), _t(e) if M > 1 else torch.zeros((B, 0), dtype=torch.float64, device=DEV))
+  R, Bm = R.cpu().numpy(), Bm.cpu().numpy()
+  for b in range(B):
+    T = np.diag(d[b]) + (np.diag(e[b], 1) + np.diag(e[b], -1) if M > 1 else 0)
+    ref = np.linalg.eigvalsh(T)
+    assert np.abs(R[b] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    assert np.abs(T @ Bm[b] - Bm[b] * R[b][None, :]).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    assert np.abs(Bm[b].T @ Bm[b] - np.eye(M)).max() < 1e-12
