@@ -168,7 +168,8 @@ typedef struct lnz_forward_args {
    * x_lo w_hi with fp16 pieces on v_mfma_f32_32x32x16_f16 (fp32 accumulate): 2^-22 relative
    * operand precision, measured 6e-7 end-to-end vs fp64 (fp32 MFMA path: 2e-7).  Needs dhid == 128,
    * filter_kind == 0, K <= 20, din0 <= 128; packs from lnz_pack_rows_f16x2 with the layer-0 input
-   * width zero-padded to 128.  gemm_mode = 0 (default) is the exact fp32 path. */
+   * width zero-padded to 128 and 16 KiB of slack behind the last layer; G followed by 64 B of
+   * slack (gains are read as whole dwordx4 groups).  gemm_mode = 0 (default) is the exact fp32 path. */
   int32_t gemm_mode;
   const void* Wp16;           /* packed fp16 hi/lo conv weights: layer l at (char*)Wp16 + w16_off[l] */
   int64_t w16_off[16];        /* byte offsets                                                     */
