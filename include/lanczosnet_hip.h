@@ -175,11 +175,18 @@ typedef struct lnz_forward_args {
   int64_t w16_off[16];        /* byte offsets                                                     */
   const void* Wp16_head;      /* packed [32, 128] head                                            */
   const void* Lp16;           /* lnz_pack_laplacian_f16x2 output (gemm_mode 1; replaces Lp there)  */
-  const int32_t* order;       /* optional [B] permutation: workgroup g processes molecules
-                                 order[4g..4g+3] (sort by node count so each group skips the same
-                                 padded GEMM2 steps); NULL = identity.  gemm_mode 1 only          */
+  const int32_t* order;       /* optional [B] permutation (lnz_balanced_order): workgroup g processes
+                                 molecules order[g*m .. g*m+m-1], m = 2 (gemm_mode 0) or 4 (mode 1);
+                                 NULL = identity.  Results do not depend on it, only the time.     */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
+/* Load-balancing permutation for lnz_forward_args.order: deals the batch, sorted by node count
+ * (row sums of mask [B,N] u8), into consecutive groups of `group` (even) molecules holding
+ * group/2 from the small end and the rest from the large end, so every workgroup skips the same
+ * amount of zero-padded work.  No reference counterpart (the reference pads every molecule to N,
+ * dataset/qm8.py:232-262).  order: [B] int32. */
+int lnz_balanced_order(const uint8_t* mask, int B, int N, int group, int32_t* order,
+                       lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);

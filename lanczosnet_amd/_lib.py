@@ -61,6 +61,7 @@ SIGNATURES = {
     'lnz_pack_rows_f16x2': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_pack_bias_rows': (C.c_int, [_P, _I, _P, _P]),
     'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
+    'lnz_balanced_order': (C.c_int, [_P, _I, _I, _I, _P, _P]),
     'lnz_pack_laplacian_f16x2': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),
     'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),

@@ -61,11 +61,15 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
   const int N = a.N, K = a.K, B = a.B;
   const int dhid = a.dhid;
   const int C = a.n_short + a.n_long + a.n_edge;
-  int mb[MOLS];  // molecule ids (an odd batch repeats the last molecule; its result is dropped)
+  // molecule ids (an odd batch repeats the last one; its result is dropped).  a.order: optional
+  // permutation that pairs a small with a large molecule so that all workgroups skip the same
+  // amount of padded GEMM2 work (the launch is one round: its time is the slowest workgroup's).
+  int mb[MOLS];
 #pragma unroll
   for (int m = 0; m < MOLS; ++m) {
     int x = blockIdx.x * MOLS + m;
-    mb[m] = x < B ? x : B - 1;
+    x = x < B ? x : B - 1;
+    mb[m] = a.order ? a.order[x] : x;
   }
 
   // ---- embedding gather (model/lanczos_net.py:154) / float features (lanczos_net_general.py:156)

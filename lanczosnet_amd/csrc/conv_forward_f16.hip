@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
     for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
     g2steps[m] = __builtin_amdgcn_readfirstlane(((last + 7) >> 3) * 4);
   }
-  int smax = g2steps[0];
+  int nblkm[M4];  // k-blocks of GEMM2 a molecule needs: block 1 covers node rows 16..31
 #pragma unroll
-  for (int m = 1; m < M4; ++m) smax = g2steps[m] > smax ? g2steps[m] : smax;
+  for (int m = 0; m < M4; ++m) nblkm[m] = g2steps[m] > 8 ? 2 : 1;
 
   const int KH = (K + 1) >> 1;
   float vreg[M4][KHT];
@@ -264,9 +264,8 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
         }
       }
       // ---------------- GEMM2 (split fp16): out_m += M_c,m Z_m ---------------------------------
-      // k-block 0 covers node rows 0..15, block 1 rows 16..31 (skipped when the whole group has
+      // k-block 0 covers node rows 0..15, block 1 rows 16..31 (skipped per molecule when it has
       // <= 16 nodes).  Short-diffusion channels first apply M = L_0 (p-1) more times to Z.
-      const int nblk = smax > 8 ? 2 : 1;
       if (c < a.n_short) {  // Z <- L_0^(p-1) Z
         const int p = a.short_dist[c];
         for (int rep = 1; rep < p; ++rep) {
@@ -275,9 +274,9 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
           for (int m = 0; m < M4; ++m) T[m] = lnz::splat16(0.0f);
 #pragma unroll
           for (int blk = 0; blk < 2; ++blk) {
-            if (blk < nblk) {
 #pragma unroll
-              for (int m = 0; m < M4; ++m) {
+            for (int m = 0; m < M4; ++m) {
+              if (blk < nblkm[m]) {
                 H8 zh, zl;
                 split8(Z[m], blk, zh.h, zl.h);
                 T[m] = mfma16(mh[m][blk].h, zh.h, T[m]);
@@ -290,18 +289,25 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
           for (int m = 0; m < M4; ++m) Z[m] = T[m];
         }
       }
+      {  // k-block 0 (node rows 0..15): all molecules, four chains interleaved
+        H8 zh[M4], zl[M4];
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        if (blk < nblk) {
-          H8 zh[M4], zl[M4];
+        for (int m = 0; m < M4; ++m) split8(Z[m], 0, zh[m].h, zl[m].h);
 #pragma unroll
-          for (int m = 0; m < M4; ++m) split8(Z[m], blk, zh[m].h, zl[m].h);
+        for (int m = 0; m < M4; ++m) out[m] = mfma16(mh[m][0].h, zh[m].h, out[m]);
 #pragma unroll
-          for (int m = 0; m < M4; ++m) out[m] = mfma16(mh[m][blk].h, zh[m].h, out[m]);
+        for (int m = 0; m < M4; ++m) out[m] = mfma16(mh[m][0].h, zl[m].h, out[m]);
 #pragma unroll
-          for (int m = 0; m < M4; ++m) out[m] = mfma16(mh[m][blk].h, zl[m].h, out[m]);
+        for (int m = 0; m < M4; ++m) out[m] = mfma16(ml[m][0].h, zh[m].h, out[m]);
+      }
 #pragma unroll
-          for (int m = 0; m < M4; ++m) out[m] = mfma16(ml[m][blk].h, zh[m].h, out[m]);
+      for (int m = 0; m < M4; ++m) {  // k-block 1 (rows 16..31): only molecules with > 16 nodes
+        if (nblkm[m] > 1) {
+          H8 zh, zl;
+          split8(Z[m], 1, zh.h, zl.h);
+          out[m] = mfma16(mh[m][1].h, zh.h, out[m]);
+          out[m] = mfma16(mh[m][1].h, zl.h, out[m]);
+          out[m] = mfma16(ml[m][1].h, zh.h, out[m]);
         }
       }
       LNZ_ACC(t_g2)

@@ -239,3 +239,56 @@ extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stri
                      stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp);
   return lnz::check_launch("lnz_pack_laplacian");
 }
+
+// ---- workgroup load balancing ------------------------------------------------------------------
+// One forward launch is a single round of workgroups, so it lasts as long as its slowest
+// workgroup.  order[] deals the size-sorted batch out so that every group of `group` consecutive
+// molecules holds group/2 from the small end and the rest from the large end: all workgroups then
+// skip the same amount of zero-padded GEMM2 work.  Counting sort on node count, one workgroup.
+__global__ __launch_bounds__(1024) void balanced_order_kernel(const uint8_t* __restrict__ mask,
+                                                              int B, int N, int group,
+                                                              int32_t* __restrict__ order) {
+  __shared__ int cnt[LNZ_TILE + 2];
+  const int tid = threadIdx.x;
+  if (tid < LNZ_TILE + 2) cnt[tid] = 0;
+  __syncthreads();
+  auto count = [&](int b) {
+    int n = 0;
+    for (int i = 0; i < N; ++i) n += mask[(int64_t)b * N + i] != 0;
+    return n;
+  };
+  for (int b = tid; b < B; b += 1024) atomicAdd(&cnt[count(b)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int n = 0; n <= N; ++n) {
+      int c = cnt[n];
+      cnt[n] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  const int half = group / 2, rest = group - half;
+  const int nfull = B / group, tail = B % group;
+  const int nlo = nfull * half + (tail < half ? tail : half);  // slots fed from the small end
+  for (int b = tid; b < B; b += 1024) {
+    int r = atomicAdd(&cnt[count(b)], 1);  // rank in the size-sorted batch (ties in any order)
+    int p;
+    if (r < nlo) {
+      p = (r / half) * group + r % half;
+    } else {
+      int t = B - 1 - r;
+      p = (t / rest) * group + half + t % rest;
+    }
+    order[p] = b;
+  }
+}
+
+extern "C" int lnz_balanced_order(const uint8_t* mask, int B, int N, int group, int32_t* order,
+                                  lnz_stream_t stream) {
+  LNZ_REQUIRE(mask && order && B > 0 && N > 0 && N <= LNZ_TILE && group >= 2 && group % 2 == 0,
+              LNZ_EINVAL, "lnz_balanced_order: bad arguments (B=%d N=%d group=%d)", B, N, group);
+  hipLaunchKernelGGL(balanced_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B,
+                     N, group, order);
+  return lnz::check_launch("lnz_balanced_order");
+}

@@ -216,6 +216,15 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None):
   return G
 
 
+def balanced_order(mask_u8, group):
+  """lnz_balanced_order: permutation dealing small and large molecules evenly over workgroups."""
+  lib = _lib.load()
+  B, N = mask_u8.shape
+  order = torch.empty((B,), dtype=torch.int32, device=mask_u8.device)
+  _lib.check(lib.lnz_balanced_order(_ptr(mask_u8), B, N, group, _ptr(order), _stream()))
+  return order
+
+
 def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
   """Launch the fused forward.  `plan` is a dict made by LanczosNet._plan() holding the packed
   parameters and the static sizes."""
@@ -264,9 +273,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
     a.Wp16, a.Wp16_head = plan['Wp16'].data_ptr(), plan['Wp16_head'].data_ptr()
     for i in range(plan['num_layer']):
       a.w16_off[i] = plan['w16_off'][i]
-    # group molecules of similar size: every workgroup of 4 then skips the same padded k-steps
-    order = torch.argsort(mask_u8.sum(dim=1, dtype=torch.int32)).to(torch.int32).contiguous()
-    a.order = order.data_ptr()
+  # One launch = one round of workgroups, so its time is the slowest workgroup's: give every
+  # workgroup the same mix of small and large molecules ("snake" over the size-sorted batch) so
+  # that all of them skip the same amount of zero-padded GEMM2 work.
+  order = balanced_order(mask_u8, 4 if a.gemm_mode == 1 else 2)
+  a.order = order.data_ptr()
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
   a.score = score.data_ptr()
   state = None

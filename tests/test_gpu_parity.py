@@ -529,3 +529,26 @@ def test_tridiag_eigh_standalone(M):
     assert np.abs(R[b] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
     assert np.abs(T @ Bm[b] - Bm[b] * R[b][None, :]).max() < 1e-12 * max(1.0, np.abs(ref).max())
     assert np.abs(Bm[b].T @ Bm[b] - np.eye(M)).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,group', [(1, 2), (3, 2), (7, 4), (1024, 2), (1024, 4), (1025, 4), (4099, 2)])
+def test_balanced_order_is_a_balanced_permutation(B, group):
+  """lnz_balanced_order: a permutation of the batch; every full group of `group` molecules takes
+  half of its members from the small end and half from the large end of the size-sorted batch."""
+  from lanczosnet_amd import ops
+  g = torch.Generator().manual_seed(B * 7 + group)
+  n = torch.randint(1, 28, (B,), generator=g)
+  mask = (torch.arange(27)[None, :] < n[:, None]).to(torch.uint8).cuda()
+  order = ops.balanced_order(mask, group).cpu().long()
+  assert sorted(order.tolist()) == list(range(B))
+  ns = n[order]
+  srt = torch.sort(n).values
+  half = group // 2
+  for gi in range(B // group):
+    grp = ns[gi * group:(gi + 1) * group]
+    lo, hi = grp[:half], grp[half:]
+    # g-th smallest block and g-th largest block of the sorted sizes
+    assert sorted(lo.tolist()) == srt[gi * half:(gi + 1) * half].tolist()
+    want_hi = srt[B - (gi + 1) * (group - half):B - gi * (group - half)].tolist()
+    assert sorted(hi.tolist()) == want_hi
