@@ -175,18 +175,28 @@ typedef struct lnz_forward_args {
   int64_t w16_off[16];        /* byte offsets                                                     */
   const void* Wp16_head;      /* packed [32, 128] head                                            */
   const void* Lp16;           /* lnz_pack_laplacian_f16x2 output (gemm_mode 1; replaces Lp there)  */
-  const int32_t* order;       /* optional [B] permutation (lnz_balanced_order): workgroup g processes
-                                 molecules order[g*m .. g*m+m-1], m = 2 (gemm_mode 0) or 4 (mode 1);
-                                 NULL = identity.  Results do not depend on it, only the time.     */
+  const int32_t* plan;        /* optional tile plan (lnz_plan_tiles): [plan_wg_cap][4][3] int32, slot s
+                                 of workgroup g = (molecule A, molecule B or -1, split row); NULL =
+                                 one tile per molecule, 4 per workgroup, in batch order.  Results
+                                 do not depend on the plan, only the time.  Pair tiles (B >= 0):
+                                 gemm_mode 0 with filter_kind 0 only.                               */
+  const int32_t* n_wg;        /* device scalar written by lnz_plan_tiles: workgroups in use          */
+  int plan_wg_cap;            /* lnz_plan_wg_cap(B, n_cu): workgroup entries in `plan` (= grid size) */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
-/* Load-balancing permutation for lnz_forward_args.order: deals the batch, sorted by node count
- * (row sums of mask [B,N] u8), into consecutive groups of `group` (even) molecules holding
- * group/2 from the small end and the rest from the large end, so every workgroup skips the same
- * amount of zero-padded work.  No reference counterpart (the reference pads every molecule to N,
- * dataset/qm8.py:232-262).  order: [B] int32. */
-int lnz_balanced_order(const uint8_t* mask, int B, int N, int group, int32_t* order,
-                       lnz_stream_t stream);
+/* Tile plan for lnz_forward_args.plan.  The forward kernels work on 32-row node tiles; with
+ * allow_pairs small molecules (extent of mask [B,N] u8) share a tile: one of <= 8 nodes with one
+ * of 17..24 (split row 8), two of <= 16 (split row 16).  The tiles are dealt over W workgroups —
+ * W = n_cu (one per compute unit) while all tiles fit in one round of <= 4 per workgroup, else
+ * ceil(tiles/4) — in descending cost order, boustrophedon, so every workgroup of the launch gets
+ * floor/ceil(tiles/W) tiles of balanced cost.  Pair tiles rely on V[:, :, k] = 0 and D[:, k] = 0
+ * for k >= n, which the reference's collate guarantees (dataset/qm8.py:264-291) and
+ * lnz_lanczos_ritz produces.  No reference counterpart (the reference pads every molecule to N,
+ * dataset/qm8.py:232-262).
+ * plan: [lnz_plan_wg_cap(B, n_cu) * 12] int32; n_wg: [1] int32 (device). */
+int lnz_plan_wg_cap(int B, int n_cu);
+int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs, int32_t* plan,
+                   int32_t* n_wg, lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);

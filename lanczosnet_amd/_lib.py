@@ -41,7 +41,7 @@ class ForwardArgs(C.Structure):
       ('Wp_head', C.c_void_p), ('bias_head', C.c_void_p),
       ('score', C.c_void_p), ('state_out', C.c_void_p),
       ('gemm_mode', C.c_int32), ('Wp16', C.c_void_p), ('w16_off', C.c_int64 * 16),
-      ('Wp16_head', C.c_void_p), ('Lp16', C.c_void_p), ('order', C.c_void_p),
+      ('Wp16_head', C.c_void_p), ('Lp16', C.c_void_p), ('plan', C.c_void_p), ('n_wg', C.c_void_p), ('plan_wg_cap', C.c_int),
   ]
 
 
@@ -61,7 +61,8 @@ SIGNATURES = {
     'lnz_pack_rows_f16x2': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_pack_bias_rows': (C.c_int, [_P, _I, _P, _P]),
     'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
-    'lnz_balanced_order': (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    'lnz_plan_wg_cap': (C.c_int, [_I, _I]),
+    'lnz_plan_tiles': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'lnz_pack_laplacian_f16x2': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),
     'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),

@@ -1,7 +1,9 @@
 // R7 (second half) + R9 + R10: the fused LanczosNet forward.
 //
-// One workgroup (dhid/32 wavefronts) per PAIR of molecules runs the WHOLE network on chip:
+// One workgroup (dhid/32 wavefronts) per PAIR of 32-row node tiles runs the WHOLE network on chip:
 // embedding -> num_layer x [ X' = relu( sum_c M_c X W_c^T + b ) ] -> gated head -> masked mean.
+// A tile holds one molecule, or (lnz_plan_tiles) two molecules of <= 16 nodes each in rows 0..15
+// and 16..31 with block-diagonal operators M_c — the per-lane molecule id is all that differs.
 //
 // Per layer and message channel c two chained matrix-core GEMMs (v_mfma_f32_32x32x2_f32, exact
 // fp32 fma chains), evaluated as  M_c (X W_c^T)  instead of the reference's  (M_c X) W_c^T :
@@ -30,7 +32,7 @@
 
 namespace {
 
-constexpr int MOLS = 2;      // molecules per workgroup; every wave works on both
+constexpr int MOLS = 2;      // node tiles per workgroup half; every wave of the half works on both
 constexpr int PITCH = 132;   // LDS row pitch (floats): conflict-free ds_read_b128 A fragments
 constexpr int KHMAX = 16;    // eigen slots per lane half (K <= 32)
 
@@ -46,47 +48,95 @@ __device__ inline f32x16 frag_from4(const float4 (&v)[4]) {
   return f;
 }
 
-// NWV wavefronts per workgroup = dhid / 32: wave w owns output-feature tile w for BOTH molecules
-// of the workgroup, so every packed-weight fragment it loads feeds 2 x 4 MFMAs.
-// FK = filter kind: 0 = diagonal gains on Ritz vectors (LanczosNet), 1 = dense K x K filters on
-// the Lanczos basis (AdaLanczosNet: M = Q DD Q^T, model/ada_lanczos_net.py:280-281).
-template <int NWV, int KHT, int FK>
-__global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_forward_args a) {
-  __shared__ __attribute__((aligned(16))) float Xs[2][MOLS][32][PITCH];
+// The argument block is read where the dispatch packet put it — the kernarg segment (constant
+// address space, scalar loads, dynamic indexing of its arrays) — instead of a private copy.
+typedef const __attribute__((address_space(4))) lnz_forward_args KArgs;
 
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
+struct TileDesc {
+  int ta;     // molecule in rows [0, split)  (the only one of a single tile)
+  int tb;     // molecule in rows [split, 32) or -1
+  int split;  // multiple of 8; 32 for a single tile
+};
+
+// One HALF of a workgroup: NWV wavefronts (wave w owns output-feature tile w) running the whole
+// network for MT node tiles, so every packed-weight fragment a wave loads feeds MT x 4 MFMAs (the
+// per-CU vector-memory path, not L2, limits a 1-tile tiling).  The two halves of a workgroup share
+// nothing but the CU and the per-layer barrier.
+// FK = filter kind: 0 = diagonal gains on Ritz vectors (LanczosNet), 1 = dense K x K filters on
+// the Lanczos basis (AdaLanczosNet: M = Q DD Q^T, model/ada_lanczos_net.py:280-281; single tiles).
+template <int MT>
+__device__ __forceinline__ TileDesc pick(const TileDesc (&td)[MT], int m) {
+  static_assert(MT <= 2, "select written for two tiles");
+  TileDesc t = td[0];
+  if (MT > 1 && m) t = td[MT - 1];
+  return t;
+}
+template <int MT>
+__device__ __forceinline__ int pick(const int (&v)[MT], int m) {
+  return (MT > 1 && m) ? v[MT - 1] : v[0];
+}
+
+// Eigen slot contracted by lane half hh at step t of the L_s build, by tile type — a fixed map, so
+// that the summation order of a molecule's filter never depends on its tile partner:
+//   single : slot k = KH*hh + t of the molecule (KH = ceil(K/2))
+//   16|16  : half 0 -> A's k = t, half 1 -> B's k = t
+//   8|24   : half 0 -> A's k = t for t < 8, B's k = t + 8 (16..23) after; half 1 -> B's k = t
+// Returns k (or -1 for an unused step); *isA says whose slot it is.
+__device__ __forceinline__ int eigen_slot(int split, int KH, int K, int hh, int t, bool* isA) {
+  int k;
+  if (split == 32) {
+    *isA = true;
+    k = t < KH ? KH * hh + t : K;
+  } else if (split == 16) {
+    *isA = hh == 0;
+    k = t;
+  } else {
+    *isA = hh == 0 && t < 8;
+    k = (hh == 0 && t >= 8) ? t + 8 : t;
+  }
+  return k < K ? k : -1;
+}
+
+template <int NWV, int KHT, int FK, int MT>
+__device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
+                                             float (*Xs)[2][32][PITCH],  // [2 buffers][tile][..]
+                                             float4 (*Vs)[4][64],        // [tile][t/4][lane]
+                                             float* Gs,  // [2 buffers][tile][n_long][2 halves][16]
+                                             const int htid, const int wave) {
+  const int lane = htid & 63;
   const int j = lane & 31, hh = lane >> 5;
   const int N = a.N, K = a.K, B = a.B;
   const int dhid = a.dhid;
   const int C = a.n_short + a.n_long + a.n_edge;
-  // molecule ids (an odd batch repeats the last one; its result is dropped).  a.order: optional
-  // permutation that pairs a small with a large molecule so that all workgroups skip the same
-  // amount of padded GEMM2 work (the launch is one round: its time is the slowest workgroup's).
-  int mb[MOLS];
+
+  // per-lane view of each tile: molecule and local node of tile row j
+  int molj[MT], jl[MT];
 #pragma unroll
-  for (int m = 0; m < MOLS; ++m) {
-    int x = blockIdx.x * MOLS + m;
-    x = x < B ? x : B - 1;
-    mb[m] = a.order ? a.order[x] : x;
+  for (int m = 0; m < MT; ++m) {
+    const bool first = j < td[m].split;
+    molj[m] = first ? td[m].ta : td[m].tb;
+    jl[m] = first ? j : j - td[m].split;
   }
 
   // ---- embedding gather (model/lanczos_net.py:154) / float features (lanczos_net_general.py:156)
   {
     const int d4 = a.din0 >> 2;
-    for (int idx = tid; idx < MOLS * 32 * d4; idx += 64 * NWV) {
-      int m = idx / (32 * d4);
-      int rem = idx - m * 32 * d4;
-      int row = rem / d4, c4 = rem - row * d4;
+    for (int idx = htid; idx < MT * 32 * d4; idx += 64 * NWV) {
+      const int m = idx / (32 * d4);
+      const int rem = idx - m * 32 * d4;
+      const int row = rem / d4, c4 = rem - row * d4;
+      const TileDesc t = pick(td, m);
+      const bool first = row < t.split;
+      const int mol = first ? t.ta : t.tb;
+      const int lrow = first ? row : row - t.split;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < N) {
+      if (lrow < N) {
         if (a.node_feat) {
-          int64_t id = a.node_feat[(int64_t)mb[m] * N + row];
+          int64_t id = a.node_feat[(int64_t)mol * N + lrow];
           id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
           v = reinterpret_cast<const float4*>(a.embedding + id * a.din0)[c4];
         } else {
-          v = reinterpret_cast<const float4*>(a.node_feat_f + ((int64_t)mb[m] * N + row) * a.din0)[c4];
+          v = reinterpret_cast<const float4*>(a.node_feat_f + ((int64_t)mol * N + lrow) * a.din0)[c4];
         }
       }
       *reinterpret_cast<float4*>(&Xs[0][m][row][4 * c4]) = v;
@@ -94,32 +144,92 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
   }
 
   // ---- rows of M_c beyond the last real node are zero (zero-padded Laplacian rows/cols, zero
-  //      rows of V): GEMM2 k-steps 4g..4g+3 only touch node rows 8g..8g+7, so a molecule with
-  //      n real nodes needs 4*ceil(n/8) of the 16 steps (wave-uniform per molecule).
-  int g2steps[MOLS];
+  //      rows of V): GEMM2 k-steps 4g..4g+3 only touch node rows 8g..8g+7, so bit g of g2mask says
+  //      whether that group of steps is needed (wave-uniform per tile): molecule A needs groups
+  //      g < ceil(nA/8), molecule B groups split/8 <= g < split/8 + ceil(nB/8).
+  //      H = steps of the L_s build (eigen_slot() above): a single tile keeps all K slots; a
+  //      pair tile drops the steps whose slots are k >= n for both molecules — those slots are
+  //      zero (dataset/qm8.py:264-291), so dropping them changes no bit.
+  const int KH = (K + 1) >> 1;
+  int g2mask[MT], H[MT];
 #pragma unroll
-  for (int m = 0; m < MOLS; ++m) {
-    int last = 0;
-    for (int i = lane; i < N; i += 64) last = a.mask[(int64_t)mb[m] * N + i] ? i + 1 : last;
+  for (int m = 0; m < MT; ++m) {
+    const bool pr = td[m].tb >= 0;
+    int la = 0, lb = 0;
+    for (int i = lane; i < N; i += 64) {
+      la = a.mask[(int64_t)td[m].ta * N + i] ? i + 1 : la;
+      if (pr) lb = a.mask[(int64_t)td[m].tb * N + i] ? i + 1 : lb;
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
-    g2steps[m] = __builtin_amdgcn_readfirstlane(((last + 7) >> 3) * 4);
+    for (int off = 32; off > 0; off >>= 1) {
+      la = max(la, __shfl_xor(la, off, 64));
+      lb = max(lb, __shfl_xor(lb, off, 64));
+    }
+    la = __builtin_amdgcn_readfirstlane(la);
+    lb = __builtin_amdgcn_readfirstlane(lb);
+    const int g0 = td[m].split >> 3;
+    g2mask[m] = ((1 << ((la + 7) >> 3)) - 1) | (((1 << ((lb + 7) >> 3)) - 1) << g0);
+    const int k16 = K < 16 ? K : 16;
+    const int nmax = la > lb ? la : lb;
+    H[m] = td[m].split == 32 ? KH : (td[m].split == 16 && nmax < k16 ? nmax : k16);
   }
 
-  // ---- basis fragments.  FK = 0: vreg[m][t] = V[mol m][j][KH*hh + t] (Ritz vectors, two k-halves)
+  // ---- basis fragments.
+  //      FK = 0: Ritz vectors staged in LDS in L_s-build fragment order, Vs[m][t/4][lane][t%4]:
+  //        lane half hh, step t contracts eigen_slot(): a lane holds V[mol][local row][k] if its
+  //        row is in the row block of the molecule owning that slot, zero otherwise
+  //        (block-diagonal L_s).
   //      FK = 1: vreg[m][r] = Q[mol m][j][cd_row(r,hh)] — the k-order that lets the same registers
-  //      serve as B operand of R = DD Q^T and as A operand of L_s = Q R.
-  const int KH = (K + 1) >> 1;
-  float vreg[MOLS][KHT];
+  //        serve as B operand of R = DD Q^T and as A operand of L_s = Q R.
+  float vreg[MT][FK ? KHT : 1];
+  if (FK == 0) {
+    for (int idx = htid; idx < MT * 4 * 64; idx += 64 * NWV) {
+      const int m = idx >> 8, t4 = (idx >> 6) & 3, ln = idx & 63;
+      const int jj = ln & 31, h = ln >> 5;
+      const TileDesc t = pick(td, m);
+      float v[4];
 #pragma unroll
-  for (int m = 0; m < MOLS; ++m) {
+      for (int u = 0; u < 4; ++u) {
+        bool isA;
+        const int k = eigen_slot(t.split, KH, K, h, 4 * t4 + u, &isA);
+        const bool first = jj < t.split;
+        const int row = first ? jj : jj - t.split;
+        const bool ok = k >= 0 && first == isA && row < N;
+        const int mol = isA ? t.ta : t.tb;
+        v[u] = ok ? a.V[((int64_t)mol * N + row) * K + k] : 0.0f;
+      }
+      Vs[m][t4][ln] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
 #pragma unroll
-    for (int t = 0; t < KHT; ++t) {
-      int k = FK ? lnz::cd_row(t, hh) : KH * hh + t;
-      bool ok = FK ? (k < K) : (t < KH && k < K);
-      vreg[m][t] = (ok && j < N) ? a.V[((int64_t)mb[m] * N + j) * K + k] : 0.0f;
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int t = 0; t < (FK ? KHT : 1); ++t) {
+        int k = lnz::cd_row(t, hh);
+        vreg[m][t] = (k < K && j < N) ? a.V[((int64_t)td[m].ta * N + j) * K + k] : 0.0f;
+      }
     }
   }
+  // ---- spectral gains of one layer, staged in LDS in the same slot order: Gs[buf][m][s][hh][t] =
+  //      g_s[k] of eigen_slot(hh, t) of the molecule owning that slot (zero for unused slots).  Layer l
+  //      uses buffer l & 1; layer l+1 is staged at the start of layer l (its buffer was last read
+  //      in layer l-1, which every wave left through the barrier).
+  auto stage_gains = [&](int l) {
+    if (FK != 0 || a.n_long == 0) return;
+    float* dst = Gs + (l & 1) * MT * a.n_long * 32;
+    for (int idx = htid; idx < MT * a.n_long * 32; idx += 64 * NWV) {
+      const int m = idx / (a.n_long * 32);
+      const int rem = idx - m * a.n_long * 32;
+      const int sc = rem >> 5, h = (rem >> 4) & 1, tt = rem & 15;
+      const TileDesc t = pick(td, m);
+      bool isA;
+      const int k = eigen_slot(t.split, KH, K, h, tt, &isA);
+      const bool ok = k >= 0;
+      const int mol = isA ? t.ta : t.tb;
+      dst[idx] = ok ? a.G[(((int64_t)l * B + mol) * a.n_long + sc) * K + k] : 0.0f;
+    }
+  };
+  stage_gains(0);
   __syncthreads();
 
 #ifdef LNZ_PROFILE_PHASES
@@ -136,12 +246,14 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
     const int Q = din >> 3;
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
     const float* __restrict__ bl = a.bias + a.b_off[l];
+    if (l + 1 < a.num_layer) stage_gains(l + 1);
+    const float* gsl = Gs + (l & 1) * MT * a.n_long * 32 + 16 * hh;
 
-    f32x16 out[MOLS];
+    f32x16 out[MT];
     {
       const float bv = bl[32 * wave + j];
 #pragma unroll
-      for (int m = 0; m < MOLS; ++m) out[m] = lnz::splat16(bv);
+      for (int m = 0; m < MT; ++m) out[m] = lnz::splat16(bv);
     }
 
     // B-operand stream of this wave's feature tile: contiguous over g = c*Q + q for the whole
@@ -152,42 +264,55 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
     float4 ring[4];
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
-    const float* xrow[MOLS];
+    const float* xrow[MT];
 #pragma unroll
-    for (int m = 0; m < MOLS; ++m) xrow[m] = &Xs[cur][m][j][4 * hh];
+    for (int m = 0; m < MT; ++m) xrow[m] = &Xs[cur][m][j][4 * hh];
 
-    // Operands of GEMM2 (per molecule, 16 registers: the 10 spectral gains g_s[k] of a long
-    // channel OR the four float4 Laplacian fragments of an edge/short channel) are fetched one
-    // channel ahead, right after the previous fragments are consumed and before that
-    // molecule's GEMM2 — so they have >= 16 MFMAs to land and are waited for together with the
+    // Operands of GEMM2 (per tile, 16 registers: the spectral gains of this lane half's eigen
+    // slots for a long channel OR the four float4 Laplacian fragments of an edge/short channel)
+    // are fetched one channel ahead, right after the previous fragments are consumed and before
+    // that tile's GEMM2 — so they have >= 16 MFMAs to land and are waited for together with the
     // oldest ring slot at the next GEMM1 loop header.
-    float mop[MOLS][16];
+    float mop[MT][16];
     auto fetch_m_operands = [&](int c, int m) {
       const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
       if (lng) {
         if (FK == 0) {
-          const float* gp = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K;
+          const float4* gp =
+              reinterpret_cast<const float4*>(gsl + (m * a.n_long + (c - a.n_short)) * 32);
 #pragma unroll
-          for (int t = 0; t < KHT; ++t) {
-            int k = KH * hh + t;
-            mop[m][t] = (t < KH && k < K) ? gp[k] : 0.0f;
+          for (int t4 = 0; t4 < 4; ++t4) {
+            const float4 v = gp[t4];
+            mop[m][4 * t4 + 0] = v.x;
+            mop[m][4 * t4 + 1] = v.y;
+            mop[m][4 * t4 + 2] = v.z;
+            mop[m][4 * t4 + 3] = v.w;
           }
         } else {
           // row j of the symmetric K x K filter DD_s, columns in cd_row order
-          const float* dp = a.G + ((((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K + j) * K;
+          const float* dp =
+              a.G + ((((int64_t)l * B + td[m].ta) * a.n_long + (c - a.n_short)) * K + j) * K;
 #pragma unroll
-          for (int t = 0; t < KHT; ++t) {
+          for (int t = 0; t < (FK ? KHT : 1); ++t) {
             int k2 = lnz::cd_row(t, hh);
             mop[m][t] = (j < K && k2 < K) ? dp[k2] : 0.0f;
           }
         }
       } else {
         const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
-        const float4* lp =
-            reinterpret_cast<const float4*>(a.Lp) + ((int64_t)mb[m] * a.n_edge + e) * 256;
+        // fragment group g of lane (j,hh) = M[j][8g + 4hh + 0..3].  Rows of molecule A take its
+        // own groups 0..split/8-1; rows of molecule B take B's groups 0.. as tile groups
+        // split/8..3 (its columns sit behind A's); the off-diagonal blocks are zero.
+        const float4* lp = reinterpret_cast<const float4*>(a.Lp) +
+                           ((int64_t)molj[m] * a.n_edge + e) * 256 + 32 * hh + jl[m];
+        const int g0 = td[m].split >> 3;
+        const int goff = j < td[m].split ? 0 : g0;
+        const int gcnt = j < td[m].split ? g0 : 4 - g0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float4 v = lp[g * 64 + lane];
+          const int gl = g - goff;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gl >= 0 && gl < gcnt) v = lp[gl * 64];
           mop[m][4 * g + 0] = v.x;
           mop[m][4 * g + 1] = v.y;
           mop[m][4 * g + 2] = v.z;
@@ -196,20 +321,20 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
       }
     };
 #pragma unroll
-    for (int m = 0; m < MOLS; ++m) fetch_m_operands(0, m);
+    for (int m = 0; m < MT; ++m) fetch_m_operands(0, m);
 
     for (int c = 0; c < C; ++c) {
       const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
 
       LNZ_T0
       // ---------------- GEMM1: Z_m = X_m W_c^T ----------------
-      f32x16 Z[MOLS];
+      f32x16 Z[MT];
 #pragma unroll
-      for (int m = 0; m < MOLS; ++m) Z[m] = lnz::splat16(0.0f);
-      const float* xq[MOLS];
-      float4 acur[MOLS];
+      for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
+      const float* xq[MT];
+      float4 acur[MT];
 #pragma unroll
-      for (int m = 0; m < MOLS; ++m) {
+      for (int m = 0; m < MT; ++m) {
         xq[m] = xrow[m];
         acur[m] = *reinterpret_cast<const float4*>(xq[m]);
       }
@@ -219,50 +344,59 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
         for (int u4 = 0; u4 < 4; ++u4) {
           ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
           // next A fragments (the read one step past the channel's last is in-bounds, unused)
-          float4 anext[MOLS];
+          float4 anext[MT];
 #pragma unroll
-          for (int m = 0; m < MOLS; ++m)
+          for (int m = 0; m < MT; ++m)
             anext[m] = *reinterpret_cast<const float4*>(xq[m] + 8 * (u4 + 1));
           // keep the prefetches ahead of this step's MFMAs (hipcc otherwise sinks all loads of
           // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
           __builtin_amdgcn_sched_barrier(0);
           const float4 bv = ring[u4];
 #pragma unroll
-          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MOLS; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MOLS; ++m) acur[m] = anext[m];
+          for (int m = 0; m < MT; ++m) acur[m] = anext[m];
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int m = 0; m < MOLS; ++m) xq[m] += 32;
+        for (int m = 0; m < MT; ++m) xq[m] += 32;
         wp += 4 * 64;
       }
 
       LNZ_ACC(t_g1)
-      // ---------------- per molecule: M_c fragments, next operands, GEMM2 ----------------
+      // ---------------- per tile: M_c fragments, next operands, GEMM2 ----------------
 #pragma unroll
-      for (int m = 0; m < MOLS; ++m) {
+      for (int m = 0; m < MT; ++m) {
         f32x16 Mf;
         if (is_long) {
           f32x16 acc = lnz::splat16(0.0f);
           if (FK == 0) {
+            const float4* vs = &Vs[m][0][lane];
 #pragma unroll
-            for (int t = 0; t < KHT; ++t) {
-              if (t < KH) acc = lnz::mfma32(vreg[m][t] * mop[m][t], vreg[m][t], acc);
+            for (int t4 = 0; t4 < 4; ++t4) {
+              if (4 * t4 < H[m]) {
+                const float4 v = vs[t4 * 64];
+                acc = lnz::mfma32(v.x * mop[m][4 * t4 + 0], v.x, acc);
+                acc = lnz::mfma32(v.y * mop[m][4 * t4 + 1], v.y, acc);
+                if (4 * t4 + 2 < H[m]) {
+                  acc = lnz::mfma32(v.z * mop[m][4 * t4 + 2], v.z, acc);
+                  acc = lnz::mfma32(v.w * mop[m][4 * t4 + 3], v.w, acc);
+                }
+              }
             }
           } else {
             // R[k1][n] = sum_k2 DD[k1][k2] Q[n][k2]  then  L_s[i][n] = sum_k1 Q[i][k1] R[k1][n]
             f32x16 R = lnz::splat16(0.0f);
 #pragma unroll
-            for (int t = 0; t < KHT; ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
+            for (int t = 0; t < (FK ? KHT : 1); ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
 #pragma unroll
-            for (int t = 0; t < KHT; ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
+            for (int t = 0; t < (FK ? KHT : 1); ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
           }
           Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]  (symmetric)
         } else {
@@ -278,7 +412,7 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
             f32x16 T = lnz::splat16(0.0f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              if (r < g2steps[m]) T = lnz::mfma32(Mf[r], Z[m][r], T);
+              if ((g2mask[m] >> (r >> 2)) & 1) T = lnz::mfma32(Mf[r], Z[m][r], T);
             }
             Z[m] = T;
           }
@@ -286,7 +420,7 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
         // GEMM2: out_m += M_c,m Z_m
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
-          if (r < g2steps[m]) {
+          if ((g2mask[m] >> (r >> 2)) & 1) {
             out[m] = lnz::mfma32(Mf[r + 0], Z[m][r + 0], out[m]);
             out[m] = lnz::mfma32(Mf[r + 1], Z[m][r + 1], out[m]);
             out[m] = lnz::mfma32(Mf[r + 2], Z[m][r + 2], out[m]);
@@ -301,7 +435,7 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
     LNZ_T0
     const int nxt = cur ^ 1;
 #pragma unroll
-    for (int m = 0; m < MOLS; ++m) {
+    for (int m = 0; m < MT; ++m) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         Xs[nxt][m][lnz::cd_row(r, hh)][32 * wave + j] = fmaxf(out[m][r], 0.0f);
@@ -312,26 +446,31 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
   }
 #ifdef LNZ_PROFILE_PHASES
   if (a.state_out && lane == 0 && blockIdx.x < 8) {
-    float* d = a.state_out + ((int64_t)B * 32 * dhid) + (blockIdx.x * 4 + wave) * 4;
+    float* d = a.state_out + ((int64_t)B * 32 * dhid) + (blockIdx.x * 8 + (htid >> 6)) * 4;
     d[0] = (float)t_g1; d[1] = (float)t_g2; d[2] = (float)t_ep; d[3] = (float)(clock64() - t_all);
   }
 #endif
 
-  // ---- optional debug/test output of the final node state
+  // ---- optional debug/test output of the final node state (rows of the tile each molecule owns)
   if (a.state_out) {
-    for (int idx = tid; idx < MOLS * 32 * dhid; idx += 64 * NWV) {
-      int m = idx / (32 * dhid);
-      int rem = idx - m * 32 * dhid;
-      int row = rem / dhid, col = rem - row * dhid;
-      if (blockIdx.x * MOLS + m < B)
-        a.state_out[((int64_t)mb[m] * 32 + row) * dhid + col] = Xs[cur][m][row][col];
+    for (int idx = htid; idx < MT * 32 * dhid; idx += 64 * NWV) {
+      const int m = idx / (32 * dhid);
+      const int rem = idx - m * 32 * dhid;
+      const int row = rem / dhid, col = rem - row * dhid;
+      const TileDesc t = pick(td, m);
+      const bool first = row < t.split;
+      const int mol = first ? t.ta : t.tb;
+      const int lrow = first ? row : row - t.split;
+      if (mol >= 0) a.state_out[((int64_t)mol * 32 + lrow) * dhid + col] = Xs[cur][m][row][col];
     }
   }
 
   // ---- head (model/lanczos_net.py:185-194): one 32-column tile = [W_o ; w_a ; 0];
-  //      wave m handles molecule m
-  if (wave < MOLS && blockIdx.x * MOLS + wave < B) {
+  //      wave m handles tile m.  Register group r>>2 of a C/D fragment covers tile rows
+  //      8(r>>2)..+7, so the two molecules of a pair tile reduce over separate registers.
+  if (wave < MT) {
     const int m = wave;
+    const TileDesc t = pick(td, m);
     const int P = a.dout;
     f32x16 acc = lnz::splat16(a.bias_head[j]);
     const float4* wh = reinterpret_cast<const float4*>(a.Wp_head) + lane;
@@ -347,21 +486,80 @@ __global__ __launch_bounds__(64 * NWV) void lanczosnet_forward_kernel(const lnz_
       acc = lnz::mfma32(av.w, bv.w, acc);
     }
     // acc[r] of lane (j,hh) = Y[cd_row(r,hh)][j]; the gate logit is column P of the same row
-    float sum = 0.0f, cnt = 0.0f;
+    const bool pr = t.tb >= 0;
+    const int64_t mol0 = t.ta, mol1 = pr ? t.tb : t.ta;
+    const int g0 = t.split >> 3;
+    float sum0 = 0.0f, sum1 = 0.0f, cnt0 = 0.0f, cnt1 = 0.0f;
     const int src = 32 * hh + P;
-    const int64_t mol = mb[m];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float logit = __shfl(acc[r], src, 64);
       float gate = 1.0f / (1.0f + __expf(-logit));
-      int row = lnz::cd_row(r, hh);
-      bool msk = row < N && a.mask[mol * N + row] != 0;
-      sum += msk ? gate * acc[r] : 0.0f;
-      cnt += msk ? 1.0f : 0.0f;
+      const int row = lnz::cd_row(r, hh);
+      const bool second = (r >> 2) >= g0;
+      const int lrow = second ? row - t.split : row;
+      const int64_t mol = second ? mol1 : mol0;
+      const bool msk = lrow < N && a.mask[mol * N + lrow] != 0;
+      const float val = msk ? gate * acc[r] : 0.0f, one = msk ? 1.0f : 0.0f;
+      sum0 += second ? 0.0f : val;
+      cnt0 += second ? 0.0f : one;
+      sum1 += second ? val : 0.0f;
+      cnt1 += second ? one : 0.0f;
     }
-    sum += __shfl_xor(sum, 32, 64);
-    cnt += __shfl_xor(cnt, 32, 64);
-    if (hh == 0 && j < P) a.score[mol * P + j] = sum / cnt;
+    sum0 += __shfl_xor(sum0, 32, 64);
+    cnt0 += __shfl_xor(cnt0, 32, 64);
+    sum1 += __shfl_xor(sum1, 32, 64);
+    cnt1 += __shfl_xor(cnt1, 32, 64);
+    if (hh == 0 && j < P) {
+      a.score[mol0 * P + j] = sum0 / cnt0;
+      if (pr) a.score[mol1 * P + j] = sum1 / cnt1;
+    }
+  }
+}
+
+// One workgroup = 2 halves x NWV wavefronts; half h works on slots 2h, 2h+1 of the workgroup's
+// plan entry (0, 1 or 2 node tiles).  With the plan of lnz_plan_tiles there is one workgroup per
+// CU while the batch fits in one round, holding floor/ceil of (tiles / CUs) tiles.
+template <int NWV, int KHT, int FK>
+__global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz_forward_args) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ __attribute__((aligned(16))) float Xs[2][2][MOLS][32][PITCH];  // [half][buffer][tile]
+  const int tid = threadIdx.x;
+  __shared__ float4 Vs[2][MOLS][4][64];  // FK = 0: Ritz-vector fragments
+  extern __shared__ __attribute__((aligned(16))) float Gs_all[];  // FK = 0: [half][2][MOLS][n_long][32]
+  float* Gs = Gs_all + (tid / (64 * NWV)) * 2 * MOLS * a.n_long * 32;
+  const int W = a.plan ? *a.n_wg : (a.B + 3) / 4;
+  if ((int)blockIdx.x >= W) return;  // the grid is sized for the unpaired worst case
+  const int half = __builtin_amdgcn_readfirstlane(tid / (64 * NWV));
+  const int htid = tid - half * 64 * NWV;
+  const int wave = __builtin_amdgcn_readfirstlane(htid >> 6);
+
+  TileDesc td[MOLS];
+  int nt = 0;
+#pragma unroll
+  for (int m = 0; m < MOLS; ++m) {
+    const int slot = (int)blockIdx.x * 4 + 2 * half + m;
+    if (a.plan) {
+      td[m].ta = a.plan[3 * slot + 0];
+      td[m].tb = a.plan[3 * slot + 1];
+      td[m].split = a.plan[3 * slot + 2];
+    } else {
+      td[m].ta = slot < a.B ? slot : -1;
+      td[m].tb = -1;
+      td[m].split = 32;
+    }
+    td[m].ta = __builtin_amdgcn_readfirstlane(td[m].ta);
+    td[m].tb = __builtin_amdgcn_readfirstlane(td[m].tb);
+    td[m].split = __builtin_amdgcn_readfirstlane(td[m].split);
+    nt += td[m].ta >= 0 ? 1 : 0;  // slots fill from 0: a used slot 1 implies a used slot 0
+  }
+  if (nt == 2) {
+    forward_half<NWV, KHT, FK, 2>(a, td, Xs[half], Vs[half], Gs, htid, wave);
+  } else if (nt == 1) {
+    const TileDesc t1[1] = {td[0]};
+    forward_half<NWV, KHT, FK, 1>(a, t1, Xs[half], Vs[half], Gs, htid, wave);
+  } else {
+    for (int l = 0; l <= a.num_layer; ++l) __syncthreads();  // keep the barrier count
   }
 }
 
@@ -405,12 +603,24 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
   LNZ_REQUIRE(a.gemm_mode == 0 || a.gemm_mode == 1, LNZ_EINVAL,
               "lnz_lanczosnet_forward: gemm_mode %d", a.gemm_mode);
   if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
-  const int grid = (a.B + MOLS - 1) / MOLS;
+  LNZ_REQUIRE(!a.plan || (a.n_wg && a.plan_wg_cap > 0), LNZ_EINVAL,
+              "lnz_lanczosnet_forward: plan without n_wg / plan_wg_cap");
+  const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;  // upper bound of the workgroup count
   LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL,
               "lnz_lanczosnet_forward: filter_kind %d", a.filter_kind);
-#define LNZ_LAUNCH(NWV_, KHT_, FK_)                                                             \
-  hipLaunchKernelGGL((lanczosnet_forward_kernel<NWV_, KHT_, FK_>), dim3(grid), dim3(64 * NWV_), \
-                     0, s, a)
+  // dynamic LDS: per-layer spectral gains of both halves, double buffered (filter_kind 0)
+  const size_t gs_bytes = a.filter_kind == 0 ? (size_t)2 * 2 * MOLS * a.n_long * 32 * sizeof(float) : 0;
+  LNZ_REQUIRE(gs_bytes <= 12288, LNZ_ENOTSUP,
+              "lnz_lanczosnet_forward: %d long-diffusion channels exceed the 12 whose gains fit in "
+              "LDS next to the node tiles", a.n_long);
+#define LNZ_LAUNCH(NWV_, KHT_, FK_)                                                              \
+  do {                                                                                           \
+    auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_>;                                       \
+    if (gs_bytes)                                                                                \
+      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)gs_bytes);                                                  \
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(128 * NWV_), gs_bytes, s, a);                       \
+  } while (0)
   if (a.filter_kind == 0) {
     const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
     if (a.dhid == 128 && k20) LNZ_LAUNCH(4, 10, 0);

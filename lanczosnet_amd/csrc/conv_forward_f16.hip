@@ -66,13 +66,20 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
   const int j = lane & 31, hh = lane >> 5;
   const int N = a.N, K = a.K, B = a.B;
   const int C = a.n_short + a.n_long + a.n_edge;
-  int mb[M4];  // molecule ids of this group (a.order: optional size-sorted permutation)
+  // molecule ids of this workgroup's four slots (a.plan: balanced deal of lnz_plan_tiles, single
+  // tiles only).  An unused slot repeats slot 0's molecule; its results are dropped.
+  if (a.plan && (int)blockIdx.x >= *a.n_wg) return;
+  int mb[M4];
+  bool used[M4];
 #pragma unroll
   for (int m = 0; m < M4; ++m) {
-    int x = blockIdx.x * M4 + m;
-    x = x < B ? x : B - 1;
-    mb[m] = a.order ? a.order[x] : x;
+    const int x = blockIdx.x * M4 + m;
+    int id = a.plan ? a.plan[3 * x] : (x < B ? x : -1);
+    used[m] = id >= 0;
+    mb[m] = id;
   }
+#pragma unroll
+  for (int m = 1; m < M4; ++m) mb[m] = used[m] ? mb[m] : mb[0];
 
   // ---- embedding gather / float features, zero padded to 128 columns, split into hi/lo ----------
   for (int idx = tid; idx < M4 * 32 * 128; idx += 256) {
@@ -340,14 +347,14 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
   if (a.state_out) {
     for (int idx = tid; idx < M4 * 32 * 128; idx += 256) {
       int m = idx >> 12, row = (idx >> 7) & 31, col = idx & 127;
-      if (blockIdx.x * M4 + m < B)
+      if (m == 0 ? used[0] : m == 1 ? used[1] : m == 2 ? used[2] : used[3])
         a.state_out[((int64_t)mb[m] * 32 + row) * 128 + col] =
             (float)Xp(cur, 0, m)[row * P16 + col] + (float)Xp(cur, 1, m)[row * P16 + col];
     }
   }
 
   // ---- head: wave m handles molecule m (split fp16 GEMM against the packed [32,128] head) ------
-  if (blockIdx.x * M4 + wave < B) {
+  if (wave == 0 ? used[0] : wave == 1 ? used[1] : wave == 2 ? used[2] : used[3]) {
     const int m = wave;
     const int P = a.dout;
     f32x16 acc = lnz::splat16(a.bias_head[j]);
@@ -403,7 +410,7 @@ int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s) {
     }
     attr_set = true;
   }
-  const int grid = (a.B + M4 - 1) / M4;
+  const int grid = a.plan ? a.plan_wg_cap : (a.B + M4 - 1) / M4;
   hipLaunchKernelGGL(lanczosnet_forward_f16x3_kernel, dim3(grid), dim3(256), kSmemBytes, s, a);
   return check_launch("lnz_lanczosnet_forward(f16x3)");
 }

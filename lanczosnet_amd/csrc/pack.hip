@@ -240,55 +240,121 @@ extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stri
   return lnz::check_launch("lnz_pack_laplacian");
 }
 
-// ---- workgroup load balancing ------------------------------------------------------------------
-// One forward launch is a single round of workgroups, so it lasts as long as its slowest
-// workgroup.  order[] deals the size-sorted batch out so that every group of `group` consecutive
-// molecules holds group/2 from the small end and the rest from the large end: all workgroups then
-// skip the same amount of zero-padded GEMM2 work.  Counting sort on node count, one workgroup.
-__global__ __launch_bounds__(1024) void balanced_order_kernel(const uint8_t* __restrict__ mask,
-                                                              int B, int N, int group,
-                                                              int32_t* __restrict__ order) {
+// ---- tile plan: pairing of small molecules + per-workgroup dealing ------------------------------
+// The forward kernels work on 32-row node tiles.  Small molecules share a tile (block-diagonal
+// operators): an (<= 8)-node molecule rides with a 17..24-node one (split row 8), two (<= 16)-node
+// molecules split at row 16.  For a QM8-like size range that turns B molecules into ~0.74 B tiles.
+//
+// A forward launch is ONE round of workgroups when B <= 4 tiles x CUs, so it lasts as long as the
+// busiest CU: the plan therefore fixes the number of workgroups W (one per CU while the tiles fit
+// in a single round of <= 4 per workgroup) and deals the tiles, in descending cost order, over the
+// workgroups boustrophedon-wise — every workgroup gets floor or ceil of T / W tiles of balanced
+// total cost.  Slot s of workgroup g is plan[(4g + s) * 3 + {0,1,2}] = (molecule A, molecule B or
+// -1, split row: rows < split belong to A; 32 for a single); an unused slot has A = -1.
+//
+// Stable counting sort on node extent in one workgroup; every molecule derives its slot from its
+// rank, so the plan is deterministic.
+__global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restrict__ mask, int B,
+                                                          int N, int n_cu, int allow_pairs,
+                                                          int wg_cap, int32_t* __restrict__ plan,
+                                                          int32_t* __restrict__ n_wg) {
   __shared__ int cnt[LNZ_TILE + 2];
+  __shared__ int cls[4];  // molecules with extent <= 8, <= 16, <= 24, <= 32 (cumulative)
+  __shared__ int wcnt[16][LNZ_TILE + 2];
   const int tid = threadIdx.x;
   if (tid < LNZ_TILE + 2) cnt[tid] = 0;
+  for (int i = tid; i < wg_cap * 12; i += 1024) plan[i] = -1;
   __syncthreads();
-  auto count = [&](int b) {
+  auto extent = [&](int b) {  // last real node + 1 (what the forward kernels size their work by)
     int n = 0;
-    for (int i = 0; i < N; ++i) n += mask[(int64_t)b * N + i] != 0;
+    for (int i = 0; i < N; ++i) n = mask[(int64_t)b * N + i] ? i + 1 : n;
     return n;
   };
-  for (int b = tid; b < B; b += 1024) atomicAdd(&cnt[count(b)], 1);
+  for (int b = tid; b < B; b += 1024) atomicAdd(&cnt[extent(b)], 1);
   __syncthreads();
   if (tid == 0) {
     int run = 0;
-    for (int n = 0; n <= N; ++n) {
-      int c = cnt[n];
+    for (int n = 0; n <= LNZ_TILE; ++n) {
+      int c = n <= N ? cnt[n] : 0;
       cnt[n] = run;
       run += c;
+      if ((n & 7) == 0 && n > 0) cls[n / 8 - 1] = run;
     }
   }
   __syncthreads();
-  const int half = group / 2, rest = group - half;
-  const int nfull = B / group, tail = B % group;
-  const int nlo = nfull * half + (tail < half ? tail : half);  // slots fed from the small end
-  for (int b = tid; b < B; b += 1024) {
-    int r = atomicAdd(&cnt[count(b)], 1);  // rank in the size-sorted batch (ties in any order)
-    int p;
-    if (r < nlo) {
-      p = (r / half) * group + r % half;
-    } else {
-      int t = B - 1 - r;
-      p = (t / rest) * group + half + t % rest;
+  const int c8 = cls[0], c16 = cls[1] - cls[0], c24 = cls[2] - cls[1], c32 = cls[3] - cls[2];
+  const int X = allow_pairs ? (c8 < c24 ? c8 : c24) : 0;       // 8|24 pairs
+  const int pool = c8 - X + c16;                               // remaining (<= 16)-node molecules
+  const int P2 = allow_pairs ? pool / 2 : 0;                   // 16|16 pairs
+  const int lone = pool - 2 * P2;                              // small singles (0/1, or all)
+  const int T = B - X - P2;
+  const int W = T <= 4 * n_cu ? (T < n_cu ? T : n_cu) : (T + 3) / 4;
+  if (tid == 0) *n_wg = W;
+  // ascending cost order: small singles, 17..24 singles, >= 25 singles, 16|16 pairs, 8|24 pairs
+  const int o24 = lone, o32 = o24 + (c24 - X), oP2 = o32 + c32, oX = oP2 + P2;
+  // Stable ranks (ties in batch order) so the plan — and with it the rounding of every score —
+  // is a pure function of the batch: chunks of 1024 molecules, per-wave ballots per extent value.
+  const int wv = tid >> 6, ln = tid & 63;
+  for (int c0 = 0; c0 < B; c0 += 1024) {
+    const int b = c0 + tid;
+    const int n = b < B ? extent(b) : -1;
+    int lr = 0;
+    for (int v = 0; v <= N; ++v) {
+      const unsigned long long mk = __ballot(n == v);
+      if (n == v) lr = __popcll(mk & ((1ull << ln) - 1ull));
+      if (ln == 0) wcnt[wv][v] = __popcll(mk);
     }
-    order[p] = b;
+    __syncthreads();
+    int r = -1;
+    if (b < B) {
+      r = cnt[n] + lr;
+      for (int w = 0; w < wv; ++w) r += wcnt[w][n];
+    }
+    __syncthreads();
+    if (tid <= N) {
+      int add = 0;
+      for (int w = 0; w < 16; ++w) add += wcnt[w][tid];
+      cnt[tid] += add;
+    }
+    __syncthreads();
+    if (b >= B) continue;
+    int tau, role, split = 32;            // role 0 = single, 1 = A of a pair, 2 = B of a pair
+    if (r < X) {
+      tau = oX + r, role = 1, split = 8;
+    } else if (r < c8 + c16) {
+      const int q = r - X;
+      if (q < 2 * P2) tau = oP2 + (q >> 1), role = 1 + (q & 1), split = 16;
+      else tau = q - 2 * P2, role = 0;
+    } else if (r < c8 + c16 + c24) {
+      const int q = r - (c8 + c16);
+      if (q < X) tau = oX + q, role = 2;
+      else tau = o24 + (q - X), role = 0;
+    } else {
+      tau = o32 + (r - (c8 + c16 + c24)), role = 0;
+    }
+    const int d = T - 1 - tau;  // position in descending cost order
+    const int round = d / W, idx = d % W;
+    const int wg = (round & 1) ? W - 1 - idx : idx;
+    int32_t* e = plan + ((int64_t)wg * 4 + round) * 3;
+    if (role == 2) {
+      e[1] = b;
+    } else {
+      e[0] = b;
+      e[2] = split;
+    }
   }
 }
 
-extern "C" int lnz_balanced_order(const uint8_t* mask, int B, int N, int group, int32_t* order,
-                                  lnz_stream_t stream) {
-  LNZ_REQUIRE(mask && order && B > 0 && N > 0 && N <= LNZ_TILE && group >= 2 && group % 2 == 0,
-              LNZ_EINVAL, "lnz_balanced_order: bad arguments (B=%d N=%d group=%d)", B, N, group);
-  hipLaunchKernelGGL(balanced_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B,
-                     N, group, order);
-  return lnz::check_launch("lnz_balanced_order");
+extern "C" int lnz_plan_wg_cap(int B, int n_cu) {
+  if (B <= 0 || n_cu <= 0) return 0;
+  return B <= 4 * n_cu ? (B < n_cu ? B : n_cu) : (B + 3) / 4;
+}
+
+extern "C" int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
+                              int32_t* plan, int32_t* n_wg, lnz_stream_t stream) {
+  LNZ_REQUIRE(mask && plan && n_wg && B > 0 && N > 0 && N <= LNZ_TILE && n_cu > 0, LNZ_EINVAL,
+              "lnz_plan_tiles: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
+  hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
+                     n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg);
+  return lnz::check_launch("lnz_plan_tiles");
 }

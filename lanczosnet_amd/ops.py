@@ -216,13 +216,28 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None):
   return G
 
 
-def balanced_order(mask_u8, group):
-  """lnz_balanced_order: permutation dealing small and large molecules evenly over workgroups."""
+_N_CU = {}
+
+
+def _n_cu(device):
+  idx = device.index if device.index is not None else torch.cuda.current_device()
+  if idx not in _N_CU:
+    _N_CU[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+  return _N_CU[idx]
+
+
+def plan_tiles(mask_u8, allow_pairs, n_cu=None):
+  """lnz_plan_tiles: small molecules share a 32-row tile; tiles are dealt evenly over one workgroup
+  per CU.  Returns (buf, cap): int32 tensor [12*cap + 1] = cap workgroup entries of 4 slots x
+  (molecule A, molecule B | -1, split row), followed by the number of workgroups in use."""
   lib = _lib.load()
   B, N = mask_u8.shape
-  order = torch.empty((B,), dtype=torch.int32, device=mask_u8.device)
-  _lib.check(lib.lnz_balanced_order(_ptr(mask_u8), B, N, group, _ptr(order), _stream()))
-  return order
+  n_cu = n_cu or _n_cu(mask_u8.device)
+  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  buf = torch.empty((12 * cap + 1,), dtype=torch.int32, device=mask_u8.device)
+  _lib.check(lib.lnz_plan_tiles(_ptr(mask_u8), B, N, n_cu, int(bool(allow_pairs)), _ptr(buf),
+                                C.c_void_p(buf.data_ptr() + 48 * cap), _stream()))
+  return buf, cap
 
 
 def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
@@ -276,8 +291,10 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
   # One launch = one round of workgroups, so its time is the slowest workgroup's: give every
   # workgroup the same mix of small and large molecules ("snake" over the size-sorted batch) so
   # that all of them skip the same amount of zero-padded GEMM2 work.
-  order = balanced_order(mask_u8, 4 if a.gemm_mode == 1 else 2)
-  a.order = order.data_ptr()
+  tiles, cap = plan_tiles(mask_u8, allow_pairs=(a.gemm_mode == 0 and a.filter_kind == 0))
+  a.plan = tiles.data_ptr()
+  a.n_wg = tiles.data_ptr() + 48 * cap
+  a.plan_wg_cap = cap
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
   a.score = score.data_ptr()
   state = None
