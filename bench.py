@@ -38,7 +38,8 @@ QM8_CFG = dict(num_atom=70, num_bond_type=6, short_diffusion_dist=[],
                spectral_filter_kind='MLP', input_dim=64, hidden_dim=[128] * 7, output_dim=16,
                num_layer=7)
 
-# Algorithmic FLOPs per molecule of the fused forward kernel in the REFERENCE's association
+# Algorithmic FLOPs per 32-row node tile (= per molecule in the reference's padding) of the fused
+# forward kernel in the REFERENCE's association
 # (SURVEY.md §8d, N = 32 tile, K = 20, S = 8, E+1 = 7, 64 -> 128 x 7 -> 16):
 #   filter build S*2N^2K per layer, long S*2N^2 d, edge (E+1)*2N^2 d, mix 2N(15d)128, head 2N*128*17
 FWD_FLOP_PER_MOL = (7 * 8 * 2 * 32 * 32 * 20
@@ -121,7 +122,8 @@ def main():
   plan = net._plan()
   gathered = [torch.empty((B, cfg['output_dim']), device=dev) for _ in range(world)] if dist else None
 
-  ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(5)] for k in range(args.steps)}
+  ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(6)] for k in range(args.steps)}
+  mask_u8 = mask.to(torch.uint8).contiguous()
 
   def step(events=None):
     if events:
@@ -135,9 +137,12 @@ def main():
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
     if events:
       events[3].record()
-    score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+    tiles = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
     if events:
       events[4].record()
+    score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
+    if events:
+      events[5].record()
     if dist:
       dist.all_gather(gathered, score)
     return score
@@ -183,8 +188,9 @@ def main():
       D, V = ops.lanczos_ritz(A, n_nodes, K)
       G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
       e0.record()
+      tiles = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
       for i in range(10):
-        ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+        ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
       e1.record()
       torch.cuda.synchronize()
     dev_rel = float((s2 - ref_score).abs().max() / ref_score.abs().max())
@@ -198,7 +204,7 @@ def main():
     net.gemm_mode = 'fp32'
     plan = plan_fp32
 
-  names = ['pack_laplacian', 'lanczos_ritz', 'spectral_gains', 'lanczosnet_forward']
+  names = ['pack_laplacian', 'lanczos_ritz', 'spectral_gains', 'plan_tiles', 'lanczosnet_forward']
   stage_ms = {nm: float(np.mean([ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)]))
               for k, nm in enumerate(names)}
 
@@ -206,7 +212,10 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     fwd_s = stage_ms['lanczosnet_forward'] * 1e-3
-    achieved = FWD_FLOP_PER_MOL * B / fwd_s / 1e12
+    # executed matrix-core work: the kernel runs 32-row node tiles; small molecules share one
+    buf, cap = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
+    n_tiles = int((buf[:12 * cap].view(cap, 4, 3)[:, :, 0] >= 0).sum().item())
+    achieved = FWD_FLOP_PER_MOL * n_tiles / fwd_s / 1e12
     traffic = None
     prof = os.path.join(ROOT, 'profiles', 'pmc_forward_hbm_bytes.json')
     if os.path.exists(prof) and B == 1024:
@@ -221,14 +230,19 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
                                'fp32, 7x128 layers, 1xMI355X per rank; step = pack L + Lanczos/QL '
-                               'Ritz pairs + spectral gains + fused forward' % (B, L.shape[1]),
+                               'Ritz pairs + spectral gains + tile plan + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, score all-gather)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
         'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0>', 'bound': 'mfma',
                      'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                      'traffic': traffic,
-                     'flops_per_launch': FWD_FLOP_PER_MOL * B,
+                     'flops_per_launch': FWD_FLOP_PER_MOL * n_tiles,
+                     'tiles_per_launch': n_tiles,
+                     'note': 'flops = 32-row tiles executed x the per-tile figure of SURVEY 8(d); '
+                             '%d molecules ride in %d tiles (lnz_plan_tiles); counting every '
+                             'molecule as its own padded tile would give %.1f TFLOP/s'
+                             % (B, n_tiles, FWD_FLOP_PER_MOL * B / fwd_s / 1e12),
                      'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4)},
     }
     if split is not None:

@@ -240,9 +240,16 @@ def plan_tiles(mask_u8, allow_pairs, n_cu=None):
   return buf, cap
 
 
-def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
+def pairing_supported(plan):
+  """Pair tiles exist in the exact-fp32 kernel with diagonal spectral gains."""
+  return plan.get('Wp16') is None and int(plan.get('filter_kind', 0)) == 0
+
+
+def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tiling='auto'):
   """Launch the fused forward.  `plan` is a dict made by LanczosNet._plan() holding the packed
-  parameters and the static sizes."""
+  parameters and the static sizes.  tiling: 'auto' = lnz_plan_tiles with pairing where the kernel
+  supports it, 'single' = planned but one molecule per tile, 'none' = no plan (batch order), or
+  the (buf, cap) pair returned by plan_tiles() for this mask (pairs only for the exact kernel)."""
   _need_cuda(node_feat, Lp, V, G, mask)
   B, N, K = V.shape
   a = _lib.ForwardArgs()
@@ -288,13 +295,17 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False):
     a.Wp16, a.Wp16_head = plan['Wp16'].data_ptr(), plan['Wp16_head'].data_ptr()
     for i in range(plan['num_layer']):
       a.w16_off[i] = plan['w16_off'][i]
-  # One launch = one round of workgroups, so its time is the slowest workgroup's: give every
-  # workgroup the same mix of small and large molecules ("snake" over the size-sorted batch) so
-  # that all of them skip the same amount of zero-padded GEMM2 work.
-  tiles, cap = plan_tiles(mask_u8, allow_pairs=(a.gemm_mode == 0 and a.filter_kind == 0))
-  a.plan = tiles.data_ptr()
-  a.n_wg = tiles.data_ptr() + 48 * cap
-  a.plan_wg_cap = cap
+  # Tile plan: small molecules share a 32-row tile and the tiles are dealt, balanced by cost, over
+  # one workgroup per CU (the launch is a single round: it lasts as long as its busiest CU).
+  if isinstance(tiling, tuple):
+    tiles, cap = tiling
+  elif tiling != 'none':
+    assert tiling in ('auto', 'single')
+    tiles, cap = plan_tiles(mask_u8, allow_pairs=(tiling == 'auto' and pairing_supported(plan)))
+  if tiling != 'none':
+    a.plan = tiles.data_ptr()
+    a.n_wg = tiles.data_ptr() + 48 * cap
+    a.plan_wg_cap = cap
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
   a.score = score.data_ptr()
   state = None

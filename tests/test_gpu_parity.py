@@ -576,3 +576,35 @@ def test_plan_tiles_covers_the_batch_once_and_balances(B, n_cu, pairs):
   want_pairs = (x + (c8 - x + c16) // 2) if pairs else 0
   assert int(paired.sum()) == want_pairs and T == B - want_pairs
   assert W == (min(T, n_cu) if T <= 4 * n_cu else (T + 3) // 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gemm', ['fp32', 'f16x3'])
+def test_tile_plans_agree_at_batch_1024(gemm):
+  """Pair tiles (8|24 and 16|16 block-diagonal), planned single tiles and the unplanned batch
+  order are three schedules of the same arithmetic: scores agree to the parity tolerance, and
+  the two single-tile schedules bit for bit (same per-molecule summation order)."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  batch = draw_batch(1024, seed=3)
+  n = _t(batch['n_nodes'])
+  assert int((n <= 8).sum()) > 0 and int(((n > 16) & (n <= 24)).sum()) > 0  # both pair kinds
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 5))
+  net.gemm_mode = gemm
+  plan = net._plan()
+  Lp = ops.pack_laplacian_for(plan, L)
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  nf, mask = _t(batch['node_feat']), _t(batch['node_mask'])
+  out = {}
+  for tiling in ('auto', 'single', 'none'):
+    sc, st = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask, return_state=True, tiling=tiling)
+    out[tiling] = (sc, st)
+  assert torch.equal(out['single'][0], out['none'][0])
+  scale = out['none'][0].abs().max().item()
+  assert (out['auto'][0] - out['none'][0]).abs().max().item() <= 1e-5 * scale
+  # node states of the real nodes
+  real = mask.bool()
+  sa, sn = out['auto'][1][:, :mask.shape[1]][real], out['none'][1][:, :mask.shape[1]][real]
+  assert (sa - sn).abs().max().item() <= 1e-5 * sn.abs().max().item()
