@@ -228,6 +228,27 @@ int lnz_ada_t_powers(const float* T, int B, int K, const int32_t* dist_host, int
 int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, float* DDp,
                                lnz_stream_t stream);
 
+/* ---- next row (SURVEY.md 8f rank 1 + 3): device-side collate from a packed molecule shard ----
+ * Replaces the per-molecule pickles of dataset/get_qm8_data.py:56-96 (dense float64 Laplacians +
+ * offline eigendecomposition), their loading (dataset/qm8.py:41-47) and the Python pad/concat of
+ * QM8Data.collate_fn (dataset/qm8.py:57-100,220-262).  A shard is four flat device arrays:
+ *   mol_off  [n_mol+1] int64   atom offsets          atoms  [total_atoms] u8  atom ids
+ *   edge_off [n_mol+1] int64   bond offsets          edges  [total_bonds] u32 = u | v<<8 | type<<16
+ *   labels   [n_mol, P] fp32                         (each undirected bond listed once)
+ * One launch builds the batch of molecules ids[0..B) (NULL = 0..B-1), padded to N nodes
+ * (N >= the largest molecule of the batch, qm8.py:66):
+ *   L [B,N,N,E+1] fp32 channels-last, channel 0 = L4 of the simple graph sum_e A_e
+ *     (get_qm8_data.py:62), channel 1+e = L4 of bond type e (utils/data_helper.py:92-116,
+ *     155-156, 261-291), computed in fp64 and rounded once — bit-identical to lnz_laplacian_l4
+ *     on the dense adjacency;
+ *   node_feat [B,N] int64 (pad 0), mask [B,N] u8, label [B,P], n_nodes [B] int32.
+ * (D, V) then come from lnz_lanczos_ritz on L[..., 0] instead of the pickled D_simple/V_simple.
+ * An id outside [0, n_mol) yields an empty molecule (n_nodes = 0).  N*N*E*4 + (E+1)*N*8 <= 64 KiB. */
+int lnz_collate_qm8(const int64_t* mol_off, const int64_t* edge_off, const uint8_t* atoms,
+                    const uint32_t* edges, const float* labels, const int64_t* ids, int64_t n_mol,
+                    int B, int N, int E, int P, int64_t* node_feat, uint8_t* mask, float* label,
+                    float* L, int32_t* n_nodes, lnz_stream_t stream);
+
 /* ---- R12: unsorted_segment_sum -----------------------------------------------------------
  * out[b, ids[b,c], x] += data[b,c,x]  /  grad_data[b,c,x] = grad_out[b, ids[b,c], x].
  * Replaces operators/src/cuda/segment_reduction.cu:39-69 (+ launchers :72-95) behind

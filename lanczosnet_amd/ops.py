@@ -216,6 +216,28 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None):
   return G
 
 
+def collate_qm8(shard, ids, N, E, P):
+  """lnz_collate_qm8: device arrays of a packed shard (dataset/packed.py) + molecule ids [B] ->
+  padded batch dict (node_feat, node_mask, label, L [B,N,N,E+1], n_nodes)."""
+  lib = _lib.load()
+  _need_cuda(shard['mol_off'], shard['edge_off'], shard['atoms'], shard['edges'], shard['labels'],
+             ids)
+  assert ids.dtype == torch.int64 and ids.is_contiguous()
+  dev = ids.device
+  B = ids.numel()
+  n_mol = shard['mol_off'].numel() - 1
+  node_feat = torch.empty((B, N), dtype=torch.int64, device=dev)
+  mask = torch.empty((B, N), dtype=torch.uint8, device=dev)
+  label = torch.empty((B, P), dtype=torch.float32, device=dev)
+  L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=dev)
+  n_nodes = torch.empty((B,), dtype=torch.int32, device=dev)
+  _lib.check(lib.lnz_collate_qm8(_ptr(shard['mol_off']), _ptr(shard['edge_off']),
+                                 _ptr(shard['atoms']), _ptr(shard['edges']), _ptr(shard['labels']),
+                                 _ptr(ids), n_mol, B, N, E, P, _ptr(node_feat), _ptr(mask),
+                                 _ptr(label), _ptr(L), _ptr(n_nodes), _stream()))
+  return dict(node_feat=node_feat, node_mask=mask, label=label, L=L, n_nodes=n_nodes)
+
+
 _N_CU = {}
 
 
