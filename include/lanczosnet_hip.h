@@ -182,8 +182,34 @@ typedef struct lnz_forward_args {
                                  gemm_mode 0 with filter_kind 0 only.                               */
   const int32_t* n_wg;        /* device scalar written by lnz_plan_tiles: workgroups in use          */
   int plan_wg_cap;            /* lnz_plan_wg_cap(B, n_cu): workgroup entries in `plan` (= grid size) */
+  /* ---- training (gemm_mode 0, filter_kind 0, dhid 128).  All buffers are
+   * molecule-major [.., B, 32, dhid] fp32 and must be ZERO-INITIALISED by the caller (rows a
+   * molecule does not own in its tile are never written). */
+  float* act_out;             /* lnz_lanczosnet_forward: optional [num_layer,B,32,dhid]; slot l receives
+                                 X_{l+1} = relu(conv layer l) — the activations the backward needs  */
+  const float* act;           /* input_grad / messages: the act_out of the forward                   */
+  float* dy;                  /* input_grad: [num_layer,B,32,dhid]; slot num_layer-1 holds, on entry,
+                                 dLoss/dY of the last conv layer (pre-activation); slots l-1 are
+                                 written with dLoss/dY_{l-1} for l = num_layer-1 .. 1              */
+  float* dx0;                 /* input_grad: [B,32,bwd_din0] dLoss/dX_0 (embedding gradient rows)    */
+  int32_t bwd_din0;           /* input_grad: width of X_0 (the model's input_dim, multiple of 32)    */
+  const float* x0;            /* messages, layer 0: X_0 [B,32,din0] (rows >= n zero)                 */
+  float* msg;                 /* messages: [B*32, C*d] with d = din0 (layer 0) or dhid: row
+                                 (b*32 + node), column c*d + i = (M_c X_l)[node][i] — the reference's
+                                 cat(msg) (model/lanczos_net.py:164-180)                           */
+  int32_t msg_layer;          /* messages: the conv layer l whose messages are built                 */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
+/* Backward of the conv stack w.r.t. its node-state inputs, in the forward's own structure:
+ *   dX_l = sum_c M_c (dY_l W_c),   dY_{l-1} = dX_l * [X_l > 0]
+ * (M_c symmetric).  Wp / w_off must hold, per KERNEL layer t = num_layer-1-l, pack_rows_k8 of the
+ * per-channel TRANSPOSED mix Wb[i][c*dhid + o] = W_l[o][c*d_l + i] ([d_l, C*dhid]); din0 = dhid;
+ * Lp, V, G, mask, plan as in the forward.  Writes dy[0..num_layer-2] and dx0. */
+int lnz_lanczosnet_input_grad(const lnz_forward_args* args, lnz_stream_t stream);
+/* Messages of conv layer msg_layer, msg = cat_c(M_c X_l): with dY_l they give the weight gradient
+ * of the reference's Linear(15 d -> 128) as ONE library GEMM, dW_l = dY_l^T msg
+ * (model/lanczos_net.py:180-182).  Reads act (or x0 for layer 0), Lp, V, G, mask, plan. */
+int lnz_lanczosnet_messages(const lnz_forward_args* args, lnz_stream_t stream);
 /* Tile plan for lnz_forward_args.plan.  The forward kernels work on 32-row node tiles; with
  * allow_pairs small molecules (extent of mask [B,N] u8) share a tile: one of <= 8 nodes with one
  * of 17..24 (split row 8), two of <= 16 (split row 16).  The tiles are dealt over W workgroups —

@@ -97,12 +97,19 @@ __device__ __forceinline__ int eigen_slot(int split, int KH, int K, int hh, int 
   return k < K ? k : -1;
 }
 
-template <int NWV, int KHT, int FK, int MT>
+// MODE 0 = forward; MODE 3 = forward that also stores every layer's activations (training);
+// MODE 1 = input-gradient pass (lnz_lanczosnet_input_grad): the same two chained GEMMs run on dY
+//          with per-channel transposed weights, kernel layer t = conv layer num_layer-1-t, the
+//          epilogue masks with the stored activation instead of bias + ReLU;
+// MODE 2 = message pass (lnz_lanczosnet_messages): GEMM1 is skipped — Z is the stored X_l block in
+//          C/D order — and every channel's M_c X_l is written out instead of accumulated.
+template <int NWV, int KHT, int FK, int MT, int MODE>
 __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                                              float (*Xs)[2][32][PITCH],  // [2 buffers][tile][..]
                                              float4 (*Vs)[4][64],        // [tile][t/4][lane]
                                              float* Gs,  // [2 buffers][tile][n_long][2 halves][16]
                                              const int htid, const int wave) {
+  constexpr bool FWD = MODE == 0 || MODE == 3;
   const int lane = htid & 63;
   const int j = lane & 31, hh = lane >> 5;
   const int N = a.N, K = a.K, B = a.B;
@@ -119,7 +126,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   }
 
   // ---- embedding gather (model/lanczos_net.py:154) / float features (lanczos_net_general.py:156)
-  {
+  //      MODE 1: the incoming gradient dY of the last conv layer
+  if (MODE != 2) {
     const int d4 = a.din0 >> 2;
     for (int idx = htid; idx < MT * 32 * d4; idx += 64 * NWV) {
       const int m = idx / (32 * d4);
@@ -130,7 +138,11 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       const int mol = first ? t.ta : t.tb;
       const int lrow = first ? row : row - t.split;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lrow < N) {
+      if (MODE == 1) {
+        if (mol >= 0 && lrow < 32)
+          v = reinterpret_cast<const float4*>(
+              a.dy + (((int64_t)(a.num_layer - 1) * B + mol) * 32 + lrow) * dhid)[c4];
+      } else if (lrow < N) {
         if (a.node_feat) {
           int64_t id = a.node_feat[(int64_t)mol * N + lrow];
           id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
@@ -229,7 +241,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       dst[idx] = ok ? a.G[(((int64_t)l * B + mol) * a.n_long + sc) * K + k] : 0.0f;
     }
   };
-  stage_gains(0);
+  stage_gains(FWD ? 0 : MODE == 1 ? a.num_layer - 1 : a.msg_layer);
   __syncthreads();
 
 #ifdef LNZ_PROFILE_PHASES
@@ -241,17 +253,24 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 #define LNZ_ACC(x)
 #endif
   int cur = 0;
-  for (int l = 0; l < a.num_layer; ++l) {
-    const int din = l == 0 ? a.din0 : dhid;
+  const int n_iter = MODE == 2 ? 1 : a.num_layer;
+  for (int l = 0; l < n_iter; ++l) {
+    // la = conv layer handled by this iteration (MODE 1 walks the stack backwards)
+    const int la = FWD ? l : MODE == 1 ? a.num_layer - 1 - l : a.msg_layer;
+    const int din = MODE == 2 ? 8 : (l == 0 ? a.din0 : dhid);
     const int Q = din >> 3;
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
-    const float* __restrict__ bl = a.bias + a.b_off[l];
-    if (l + 1 < a.num_layer) stage_gains(l + 1);
-    const float* gsl = Gs + (l & 1) * MT * a.n_long * 32 + 16 * hh;
+    if (FWD && l + 1 < a.num_layer) stage_gains(l + 1);
+    if (MODE == 1 && la > 0) stage_gains(la - 1);
+    const float* gsl = Gs + (la & 1) * MT * a.n_long * 32 + 16 * hh;
+    // width this iteration produces: waves beyond it only keep the barrier
+    const int wout = FWD ? dhid : MODE == 1 ? (la == 0 ? a.bwd_din0 : dhid)
+                                                  : (la == 0 ? a.din0 : dhid);
+    const bool active = FWD || 32 * wave < wout;
 
     f32x16 out[MT];
     {
-      const float bv = bl[32 * wave + j];
+      const float bv = FWD ? (a.bias + a.b_off[l])[32 * wave + j] : 0.0f;
 #pragma unroll
       for (int m = 0; m < MT; ++m) out[m] = lnz::splat16(bv);
     }
@@ -262,8 +281,29 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     const int Gtot = C * Q;
     const float4* __restrict__ wp = Wl + (int64_t)wave * Gtot * 64 + lane;
     float4 ring[4];
+    if (MODE != 2 && active) {
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
+      for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
+    }
+    // MODE 2: this wave's 32 columns of X_l in C/D order — Z of every channel
+    f32x16 Xblk[MODE == 2 ? MT : 1];
+    if (MODE == 2 && active) {
+      const float* src = la == 0 ? a.x0 : a.act + (int64_t)(la - 1) * B * 32 * dhid;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // rows 8g + 4hh + u: one owner per group (split % 8 == 0)
+          const bool first = 8 * g < td[m].split;
+          const int mol = first ? td[m].ta : td[m].tb;
+          const int lrow0 = 8 * g + 4 * hh - (first ? 0 : td[m].split);
+          const float* p = src + ((int64_t)(mol >= 0 ? mol : 0) * 32 + lrow0) * wout + 32 * wave + j;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            Xblk[MODE == 2 ? m : 0][4 * g + u] = mol >= 0 ? p[u * wout] : 0.0f;
+        }
+      }
+    }
+
     const float* xrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) xrow[m] = &Xs[cur][m][j][4 * hh];
@@ -320,53 +360,58 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         }
       }
     };
+    if (active) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) fetch_m_operands(0, m);
+      for (int m = 0; m < MT; ++m) fetch_m_operands(0, m);
+    }
 
-    for (int c = 0; c < C; ++c) {
+    for (int c = 0; active && c < C; ++c) {
       const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
 
       LNZ_T0
       // ---------------- GEMM1: Z_m = X_m W_c^T ----------------
       f32x16 Z[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
-      const float* xq[MT];
-      float4 acur[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        xq[m] = xrow[m];
-        acur[m] = *reinterpret_cast<const float4*>(xq[m]);
-      }
-#pragma unroll 1
-      for (int q0 = 0; q0 < Q; q0 += 4) {
-#pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-          ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
-          // next A fragments (the read one step past the channel's last is in-bounds, unused)
-          float4 anext[MT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            anext[m] = *reinterpret_cast<const float4*>(xq[m] + 8 * (u4 + 1));
-          // keep the prefetches ahead of this step's MFMAs (hipcc otherwise sinks all loads of
-          // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
-          __builtin_amdgcn_sched_barrier(0);
-          const float4 bv = ring[u4];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acur[m] = anext[m];
-          __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < MT; ++m) Z[m] = MODE == 2 ? Xblk[MODE == 2 ? m : 0] : lnz::splat16(0.0f);
+      if (MODE != 2) {
+        const float* xq[MT];
+        float4 acur[MT];
+  #pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          xq[m] = xrow[m];
+          acur[m] = *reinterpret_cast<const float4*>(xq[m]);
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) xq[m] += 32;
-        wp += 4 * 64;
+  #pragma unroll 1
+        for (int q0 = 0; q0 < Q; q0 += 4) {
+  #pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) {
+            ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
+            // next A fragments (the read one step past the channel's last is in-bounds, unused)
+            float4 anext[MT];
+  #pragma unroll
+            for (int m = 0; m < MT; ++m)
+              anext[m] = *reinterpret_cast<const float4*>(xq[m] + 8 * (u4 + 1));
+            // keep the prefetches ahead of this step's MFMAs (hipcc otherwise sinks all loads of
+            // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 bv = ring[u4];
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
+  #pragma unroll
+            for (int m = 0; m < MT; ++m) acur[m] = anext[m];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+  #pragma unroll
+          for (int m = 0; m < MT; ++m) xq[m] += 32;
+          wp += 4 * 64;
+        }
+
       }
 
       LNZ_ACC(t_g1)
@@ -417,28 +462,86 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             Z[m] = T;
           }
         }
-        // GEMM2: out_m += M_c,m Z_m
+        // GEMM2: out_m += M_c,m Z_m   (MODE 2: the message M_c,m X_m itself, written out)
+        f32x16 P = lnz::splat16(0.0f);
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
           if ((g2mask[m] >> (r >> 2)) & 1) {
-            out[m] = lnz::mfma32(Mf[r + 0], Z[m][r + 0], out[m]);
-            out[m] = lnz::mfma32(Mf[r + 1], Z[m][r + 1], out[m]);
-            out[m] = lnz::mfma32(Mf[r + 2], Z[m][r + 2], out[m]);
-            out[m] = lnz::mfma32(Mf[r + 3], Z[m][r + 3], out[m]);
+            if (MODE == 2) {
+              P = lnz::mfma32(Mf[r + 0], Z[m][r + 0], P);
+              P = lnz::mfma32(Mf[r + 1], Z[m][r + 1], P);
+              P = lnz::mfma32(Mf[r + 2], Z[m][r + 2], P);
+              P = lnz::mfma32(Mf[r + 3], Z[m][r + 3], P);
+            } else {
+              out[m] = lnz::mfma32(Mf[r + 0], Z[m][r + 0], out[m]);
+              out[m] = lnz::mfma32(Mf[r + 1], Z[m][r + 1], out[m]);
+              out[m] = lnz::mfma32(Mf[r + 2], Z[m][r + 2], out[m]);
+              out[m] = lnz::mfma32(Mf[r + 3], Z[m][r + 3], out[m]);
+            }
+          }
+        }
+        if (MODE == 2) {
+          const int64_t ld = (int64_t)C * wout;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if ((g2mask[m] >> g) & 1) {  // rows of groups no molecule owns stay zero
+              const bool first = 8 * g < td[m].split;
+              const int mol = first ? td[m].ta : td[m].tb;
+              const int lrow0 = 8 * g + 4 * hh - (first ? 0 : td[m].split);
+              float* p = a.msg + ((int64_t)mol * 32 + lrow0) * ld + (int64_t)c * wout + 32 * wave + j;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) p[u * ld] = P[4 * g + u];
+            }
           }
         }
       }
       LNZ_ACC(t_g2)
     }
 
-    // ---------------- epilogue: ReLU, X' -> LDS (other buffer), one barrier per layer -------
+    // ---------------- epilogue: X' -> LDS (other buffer), one barrier per layer -------------
+    //   MODE 0: ReLU (+ the activation store training asks for)
+    //   MODE 1: dY_{la-1} = dX_la * [X_la > 0] -> LDS and dy[la-1]; the last iteration writes dX_0
     LNZ_T0
     const int nxt = cur ^ 1;
+    if (MODE != 2 && active) {
+      const int col = 32 * wave + j;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Xs[nxt][m][lnz::cd_row(r, hh)][32 * wave + j] = fmaxf(out[m][r], 0.0f);
+        for (int g = 0; g < 4; ++g) {  // rows 8g + 4hh + u: one owner per group (split % 8 == 0)
+          const bool first = 8 * g < td[m].split;
+          const int mol = first ? td[m].ta : td[m].tb;
+          const int lrow0 = 8 * g + 4 * hh - (first ? 0 : td[m].split);
+          const int64_t rowbase = (int64_t)(mol >= 0 ? mol : 0) * 32 + lrow0;
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = out[m][4 * g + u];
+          if (FWD) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.0f);
+            if (MODE == 3 && mol >= 0) {
+              float* p = a.act_out + ((int64_t)l * B * 32 + rowbase) * dhid + col;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) p[u * dhid] = v[u];
+            }
+          } else if (la > 0) {
+            const int64_t at = ((int64_t)(la - 1) * B * 32 + rowbase) * dhid + col;
+            const float* xa = a.act + at;
+            float* dyp = a.dy + at;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              v[u] = (mol >= 0 && xa[u * dhid] > 0.0f) ? v[u] : 0.0f;
+              if (mol >= 0) dyp[u * dhid] = v[u];
+            }
+          } else if (mol >= 0) {
+            float* p = a.dx0 + rowbase * a.bwd_din0 + col;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u * a.bwd_din0] = v[u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) Xs[nxt][m][8 * g + 4 * hh + u][col] = v[u];
+        }
+      }
     }
     __syncthreads();
     cur = nxt;
@@ -450,6 +553,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     d[0] = (float)t_g1; d[1] = (float)t_g2; d[2] = (float)t_ep; d[3] = (float)(clock64() - t_all);
   }
 #endif
+
+  if (!FWD) return;
 
   // ---- optional debug/test output of the final node state (rows of the tile each molecule owns)
   if (a.state_out) {
@@ -520,7 +625,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 // One workgroup = 2 halves x NWV wavefronts; half h works on slots 2h, 2h+1 of the workgroup's
 // plan entry (0, 1 or 2 node tiles).  With the plan of lnz_plan_tiles there is one workgroup per
 // CU while the batch fits in one round, holding floor/ceil of (tiles / CUs) tiles.
-template <int NWV, int KHT, int FK>
+template <int NWV, int KHT, int FK, int MODE>
 __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) float Xs[2][2][MOLS][32][PITCH];  // [half][buffer][tile]
@@ -554,12 +659,13 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
     nt += td[m].ta >= 0 ? 1 : 0;  // slots fill from 0: a used slot 1 implies a used slot 0
   }
   if (nt == 2) {
-    forward_half<NWV, KHT, FK, 2>(a, td, Xs[half], Vs[half], Gs, htid, wave);
+    forward_half<NWV, KHT, FK, 2, MODE>(a, td, Xs[half], Vs[half], Gs, htid, wave);
   } else if (nt == 1) {
     const TileDesc t1[1] = {td[0]};
-    forward_half<NWV, KHT, FK, 1>(a, t1, Xs[half], Vs[half], Gs, htid, wave);
+    forward_half<NWV, KHT, FK, 1, MODE>(a, t1, Xs[half], Vs[half], Gs, htid, wave);
   } else {
-    for (int l = 0; l <= a.num_layer; ++l) __syncthreads();  // keep the barrier count
+    const int nb = MODE == 2 ? 2 : a.num_layer + 1;  // keep the barrier count of the other half
+    for (int l = 0; l < nb; ++l) __syncthreads();
   }
 }
 
@@ -571,69 +677,106 @@ int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_for
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
 
-extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream) {
-  LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_forward: null args");
-  const lnz_forward_args& a = *args;
+static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const char* who) {
   LNZ_REQUIRE(a.B > 0 && a.N > 0 && a.K > 0 && a.num_layer > 0, LNZ_EINVAL,
-              "lnz_lanczosnet_forward: bad sizes (B=%d N=%d K=%d L=%d)", a.B, a.N, a.K,
-              a.num_layer);
+              "%s: bad sizes (B=%d N=%d K=%d L=%d)", who, a.B, a.N, a.K, a.num_layer);
   LNZ_REQUIRE(a.N <= LNZ_TILE, LNZ_ENOTSUP,
-              "lnz_lanczosnet_forward: N=%d > %d-node tile (multi-tile molecules not built yet)",
-              a.N, LNZ_TILE);
-  LNZ_REQUIRE(a.K <= 2 * KHMAX, LNZ_ENOTSUP, "lnz_lanczosnet_forward: K=%d > %d", a.K, 2 * KHMAX);
-  LNZ_REQUIRE(a.num_layer <= 16, LNZ_ENOTSUP, "lnz_lanczosnet_forward: num_layer=%d > 16",
-              a.num_layer);
-  LNZ_REQUIRE(a.dhid == 64 || a.dhid == 128, LNZ_ENOTSUP,
-              "lnz_lanczosnet_forward: hidden width %d not in {64,128}", a.dhid);
+              "%s: N=%d > %d-node tile (multi-tile molecules not built yet)", who, a.N, LNZ_TILE);
+  LNZ_REQUIRE(a.K <= 2 * KHMAX, LNZ_ENOTSUP, "%s: K=%d > %d", who, a.K, 2 * KHMAX);
+  LNZ_REQUIRE(a.num_layer <= 16, LNZ_ENOTSUP, "%s: num_layer=%d > 16", who, a.num_layer);
+  LNZ_REQUIRE(a.dhid == 64 || a.dhid == 128, LNZ_ENOTSUP, "%s: hidden width %d not in {64,128}",
+              who, a.dhid);
   LNZ_REQUIRE(a.din0 > 0 && a.din0 % 32 == 0 && a.din0 <= 128, LNZ_ENOTSUP,
-              "lnz_lanczosnet_forward: input width %d must be a multiple of 32, <= 128 "
-              "(zero-pad features and weight columns on the host)", a.din0);
-  LNZ_REQUIRE(a.dout >= 1 && a.dout <= 31, LNZ_ENOTSUP,
-              "lnz_lanczosnet_forward: output width %d not in 1..31", a.dout);
+              "%s: input width %d must be a multiple of 32, <= 128 (zero-pad features and weight "
+              "columns on the host)", who, a.din0);
   LNZ_REQUIRE(a.n_short >= 0 && a.n_short <= 8 && a.n_long >= 0 && a.n_edge >= 1 &&
                   a.n_short + a.n_long + a.n_edge <= LNZ_MAX_CHANNELS,
-              LNZ_EINVAL, "lnz_lanczosnet_forward: bad channel counts");
-  LNZ_REQUIRE((a.node_feat && a.embedding && a.num_atom > 0) || a.node_feat_f, LNZ_EINVAL,
-              "lnz_lanczosnet_forward: need node_feat+embedding or node_feat_f");
-  LNZ_REQUIRE(a.mask && (a.Lp || (a.gemm_mode == 1 && a.Lp16)) && a.V && a.Wp && a.bias &&
-                  a.Wp_head && a.bias_head && a.score,
-              LNZ_EINVAL, "lnz_lanczosnet_forward: null tensor pointer");
-  LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "lnz_lanczosnet_forward: G missing");
-  hipStream_t s = (hipStream_t)stream;
-  LNZ_REQUIRE(a.gemm_mode == 0 || a.gemm_mode == 1, LNZ_EINVAL,
-              "lnz_lanczosnet_forward: gemm_mode %d", a.gemm_mode);
-  if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
+              LNZ_EINVAL, "%s: bad channel counts", who);
+  LNZ_REQUIRE(a.mask && a.V && (a.Lp || (a.gemm_mode == 1 && a.Lp16)), LNZ_EINVAL,
+              "%s: null tensor pointer", who);
+  LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "%s: G missing", who);
+  LNZ_REQUIRE(a.gemm_mode == 0 || a.gemm_mode == 1, LNZ_EINVAL, "%s: gemm_mode %d", who,
+              a.gemm_mode);
+  LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL, "%s: filter_kind %d", who,
+              a.filter_kind);
   LNZ_REQUIRE(!a.plan || (a.n_wg && a.plan_wg_cap > 0), LNZ_EINVAL,
-              "lnz_lanczosnet_forward: plan without n_wg / plan_wg_cap");
+              "%s: plan without n_wg / plan_wg_cap", who);
+  if (mode == 0) {
+    LNZ_REQUIRE(a.dout >= 1 && a.dout <= 31, LNZ_ENOTSUP, "%s: output width %d not in 1..31", who,
+                a.dout);
+    LNZ_REQUIRE((a.node_feat && a.embedding && a.num_atom > 0) || a.node_feat_f, LNZ_EINVAL,
+                "%s: need node_feat+embedding or node_feat_f", who);
+    LNZ_REQUIRE(a.Wp && a.bias && a.Wp_head && a.bias_head && a.score, LNZ_EINVAL,
+                "%s: null tensor pointer", who);
+    LNZ_REQUIRE(!a.act_out || (a.gemm_mode == 0 && a.filter_kind == 0), LNZ_ENOTSUP,
+                "%s: act_out needs gemm_mode 0 and filter_kind 0", who);
+    if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
+  } else {
+    LNZ_REQUIRE(a.gemm_mode == 0 && a.filter_kind == 0 && a.dhid == 128, LNZ_ENOTSUP,
+                "%s: built for gemm_mode 0, filter_kind 0, hidden width 128", who);
+    LNZ_REQUIRE(a.act || a.num_layer == 1, LNZ_EINVAL, "%s: act missing", who);
+    if (mode == 1) {
+      LNZ_REQUIRE(a.Wp && a.dy && a.dx0 && a.din0 == a.dhid && a.bwd_din0 > 0 &&
+                      a.bwd_din0 % 32 == 0 && a.bwd_din0 <= a.dhid,
+                  LNZ_EINVAL, "%s: need Wp (transposed packs), dy, dx0, din0 == dhid, bwd_din0", who);
+    } else {
+      LNZ_REQUIRE(a.msg && a.msg_layer >= 0 && a.msg_layer < a.num_layer &&
+                      (a.msg_layer > 0 || a.x0),
+                  LNZ_EINVAL, "%s: need msg, msg_layer in range, x0 for layer 0", who);
+    }
+  }
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;  // upper bound of the workgroup count
-  LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL,
-              "lnz_lanczosnet_forward: filter_kind %d", a.filter_kind);
   // dynamic LDS: per-layer spectral gains of both halves, double buffered (filter_kind 0)
   const size_t gs_bytes = a.filter_kind == 0 ? (size_t)2 * 2 * MOLS * a.n_long * 32 * sizeof(float) : 0;
   LNZ_REQUIRE(gs_bytes <= 12288, LNZ_ENOTSUP,
-              "lnz_lanczosnet_forward: %d long-diffusion channels exceed the 12 whose gains fit in "
-              "LDS next to the node tiles", a.n_long);
-#define LNZ_LAUNCH(NWV_, KHT_, FK_)                                                              \
+              "%s: %d long-diffusion channels exceed the 12 whose gains fit in LDS next to the node "
+              "tiles", who, a.n_long);
+#define LNZ_LAUNCH(NWV_, KHT_, FK_, MODE_)                                                       \
   do {                                                                                           \
-    auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_>;                                       \
+    auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_, MODE_>;                                \
     if (gs_bytes)                                                                                \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 (int)gs_bytes);                                                  \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(128 * NWV_), gs_bytes, s, a);                       \
   } while (0)
-  if (a.filter_kind == 0) {
-    const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
-    if (a.dhid == 128 && k20) LNZ_LAUNCH(4, 10, 0);
-    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 0);
-    else if (k20) LNZ_LAUNCH(2, 10, 0);
-    else LNZ_LAUNCH(2, KHMAX, 0);
+  const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
+  if (mode == 1) {
+    if (k20) LNZ_LAUNCH(4, 10, 0, 1);
+    else LNZ_LAUNCH(4, KHMAX, 0, 1);
+  } else if (mode == 2) {
+    if (k20) LNZ_LAUNCH(4, 10, 0, 2);
+    else LNZ_LAUNCH(4, KHMAX, 0, 2);
+  } else if (a.filter_kind == 0 && a.act_out) {
+    LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
+    if (k20) LNZ_LAUNCH(4, 10, 0, 3);
+    else LNZ_LAUNCH(4, KHMAX, 0, 3);
+  } else if (a.filter_kind == 0) {
+    if (a.dhid == 128 && k20) LNZ_LAUNCH(4, 10, 0, 0);
+    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 0, 0);
+    else if (k20) LNZ_LAUNCH(2, 10, 0, 0);
+    else LNZ_LAUNCH(2, KHMAX, 0, 0);
   } else {
     const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
-    if (a.dhid == 128 && k24) LNZ_LAUNCH(4, 12, 1);
-    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 1);
-    else if (k24) LNZ_LAUNCH(2, 12, 1);
-    else LNZ_LAUNCH(2, KHMAX, 1);
+    if (a.dhid == 128 && k24) LNZ_LAUNCH(4, 12, 1, 0);
+    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 1, 0);
+    else if (k24) LNZ_LAUNCH(2, 12, 1, 0);
+    else LNZ_LAUNCH(2, KHMAX, 1, 0);
   }
 #undef LNZ_LAUNCH
-  return lnz::check_launch("lnz_lanczosnet_forward");
+  return lnz::check_launch(who);
+}
+
+extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream) {
+  LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_forward: null args");
+  return launch_conv(*args, 0, (hipStream_t)stream, "lnz_lanczosnet_forward");
+}
+
+extern "C" int lnz_lanczosnet_input_grad(const lnz_forward_args* args, lnz_stream_t stream) {
+  LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_input_grad: null args");
+  return launch_conv(*args, 1, (hipStream_t)stream, "lnz_lanczosnet_input_grad");
+}
+
+extern "C" int lnz_lanczosnet_messages(const lnz_forward_args* args, lnz_stream_t stream) {
+  LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_messages: null args");
+  return launch_conv(*args, 2, (hipStream_t)stream, "lnz_lanczosnet_messages");
 }

@@ -38,6 +38,9 @@ class _LanczosNetBase(nn.Module):
     # 'fp32' (default): exact fp32 MFMA.  'f16x3': opt-in split-precision GEMM1 (x_hi w_hi + x_hi w_lo
     # + x_lo w_hi on fp16 MFMA, fp32 accumulate; 6e-7 vs fp64, parity bar 1e-5) — see DESIGN.md §4.7
     gemm_mode = os.environ.get('LANCZOSNET_GEMM', 'fp32')
+    # 'hip' = HIP backward kernels where built (LanczosNet, width 128); 'torch' = autograd through
+    # the torch recomputation everywhere (the gradient oracle the HIP backward is tested against)
+    backward_impl = os.environ.get('LANCZOSNET_BACKWARD', 'hip')
     _spectral_hidden = _SPECTRAL_HIDDEN
 
     def _spectral_io(self):
@@ -303,6 +306,39 @@ class _LanczosNetBase(nn.Module):
         self._plan_large_cache = dict(sig=sig, mlp_pack=buf)
         return self._plan_large_cache
 
+    def _fused_backward_supported(self):
+        """The HIP backward (lnz_lanczosnet_input_grad / _messages) is built for the exact-fp32
+        LanczosNet kernel with hidden width 128."""
+        return (self.filter_kind == 0 and self.gemm_mode == 'fp32' and self._fused_supported()
+                and self.hidden_dim[0] == 128 and self.backward_impl == 'hip')
+
+    @torch.no_grad()
+    def _plan_backward(self):
+        """Transposed packs for lnz_lanczosnet_input_grad: kernel layer t = conv layer L-1-t holds
+        pack_rows_k8 of Wb[i][c*128 + o] = W_l[o][c*d_l + i]."""
+        plan = self._plan()
+        if 'Wp_t' in plan:
+            return plan
+        dev = self.filter[0].weight.device
+        n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
+        dhid, din0, din0p = plan['dhid'], plan['din0_raw'], plan['din0']
+        packs, offs, off = [], [], 0
+        for t in range(self.num_layer):
+            la = self.num_layer - 1 - t
+            w = self.filter[la].weight.detach().float()
+            d = din0 if la == 0 else dhid
+            w = w.view(dhid, n_chan, d)
+            if la == 0 and din0p != din0:
+                w = torch.nn.functional.pad(w, (0, din0p - din0))
+            wb = w.permute(2, 1, 0).reshape(w.shape[2], n_chan * dhid).contiguous()
+            pk = ops.pack_rows_k8(wb)
+            packs.append(pk)
+            offs.append(off)
+            off += pk.numel()
+        plan['Wp_t'] = torch.cat(packs + [torch.zeros(1024, dtype=torch.float32, device=dev)])
+        plan['wt_off'] = offs
+        return plan
+
     def _torch_forward(self, node_feat, L, D, V, mask):
         """Differentiable torch restatement of the same math (device tensors, channel-major L,
         `M_c (X W_c^T)` association) — used ONLY inside backward to obtain parameter gradients;
@@ -360,15 +396,126 @@ class _LanczosNetBase(nn.Module):
                 self._warned_library_path = True
             score = self._large_graph_forward(node_feat, L, D, V, mask)
         elif self._needs_grad():
-            # training (runner/qm8_runner.py:216-248): forward = HIP kernels, backward = autograd
-            # through a torch recomputation on the same device (_LanczosNetFunction)
-            score = _LanczosNetFunction.apply(self, node_feat, L, D, V, mask,
-                                              *[p for p in self.parameters()])
+            # training (runner/qm8_runner.py:216-248): forward = HIP kernels; backward = the HIP
+            # input-gradient and message kernels + library GEMMs (_LanczosNetFusedFunction) where
+            # built, else autograd through a torch recomputation (_LanczosNetFunction)
+            fn = _LanczosNetFusedFunction if self._fused_backward_supported() else _LanczosNetFunction
+            score = fn.apply(self, node_feat, L, D, V, mask, *[p for p in self.parameters()])
         else:
             score = self._hip_forward(node_feat, L, D, V, mask)
         if label is not None:
             return score, self.loss_func(score, label)
         return score
+
+
+class _LanczosNetFusedFunction(torch.autograd.Function):
+    """Training through the HIP kernels.
+
+    forward: the fused kernel, storing every layer's activations.
+    backward: head by torch autograd on the stored last state; node-state gradients of the whole
+    conv stack by lnz_lanczosnet_input_grad (the forward's two chained GEMMs run on dY with
+    transposed weights); per layer the reference's message matrix by lnz_lanczosnet_messages and
+    dW = dY^T msg as one library GEMM; spectral-MLP gradients from dG[b,k,s] =
+    sum_i ((V^T dY) W_s)[b,k,i] (V^T X)[b,k,i] and torch autograd through the small MLP; embedding
+    rows by index_add.  Inputs L, D, V, mask, node ids are data: no gradient."""
+
+    @staticmethod
+    def forward(ctx, module, node_feat, L, D, V, mask, *params):
+        plan = module._plan()
+        mask_u8 = mask.to(torch.uint8).contiguous()
+        Vc = V.float().contiguous()
+        B = Vc.shape[0]
+        Lp = ops.pack_laplacian_for(plan, L)
+        G = None
+        if module.num_scale_long > 0:
+            G = ops.spectral_gains(D, module.long_diffusion_dist, module.num_layer, plan['mlp_pack'])
+        tiles = ops.plan_tiles(mask_u8, allow_pairs=True)
+        act = torch.zeros((module.num_layer, B, 32, plan['dhid']), dtype=torch.float32,
+                          device=Vc.device)
+        score = ops.lanczosnet_forward(plan, node_feat, Lp, Vc, G, mask_u8, tiling=tiles,
+                                       act_out=act)
+        ctx.module, ctx.cap = module, tiles[1]
+        ctx.save_for_backward(node_feat, D, Vc, mask_u8, Lp, G, act, tiles[0])
+        return score
+
+    @staticmethod
+    def backward(ctx, grad_score):
+        m = ctx.module
+        node_feat, D, V, mask_u8, Lp, G, act, tile_buf = ctx.saved_tensors
+        tiles = (tile_buf, ctx.cap)
+        plan = m._plan_backward()
+        B, N, K = V.shape
+        Lnum, dh = m.num_layer, plan['dhid']
+        din0, din0p = plan['din0_raw'], plan['din0']
+        S, n_short = m.num_scale_long, m.num_scale_short
+        n_chan = n_short + S + m.num_edgetype + 1
+        dev = V.device
+        grads = {}
+
+        # ---- head (model/lanczos_net.py:185-194) on the stored last state
+        head_params = list(m.filter[-1].parameters()) + list(m.att_func.parameters())
+        with torch.enable_grad():
+            XL = act[Lnum - 1][:, :N].detach().requires_grad_(True)
+            y = m.filter[-1](XL) * m.att_func(XL)
+            mk = (mask_u8 != 0).float().unsqueeze(2)
+            score = (y * mk).sum(dim=1) / mk.sum(dim=1)
+            hg = torch.autograd.grad(score, [XL] + head_params, grad_score.contiguous())
+        for p_, g_ in zip(head_params, hg[1:]):
+            grads[id(p_)] = g_
+        dy = torch.zeros((Lnum, B, 32, dh), dtype=torch.float32, device=dev)
+        dy[Lnum - 1][:, :N] = hg[0] * (XL > 0).float()
+        dx0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
+
+        # ---- node-state gradients of the conv stack
+        ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles)
+
+        # ---- X_0
+        x0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
+        if m.general:
+            x0[:, :N, :din0] = node_feat.float()
+        else:
+            x0[:, :N, :din0] = m.embedding.weight.detach()[node_feat]
+
+        # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l
+        msg_h = torch.zeros((B * 32, n_chan * dh), dtype=torch.float32, device=dev)
+        msg_0 = torch.zeros((B * 32, n_chan * din0p), dtype=torch.float32, device=dev)
+        for la in range(Lnum):
+            msg = msg_0 if la == 0 else msg_h
+            ops.lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, la, msg, tiles)
+            dyl = dy[la].view(B * 32, dh)
+            dW = dyl.t() @ msg
+            if la == 0 and din0p != din0:
+                dW = dW.view(dh, n_chan, din0p)[:, :, :din0].reshape(dh, n_chan * din0)
+            grads[id(m.filter[la].weight)] = dW
+            grads[id(m.filter[la].bias)] = dyl.sum(dim=0)
+
+        # ---- spectral filter MLPs (model/lanczos_net.py:95-123): dG, then autograd through the MLP
+        if S > 0 and m._has_mlp():
+            Vt = V.transpose(1, 2)
+            pows = torch.stack([torch.pow(D.float(), p) for p in m.long_diffusion_dist], dim=2)
+            for la in range(Lnum):
+                d = din0 if la == 0 else dh
+                Xl = (x0 if la == 0 else act[la - 1])[:, :N, :d]
+                dYv = torch.bmm(Vt, dy[la][:, :N])                      # [B,K,dh]
+                Xv = torch.bmm(Vt, Xl)                                  # [B,K,d]
+                Wl = m.filter[la].weight.detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]
+                R = torch.matmul(dYv.reshape(B * K, dh), Wl.reshape(dh, S * d)).view(B, K, S, d)
+                dG = (R * Xv.unsqueeze(2)).sum(dim=3)                   # [B,K,S]
+                mlp_params = list(m.spectral_filter[la].parameters())
+                with torch.enable_grad():
+                    Gl = m.spectral_filter[la](pows.view(-1, S)).view(B, K, S)
+                    gg = torch.autograd.grad(Gl, mlp_params, dG)
+                for p_, g_ in zip(mlp_params, gg):
+                    grads[id(p_)] = g_
+
+        # ---- embedding rows
+        if not m.general:
+            dE = torch.zeros_like(m.embedding.weight)
+            dE.index_add_(0, node_feat.reshape(-1), dx0[:, :N, :din0].reshape(-1, din0))
+            grads[id(m.embedding.weight)] = dE
+
+        out = [grads.get(id(p_)) if p_.requires_grad else None for p_ in m.parameters()]
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class _LanczosNetFunction(torch.autograd.Function):

@@ -267,11 +267,14 @@ def pairing_supported(plan):
   return plan.get('Wp16') is None and int(plan.get('filter_kind', 0)) == 0
 
 
-def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tiling='auto'):
+def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tiling='auto',
+                       act_out=None):
   """Launch the fused forward.  `plan` is a dict made by LanczosNet._plan() holding the packed
   parameters and the static sizes.  tiling: 'auto' = lnz_plan_tiles with pairing where the kernel
   supports it, 'single' = planned but one molecule per tile, 'none' = no plan (batch order), or
-  the (buf, cap) pair returned by plan_tiles() for this mask (pairs only for the exact kernel)."""
+  the (buf, cap) pair returned by plan_tiles() for this mask (pairs only for the exact kernel).
+  act_out: optional zero-initialised [num_layer,B,32,dhid] that receives every layer's activations
+  (training forward)."""
   _need_cuda(node_feat, Lp, V, G, mask)
   B, N, K = V.shape
   a = _lib.ForwardArgs()
@@ -330,6 +333,10 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     a.plan_wg_cap = cap
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
   a.score = score.data_ptr()
+  if act_out is not None:
+    assert tuple(act_out.shape) == (plan['num_layer'], B, 32, plan['dhid']) and \
+        act_out.is_contiguous() and act_out.dtype == torch.float32
+    a.act_out = act_out.data_ptr()
   state = None
   if return_state:
     state = torch.zeros((B, 32, plan['dhid']), dtype=torch.float32, device=V.device)
@@ -338,6 +345,62 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   with torch.cuda.device(V.device):
     _lib.check(lib.lnz_lanczosnet_forward(C.byref(a), _stream()))
   return (score, state) if return_state else score
+
+
+def _training_args(plan, Lp, V, G, mask_u8, tiling):
+  """Common part of the two training launches: sizes, operators, gains, tile plan."""
+  B, N, K = V.shape
+  a = _lib.ForwardArgs()
+  a.B, a.N, a.K = B, N, K
+  a.num_layer = plan['num_layer']
+  a.dhid, a.dout = plan['dhid'], plan['dout']
+  a.n_short, a.n_long, a.n_edge = len(plan['short']), plan['n_long'], plan['n_edge']
+  for i, p in enumerate(plan['short']):
+    a.short_dist[i] = int(p)
+  a.mask, a.V, a.Lp = mask_u8.data_ptr(), V.data_ptr(), Lp.data_ptr()
+  a.G = G.data_ptr() if G is not None else None
+  a.filter_kind, a.gemm_mode = 0, 0
+  tiles, cap = tiling
+  a.plan, a.n_wg, a.plan_wg_cap = tiles.data_ptr(), tiles.data_ptr() + 48 * cap, cap
+  return a
+
+
+def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling):
+  """lnz_lanczosnet_input_grad: dy[num_layer-1] holds dLoss/dY of the last conv layer on entry;
+  fills dy[0..num_layer-2] and dx0 [B,32,din0].  plan['Wp_t'] / plan['wt_off']: transposed packs in
+  kernel-layer order (LanczosNet._plan_backward).  All buffers zero-initialised by the caller."""
+  _need_cuda(Lp, V, G, mask_u8, act, dy, dx0)
+  a = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  B = V.shape[0]
+  L, dh = plan['num_layer'], plan['dhid']
+  assert tuple(dy.shape) == (L, B, 32, dh) and dy.is_contiguous() and dy.dtype == torch.float32
+  assert tuple(act.shape) == (L, B, 32, dh) and act.is_contiguous() and act.dtype == torch.float32
+  assert tuple(dx0.shape) == (B, 32, plan['din0']) and dx0.is_contiguous()
+  a.din0, a.bwd_din0 = dh, plan['din0']
+  a.Wp = plan['Wp_t'].data_ptr()
+  for i in range(L):
+    a.w_off[i] = plan['wt_off'][i]
+  a.act, a.dy, a.dx0 = act.data_ptr(), dy.data_ptr(), dx0.data_ptr()
+  lib = _lib.load()
+  with torch.cuda.device(V.device):
+    _lib.check(lib.lnz_lanczosnet_input_grad(C.byref(a), _stream()))
+
+
+def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling):
+  """lnz_lanczosnet_messages: msg [B*32, C*d] = cat_c(M_c X_layer) (zero-initialised by the
+  caller); x0 [B,32,din0] is X_0, act the stored activations of the forward."""
+  _need_cuda(Lp, V, G, mask_u8, act, x0, msg)
+  a = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  B = V.shape[0]
+  d = plan['din0'] if layer == 0 else plan['dhid']
+  Cn = a.n_short + a.n_long + a.n_edge
+  assert tuple(msg.shape) == (B * 32, Cn * d) and msg.is_contiguous() and msg.dtype == torch.float32
+  assert tuple(x0.shape) == (B, 32, plan['din0']) and x0.is_contiguous()
+  a.din0 = plan['din0']
+  a.act, a.x0, a.msg, a.msg_layer = act.data_ptr(), x0.data_ptr(), msg.data_ptr(), layer
+  lib = _lib.load()
+  with torch.cuda.device(V.device):
+    _lib.check(lib.lnz_lanczosnet_messages(C.byref(a), _stream()))
 
 
 # ------------------------------------------------------------------------------ R4, R5, R8 (Ada)
