@@ -489,30 +489,46 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
             grads[id(m.filter[la].weight)] = dW
             grads[id(m.filter[la].bias)] = dyl.sum(dim=0)
 
-        # ---- spectral filter MLPs (model/lanczos_net.py:95-123): dG, then autograd through the MLP
+        # ---- spectral filter MLPs (model/lanczos_net.py:95-123): dG, then autograd through the MLPs.
+        #      All layers at once: one batched V^T [dY_0..dY_L-1 | X_0..X_L-1], one batched MLP.
         if S > 0 and m._has_mlp():
             Vt = V.transpose(1, 2)
-            pows = torch.stack([torch.pow(D.float(), p) for p in m.long_diffusion_dist], dim=2)
+            cat = torch.cat([dy[:, :, :N].permute(1, 2, 0, 3).reshape(B, N, Lnum * dh),
+                             x0[:, :N],
+                             act[:Lnum - 1, :, :N].permute(1, 2, 0, 3).reshape(B, N, (Lnum - 1) * dh)],
+                            dim=2)
+            proj = torch.bmm(Vt, cat)                                   # [B,K,L*dh + din0p + (L-1)*dh]
+            dYv = proj[:, :, :Lnum * dh].reshape(B * K, Lnum, dh)
+            dG = []
             for la in range(Lnum):
                 d = din0 if la == 0 else dh
-                Xl = (x0 if la == 0 else act[la - 1])[:, :N, :d]
-                dYv = torch.bmm(Vt, dy[la][:, :N])                      # [B,K,dh]
-                Xv = torch.bmm(Vt, Xl)                                  # [B,K,d]
+                lo = Lnum * dh if la == 0 else Lnum * dh + din0p + (la - 1) * dh
+                Xv = proj[:, :, lo:lo + d]                              # [B,K,d]
                 Wl = m.filter[la].weight.detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]
-                R = torch.matmul(dYv.reshape(B * K, dh), Wl.reshape(dh, S * d)).view(B, K, S, d)
-                dG = (R * Xv.unsqueeze(2)).sum(dim=3)                   # [B,K,S]
-                mlp_params = list(m.spectral_filter[la].parameters())
-                with torch.enable_grad():
-                    Gl = m.spectral_filter[la](pows.view(-1, S)).view(B, K, S)
-                    gg = torch.autograd.grad(Gl, mlp_params, dG)
-                for p_, g_ in zip(mlp_params, gg):
-                    grads[id(p_)] = g_
+                R = torch.matmul(dYv[:, la], Wl.reshape(dh, S * d)).view(B, K, S, d)
+                dG.append((R * Xv.unsqueeze(2)).sum(dim=3))             # [B,K,S]
+            dG = torch.stack(dG).reshape(Lnum, B * K, S)               # [L, B*K, S]
+            pows = torch.stack([torch.pow(D.float(), p) for p in m.long_diffusion_dist],
+                               dim=2).view(1, B * K, S).expand(Lnum, B * K, S)
+            lin_idx = [i for i, mod in enumerate(m.spectral_filter[0]) if isinstance(mod, nn.Linear)]
+            with torch.enable_grad():
+                h = pows
+                for li, i in enumerate(lin_idx):
+                    Wst = torch.stack([m.spectral_filter[t][i].weight for t in range(Lnum)])
+                    bst = torch.stack([m.spectral_filter[t][i].bias for t in range(Lnum)])
+                    h = torch.baddbmm(bst.unsqueeze(1), h, Wst.transpose(1, 2))
+                    if li + 1 < len(lin_idx):
+                        h = torch.relu(h)
+                mlp_params = [m.spectral_filter[t][i].weight for i in lin_idx for t in range(Lnum)] + \
+                             [m.spectral_filter[t][i].bias for i in lin_idx for t in range(Lnum)]
+                gg = torch.autograd.grad(h, mlp_params, dG)
+            for p_, g_ in zip(mlp_params, gg):
+                grads[id(p_)] = g_
 
-        # ---- embedding rows
+        # ---- embedding rows: one-hot^T dX_0 as a GEMM (index_add's atomics are 10x slower here)
         if not m.general:
-            dE = torch.zeros_like(m.embedding.weight)
-            dE.index_add_(0, node_feat.reshape(-1), dx0[:, :N, :din0].reshape(-1, din0))
-            grads[id(m.embedding.weight)] = dE
+            onehot = torch.nn.functional.one_hot(node_feat.reshape(-1), m.num_atom).to(torch.float32)
+            grads[id(m.embedding.weight)] = onehot.t() @ dx0[:, :N, :din0].reshape(-1, din0)
 
         out = [grads.get(id(p_)) if p_.requires_grad else None for p_ in m.parameters()]
         return (None, None, None, None, None, None) + tuple(out)
