@@ -198,6 +198,9 @@ typedef struct lnz_forward_args {
                                  (b*32 + node), column c*d + i = (M_c X_l)[node][i] — the reference's
                                  cat(msg) (model/lanczos_net.py:164-180)                           */
   int32_t msg_layer;          /* messages: the conv layer l whose messages are built                 */
+  const int64_t* row_off;     /* messages, optional [B]: first row of each molecule in a COMPACT msg
+                                 (real nodes only: row_off = exclusive scan of the node counts, rows
+                                 >= n are not written); NULL = row b*32 + node                     */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
 /* Backward of the conv stack w.r.t. its node-state inputs, in the forward's own structure:

@@ -163,7 +163,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   //      pair tile drops the steps whose slots are k >= n for both molecules — those slots are
   //      zero (dataset/qm8.py:264-291), so dropping them changes no bit.
   const int KH = (K + 1) >> 1;
-  int g2mask[MT], H[MT];
+  int g2mask[MT], H[MT], nA[MT], nB[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const bool pr = td[m].tb >= 0;
@@ -180,6 +180,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     la = __builtin_amdgcn_readfirstlane(la);
     lb = __builtin_amdgcn_readfirstlane(lb);
     const int g0 = td[m].split >> 3;
+    nA[m] = la;
+    nB[m] = lb;
     g2mask[m] = ((1 << ((la + 7) >> 3)) - 1) | (((1 << ((lb + 7) >> 3)) - 1) << g0);
     const int k16 = K < 16 ? K : 16;
     const int nmax = la > lb ? la : lb;
@@ -484,13 +486,17 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           const int64_t ld = (int64_t)C * wout;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            if ((g2mask[m] >> g) & 1) {  // rows of groups no molecule owns stay zero
+            if ((g2mask[m] >> g) & 1) {  // rows of groups no molecule owns are never written
               const bool first = 8 * g < td[m].split;
               const int mol = first ? td[m].ta : td[m].tb;
               const int lrow0 = 8 * g + 4 * hh - (first ? 0 : td[m].split);
-              float* p = a.msg + ((int64_t)mol * 32 + lrow0) * ld + (int64_t)c * wout + 32 * wave + j;
+              // row_off: compact row numbering (real nodes only); else 32 rows per molecule
+              const int64_t r0 = a.row_off ? (int64_t)a.row_off[mol] + lrow0 : (int64_t)mol * 32 + lrow0;
+              const int nmol = a.row_off ? (first ? nA[m] : nB[m]) : 32;
+              float* p = a.msg + r0 * ld + (int64_t)c * wout + 32 * wave + j;
 #pragma unroll
-              for (int u = 0; u < 4; ++u) p[u * ld] = P[4 * g + u];
+              for (int u = 0; u < 4; ++u)
+                if (lrow0 + u < nmol) p[u * ld] = P[4 * g + u];
             }
           }
         }

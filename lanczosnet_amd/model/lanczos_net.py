@@ -476,13 +476,21 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         else:
             x0[:, :N, :din0] = m.embedding.weight.detach()[node_feat]
 
-        # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l
-        msg_h = torch.zeros((B * 32, n_chan * dh), dtype=torch.float32, device=dev)
-        msg_0 = torch.zeros((B * 32, n_chan * din0p), dtype=torch.float32, device=dev)
+        # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l, over
+        #      the REAL node rows only (half of the padded rows are empty): compact row numbering
+        # node extent (last real node + 1) — what the kernels size a molecule by
+        n_mol = ((mask_u8 != 0).long() * torch.arange(1, N + 1, device=dev).view(1, N)).amax(dim=1)
+        row_off = (torch.cumsum(n_mol, 0) - n_mol).contiguous()                  # int64 [B]
+        node = torch.arange(32, device=dev).view(1, 32)
+        real = (node < n_mol.view(B, 1)).view(-1).nonzero().view(-1)             # sync: row count
+        R_tot = real.numel()
+        msg_buf = torch.empty((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
         for la in range(Lnum):
-            msg = msg_0 if la == 0 else msg_h
-            ops.lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, la, msg, tiles)
-            dyl = dy[la].view(B * 32, dh)
+            d = din0p if la == 0 else dh
+            msg = msg_buf[:R_tot * n_chan * d].view(R_tot, n_chan * d)
+            ops.lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, la, msg, tiles,
+                                    row_off=row_off)
+            dyl = dy[la].view(B * 32, dh).index_select(0, real)
             dW = dyl.t() @ msg
             if la == 0 and din0p != din0:
                 dW = dW.view(dh, n_chan, din0p)[:, :, :din0].reshape(dh, n_chan * din0)

@@ -386,18 +386,24 @@ def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling):
     _lib.check(lib.lnz_lanczosnet_input_grad(C.byref(a), _stream()))
 
 
-def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling):
+def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, row_off=None):
   """lnz_lanczosnet_messages: msg [B*32, C*d] = cat_c(M_c X_layer) (zero-initialised by the
-  caller); x0 [B,32,din0] is X_0, act the stored activations of the forward."""
+  caller); x0 [B,32,din0] is X_0, act the stored activations of the forward.  With row_off [B]
+  int64 (exclusive scan of the node counts) msg is compact, [sum(n), C*d], real nodes only, and
+  needs no initialisation."""
   _need_cuda(Lp, V, G, mask_u8, act, x0, msg)
   a = _training_args(plan, Lp, V, G, mask_u8, tiling)
   B = V.shape[0]
   d = plan['din0'] if layer == 0 else plan['dhid']
   Cn = a.n_short + a.n_long + a.n_edge
-  assert tuple(msg.shape) == (B * 32, Cn * d) and msg.is_contiguous() and msg.dtype == torch.float32
+  assert msg.shape[1] == Cn * d and msg.is_contiguous() and msg.dtype == torch.float32
+  assert row_off is not None or msg.shape[0] == B * 32
   assert tuple(x0.shape) == (B, 32, plan['din0']) and x0.is_contiguous()
   a.din0 = plan['din0']
   a.act, a.x0, a.msg, a.msg_layer = act.data_ptr(), x0.data_ptr(), msg.data_ptr(), layer
+  if row_off is not None:
+    assert row_off.dtype == torch.int64 and row_off.is_contiguous() and row_off.numel() == B
+    a.row_off = row_off.data_ptr()
   lib = _lib.load()
   with torch.cuda.device(V.device):
     _lib.check(lib.lnz_lanczosnet_messages(C.byref(a), _stream()))

@@ -72,6 +72,33 @@ def _free_port():
   return p
 
 
+def _grad_worker(rank, world, port, out_dir):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    x, y = torch.randn(11, 5), torch.randn(11, 3)
+    ref = torch.autograd.grad(torch.nn.functional.mse_loss(net(x), y), list(net.parameters()))
+    lo, hi = lnz_dist.shard_bounds(11, rank, world)  # uneven shards: 11 rows over 2 or 3 ranks
+    torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+    lnz_dist.all_reduce_gradients(net.parameters(), hi - lo)
+    ok = all(torch.allclose(p.grad, g, rtol=1e-5, atol=1e-7) for p, g in zip(net.parameters(), ref))
+    np.save(os.path.join(out_dir, 'g%d.npy' % rank), np.array([ok], dtype=np.int64))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gradient_all_reduce_is_the_full_batch_gradient(world, tmp_path):
+  """Shard-size-weighted flat-bucket all-reduce == gradient of the unsharded mean loss."""
+  port = _free_port()
+  mp.spawn(_grad_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  for r in range(world):
+    assert np.load(os.path.join(str(tmp_path), 'g%d.npy' % r))[0] == 1
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_forward_matches_single_process(world, tmp_path):
   mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
