@@ -233,7 +233,7 @@ def main():
                                'Ritz pairs + spectral gains + tile plan + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, score all-gather)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
-        'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0>', 'bound': 'mfma',
+        'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',
                      'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                      'traffic': traffic,
