@@ -642,3 +642,38 @@ def test_hip_backward_matches_torch_autograd_elementwise(B, seed):
     # both sides are fp32 sums over up to 32768 node rows in different orders
     assert (a - b).abs().max().item() <= 1e-3 * scale + 1e-10, (k, (a - b).abs().max().item(), scale)
     assert (a - b).norm().item() <= 1e-3 * b.norm().item() + 1e-10, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,general', [('MLP', False), ('None', False), ('MLP', True)])
+def test_hip_backward_short_channels_general_and_power_filters(kind, general):
+  """The HIP backward on the branches the QM8 config does not reach: short-diffusion channels
+  (M = L_0^p chains), plain-power spectral filters (no MLP parameters), float node features
+  with an input width that is zero-padded to 32 columns (LanczosNetGeneral)."""
+  from lanczosnet_amd import ops
+  cfg = dict(num_atom=13, num_bond_type=2, short_diffusion_dist=[1, 3], long_diffusion_dist=[2, 5, 7],
+             num_eig_vec=12, spectral_filter_kind=kind, input_dim=10 if general else 32,
+             hidden_dim=[128, 128, 128], output_dim=4, num_layer=3)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 21, general=general), general=general).train()
+  assert net._fused_backward_supported()
+  batch = draw_batch(29, seed=8, n_min=4, n_max=24, num_atom=13, num_bond_type=2, num_label=4)
+  n = _t(batch['n_nodes'])
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 12)
+  mask, label = _t(batch['node_mask']), _t(batch['label'])
+  if general:
+    rs = np.random.RandomState(1)
+    nf = _t(rs.randn(29, L.shape[1], 10).astype(np.float32)) * mask.unsqueeze(2).float()
+  else:
+    nf = _t(batch['node_feat'])
+  got = {}
+  for impl in ('hip', 'torch'):
+    net.backward_impl = impl
+    net.zero_grad(set_to_none=True)
+    score, loss = net(nf, L, D, V, label=label, mask=mask)
+    loss.backward()
+    got[impl] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+  assert set(got['hip']) == set(got['torch'])
+  for k in got['hip']:
+    a, b = got['hip'][k], got['torch'][k]
+    assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-9, k
