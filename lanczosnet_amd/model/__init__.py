@@ -1,3 +1,4 @@
 from .lanczos_net import LanczosNet, LanczosNetGeneral, AdaLanczosNet  # noqa: F401
+from .baselines import GCN, DCNN  # noqa: F401
 
-__all__ = ['LanczosNet', 'LanczosNetGeneral', 'AdaLanczosNet']
+__all__ = ['LanczosNet', 'LanczosNetGeneral', 'AdaLanczosNet', 'GCN', 'DCNN']

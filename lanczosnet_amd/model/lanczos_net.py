@@ -56,14 +56,15 @@ class _LanczosNetBase(nn.Module):
         self.num_layer = m.num_layer
         self._read_dataset(config.dataset)
         self.dropout = _opt(m, 'dropout', 0.0)
-        self.short_diffusion_dist = check_dist(list(m.short_diffusion_dist))
-        self.long_diffusion_dist = check_dist(list(m.long_diffusion_dist))
+        short, long_, num_eig, kind = self._diffusion_conf(m)
+        self.short_diffusion_dist = check_dist(short)
+        self.long_diffusion_dist = check_dist(long_)
         self.max_short_diffusion_dist = max(self.short_diffusion_dist, default=None)
         self.max_long_diffusion_dist = max(self.long_diffusion_dist, default=None)
         self.num_scale_short = len(self.short_diffusion_dist)
         self.num_scale_long = len(self.long_diffusion_dist)
-        self.num_eig_vec = m.num_eig_vec
-        self.spectral_filter_kind = m.spectral_filter_kind
+        self.num_eig_vec = num_eig
+        self.spectral_filter_kind = kind
 
         self._override_dims()
         widths = [self.input_dim] + self.hidden_dim + [self.output_dim]
@@ -90,6 +91,34 @@ class _LanczosNetBase(nn.Module):
     # -- configuration hooks ------------------------------------------------------------
     def _override_dims(self):
         pass
+
+    def _channel_order(self):
+        """Reference column-block index of each KERNEL message channel (kernel order: short, long,
+        edge types) — None when the reference concatenates in that order (model/lanczos_net.py:
+        164-180); the DCNN baseline puts the edge types first (model/dcnn.py:90-97)."""
+        return None
+
+    def _mix_weight(self, t):
+        """Weight of conv layer t with its column blocks in kernel channel order (differentiable)."""
+        w = self.filter[t].weight
+        order = self._channel_order()
+        if order is None:
+            return w
+        d = w.shape[1] // len(order)
+        return w.view(w.shape[0], len(order), d)[:, order, :].reshape(w.shape[0], -1)
+
+    def _to_reference_channel_order(self, dW):
+        order = self._channel_order()
+        if order is None:
+            return dW
+        d = dW.shape[1] // len(order)
+        inv = [order.index(i) for i in range(len(order))]
+        return dW.view(dW.shape[0], len(order), d)[:, inv, :].reshape(dW.shape[0], -1)
+
+    def _diffusion_conf(self, m):
+        """(short distances, long distances, K, spectral filter kind) from the model config."""
+        return (list(m.short_diffusion_dist), list(m.long_diffusion_dist), m.num_eig_vec,
+                m.spectral_filter_kind)
 
     def _guard_forward(self, L, mask):
         if mask is None:
@@ -159,7 +188,7 @@ class _LanczosNetBase(nn.Module):
         din0p = (din0 + 31) // 32 * 32
         n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
         for t in range(self.num_layer):
-            w = self.filter[t].weight
+            w = self._mix_weight(t)
             if t == 0 and din0p != din0:
                 w = torch.nn.functional.pad(w.view(dhid, n_chan, din0), (0, din0p - din0))
                 w = w.reshape(dhid, n_chan * din0p)
@@ -198,7 +227,7 @@ class _LanczosNetBase(nn.Module):
                                           "width 128 and num_eig_vec <= 20")
             packs16, w16_off, off = [], [], 0
             for t in range(self.num_layer):
-                w = self.filter[t].weight
+                w = self._mix_weight(t)
                 d_in = w.shape[1] // n_chan
                 if d_in != 128:  # every layer consumes 128 input columns: zero-pad layer 0
                     w = torch.nn.functional.pad(w.view(dhid, n_chan, d_in), (0, 128 - d_in))
@@ -263,7 +292,7 @@ class _LanczosNetBase(nn.Module):
         Vt = Vf.transpose(1, 2).contiguous()
         state = node_feat.float() if self.general else self.embedding(node_feat)
         for t in range(self.num_layer):
-            W, bias = self.filter[t].weight, self.filter[t].bias
+            W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)
             out = bias.view(1, 1, -1).expand(B, N, -1).clone()
@@ -325,7 +354,7 @@ class _LanczosNetBase(nn.Module):
         packs, offs, off = [], [], 0
         for t in range(self.num_layer):
             la = self.num_layer - 1 - t
-            w = self.filter[la].weight.detach().float()
+            w = self._mix_weight(la).detach().float()
             d = din0 if la == 0 else dhid
             w = w.view(dhid, n_chan, d)
             if la == 0 and din0p != din0:
@@ -351,7 +380,7 @@ class _LanczosNetBase(nn.Module):
         if S > 0:
             pows = torch.stack([torch.pow(D.float(), p) for p in self.long_diffusion_dist], dim=2)
         for t in range(self.num_layer):
-            W, bias = self.filter[t].weight, self.filter[t].bias
+            W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)                       # [dout, C, d_in]
             Z = torch.einsum('bnd,ocd->bcno', state, Wc)             # X W_c^T  [B, C, N, dout]
@@ -494,7 +523,7 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
             dW = dyl.t() @ msg
             if la == 0 and din0p != din0:
                 dW = dW.view(dh, n_chan, din0p)[:, :, :din0].reshape(dh, n_chan * din0)
-            grads[id(m.filter[la].weight)] = dW
+            grads[id(m.filter[la].weight)] = m._to_reference_channel_order(dW)
             grads[id(m.filter[la].bias)] = dyl.sum(dim=0)
 
         # ---- spectral filter MLPs (model/lanczos_net.py:95-123): dG, then autograd through the MLPs.
@@ -512,7 +541,7 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
                 d = din0 if la == 0 else dh
                 lo = Lnum * dh if la == 0 else Lnum * dh + din0p + (la - 1) * dh
                 Xv = proj[:, :, lo:lo + d]                              # [B,K,d]
-                Wl = m.filter[la].weight.detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]
+                Wl = m._mix_weight(la).detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]
                 R = torch.matmul(dYv[:, la], Wl.reshape(dh, S * d)).view(B, K, S, d)
                 dG.append((R * Xv.unsqueeze(2)).sum(dim=3))             # [B,K,S]
             dG = torch.stack(dG).reshape(Lnum, B * K, S)               # [L, B*K, S]
@@ -712,7 +741,7 @@ class AdaLanczosNet(_LanczosNetBase):
         for t in range(self.num_layer):
             DD = self.spectral_filter[t](tcat).view(B, K, K, S)
             DD = (DD + DD.transpose(1, 2)) * 0.5
-            W, bias = self.filter[t].weight, self.filter[t].bias
+            W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)
             Z = torch.einsum('bnd,ocd->bcno', state, Wc)
