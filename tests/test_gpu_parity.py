@@ -677,3 +677,47 @@ def test_hip_backward_short_channels_general_and_power_filters(kind, general):
   for k in got['hip']:
     a, b = got['hip'][k], got['torch'][k]
     assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-9, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+def test_tile_plan_fuzz_against_unplanned_schedule_and_oracle(seed):
+  """Random architectures / eigen counts / size ranges: the planned schedule with pair tiles, the
+  unplanned batch order and (on a few molecules) the fp64 oracle agree to the parity tolerance."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(100 + seed)
+  dh = int(rs.choice([64, 128]))
+  cfg = dict(num_atom=17, num_bond_type=int(rs.randint(1, 5)),
+             short_diffusion_dist=sorted(rs.choice(np.arange(1, 6), size=rs.randint(0, 3), replace=False).tolist()),
+             long_diffusion_dist=sorted(rs.choice(np.arange(1, 12), size=rs.randint(0, 5), replace=False).tolist()),
+             num_eig_vec=int(rs.choice([4, 9, 12, 20, 27, 32])),
+             spectral_filter_kind=str(rs.choice(['MLP', 'None'])),
+             input_dim=int(rs.choice([32, 64])), hidden_dim=[dh] * 3, output_dim=int(rs.randint(1, 20)),
+             num_layer=int(rs.randint(1, 4)))
+  cfg['hidden_dim'] = [dh] * cfg['num_layer']
+  n_max = int(rs.choice([9, 16, 24, 32]))
+  B = int(rs.randint(1, 70))
+  batch = draw_batch(B, seed=seed, n_min=int(rs.randint(1, 5)), n_max=n_max, num_atom=17,
+                     num_bond_type=cfg['num_bond_type'], num_label=cfg['output_dim'])
+  P = oracle.make_lanczosnet_params(cfg, 50 + seed)
+  net = _model(cfg, P)
+  n = _t(batch['n_nodes'])
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  K = cfg['num_eig_vec']
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, K)
+  plan = net._plan()
+  Lp = ops.pack_laplacian_for(plan, L)
+  G = None
+  if cfg['long_diffusion_dist']:
+    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  nf, mask = _t(batch['node_feat']), _t(batch['node_mask'])
+  s_auto = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask, tiling='auto')
+  s_none = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask, tiling='none')
+  scale = s_none.abs().max().item() + 1e-12
+  assert torch.isfinite(s_auto).all()
+  assert (s_auto - s_none).abs().max().item() <= 1e-5 * scale, cfg
+  nb = min(B, 6)
+  ref = oracle.lanczos_net_forward(P, cfg, batch['node_feat'][:nb], L[:nb].cpu().numpy(),
+                                   D[:nb].cpu().numpy(), V[:nb].cpu().numpy(),
+                                   batch['node_mask'][:nb], dtype=np.float64)
+  assert rel_err(s_auto[:nb].cpu().numpy(), ref) < 1e-5, cfg
