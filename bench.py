@@ -134,10 +134,11 @@ def main():
     D, V = ops.lanczos_ritz(A, n_nodes, K)
     if events:
       events[2].record()
-    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+    tiles, rows = ops.plan_batch(mask_u8, ops.pairing_supported(plan), K)
     if events:
       events[3].record()
-    tiles = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
+    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
+                           rows=rows)
     if events:
       events[4].record()
     score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
@@ -204,7 +205,7 @@ def main():
     net.gemm_mode = 'fp32'
     plan = plan_fp32
 
-  names = ['pack_laplacian', 'lanczos_ritz', 'spectral_gains', 'plan_tiles', 'lanczosnet_forward']
+  names = ['pack_laplacian', 'lanczos_ritz', 'plan_batch', 'spectral_gains', 'lanczosnet_forward']
   stage_ms = {nm: float(np.mean([ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)]))
               for k, nm in enumerate(names)}
 
@@ -230,7 +231,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
                                'fp32, 7x128 layers, 1xMI355X per rank; step = pack L + Lanczos/QL '
-                               'Ritz pairs + spectral gains + tile plan + fused forward' % (B, L.shape[1]),
+                               'Ritz pairs + batch plan + spectral gains + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, score all-gather)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
         'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',

@@ -128,6 +128,12 @@ int lnz_pack_spectral_mlp(const float* W0, const float* b0, const float* W2, con
 int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,
                        int num_layer, int kind, const float* mlp_pack, float* G,
                        lnz_stream_t stream);
+/* Same, but (kind 0) only for the rows listed in rows[0 .. *n_rows) (device memory, from
+ * lnz_plan_batch); every other entry of G is left untouched — zero-initialise G.  rows NULL =
+ * lnz_spectral_gains. */
+int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_host, int S,
+                            int num_layer, int kind, const float* mlp_pack, const int32_t* rows,
+                            const int32_t* n_rows, float* G, lnz_stream_t stream);
 
 /* ---- R7 (second half) + R9 + R10: fused LanczosNet forward ------------------------------
  * One workgroup per molecule runs the whole network on chip: embedding gather, then per conv
@@ -226,6 +232,12 @@ int lnz_lanczosnet_messages(const lnz_forward_args* args, lnz_stream_t stream);
 int lnz_plan_wg_cap(int B, int n_cu);
 int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs, int32_t* plan,
                    int32_t* n_wg, lnz_stream_t stream);
+/* lnz_plan_tiles plus the list of eigen slots that carry a Ritz pair: gain_rows [<= B*K] int32 =
+ * b*K + k for k < min(n_b, K) (any order), n_gain_rows [1] — input of lnz_spectral_gains_rows,
+ * which then skips the MLP for the zero-padded eigen columns (~18 % of the rows for QM8 sizes). */
+int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs, int32_t* plan,
+                   int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
+                   lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);

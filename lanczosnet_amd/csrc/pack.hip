@@ -257,12 +257,16 @@ extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stri
 __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restrict__ mask, int B,
                                                           int N, int n_cu, int allow_pairs,
                                                           int wg_cap, int32_t* __restrict__ plan,
-                                                          int32_t* __restrict__ n_wg) {
+                                                          int32_t* __restrict__ n_wg, int K,
+                                                          int32_t* __restrict__ gain_rows,
+                                                          int32_t* __restrict__ n_gain_rows) {
   __shared__ int cnt[LNZ_TILE + 2];
   __shared__ int cls[4];  // molecules with extent <= 8, <= 16, <= 24, <= 32 (cumulative)
   __shared__ int wcnt[16][LNZ_TILE + 2];
+  __shared__ int n_slots;  // eigen slots that carry a Ritz pair (gain_rows)
   const int tid = threadIdx.x;
   if (tid < LNZ_TILE + 2) cnt[tid] = 0;
+  if (tid == 0) n_slots = 0;
   for (int i = tid; i < wg_cap * 12; i += 1024) plan[i] = -1;
   __syncthreads();
   auto extent = [&](int b) {  // last real node + 1 (what the forward kernels size their work by)
@@ -318,6 +322,11 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
     }
     __syncthreads();
     if (b >= B) continue;
+    if (gain_rows) {  // the k < min(n, K) eigen slots of this molecule, as rows b*K + k of D
+      const int c = n < K ? n : K;
+      const int base = atomicAdd(&n_slots, c);
+      for (int k = 0; k < c; ++k) gain_rows[base + k] = b * K + k;
+    }
     int tau, role, split = 32;            // role 0 = single, 1 = A of a pair, 2 = B of a pair
     if (r < X) {
       tau = oX + r, role = 1, split = 8;
@@ -343,6 +352,8 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
       e[2] = split;
     }
   }
+  __syncthreads();
+  if (gain_rows && tid == 0) *n_gain_rows = n_slots;
 }
 
 extern "C" int lnz_plan_wg_cap(int B, int n_cu) {
@@ -350,11 +361,20 @@ extern "C" int lnz_plan_wg_cap(int B, int n_cu) {
   return B <= 4 * n_cu ? (B < n_cu ? B : n_cu) : (B + 3) / 4;
 }
 
+extern "C" int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
+                              int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
+                              int32_t* n_gain_rows, lnz_stream_t stream) {
+  LNZ_REQUIRE(mask && plan && n_wg && B > 0 && N > 0 && N <= LNZ_TILE && n_cu > 0, LNZ_EINVAL,
+              "lnz_plan_batch: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
+  LNZ_REQUIRE(!gain_rows || (n_gain_rows && K > 0), LNZ_EINVAL,
+              "lnz_plan_batch: gain_rows needs n_gain_rows and K > 0");
+  hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
+                     n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows,
+                     n_gain_rows);
+  return lnz::check_launch("lnz_plan_batch");
+}
+
 extern "C" int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
                               int32_t* plan, int32_t* n_wg, lnz_stream_t stream) {
-  LNZ_REQUIRE(mask && plan && n_wg && B > 0 && N > 0 && N <= LNZ_TILE && n_cu > 0, LNZ_EINVAL,
-              "lnz_plan_tiles: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
-  hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
-                     n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg);
-  return lnz::check_launch("lnz_plan_tiles");
+  return lnz_plan_batch(mask, B, N, n_cu, allow_pairs, plan, n_wg, 0, nullptr, nullptr, stream);
 }

@@ -100,14 +100,21 @@ __device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (
   return acc;
 }
 
+// rows / n_rows (optional): compact list of the (b*K + k) eigen slots that carry a Ritz pair
+// (k < min(n_b, K), lnz_plan_batch) — the slots of zero-padded eigen columns are skipped: their
+// gains never reach an output (the V column is zero, model/lanczos_net.py:114-117).
 __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
     const float* __restrict__ D, int R, int B, int K, DistArr dist, int S,
-    const float* __restrict__ mlp_pack, float* __restrict__ G) {
+    const float* __restrict__ mlp_pack, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ n_rows, float* __restrict__ G) {
   const int lane = threadIdx.x;
   const int j = lane & 31, hh = lane >> 5;
   const int l = blockIdx.y;
-  const int row = blockIdx.x * 32 + j;
-  const bool valid = row < R;
+  if (rows) R = *n_rows;
+  if ((int)blockIdx.x * 32 >= R) return;
+  const int idx = blockIdx.x * 32 + j;
+  const bool valid = idx < R;
+  const int row = valid ? (rows ? rows[idx] : idx) : 0;
   const float dval = valid ? D[row] : 0.0f;
   const float* pk = mlp_pack + (int64_t)l * PACK_SIZE;
 
@@ -218,9 +225,11 @@ extern "C" int lnz_pack_spectral_mlp(const float* W0, const float* b0, const flo
   return LNZ_OK;
 }
 
-extern "C" int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,
-                                  int num_layer, int kind, const float* mlp_pack, float* G,
-                                  lnz_stream_t stream) {
+extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_host,
+                                       int S, int num_layer, int kind, const float* mlp_pack,
+                                       const int32_t* rows, const int32_t* n_rows, float* G,
+                                       lnz_stream_t stream) {
+  LNZ_REQUIRE(!rows || n_rows, LNZ_EINVAL, "lnz_spectral_gains_rows: rows without n_rows");
   LNZ_REQUIRE(D && dist_host && G && B > 0 && K > 0 && num_layer > 0, LNZ_EINVAL,
               "lnz_spectral_gains: bad arguments (B=%d K=%d L=%d)", B, K, num_layer);
   LNZ_REQUIRE(S >= 1 && S <= SMAX, LNZ_ENOTSUP, "lnz_spectral_gains: S=%d not in 1..%d", S, SMAX);
@@ -232,11 +241,18 @@ extern "C" int lnz_spectral_gains(const float* D, int B, int K, const int32_t* d
     int R = B * K;
     dim3 grid((R + 31) / 32, num_layer);
     hipLaunchKernelGGL(spectral_gains_mlp_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
-                       mlp_pack, G);
+                       mlp_pack, rows, n_rows, G);
   } else {
     int64_t total = (int64_t)num_layer * B * S * K;
     hipLaunchKernelGGL(spectral_gains_pow_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
                        s, D, B, K, dist, S, num_layer, G);
   }
   return lnz::check_launch("lnz_spectral_gains");
+}
+
+extern "C" int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,
+                                  int num_layer, int kind, const float* mlp_pack, float* G,
+                                  lnz_stream_t stream) {
+  return lnz_spectral_gains_rows(D, B, K, dist_host, S, num_layer, kind, mlp_pack, nullptr,
+                                 nullptr, G, stream);
 }

@@ -261,11 +261,14 @@ class _LanczosNetBase(nn.Module):
     @torch.no_grad()
     def _hip_forward(self, node_feat, L, D, V, mask):
         plan = self._plan()
+        mask_u8 = mask.to(torch.uint8).contiguous()
         Lp = ops.pack_laplacian_for(plan, L)
+        tiles, rows = ops.plan_batch(mask_u8, ops.pairing_supported(plan), V.shape[2])
         G = None
         if self.num_scale_long > 0:
-            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
-        return ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask)
+            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'],
+                                   rows=rows)
+        return ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
 
     @torch.no_grad()
     def _large_graph_forward(self, node_feat, L, D, V, mask, gemm_dtype=None):
@@ -455,10 +458,11 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         Vc = V.float().contiguous()
         B = Vc.shape[0]
         Lp = ops.pack_laplacian_for(plan, L)
+        tiles, rows = ops.plan_batch(mask_u8, True, Vc.shape[2])
         G = None
         if module.num_scale_long > 0:
-            G = ops.spectral_gains(D, module.long_diffusion_dist, module.num_layer, plan['mlp_pack'])
-        tiles = ops.plan_tiles(mask_u8, allow_pairs=True)
+            G = ops.spectral_gains(D, module.long_diffusion_dist, module.num_layer, plan['mlp_pack'],
+                                   rows=rows)
         act = torch.zeros((module.num_layer, B, 32, plan['dhid']), dtype=torch.float32,
                           device=Vc.device)
         score = ops.lanczosnet_forward(plan, node_feat, Lp, Vc, G, mask_u8, tiling=tiles,

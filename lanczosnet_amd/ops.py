@@ -198,21 +198,26 @@ def pack_spectral_mlp(linears, S, out=None):
 
 
 # ------------------------------------------------------------------------------------------ R7
-def spectral_gains(D, dist, num_layer, mlp_pack=None):
-  """D [B,K] -> G [num_layer,B,S,K].  mlp_pack=None selects the plain-power branch."""
+def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None):
+  """D [B,K] -> G [num_layer,B,S,K].  mlp_pack=None selects the plain-power branch.
+  rows: optional (gain_rows, n_gain_rows) int32 device tensors from plan_batch(): the MLP runs
+  only on the eigen slots that carry a Ritz pair, every other entry of G is zero."""
   _need_cuda(D, mlp_pack)
   D = _f32c(D)
   B, K = D.shape
   S = len(dist)
+  use_rows = rows is not None and mlp_pack is not None
   # + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
-  Gbuf = torch.empty((num_layer * B * S * K + 16,), dtype=torch.float32, device=D.device)
+  alloc = torch.zeros if use_rows else torch.empty
+  Gbuf = alloc((num_layer * B * S * K + 16,), dtype=torch.float32, device=D.device)
   G = Gbuf[:num_layer * B * S * K].view(num_layer, B, S, K)
   darr = (C.c_int32 * S)(*[int(x) for x in dist])
   lib = _lib.load()
   with torch.cuda.device(D.device):
-    _lib.check(lib.lnz_spectral_gains(_ptr(D), B, K, darr, S, num_layer,
-                                      0 if mlp_pack is not None else 1, _ptr(mlp_pack), _ptr(G),
-                                      _stream()))
+    _lib.check(lib.lnz_spectral_gains_rows(
+        _ptr(D), B, K, darr, S, num_layer, 0 if mlp_pack is not None else 1, _ptr(mlp_pack),
+        _ptr(rows[0]) if use_rows else C.c_void_p(0), _ptr(rows[1]) if use_rows else C.c_void_p(0),
+        _ptr(G), _stream()))
   return G
 
 
@@ -246,6 +251,21 @@ def _n_cu(device):
   if idx not in _N_CU:
     _N_CU[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
   return _N_CU[idx]
+
+
+def plan_batch(mask_u8, allow_pairs, K, n_cu=None):
+  """lnz_plan_batch: the tile plan of plan_tiles() plus the list of eigen slots that carry a Ritz
+  pair.  Returns ((buf, cap), (gain_rows, n_gain_rows)); pass the first to lanczosnet_forward
+  (tiling=) and the second to spectral_gains (rows=)."""
+  lib = _lib.load()
+  B, N = mask_u8.shape
+  n_cu = n_cu or _n_cu(mask_u8.device)
+  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=mask_u8.device)
+  n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
+  _lib.check(lib.lnz_plan_batch(_ptr(mask_u8), B, N, n_cu, int(bool(allow_pairs)), _ptr(buf),
+                                _ptr(n_wg), K, _ptr(rows), _ptr(n_rows), _stream()))
+  return (buf, cap), (rows, n_rows)
 
 
 def plan_tiles(mask_u8, allow_pairs, n_cu=None):

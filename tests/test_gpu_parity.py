@@ -721,3 +721,37 @@ def test_tile_plan_fuzz_against_unplanned_schedule_and_oracle(seed):
                                    D[:nb].cpu().numpy(), V[:nb].cpu().numpy(),
                                    batch['node_mask'][:nb], dtype=np.float64)
   assert rel_err(s_auto[:nb].cpu().numpy(), ref) < 1e-5, cfg
+
+
+@pytest.mark.gpu
+def test_gain_row_compaction_computes_exactly_the_live_eigen_slots():
+  """lnz_plan_batch + lnz_spectral_gains_rows: the MLP runs only on slots k < min(n, K); there the
+  gains are bit-identical to the full computation, elsewhere G is zero, and the scores agree."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  batch = draw_batch(300, seed=9, n_min=2, n_max=26)
+  n = _t(batch['n_nodes'])
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 5))
+  plan = net._plan()
+  mask = _t(batch['node_mask'])
+  tiles, rows = ops.plan_batch(mask.contiguous(), True, 20)
+  n_rows = int(rows[1].item())
+  live = torch.clamp(n, max=20).long()
+  assert n_rows == int(live.sum())
+  got = sorted(rows[0][:n_rows].cpu().tolist())
+  want = sorted(int(b) * 20 + k for b in range(300) for k in range(int(live[b])))
+  assert got == want
+  G_full = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  G_rows = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
+                              rows=rows)
+  slot = (torch.arange(20, device=DEV)[None, :] < live[:, None])            # [B,K]
+  sel = slot[None, :, None, :].expand_as(G_full)
+  assert torch.equal(G_rows[sel], G_full[sel])
+  assert (G_rows[~sel] == 0).all()
+  Lp = ops.pack_laplacian_for(plan, L)
+  nf = _t(batch['node_feat'])
+  s1 = ops.lanczosnet_forward(plan, nf, Lp, V, G_full, mask, tiling=tiles)
+  s2 = ops.lanczosnet_forward(plan, nf, Lp, V, G_rows, mask, tiling=tiles)
+  assert torch.equal(s1, s2)
