@@ -238,6 +238,14 @@ int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
 int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs, int32_t* plan,
                    int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
                    lnz_stream_t stream);
+/* lnz_pack_laplacian + lnz_plan_batch in ONE launch (workgroup B plans while 0..B-1 pack): the two
+ * byte movers in front of the Lanczos kernel are independent, and the planner is a single
+ * latency-bound workgroup.  Arguments as in the two functions; gain_rows may be NULL. */
+int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                            int64_t stride_ch, int B, int N, int C, float* Lp,
+                            const uint8_t* mask, int n_cu, int allow_pairs, int32_t* plan,
+                            int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
+                            lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);

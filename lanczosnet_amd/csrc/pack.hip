@@ -131,11 +131,9 @@ extern "C" int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_st
 // one molecule's whole [N, N, C] block with fully coalesced reads into LDS, then writes
 // the C packed tiles with coalesced float4 stores — each HBM byte is touched once.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_laplacian_kernel(
+__device__ __forceinline__ void pack_laplacian_body(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
-    float4* __restrict__ Lp) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // [N*N*C], source order if dense
-  const int b = blockIdx.x;
+    float4* __restrict__ Lp, float* tile, const int b) {  // tile: LDS [N*N*C], source order if dense
   const float* Lb = L + (int64_t)b * sb;
   const bool dense_cl = (sch == 1 && sc == C && sr == (int64_t)N * C);
   const int total = N * N * C;
@@ -165,6 +163,13 @@ __global__ __launch_bounds__(256) void pack_laplacian_kernel(
     }
     Lp[((int64_t)b * C + c) * 256 + (o & 255)] = make_float4(v[0], v[1], v[2], v[3]);
   }
+}
+
+__global__ __launch_bounds__(256) void pack_laplacian_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    float4* __restrict__ Lp) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blockIdx.x);
 }
 
 // Lp16[b][c][blk][piece][lane] (uint4 = 8 halves): element e = L[b][lane&31][cd_row(8 blk + e, lane>>5)][c]
@@ -254,12 +259,12 @@ extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stri
 //
 // Stable counting sort on node extent in one workgroup; every molecule derives its slot from its
 // rank, so the plan is deterministic.
-__global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restrict__ mask, int B,
-                                                          int N, int n_cu, int allow_pairs,
-                                                          int wg_cap, int32_t* __restrict__ plan,
-                                                          int32_t* __restrict__ n_wg, int K,
-                                                          int32_t* __restrict__ gain_rows,
-                                                          int32_t* __restrict__ n_gain_rows) {
+__device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask, int B, int N,
+                                                int n_cu, int allow_pairs, int wg_cap,
+                                                int32_t* __restrict__ plan,
+                                                int32_t* __restrict__ n_wg, int K,
+                                                int32_t* __restrict__ gain_rows,
+                                                int32_t* __restrict__ n_gain_rows) {
   __shared__ int cnt[LNZ_TILE + 2];
   __shared__ int cls[4];  // molecules with extent <= 8, <= 16, <= 24, <= 32 (cumulative)
   __shared__ int wcnt[16][LNZ_TILE + 2];
@@ -274,7 +279,10 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
     for (int i = 0; i < N; ++i) n = mask[(int64_t)b * N + i] ? i + 1 : n;
     return n;
   };
-  for (int b = tid; b < B; b += 1024) atomicAdd(&cnt[extent(b)], 1);
+  // B <= 1024 (one chunk): every thread owns one molecule and keeps its extent in a register
+  const int n_own = tid < B ? extent(tid) : -1;
+  if (n_own >= 0) atomicAdd(&cnt[n_own], 1);
+  for (int b = tid + 1024; b < B; b += 1024) atomicAdd(&cnt[extent(b)], 1);
   __syncthreads();
   if (tid == 0) {
     int run = 0;
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
   const int wv = tid >> 6, ln = tid & 63;
   for (int c0 = 0; c0 < B; c0 += 1024) {
     const int b = c0 + tid;
-    const int n = b < B ? extent(b) : -1;
+    const int n = c0 == 0 ? n_own : (b < B ? extent(b) : -1);
     int lr = 0;
     for (int v = 0; v <= N; ++v) {
       const unsigned long long mk = __ballot(n == v);
@@ -354,6 +362,52 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
   }
   __syncthreads();
   if (gain_rows && tid == 0) *n_gain_rows = n_slots;
+}
+
+__global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restrict__ mask, int B,
+                                                          int N, int n_cu, int allow_pairs,
+                                                          int wg_cap, int32_t* __restrict__ plan,
+                                                          int32_t* __restrict__ n_wg, int K,
+                                                          int32_t* __restrict__ gain_rows,
+                                                          int32_t* __restrict__ n_gain_rows) {
+  plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+}
+
+// Both byte movers that precede the Lanczos kernel in ONE launch: workgroup 0 plans the batch,
+// workgroups 1..B pack a molecule's Laplacian tile each — the single-workgroup planner (~15 us of
+// latency-bound work) runs under the packing instead of behind it.
+__global__ __launch_bounds__(1024) void pack_plan_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
+    int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
+    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  if (blockIdx.x == 0) {  // dispatched first: the planner's latency chain starts immediately
+    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+  } else {
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, (int)blockIdx.x - 1);
+  }
+}
+
+extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t stride_r,
+                                       int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                       float* Lp, const uint8_t* mask, int n_cu, int allow_pairs,
+                                       int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
+                                       int32_t* n_gain_rows, lnz_stream_t stream) {
+  LNZ_REQUIRE(L && Lp && mask && plan && n_wg && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS &&
+                  n_cu > 0,
+              LNZ_EINVAL, "lnz_pack_laplacian_plan: bad arguments (B=%d C=%d n_cu=%d)", B, C, n_cu);
+  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_pack_laplacian_plan: N=%d > %d", N,
+              LNZ_TILE);
+  LNZ_REQUIRE(!gain_rows || (n_gain_rows && K > 0), LNZ_EINVAL,
+              "lnz_pack_laplacian_plan: gain_rows needs n_gain_rows and K > 0");
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(lds <= 48 * 1024, LNZ_ENOTSUP,
+              "lnz_pack_laplacian_plan: N*N*C*4 = %zu B exceeds the 48 KiB staging tile", lds);
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(B + 1), dim3(1024), lds, (hipStream_t)stream, L,
+                     stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
+                     allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows);
+  return lnz::check_launch("lnz_pack_laplacian_plan");
 }
 
 extern "C" int lnz_plan_wg_cap(int B, int n_cu) {

@@ -262,8 +262,7 @@ class _LanczosNetBase(nn.Module):
     def _hip_forward(self, node_feat, L, D, V, mask):
         plan = self._plan()
         mask_u8 = mask.to(torch.uint8).contiguous()
-        Lp = ops.pack_laplacian_for(plan, L)
-        tiles, rows = ops.plan_batch(mask_u8, ops.pairing_supported(plan), V.shape[2])
+        Lp, tiles, rows = ops.pack_and_plan(plan, L, mask_u8, V.shape[2])
         G = None
         if self.num_scale_long > 0:
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'],
@@ -457,8 +456,7 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         mask_u8 = mask.to(torch.uint8).contiguous()
         Vc = V.float().contiguous()
         B = Vc.shape[0]
-        Lp = ops.pack_laplacian_for(plan, L)
-        tiles, rows = ops.plan_batch(mask_u8, True, Vc.shape[2])
+        Lp, tiles, rows = ops.pack_and_plan(plan, L, mask_u8, Vc.shape[2])
         G = None
         if module.num_scale_long > 0:
             G = ops.spectral_gains(D, module.long_diffusion_dist, module.num_layer, plan['mlp_pack'],

@@ -182,6 +182,32 @@ def pack_laplacian_for(plan, L):
   return pack_laplacian_f16x2(Lf) if plan.get('Wp16') is not None else pack_laplacian(Lf)
 
 
+def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
+  """Everything the fused forward needs besides (V, G), in the fewest launches: the Laplacian pack
+  for `plan`, the tile plan and the live-eigen-slot list.  Exact-fp32 plans use the single
+  lnz_pack_laplacian_plan launch (the planner runs under the packing); the split-precision pack
+  falls back to two launches.  Returns (Lp, tiles, rows) for lanczosnet_forward / spectral_gains."""
+  Lf = L if L.dtype == torch.float32 else L.float()
+  if plan.get('Wp16') is not None or Lf.shape[1] * Lf.shape[1] * Lf.shape[3] * 4 > 48 * 1024:
+    tiles, rows = plan_batch(mask_u8, pairing_supported(plan), K, n_cu)
+    return pack_laplacian_for(plan, Lf), tiles, rows
+  _need_cuda(Lf, mask_u8)
+  lib = _lib.load()
+  B, N, _, Cn = Lf.shape
+  n_cu = n_cu or _n_cu(Lf.device)
+  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=Lf.device)
+  buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=Lf.device)
+  n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
+  sb, sr, sc, sch = Lf.stride()
+  with torch.cuda.device(Lf.device):
+    _lib.check(lib.lnz_pack_laplacian_plan(
+        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), n_cu,
+        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
+        _stream()))
+  return Lp, (buf, cap), (rows, n_rows)
+
+
 def pack_spectral_mlp(linears, S, out=None):
   """linears: 4 (weight, bias) pairs of one `spectral_filter[l]` Sequential -> packed buffer."""
   lib = _lib.load()
