@@ -538,6 +538,7 @@ __global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
           double z0 = sm.Qt[(m - 1) * LD + r];
           double ei = readlane_f64(ereg, m - 1);
           double di = readlane_f64(dreg, m - 1);
+#pragma unroll 2
           for (int i = m - 1; i >= l; --i) {
             // prefetch the next rotation's inputs: none of them is written by this rotation
             const int ip = i > l ? i - 1 : l;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
             const double d_next = hp + s * (c * g + s * di);
             ereg = (r == i + 1) ? e_next : ereg;
             dreg = (r == i + 1) ? d_next : dreg;
-            if (h == 0) sm.Qt[(i + 1) * LD + r] = s * z0 + c * carry;
+            sm.Qt[(i + 1) * LD + r] = s * z0 + c * carry;  // both halves hold the same value
             carry = c * z0 - s * carry;
             z0 = znext;
             ei = ei_n;
