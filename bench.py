@@ -136,7 +136,7 @@ def main():
       events[2].record()
       events[3].record()
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
-                           rows=rows)
+                           rows=rows, zero_fill=not ops.pairing_supported(plan))
     if events:
       events[4].record()
     score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)

@@ -238,7 +238,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       const TileDesc t = pick(td, m);
       bool isA;
       const int k = eigen_slot(t.split, KH, K, h, tt, &isA);
-      const bool ok = k >= 0;
+      // slots k >= n belong to zero-padded eigen columns: their gains are never computed by
+      // lnz_spectral_gains_rows and never read here (G may be uninitialised there)
+      const bool ok = k >= 0 && k < (isA ? pick(nA, m) : pick(nB, m));
       const int mol = isA ? t.ta : t.tb;
       dst[idx] = ok ? a.G[(((int64_t)l * B + mol) * a.n_long + sc) * K + k] : 0.0f;
     }

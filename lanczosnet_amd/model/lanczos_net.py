@@ -266,7 +266,7 @@ class _LanczosNetBase(nn.Module):
         G = None
         if self.num_scale_long > 0:
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'],
-                                   rows=rows)
+                                   rows=rows, zero_fill=not ops.pairing_supported(plan))
         return ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
 
     @torch.no_grad()

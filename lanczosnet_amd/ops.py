@@ -224,17 +224,19 @@ def pack_spectral_mlp(linears, S, out=None):
 
 
 # ------------------------------------------------------------------------------------------ R7
-def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None):
+def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True):
   """D [B,K] -> G [num_layer,B,S,K].  mlp_pack=None selects the plain-power branch.
   rows: optional (gain_rows, n_gain_rows) int32 device tensors from plan_batch(): the MLP runs
-  only on the eigen slots that carry a Ritz pair, every other entry of G is zero."""
+  only on the eigen slots that carry a Ritz pair, every other entry of G is zero — or left
+  uninitialised with zero_fill=False, which is what the exact-fp32 forward kernel needs (it never
+  reads the slots k >= n))."""
   _need_cuda(D, mlp_pack)
   D = _f32c(D)
   B, K = D.shape
   S = len(dist)
   use_rows = rows is not None and mlp_pack is not None
   # + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
-  alloc = torch.zeros if use_rows else torch.empty
+  alloc = torch.zeros if (use_rows and zero_fill) else torch.empty
   Gbuf = alloc((num_layer * B * S * K + 16,), dtype=torch.float32, device=D.device)
   G = Gbuf[:num_layer * B * S * K].view(num_layer, B, S, K)
   darr = (C.c_int32 * S)(*[int(x) for x in dist])

@@ -755,3 +755,10 @@ def test_gain_row_compaction_computes_exactly_the_live_eigen_slots():
   s1 = ops.lanczosnet_forward(plan, nf, Lp, V, G_full, mask, tiling=tiles)
   s2 = ops.lanczosnet_forward(plan, nf, Lp, V, G_rows, mask, tiling=tiles)
   assert torch.equal(s1, s2)
+  # the exact-fp32 kernel never reads the dead slots: poison them
+  G_nan = G_rows.clone()
+  G_nan[~sel] = float('nan')
+  s3 = ops.lanczosnet_forward(plan, nf, Lp, V, G_nan, mask, tiling=tiles)
+  assert torch.equal(s1, s3)
+  s4 = ops.lanczosnet_forward(plan, nf, Lp, V, G_nan, mask, tiling='none')
+  assert torch.isfinite(s4).all()
