@@ -128,11 +128,9 @@ def main():
   def step(events=None):
     if events:
       events[0].record()
-    Lp, tiles, rows = ops.pack_and_plan(plan, L, mask_u8, K)
+    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
     if events:
       events[1].record()
-    D, V = ops.lanczos_ritz(A, n_nodes, K)
-    if events:
       events[2].record()
       events[3].record()
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
@@ -203,7 +201,7 @@ def main():
     net.gemm_mode = 'fp32'
     plan = plan_fp32
 
-  names = ['pack_laplacian+plan', 'lanczos_ritz', '-', 'spectral_gains', 'lanczosnet_forward']
+  names = ['prepare_batch(pack+plan+lanczos_ritz)', '-', '-', 'spectral_gains', 'lanczosnet_forward']
   stage_ms = {nm: float(np.mean([ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)]))
               for k, nm in enumerate(names) if nm != '-'}
 
@@ -228,8 +226,8 @@ def main():
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
-                               'fp32, 7x128 layers, 1xMI355X per rank; step = pack L + batch plan '
-                               '(one launch) + Lanczos/QL Ritz pairs + spectral gains + fused forward' % (B, L.shape[1]),
+                               'fp32, 7x128 layers, 1xMI355X per rank; step = [pack L + batch plan + '
+                               'Lanczos/QL Ritz pairs] (one launch) + spectral gains + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, score all-gather)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
         'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',

@@ -238,6 +238,16 @@ int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
 int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs, int32_t* plan,
                    int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
                    lnz_stream_t stream);
+/* The whole batch preparation in ONE launch: lnz_plan_batch (workgroup 0), lnz_lanczos_ritz on
+ * channel 0 of L (workgroups 1..B, dispatched first: they are the long, latency-bound pole) and
+ * lnz_pack_laplacian (workgroups B+1..2B) — the two byte movers run in the shadow of the Lanczos
+ * wavefronts instead of in front of them.  L [B,N,N,C] with strides (elements); n_nodes [B] as
+ * for lnz_lanczos_ritz; outputs as in the three functions.  N <= 32. */
+int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                      int64_t stride_ch, int B, int N, int C, float* Lp, const uint8_t* mask,
+                      const int32_t* n_nodes, int n_cu, int allow_pairs, int32_t* plan,
+                      int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
+                      float* V, int32_t* info, lnz_stream_t stream);
 /* lnz_pack_laplacian + lnz_plan_batch in ONE launch (workgroup B plans while 0..B-1 pack): the two
  * byte movers in front of the Lanczos kernel are independent, and the planner is a single
  * latency-bound workgroup.  Arguments as in the two functions; gain_rows may be NULL. */

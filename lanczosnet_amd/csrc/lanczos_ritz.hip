@@ -20,6 +20,7 @@
 // residual on breakdown; implicit-shift QL (EISPACK tql2 recurrences) with the rotations
 // applied directly to Qt, so Qt ends up holding the Ritz vectors V = Q B.
 #include "common.hpp"
+#include "prep.hpp"
 
 namespace {
 
@@ -417,14 +418,13 @@ __device__ inline double cgs2_32(Ritz32Smem& sm, double& x, int j, int r, int h)
   return coef;
 }
 
-__global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
+// body of one molecule's wavefront (lane = 0..63); the caller owns the LDS block
+__device__ __forceinline__ void lanczos_ritz32_body(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
-    float* __restrict__ V, int32_t* __restrict__ info) {
+    float* __restrict__ V, int32_t* __restrict__ info, const int b, const int lane,
+    Ritz32Smem& sm) {
   constexpr int LD = Ritz32Smem::LD;
-  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
   int n = n_nodes[b];
   n = n < 0 ? 0 : (n > N ? N : n);
@@ -643,7 +643,63 @@ __global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
 #endif
 }
 
+__global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
+    const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
+    const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
+    float* __restrict__ V, int32_t* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
+  lanczos_ritz32_body(A, sb, sr, sc, n_nodes, N, K, D, V, info, blockIdx.x, threadIdx.x, sm);
+}
+
+// Everything the fused forward needs from a collated batch besides the gains, in ONE launch of
+// 512-thread workgroups: workgroup 0 plans the batch (tile plan + live eigen slots), workgroups
+// 1..B are the Lanczos/QL wavefronts (one live wave each — the other seven exit at once, and a
+// terminated wave does not take part in barriers), workgroups B+1..2B pack the Laplacian tiles.
+// The Ritz wavefronts are the long pole (latency bound, one wave per SIMD); dispatched first, they
+// leave most of the machine idle, and the two byte movers run in that shadow instead of in front.
+__global__ __launch_bounds__(512) void prepare_batch_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
+    int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
+    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
+    const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
+    int32_t* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
+  const int blk = blockIdx.x;
+  if (blk == 0) {
+    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+  } else if (blk <= B) {
+    if (threadIdx.x >= 64) return;
+    // channel 0 of L is the simple-graph Laplacian the Ritz pairs belong to (dataset/qm8.py:262)
+    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x, sm);
+  } else {
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B);
+  }
+}
+
 }  // namespace
+
+extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r,
+                                 int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                 float* Lp, const uint8_t* mask, const int32_t* n_nodes, int n_cu,
+                                 int allow_pairs, int32_t* plan, int32_t* n_wg, int K,
+                                 int32_t* gain_rows, int32_t* n_gain_rows, float* D, float* V,
+                                 int32_t* info, lnz_stream_t stream) {
+  LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && D && V && B > 0 && C > 0 &&
+                  C <= LNZ_MAX_CHANNELS && n_cu > 0 && K > 0,
+              LNZ_EINVAL, "lnz_prepare_batch: bad arguments (B=%d C=%d K=%d)", B, C, K);
+  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch: N=%d > %d", N, LNZ_TILE);
+  LNZ_REQUIRE(!gain_rows || n_gain_rows, LNZ_EINVAL, "lnz_prepare_batch: gain_rows needs n_gain_rows");
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
+              "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
+  hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(512), lds, (hipStream_t)stream,
+                     L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
+                     allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
+                     n_nodes, D, V, info);
+  return lnz::check_launch("lnz_prepare_batch");
+}
 
 extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r,
                                 int64_t stride_c, const int32_t* n_nodes, int B, int N, int K,

@@ -1,5 +1,6 @@
 // Operand packing into v_mfma_f32_32x32x2_f32 fragment order, error state, ABI version.
 #include "common.hpp"
+#include "prep.hpp"
 
 namespace lnz {
 static thread_local char g_err[512] = "";
@@ -125,46 +126,6 @@ extern "C" int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_st
   return lnz::check_launch("lnz_pack_bias_rows");
 }
 
-// ---------------------------------------------------------------------------------------
-// Lp[b][c][g][lane][u] = L[b][lane & 31][8 g + 4 (lane >> 5) + u][c]   (zero beyond N)
-// The source is channels-last (stride_ch = 1 for the collate layout): a workgroup stages
-// one molecule's whole [N, N, C] block with fully coalesced reads into LDS, then writes
-// the C packed tiles with coalesced float4 stores — each HBM byte is touched once.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void pack_laplacian_body(
-    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
-    float4* __restrict__ Lp, float* tile, const int b) {  // tile: LDS [N*N*C], source order if dense
-  const float* Lb = L + (int64_t)b * sb;
-  const bool dense_cl = (sch == 1 && sc == C && sr == (int64_t)N * C);
-  const int total = N * N * C;
-  if (dense_cl) {
-    for (int i = threadIdx.x; i < total; i += blockDim.x) tile[i] = Lb[i];
-  } else {
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      int c = i % C;
-      int m = (i / C) % N;
-      int r = i / (C * N);
-      tile[i] = Lb[r * sr + m * sc + c * sch];
-    }
-  }
-  __syncthreads();
-  // C * 4 * 64 float4 outputs
-  for (int o = threadIdx.x; o < C * 256; o += blockDim.x) {
-    int lane = o & 63;
-    int g = (o >> 6) & 3;
-    int c = o >> 8;
-    int row = lane & 31;
-    int col0 = 8 * g + 4 * (lane >> 5);
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int col = col0 + u;
-      v[u] = (row < N && col < N) ? tile[(row * N + col) * C + c] : 0.0f;
-    }
-    Lp[((int64_t)b * C + c) * 256 + (o & 255)] = make_float4(v[0], v[1], v[2], v[3]);
-  }
-}
-
 __global__ __launch_bounds__(256) void pack_laplacian_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
     float4* __restrict__ Lp) {
@@ -243,125 +204,6 @@ extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stri
   hipLaunchKernelGGL(pack_laplacian_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, L,
                      stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp);
   return lnz::check_launch("lnz_pack_laplacian");
-}
-
-// ---- tile plan: pairing of small molecules + per-workgroup dealing ------------------------------
-// The forward kernels work on 32-row node tiles.  Small molecules share a tile (block-diagonal
-// operators): an (<= 8)-node molecule rides with a 17..24-node one (split row 8), two (<= 16)-node
-// molecules split at row 16.  For a QM8-like size range that turns B molecules into ~0.74 B tiles.
-//
-// A forward launch is ONE round of workgroups when B <= 4 tiles x CUs, so it lasts as long as the
-// busiest CU: the plan therefore fixes the number of workgroups W (one per CU while the tiles fit
-// in a single round of <= 4 per workgroup) and deals the tiles, in descending cost order, over the
-// workgroups boustrophedon-wise — every workgroup gets floor or ceil of T / W tiles of balanced
-// total cost.  Slot s of workgroup g is plan[(4g + s) * 3 + {0,1,2}] = (molecule A, molecule B or
-// -1, split row: rows < split belong to A; 32 for a single); an unused slot has A = -1.
-//
-// Stable counting sort on node extent in one workgroup; every molecule derives its slot from its
-// rank, so the plan is deterministic.
-__device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask, int B, int N,
-                                                int n_cu, int allow_pairs, int wg_cap,
-                                                int32_t* __restrict__ plan,
-                                                int32_t* __restrict__ n_wg, int K,
-                                                int32_t* __restrict__ gain_rows,
-                                                int32_t* __restrict__ n_gain_rows) {
-  __shared__ int cnt[LNZ_TILE + 2];
-  __shared__ int cls[4];  // molecules with extent <= 8, <= 16, <= 24, <= 32 (cumulative)
-  __shared__ int wcnt[16][LNZ_TILE + 2];
-  __shared__ int n_slots;  // eigen slots that carry a Ritz pair (gain_rows)
-  const int tid = threadIdx.x;
-  if (tid < LNZ_TILE + 2) cnt[tid] = 0;
-  if (tid == 0) n_slots = 0;
-  for (int i = tid; i < wg_cap * 12; i += 1024) plan[i] = -1;
-  __syncthreads();
-  auto extent = [&](int b) {  // last real node + 1 (what the forward kernels size their work by)
-    int n = 0;
-    for (int i = 0; i < N; ++i) n = mask[(int64_t)b * N + i] ? i + 1 : n;
-    return n;
-  };
-  // B <= 1024 (one chunk): every thread owns one molecule and keeps its extent in a register
-  const int n_own = tid < B ? extent(tid) : -1;
-  if (n_own >= 0) atomicAdd(&cnt[n_own], 1);
-  for (int b = tid + 1024; b < B; b += 1024) atomicAdd(&cnt[extent(b)], 1);
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int n = 0; n <= LNZ_TILE; ++n) {
-      int c = n <= N ? cnt[n] : 0;
-      cnt[n] = run;
-      run += c;
-      if ((n & 7) == 0 && n > 0) cls[n / 8 - 1] = run;
-    }
-  }
-  __syncthreads();
-  const int c8 = cls[0], c16 = cls[1] - cls[0], c24 = cls[2] - cls[1], c32 = cls[3] - cls[2];
-  const int X = allow_pairs ? (c8 < c24 ? c8 : c24) : 0;       // 8|24 pairs
-  const int pool = c8 - X + c16;                               // remaining (<= 16)-node molecules
-  const int P2 = allow_pairs ? pool / 2 : 0;                   // 16|16 pairs
-  const int lone = pool - 2 * P2;                              // small singles (0/1, or all)
-  const int T = B - X - P2;
-  const int W = T <= 4 * n_cu ? (T < n_cu ? T : n_cu) : (T + 3) / 4;
-  if (tid == 0) *n_wg = W;
-  // ascending cost order: small singles, 17..24 singles, >= 25 singles, 16|16 pairs, 8|24 pairs
-  const int o24 = lone, o32 = o24 + (c24 - X), oP2 = o32 + c32, oX = oP2 + P2;
-  // Stable ranks (ties in batch order) so the plan — and with it the rounding of every score —
-  // is a pure function of the batch: chunks of 1024 molecules, per-wave ballots per extent value.
-  const int wv = tid >> 6, ln = tid & 63;
-  for (int c0 = 0; c0 < B; c0 += 1024) {
-    const int b = c0 + tid;
-    const int n = c0 == 0 ? n_own : (b < B ? extent(b) : -1);
-    int lr = 0;
-    for (int v = 0; v <= N; ++v) {
-      const unsigned long long mk = __ballot(n == v);
-      if (n == v) lr = __popcll(mk & ((1ull << ln) - 1ull));
-      if (ln == 0) wcnt[wv][v] = __popcll(mk);
-    }
-    __syncthreads();
-    int r = -1;
-    if (b < B) {
-      r = cnt[n] + lr;
-      for (int w = 0; w < wv; ++w) r += wcnt[w][n];
-    }
-    __syncthreads();
-    if (tid <= N) {
-      int add = 0;
-      for (int w = 0; w < 16; ++w) add += wcnt[w][tid];
-      cnt[tid] += add;
-    }
-    __syncthreads();
-    if (b >= B) continue;
-    if (gain_rows) {  // the k < min(n, K) eigen slots of this molecule, as rows b*K + k of D
-      const int c = n < K ? n : K;
-      const int base = atomicAdd(&n_slots, c);
-      for (int k = 0; k < c; ++k) gain_rows[base + k] = b * K + k;
-    }
-    int tau, role, split = 32;            // role 0 = single, 1 = A of a pair, 2 = B of a pair
-    if (r < X) {
-      tau = oX + r, role = 1, split = 8;
-    } else if (r < c8 + c16) {
-      const int q = r - X;
-      if (q < 2 * P2) tau = oP2 + (q >> 1), role = 1 + (q & 1), split = 16;
-      else tau = q - 2 * P2, role = 0;
-    } else if (r < c8 + c16 + c24) {
-      const int q = r - (c8 + c16);
-      if (q < X) tau = oX + q, role = 2;
-      else tau = o24 + (q - X), role = 0;
-    } else {
-      tau = o32 + (r - (c8 + c16 + c24)), role = 0;
-    }
-    const int d = T - 1 - tau;  // position in descending cost order
-    const int round = d / W, idx = d % W;
-    const int wg = (round & 1) ? W - 1 - idx : idx;
-    int32_t* e = plan + ((int64_t)wg * 4 + round) * 3;
-    if (role == 2) {
-      e[1] = b;
-    } else {
-      e[0] = b;
-      e[2] = split;
-    }
-  }
-  __syncthreads();
-  if (gain_rows && tid == 0) *n_gain_rows = n_slots;
 }
 
 __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restrict__ mask, int B,

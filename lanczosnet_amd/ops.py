@@ -208,6 +208,35 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
   return Lp, (buf, cap), (rows, n_rows)
 
 
+def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
+  """lnz_prepare_batch: Laplacian pack, batch plan and the Ritz pairs of L[..., 0] in one launch
+  (exact-fp32 plans, N <= 32).  Returns (Lp, tiles, rows, D, V)."""
+  Lf = L if L.dtype == torch.float32 else L.float()
+  B, N, _, Cn = Lf.shape
+  if plan.get('Wp16') is not None or N > 32 or N * N * Cn * 4 > 40 * 1024:
+    Lp, tiles, rows = pack_and_plan(plan, Lf, mask_u8, K, n_cu)
+    D, V = lanczos_ritz(Lf[:, :, :, 0], n_nodes, K)
+    return Lp, tiles, rows, D, V
+  _need_cuda(Lf, mask_u8, n_nodes)
+  lib = _lib.load()
+  n_cu = n_cu or _n_cu(Lf.device)
+  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  dev = Lf.device
+  Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=dev)
+  buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=dev)
+  n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
+  D = torch.empty((B, K), dtype=torch.float32, device=dev)
+  V = torch.empty((B, N, K), dtype=torch.float32, device=dev)
+  nn = n_nodes.to(torch.int32).contiguous()
+  sb, sr, sc, sch = Lf.stride()
+  with torch.cuda.device(dev):
+    _lib.check(lib.lnz_prepare_batch(
+        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
+        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
+        _ptr(D), _ptr(V), C.c_void_p(0), _stream()))
+  return Lp, (buf, cap), (rows, n_rows), D, V
+
+
 def pack_spectral_mlp(linears, S, out=None):
   """linears: 4 (weight, bias) pairs of one `spectral_filter[l]` Sequential -> packed buffer."""
   lib = _lib.load()

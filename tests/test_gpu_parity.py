@@ -762,3 +762,27 @@ def test_gain_row_compaction_computes_exactly_the_live_eigen_slots():
   assert torch.equal(s1, s3)
   s4 = ops.lanczosnet_forward(plan, nf, Lp, V, G_nan, mask, tiling='none')
   assert torch.isfinite(s4).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B', [1, 33, 1024])
+def test_prepare_batch_is_the_three_launches_in_one(B):
+  """lnz_prepare_batch (plan + Lanczos/QL + pack in one launch) returns bit for bit what
+  lnz_pack_laplacian_plan and lnz_lanczos_ritz return separately."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 5))
+  plan = net._plan()
+  batch = draw_batch(B, seed=B, n_min=1, n_max=26)
+  n = _t(batch['n_nodes'])
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  mask = _t(batch['node_mask']).contiguous()
+  Lp1, tiles1, rows1 = ops.pack_and_plan(plan, L, mask, 20)
+  D1, V1 = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+  Lp2, tiles2, rows2, D2, V2 = ops.prepare_batch(plan, L, mask, n, 20)
+  assert torch.equal(Lp1, Lp2) and torch.equal(D1, D2) and torch.equal(V1, V2)
+  cap = tiles1[1]
+  assert tiles2[1] == cap and torch.equal(tiles1[0][:12 * cap + 1], tiles2[0][:12 * cap + 1])
+  nr = int(rows1[1].item())
+  assert int(rows2[1].item()) == nr
+  assert sorted(rows1[0][:nr].tolist()) == sorted(rows2[0][:nr].tolist())
