@@ -125,17 +125,18 @@ def main():
   ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(6)] for k in range(args.steps)}
   mask_u8 = mask.to(torch.uint8).contiguous()
 
+  last_sync = [None]
+
   def step(events=None):
     if events:
       events[0].record()
-    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
+    Lp, tiles, rows, D, V, G, last_sync[0] = ops.prepare_batch(
+        plan, L, mask_u8, n_nodes, K,
+        gains=(cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack']))
     if events:
       events[1].record()
       events[2].record()
       events[3].record()
-    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
-                           rows=rows, zero_fill=not ops.pairing_supported(plan))
-    if events:
       events[4].record()
     score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
     if events:
@@ -164,6 +165,7 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
+  assert last_sync[0] is None or int(last_sync[0][-1]) == 0, 'gains consumer timed out'
 
   # secondary measurement (N = 1 only, never `value`): the opt-in split-precision GEMM mode
   split = None
@@ -201,7 +203,7 @@ def main():
     net.gemm_mode = 'fp32'
     plan = plan_fp32
 
-  names = ['prepare_batch(pack+plan+lanczos_ritz)', '-', '-', 'spectral_gains', 'lanczosnet_forward']
+  names = ['prepare_batch(pack+plan+lanczos_ritz+gains)', '-', '-', '-', 'lanczosnet_forward']
   stage_ms = {nm: float(np.mean([ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)]))
               for k, nm in enumerate(names) if nm != '-'}
 
@@ -227,7 +229,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
                                'fp32, 7x128 layers, 1xMI355X per rank; step = [pack L + batch plan + '
-                               'Lanczos/QL Ritz pairs] (one launch) + spectral gains + fused forward' % (B, L.shape[1]),
+                               'Lanczos/QL Ritz pairs + spectral gains] (one launch) + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, score all-gather)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
         'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',

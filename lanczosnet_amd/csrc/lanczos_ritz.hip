@@ -21,6 +21,7 @@
 // applied directly to Qt, so Qt ends up holding the Ritz vectors V = Q B.
 #include "common.hpp"
 #include "prep.hpp"
+#include "gains_body.hpp"
 
 namespace {
 
@@ -423,7 +424,7 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info, const int b, const int lane,
-    Ritz32Smem& sm) {
+    Ritz32Smem& sm, int32_t* __restrict__ done = nullptr) {
   constexpr int LD = Ritz32Smem::LD;
   const int r = lane & 31, h = lane >> 5;
   int n = n_nodes[b];
@@ -631,6 +632,10 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     Vb[idx] = v;
   }
   if (info && lane == 0) info[b] = nrestart;
+  if (done) {  // publish (D, V) of this molecule to the gains consumers of the fused launch
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef LNZ_PROFILE_PHASES
   __syncthreads();
   if (lane == 0) {
@@ -678,6 +683,65 @@ __global__ __launch_bounds__(512) void prepare_batch_kernel(
   }
 }
 
+// Bounded spin on a flag published with release semantics at agent scope (another workgroup,
+// possibly on another XCD).  Returns false on timeout instead of hanging the GPU.
+__device__ __forceinline__ bool wait_flag(const int32_t* f) {
+  for (int it = 0; it < (1 << 21); ++it) {
+    if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return false;
+}
+
+// lnz_prepare_batch plus the spectral gains, still ONE launch (256-thread workgroups).  The Ritz
+// wavefronts (workgroups 1..B, one live wave each) are latency bound and leave the matrix pipes
+// idle; molecules finish at very different times (QL is ~n^2).  Workgroups beyond 2B are gains
+// CONSUMERS: wave (t, l) waits for the batch plan, then for the `done` flag of the molecules whose
+// eigen slots make up row tile t (the plan lists the live slots in extent order, so a tile holds
+// molecules that finish together and the tiles become ready in index order), and runs the MLP of
+// conv layer l on it — most of the gains are computed in the shadow of the slow molecules.
+// Forward progress: workgroups are dispatched in index order, so every producer is resident or
+// queued ahead of any spinning consumer; the spin is bounded and reports a timeout in sync[B+1].
+// sync: [B+2] int32, zero on entry: [0] plan ready, [1..B] molecule done, [B+1] timeout.
+__global__ __launch_bounds__(256) void prepare_batch_gains_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
+    int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
+    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
+    const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
+    int32_t* __restrict__ sync, lnz_gains::DistArr dist, int S, int num_layer,
+    const float* __restrict__ mlp_pack, float* __restrict__ G) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
+  const int blk = blockIdx.x;
+  if (blk == 0) {
+    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows,
+                    sync);
+  } else if (blk <= B) {
+    if (threadIdx.x >= 64) return;
+    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm,
+                        sync + 1);
+  } else if (blk <= 2 * B) {
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B);
+  } else {
+    const int lane = threadIdx.x & 63;
+    const int gw = (blk - 2 * B - 1) * 4 + (threadIdx.x >> 6);
+    const int t = gw / num_layer, l = gw - t * num_layer;
+    bool ok = wait_flag(sync);
+    const int R = ok ? __hip_atomic_load(n_gain_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    if (ok && 32 * t >= R) return;
+    const int idx = 32 * t + (lane & 31);
+    const bool valid = ok && idx < R;
+    const int row = valid ? gain_rows[idx] : 0;
+    if (valid) ok = wait_flag(sync + 1 + row / K);
+    if (!__all(ok)) {  // wave-uniform: never run half a tile
+      if (lane == 0) sync[B + 1] = 1;
+      return;
+    }
+    lnz_gains::gains_mlp_tile(D, row, valid, l, lane, B, K, dist, S, mlp_pack, G);
+  }
+}
+
 }  // namespace
 
 extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r,
@@ -699,6 +763,37 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
                      n_nodes, D, V, info);
   return lnz::check_launch("lnz_prepare_batch");
+}
+
+extern "C" int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t stride_r,
+                                       int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                       float* Lp, const uint8_t* mask, const int32_t* n_nodes,
+                                       int n_cu, int allow_pairs, int32_t* plan, int32_t* n_wg,
+                                       int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
+                                       float* V, int32_t* sync, const int32_t* dist_host, int S,
+                                       int num_layer, const float* mlp_pack, float* G,
+                                       lnz_stream_t stream) {
+  LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && gain_rows && n_gain_rows && D && V &&
+                  sync && dist_host && mlp_pack && G && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS &&
+                  n_cu > 0 && K > 0 && num_layer > 0,
+              LNZ_EINVAL, "lnz_prepare_batch_gains: bad arguments (B=%d C=%d K=%d)", B, C, K);
+  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch_gains: N=%d > %d", N,
+              LNZ_TILE);
+  LNZ_REQUIRE(S >= 1 && S <= lnz_gains::SMAX, LNZ_ENOTSUP, "lnz_prepare_batch_gains: S=%d", S);
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
+              "lnz_prepare_batch_gains: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
+  lnz_gains::DistArr dist;
+  for (int i = 0; i < lnz_gains::SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
+  const int64_t tiles = ((int64_t)B * K + 31) / 32;
+  const int64_t grid = 2 * (int64_t)B + 1 + (tiles * num_layer + 3) / 4;
+  LNZ_REQUIRE(grid < (1ll << 31), LNZ_ENOTSUP, "lnz_prepare_batch_gains: batch too large");
+  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), lds,
+                     (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
+                     (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
+                     K, gain_rows, n_gain_rows, n_nodes, D, V, sync, dist, S, num_layer, mlp_pack,
+                     G);
+  return lnz::check_launch("lnz_prepare_batch_gains");
 }
 
 extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r,

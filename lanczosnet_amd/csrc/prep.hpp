@@ -63,15 +63,16 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
                                                 int32_t* __restrict__ plan,
                                                 int32_t* __restrict__ n_wg, int K,
                                                 int32_t* __restrict__ gain_rows,
-                                                int32_t* __restrict__ n_gain_rows) {
+                                                int32_t* __restrict__ n_gain_rows,
+                                                int32_t* __restrict__ plan_flag = nullptr) {
   __shared__ int cnt[LNZ_TILE + 2];
   __shared__ int cls[4];  // molecules with extent <= 8, <= 16, <= 24, <= 32 (cumulative)
   __shared__ int wcnt[16][LNZ_TILE + 2];
   const int NT = blockDim.x;  // multiple of 64, <= 1024
-  __shared__ int n_slots;  // eigen slots that carry a Ritz pair (gain_rows)
+  __shared__ int first[LNZ_TILE + 2];  // first rank of each extent value
+  __shared__ int rbase[LNZ_TILE + 2];  // first gain row of each extent value
   const int tid = threadIdx.x;
   if (tid < LNZ_TILE + 2) cnt[tid] = 0;
-  if (tid == 0) n_slots = 0;
   for (int i = tid; i < wg_cap * 12; i += NT) plan[i] = -1;
   __syncthreads();
   auto extent = [&](int b) {  // last real node + 1 (what the forward kernels size their work by)
@@ -85,13 +86,17 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
   for (int b = tid + NT; b < B; b += NT) atomicAdd(&cnt[extent(b)], 1);
   __syncthreads();
   if (tid == 0) {
-    int run = 0;
+    int run = 0, rrun = 0;
     for (int n = 0; n <= LNZ_TILE; ++n) {
       int c = n <= N ? cnt[n] : 0;
       cnt[n] = run;
+      first[n] = run;
+      rbase[n] = rrun;
       run += c;
+      rrun += c * (n < K ? n : K);
       if ((n & 7) == 0 && n > 0) cls[n / 8 - 1] = run;
     }
+    if (gain_rows) *n_gain_rows = rrun;
   }
   __syncthreads();
   const int c8 = cls[0], c16 = cls[1] - cls[0], c24 = cls[2] - cls[1], c32 = cls[3] - cls[2];
@@ -130,9 +135,11 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
     }
     __syncthreads();
     if (b >= B) continue;
-    if (gain_rows) {  // the k < min(n, K) eigen slots of this molecule, as rows b*K + k of D
+    if (gain_rows) {
+      // the k < min(n, K) eigen slots of this molecule, as rows b*K + k of D, in extent-sorted
+      // order: row tiles hold molecules of similar size, which finish their Lanczos/QL together
       const int c = n < K ? n : K;
-      const int base = atomicAdd(&n_slots, c);
+      const int base = rbase[n] + (r - first[n]) * c;
       for (int k = 0; k < c; ++k) gain_rows[base + k] = b * K + k;
     }
     int tau, role, split = 32;            // role 0 = single, 1 = A of a pair, 2 = B of a pair
@@ -160,7 +167,10 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
       e[2] = split;
     }
   }
-  __syncthreads();
-  if (gain_rows && tid == 0) *n_gain_rows = n_slots;
+  if (plan_flag) {  // publish to the consumers of the fused preparation launch
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(plan_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
