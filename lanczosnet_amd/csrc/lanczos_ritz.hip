@@ -719,6 +719,9 @@ __global__ __launch_bounds__(256) void prepare_batch_gains_kernel(
                     sync);
   } else if (blk <= B) {
     if (threadIdx.x >= 64) return;
+    // the Lanczos/QL chain is the critical path of the launch: it wins every issue arbitration
+    // against the consumer wave that shares its SIMD
+    __builtin_amdgcn_s_setprio(3);
     lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm,
                         sync + 1);
   } else if (blk <= 2 * B) {
