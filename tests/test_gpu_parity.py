@@ -789,7 +789,7 @@ def test_prepare_batch_is_the_three_launches_in_one(B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B', [1, 33, 1024, 3000])
+@pytest.mark.parametrize('B', [1, 33, 1024, 3000, 8192])
 def test_prepare_batch_gains_overlapped_launch_matches_the_separate_kernels(B):
   """lnz_prepare_batch_gains (plan + Lanczos/QL + pack + gains consumers in one launch): every
   output bit-identical to the separate launches on the live eigen slots, no consumer timeout,
