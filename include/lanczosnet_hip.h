@@ -106,6 +106,14 @@ int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_stream_t stre
  * Replaces the per-slice `L[:, :, :, ii]` strided-view clones of model/lanczos_net.py:172-178. */
 int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                        int64_t stride_ch, int B, int N, int C, float* Lp, lnz_stream_t stream);
+/* Same, plus ident [B] uint32 (may be NULL): bit c is set when channel c of molecule b is an
+ * identity on its nodes — the tile is diag(0/1): L4 of a bond type the molecule does not contain
+ * (utils/data_helper.py:92-116 on an empty A_e) — so that lnz_lanczosnet_forward can add Z_c
+ * instead of multiplying by M_c (lnz_forward_args.ident).  The ident argument of
+ * lnz_pack_laplacian_plan / lnz_prepare_batch[_gains] is the same array. */
+int lnz_pack_laplacian_ident(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                             int64_t stride_ch, int B, int N, int C, float* Lp, uint32_t* ident,
+                             lnz_stream_t stream);
 
 /* Same tile split into fp16 hi/lo pieces for the split-precision GEMM2 (gemm_mode = 1):
  * Lp16[b][c][blk][piece][lane][e] = L[b][lane&31][cd_row(8*blk+e, lane>>5)][c]; B*C*4096 bytes. */
@@ -204,6 +212,9 @@ typedef struct lnz_forward_args {
                                  (b*32 + node), column c*d + i = (M_c X_l)[node][i] — the reference's
                                  cat(msg) (model/lanczos_net.py:164-180)                           */
   int32_t msg_layer;          /* messages: the conv layer l whose messages are built                 */
+  const uint32_t* ident;      /* forward, optional [B] (lnz_pack_laplacian_ident): edge-type channels
+                                 that are identities on a molecule skip their Laplacian fragments
+                                 and GEMM2 (out += Z_c; same bits on the real nodes)               */
   const int64_t* row_off;     /* messages, optional [B]: first row of each molecule in a COMPACT msg
                                  (real nodes only: row_off = exclusive scan of the node counts, rows
                                  >= n are not written); NULL = row b*32 + node                     */
@@ -247,7 +258,7 @@ int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r, int64_
                       int64_t stride_ch, int B, int N, int C, float* Lp, const uint8_t* mask,
                       const int32_t* n_nodes, int n_cu, int allow_pairs, int32_t* plan,
                       int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
-                      float* V, int32_t* info, lnz_stream_t stream);
+                      float* V, int32_t* info, uint32_t* ident, lnz_stream_t stream);
 /* lnz_prepare_batch plus lnz_spectral_gains_rows (kind 0), still ONE launch: extra workgroups are
  * gains consumers that wait — bounded spin on release/acquire flags at agent scope — for the batch
  * plan and for the Lanczos/QL wavefronts of the molecules whose eigen slots form their row tile,
@@ -262,7 +273,7 @@ int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t stride_r, 
                             int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
                             int32_t* n_gain_rows, float* D, float* V, int32_t* sync,
                             const int32_t* dist_host, int S, int num_layer, const float* mlp_pack,
-                            float* G, lnz_stream_t stream);
+                            float* G, uint32_t* ident, lnz_stream_t stream);
 /* lnz_pack_laplacian + lnz_plan_batch in ONE launch (workgroup B plans while 0..B-1 pack): the two
  * byte movers in front of the Lanczos kernel are independent, and the planner is a single
  * latency-bound workgroup.  Arguments as in the two functions; gain_rows may be NULL. */
@@ -270,7 +281,7 @@ int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t stride_r, 
                             int64_t stride_ch, int B, int N, int C, float* Lp,
                             const uint8_t* mask, int n_cu, int allow_pairs, int32_t* plan,
                             int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
-                            lnz_stream_t stream);
+                            uint32_t* ident, lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);

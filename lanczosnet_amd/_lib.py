@@ -43,7 +43,7 @@ class ForwardArgs(C.Structure):
       ('gemm_mode', C.c_int32), ('Wp16', C.c_void_p), ('w16_off', C.c_int64 * 16),
       ('Wp16_head', C.c_void_p), ('Lp16', C.c_void_p), ('plan', C.c_void_p), ('n_wg', C.c_void_p), ('plan_wg_cap', C.c_int),
       ('act_out', C.c_void_p), ('act', C.c_void_p), ('dy', C.c_void_p), ('dx0', C.c_void_p),
-      ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('row_off', C.c_void_p),
+      ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p),
   ]
 
 
@@ -65,9 +65,10 @@ SIGNATURES = {
     'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_collate_qm8': (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     'lnz_plan_wg_cap': (C.c_int, [_I, _I]),
-    'lnz_pack_laplacian_plan': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P]),
-    'lnz_prepare_batch_gains': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P, _P]),
-    'lnz_prepare_batch': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    'lnz_pack_laplacian_plan': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    'lnz_pack_laplacian_ident': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
+    'lnz_prepare_batch_gains': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P, _P, _P]),
+    'lnz_prepare_batch': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'lnz_plan_batch': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     'lnz_plan_tiles': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'lnz_pack_laplacian_f16x2': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),

@@ -188,6 +188,16 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     H[m] = td[m].split == 32 ? KH : (td[m].split == 16 && nmax < k16 ? nmax : k16);
   }
 
+  // ---- edge-type channels that are identities on every molecule of a tile (a bond type the
+  //      molecule does not contain): out += Z_c instead of M_c Z_c, no Laplacian fragments
+  int idm[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    unsigned v = (FWD && a.ident) ? a.ident[td[m].ta] : 0u;
+    if (FWD && a.ident && td[m].tb >= 0) v &= a.ident[td[m].tb];
+    idm[m] = __builtin_amdgcn_readfirstlane((int)v);
+  }
+
   // ---- basis fragments.
   //      FK = 0: Ritz vectors staged in LDS in L_s-build fragment order, Vs[m][t/4][lane][t%4]:
   //        lane half hh, step t contracts eigen_slot(): a lane holds V[mol][local row][k] if its
@@ -342,6 +352,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             mop[m][t] = (j < K && k2 < K) ? dp[k2] : 0.0f;
           }
         }
+      } else if (c >= a.n_short && ((idm[m] >> (c - a.n_short - a.n_long)) & 1)) {
+        // identity channel: nothing to fetch
       } else {
         const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
         // fragment group g of lane (j,hh) = M[j][8g + 4hh + 0..3].  Rows of molecule A take its
@@ -422,6 +434,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       // ---------------- per tile: M_c fragments, next operands, GEMM2 ----------------
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
+        // M_c is the identity on this tile's molecules: out += Z_c (bit-identical on their nodes)
+        const bool idc = FWD && !is_long && c >= a.n_short &&
+                         ((idm[m] >> (c - a.n_short - a.n_long)) & 1);
         f32x16 Mf;
         if (is_long) {
           f32x16 acc = lnz::splat16(0.0f);
@@ -448,7 +463,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             for (int t = 0; t < (FK ? KHT : 1); ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
           }
           Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]  (symmetric)
-        } else {
+        } else if (!idc) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) Mf[r] = mop[m][r];
         }
@@ -468,9 +483,13 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         }
         // GEMM2: out_m += M_c,m Z_m   (MODE 2: the message M_c,m X_m itself, written out)
         f32x16 P = lnz::splat16(0.0f);
+        if (idc) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[m][r] += Z[m][r];
+        }
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
-          if ((g2mask[m] >> (r >> 2)) & 1) {
+          if (!idc && ((g2mask[m] >> (r >> 2)) & 1)) {
             if (MODE == 2) {
               P = lnz::mfma32(Mf[r + 0], Z[m][r + 0], P);
               P = lnz::mfma32(Mf[r + 1], Z[m][r + 1], P);

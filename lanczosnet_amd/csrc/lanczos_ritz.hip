@@ -668,7 +668,7 @@ __global__ __launch_bounds__(512) void prepare_batch_kernel(
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
-    int32_t* __restrict__ info) {
+    int32_t* __restrict__ info, uint32_t* __restrict__ ident) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
   const int blk = blockIdx.x;
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512) void prepare_batch_kernel(
     // channel 0 of L is the simple-graph Laplacian the Ritz pairs belong to (dataset/qm8.py:262)
     lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x, sm);
   } else {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B);
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B, ident);
   }
 }
 
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void prepare_batch_gains_kernel(
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
     int32_t* __restrict__ sync, lnz_gains::DistArr dist, int S, int num_layer,
-    const float* __restrict__ mlp_pack, float* __restrict__ G) {
+    const float* __restrict__ mlp_pack, float* __restrict__ G, uint32_t* __restrict__ ident) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
   const int blk = blockIdx.x;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(256) void prepare_batch_gains_kernel(
     lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm,
                         sync + 1);
   } else if (blk <= 2 * B) {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B);
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B, ident);
   } else {
     const int lane = threadIdx.x & 63;
     const int gw = (blk - 2 * B - 1) * 4 + (threadIdx.x >> 6);
@@ -752,7 +752,7 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
                                  float* Lp, const uint8_t* mask, const int32_t* n_nodes, int n_cu,
                                  int allow_pairs, int32_t* plan, int32_t* n_wg, int K,
                                  int32_t* gain_rows, int32_t* n_gain_rows, float* D, float* V,
-                                 int32_t* info, lnz_stream_t stream) {
+                                 int32_t* info, uint32_t* ident, lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && D && V && B > 0 && C > 0 &&
                   C <= LNZ_MAX_CHANNELS && n_cu > 0 && K > 0,
               LNZ_EINVAL, "lnz_prepare_batch: bad arguments (B=%d C=%d K=%d)", B, C, K);
@@ -764,7 +764,7 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
   hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(512), lds, (hipStream_t)stream,
                      L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
-                     n_nodes, D, V, info);
+                     n_nodes, D, V, info, ident);
   return lnz::check_launch("lnz_prepare_batch");
 }
 
@@ -775,7 +775,7 @@ extern "C" int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t
                                        int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
                                        float* V, int32_t* sync, const int32_t* dist_host, int S,
                                        int num_layer, const float* mlp_pack, float* G,
-                                       lnz_stream_t stream) {
+                                       uint32_t* ident, lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && gain_rows && n_gain_rows && D && V &&
                   sync && dist_host && mlp_pack && G && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS &&
                   n_cu > 0 && K > 0 && num_layer > 0,
@@ -795,7 +795,7 @@ extern "C" int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, sync, dist, S, num_layer, mlp_pack,
-                     G);
+                     G, ident);
   return lnz::check_launch("lnz_prepare_batch_gains");
 }
 

@@ -128,9 +128,9 @@ extern "C" int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_st
 
 __global__ __launch_bounds__(256) void pack_laplacian_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
-    float4* __restrict__ Lp) {
+    float4* __restrict__ Lp, uint32_t* __restrict__ ident) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
-  pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blockIdx.x);
+  pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blockIdx.x, ident);
 }
 
 // Lp16[b][c][blk][piece][lane] (uint4 = 8 halves): element e = L[b][lane&31][cd_row(8 blk + e, lane>>5)][c]
@@ -190,9 +190,9 @@ extern "C" int lnz_pack_laplacian_f16x2(const float* L, int64_t stride_b, int64_
   return lnz::check_launch("lnz_pack_laplacian_f16x2");
 }
 
-extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r,
-                                  int64_t stride_c, int64_t stride_ch, int B, int N, int C,
-                                  float* Lp, lnz_stream_t stream) {
+extern "C" int lnz_pack_laplacian_ident(const float* L, int64_t stride_b, int64_t stride_r,
+                                        int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                        float* Lp, uint32_t* ident, lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS, LNZ_EINVAL,
               "lnz_pack_laplacian: bad arguments (B=%d C=%d)", B, C);
   LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP,
@@ -202,8 +202,15 @@ extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stri
   LNZ_REQUIRE(lds <= 64 * 1024, LNZ_ENOTSUP,
               "lnz_pack_laplacian: N*N*C*4 = %zu B exceeds the 64 KiB staging tile", lds);
   hipLaunchKernelGGL(pack_laplacian_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, L,
-                     stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp);
+                     stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, ident);
   return lnz::check_launch("lnz_pack_laplacian");
+}
+
+extern "C" int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r,
+                                  int64_t stride_c, int64_t stride_ch, int B, int N, int C,
+                                  float* Lp, lnz_stream_t stream) {
+  return lnz_pack_laplacian_ident(L, stride_b, stride_r, stride_c, stride_ch, B, N, C, Lp, nullptr,
+                                  stream);
 }
 
 __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restrict__ mask, int B,
@@ -222,12 +229,13 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
     float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
-    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows) {
+    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
+    uint32_t* __restrict__ ident) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   if (blockIdx.x == 0) {  // dispatched first: the planner's latency chain starts immediately
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
   } else {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, (int)blockIdx.x - 1);
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, (int)blockIdx.x - 1, ident);
   }
 }
 
@@ -235,7 +243,8 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
                                        int64_t stride_c, int64_t stride_ch, int B, int N, int C,
                                        float* Lp, const uint8_t* mask, int n_cu, int allow_pairs,
                                        int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
-                                       int32_t* n_gain_rows, lnz_stream_t stream) {
+                                       int32_t* n_gain_rows, uint32_t* ident,
+                                       lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && mask && plan && n_wg && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS &&
                   n_cu > 0,
               LNZ_EINVAL, "lnz_pack_laplacian_plan: bad arguments (B=%d C=%d n_cu=%d)", B, C, n_cu);
@@ -248,7 +257,8 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
               "lnz_pack_laplacian_plan: N*N*C*4 = %zu B exceeds the 48 KiB staging tile", lds);
   hipLaunchKernelGGL(pack_plan_kernel, dim3(B + 1), dim3(1024), lds, (hipStream_t)stream, L,
                      stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
-                     allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows);
+                     allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
+                     ident);
   return lnz::check_launch("lnz_pack_laplacian_plan");
 }
 

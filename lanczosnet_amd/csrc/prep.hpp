@@ -11,7 +11,10 @@
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void pack_laplacian_body(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
-    float4* __restrict__ Lp, float* tile, const int b) {  // tile: LDS [N*N*C], source order if dense
+    float4* __restrict__ Lp, float* tile, const int b,  // tile: LDS [N*N*C], source order if dense
+    uint32_t* __restrict__ ident = nullptr) {
+  __shared__ unsigned not_ident;
+  if (threadIdx.x == 0) not_ident = 0u;
   const float* Lb = L + (int64_t)b * sb;
   const bool dense_cl = (sch == 1 && sc == C && sr == (int64_t)N * C);
   const int total = N * N * C;
@@ -26,6 +29,20 @@ __device__ __forceinline__ void pack_laplacian_body(
     }
   }
   __syncthreads();
+  if (ident) {
+    // channel c is an IDENTITY on this molecule when its tile is diag(0/1) — a bond type the
+    // molecule does not contain (L4 of the empty graph) — and the forward adds Z instead of M Z
+    unsigned bad = 0u;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int c = i % C, m = (i / C) % N, r = i / (C * N);
+      const float v = tile[i];
+      const bool ok = v == 0.0f || (r == m && v == 1.0f);
+      bad |= ok ? 0u : (1u << c);
+    }
+    if (bad) atomicOr(&not_ident, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) ident[b] = ~not_ident & (C >= 32 ? 0xffffffffu : ((1u << C) - 1u));
+  }
   // C * 4 * 64 float4 outputs
   for (int o = threadIdx.x; o < C * 256; o += blockDim.x) {
     int lane = o & 63;

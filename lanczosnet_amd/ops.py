@@ -154,10 +154,13 @@ def pack_laplacian(L):
   assert L.dim() == 4 and L.dtype == torch.float32
   B, N, _, Cn = L.shape
   Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=L.device)
+  # identity-channel bits ride along with the pack (read by lanczosnet_forward)
+  Lp.ident = torch.empty((B,), dtype=torch.int32, device=L.device)
   sb, sr, sc, sch = L.stride()
   lib = _lib.load()
   with torch.cuda.device(L.device):
-    _lib.check(lib.lnz_pack_laplacian(_ptr(L), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _stream()))
+    _lib.check(lib.lnz_pack_laplacian_ident(_ptr(L), sb, sr, sc, sch, B, N, Cn, _ptr(Lp),
+                                            _ptr(Lp.ident), _stream()))
   return Lp
 
 
@@ -197,6 +200,7 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
   n_cu = n_cu or _n_cu(Lf.device)
   cap = lib.lnz_plan_wg_cap(B, n_cu)
   Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=Lf.device)
+  Lp.ident = torch.empty((B,), dtype=torch.int32, device=Lf.device)
   buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=Lf.device)
   n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
   sb, sr, sc, sch = Lf.stride()
@@ -204,7 +208,7 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
     _lib.check(lib.lnz_pack_laplacian_plan(
         _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), n_cu,
         int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
-        _stream()))
+        _ptr(Lp.ident), _stream()))
   return Lp, (buf, cap), (rows, n_rows)
 
 
@@ -229,6 +233,7 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
   cap = lib.lnz_plan_wg_cap(B, n_cu)
   dev = Lf.device
   Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=dev)
+  Lp.ident = torch.empty((B,), dtype=torch.int32, device=dev)
   buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=dev)
   n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
   D = torch.empty((B, K), dtype=torch.float32, device=dev)
@@ -240,7 +245,7 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
             _ptr(D), _ptr(V))
   if gains is None or gains[2] is None:
     with torch.cuda.device(dev):
-      _lib.check(lib.lnz_prepare_batch(*common, C.c_void_p(0), _stream()))
+      _lib.check(lib.lnz_prepare_batch(*common, C.c_void_p(0), _ptr(Lp.ident), _stream()))
     if gains is None:
       return Lp, (buf, cap), (rows, n_rows), D, V
     G = spectral_gains(D, gains[0], gains[1], None)  # plain-power filters: no MLP to overlap
@@ -254,7 +259,7 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
   darr = (C.c_int32 * S)(*[int(x) for x in dist])
   with torch.cuda.device(dev):
     _lib.check(lib.lnz_prepare_batch_gains(*common, _ptr(sync), darr, S, num_layer, _ptr(mlp_pack),
-                                           _ptr(G), _stream()))
+                                           _ptr(G), _ptr(Lp.ident), _stream()))
   return Lp, (buf, cap), (rows, n_rows), D, V, G, sync
 
 
@@ -366,13 +371,14 @@ def pairing_supported(plan):
 
 
 def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tiling='auto',
-                       act_out=None):
+                       act_out=None, use_ident=True):
   """Launch the fused forward.  `plan` is a dict made by LanczosNet._plan() holding the packed
   parameters and the static sizes.  tiling: 'auto' = lnz_plan_tiles with pairing where the kernel
   supports it, 'single' = planned but one molecule per tile, 'none' = no plan (batch order), or
   the (buf, cap) pair returned by plan_tiles() for this mask (pairs only for the exact kernel).
   act_out: optional zero-initialised [num_layer,B,32,dhid] that receives every layer's activations
-  (training forward)."""
+  (training forward).  use_ident=False ignores the identity-channel bits of the pack (every
+  channel goes through its Laplacian fragments)."""
   _need_cuda(node_feat, Lp, V, G, mask)
   B, N, K = V.shape
   a = _lib.ForwardArgs()
@@ -401,6 +407,9 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     a.Lp, a.Lp16 = None, Lp.data_ptr()
   else:
     a.Lp, a.Lp16 = Lp.data_ptr(), None
+    ident = getattr(Lp, 'ident', None)  # identity-channel bits written by the pack kernels
+    if ident is not None and use_ident:
+      a.ident = ident.data_ptr()
   a.filter_kind = int(plan.get('filter_kind', 0))
   if G is not None:
     want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if a.filter_kind == 1 else ())

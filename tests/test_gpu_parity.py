@@ -818,3 +818,31 @@ def test_prepare_batch_gains_overlapped_launch_matches_the_separate_kernels(B):
   s1 = ops.lanczosnet_forward(plan, nf, Lp1, V1, G1, mask, tiling=tiles1)
   s2 = ops.lanczosnet_forward(plan, nf, Lp2, V2, G2, mask, tiling=tiles2)
   assert torch.equal(s1, s2)
+
+
+@pytest.mark.gpu
+def test_identity_channel_shortcut_is_bit_identical_and_detects_exactly_the_empty_bond_types():
+  """lnz_pack_laplacian_ident flags channel c of molecule b iff that bond type is absent (its L4 is
+  diag(0/1)); the forward's out += Z shortcut gives the same bits as the Laplacian fragments."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  batch = draw_batch(1024, seed=2)
+  n = _t(batch['n_nodes'])
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  Lp = ops.pack_laplacian(L)
+  ident = Lp.ident.cpu().numpy().astype(np.int64) & 0x7f
+  has = (batch['adjs'].sum(axis=(1, 2)) > 0)                     # [B,E] bond type present
+  want = np.zeros(1024, np.int64)
+  for e in range(6):
+    want |= ((~has[:, e]).astype(np.int64) << (e + 1))
+  want |= (batch['n_nodes'] <= 1).astype(np.int64)                # channel 0: only a single atom
+  np.testing.assert_array_equal(ident, want)
+  assert (ident != 0).mean() > 0.5                                # the shortcut is exercised
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 5))
+  plan = net._plan()
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  nf, mask = _t(batch['node_feat']), _t(batch['node_mask'])
+  s1 = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask, use_ident=True)
+  s0 = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask, use_ident=False)
+  assert torch.equal(s1, s0)
