@@ -56,7 +56,8 @@ int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B, int N, in
  * up to the basis of degenerate eigenspaces and eigenvector sign.  fp64 arithmetic.
  * A is addressed as A[b*stride_b + r*stride_r + c*stride_c] (elements) so channel 0 of a
  * channels-last L [B,N,N,E+1] can be passed without a copy.  N <= 64.
- * D [B,K], V [B,N,K].  info [B] (optional, may be NULL): number of Lanczos restarts. */
+ * D [B,K], V [B,N,K].  info [B] (optional, may be NULL): number of Lanczos restarts, + 256 when
+ * the N <= 32 kernel fell back from its parallel tridiagonal eigensolver to the QL sweep. */
 int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                      const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                      int32_t* info, lnz_stream_t stream);

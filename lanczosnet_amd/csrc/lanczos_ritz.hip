@@ -419,6 +419,279 @@ __device__ inline double cgs2_32(Ritz32Smem& sm, double& x, int j, int r, int h)
   return coef;
 }
 
+// -----------------------------------------------------------------------------------------
+// Eigendecomposition of the Lanczos tridiagonal T (n <= 32) with every lane working, instead of the
+// implicit-QL sweep whose ~n^2 rotations form one serial chain that all 64 lanes recompute
+// (80 % of a 26-atom molecule's time):
+//   1. T splits where Lanczos restarted (off-diagonal exactly 0) or an off-diagonal is negligible;
+//      lane k owns the (k - s)-th eigenvalue of its unreduced block [s, t] — simple there, while
+//      equal eigenvalues of different blocks get eigenvectors with disjoint support;
+//   2. eigenvalue: section search on Sturm counts (LAPACK dstebz's recurrence), the two lane
+//      halves probing the interval at 1/3 and 2/3 — the interval shrinks 3x per pass;
+//   3. eigenvector of the block: twisted factorisation (the dlar1v / MRRR vector: stationary and
+//      progressive qd transforms of T - lambda, twist at min |gamma|), one lane per vector, no
+//      pivoting, no iteration.  Orthogonality of twisted vectors degrades like eps / relative
+//      gap, so a block with two eigenvalues closer than ~1e-8 |T| makes the function return
+//      false (early, before anything is overwritten) and the caller falls back to the QL sweep;
+//   4. Ritz vectors V = Q S: lane (k, h) accumulates 16 node rows of column k from broadcast
+//      reads of the basis, then the basis rows are overwritten by the Ritz vectors.
+// On exit sm.dd[k] / sm.Qt[k][.] hold eigenpair k (any order), like after the QL sweep.
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  return fma(y, fma(-x, y, 1.0), y);
+}
+
+// Eigenvalue of rank (r - s) of the lane's block (see tridiag_eig_parallel).  Kept out of line:
+// inlined, its two 32-entry register arrays stay allocated next to those of the eigenvector stage
+// and push the kernel past 256 registers.
+__device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem& sm, const int n,
+                                                               const int r, const int h, const int s,
+                                                               const int t, const int jloc,
+                                                               const double gsc, bool* bail,
+                                                               double* blo, double* bhi) {
+  const bool act = r < n;
+    // ---- 2. eigenvalue.  Sturm count in product form — p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},
+    //      one dependent FMA per row instead of a division; the count is the number of sign
+    //      changes, collected as sign bits.  The lane's rows outside its block are replaced by a
+    //      diagonal above the spectrum (never a sign change) with no coupling, so the 32-row
+    //      recurrence is straight-line code with no predicate.  Each lane carries two probe
+    //      points, the two lane halves four: the bracket shrinks 5x per pass.
+    double dv[32], e2[32];
+    const double pad = 2.0 * gsc + 1.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const bool in = act && i >= s && i <= t;
+      dv[i] = in ? sm.za[i] : pad;
+      e2[i] = (in && i < t) ? sm.ca[i] : 0.0;
+    }
+    double lo = -gsc, hi = gsc;
+    bool cluster = false;
+    for (int it = 0; it < 30; ++it) {
+      const double w = (hi - lo) * 0.2;
+      const double xa = lo + w * (h ? 3.0 : 1.0), xb = lo + w * (h ? 4.0 : 2.0);
+      double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
+      unsigned ma = 0u, mb = 0u;  // sign bits of p_0 .. p_31, row 31 in bit 0
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        const double ep = i > 0 ? e2[i > 0 ? i - 1 : 0] : 0.0;
+        const double pa = fma(dv[i] - xa, a1, -(ep * a2));
+        const double pb = fma(dv[i] - xb, b1, -(ep * b2));
+        ma = (ma << 1) | ((unsigned)__double2hiint(pa) >> 31);
+        mb = (mb << 1) | ((unsigned)__double2hiint(pb) >> 31);
+        a2 = a1, a1 = pa, b2 = b1, b1 = pb;
+        if ((i & 7) == 7) {  // keep |p| inside the exponent range
+          const double fa = fabs(a1), fb = fabs(b1);
+          const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
+          const double kb = fb < 1e-100 ? 1e100 : (fb > 1e100 ? 1e-100 : 1.0);
+          a1 *= ka, a2 *= ka, b1 *= kb, b2 *= kb;
+        }
+      }
+      // sign changes between consecutive p (p_{-1} = 1 > 0)
+      const int ca = __popc(ma ^ (ma >> 1)), cb = __popc(mb ^ (mb >> 1));
+      const int oa = __shfl_xor(ca, 32, 64), ob = __shfl_xor(cb, 32, 64);
+      // eigenvalues of the block below lo + w, lo + 2w, lo + 3w, lo + 4w
+      const int c1 = h ? oa : ca, c2 = h ? ob : cb, c3 = h ? ca : oa, c4 = h ? cb : ob;
+      const double x1 = lo + w, x2 = lo + 2.0 * w, x3 = lo + 3.0 * w, x4 = lo + 4.0 * w;
+      if (c1 > jloc) {
+        hi = x1;
+      } else if (c2 > jloc) {
+        lo = x1, hi = x2;
+      } else if (c3 > jloc) {
+        lo = x2, hi = x3;
+      } else if (c4 > jloc) {
+        lo = x3, hi = x4;
+      } else {
+        lo = x4;
+      }
+      if (it == 12) {
+        // Bracket width is now ~1e-8 |T|.  Two eigenvalues of ONE block still sharing a bracket:
+        // a degenerate eigenvalue whose second copy crept into the Krylov space through round-off
+        // instead of a clean breakdown — the twisted vectors of such a pair would coincide.
+        // Rare (about one molecule per thousand): give up early, the caller runs the QL sweep.
+        const double lo_n = __shfl_up(lo, 1, 64);
+        const int s_n = __shfl_up(s, 1, 64);
+        cluster = act && (r & 31) > 0 && s_n == s && lo_n == lo;
+        if (__any(cluster)) {
+          *bail = cluster;  // per lane: shares its bracket with the lane below
+          *blo = lo, *bhi = hi;
+          return 0.0;
+        }
+      }
+      const bool done = !act || (hi - lo) <= 4.0 * kEps * fmax(fabs(lo), fabs(hi)) + 1e-300;
+      if (__all(done)) break;
+    }
+    return 0.5 * (lo + hi);
+}
+
+__device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, const double ereg,
+                                            const int n, const int r, const int h) {
+  constexpr int LD = Ritz32Smem::LD;
+  // ---- d, e -> LDS (broadcast reads); negligible couplings split the matrix
+  {
+    const double dn = __shfl_down(dreg, 1, 64);
+    const bool live = r < n - 1 && fabs(ereg) > kEps * (fabs(dreg) + fabs(dn));
+    if (h == 0) {
+      sm.za[r] = r < n ? dreg : 0.0;
+      sm.zb[r] = live ? ereg : 0.0;
+      sm.ca[r] = live ? ereg * ereg : 0.0;
+    }
+  }
+  __syncthreads();
+  const bool act = r < n;
+  // block [s, t] of this lane's index; the lane owns the (r - s)-th eigenvalue of that block
+  int s = r, t = r;
+  if (act) {
+    while (s > 0 && sm.zb[s - 1] != 0.0) --s;
+    while (t < n - 1 && sm.zb[t] != 0.0) ++t;
+  }
+  double gmax = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double el = i > 0 ? fabs(sm.zb[i - 1]) : 0.0;
+    gmax = fmax(gmax, fabs(sm.za[i]) + el + fabs(sm.zb[i]));
+  }
+  const double gsc = gmax > 0.0 ? gmax : 1.0;
+  bool bail = false;
+  double blo = 0.0, bhi = 0.0;
+  double lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail, &blo, &bhi);
+  if (__any(bail)) {
+    // Rescue of a cluster (rare, ~2 molecules per thousand).  The second copy of a degenerate
+    // eigenvalue enters the Krylov space through a coupling of round-off size that stayed above
+    // the breakdown threshold: the block is reducible in all but name.  The cluster's lanes drop
+    // the couplings below 1e-6 |T| of their block — each sub-block then holds the eigenvalue
+    // once — and take the sub-block that the rank inside the shared bracket selects; their Ritz
+    // residual grows by at most the dropped coupling times a vector component.  Every other lane
+    // keeps its block.  If a sub-block still holds a pair, the caller runs the QL sweep.
+    const int upper = __shfl_down(bail ? 1 : 0, 1, 64);  // all lanes take part in the shuffle
+    const bool member = bail || (upper != 0 && (r & 31) < 31);
+    auto count = [&](double x, int a, int b) {  // eigenvalues of rows a..b (no outside coupling) below x
+      int c = 0;
+      double q = 1.0;
+      for (int i = a; i <= b; ++i) {
+        const double e2p = i > a ? sm.ca[i - 1] : 0.0;
+        q = (sm.za[i] - x) - e2p / q;
+        q = fabs(q) < 1e-290 ? -1e-290 : q;
+        c += q < 0.0 ? 1 : 0;
+      }
+      return c;
+    };
+    int jl = r - s;
+    if (member && act) {
+      const double wd = 1e-6 * gsc;
+      const double xl = blo - wd, xh = bhi + wd;
+      int g = (r - s) - count(xl, s, t);  // rank inside the widened bracket
+      int a = s;
+      bool found = false;
+      for (int i = s; i <= t && !found; ++i) {
+        if (i == t || fabs(sm.zb[i]) <= wd) {
+          const int below = count(xl, a, i);
+          const int inside = count(xh, a, i) - below;
+          if (g < inside) {
+            jl = below + g;
+            s = a, t = i;
+            found = true;
+          } else {
+            g -= inside;
+            a = i + 1;
+          }
+        }
+      }
+      jl = found ? jl : r - s;
+    }
+    bool bail2 = false;
+    lam = tridiag_eigenvalue(sm, n, r, h, s, t, jl, gsc, &bail2, &blo, &bhi);
+    if (__any(bail2)) return false;
+  }
+  // ---- 3. eigenvector of the block: twisted factorisation of T - lam
+  double z[32];
+  {
+    double Dm[32];
+    const double tiny = kEps * gsc;
+    // stationary transform, top down: D+_{i+1} = (d_{i+1} - lam) - e_i^2 / D+_i   (parked in z)
+    double Dp = 1.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      z[i] = 0.0;
+      if (i < n) {
+        const bool in = act && i >= s && i <= t;
+        const double di = sm.za[i] - lam;
+        const double e2p = i > 0 ? sm.ca[i > 0 ? i - 1 : 0] : 0.0;
+        double dnew = (i > s) ? di - e2p * rcp_nr(Dp) : di;
+        dnew = fabs(dnew) < tiny ? (dnew < 0.0 ? -tiny : tiny) : dnew;
+        Dp = in ? dnew : Dp;
+        z[i] = in ? dnew : 0.0;
+      }
+    }
+    // progressive transform, bottom up: D-_i = (d_i - lam) - e_i^2 / D-_{i+1};
+    // gamma_i = D+_i + D-_i - (d_i - lam); twist where |gamma| is smallest
+    double Dn = 1.0, gbest = 1e300;
+    int tw = s;
+#pragma unroll
+    for (int i = 31; i >= 0; --i) {
+      Dm[i] = 1.0;
+      if (i < n) {
+        const bool in = act && i >= s && i <= t;
+        const double di = sm.za[i] - lam;
+        const double e2 = sm.ca[i];
+        double dnew = (i < t) ? di - e2 * rcp_nr(Dn) : di;
+        dnew = fabs(dnew) < tiny ? (dnew < 0.0 ? -tiny : tiny) : dnew;
+        Dn = in ? dnew : Dn;
+        Dm[i] = in ? dnew : 1.0;
+        const double g = fabs(z[i] + dnew - di);
+        if (in && g < gbest) {
+          gbest = g;
+          tw = i;
+        }
+      }
+    }
+    // z_tw = 1; upward z_i = -(e_i / D+_i) z_{i+1} (D+_i is read from z[i] before it is replaced);
+    // downward z_{i+1} = -(e_i / D-_{i+1}) z_i
+#pragma unroll
+    for (int i = 31; i >= 0; --i) {
+      if (i < n) {
+        const bool in = act && i >= s && i <= t;
+        const double up = i < 31 ? -(sm.zb[i] * rcp_nr(z[i])) * z[i < 31 ? i + 1 : 31] : 0.0;
+        z[i] = !in ? 0.0 : (i == tw ? 1.0 : (i < tw ? up : 0.0));
+      }
+    }
+#pragma unroll
+    for (int i = 1; i < 32; ++i) {
+      if (i < n) {
+        const bool in = act && i >= s && i <= t;
+        z[i] = (in && i > tw) ? -(sm.zb[i - 1] * rcp_nr(Dm[i])) * z[i - 1] : z[i];
+      }
+    }
+    double nn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) nn = fma(z[i], z[i], nn);
+    const double sc = act ? rsqrt(nn) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) z[i] *= sc;
+  }
+
+  // ---- 4. V = Q S: column k, node rows 16h .. 16h+15
+  double acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    if (i < n) {
+      double q[16];
+      load16(&sm.Qt[i * LD + 16 * h], q);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] = fma(q[u], z[i], acc[u]);
+    }
+  }
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sm.Qt[r * LD + 16 * h + u] = acc[u];
+    if (h == 0) sm.dd[r] = lam;
+  }
+  __syncthreads();
+  return true;
+}
+
 // body of one molecule's wavefront (lane = 0..63); the caller owns the LDS block
 __device__ __forceinline__ void lanczos_ritz32_body(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
@@ -510,6 +783,13 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     tp1 = clock64();
 #endif
 
+#ifndef LNZ_RITZ32_QL
+    const bool solved = tridiag_eig_parallel(sm, dreg, ereg, n, r, h);
+#else
+    const bool solved = false;
+#endif
+    if (!solved) {
+    nrestart += 256;  // diagnostic: the QL fallback ran (info = restarts + 256)
     // ---- implicit-shift QL (tql2 recurrences); d/e in lane registers, eigenvectors in Qt ----
     double f = 0.0, tst1 = 0.0;
     for (int l = 0; l < n; ++l) {
@@ -591,6 +871,7 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     }
     if (h == 0) sm.dd[r] = dreg;
     __syncthreads();
+    }
 #ifdef LNZ_PROFILE_PHASES
     tp2 = clock64();
 #endif
@@ -657,12 +938,12 @@ __global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
 }
 
 // Everything the fused forward needs from a collated batch besides the gains, in ONE launch of
-// 512-thread workgroups: workgroup 0 plans the batch (tile plan + live eigen slots), workgroups
-// 1..B are the Lanczos/QL wavefronts (one live wave each — the other seven exit at once, and a
+// 256-thread workgroups: workgroup 0 plans the batch (tile plan + live eigen slots), workgroups
+// 1..B are the Lanczos/QL wavefronts (one live wave each — the other three exit at once, and a
 // terminated wave does not take part in barriers), workgroups B+1..2B pack the Laplacian tiles.
 // The Ritz wavefronts are the long pole (latency bound, one wave per SIMD); dispatched first, they
 // leave most of the machine idle, and the two byte movers run in that shadow instead of in front.
-__global__ __launch_bounds__(512) void prepare_batch_kernel(
+__global__ __launch_bounds__(256) void prepare_batch_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
     float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
@@ -683,6 +964,9 @@ __global__ __launch_bounds__(512) void prepare_batch_kernel(
   }
 }
 
+constexpr int kPrepLds = 20480;  // static LDS of the fused preparation launch (>= sizeof(Ritz32Smem))
+static_assert(sizeof(Ritz32Smem) <= kPrepLds, "Ritz scratch must fit the shared block");
+
 // Bounded spin on a flag published with release semantics at agent scope (another workgroup,
 // possibly on another XCD).  Returns false on timeout instead of hanging the GPU.
 __device__ __forceinline__ bool wait_flag(const int32_t* f) {
@@ -695,24 +979,28 @@ __device__ __forceinline__ bool wait_flag(const int32_t* f) {
 
 // lnz_prepare_batch plus the spectral gains, still ONE launch (256-thread workgroups).  The Ritz
 // wavefronts (workgroups 1..B, one live wave each) are latency bound and leave the matrix pipes
-// idle; molecules finish at very different times (QL is ~n^2).  Workgroups beyond 2B are gains
-// CONSUMERS: wave (t, l) waits for the batch plan, then for the `done` flag of the molecules whose
+// idle; molecules finish at different times.  The workgroups behind them are gains CONSUMERS: wave (t, l) waits for the batch plan, then for the `done` flag of the molecules whose
 // eigen slots make up row tile t (the plan lists the live slots in extent order, so a tile holds
 // molecules that finish together and the tiles become ready in index order), and runs the MLP of
 // conv layer l on it — most of the gains are computed in the shadow of the slow molecules.
 // Forward progress: workgroups are dispatched in index order, so every producer is resident or
 // queued ahead of any spinning consumer; the spin is bounded and reports a timeout in sync[B+1].
 // sync: [B+2] int32, zero on entry: [0] plan ready, [1..B] molecule done, [B+1] timeout.
-__global__ __launch_bounds__(256) void prepare_batch_gains_kernel(
+__global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
     float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
     int32_t* __restrict__ sync, lnz_gains::DistArr dist, int S, int num_layer,
-    const float* __restrict__ mlp_pack, float* __restrict__ G, uint32_t* __restrict__ ident) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
+    const float* __restrict__ mlp_pack, float* __restrict__ G, uint32_t* __restrict__ ident,
+    int n_cons) {  // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
+  // tile): with a separate dynamic tile every workgroup carried 32 KB and the four resident Ritz
+  // workgroups of a CU left room for ONE more — the pack workgroups trickled through and the
+  // consumers started 50 us late.
+  __shared__ __attribute__((aligned(16))) unsigned char ubuf[kPrepLds];
+  Ritz32Smem& sm = *reinterpret_cast<Ritz32Smem*>(ubuf);
+  float* tile = reinterpret_cast<float*>(ubuf);
   const int blk = blockIdx.x;
   if (blk == 0) {
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows,
@@ -761,7 +1049,7 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
   size_t lds = (size_t)N * N * C * sizeof(float);
   LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
-  hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(512), lds, (hipStream_t)stream,
+  hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(256), lds, (hipStream_t)stream,
                      L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
                      n_nodes, D, V, info, ident);
@@ -784,18 +1072,19 @@ extern "C" int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t
               LNZ_TILE);
   LNZ_REQUIRE(S >= 1 && S <= lnz_gains::SMAX, LNZ_ENOTSUP, "lnz_prepare_batch_gains: S=%d", S);
   size_t lds = (size_t)N * N * C * sizeof(float);
-  LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
-              "lnz_prepare_batch_gains: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
+  LNZ_REQUIRE(lds <= (size_t)kPrepLds, LNZ_ENOTSUP,
+              "lnz_prepare_batch_gains: N*N*C*4 = %zu B exceeds the %d B staging tile", lds, kPrepLds);
   lnz_gains::DistArr dist;
   for (int i = 0; i < lnz_gains::SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
   const int64_t tiles = ((int64_t)B * K + 31) / 32;
-  const int64_t grid = 2 * (int64_t)B + 1 + (tiles * num_layer + 3) / 4;
+  const int64_t n_cons = (tiles * num_layer + 3) / 4;  // consumer workgroups (4 waves each)
+  const int64_t grid = 2 * (int64_t)B + 1 + n_cons;
   LNZ_REQUIRE(grid < (1ll << 31), LNZ_ENOTSUP, "lnz_prepare_batch_gains: batch too large");
-  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), lds,
+  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), 0,
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, sync, dist, S, num_layer, mlp_pack,
-                     G, ident);
+                     G, ident, (int)n_cons);
   return lnz::check_launch("lnz_prepare_batch_gains");
 }
 

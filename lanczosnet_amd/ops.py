@@ -243,6 +243,12 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
   common = (_ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
             int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
             _ptr(D), _ptr(V))
+  if gains is not None and gains[2] is not None and N * N * Cn * 4 > 20480:
+    # the one-launch variant stages the pack tile in a 20 KB static LDS block
+    Lp, tiles, rows, D, V = prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu)
+    G = spectral_gains(D, gains[0], gains[1], gains[2], rows=rows,
+                       zero_fill=not pairing_supported(plan))
+    return Lp, tiles, rows, D, V, G, None
   if gains is None or gains[2] is None:
     with torch.cuda.device(dev):
       _lib.check(lib.lnz_prepare_batch(*common, C.c_void_p(0), _ptr(Lp.ident), _stream()))
