@@ -449,7 +449,8 @@ __device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem&
                                                                const int r, const int h, const int s,
                                                                const int t, const int jloc,
                                                                const double gsc, bool* bail,
-                                                               double* blo, double* bhi) {
+                                                               double* blo, double* bhi,
+                                                               const bool may_bail) {
   const bool act = r < n;
     // ---- 2. eigenvalue.  Sturm count in product form — p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},
     //      one dependent FMA per row instead of a division; the count is the number of sign
@@ -504,7 +505,7 @@ __device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem&
       } else {
         lo = x4;
       }
-      if (it == 12) {
+      if (may_bail && it == 12) {
         // Bracket width is now ~1e-8 |T|.  Two eigenvalues of ONE block still sharing a bracket:
         // a degenerate eigenvalue whose second copy crept into the Krylov space through round-off
         // instead of a clean breakdown — the twisted vectors of such a pair would coincide.
@@ -553,17 +554,24 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
   const double gsc = gmax > 0.0 ? gmax : 1.0;
   bool bail = false;
   double blo = 0.0, bhi = 0.0;
-  double lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail, &blo, &bhi);
+  double lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail, &blo, &bhi, true);
+  // twist window: where this lane looks for the twist index (its whole block unless it is part
+  // of a cluster, see below)
+  int ws = s, wt = t;
+  bool member = false;
   if (__any(bail)) {
     // Rescue of a cluster (rare, ~2 molecules per thousand).  The second copy of a degenerate
-    // eigenvalue enters the Krylov space through a coupling of round-off size that stayed above
-    // the breakdown threshold: the block is reducible in all but name.  The cluster's lanes drop
-    // the couplings below 1e-6 |T| of their block — each sub-block then holds the eigenvalue
-    // once — and take the sub-block that the rank inside the shared bracket selects; their Ritz
-    // residual grows by at most the dropped coupling times a vector component.  Every other lane
-    // keeps its block.  If a sub-block still holds a pair, the caller runs the QL sweep.
+    // eigenvalue enters the Krylov space through couplings of round-off origin that stayed above
+    // the breakdown threshold, so the block holds the eigenvalue twice (to ~1e-9) with one copy
+    // living mostly on either side of a weak coupling.  The twisted factorisation of the FULL block
+    // yields an accurate eigenvector for EVERY twist index where gamma is tiny — one such index on
+    // each side.  The cluster's lanes therefore cut their block at its couplings below 1e-3 |T|
+    // into windows, take the window that the rank inside the shared bracket selects (Sturm counts
+    // of the window's own sub-matrix), look for their twist index only there, and the upper lane
+    // is finally orthogonalised against the lower one.  If the windows cannot separate the
+    // copies, the caller runs the QL sweep.
     const int upper = __shfl_down(bail ? 1 : 0, 1, 64);  // all lanes take part in the shuffle
-    const bool member = bail || (upper != 0 && (r & 31) < 31);
+    member = bail || (upper != 0 && (r & 31) < 31);
     auto count = [&](double x, int a, int b) {  // eigenvalues of rows a..b (no outside coupling) below x
       int c = 0;
       double q = 1.0;
@@ -575,32 +583,31 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
       }
       return c;
     };
-    int jl = r - s;
+    bool ok = true;
     if (member && act) {
-      const double wd = 1e-6 * gsc;
+      const double cut = 1e-3 * gsc, wd = 1e-5 * gsc;
       const double xl = blo - wd, xh = bhi + wd;
       int g = (r - s) - count(xl, s, t);  // rank inside the widened bracket
       int a = s;
       bool found = false;
       for (int i = s; i <= t && !found; ++i) {
-        if (i == t || fabs(sm.zb[i]) <= wd) {
-          const int below = count(xl, a, i);
-          const int inside = count(xh, a, i) - below;
+        if (i == t || fabs(sm.zb[i]) <= cut) {
+          const int inside = count(xh, a, i) - count(xl, a, i);
           if (g < inside) {
-            jl = below + g;
-            s = a, t = i;
+            ws = a, wt = i;
             found = true;
+            ok = inside == 1;  // two copies in one window: not separable this way
           } else {
             g -= inside;
             a = i + 1;
           }
         }
       }
-      jl = found ? jl : r - s;
+      ok = ok && found;
     }
+    if (__any(!ok)) return false;
     bool bail2 = false;
-    lam = tridiag_eigenvalue(sm, n, r, h, s, t, jl, gsc, &bail2, &blo, &bhi);
-    if (__any(bail2)) return false;
+    lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail2, &blo, &bhi, false);
   }
   // ---- 3. eigenvector of the block: twisted factorisation of T - lam
   double z[32];
@@ -638,7 +645,7 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
         Dn = in ? dnew : Dn;
         Dm[i] = in ? dnew : 1.0;
         const double g = fabs(z[i] + dnew - di);
-        if (in && g < gbest) {
+        if (in && i >= ws && i <= wt && g < gbest) {
           gbest = g;
           tw = i;
         }
@@ -667,6 +674,44 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     const double sc = act ? rsqrt(nn) : 0.0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) z[i] *= sc;
+  }
+
+  if (__any(member)) {
+    // cluster lanes: modified Gram-Schmidt in lane order.  pos = how many consecutive lower lanes
+    // belong to the same cluster; the lane at position p is orthogonalised against the (final)
+    // vectors of the p lanes below it.
+    int pos = 0;
+    {
+      bool chain = true;
+      for (int d = 1; d <= 3; ++d) {
+        const int s_lo = __shfl_up(s, d, 64);
+        const int m_lo = __shfl_up(member ? 1 : 0, d, 64);
+        const double l_lo = __shfl_up(lam, d, 64);
+        chain = chain && act && member && m_lo != 0 && (r & 31) >= d && s_lo == s &&
+                fabs(lam - l_lo) <= 1e-6 * gsc;
+        pos += chain ? 1 : 0;
+      }
+    }
+    for (int p = 1; p <= 3; ++p) {
+      if (!__any(pos >= p)) break;
+      for (int d = 1; d <= p; ++d) {
+        const bool fix = pos == p;
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) dot = fma(z[i], __shfl_up(z[i], d, 64), dot);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const double zl = __shfl_up(z[i], d, 64);
+          z[i] = fix ? fma(-dot, zl, z[i]) : z[i];
+        }
+      }
+      double nn = 0.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) nn = fma(z[i], z[i], nn);
+      const double sc = (pos == p && nn > 0.0) ? rsqrt(nn) : 1.0;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) z[i] *= sc;
+    }
   }
 
   // ---- 4. V = Q S: column k, node rows 16h .. 16h+15
