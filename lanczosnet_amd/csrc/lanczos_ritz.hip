@@ -451,6 +451,8 @@ __device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem&
                                                                const double gsc, bool* bail,
                                                                double* blo, double* bhi,
                                                                const bool may_bail) {
+  // may_bail: first call (start from the spectral bound, stop at pass 12 if a cluster shows);
+  // otherwise resume from the bracket the first call returned in *blo / *bhi
   const bool act = r < n;
     // ---- 2. eigenvalue.  Sturm count in product form — p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},
     //      one dependent FMA per row instead of a division; the count is the number of sign
@@ -466,9 +468,9 @@ __device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem&
       dv[i] = in ? sm.za[i] : pad;
       e2[i] = (in && i < t) ? sm.ca[i] : 0.0;
     }
-    double lo = -gsc, hi = gsc;
+    double lo = may_bail ? -gsc : *blo, hi = may_bail ? gsc : *bhi;
     bool cluster = false;
-    for (int it = 0; it < 30; ++it) {
+    for (int it = may_bail ? 0 : 13; it < 30; ++it) {
       const double w = (hi - lo) * 0.2;
       const double xa = lo + w * (h ? 3.0 : 1.0), xb = lo + w * (h ? 4.0 : 2.0);
       double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
