@@ -82,6 +82,9 @@ def main():
   ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--batch', type=int, default=1024, help='molecules per GPU')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--pipeline', action='store_true',
+                  help='software pipeline over the stream of batches: one launch prepares batch k+1 '
+                       'and computes the spectral gains of batch k')
   ap.add_argument('--overlap-gains', action='store_true',
                   help='spectral gains inside the preparation launch (consumer wavefronts)')
   ap.add_argument('--cpu-reps', type=int, default=3)
@@ -157,16 +160,46 @@ def main():
       dist.all_gather(gathered, score)
     return score
 
+  gains_cfg = (cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+
+  def run_pipelined(n_steps, events=None):
+    # batch k+1 is prepared while the gains of batch k are computed (one launch), then batch k is
+    # forwarded: every batch still gets its own preparation, gains and forward
+    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)      # prologue: batch 0
+    score = None
+    for k in range(n_steps):
+      ev_k = events[k] if events else None
+      if ev_k:
+        ev_k[0].record()
+      nLp, ntiles, nrows, nD, nV, G = ops.prepare_batch_prev_gains(
+          plan, L, mask_u8, n_nodes, K, prev=(D, rows), gains=gains_cfg)
+      if ev_k:
+        for j in (1, 2, 3, 4):
+          ev_k[j].record()
+      score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
+      if ev_k:
+        ev_k[5].record()
+      if dist:
+        dist.all_gather(gathered, score)
+      Lp, tiles, rows, D, V = nLp, ntiles, nrows, nD, nV
+    return score
+
   with torch.no_grad():
-    for _ in range(args.warmup):
-      score = step()
+    if args.pipeline:
+      score = run_pipelined(args.warmup)
+    else:
+      for _ in range(args.warmup):
+        score = step()
     torch.cuda.synchronize()
     if dist:
       dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-      score = step(ev[i])
+    if args.pipeline:
+      score = run_pipelined(args.steps, ev)
+    else:
+      for i in range(args.steps):
+        score = step(ev[i])
     torch.cuda.synchronize()
     if dist:
       dist.barrier()
@@ -178,6 +211,23 @@ def main():
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
   assert last_sync[0] is None or int(last_sync[0][-1]) == 0, 'gains consumer timed out'
+
+  # secondary measurement (N = 1 only, never `value`): software pipeline over the stream of batches
+  pipe = None
+  if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.pipeline \
+      and not args.overlap_gains:
+    with torch.no_grad():
+      run_pipelined(args.warmup)
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      sp = run_pipelined(args.steps)
+      torch.cuda.synchronize()
+      elp = time.perf_counter() - t1
+    pipe = {'mode': 'one launch prepares batch k+1 (plan + Lanczos/eigensolve + pack) and computes the '
+                    'spectral gains of batch k; then forward of batch k (lnz_prepare_batch_prev_gains)',
+            'value': round(B * args.steps / elp, 1), 'unit': 'molecules/s',
+            'ms_per_step': round(1e3 * elp / args.steps, 4),
+            'scores_equal_sequential': bool(torch.equal(sp, score))}
 
   # secondary measurement (N = 1 only, never `value`): the opt-in split-precision GEMM mode
   split = None
@@ -258,6 +308,8 @@ def main():
     }
     if split is not None:
       out['config']['split_precision_mode'] = split
+    if pipe is not None:
+      out['config']['pipelined_stream_mode'] = pipe
     if world == 1 and not args.no_cpu_baseline:
       torch.set_num_threads(os.cpu_count() or 1)
       v, times = cpu_baseline(cfg, params, B, args.cpu_reps)

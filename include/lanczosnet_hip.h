@@ -275,6 +275,19 @@ int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t stride_r, 
                             int32_t* n_gain_rows, float* D, float* V, int32_t* sync,
                             const int32_t* dist_host, int S, int num_layer, const float* mlp_pack,
                             float* G, uint32_t* ident, lnz_stream_t stream);
+/* Software pipeline over a STREAM of batches: lnz_prepare_batch of batch k+1 and the spectral
+ * gains (kind 0, live rows) of batch k in one launch.  The two are independent — no flags — and
+ * complementary: the Lanczos / eigensolve wavefronts are latency bound (one per SIMD, matrix pipes
+ * idle), the MLP is matrix-pipe work.  D_prev [B_prev,K], rows_prev / n_rows_prev: outputs of the
+ * previous preparation; G_prev [num_layer,B_prev,S,K]: live slots written.  Everything else as in
+ * lnz_prepare_batch. */
+int lnz_prepare_batch_prev_gains(
+    const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c, int64_t stride_ch, int B,
+    int N, int C, float* Lp, const uint8_t* mask, const int32_t* n_nodes, int n_cu, int allow_pairs,
+    int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
+    float* V, uint32_t* ident, const float* D_prev, int B_prev, const int32_t* rows_prev,
+    const int32_t* n_rows_prev, const int32_t* dist_host, int S, int num_layer,
+    const float* mlp_pack, float* G_prev, lnz_stream_t stream);
 /* lnz_pack_laplacian + lnz_plan_batch in ONE launch (workgroup B plans while 0..B-1 pack): the two
  * byte movers in front of the Lanczos kernel are independent, and the planner is a single
  * latency-bound workgroup.  Arguments as in the two functions; gain_rows may be NULL. */

@@ -1041,7 +1041,12 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
     int32_t* __restrict__ sync, lnz_gains::DistArr dist, int S, int num_layer,
     const float* __restrict__ mlp_pack, float* __restrict__ G, uint32_t* __restrict__ ident,
-    int n_cons) {  // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
+    int n_cons, const float* __restrict__ Dg, const int32_t* __restrict__ rows_g,
+    const int32_t* __restrict__ n_rows_g, int Bg) {
+  // sync != NULL: the gains belong to THIS batch (Dg = D, rows_g = gain_rows): consumers wait on
+  // flags.  sync == NULL: software pipeline over a stream of batches — the gains blocks work on the
+  // PREVIOUS batch (Dg, rows_g complete before the launch, Bg molecules), independent of everything
+  // else in the launch; they follow the Ritz wavefronts directly and the pack goes last.  // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
   // tile): with a separate dynamic tile every workgroup carried 32 KB and the four resident Ritz
   // workgroups of a CU left room for ONE more — the pack workgroups trickled through and the
   // consumers started 50 us late.
@@ -1058,25 +1063,39 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
     // against the consumer wave that shares its SIMD
     __builtin_amdgcn_s_setprio(3);
     lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm,
-                        sync + 1);
-  } else if (blk <= 2 * B) {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B, ident);
+                        sync ? sync + 1 : nullptr);
   } else {
+    // Behind the Ritz workgroups: sync mode = all pack workgroups, then the consumers; pipelined
+    // mode = the gains workgroups, then the pack (needed by the next launch only).  Alternating the
+    // two measured slower (229 vs 182 us).
+    const int p = blk - B - 1;
+    int pack_id, cons_id;
+    if (sync) {
+      pack_id = p < B ? p : -1;
+      cons_id = p - B;
+    } else {
+      pack_id = p >= n_cons ? p - n_cons : -1;
+      cons_id = p;
+    }
+    if (pack_id >= 0) {
+      pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, pack_id, ident);
+      return;
+    }
     const int lane = threadIdx.x & 63;
-    const int gw = (blk - 2 * B - 1) * 4 + (threadIdx.x >> 6);
+    const int gw = cons_id * 4 + (threadIdx.x >> 6);
     const int t = gw / num_layer, l = gw - t * num_layer;
-    bool ok = wait_flag(sync);
-    const int R = ok ? __hip_atomic_load(n_gain_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    bool ok = sync ? wait_flag(sync) : true;
+    const int R = ok ? __hip_atomic_load(n_rows_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     if (ok && 32 * t >= R) return;
     const int idx = 32 * t + (lane & 31);
     const bool valid = ok && idx < R;
-    const int row = valid ? gain_rows[idx] : 0;
-    if (valid) ok = wait_flag(sync + 1 + row / K);
+    const int row = valid ? rows_g[idx] : 0;
+    if (sync && valid) ok = wait_flag(sync + 1 + row / K);
     if (!__all(ok)) {  // wave-uniform: never run half a tile
       if (lane == 0) sync[B + 1] = 1;
       return;
     }
-    lnz_gains::gains_mlp_tile(D, row, valid, l, lane, B, K, dist, S, mlp_pack, G);
+    lnz_gains::gains_mlp_tile(Dg, row, valid, l, lane, Bg, K, dist, S, mlp_pack, G);
   }
 }
 
@@ -1131,8 +1150,40 @@ extern "C" int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, sync, dist, S, num_layer, mlp_pack,
-                     G, ident, (int)n_cons);
+                     G, ident, (int)n_cons, D, gain_rows, n_gain_rows, B);
   return lnz::check_launch("lnz_prepare_batch_gains");
+}
+
+extern "C" int lnz_prepare_batch_prev_gains(
+    const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c, int64_t stride_ch, int B,
+    int N, int C, float* Lp, const uint8_t* mask, const int32_t* n_nodes, int n_cu, int allow_pairs,
+    int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
+    float* V, uint32_t* ident, const float* D_prev, int B_prev, const int32_t* rows_prev,
+    const int32_t* n_rows_prev, const int32_t* dist_host, int S, int num_layer,
+    const float* mlp_pack, float* G_prev, lnz_stream_t stream) {
+  LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && gain_rows && n_gain_rows && D && V &&
+                  D_prev && rows_prev && n_rows_prev && dist_host && mlp_pack && G_prev && B > 0 &&
+                  B_prev > 0 && C > 0 && C <= LNZ_MAX_CHANNELS && n_cu > 0 && K > 0 && num_layer > 0,
+              LNZ_EINVAL, "lnz_prepare_batch_prev_gains: bad arguments (B=%d C=%d K=%d)", B, C, K);
+  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: N=%d > %d", N,
+              LNZ_TILE);
+  LNZ_REQUIRE(S >= 1 && S <= lnz_gains::SMAX, LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: S=%d", S);
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(lds <= (size_t)kPrepLds, LNZ_ENOTSUP,
+              "lnz_prepare_batch_prev_gains: N*N*C*4 = %zu B exceeds the %d B staging tile", lds,
+              kPrepLds);
+  lnz_gains::DistArr dist;
+  for (int i = 0; i < lnz_gains::SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
+  const int64_t tiles = ((int64_t)B_prev * K + 31) / 32;
+  const int64_t n_cons = (tiles * num_layer + 3) / 4;
+  const int64_t grid = 2 * (int64_t)B + 1 + n_cons;
+  LNZ_REQUIRE(grid < (1ll << 31), LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: batch too large");
+  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
+                     (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
+                     K, gain_rows, n_gain_rows, n_nodes, D, V, (int32_t*)nullptr, dist, S, num_layer,
+                     mlp_pack, G_prev, ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev);
+  return lnz::check_launch("lnz_prepare_batch_prev_gains");
 }
 
 extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r,

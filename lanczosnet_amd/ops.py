@@ -269,6 +269,43 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
   return Lp, (buf, cap), (rows, n_rows), D, V, G, sync
 
 
+def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=None):
+  """lnz_prepare_batch_prev_gains: the preparation of THIS batch and the spectral gains of the
+  PREVIOUS one in a single launch (software pipeline over a stream of batches).
+  prev = (D_prev, rows_prev) from the previous prepare_batch*/ call; gains = (dist, num_layer,
+  mlp_pack).  Returns (Lp, tiles, rows, D, V, G_prev)."""
+  Lf = L if L.dtype == torch.float32 else L.float()
+  B, N, _, Cn = Lf.shape
+  _need_cuda(Lf, mask_u8, n_nodes, prev[0])
+  assert plan.get('Wp16') is None and N <= 32 and N * N * Cn * 4 <= 20480
+  lib = _lib.load()
+  n_cu = n_cu or _n_cu(Lf.device)
+  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  dev = Lf.device
+  Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=dev)
+  Lp.ident = torch.empty((B,), dtype=torch.int32, device=dev)
+  buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=dev)
+  n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
+  D = torch.empty((B, K), dtype=torch.float32, device=dev)
+  V = torch.empty((B, N, K), dtype=torch.float32, device=dev)
+  nn = n_nodes.to(torch.int32).contiguous()
+  D_prev, (rows_prev, n_rows_prev) = prev
+  Bp = D_prev.shape[0]
+  dist, num_layer, mlp_pack = gains
+  S = len(dist)
+  Gbuf = torch.empty((num_layer * Bp * S * K + 16,), dtype=torch.float32, device=dev)
+  G = Gbuf[:num_layer * Bp * S * K].view(num_layer, Bp, S, K)
+  darr = (C.c_int32 * S)(*[int(x) for x in dist])
+  sb, sr, sc, sch = Lf.stride()
+  with torch.cuda.device(dev):
+    _lib.check(lib.lnz_prepare_batch_prev_gains(
+        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
+        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
+        _ptr(D), _ptr(V), _ptr(Lp.ident), _ptr(D_prev), Bp, _ptr(rows_prev), _ptr(n_rows_prev),
+        darr, S, num_layer, _ptr(mlp_pack), _ptr(G), _stream()))
+  return Lp, (buf, cap), (rows, n_rows), D, V, G
+
+
 def pack_spectral_mlp(linears, S, out=None):
   """linears: 4 (weight, bias) pairs of one `spectral_filter[l]` Sequential -> packed buffer."""
   lib = _lib.load()

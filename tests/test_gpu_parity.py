@@ -874,3 +874,31 @@ def test_ritz_pairs_orthonormal_and_accurate_including_degenerate_clusters(seed)
     want = lam[order][:min(nb, 20)]
     got = Dd[b, :min(nb, 20)].cpu()
     assert (torch.sort(got).values - torch.sort(want).values).abs().max().item() < 2e-6, b
+
+
+@pytest.mark.gpu
+def test_pipelined_preparation_computes_the_previous_batch_gains():
+  """lnz_prepare_batch_prev_gains: batch B's preparation and batch A's spectral gains in one launch
+  equal the separate launches bit for bit (different batch sizes on purpose)."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 5))
+  plan = net._plan()
+  gains = (cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  ba, bb = draw_batch(700, seed=1, n_min=1, n_max=26), draw_batch(1024, seed=2)
+  prep = {}
+  for key, b in (('a', ba), ('b', bb)):
+    n = _t(b['n_nodes'])
+    L = ops.laplacian_l4(_t(b['adjs']), n)
+    mask = _t(b['node_mask']).contiguous()
+    prep[key] = (L, mask, n) + tuple(ops.prepare_batch(plan, L, mask, n, 20))
+  La, ma, na, Lpa, tla, rowsa, Da, Va = prep['a']
+  Lb, mb, nb, Lpb, tlb, rowsb, Db, Vb = prep['b']
+  Ga = ops.spectral_gains(Da, *gains, rows=rowsa)
+  Lp2, tl2, rows2, D2, V2, G2 = ops.prepare_batch_prev_gains(plan, Lb, mb, nb, 20, prev=(Da, rowsa),
+                                                             gains=gains)
+  assert torch.equal(Lp2, Lpb) and torch.equal(D2, Db) and torch.equal(V2, Vb)
+  assert torch.equal(tl2[0][:12 * tl2[1] + 1], tlb[0][:12 * tlb[1] + 1])
+  live = torch.clamp(na, max=20).long()
+  sel = (torch.arange(20, device=DEV)[None, :] < live[:, None])[None, :, None, :].expand_as(Ga)
+  assert torch.equal(Ga[sel], G2[sel])
