@@ -85,8 +85,6 @@ def main():
   ap.add_argument('--pipeline', action='store_true',
                   help='software pipeline over the stream of batches: one launch prepares batch k+1 '
                        'and computes the spectral gains of batch k')
-  ap.add_argument('--overlap-gains', action='store_true',
-                  help='spectral gains inside the preparation launch (consumer wavefronts)')
   ap.add_argument('--cpu-reps', type=int, default=3)
   ap.add_argument('--gemm', default='fp32', choices=['fp32', 'f16x3'],
                   help="fp32 = exact fp32 MFMA (headline); f16x3 = opt-in split-precision GEMM1")
@@ -130,26 +128,16 @@ def main():
   ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(6)] for k in range(args.steps)}
   mask_u8 = mask.to(torch.uint8).contiguous()
 
-  last_sync = [None]
-
   def step(events=None):
     if events:
       events[0].record()
-    if args.overlap_gains:
-      Lp, tiles, rows, D, V, G, last_sync[0] = ops.prepare_batch(
-          plan, L, mask_u8, n_nodes, K,
-          gains=(cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack']))
-      if events:
-        events[1].record()
-        events[2].record()
-    else:
-      Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
-      if events:
-        events[1].record()
-      G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
-                             rows=rows, zero_fill=not ops.pairing_supported(plan))
-      if events:
-        events[2].record()
+    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
+    if events:
+      events[1].record()
+    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
+                           rows=rows, zero_fill=not ops.pairing_supported(plan))
+    if events:
+      events[2].record()
     if events:
       events[3].record()
       events[4].record()
@@ -210,12 +198,10 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
-  assert last_sync[0] is None or int(last_sync[0][-1]) == 0, 'gains consumer timed out'
 
   # secondary measurement (N = 1 only, never `value`): software pipeline over the stream of batches
   pipe = None
-  if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.pipeline \
-      and not args.overlap_gains:
+  if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.pipeline:
     with torch.no_grad():
       run_pipelined(args.warmup)
       torch.cuda.synchronize()

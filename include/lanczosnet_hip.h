@@ -260,21 +260,6 @@ int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r, int64_
                       const int32_t* n_nodes, int n_cu, int allow_pairs, int32_t* plan,
                       int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
                       float* V, int32_t* info, uint32_t* ident, lnz_stream_t stream);
-/* lnz_prepare_batch plus lnz_spectral_gains_rows (kind 0), still ONE launch: extra workgroups are
- * gains consumers that wait — bounded spin on release/acquire flags at agent scope — for the batch
- * plan and for the Lanczos/QL wavefronts of the molecules whose eigen slots form their row tile,
- * so most of the spectral-filter MLP runs on the matrix pipes the latency-bound Ritz wavefronts
- * leave idle.  sync: [B+2] int32, ZERO on entry ([0] plan ready, [1..B] molecule done, [B+1] set
- * if a consumer timed out — then G is incomplete; never observed).  G [num_layer,B,S,K]: live
- * slots written, the rest untouched.  Other arguments as in lnz_prepare_batch /
- * lnz_spectral_gains. */
-int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
-                            int64_t stride_ch, int B, int N, int C, float* Lp,
-                            const uint8_t* mask, const int32_t* n_nodes, int n_cu, int allow_pairs,
-                            int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
-                            int32_t* n_gain_rows, float* D, float* V, int32_t* sync,
-                            const int32_t* dist_host, int S, int num_layer, const float* mlp_pack,
-                            float* G, uint32_t* ident, lnz_stream_t stream);
 /* Software pipeline over a STREAM of batches: lnz_prepare_batch of batch k+1 and the spectral
  * gains (kind 0, live rows) of batch k in one launch.  The two are independent — no flags — and
  * complementary: the Lanczos / eigensolve wavefronts are latency bound (one per SIMD, matrix pipes

@@ -67,7 +67,6 @@ SIGNATURES = {
     'lnz_plan_wg_cap': (C.c_int, [_I, _I]),
     'lnz_pack_laplacian_plan': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     'lnz_pack_laplacian_ident': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
-    'lnz_prepare_batch_gains': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P, _P, _P]),
     'lnz_prepare_batch_prev_gains': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P, _P]),
     'lnz_prepare_batch': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'lnz_plan_batch': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),

@@ -744,7 +744,7 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info, const int b, const int lane,
-    Ritz32Smem& sm, int32_t* __restrict__ done = nullptr) {
+    Ritz32Smem& sm) {
   constexpr int LD = Ritz32Smem::LD;
   const int r = lane & 31, h = lane >> 5;
   int n = n_nodes[b];
@@ -960,10 +960,6 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     Vb[idx] = v;
   }
   if (info && lane == 0) info[b] = nrestart;
-  if (done) {  // publish (D, V) of this molecule to the gains consumers of the fused launch
-    __threadfence();
-    if (lane == 0) __hip_atomic_store(done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
 #ifdef LNZ_PROFILE_PHASES
   __syncthreads();
   if (lane == 0) {
@@ -1014,39 +1010,27 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
 constexpr int kPrepLds = 20480;  // static LDS of the fused preparation launch (>= sizeof(Ritz32Smem))
 static_assert(sizeof(Ritz32Smem) <= kPrepLds, "Ritz scratch must fit the shared block");
 
-// Bounded spin on a flag published with release semantics at agent scope (another workgroup,
-// possibly on another XCD).  Returns false on timeout instead of hanging the GPU.
-__device__ __forceinline__ bool wait_flag(const int32_t* f) {
-  for (int it = 0; it < (1 << 21); ++it) {
-    if (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-    __builtin_amdgcn_s_sleep(8);
-  }
-  return false;
-}
-
-// lnz_prepare_batch plus the spectral gains, still ONE launch (256-thread workgroups).  The Ritz
-// wavefronts (workgroups 1..B, one live wave each) are latency bound and leave the matrix pipes
-// idle; molecules finish at different times.  The workgroups behind them are gains CONSUMERS: wave (t, l) waits for the batch plan, then for the `done` flag of the molecules whose
-// eigen slots make up row tile t (the plan lists the live slots in extent order, so a tile holds
-// molecules that finish together and the tiles become ready in index order), and runs the MLP of
-// conv layer l on it — most of the gains are computed in the shadow of the slow molecules.
-// Forward progress: workgroups are dispatched in index order, so every producer is resident or
-// queued ahead of any spinning consumer; the spin is bounded and reports a timeout in sync[B+1].
-// sync: [B+2] int32, zero on entry: [0] plan ready, [1..B] molecule done, [B+1] timeout.
+// Software pipeline over a stream of batches, ONE launch of 256-thread workgroups: workgroup 0
+// plans batch k+1, workgroups 1..B are its Lanczos / eigensolve wavefronts (one live wave each,
+// raised issue priority), the next n_cons workgroups run the spectral-gains MLP of batch k (whose
+// D and live-row list were completed by the previous launch: no dependency inside this one), the
+// last B workgroups pack batch k+1's Laplacian tiles.  The Ritz wavefronts are latency bound and
+// leave the matrix pipes idle; the MLP is matrix-pipe work: one gains wave runs next to each Ritz
+// wave (2 waves per SIMD at 248 VGPRs), two once the Ritz waves are gone.
+// (A same-batch variant, gains consumers spinning on per-molecule `done` flags, was built and
+// measured: 253 us with the QL eigensolver, 244 us with the parallel one — slower than the plain
+// launches once all molecules finish within a narrow window; it was removed.)
 __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
     float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
-    int32_t* __restrict__ sync, lnz_gains::DistArr dist, int S, int num_layer,
+    lnz_gains::DistArr dist, int S, int num_layer,
     const float* __restrict__ mlp_pack, float* __restrict__ G, uint32_t* __restrict__ ident,
     int n_cons, const float* __restrict__ Dg, const int32_t* __restrict__ rows_g,
     const int32_t* __restrict__ n_rows_g, int Bg) {
-  // sync != NULL: the gains belong to THIS batch (Dg = D, rows_g = gain_rows): consumers wait on
-  // flags.  sync == NULL: software pipeline over a stream of batches — the gains blocks work on the
-  // PREVIOUS batch (Dg, rows_g complete before the launch, Bg molecules), independent of everything
-  // else in the launch; they follow the Ritz wavefronts directly and the pack goes last.  // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
+  // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
   // tile): with a separate dynamic tile every workgroup carried 32 KB and the four resident Ritz
   // workgroups of a CU left room for ONE more — the pack workgroups trickled through and the
   // consumers started 50 us late.
@@ -1055,46 +1039,29 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
   float* tile = reinterpret_cast<float*>(ubuf);
   const int blk = blockIdx.x;
   if (blk == 0) {
-    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows,
-                    sync);
+    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
   } else if (blk <= B) {
     if (threadIdx.x >= 64) return;
-    // the Lanczos/QL chain is the critical path of the launch: it wins every issue arbitration
-    // against the consumer wave that shares its SIMD
+    // the Lanczos / eigensolve chain is the critical path of the launch: it wins every issue
+    // arbitration against the gains wave that shares its SIMD
     __builtin_amdgcn_s_setprio(3);
-    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm,
-                        sync ? sync + 1 : nullptr);
+    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm);
   } else {
-    // Behind the Ritz workgroups: sync mode = all pack workgroups, then the consumers; pipelined
-    // mode = the gains workgroups, then the pack (needed by the next launch only).  Alternating the
-    // two measured slower (229 vs 182 us).
+    // behind the Ritz workgroups: the gains workgroups, then the pack (needed by the next launch
+    // only).  Alternating the two measured slower (229 vs 182 us).
     const int p = blk - B - 1;
-    int pack_id, cons_id;
-    if (sync) {
-      pack_id = p < B ? p : -1;
-      cons_id = p - B;
-    } else {
-      pack_id = p >= n_cons ? p - n_cons : -1;
-      cons_id = p;
-    }
-    if (pack_id >= 0) {
-      pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, pack_id, ident);
+    if (p >= n_cons) {
+      pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, p - n_cons, ident);
       return;
     }
     const int lane = threadIdx.x & 63;
-    const int gw = cons_id * 4 + (threadIdx.x >> 6);
+    const int gw = p * 4 + (threadIdx.x >> 6);
     const int t = gw / num_layer, l = gw - t * num_layer;
-    bool ok = sync ? wait_flag(sync) : true;
-    const int R = ok ? __hip_atomic_load(n_rows_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    if (ok && 32 * t >= R) return;
+    const int R = *n_rows_g;
+    if (32 * t >= R) return;
     const int idx = 32 * t + (lane & 31);
-    const bool valid = ok && idx < R;
+    const bool valid = idx < R;
     const int row = valid ? rows_g[idx] : 0;
-    if (sync && valid) ok = wait_flag(sync + 1 + row / K);
-    if (!__all(ok)) {  // wave-uniform: never run half a tile
-      if (lane == 0) sync[B + 1] = 1;
-      return;
-    }
     lnz_gains::gains_mlp_tile(Dg, row, valid, l, lane, Bg, K, dist, S, mlp_pack, G);
   }
 }
@@ -1120,38 +1087,6 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
                      n_nodes, D, V, info, ident);
   return lnz::check_launch("lnz_prepare_batch");
-}
-
-extern "C" int lnz_prepare_batch_gains(const float* L, int64_t stride_b, int64_t stride_r,
-                                       int64_t stride_c, int64_t stride_ch, int B, int N, int C,
-                                       float* Lp, const uint8_t* mask, const int32_t* n_nodes,
-                                       int n_cu, int allow_pairs, int32_t* plan, int32_t* n_wg,
-                                       int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
-                                       float* V, int32_t* sync, const int32_t* dist_host, int S,
-                                       int num_layer, const float* mlp_pack, float* G,
-                                       uint32_t* ident, lnz_stream_t stream) {
-  LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && gain_rows && n_gain_rows && D && V &&
-                  sync && dist_host && mlp_pack && G && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS &&
-                  n_cu > 0 && K > 0 && num_layer > 0,
-              LNZ_EINVAL, "lnz_prepare_batch_gains: bad arguments (B=%d C=%d K=%d)", B, C, K);
-  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch_gains: N=%d > %d", N,
-              LNZ_TILE);
-  LNZ_REQUIRE(S >= 1 && S <= lnz_gains::SMAX, LNZ_ENOTSUP, "lnz_prepare_batch_gains: S=%d", S);
-  size_t lds = (size_t)N * N * C * sizeof(float);
-  LNZ_REQUIRE(lds <= (size_t)kPrepLds, LNZ_ENOTSUP,
-              "lnz_prepare_batch_gains: N*N*C*4 = %zu B exceeds the %d B staging tile", lds, kPrepLds);
-  lnz_gains::DistArr dist;
-  for (int i = 0; i < lnz_gains::SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
-  const int64_t tiles = ((int64_t)B * K + 31) / 32;
-  const int64_t n_cons = (tiles * num_layer + 3) / 4;  // consumer workgroups (4 waves each)
-  const int64_t grid = 2 * (int64_t)B + 1 + n_cons;
-  LNZ_REQUIRE(grid < (1ll << 31), LNZ_ENOTSUP, "lnz_prepare_batch_gains: batch too large");
-  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), 0,
-                     (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
-                     (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
-                     K, gain_rows, n_gain_rows, n_nodes, D, V, sync, dist, S, num_layer, mlp_pack,
-                     G, ident, (int)n_cons, D, gain_rows, n_gain_rows, B);
-  return lnz::check_launch("lnz_prepare_batch_gains");
 }
 
 extern "C" int lnz_prepare_batch_prev_gains(
@@ -1181,8 +1116,8 @@ extern "C" int lnz_prepare_batch_prev_gains(
   hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), 0,
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
-                     K, gain_rows, n_gain_rows, n_nodes, D, V, (int32_t*)nullptr, dist, S, num_layer,
-                     mlp_pack, G_prev, ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev);
+                     K, gain_rows, n_gain_rows, n_nodes, D, V, dist, S, num_layer, mlp_pack, G_prev,
+                     ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev);
   return lnz::check_launch("lnz_prepare_batch_prev_gains");
 }
 

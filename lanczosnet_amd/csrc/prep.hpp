@@ -80,8 +80,7 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
                                                 int32_t* __restrict__ plan,
                                                 int32_t* __restrict__ n_wg, int K,
                                                 int32_t* __restrict__ gain_rows,
-                                                int32_t* __restrict__ n_gain_rows,
-                                                int32_t* __restrict__ plan_flag = nullptr) {
+                                                int32_t* __restrict__ n_gain_rows) {
   __shared__ int cnt[LNZ_TILE + 2];
   __shared__ int cls[4];  // molecules with extent <= 8, <= 16, <= 24, <= 32 (cumulative)
   __shared__ int wcnt[16][LNZ_TILE + 2];
@@ -183,11 +182,6 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
       e[0] = b;
       e[2] = split;
     }
-  }
-  if (plan_flag) {  // publish to the consumers of the fused preparation launch
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(plan_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -212,21 +212,15 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
   return Lp, (buf, cap), (rows, n_rows)
 
 
-def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
+def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
   """lnz_prepare_batch: Laplacian pack, batch plan and the Ritz pairs of L[..., 0] in one launch
-  (exact-fp32 plans, N <= 32).  Returns (Lp, tiles, rows, D, V).
-  gains=(dist, num_layer, mlp_pack): lnz_prepare_batch_gains — the spectral gains of the MLP filter
-  are computed in the same launch, in the shadow of the Lanczos wavefronts; returns
-  (Lp, tiles, rows, D, V, G, sync) where sync[-1] != 0 would flag a consumer timeout."""
+  (exact-fp32 plans, N <= 32).  Returns (Lp, tiles, rows, D, V)."""
   Lf = L if L.dtype == torch.float32 else L.float()
   B, N, _, Cn = Lf.shape
   if plan.get('Wp16') is not None or N > 32 or N * N * Cn * 4 > 40 * 1024:
     Lp, tiles, rows = pack_and_plan(plan, Lf, mask_u8, K, n_cu)
     D, V = lanczos_ritz(Lf[:, :, :, 0], n_nodes, K)
-    if gains is None:
-      return Lp, tiles, rows, D, V
-    G = spectral_gains(D, gains[0], gains[1], gains[2], rows=rows)
-    return Lp, tiles, rows, D, V, G, None
+    return Lp, tiles, rows, D, V
   _need_cuda(Lf, mask_u8, n_nodes)
   lib = _lib.load()
   n_cu = n_cu or _n_cu(Lf.device)
@@ -240,33 +234,12 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, gains=None):
   V = torch.empty((B, N, K), dtype=torch.float32, device=dev)
   nn = n_nodes.to(torch.int32).contiguous()
   sb, sr, sc, sch = Lf.stride()
-  common = (_ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
-            int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
-            _ptr(D), _ptr(V))
-  if gains is not None and gains[2] is not None and N * N * Cn * 4 > 20480:
-    # the one-launch variant stages the pack tile in a 20 KB static LDS block
-    Lp, tiles, rows, D, V = prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu)
-    G = spectral_gains(D, gains[0], gains[1], gains[2], rows=rows,
-                       zero_fill=not pairing_supported(plan))
-    return Lp, tiles, rows, D, V, G, None
-  if gains is None or gains[2] is None:
-    with torch.cuda.device(dev):
-      _lib.check(lib.lnz_prepare_batch(*common, C.c_void_p(0), _ptr(Lp.ident), _stream()))
-    if gains is None:
-      return Lp, (buf, cap), (rows, n_rows), D, V
-    G = spectral_gains(D, gains[0], gains[1], None)  # plain-power filters: no MLP to overlap
-    return Lp, (buf, cap), (rows, n_rows), D, V, G, None
-  dist, num_layer, mlp_pack = gains
-  S = len(dist)
-  # + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
-  Gbuf = torch.empty((num_layer * B * S * K + 16,), dtype=torch.float32, device=dev)
-  G = Gbuf[:num_layer * B * S * K].view(num_layer, B, S, K)
-  sync = torch.zeros((B + 2,), dtype=torch.int32, device=dev)
-  darr = (C.c_int32 * S)(*[int(x) for x in dist])
   with torch.cuda.device(dev):
-    _lib.check(lib.lnz_prepare_batch_gains(*common, _ptr(sync), darr, S, num_layer, _ptr(mlp_pack),
-                                           _ptr(G), _ptr(Lp.ident), _stream()))
-  return Lp, (buf, cap), (rows, n_rows), D, V, G, sync
+    _lib.check(lib.lnz_prepare_batch(
+        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
+        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
+        _ptr(D), _ptr(V), C.c_void_p(0), _ptr(Lp.ident), _stream()))
+  return Lp, (buf, cap), (rows, n_rows), D, V
 
 
 def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=None):

@@ -789,38 +789,6 @@ def test_prepare_batch_is_the_three_launches_in_one(B):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B', [1, 33, 1024, 3000, 8192])
-def test_prepare_batch_gains_overlapped_launch_matches_the_separate_kernels(B):
-  """lnz_prepare_batch_gains (plan + Lanczos/QL + pack + gains consumers in one launch): every
-  output bit-identical to the separate launches on the live eigen slots, no consumer timeout,
-  and identical scores."""
-  from lanczosnet_amd import ops
-  cfg = dict(oracle.DEFAULT_QM8_CFG)
-  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 5))
-  plan = net._plan()
-  batch = draw_batch(B, seed=B + 1, n_min=1, n_max=26)
-  n = _t(batch['n_nodes'])
-  L = ops.laplacian_l4(_t(batch['adjs']), n)
-  mask = _t(batch['node_mask']).contiguous()
-  Lp1, tiles1, rows1, D1, V1 = ops.prepare_batch(plan, L, mask, n, 20)
-  G1 = ops.spectral_gains(D1, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
-                          rows=rows1)
-  for rep in range(3):
-    Lp2, tiles2, rows2, D2, V2, G2, sync = ops.prepare_batch(
-        plan, L, mask, n, 20,
-        gains=(cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack']))
-    assert int(sync[-1]) == 0 and int(sync[0]) == 1 and bool((sync[1:-1] == 1).all())
-    assert torch.equal(Lp1, Lp2) and torch.equal(D1, D2) and torch.equal(V1, V2)
-    live = torch.clamp(n, max=20).long()
-    sel = (torch.arange(20, device=DEV)[None, :] < live[:, None])[None, :, None, :].expand_as(G1)
-    assert torch.equal(G1[sel], G2[sel]), rep
-  nf = _t(batch['node_feat'])
-  s1 = ops.lanczosnet_forward(plan, nf, Lp1, V1, G1, mask, tiling=tiles1)
-  s2 = ops.lanczosnet_forward(plan, nf, Lp2, V2, G2, mask, tiling=tiles2)
-  assert torch.equal(s1, s2)
-
-
-@pytest.mark.gpu
 def test_identity_channel_shortcut_is_bit_identical_and_detects_exactly_the_empty_bond_types():
   """lnz_pack_laplacian_ident flags channel c of molecule b iff that bond type is absent (its L4 is
   diag(0/1)); the forward's out += Z shortcut gives the same bits as the Laplacian fragments."""
