@@ -234,8 +234,8 @@ int lnz_lanczosnet_messages(const lnz_forward_args* args, lnz_stream_t stream);
 /* Tile plan for lnz_forward_args.plan.  The forward kernels work on 32-row node tiles; with
  * allow_pairs small molecules (extent of mask [B,N] u8) share a tile: one of <= 8 nodes with one
  * of 17..24 (split row 8), two of <= 16 (split row 16).  The tiles are dealt over W workgroups —
- * W = n_cu (one per compute unit) while all tiles fit in one round of <= 4 per workgroup, else
- * ceil(tiles/4) — in descending cost order, boustrophedon, so every workgroup of the launch gets
+ * W = R * n_cu with R = ceil(tiles / (4 n_cu)) rounds (one workgroup per compute unit and round;
+ * W = tiles when there are fewer than n_cu) — in descending cost order, boustrophedon, so every workgroup of the launch gets
  * floor/ceil(tiles/W) tiles of balanced cost.  Pair tiles rely on V[:, :, k] = 0 and D[:, k] = 0
  * for k >= n, which the reference's collate guarantees (dataset/qm8.py:264-291) and
  * lnz_lanczos_ritz produces.  No reference counterpart (the reference pads every molecule to N,

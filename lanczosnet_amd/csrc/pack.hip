@@ -264,7 +264,7 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
 
 extern "C" int lnz_plan_wg_cap(int B, int n_cu) {
   if (B <= 0 || n_cu <= 0) return 0;
-  return B <= 4 * n_cu ? (B < n_cu ? B : n_cu) : (B + 3) / 4;
+  return B < n_cu ? B : ((B + 4 * n_cu - 1) / (4 * n_cu)) * n_cu;
 }
 
 extern "C" int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,

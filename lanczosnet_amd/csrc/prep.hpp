@@ -121,7 +121,8 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
   const int P2 = allow_pairs ? pool / 2 : 0;                   // 16|16 pairs
   const int lone = pool - 2 * P2;                              // small singles (0/1, or all)
   const int T = B - X - P2;
-  const int W = T <= 4 * n_cu ? (T < n_cu ? T : n_cu) : (T + 3) / 4;
+  // rounds R = ceil(T / (4 CUs)); R workgroups per CU hold floor/ceil(T / W) <= 4 tiles each
+  const int W = T < n_cu ? T : ((T + 4 * n_cu - 1) / (4 * n_cu)) * n_cu;
   if (tid == 0) *n_wg = W;
   // ascending cost order: small singles, 17..24 singles, >= 25 singles, 16|16 pairs, 8|24 pairs
   const int o24 = lone, o32 = o24 + (c24 - X), oP2 = o32 + c32, oX = oP2 + P2;

@@ -579,7 +579,7 @@ def test_plan_tiles_covers_the_batch_once_and_balances(B, n_cu, pairs):
   x = min(c8, c24)
   want_pairs = (x + (c8 - x + c16) // 2) if pairs else 0
   assert int(paired.sum()) == want_pairs and T == B - want_pairs
-  assert W == (min(T, n_cu) if T <= 4 * n_cu else (T + 3) // 4)
+  assert W == (T if T < n_cu else -(-T // (4 * n_cu)) * n_cu)
 
 
 @pytest.mark.gpu
