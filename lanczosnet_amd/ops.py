@@ -217,7 +217,12 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
   (exact-fp32 plans, N <= 32).  Returns (Lp, tiles, rows, D, V)."""
   Lf = L if L.dtype == torch.float32 else L.float()
   B, N, _, Cn = Lf.shape
-  if plan.get('Wp16') is not None or N > 32 or N * N * Cn * 4 > 40 * 1024:
+  # The single launch pays when the Ritz wavefronts are latency bound (about one per SIMD); with
+  # several waves per SIMD they are throughput bound and the 64-thread standalone kernel, which
+  # does not carry three idle waves and a pack tile per workgroup, is faster (B = 8192: 0.55 vs
+  # 0.80 ms).
+  if plan.get('Wp16') is not None or N > 32 or N * N * Cn * 4 > 40 * 1024 or \
+      B > 8 * (n_cu or _n_cu(Lf.device)):
     Lp, tiles, rows = pack_and_plan(plan, Lf, mask_u8, K, n_cu)
     D, V = lanczos_ritz(Lf[:, :, :, 0], n_nodes, K)
     return Lp, tiles, rows, D, V
