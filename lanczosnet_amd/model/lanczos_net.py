@@ -305,18 +305,28 @@ class _LanczosNetBase(nn.Module):
                     z = torch.bmm(Lc[:, 0].float(), z)
                 out += z
                 c += 1
-            for s_ in range(S):
-                z = torch.matmul(state, Wc[:, c].t())                # X W_s^T      [B,N,dout]
-                y = torch.bmm(Vt, z)                                  # V^T z        [B,K,dout]
-                out += torch.bmm(Vf, G[t, :, s_, :].unsqueeze(2) * y)
-                c += 1
-            for e in range(self.num_edgetype + 1):
-                z = torch.matmul(state, Wc[:, c].t())
+            if S > 0:
+                # sum_s V diag(g_s) V^T X W_s^T = V [ sum_s (g_s * (V^T X)) W_s^T ]: project X to the
+                # K eigen directions ONCE, mix the S channels there (K rows instead of N), lift
+                # back once — 13x fewer FLOPs than S full-size GEMM chains at N = 2048, K = 64
+                Y = torch.bmm(Vt, state)                              # V^T X        [B,K,d_in]
+                Gt = G[t].transpose(1, 2)                             # [B,K,S]
+                Ys = (Gt.unsqueeze(3) * Y.unsqueeze(2)).reshape(B, Y.shape[1], S * d_in)
+                Wl = Wc[:, c:c + S].reshape(W.shape[0], S * d_in)     # [dout, S*d_in]
+                out += torch.bmm(Vf, torch.matmul(Ys, Wl.t()))        # V T          [B,N,dout]
+                c += S
+            E1 = self.num_edgetype + 1
+            dout = W.shape[0]
+            # X W_e^T for all edge types in one GEMM, then one N x N batched GEMM per type
+            Z = torch.matmul(state, Wc[:, c:c + E1].permute(1, 0, 2).reshape(E1 * dout, d_in).t())
+            Z = Z.view(B, N, E1, dout)
+            for e in range(E1):
+                z = Z[:, :, e]
                 if gemm_dtype is not None:
                     out += torch.bmm(Lc[:, e], z.to(gemm_dtype)).float()
                 else:
-                    out += torch.bmm(Lc[:, e], z)
-                c += 1
+                    out = torch.baddbmm(out, Lc[:, e], z)
+            c += E1
             state = torch.relu_(out)
         y = self.filter[-1](state) * self.att_func(state)
         m = (mask != 0).float().unsqueeze(2)
