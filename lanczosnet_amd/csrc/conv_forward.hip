@@ -29,11 +29,22 @@
 // HBM bytes per molecule: Lp 28,672 + V 2,560 + G 4,480 + ids 256 + mask 32 in, 64 out; the
 // 7.4 MB of packed weights are shared by all workgroups and stay L2 / Infinity-Cache resident.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
 constexpr int MOLS = 2;      // node tiles per workgroup half; every wave of the half works on both
 constexpr int PITCH = 132;   // LDS row pitch (floats): conflict-free ds_read_b128 A fragments
+// LDS-qualified pointer: keeps the A-fragment reads ds_read_b128 (a generic pointer that the
+// compiler cannot trace back to __shared__ becomes flat_load, which also ties up vmcnt)
+typedef const __attribute__((address_space(3))) float* lds_cptr;
+__device__ __forceinline__ float4 lds_f4(lds_cptr p) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) f4v* lds_c4ptr;
+  const f4v v = *(lds_c4ptr)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+constexpr int VPITCH = 36;   // Ritz-vector row pitch: 16 B aligned, conflict-free float4 rows
 constexpr int KHMAX = 16;    // eigen slots per lane half (K <= 32)
 
 __device__ inline f32x16 frag_from4(const float4 (&v)[4]) {
@@ -76,27 +87,15 @@ __device__ __forceinline__ int pick(const int (&v)[MT], int m) {
   return (MT > 1 && m) ? v[MT - 1] : v[0];
 }
 
-// Eigen slot contracted by lane half hh at step t of the L_s build, by tile type — a fixed map, so
-// that the summation order of a molecule's filter never depends on its tile partner:
-//   single : slot k = KH*hh + t of the molecule (KH = ceil(K/2))
-//   16|16  : half 0 -> A's k = t, half 1 -> B's k = t
-//   8|24   : half 0 -> A's k = t for t < 8, B's k = t + 8 (16..23) after; half 1 -> B's k = t
-// Returns k (or -1 for an unused step); *isA says whose slot it is.
-__device__ __forceinline__ int eigen_slot(int split, int KH, int K, int hh, int t, bool* isA) {
-  int k;
-  if (split == 32) {
-    *isA = true;
-    k = t < KH ? KH * hh + t : K;
-  } else if (split == 16) {
-    *isA = hh == 0;
-    k = t;
-  } else {
-    *isA = hh == 0 && t < 8;
-    k = (hh == 0 && t >= 8) ? t + 8 : t;
-  }
-  return k < K ? k : -1;
-}
-
+// Long-scale spectral channels run in EIGEN SPACE (FK = 0):
+//   sum_s V diag(g_s) V^T X W_s^T  =  V [ sum_s diag(g_s) (Y W_s^T) ],   Y = V^T X
+// so a layer projects once (Y, 16 MFMAs per tile and wave), runs GEMM1 of every long channel on Y,
+// scales the result rows (= eigen slots) by the channel's gains on the VALU, and lifts the sum back
+// through V once (<= 16 MFMAs) — instead of building L_s and running GEMM2 per channel.
+// Slot rows of a tile follow its node rows: row rho < split is eigen slot k = rho of molecule A,
+// row rho >= split is slot k = rho - split of molecule B (a molecule has <= min(n, K) live slots and
+// n <= its row extent), so V^T and V are block-diagonal exactly like the Laplacians and the
+// summation order of a molecule's terms never depends on its tile partner.
 // MODE 0 = forward; MODE 3 = forward that also stores every layer's activations (training);
 // MODE 1 = input-gradient pass (lnz_lanczosnet_input_grad): the same two chained GEMMs run on dY
 //          with per-channel transposed weights, kernel layer t = conv layer num_layer-1-t, the
@@ -106,15 +105,17 @@ __device__ __forceinline__ int eigen_slot(int split, int KH, int K, int hh, int 
 template <int NWV, int KHT, int FK, int MT, int MODE>
 __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                                              float (*Xs)[2][32][PITCH],  // [2 buffers][tile][..]
-                                             float4 (*Vs)[4][64],        // [tile][t/4][lane]
+                                             float (*Vm)[32][VPITCH],      // [tile][node row][slot row]
                                              float* Gs,  // [2 buffers][tile][n_long][2 halves][16]
                                              const int htid, const int wave) {
   constexpr bool FWD = MODE == 0 || MODE == 3;
+  constexpr bool ES = FK == 0;  // long channels in eigen space
   const int lane = htid & 63;
   const int j = lane & 31, hh = lane >> 5;
   const int N = a.N, K = a.K, B = a.B;
   const int dhid = a.dhid;
   const int C = a.n_short + a.n_long + a.n_edge;
+  const bool es = ES && a.n_long > 0;
 
   // per-lane view of each tile: molecule and local node of tile row j
   int molj[MT], jl[MT];
@@ -159,11 +160,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   //      rows of V): GEMM2 k-steps 4g..4g+3 only touch node rows 8g..8g+7, so bit g of g2mask says
   //      whether that group of steps is needed (wave-uniform per tile): molecule A needs groups
   //      g < ceil(nA/8), molecule B groups split/8 <= g < split/8 + ceil(nB/8).
-  //      H = steps of the L_s build (eigen_slot() above): a single tile keeps all K slots; a
-  //      pair tile drops the steps whose slots are k >= n for both molecules — those slots are
-  //      zero (dataset/qm8.py:264-291), so dropping them changes no bit.
-  const int KH = (K + 1) >> 1;
-  int g2mask[MT], H[MT], nA[MT], nB[MT];
+  //      smask is the same for the eigen-slot rows (lift-back k-steps): A has min(nA, K) live
+  //      slots from row 0, B min(nB, K) from row split (slots k >= n are zero, dataset/qm8.py:264-291).
+  int g2mask[MT], smask[MT], nA[MT], nB[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const bool pr = td[m].tb >= 0;
@@ -183,9 +182,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     nA[m] = la;
     nB[m] = lb;
     g2mask[m] = ((1 << ((la + 7) >> 3)) - 1) | (((1 << ((lb + 7) >> 3)) - 1) << g0);
-    const int k16 = K < 16 ? K : 16;
-    const int nmax = la > lb ? la : lb;
-    H[m] = td[m].split == 32 ? KH : (td[m].split == 16 && nmax < k16 ? nmax : k16);
+    const int sa = la < K ? la : K, sb = lb < K ? lb : K;
+    smask[m] = ((1 << ((sa + 7) >> 3)) - 1) | (((1 << ((sb + 7) >> 3)) - 1) << g0);
   }
 
   // ---- edge-type channels that are identities on every molecule of a tile (a bond type the
@@ -199,30 +197,23 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   }
 
   // ---- basis fragments.
-  //      FK = 0: Ritz vectors staged in LDS in L_s-build fragment order, Vs[m][t/4][lane][t%4]:
-  //        lane half hh, step t contracts eigen_slot(): a lane holds V[mol][local row][k] if its
-  //        row is in the row block of the molecule owning that slot, zero otherwise
-  //        (block-diagonal L_s).
+  //      FK = 0: Ritz vectors staged in LDS as the tile's [node row][slot row] matrix (zero off
+  //        the diagonal blocks), Vm[m][j][rho].  The lift-back reads row j as A operand (float4s
+  //        of slots cd_row(r..r+3, hh): the order in which the C/D registers of the slot-row sum
+  //        chain as B operand), the projection reads column rho as A operand of V^T.
   //      FK = 1: vreg[m][r] = Q[mol m][j][cd_row(r,hh)] — the k-order that lets the same registers
   //        serve as B operand of R = DD Q^T and as A operand of L_s = Q R.
   float vreg[MT][FK ? KHT : 1];
   if (FK == 0) {
-    for (int idx = htid; idx < MT * 4 * 64; idx += 64 * NWV) {
-      const int m = idx >> 8, t4 = (idx >> 6) & 3, ln = idx & 63;
-      const int jj = ln & 31, h = ln >> 5;
+    for (int idx = htid; idx < MT * 32 * 32; idx += 64 * NWV) {
+      const int m = idx >> 10, jj = (idx >> 5) & 31, rho = idx & 31;
       const TileDesc t = pick(td, m);
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bool isA;
-        const int k = eigen_slot(t.split, KH, K, h, 4 * t4 + u, &isA);
-        const bool first = jj < t.split;
-        const int row = first ? jj : jj - t.split;
-        const bool ok = k >= 0 && first == isA && row < N;
-        const int mol = isA ? t.ta : t.tb;
-        v[u] = ok ? a.V[((int64_t)mol * N + row) * K + k] : 0.0f;
-      }
-      Vs[m][t4][ln] = make_float4(v[0], v[1], v[2], v[3]);
+      const bool first = jj < t.split, sfirst = rho < t.split;
+      const int row = first ? jj : jj - t.split;
+      const int k = sfirst ? rho : rho - t.split;
+      const int mol = first ? t.ta : t.tb;
+      const bool ok = sfirst == first && k < K && row < N && mol >= 0;
+      Vm[m][jj][rho] = ok ? a.V[((int64_t)mol * N + row) * K + k] : 0.0f;
     }
   } else {
 #pragma unroll
@@ -234,8 +225,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       }
     }
   }
-  // ---- spectral gains of one layer, staged in LDS in the same slot order: Gs[buf][m][s][hh][t] =
-  //      g_s[k] of eigen_slot(hh, t) of the molecule owning that slot (zero for unused slots).  Layer l
+  // ---- spectral gains of one layer, staged in LDS by slot row: Gs[buf][m][s][rho] = g_s[k] of
+  //      slot row rho of the molecule owning it (zero for unused slots).  Layer l
   //      uses buffer l & 1; layer l+1 is staged at the start of layer l (its buffer was last read
   //      in layer l-1, which every wave left through the barrier).
   auto stage_gains = [&](int l) {
@@ -244,13 +235,13 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     for (int idx = htid; idx < MT * a.n_long * 32; idx += 64 * NWV) {
       const int m = idx / (a.n_long * 32);
       const int rem = idx - m * a.n_long * 32;
-      const int sc = rem >> 5, h = (rem >> 4) & 1, tt = rem & 15;
+      const int sc = rem >> 5, rho = rem & 31;
       const TileDesc t = pick(td, m);
-      bool isA;
-      const int k = eigen_slot(t.split, KH, K, h, tt, &isA);
+      const bool isA = rho < t.split;
+      const int k = isA ? rho : rho - t.split;
       // slots k >= n belong to zero-padded eigen columns: their gains are never computed by
       // lnz_spectral_gains_rows and never read here (G may be uninitialised there)
-      const bool ok = k >= 0 && k < (isA ? pick(nA, m) : pick(nB, m));
+      const bool ok = k < K && k < (isA ? pick(nA, m) : pick(nB, m));
       const int mol = isA ? t.ta : t.tb;
       dst[idx] = ok ? a.G[(((int64_t)l * B + mol) * a.n_long + sc) * K + k] : 0.0f;
     }
@@ -259,11 +250,13 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   __syncthreads();
 
 #ifdef LNZ_PROFILE_PHASES
-  long long t_g1 = 0, t_g2 = 0, t_ep = 0, t_all = clock64();
+  long long t_g1 = 0, t_g2 = 0, t_ep = 0, t_pr = 0, t_mb = 0, t_all = clock64();
 #define LNZ_T0 long long _t0 = clock64();
+#define LNZ_TR _t0 = clock64();
 #define LNZ_ACC(x) { long long _t1 = clock64(); x += _t1 - _t0; _t0 = _t1; }
 #else
 #define LNZ_T0
+#define LNZ_TR
 #define LNZ_ACC(x)
 #endif
   int cur = 0;
@@ -276,7 +269,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
     if (FWD && l + 1 < a.num_layer) stage_gains(l + 1);
     if (MODE == 1 && la > 0) stage_gains(la - 1);
-    const float* gsl = Gs + (la & 1) * MT * a.n_long * 32 + 16 * hh;
+    const float* gsl = Gs + (la & 1) * MT * a.n_long * 32;
     // width this iteration produces: waves beyond it only keep the barrier
     const int wout = FWD ? dhid : MODE == 1 ? (la == 0 ? a.bwd_din0 : dhid)
                                                   : (la == 0 ? a.din0 : dhid);
@@ -291,13 +284,18 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 
     // B-operand stream of this wave's feature tile: contiguous over g = c*Q + q for the whole
     // layer, read through a 4-slot register ring with prefetch distance 3 steps.  One running
-    // pointer + immediate offsets; over-reads 3 steps past the layer (host keeps 3 KiB slack).
+    // pointer + immediate offsets; over-reads up to 7 steps past the layer (host keeps 8 KiB slack).
     const int Gtot = C * Q;
     const float4* __restrict__ wp = Wl + (int64_t)wave * Gtot * 64 + lane;
-    float4 ring[4];
+    // Layers whose channels have a multiple of 8 k-steps use all 8 ring slots (prefetch distance
+    // 7 steps: with one tile a step is only 4 MFMAs, and three steps do not cover an L2 miss);
+    // the narrow first layer keeps the 4-slot rotation.
+    float4 ring[8];
+    const bool deep = MODE == 0 && (Q & 7) == 0;  // the other modes have no registers to spare
     if (MODE != 2 && active) {
 #pragma unroll
-      for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
+      for (int sl = 0; sl < 7; ++sl)
+        if (sl < 3 || deep) ring[sl] = wp[sl * 64];
     }
     // MODE 2: this wave's 32 columns of X_l in C/D order — Z of every channel
     f32x16 Xblk[MODE == 2 ? MT : 1];
@@ -318,9 +316,52 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       }
     }
 
-    const float* xrow[MT];
+    lds_cptr xrow[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) xrow[m] = &Xs[cur][m][j][4 * hh];
+    for (int m = 0; m < MT; ++m) xrow[m] = (lds_cptr)&Xs[cur][m][j][4 * hh];
+
+    // ---------------- eigen-space projection Y = V^T X (long channels, FK = 0) ----------------
+    //   A operand: V^T fragments, lane (slot row j, hh) step r = Vm[node row cd_row(r,hh)][slot j];
+    //   B operand: X rows in the same order.  Forward modes put
+    //   Y where the layer's output will go (the other X buffer is free until the epilogue) so the
+    //   long channels' GEMM1 reads it as A operand; MODE 2 keeps this wave's block in registers.
+    const int nxt = cur ^ 1;
+    LNZ_T0
+    f32x16 Yblk[(ES && MODE == 2) ? MT : 1];
+    if (es) {
+      if (32 * wave < din || MODE == 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (MODE == 2 && !active) continue;
+          float vt[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vt[r] = Vm[m][lnz::cd_row(r, hh)][j];
+          f32x16 Y = lnz::splat16(0.0f);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if ((g2mask[m] >> g) & 1) {
+#pragma unroll
+              for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                const float xb = MODE == 2 ? Xblk[MODE == 2 ? m : 0][r]
+                                           : Xs[cur][m][lnz::cd_row(r, hh)][32 * wave + j];
+                Y = lnz::mfma32(vt[r], xb, Y);
+              }
+            }
+          }
+          if (MODE == 2) {
+            Yblk[(ES && MODE == 2) ? m : 0] = Y;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Xs[nxt][m][lnz::cd_row(r, hh)][32 * wave + j] = Y[r];
+          }
+        }
+      }
+      if (MODE != 2) __syncthreads();
+    }
+    LNZ_ACC(t_pr)
+    lds_cptr yrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) yrow[m] = (lds_cptr)&Xs[nxt][m][j][4 * hh];
 
     // Operands of GEMM2 (per tile, 16 registers: the spectral gains of this lane half's eigen
     // slots for a long channel OR the four float4 Laplacian fragments of an edge/short channel)
@@ -331,18 +372,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     auto fetch_m_operands = [&](int c, int m) {
       const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
       if (lng) {
-        if (FK == 0) {
-          const float4* gp =
-              reinterpret_cast<const float4*>(gsl + (m * a.n_long + (c - a.n_short)) * 32);
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) {
-            const float4 v = gp[t4];
-            mop[m][4 * t4 + 0] = v.x;
-            mop[m][4 * t4 + 1] = v.y;
-            mop[m][4 * t4 + 2] = v.z;
-            mop[m][4 * t4 + 3] = v.w;
-          }
-        } else {
+        if (FK != 0) {
           // row j of the symmetric K x K filter DD_s, columns in cd_row order
           const float* dp =
               a.G + ((((int64_t)l * B + td[m].ta) * a.n_long + (c - a.n_short)) * K + j) * K;
@@ -351,7 +381,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             int k2 = lnz::cd_row(t, hh);
             mop[m][t] = (j < K && k2 < K) ? dp[k2] : 0.0f;
           }
-        }
+        }  // FK = 0: the eigen-space block below reads its gains from LDS itself
       } else if (c >= a.n_short && ((idm[m] >> (c - a.n_short - a.n_long)) & 1)) {
         // identity channel: nothing to fetch
       } else {
@@ -359,16 +389,17 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         // fragment group g of lane (j,hh) = M[j][8g + 4hh + 0..3].  Rows of molecule A take its
         // own groups 0..split/8-1; rows of molecule B take B's groups 0.. as tile groups
         // split/8..3 (its columns sit behind A's); the off-diagonal blocks are zero.
-        const float4* lp = reinterpret_cast<const float4*>(a.Lp) +
-                           ((int64_t)molj[m] * a.n_edge + e) * 256 + 32 * hh + jl[m];
         const int g0 = td[m].split >> 3;
-        const int goff = j < td[m].split ? 0 : g0;
-        const int gcnt = j < td[m].split ? g0 : 4 - g0;
+        const bool rowA = j < td[m].split;
+        // per-lane base shifted by the row block's first group: group g sits at lpl[g * 64]
+        // (constant offsets, nothing per-group to keep in registers)
+        const float4* lpl = reinterpret_cast<const float4*>(a.Lp) +
+                            ((int64_t)molj[m] * a.n_edge + e) * 256 + 32 * hh + jl[m] -
+                            (rowA ? 0 : g0 * 64);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int gl = g - goff;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (gl >= 0 && gl < gcnt) v = lp[gl * 64];
+          if (rowA ? g < g0 : g >= g0) v = lpl[g * 64];
           mop[m][4 * g + 0] = v.x;
           mop[m][4 * g + 1] = v.y;
           mop[m][4 * g + 2] = v.z;
@@ -376,59 +407,178 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         }
       }
     };
-    if (active) {
+    if (active && !es) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) fetch_m_operands(0, m);
     }
 
-    for (int c = 0; active && c < C; ++c) {
+    auto store_message = [&](int c, int m, const f32x16& P) {
+      const int64_t ld = (int64_t)C * wout;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if ((g2mask[m] >> g) & 1) {  // rows of groups no molecule owns are never written
+          const bool first = 8 * g < td[m].split;
+          const int mol = first ? td[m].ta : td[m].tb;
+          const int lrow0 = 8 * g + 4 * hh - (first ? 0 : td[m].split);
+          // row_off: compact row numbering (real nodes only); else 32 rows per molecule
+          const int64_t r0 = a.row_off ? (int64_t)a.row_off[mol] + lrow0 : (int64_t)mol * 32 + lrow0;
+          const int nmol = a.row_off ? (first ? nA[m] : nB[m]) : 32;
+          float* p = a.msg + r0 * ld + (int64_t)c * wout + 32 * wave + j;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (lrow0 + u < nmol) p[u * ld] = P[4 * g + u];
+        }
+      }
+    };
+
+    // GEMM1 of one channel into Z: Z_m (+)= [diag(g)] A_m W_c^T, A rows from `rows` (X or Y).
+    // SC: scale this lane's A-operand row by gl[m] (eigen-space long channels).
+    f32x16 Z[MT];
+    float gl[MT];
+    auto gemm1_rd = [&](auto scaled, auto depth, const lds_cptr (&rows)[MT]) {
+      constexpr bool SC = decltype(scaled)::value;
+      constexpr int RD = decltype(depth)::value;  // ring slots = steps per unrolled body
+      lds_cptr xq[MT];
+      float4 acur[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        xq[m] = rows[m];
+        acur[m] = lds_f4(xq[m]);
+      }
+#pragma unroll 1
+      for (int q0 = 0; q0 < Q; q0 += RD) {
+#pragma unroll
+        for (int u4 = 0; u4 < RD; ++u4) {
+#ifndef LNZ_EXP_NO_WLOAD
+          ring[(u4 + RD - 1) & (RD - 1)] = wp[(u4 + RD - 1) * 64];
+#endif
+          // next A fragments (the read one step past the channel's last is in-bounds, unused)
+          float4 anext[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            anext[m] = lds_f4(xq[m] + 8 * (u4 + 1));
+          // keep the prefetches ahead of this step's MFMAs (hipcc otherwise sinks all loads of
+          // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
+          __builtin_amdgcn_sched_barrier(0);
+          const float4 bv = ring[u4];
+          if (SC) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acur[m].x *= gl[m];
+              acur[m].y *= gl[m];
+              acur[m].z *= gl[m];
+              acur[m].w *= gl[m];
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acur[m] = anext[m];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xq[m] += 8 * RD;
+        wp += RD * 64;
+      }
+    };
+    auto gemm1 = [&](auto scaled, const lds_cptr (&rows)[MT]) {
+      if (deep) gemm1_rd(scaled, std::integral_constant<int, 8>{}, rows);
+      else gemm1_rd(scaled, std::integral_constant<int, 4>{}, rows);
+    };
+
+    // ---------------- eigen-space block: all long channels of the layer ----------------
+    //   runs BEFORE the node-space channels (its own loop nest keeps the register allocation of
+    //   both parts tight); with short channels present the weight stream is re-entered at the
+    //   long block, rewound for the short channels and skipped over afterwards.
+    const int c_end = a.n_short + a.n_long;           // first edge channel
+    const int c_first = a.n_short > 0 ? 0 : c_end;    // first node-space channel
+    auto prime_ring = [&](int step0) {
+      wp = Wl + ((int64_t)wave * Gtot + step0) * 64 + lane;
+#pragma unroll
+      for (int sl = 0; sl < 7; ++sl)
+        if (sl < 3 || deep) ring[sl] = wp[sl * 64];
+    };
+    if (es && active) {
+      LNZ_T0
+      if (MODE != 2 && a.n_short > 0) prime_ring(a.n_short * Q);
+        const float* gp = gsl + j;
+        if (MODE != 2) {
+          // Z_m = sum_s diag(g_s) Y_m W_s^T: the A-operand rows (slots) carry the gains, one
+          // accumulator runs over the channels; then out_m += V_m Z_m and the Y buffer is released
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
+          for (int s = 0; s < a.n_long; ++s) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) gl[m] = gp[(m * a.n_long + s) * 32];
+            gemm1(std::true_type{}, yrow);
+          }
+          LNZ_ACC(t_g1)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            if (c_first < C) fetch_m_operands(c_first, m);
+            const float* vs = &Vm[m][j][4 * hh];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+              if ((smask[m] >> t4) & 1) {
+                const float4 v = *reinterpret_cast<const float4*>(vs + 8 * t4);
+                out[m] = lnz::mfma32(v.x, Z[m][4 * t4 + 0], out[m]);
+                out[m] = lnz::mfma32(v.y, Z[m][4 * t4 + 1], out[m]);
+                out[m] = lnz::mfma32(v.z, Z[m][4 * t4 + 2], out[m]);
+                out[m] = lnz::mfma32(v.w, Z[m][4 * t4 + 3], out[m]);
+              }
+            }
+          }
+          // every wave is done reading Y before the epilogue overwrites it
+          __syncthreads();
+          LNZ_ACC(t_mb)
+        } else {
+          // messages g_s * Y lifted back through V, one per channel
+          for (int s = 0; s < a.n_long; ++s) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float* g4 = gsl + (m * a.n_long + s) * 32 + 4 * hh;
+              const float* vs = &Vm[m][j][4 * hh];
+              f32x16 P = lnz::splat16(0.0f);
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) {
+                if ((smask[m] >> t4) & 1) {
+                  const float4 v = *reinterpret_cast<const float4*>(vs + 8 * t4);
+                  const float4 g = *reinterpret_cast<const float4*>(g4 + 8 * t4);
+                  const f32x16& Y = Yblk[(ES && MODE == 2) ? m : 0];
+                  P = lnz::mfma32(v.x, g.x * Y[4 * t4 + 0], P);
+                  P = lnz::mfma32(v.y, g.y * Y[4 * t4 + 1], P);
+                  P = lnz::mfma32(v.z, g.z * Y[4 * t4 + 2], P);
+                  P = lnz::mfma32(v.w, g.w * Y[4 * t4 + 3], P);
+                }
+              }
+              store_message(a.n_short + s, m, P);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (c_first < C) fetch_m_operands(c_first, m);
+        }
+      if (MODE != 2 && a.n_short > 0) prime_ring(0);
+    }
+    for (int c = es ? c_first : 0; active && c < C; ++c) {
+      if (es && c == a.n_short && c < c_end) {  // past the short channels: skip the long block
+        c = c_end;
+        if (MODE != 2) prime_ring(c_end * Q);
+        if (c >= C) break;
+      }
       const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
 
       LNZ_T0
       // ---------------- GEMM1: Z_m = X_m W_c^T ----------------
-      f32x16 Z[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) Z[m] = MODE == 2 ? Xblk[MODE == 2 ? m : 0] : lnz::splat16(0.0f);
-      if (MODE != 2) {
-        const float* xq[MT];
-        float4 acur[MT];
-  #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          xq[m] = xrow[m];
-          acur[m] = *reinterpret_cast<const float4*>(xq[m]);
-        }
-  #pragma unroll 1
-        for (int q0 = 0; q0 < Q; q0 += 4) {
-  #pragma unroll
-          for (int u4 = 0; u4 < 4; ++u4) {
-            ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
-            // next A fragments (the read one step past the channel's last is in-bounds, unused)
-            float4 anext[MT];
-  #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              anext[m] = *reinterpret_cast<const float4*>(xq[m] + 8 * (u4 + 1));
-            // keep the prefetches ahead of this step's MFMAs (hipcc otherwise sinks all loads of
-            // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 bv = ring[u4];
-  #pragma unroll
-            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
-  #pragma unroll
-            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
-  #pragma unroll
-            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
-  #pragma unroll
-            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
-  #pragma unroll
-            for (int m = 0; m < MT; ++m) acur[m] = anext[m];
-            __builtin_amdgcn_sched_barrier(0);
-          }
-  #pragma unroll
-          for (int m = 0; m < MT; ++m) xq[m] += 32;
-          wp += 4 * 64;
-        }
-
-      }
+      if (MODE != 2) gemm1(std::false_type{}, xrow);
 
       LNZ_ACC(t_g1)
       // ---------------- per tile: M_c fragments, next operands, GEMM2 ----------------
@@ -439,35 +589,22 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                          ((idm[m] >> (c - a.n_short - a.n_long)) & 1);
         f32x16 Mf;
         if (is_long) {
+          // FK = 1: R[k1][n] = sum_k2 DD[k1][k2] Q[n][k2], L_s[i][n] = sum_k1 Q[i][k1] R[k1][n]
           f32x16 acc = lnz::splat16(0.0f);
-          if (FK == 0) {
-            const float4* vs = &Vs[m][0][lane];
+          f32x16 R = lnz::splat16(0.0f);
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-              if (4 * t4 < H[m]) {
-                const float4 v = vs[t4 * 64];
-                acc = lnz::mfma32(v.x * mop[m][4 * t4 + 0], v.x, acc);
-                acc = lnz::mfma32(v.y * mop[m][4 * t4 + 1], v.y, acc);
-                if (4 * t4 + 2 < H[m]) {
-                  acc = lnz::mfma32(v.z * mop[m][4 * t4 + 2], v.z, acc);
-                  acc = lnz::mfma32(v.w * mop[m][4 * t4 + 3], v.w, acc);
-                }
-              }
-            }
-          } else {
-            // R[k1][n] = sum_k2 DD[k1][k2] Q[n][k2]  then  L_s[i][n] = sum_k1 Q[i][k1] R[k1][n]
-            f32x16 R = lnz::splat16(0.0f);
+          for (int t = 0; t < (FK ? KHT : 1); ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
 #pragma unroll
-            for (int t = 0; t < (FK ? KHT : 1); ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
-#pragma unroll
-            for (int t = 0; t < (FK ? KHT : 1); ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
-          }
+          for (int t = 0; t < (FK ? KHT : 1); ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
           Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]  (symmetric)
         } else if (!idc) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) Mf[r] = mop[m][r];
         }
-        if (c + 1 < C) fetch_m_operands(c + 1, m);
+        {
+          const int cn = (es && c + 1 == a.n_short) ? c_end : c + 1;
+          if (cn < C) fetch_m_operands(cn, m);
+        }
 
         // short diffusion: Z <- L_0^(p-1) Z
         if (c < a.n_short) {
@@ -503,24 +640,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             }
           }
         }
-        if (MODE == 2) {
-          const int64_t ld = (int64_t)C * wout;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if ((g2mask[m] >> g) & 1) {  // rows of groups no molecule owns are never written
-              const bool first = 8 * g < td[m].split;
-              const int mol = first ? td[m].ta : td[m].tb;
-              const int lrow0 = 8 * g + 4 * hh - (first ? 0 : td[m].split);
-              // row_off: compact row numbering (real nodes only); else 32 rows per molecule
-              const int64_t r0 = a.row_off ? (int64_t)a.row_off[mol] + lrow0 : (int64_t)mol * 32 + lrow0;
-              const int nmol = a.row_off ? (first ? nA[m] : nB[m]) : 32;
-              float* p = a.msg + r0 * ld + (int64_t)c * wout + 32 * wave + j;
-#pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (lrow0 + u < nmol) p[u * ld] = P[4 * g + u];
-            }
-          }
-        }
+        if (MODE == 2) store_message(c, m, P);
       }
       LNZ_ACC(t_g2)
     }
@@ -528,8 +648,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     // ---------------- epilogue: X' -> LDS (other buffer), one barrier per layer -------------
     //   MODE 0: ReLU (+ the activation store training asks for)
     //   MODE 1: dY_{la-1} = dX_la * [X_la > 0] -> LDS and dy[la-1]; the last iteration writes dX_0
-    LNZ_T0
-    const int nxt = cur ^ 1;
+    LNZ_TR
+    if (es && MODE != 2 && !active) __syncthreads();
     if (MODE != 2 && active) {
       const int col = 32 * wave + j;
 #pragma unroll
@@ -576,8 +696,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   }
 #ifdef LNZ_PROFILE_PHASES
   if (a.state_out && lane == 0 && blockIdx.x < 8) {
-    float* d = a.state_out + ((int64_t)B * 32 * dhid) + (blockIdx.x * 8 + (htid >> 6)) * 4;
+    float* d = a.state_out + ((int64_t)B * 32 * dhid) + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
     d[0] = (float)t_g1; d[1] = (float)t_g2; d[2] = (float)t_ep; d[3] = (float)(clock64() - t_all);
+    d[4] = (float)t_pr; d[5] = (float)t_mb; d[6] = (float)MT;
   }
 #endif
 
@@ -657,7 +778,7 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) float Xs[2][2][MOLS][32][PITCH];  // [half][buffer][tile]
   const int tid = threadIdx.x;
-  __shared__ float4 Vs[2][MOLS][4][64];  // FK = 0: Ritz-vector fragments
+  __shared__ __attribute__((aligned(16))) float Vm[2][MOLS][32][VPITCH];  // FK = 0: Ritz vectors
   extern __shared__ __attribute__((aligned(16))) float Gs_all[];  // FK = 0: [half][2][MOLS][n_long][32]
   float* Gs = Gs_all + (tid / (64 * NWV)) * 2 * MOLS * a.n_long * 32;
   const int W = a.plan ? *a.n_wg : (a.B + 3) / 4;
@@ -686,12 +807,14 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
     nt += td[m].ta >= 0 ? 1 : 0;  // slots fill from 0: a used slot 1 implies a used slot 0
   }
   if (nt == 2) {
-    forward_half<NWV, KHT, FK, 2, MODE>(a, td, Xs[half], Vs[half], Gs, htid, wave);
+    forward_half<NWV, KHT, FK, 2, MODE>(a, td, Xs[half], Vm[half], Gs, htid, wave);
   } else if (nt == 1) {
     const TileDesc t1[1] = {td[0]};
-    forward_half<NWV, KHT, FK, 1, MODE>(a, t1, Xs[half], Vs[half], Gs, htid, wave);
+    forward_half<NWV, KHT, FK, 1, MODE>(a, t1, Xs[half], Vm[half], Gs, htid, wave);
   } else {
-    const int nb = MODE == 2 ? 2 : a.num_layer + 1;  // keep the barrier count of the other half
+    // keep the barrier count of the other half (eigen-space layers have three barriers)
+    const int per = (FK == 0 && a.n_long > 0) ? 3 : 1;
+    const int nb = MODE == 2 ? 2 : per * a.num_layer + 1;
     for (int l = 0; l < nb; ++l) __syncthreads();
   }
 }

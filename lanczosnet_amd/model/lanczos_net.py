@@ -214,8 +214,8 @@ class _LanczosNetBase(nn.Module):
                     dout=P, filter_kind=self.filter_kind,
                     short=list(self.short_diffusion_dist), n_long=self.num_scale_long,
                     n_edge=self.num_edgetype + 1,
-                    # + slack: the kernel's weight prefetch ring over-reads 3 steps (3 KiB)
-                    Wp=torch.cat(packs + [torch.zeros(1024, dtype=torch.float32, device=dev)]),
+                    # + slack: the kernel's weight prefetch ring over-reads up to 7 steps (7 KiB)
+                    Wp=torch.cat(packs + [torch.zeros(2048, dtype=torch.float32, device=dev)]),
                     bias=torch.cat(biases).contiguous(),
                     w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
                     bias_head=bias_head,
@@ -376,7 +376,7 @@ class _LanczosNetBase(nn.Module):
             packs.append(pk)
             offs.append(off)
             off += pk.numel()
-        plan['Wp_t'] = torch.cat(packs + [torch.zeros(1024, dtype=torch.float32, device=dev)])
+        plan['Wp_t'] = torch.cat(packs + [torch.zeros(2048, dtype=torch.float32, device=dev)])
         plan['wt_off'] = offs
         return plan
 
