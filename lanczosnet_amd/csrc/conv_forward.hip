@@ -110,6 +110,11 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                                              const int htid, const int wave) {
   constexpr bool FWD = MODE == 0 || MODE == 3;
   constexpr bool ES = FK == 0;  // long channels in eigen space
+#ifdef LNZ_EXP_PRIO
+  // the two-tile half is the critical path of a 3-tile workgroup: let it issue first, the
+  // one-tile half fills the matrix-pipe slots it leaves
+  __builtin_amdgcn_s_setprio(MT == 2 ? 3 : 0);
+#endif
   const int lane = htid & 63;
   const int j = lane & 31, hh = lane >> 5;
   const int N = a.N, K = a.K, B = a.B;

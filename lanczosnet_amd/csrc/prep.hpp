@@ -70,7 +70,8 @@ __device__ __forceinline__ void pack_laplacian_body(
 // busiest CU: the plan therefore fixes the number of workgroups W (one per CU while the tiles fit
 // in a single round of <= 4 per workgroup) and deals the tiles, in descending cost order, over the
 // workgroups boustrophedon-wise — every workgroup gets floor or ceil of T / W tiles of balanced
-// total cost.  Slot s of workgroup g is plan[(4g + s) * 3 + {0,1,2}] = (molecule A, molecule B or
+// total cost (the r-th tile dealt to a workgroup sits in slot 0, 2, 1, 3: the halves fill
+// alternately).  Slot s of workgroup g is plan[(4g + s) * 3 + {0,1,2}] = (molecule A, molecule B or
 // -1, split row: rows < split belong to A; 32 for a single); an unused slot has A = -1.
 //
 // Stable counting sort on node extent in one workgroup; every molecule derives its slot from its
@@ -176,7 +177,10 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
     const int d = T - 1 - tau;  // position in descending cost order
     const int round = d / W, idx = d % W;
     const int wg = (round & 1) ? W - 1 - idx : idx;
-    int32_t* e = plan + ((int64_t)wg * 4 + round) * 3;
+    // rounds 0, 1, 2, 3 -> slots 0, 2, 1, 3: a workgroup's second tile goes to its other half
+    // (two halves with one tile each beat one half with two), the third joins the first
+    const int slot = round == 1 ? 2 : round == 2 ? 1 : round;
+    int32_t* e = plan + ((int64_t)wg * 4 + slot) * 3;
     if (role == 2) {
       e[1] = b;
     } else {
