@@ -133,18 +133,20 @@ def main():
   ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(6)] for k in range(args.steps)}
   mask_u8 = mask.to(torch.uint8).contiguous()
 
-  def step(events=None):
-    if events:
+  def step(events=None, all_stages=False):
+    # the timed loop brackets only the dominant kernel with HIP events (the roofline's live launch
+    # duration); the per-stage breakdown comes from a separate, untimed pass (all_stages) so that
+    # the event markers between the short launches do not sit in the measured region
+    if events and all_stages:
       events[0].record()
     Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
-    if events:
+    if events and all_stages:
       events[1].record()
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
                            rows=rows, zero_fill=not ops.pairing_supported(plan))
-    if events:
+    if events and all_stages:
       events[2].record()
     if events:
-      events[3].record()
       events[4].record()
     score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
     if events:
@@ -167,8 +169,8 @@ def main():
       nLp, ntiles, nrows, nD, nV, G = ops.prepare_batch_prev_gains(
           plan, L, mask_u8, n_nodes, K, prev=(D, rows), gains=gains_cfg)
       if ev_k:
-        for j in (1, 2, 3, 4):
-          ev_k[j].record()
+        ev_k[1].record()
+        ev_k[4].record()
       score = ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
       if ev_k:
         ev_k[5].record()
@@ -256,9 +258,21 @@ def main():
     net.gemm_mode = 'fp32'
     plan = plan_fp32
 
-  names = ['prepare_batch(plan+lanczos_ritz+pack)', 'spectral_gains', '-', '-', 'lanczosnet_forward']
-  stage_ms = {nm: float(np.mean([ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)]))
-              for k, nm in enumerate(names) if nm != '-'}
+  # forward launch duration: HIP events of the timed region; the other stages: an untimed pass
+  stage_ms = {}
+  if not args.pipeline:
+    ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(min(args.steps, 20))]
+    with torch.no_grad():
+      for e in ev2:
+        step(e, all_stages=True)
+    torch.cuda.synchronize()
+    stage_ms['prepare_batch(plan+lanczos_ritz+pack)'] = float(np.mean([e[0].elapsed_time(e[1]) for e in ev2]))
+    stage_ms['spectral_gains'] = float(np.mean([e[1].elapsed_time(e[2]) for e in ev2]))
+  else:
+    stage_ms['prepare_batch(k+1)+spectral_gains(k)'] = float(
+        np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(args.steps)]))
+  stage_ms['lanczosnet_forward'] = float(
+      np.mean([ev[i][4].elapsed_time(ev[i][5]) for i in range(args.steps)]))
 
   if rank == 0:
     ms_per_step = 1e3 * elapsed / args.steps
