@@ -62,6 +62,54 @@ def all_gather_scores(local_score, n_global, group=None):
     return torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], dim=0)
 
 
+class AsyncScoreGather:
+    """The per-step all-gather of shard scores for a STREAM of batches, kept off the critical path.
+
+    `submit(score_k)` issues the collective asynchronously (on RCCL's own stream, ordered after
+    the kernels that produced `score_k`) into one of `depth` result buffers and returns at once,
+    so the compute stream goes on to the next batch instead of waiting for a latency-bound 64 KiB
+    exchange — and a slow rank delays its peers only when it falls `depth` steps behind, not at
+    every step.  `result(ticket)` / `drain()` wait for the gathers.  Equal shards (the bench and
+    the runner's full batches); `all_gather_scores` handles a ragged tail batch."""
+
+    def __init__(self, shard_rows, width, device, dtype=torch.float32, depth=2, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bufs = [torch.empty((self.world * shard_rows, width), dtype=dtype, device=device)
+                     for _ in range(depth)]
+        self.work = [None] * depth
+        self.issued = 0
+
+    def submit(self, local_score):
+        i = self.issued % len(self.bufs)
+        if self.work[i] is not None:
+            self.work[i].wait()  # this buffer's previous gather (depth steps ago) has landed
+            self.work[i] = None
+        if self.world == 1:
+            self.bufs[i].copy_(local_score)
+        else:
+            self.work[i] = dist.all_gather_into_tensor(self.bufs[i], local_score.contiguous(),
+                                                       group=self.group, async_op=True)
+        self.issued += 1
+        return self.issued - 1
+
+    def result(self, ticket):
+        """Full [world * shard_rows, width] scores of submit() number `ticket` (one of the last
+        `depth` submissions)."""
+        assert self.issued - len(self.bufs) <= ticket < self.issued, 'result buffer already reused'
+        i = ticket % len(self.bufs)
+        if self.work[i] is not None:
+            self.work[i].wait()
+            self.work[i] = None
+        return self.bufs[i]
+
+    def drain(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+
+
 def global_mse(local_score, local_label, group=None):
     """Size-weighted global mean squared error == MSELoss over the unsharded batch
     (model/lanczos_net.py:66,197).  One all-reduce of two scalars."""

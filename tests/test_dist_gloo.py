@@ -90,6 +90,45 @@ def _grad_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _gather_worker(rank, world, port, out_dir):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    rows, width, steps = 5, 4, 7
+    g = lnz_dist.AsyncScoreGather(rows, width, 'cpu', depth=2)
+    ok = True
+    tickets = []
+    for k in range(steps):
+      local = torch.full((rows, width), float(100 * k + rank))
+      tickets.append(g.submit(local))
+      if k >= 1:  # the previous step's result is still held (depth 2)
+        prev = g.result(tickets[k - 1])
+        want = torch.cat([torch.full((rows, width), float(100 * (k - 1) + r)) for r in range(world)])
+        ok = ok and bool(torch.equal(prev, want))
+    g.drain()
+    last = g.result(tickets[-1])
+    want = torch.cat([torch.full((rows, width), float(100 * (steps - 1) + r)) for r in range(world)])
+    ok = ok and bool(torch.equal(last, want))
+    try:
+      g.result(tickets[0])  # long overwritten: must refuse
+      ok = False
+    except AssertionError:
+      pass
+    np.save(os.path.join(out_dir, 'a%d.npy' % rank), np.array([ok], dtype=np.int64))
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_async_score_gather_streams_batches(world, tmp_path):
+  """AsyncScoreGather (bench.py's per-step exchange): every submitted shard score arrives in
+  rank order in its own result buffer, `depth` steps stay readable, older tickets are refused."""
+  mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  for r in range(world):
+    assert np.load(os.path.join(str(tmp_path), 'a%d.npy' % r))[0] == 1
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_gradient_all_reduce_is_the_full_batch_gradient(world, tmp_path):
   """Shard-size-weighted flat-bucket all-reduce == gradient of the unsharded mean loss."""
