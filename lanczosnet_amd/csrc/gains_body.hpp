@@ -65,7 +65,8 @@ __device__ inline f32x16 relu_bias16(f32x16 v, f32x16 b) {
 template <int F0>
 __device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (&ring)[RING],
                                     const f32x16 (&Hin)[HT]) {
-  f32x16 acc = lnz::splat16(0.0f);
+  // two accumulator chains (even / odd k-steps): consecutive MFMAs never depend on each other
+  f32x16 acc = lnz::splat16(0.0f), acc1 = lnz::splat16(0.0f);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     constexpr int D = RING - 2;
@@ -74,11 +75,13 @@ __device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (
     const float4 a = ring[(F0 + q) % RING];
     const int ti = q >> 2, g = q & 3;
     acc = lnz::mfma32(a.x, Hin[ti][4 * g + 0], acc);
-    acc = lnz::mfma32(a.y, Hin[ti][4 * g + 1], acc);
+    acc1 = lnz::mfma32(a.y, Hin[ti][4 * g + 1], acc1);
     acc = lnz::mfma32(a.z, Hin[ti][4 * g + 2], acc);
-    acc = lnz::mfma32(a.w, Hin[ti][4 * g + 3], acc);
+    acc1 = lnz::mfma32(a.w, Hin[ti][4 * g + 3], acc1);
     __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
   return acc;
 }
 
