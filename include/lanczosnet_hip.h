@@ -219,6 +219,9 @@ typedef struct lnz_forward_args {
   const int64_t* row_off;     /* messages, optional [B]: first row of each molecule in a COMPACT msg
                                  (real nodes only: row_off = exclusive scan of the node counts, rows
                                  >= n are not written); NULL = row b*32 + node                     */
+  float* dgains;              /* gain_grad: [num_layer,B,K,n_long] dLoss/dG, ZERO-INITIALISED by the
+                                 caller (slots beyond a molecule's row block in a shared tile are
+                                 dead, k >= n, and are not written)                                */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
 /* Backward of the conv stack w.r.t. its node-state inputs, in the forward's own structure:
@@ -227,6 +230,12 @@ int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
  * per-channel TRANSPOSED mix Wb[i][c*dhid + o] = W_l[o][c*d_l + i] ([d_l, C*dhid]); din0 = dhid;
  * Lp, V, G, mask, plan as in the forward.  Writes dy[0..num_layer-2] and dx0. */
 int lnz_lanczosnet_input_grad(const lnz_forward_args* args, lnz_stream_t stream);
+/* Gradient w.r.t. the spectral gains (the input of the filter MLPs' backward,
+ * model/lanczos_net.py:95-123), in eigen space:
+ *   dG[l][b][k][s] = sum_o (V^T dY_l)[k][o] * ((V^T X_l) W_{l,s}^T)[k][o]
+ * Reads dy (all num_layer slots, as left by lnz_lanczosnet_input_grad), act / x0 (X_l), V, mask,
+ * plan and the FORWARD weight packs Wp / w_off (not the transposed ones); writes dgains. */
+int lnz_lanczosnet_gain_grad(const lnz_forward_args* args, lnz_stream_t stream);
 /* Messages of conv layer msg_layer, msg = cat_c(M_c X_l): with dY_l they give the weight gradient
  * of the reference's Linear(15 d -> 128) as ONE library GEMM, dW_l = dY_l^T msg
  * (model/lanczos_net.py:180-182).  Reads act (or x0 for layer 0), Lp, V, G, mask, plan. */

@@ -43,7 +43,7 @@ class ForwardArgs(C.Structure):
       ('gemm_mode', C.c_int32), ('Wp16', C.c_void_p), ('w16_off', C.c_int64 * 16),
       ('Wp16_head', C.c_void_p), ('Lp16', C.c_void_p), ('plan', C.c_void_p), ('n_wg', C.c_void_p), ('plan_wg_cap', C.c_int),
       ('act_out', C.c_void_p), ('act', C.c_void_p), ('dy', C.c_void_p), ('dx0', C.c_void_p),
-      ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p),
+      ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p), ('dgains', C.c_void_p),
   ]
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     'lnz_spectral_gains_rows': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_lanczosnet_input_grad': (C.c_int, [C.POINTER(ForwardArgs), _P]),
     'lnz_lanczosnet_messages': (C.c_int, [C.POINTER(ForwardArgs), _P]),
+    'lnz_lanczosnet_gain_grad': (C.c_int, [C.POINTER(ForwardArgs), _P]),
     'lnz_lanczosnet_forward': (C.c_int, [C.POINTER(ForwardArgs), _P]),
     'lnz_forward_args_size': (C.c_int64, []),
     'lnz_ada_graph_laplacian': (C.c_int, [_P, _P, _I, _P, _I, _P, _L, _L, _L, _I, _I, _P, _P]),

@@ -824,6 +824,235 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
   }
 }
 
+
+// -----------------------------------------------------------------------------------------
+// Gradient of the loss w.r.t. the spectral gains (training), in eigen space:
+//   out_l += V [ sum_s diag(g_s) (V^T X_l) W_s^T ]   =>   dG[l][b][k][s] = sum_o P[k][o] Q_s[k][o],
+//   P = V^T dY_l  (slot rows x dhid),   Q_s = (V^T X_l) W_s^T
+// One half = NWV wavefronts x MT node tiles, every conv layer in turn: X_l and dY_l are staged in
+// the two LDS tile buffers, projected (Y to LDS over X_l, P kept in C/D registers), then each long
+// channel's GEMM1 runs on Y with the FORWARD weight pack and its result is multiplied with P and
+// reduced over the wave's 32 output columns (lane shuffles) and over the NWV waves (LDS, fixed
+// order: deterministic).  No gains, Laplacians or activations other than X_l / dY_l are read.
+template <int NWV, int MT>
+__device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT],
+                                               float (*Xs)[2][32][PITCH], float (*Vm)[32][VPITCH],
+                                               const int htid, const int wave) {
+  const int lane = htid & 63;
+  const int j = lane & 31, hh = lane >> 5;
+  const int N = a.N, K = a.K, B = a.B, dhid = a.dhid, S = a.n_long;
+  const int C = a.n_short + a.n_long + a.n_edge;
+
+  int g2mask[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const bool pr = td[m].tb >= 0;
+    int la = 0, lb = 0;
+    for (int i = lane; i < N; i += 64) {
+      la = a.mask[(int64_t)td[m].ta * N + i] ? i + 1 : la;
+      if (pr) lb = a.mask[(int64_t)td[m].tb * N + i] ? i + 1 : lb;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      la = max(la, __shfl_xor(la, off, 64));
+      lb = max(lb, __shfl_xor(lb, off, 64));
+    }
+    la = __builtin_amdgcn_readfirstlane(la);
+    lb = __builtin_amdgcn_readfirstlane(lb);
+    g2mask[m] = ((1 << ((la + 7) >> 3)) - 1) | (((1 << ((lb + 7) >> 3)) - 1) << (td[m].split >> 3));
+  }
+  // Ritz tile [node row][slot row], block diagonal (as in forward_half)
+  for (int idx = htid; idx < MT * 32 * 32; idx += 64 * NWV) {
+    const int m = idx >> 10, jj = (idx >> 5) & 31, rho = idx & 31;
+    const TileDesc t = pick(td, m);
+    const bool first = jj < t.split, sfirst = rho < t.split;
+    const int row = first ? jj : jj - t.split;
+    const int k = sfirst ? rho : rho - t.split;
+    const int mol = first ? t.ta : t.tb;
+    const bool ok = sfirst == first && k < K && row < N && mol >= 0;
+    Vm[m][jj][rho] = ok ? a.V[((int64_t)mol * N + row) * K + k] : 0.0f;
+  }
+
+  for (int la = 0; la < a.num_layer; ++la) {
+    const int din = la == 0 ? a.din0 : dhid;
+    const int Q = din >> 3;
+    // ---- stage X_la (buffer 0) and dY_la (buffer 1): rows of the tile's molecules, zero elsewhere
+    {
+      const float* xsrc = la == 0 ? a.x0 : a.act + (int64_t)(la - 1) * B * 32 * dhid;
+      const int d4 = din >> 2, e4 = dhid >> 2;
+      for (int idx = htid; idx < MT * 32 * (d4 + e4); idx += 64 * NWV) {
+        const int m = idx / (32 * (d4 + e4));
+        const int rem = idx - m * 32 * (d4 + e4);
+        const int row = rem / (d4 + e4), c = rem - row * (d4 + e4);
+        const TileDesc t = pick(td, m);
+        const bool first = row < t.split;
+        const int mol = first ? t.ta : t.tb;
+        const int lrow = first ? row : row - t.split;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < d4) {
+          if (mol >= 0) v = reinterpret_cast<const float4*>(xsrc + ((int64_t)mol * 32 + lrow) * din)[c];
+          *reinterpret_cast<float4*>(&Xs[0][m][row][4 * c]) = v;
+        } else {
+          if (mol >= 0)
+            v = reinterpret_cast<const float4*>(
+                a.dy + (((int64_t)la * B + mol) * 32 + lrow) * dhid)[c - d4];
+          *reinterpret_cast<float4*>(&Xs[1][m][row][4 * (c - d4)]) = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- projections: P = V^T dY (registers), Y = V^T X (registers, then LDS over X)
+    f32x16 Pb[MT], Yb[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float vt[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vt[r] = Vm[m][lnz::cd_row(r, hh)][j];
+      f32x16 Pm = lnz::splat16(0.0f), Ym = lnz::splat16(0.0f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if ((g2mask[m] >> g) & 1) {
+#pragma unroll
+          for (int r = 4 * g; r < 4 * g + 4; ++r) {
+            Pm = lnz::mfma32(vt[r], Xs[1][m][lnz::cd_row(r, hh)][32 * wave + j], Pm);
+            if (32 * wave < din)
+              Ym = lnz::mfma32(vt[r], Xs[0][m][lnz::cd_row(r, hh)][32 * wave + j], Ym);
+          }
+        }
+      }
+      Pb[m] = Pm;
+      Yb[m] = Ym;
+    }
+    __syncthreads();  // every wave has read X and dY
+    if (32 * wave < din) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Xs[0][m][lnz::cd_row(r, hh)][32 * wave + j] = Yb[m][r];
+      }
+    }
+    __syncthreads();
+    // ---- long channels: Q_s = Y W_s^T, row-wise <P, Q_s> over this wave's 32 columns
+    const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[la]);
+    const float4* __restrict__ wp =
+        Wl + ((int64_t)wave * (C * Q) + (int64_t)a.n_short * Q) * 64 + lane;
+    float4 ring[4];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
+    lds_cptr yrow[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) yrow[m] = (lds_cptr)&Xs[0][m][j][4 * hh];
+    for (int s = 0; s < S; ++s) {
+      f32x16 Z[MT];
+      lds_cptr xq[MT];
+      float4 acur[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        Z[m] = lnz::splat16(0.0f);
+        xq[m] = yrow[m];
+        acur[m] = lds_f4(xq[m]);
+      }
+#pragma unroll 1
+      for (int q0 = 0; q0 < Q; q0 += 4) {
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+          ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
+          float4 anext[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) anext[m] = lds_f4(xq[m] + 8 * (u4 + 1));
+          __builtin_amdgcn_sched_barrier(0);
+          const float4 bv = ring[u4];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acur[m] = anext[m];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) xq[m] += 32;
+        wp += 4 * 64;
+      }
+      // partial[rho] over the 32 lanes of a half-wave; the dY buffer (free since the projection)
+      // collects [wave][s][rho] per tile
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float* red = &Xs[1][m][0][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = Pb[m][r] * Z[m][r];
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          if (j == 0) red[(wave * S + s) * 32 + lnz::cd_row(r, hh)] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- sum over the waves (fixed order) and store dG[la][mol][k][s]
+    for (int idx = htid; idx < MT * S * 32; idx += 64 * NWV) {
+      const int m = idx / (S * 32);
+      const int rem = idx - m * S * 32;
+      const int s = rem >> 5, rho = rem & 31;
+      const TileDesc t = pick(td, m);
+      const bool isA = rho < t.split;
+      const int k = isA ? rho : rho - t.split;
+      const int mol = isA ? t.ta : t.tb;
+      if (mol >= 0 && k < K) {
+        const float* red = &Xs[1][m][0][0];
+        float v = 0.0f;
+        for (int w = 0; w < NWV; ++w) v += red[(w * S + s) * 32 + rho];
+        a.dgains[(((int64_t)la * B + mol) * K + k) * S + s] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int NWV>
+__global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const lnz_forward_args) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ __attribute__((aligned(16))) float Xs[2][2][MOLS][32][PITCH];  // [half][buffer][tile]
+  __shared__ __attribute__((aligned(16))) float Vm[2][MOLS][32][VPITCH];
+  const int tid = threadIdx.x;
+  const int W = a.plan ? *a.n_wg : (a.B + 3) / 4;
+  if ((int)blockIdx.x >= W) return;
+  const int half = __builtin_amdgcn_readfirstlane(tid / (64 * NWV));
+  const int htid = tid - half * 64 * NWV;
+  const int wave = __builtin_amdgcn_readfirstlane(htid >> 6);
+  TileDesc td[MOLS];
+  int nt = 0;
+#pragma unroll
+  for (int m = 0; m < MOLS; ++m) {
+    const int slot = (int)blockIdx.x * 4 + 2 * half + m;
+    if (a.plan) {
+      td[m].ta = a.plan[3 * slot + 0];
+      td[m].tb = a.plan[3 * slot + 1];
+      td[m].split = a.plan[3 * slot + 2];
+    } else {
+      td[m].ta = slot < a.B ? slot : -1;
+      td[m].tb = -1;
+      td[m].split = 32;
+    }
+    td[m].ta = __builtin_amdgcn_readfirstlane(td[m].ta);
+    td[m].tb = __builtin_amdgcn_readfirstlane(td[m].tb);
+    td[m].split = __builtin_amdgcn_readfirstlane(td[m].split);
+    nt += td[m].ta >= 0 ? 1 : 0;
+  }
+  if (nt == 2) {
+    gain_grad_half<NWV, 2>(a, td, Xs[half], Vm[half], htid, wave);
+  } else if (nt == 1) {
+    const TileDesc t1[1] = {td[0]};
+    gain_grad_half<NWV, 1>(a, t1, Xs[half], Vm[half], htid, wave);
+  } else {
+    for (int l = 0; l < 5 * a.num_layer; ++l) __syncthreads();  // five barriers per layer
+  }
+}
+
 }  // namespace
 
 namespace lnz {
@@ -929,6 +1158,28 @@ extern "C" int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t
 extern "C" int lnz_lanczosnet_input_grad(const lnz_forward_args* args, lnz_stream_t stream) {
   LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_input_grad: null args");
   return launch_conv(*args, 1, (hipStream_t)stream, "lnz_lanczosnet_input_grad");
+}
+
+extern "C" int lnz_lanczosnet_gain_grad(const lnz_forward_args* args, lnz_stream_t stream) {
+  LNZ_REQUIRE(args, LNZ_EINVAL, "lnz_lanczosnet_gain_grad: null args");
+  const lnz_forward_args& a = *args;
+  const char* who = "lnz_lanczosnet_gain_grad";
+  LNZ_REQUIRE(a.B > 0 && a.N > 0 && a.N <= LNZ_TILE && a.K > 0 && a.K <= 2 * KHMAX &&
+                  a.num_layer > 0 && a.num_layer <= 16,
+              LNZ_EINVAL, "%s: bad sizes (B=%d N=%d K=%d L=%d)", who, a.B, a.N, a.K, a.num_layer);
+  LNZ_REQUIRE(a.gemm_mode == 0 && a.filter_kind == 0 && a.dhid == 128 && a.n_long > 0 &&
+                  a.n_long <= 16 && a.din0 > 0 && a.din0 % 32 == 0 && a.din0 <= 128,
+              LNZ_ENOTSUP, "%s: built for gemm_mode 0, filter_kind 0, hidden width 128, "
+              "1..16 long channels, input width a multiple of 32", who);
+  LNZ_REQUIRE(a.mask && a.V && a.Wp && a.dy && a.x0 && a.dgains && (a.act || a.num_layer == 1),
+              LNZ_EINVAL, "%s: null tensor pointer (mask, V, Wp, dy, x0, act, dgains)", who);
+  LNZ_REQUIRE(!a.plan || (a.n_wg && a.plan_wg_cap > 0), LNZ_EINVAL,
+              "%s: plan without n_wg / plan_wg_cap", who);
+  // [wave][s][32] partial sums of a tile live in its 32 x PITCH dY buffer
+  LNZ_REQUIRE(4 * a.n_long * 32 <= 32 * PITCH, LNZ_ENOTSUP, "%s: too many long channels", who);
+  const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;
+  hipLaunchKernelGGL(lanczosnet_gain_grad_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  return lnz::check_launch(who);
 }
 
 extern "C" int lnz_lanczosnet_messages(const lnz_forward_args* args, lnz_stream_t stream) {

@@ -540,7 +540,12 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
 
         # ---- spectral filter MLPs (model/lanczos_net.py:95-123): dG, then autograd through the MLPs.
         #      All layers at once: one batched V^T [dY_0..dY_L-1 | X_0..X_L-1], one batched MLP.
-        if S > 0 and m._has_mlp():
+        if S > 0 and m._has_mlp() and os.environ.get('LANCZOSNET_DGAINS', 'hip') == 'hip':
+            # dG[l][b][k][s] = sum_o (V^T dY_l)[k][o] ((V^T X_l) W_{l,s}^T)[k][o]: one HIP launch in
+            # the forward's tile structure (lnz_lanczosnet_gain_grad)
+            dG = ops.lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiles)
+            dG = dG.view(Lnum, B * K, S)
+        elif S > 0 and m._has_mlp():
             Vt = V.transpose(1, 2)
             cat = torch.cat([dy[:, :, :N].permute(1, 2, 0, 3).reshape(B, N, Lnum * dh),
                              x0[:, :N],
@@ -557,6 +562,7 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
                 R = torch.matmul(dYv[:, la], Wl.reshape(dh, S * d)).view(B, K, S, d)
                 dG.append((R * Xv.unsqueeze(2)).sum(dim=3))             # [B,K,S]
             dG = torch.stack(dG).reshape(Lnum, B * K, S)               # [L, B*K, S]
+        if S > 0 and m._has_mlp():
             pows = torch.stack([torch.pow(D.float(), p) for p in m.long_diffusion_dist],
                                dim=2).view(1, B * K, S).expand(Lnum, B * K, S)
             lin_idx = [i for i, mod in enumerate(m.spectral_filter[0]) if isinstance(mod, nn.Linear)]

@@ -537,6 +537,32 @@ def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, ro
     _lib.check(lib.lnz_lanczosnet_messages(C.byref(a), _stream()))
 
 
+def lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiling):
+  """lnz_lanczosnet_gain_grad: dG [num_layer,B,K,S] = dLoss/d(spectral gains) from the stored
+  activations (act, x0) and the pre-activation gradients dy left by lanczosnet_input_grad —
+  sum_o (V^T dY_l)[k][o] ((V^T X_l) W_{l,s}^T)[k][o], evaluated per node tile in eigen space.
+  Uses the FORWARD weight packs of `plan`."""
+  _need_cuda(V, mask_u8, act, x0, dy)
+  a = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  B, _, K = V.shape
+  L, dh, S = plan['num_layer'], plan['dhid'], plan['n_long']
+  assert tuple(dy.shape) == (L, B, 32, dh) and dy.is_contiguous() and dy.dtype == torch.float32
+  assert tuple(act.shape) == (L, B, 32, dh) and act.is_contiguous() and act.dtype == torch.float32
+  assert tuple(x0.shape) == (B, 32, plan['din0']) and x0.is_contiguous()
+  a.din0 = plan['din0']
+  a.Wp = plan['Wp'].data_ptr()
+  for i in range(L):
+    a.w_off[i] = plan['w_off'][i]
+  # zero-initialised: eigen slots beyond a molecule's row block (k >= split of a shared tile) are
+  # dead (k >= n) and are not written
+  dG = torch.zeros((L, B, K, S), dtype=torch.float32, device=V.device)
+  a.act, a.x0, a.dy, a.dgains = act.data_ptr(), x0.data_ptr(), dy.data_ptr(), dG.data_ptr()
+  lib = _lib.load()
+  with torch.cuda.device(V.device):
+    _lib.check(lib.lnz_lanczosnet_gain_grad(C.byref(a), _stream()))
+  return dG
+
+
 # ------------------------------------------------------------------------------ R4, R5, R8 (Ada)
 def ada_graph_laplacian(node_feat, embedding, L0):
   """Learned Laplacian (model/ada_lanczos_net.py:101-137).  node_feat: [B,N] int64 ids (with

@@ -871,3 +871,44 @@ def test_pipelined_preparation_computes_the_previous_batch_gains():
   live = torch.clamp(na, max=20).long()
   sel = (torch.arange(20, device=DEV)[None, :] < live[:, None])[None, :, None, :].expand_as(Ga)
   assert torch.equal(Ga[sel], G2[sel])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,pairs', [(8, True), (1024, True), (37, False)])
+def test_gain_grad_kernel_matches_the_eigen_space_formula(B, pairs):
+  """lnz_lanczosnet_gain_grad: dG[l][b][k][s] = sum_o (V^T dY_l)[k][o] ((V^T X_l) W_{l,s}^T)[k][o]
+  on random activations / gradients, pair tiles and single tiles, against plain torch (fp32);
+  dead slots (k >= n) are exactly zero; repeated launches are bit-identical."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net = _model(cfg, oracle.make_lanczosnet_params(cfg, 1))
+  batch = draw_batch(B, seed=2)
+  n = _t(batch['n_nodes'])
+  mask = _t(batch['node_mask']).to(torch.uint8).contiguous()
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  K, Lnum, dh, S = cfg['num_eig_vec'], cfg['num_layer'], 128, len(cfg['long_diffusion_dist'])
+  D, V = ops.lanczos_ritz(L[..., 0], n, K)
+  plan = net._plan_backward()
+  Lp = ops.pack_laplacian_for(plan, L)
+  N, din0p = V.shape[1], plan['din0']
+  g = torch.Generator(device=DEV).manual_seed(1)
+  rows = (torch.arange(32, device=DEV)[None, :] < n[:, None]).float()
+  act = torch.rand((Lnum, B, 32, dh), device=DEV, generator=g) * rows[None, :, :, None]
+  dy = torch.randn((Lnum, B, 32, dh), device=DEV, generator=g) * rows[None, :, :, None]
+  x0 = torch.randn((B, 32, din0p), device=DEV, generator=g) * rows[:, :, None]
+  tiles = ops.plan_tiles(mask, allow_pairs=pairs)
+  dG = ops.lanczosnet_gain_grad(plan, Lp, V, None, mask, act, x0, dy, tiles)
+  assert torch.equal(dG, ops.lanczosnet_gain_grad(plan, Lp, V, None, mask, act, x0, dy, tiles))
+  n_chan = S + cfg['num_bond_type'] + 1
+  Vt = V.transpose(1, 2)
+  ref = []
+  for la in range(Lnum):
+    X = x0[:, :N] if la == 0 else act[la - 1][:, :N]
+    W = net._mix_weight(la).detach().view(dh, n_chan, -1)[:, :S, :]
+    W = torch.nn.functional.pad(W, (0, X.shape[2] - W.shape[2]))
+    Qs = torch.einsum('bki,osi->bkso', torch.bmm(Vt, X), W)
+    ref.append((Qs * torch.bmm(Vt, dy[la][:, :N]).unsqueeze(2)).sum(3))
+  ref = torch.stack(ref)
+  assert (dG - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+  dead = (torch.arange(K, device=DEV)[None, :] >= n[:, None])
+  assert (dG[:, dead] == 0).all()
