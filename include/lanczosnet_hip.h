@@ -134,6 +134,10 @@ int64_t lnz_spectral_mlp_pack_size(int S);
 int lnz_pack_spectral_mlp(const float* W0, const float* b0, const float* W2, const float* b2,
                           const float* W4, const float* b4, const float* W6, const float* b6,
                           int S, float* pack, lnz_stream_t stream);
+/* Same packs for ALL conv layers in one launch: ptrs[l*8 + {0..7}] = W0, b0, W2, b2, W4, b4, W6, b6
+ * of layer l (host array of device pointers); pack holds num_layer consecutive layer packs. */
+int lnz_pack_spectral_mlp_layers(const float* const* ptrs, int num_layer, int S, float* pack,
+                                 lnz_stream_t stream);
 int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,
                        int num_layer, int kind, const float* mlp_pack, float* G,
                        lnz_stream_t stream);

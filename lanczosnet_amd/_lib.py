@@ -74,6 +74,7 @@ SIGNATURES = {
     'lnz_pack_laplacian_f16x2': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),
     'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),
+    'lnz_pack_spectral_mlp_layers': (C.c_int, [_P, _I, _I, _P, _P]),
     'lnz_spectral_gains': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P]),
     'lnz_spectral_gains_rows': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_lanczosnet_input_grad': (C.c_int, [C.POINTER(ForwardArgs), _P]),

@@ -83,6 +83,72 @@ extern "C" int lnz_pack_spectral_mlp(const float* W0, const float* b0, const flo
   return LNZ_OK;
 }
 
+// All conv layers' MLP packs in ONE launch (a training step re-packs every layer after the
+// optimizer update: 8 launches per layer otherwise).  grid.y = layer, one thread per pack float.
+struct MlpLayerPtrs {
+  const float* p[16][8];  // [layer][W0, b0, W2, b2, W4, b4, W6, b6]
+};
+
+__device__ inline float rows_k8_elem(const float* __restrict__ W, int rows, int cols, int ld,
+                                     int Q, int f) {
+  const int idx4 = f >> 2, u = f & 3;
+  const int lane = idx4 & 63, q = (idx4 >> 6) % Q, rt = (idx4 >> 6) / Q;
+  const int row = 32 * rt + (lane & 31), col = 8 * q + 4 * (lane >> 5) + u;
+  return (row < rows && col < cols) ? W[(int64_t)row * ld + col] : 0.0f;
+}
+
+__device__ inline float bias_rows_elem(const float* __restrict__ b, int rows, int f) {
+  const int r = f & 15, lane = (f >> 4) & 63, rt = f >> 10;
+  const int row = 32 * rt + lnz::cd_row(r, lane >> 5);
+  return row < rows ? b[row] : 0.0f;
+}
+
+__global__ void pack_spectral_mlp_layers_kernel(MlpLayerPtrs ptrs, int S, float* __restrict__ pack) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= PACK_SIZE) return;
+  const int l = blockIdx.y;
+  const float* const* pl = ptrs.p[l];
+  float v = 0.0f;  // the prefetch slack behind W6 stays zero
+  if (f < OFF_B0) {
+    const int lane = f & 63, t = (f >> 6) & 7, ot = f >> 9;
+    const int feat = 8 * (lane >> 5) + t;
+    v = feat < S ? pl[0][(32 * ot + (lane & 31)) * S + feat] : 0.0f;
+  } else if (f < OFF_B2) {
+    v = bias_rows_elem(pl[1], HID, f - OFF_B0);
+  } else if (f < OFF_B4) {
+    v = bias_rows_elem(pl[3], HID, f - OFF_B2);
+  } else if (f < OFF_B6) {
+    v = bias_rows_elem(pl[5], HID, f - OFF_B4);
+  } else if (f < OFF_W2) {
+    v = bias_rows_elem(pl[7], S, f - OFF_B6);
+  } else if (f < OFF_W4) {
+    v = rows_k8_elem(pl[2], HID, HID, HID, HID / 8, f - OFF_W2);
+  } else if (f < OFF_W6) {
+    v = rows_k8_elem(pl[4], HID, HID, HID, HID / 8, f - OFF_W4);
+  } else if (f < OFF_W6 + 16 * 256) {
+    v = rows_k8_elem(pl[6], S, HID, HID, HID / 8, f - OFF_W6);
+  }
+  pack[(int64_t)l * PACK_SIZE + f] = v;
+}
+
+extern "C" int lnz_pack_spectral_mlp_layers(const float* const* ptrs, int num_layer, int S,
+                                            float* pack, lnz_stream_t stream) {
+  LNZ_REQUIRE(ptrs && pack && num_layer >= 1 && num_layer <= 16, LNZ_EINVAL,
+              "lnz_pack_spectral_mlp_layers: bad arguments (L=%d)", num_layer);
+  LNZ_REQUIRE(S >= 1 && S <= SMAX, LNZ_ENOTSUP, "lnz_pack_spectral_mlp_layers: S=%d not in 1..%d",
+              S, SMAX);
+  MlpLayerPtrs mp;
+  for (int l = 0; l < 16; ++l)
+    for (int i = 0; i < 8; ++i) {
+      mp.p[l][i] = l < num_layer ? ptrs[l * 8 + i] : nullptr;
+      LNZ_REQUIRE(l >= num_layer || mp.p[l][i], LNZ_EINVAL,
+                  "lnz_pack_spectral_mlp_layers: null pointer (layer %d, tensor %d)", l, i);
+    }
+  hipLaunchKernelGGL(pack_spectral_mlp_layers_kernel, dim3((PACK_SIZE + 255) / 256, num_layer),
+                     dim3(256), 0, (hipStream_t)stream, mp, S, pack);
+  return lnz::check_launch("lnz_pack_spectral_mlp_layers");
+}
+
 extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_host,
                                        int S, int num_layer, int kind, const float* mlp_pack,
                                        const int32_t* rows, const int32_t* n_rows, float* G,

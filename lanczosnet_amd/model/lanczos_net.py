@@ -187,15 +187,26 @@ class _LanczosNetBase(nn.Module):
         din0 = self.input_dim
         din0p = (din0 + 31) // 32 * 32
         n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
+        # layer 0 has its own width; the other layers share a shape and are packed by one launch
+        # (rows of the stacked matrix are whole 32-row tiles of each layer, so the pack of the
+        # stack is the concatenation of the per-layer packs)
+        w = self._mix_weight(0)
+        if din0p != din0:
+            w = torch.nn.functional.pad(w.view(dhid, n_chan, din0), (0, din0p - din0))
+            w = w.reshape(dhid, n_chan * din0p)
+        wp = ops.pack_rows_k8(w)
+        packs.append(wp)
+        w_off.append(0)
+        woff = wp.numel()
+        if self.num_layer > 1:
+            stack = torch.cat([self._mix_weight(t) for t in range(1, self.num_layer)], dim=0)
+            wps = ops.pack_rows_k8(stack)
+            packs.append(wps)
+            per = wps.numel() // (self.num_layer - 1)
+            for t in range(1, self.num_layer):
+                w_off.append(woff)
+                woff += per
         for t in range(self.num_layer):
-            w = self._mix_weight(t)
-            if t == 0 and din0p != din0:
-                w = torch.nn.functional.pad(w.view(dhid, n_chan, din0), (0, din0p - din0))
-                w = w.reshape(dhid, n_chan * din0p)
-            wp = ops.pack_rows_k8(w)
-            packs.append(wp)
-            w_off.append(woff)
-            woff += wp.numel()
             biases.append(self.filter[t].bias.detach().float())
             b_off.append(boff)
             boff += dhid
@@ -246,12 +257,9 @@ class _LanczosNetBase(nn.Module):
         elif self.gemm_mode != 'fp32':
             raise ValueError("gemm_mode must be 'fp32' or 'f16x3'")
         if self._has_mlp() and self.filter_kind == 0:
-            size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
-            buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)
-            for t, seq in enumerate(self.spectral_filter):
-                lins = [(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
-                ops.pack_spectral_mlp(lins, self.num_scale_long, out=buf[t])
-            plan['mlp_pack'] = buf
+            plan['mlp_pack'] = ops.pack_spectral_mlp_layers(
+                [[(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
+                 for seq in self.spectral_filter], self.num_scale_long)
         else:
             plan['mlp_pack'] = None
         self._plan_cache = plan
@@ -339,11 +347,9 @@ class _LanczosNetBase(nn.Module):
         if cache is not None and cache['sig'] == sig:
             return cache
         dev = self.filter[0].weight.device
-        size = ops._lib.load().lnz_spectral_mlp_pack_size(self.num_scale_long)
-        buf = torch.empty((self.num_layer, size), dtype=torch.float32, device=dev)
-        for t, seq in enumerate(self.spectral_filter):
-            lins = [(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
-            ops.pack_spectral_mlp(lins, self.num_scale_long, out=buf[t])
+        buf = ops.pack_spectral_mlp_layers(
+            [[(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)] for seq in self.spectral_filter],
+            self.num_scale_long)
         self._plan_large_cache = dict(sig=sig, mlp_pack=buf)
         return self._plan_large_cache
 
@@ -364,18 +370,27 @@ class _LanczosNetBase(nn.Module):
         n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
         dhid, din0, din0p = plan['dhid'], plan['din0_raw'], plan['din0']
         packs, offs, off = [], [], 0
-        for t in range(self.num_layer):
-            la = self.num_layer - 1 - t
-            w = self._mix_weight(la).detach().float()
-            d = din0 if la == 0 else dhid
-            w = w.view(dhid, n_chan, d)
-            if la == 0 and din0p != din0:
-                w = torch.nn.functional.pad(w, (0, din0p - din0))
-            wb = w.permute(2, 1, 0).reshape(w.shape[2], n_chan * dhid).contiguous()
-            pk = ops.pack_rows_k8(wb)
+        # kernel layers 0 .. L-2 = conv layers L-1 .. 1 (one shape: packed by one launch), then
+        # conv layer 0 with its own width
+        if self.num_layer > 1:
+            wbs = []
+            for t in range(self.num_layer - 1):
+                w = self._mix_weight(self.num_layer - 1 - t).detach().float().view(dhid, n_chan, dhid)
+                wbs.append(w.permute(2, 1, 0).reshape(dhid, n_chan * dhid))
+            pk = ops.pack_rows_k8(torch.cat(wbs, dim=0).contiguous())
             packs.append(pk)
-            offs.append(off)
-            off += pk.numel()
+            per = pk.numel() // (self.num_layer - 1)
+            for t in range(self.num_layer - 1):
+                offs.append(off)
+                off += per
+        w = self._mix_weight(0).detach().float().view(dhid, n_chan, din0)
+        if din0p != din0:
+            w = torch.nn.functional.pad(w, (0, din0p - din0))
+        wb = w.permute(2, 1, 0).reshape(w.shape[2], n_chan * dhid).contiguous()
+        pk = ops.pack_rows_k8(wb)
+        packs.append(pk)
+        offs.append(off)
+        off += pk.numel()
         plan['Wp_t'] = torch.cat(packs + [torch.zeros(2048, dtype=torch.float32, device=dev)])
         plan['wt_off'] = offs
         return plan

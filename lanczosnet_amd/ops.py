@@ -299,6 +299,25 @@ def pack_spectral_mlp(linears, S, out=None):
   return out
 
 
+def pack_spectral_mlp_layers(layers, S):
+  """layers: per conv layer, the 4 (weight, bias) pairs of its `spectral_filter[l]` -> one
+  [num_layer, pack_size] buffer, packed by ONE launch (lnz_pack_spectral_mlp_layers)."""
+  lib = _lib.load()
+  size = lib.lnz_spectral_mlp_pack_size(S)
+  keep, ptrs = [], []
+  for lins in layers:
+    assert len(lins) == 4
+    for (w, b) in lins:
+      _need_cuda(w, b)
+      keep += [_f32c(w), _f32c(b)]
+  dev = keep[0].device
+  arr = (C.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+  out = torch.empty((len(layers), size), dtype=torch.float32, device=dev)
+  with torch.cuda.device(dev):
+    _lib.check(lib.lnz_pack_spectral_mlp_layers(arr, len(layers), S, _ptr(out), _stream()))
+  return out
+
+
 # ------------------------------------------------------------------------------------------ R7
 def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True):
   """D [B,K] -> G [num_layer,B,S,K].  mlp_pack=None selects the plain-power branch.
