@@ -196,8 +196,9 @@ typedef struct lnz_forward_args {
   const void* Lp16;           /* lnz_pack_laplacian_f16x2 output (gemm_mode 1; replaces Lp there)  */
   const int32_t* plan;        /* optional tile plan (lnz_plan_tiles): [plan_wg_cap][4][3] int32, slot s
                                  of workgroup g = (molecule A, molecule B or -1, split row); NULL =
-                                 one tile per molecule, 4 per workgroup, in batch order.  Results
-                                 do not depend on the plan, only the time.  Pair tiles (B >= 0):
+                                 one tile per molecule, 4 per workgroup, in batch order.  The plan
+                                 changes the time, and the scores only by fp32 re-association
+                                 (<= 1e-6 relative; tested at 1e-5).  Pair tiles (B >= 0):
                                  gemm_mode 0 with filter_kind 0 only.                               */
   const int32_t* n_wg;        /* device scalar written by lnz_plan_tiles: workgroups in use          */
   int plan_wg_cap;            /* lnz_plan_wg_cap(B, n_cu): workgroup entries in `plan` (= grid size) */
