@@ -521,7 +521,10 @@ __device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem&
           return 0.0;
         }
       }
-      const bool done = !act || (hi - lo) <= 4.0 * kEps * fmax(fabs(lo), fabs(hi)) + 1e-300;
+      // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T| — an
+      // eigenvalue at (or next to) zero would otherwise keep every lane of the wave in the loop
+      // for all 30 passes without gaining anything the fp32 outputs or the twisted vectors need
+      const bool done = !act || (hi - lo) <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
       if (__all(done)) break;
     }
     return 0.5 * (lo + hi);
