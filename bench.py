@@ -254,8 +254,9 @@ def main():
       torch.cuda.synchronize()
     dev_rel = float((s2 - ref_score).abs().max() / ref_score.abs().max())
     split = {'mode': 'f16x3: X W^T as x_hi w_hi + x_hi w_lo + x_lo w_hi on v_mfma_f32_32x32x16_f16, '
-                     'fp32 accumulate; GEMM2 and everything else exact fp32 (opt-in, parity-tested '
-                     'at the same 1e-5 bar)',
+                     'fp32 accumulate; edge-type GEMM2 in the same split, spectral channels in eigen space '
+                     '(projection exact fp32), everything else exact fp32 (opt-in, parity-tested at '
+                     'the same 1e-5 bar)',
              'value': round(B * args.steps / el2, 1), 'unit': 'molecules/s',
              'ms_per_step': round(1e3 * el2 / args.steps, 4),
              'forward_ms': round(e0.elapsed_time(e1) / 10, 4),

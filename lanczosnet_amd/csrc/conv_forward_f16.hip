@@ -6,9 +6,12 @@
 // runs on v_mfma_f32_32x32x16_f16 (32 cycles per 32x32x16) instead of v_mfma_f32_32x32x2_f32
 // (64 cycles per 32x32x2): 3/16 of the issue cycles.  The dropped x_lo w_lo term is 2^-22 relative;
 // end-to-end deviation from fp64 is 6e-7 (exact-fp32 path: 2e-7; parity bar 1e-5).
-// GEMM2 (M_c Z_c) uses the same split (M_c pieces pre-split by lnz_pack_laplacian_f16x2 or split from
-// the L_s registers, Z_c split from the GEMM1 accumulators); the L_s build, the head accumulation and
-// everything else stay exact fp32.
+// GEMM2 (M_c Z_c) of the edge / short channels uses the same split (M_c pieces pre-split by
+// lnz_pack_laplacian_f16x2, Z_c split from the GEMM1 accumulators).  The long-scale spectral
+// channels run in eigen space like the fp32 kernel (conv_forward.hip): Y = V^T X once per layer
+// (exact fp32 MFMA, Y stored as fp16 hi/lo in the other X buffer), GEMM1 of every long channel on
+// Y, T += diag(g_s) (Y W_s^T) on the VALU in fp32, one lift out += V T (split) — no L_s build, no
+// per-channel GEMM2.  The head accumulation and everything else stay exact fp32.
 //
 // With GEMM1 this cheap the per-CU vector-memory path becomes the limiter unless every packed
 // weight fragment is reused more: ONE workgroup per CU-sized group of FOUR molecules, four
@@ -28,6 +31,8 @@ constexpr int P16 = 136;       // LDS row pitch in halves
 constexpr int KB = 8;          // k-blocks (of 16) per channel: input width 128
 constexpr int RING_D = 6;      // weight prefetch distance in k-blocks
 constexpr int KHT = 10;        // eigen slots per lane half (K <= 20)
+constexpr int GK = 24;         // gains per (molecule, channel) kept in LDS (slots k < 24, K <= 20 live)
+constexpr int VP = 33;         // Ritz-vector LDS row pitch (floats): conflict-free column reads
 
 union H8 {
   uint4 u;
@@ -59,6 +64,10 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   // [buf][piece][mol][32][P16]
   auto Xp = [&](int buf, int piece, int m) { return smem + (((buf * 2 + piece) * M4 + m) * 32) * P16; };
+  // Ritz vectors of the four molecules, fp32 [mol][node][slot] (pitch VP), behind the X tiles:
+  // column reads feed the projection, row reads the lift
+  float* Vs = reinterpret_cast<float*>(smem + 2 * 2 * M4 * 32 * P16);
+  float* Gl = Vs + M4 * 32 * VP;  // this layer's gains [mol][s][slot k < GK]
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,15 +119,11 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
 #pragma unroll
   for (int m = 0; m < M4; ++m) nblkm[m] = g2steps[m] > 8 ? 2 : 1;
 
-  const int KH = (K + 1) >> 1;
-  float vreg[M4][KHT];
-#pragma unroll
-  for (int m = 0; m < M4; ++m) {
-#pragma unroll
-    for (int t = 0; t < KHT; ++t) {
-      int k = KH * hh + t;
-      vreg[m][t] = (t < KH && k < K && j < N) ? a.V[((int64_t)mb[m] * N + j) * K + k] : 0.0f;
-    }
+  for (int idx = tid; idx < M4 * 32 * 32; idx += 256) {
+    const int m = idx >> 10, node = (idx >> 5) & 31, slot = idx & 31;
+    const int mol = m == 0 ? mb[0] : m == 1 ? mb[1] : m == 2 ? mb[2] : mb[3];
+    Vs[(m * 32 + node) * VP + slot] =
+        (node < N && slot < K) ? a.V[((int64_t)mol * N + node) * K + slot] : 0.0f;
   }
   __syncthreads();
 
@@ -149,24 +154,75 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
       ringh[sl] = wp[sl * 128];
       ringl[sl] = wp[sl * 128 + 64];
     }
+    const int nxt = cur ^ 1;
     const _Float16* xa[M4][2];
+    const _Float16* ya[M4][2];
 #pragma unroll
     for (int m = 0; m < M4; ++m) {
       xa[m][0] = Xp(cur, 0, m) + j * P16 + 8 * hh;
       xa[m][1] = Xp(cur, 1, m) + j * P16 + 8 * hh;
+      ya[m][0] = Xp(nxt, 0, m) + j * P16 + 8 * hh;
+      ya[m][1] = Xp(nxt, 1, m) + j * P16 + 8 * hh;
     }
+
+    // ---------------- eigen-space projection Y_m = V_m^T X_m (exact fp32 MFMA) ----------------
+    //   A: V^T fragments (lane = slot row j, step r = node cd_row(r,hh)), L2 resident;
+    //   B: X rows rebuilt from their fp16 pieces; Y (rows = eigen slots) goes, split, into the
+    //   other X buffer — free until this layer's epilogue
+    const float* vsl = Vs;
+    if (a.n_long > 0) {
+#pragma unroll
+      for (int m = 0; m < M4; ++m) {
+        f32x16 Y = lnz::splat16(0.0f);
+        const float* vp = vsl + m * 32 * VP + j;
+        const _Float16* x0 = Xp(cur, 0, m) + 32 * wave + j;
+        const _Float16* x1 = Xp(cur, 1, m) + 32 * wave + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (4 * g < g2steps[m]) {  // node rows beyond the molecule are zero
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+              const int node = lnz::cd_row(r, hh);
+              const float vt = vp[node * VP];
+              const float xb = (float)x0[node * P16] + (float)x1[node * P16];
+              Y = lnz::mfma32(vt, xb, Y);
+            }
+          }
+        }
+        _Float16* yh = Xp(nxt, 0, m) + 32 * wave + j;
+        _Float16* yl = Xp(nxt, 1, m) + 32 * wave + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = lnz::cd_row(r, hh);
+          split_store(yh + row * P16, yl + row * P16, Y[r]);
+        }
+        // one molecule at a time: the scheduler otherwise hoists all four molecules' 192 LDS
+        // reads to the top and spills their addresses
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      for (int idx = tid; idx < M4 * a.n_long * GK; idx += 256) {
+        const int m = idx / (a.n_long * GK);
+        const int rem = idx - m * a.n_long * GK;
+        const int sc = rem / GK, k = rem - sc * GK;
+        const int mol = m == 0 ? mb[0] : m == 1 ? mb[1] : m == 2 ? mb[2] : mb[3];
+        Gl[idx] = k < K ? a.G[(((int64_t)l * B + mol) * a.n_long + sc) * K + k] : 0.0f;
+      }
+      __syncthreads();
+    }
+    f32x16 Tsum[M4];
+#pragma unroll
+    for (int m = 0; m < M4; ++m) Tsum[m] = lnz::splat16(0.0f);
 
     // GEMM2 operands of the CURRENT channel, fetched at its start (they have the whole GEMM1 to
     // land): 16 floats per molecule as four dwordx4 — the Laplacian fragments of an edge/short
-    // channel, or (long channel) the gains g_s[KH*hh .. +15] (10 used; G is padded by 64 B).
+    // channel, or (long channel) the gains of the 16 slot rows this lane's C/D registers hold.
     float mop[M4][16];
     auto fetch_m_operands = [&](int c, int m) {
       const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
       const float* src;
       int stride4;
       if (lng) {
-        src = a.G + (((int64_t)l * B + mb[m]) * a.n_long + (c - a.n_short)) * K + KH * hh;
-        stride4 = 1;
+        return;  // gains come from LDS after GEMM1
       } else {
         // [blk][piece][lane] uint4: g = 2 blk + piece
         const int e = c < a.n_short ? 0 : c - a.n_short - a.n_long;
@@ -197,8 +253,8 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
       H8 ah[M4], al[M4];
 #pragma unroll
       for (int m = 0; m < M4; ++m) {
-        ah[m].u = *reinterpret_cast<const uint4*>(xa[m][0]);
-        al[m].u = *reinterpret_cast<const uint4*>(xa[m][1]);
+        ah[m].u = *reinterpret_cast<const uint4*>(is_long ? ya[m][0] : xa[m][0]);
+        al[m].u = *reinterpret_cast<const uint4*>(is_long ? ya[m][1] : xa[m][1]);
       }
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -209,8 +265,8 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
         if (kb + 1 < KB) {
 #pragma unroll
           for (int m = 0; m < M4; ++m) {
-            nh[m].u = *reinterpret_cast<const uint4*>(xa[m][0] + 16 * (kb + 1));
-            nl[m].u = *reinterpret_cast<const uint4*>(xa[m][1] + 16 * (kb + 1));
+            nh[m].u = *reinterpret_cast<const uint4*>((is_long ? ya[m][0] : xa[m][0]) + 16 * (kb + 1));
+            nl[m].u = *reinterpret_cast<const uint4*>((is_long ? ya[m][1] : xa[m][1]) + 16 * (kb + 1));
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -235,30 +291,54 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
       wp += KB * 128;
 
       LNZ_ACC(t_g1)
-      // ---------------- M_c operand pieces (A of GEMM2), per molecule and k-block --------------
-      // long: L_s = V diag(g_s) V^T by exact fp32 MFMAs (four chains interleaved), then split;
-      // edge/short: pre-split fragments from lnz_pack_laplacian_f16x2.
-      H8 mh[M4][2], ml[M4][2];
       if (is_long) {
-        f32x16 Ls[M4];
-#pragma unroll
-        for (int m = 0; m < M4; ++m) Ls[m] = lnz::splat16(0.0f);
-#pragma unroll
-        for (int t = 0; t < KHT; ++t) {
-          if (t < KH) {
-#pragma unroll
-            for (int m = 0; m < M4; ++m) {
-              const float g = (KH * hh + t < K) ? mop[m][t] : 0.0f;
-              Ls[m] = lnz::mfma32(vreg[m][t] * g, vreg[m][t], Ls[m]);
-            }
-          }
-        }
+        // ---------------- eigen space: T_m += diag(g_c) Z_m; after the last long channel the
+        //                  lift out_m += V_m T_m (split fp16), then the Y buffer is released --------
 #pragma unroll
         for (int m = 0; m < M4; ++m) {
-          split8(Ls[m], 0, mh[m][0].h, ml[m][0].h);
-          split8(Ls[m], 1, mh[m][1].h, ml[m][1].h);
+          // gains of the slot rows of this lane's C/D registers: rows 8g + 4hh + u < GK
+          const float* gp = Gl + (m * a.n_long + (c - a.n_short)) * GK + 4 * hh;
+#pragma unroll
+          for (int g = 0; g < GK / 8; ++g) {
+            const float4 gv = *reinterpret_cast<const float4*>(gp + 8 * g);
+            Tsum[m][4 * g + 0] = fmaf(gv.x, Z[m][4 * g + 0], Tsum[m][4 * g + 0]);
+            Tsum[m][4 * g + 1] = fmaf(gv.y, Z[m][4 * g + 1], Tsum[m][4 * g + 1]);
+            Tsum[m][4 * g + 2] = fmaf(gv.z, Z[m][4 * g + 2], Tsum[m][4 * g + 2]);
+            Tsum[m][4 * g + 3] = fmaf(gv.w, Z[m][4 * g + 3], Tsum[m][4 * g + 3]);
+          }
         }
-      } else {
+        if (c + 1 == a.n_short + a.n_long) {
+#pragma unroll
+          for (int m = 0; m < M4; ++m) {
+            const float* vrow = vsl + (m * 32 + j) * VP;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+              if (16 * blk < K) {  // k-block 1 holds slots 16..31
+                H8 vh, vl, th, tl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const int slot = lnz::cd_row(8 * blk + e, hh);
+                  const float x = vrow[slot];
+                  const _Float16 xh = (_Float16)x;
+                  vh.h[e] = xh;
+                  vl.h[e] = (_Float16)(x - (float)xh);
+                }
+                split8(Tsum[m], blk, th.h, tl.h);
+                out[m] = mfma16(vh.h, th.h, out[m]);
+                out[m] = mfma16(vh.h, tl.h, out[m]);
+                out[m] = mfma16(vl.h, th.h, out[m]);
+              }
+            }
+          }
+          __syncthreads();  // every wave is done reading Y before the epilogue overwrites it
+        }
+        LNZ_ACC(t_g2)
+        continue;
+      }
+      // ---------------- M_c operand pieces (A of GEMM2), per molecule and k-block --------------
+      // edge/short: pre-split fragments from lnz_pack_laplacian_f16x2.
+      H8 mh[M4][2], ml[M4][2];
+      {
 #pragma unroll
         for (int m = 0; m < M4; ++m) {
 #pragma unroll
@@ -322,7 +402,6 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
 
     // ---------------- epilogue: ReLU, split, X' -> LDS (other buffer), one barrier per layer ----
     LNZ_T0
-    const int nxt = cur ^ 1;
 #pragma unroll
     for (int m = 0; m < M4; ++m) {
       _Float16* xh = Xp(nxt, 0, m) + 32 * wave + j;
@@ -390,7 +469,9 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
   }
 }
 
-constexpr size_t kSmemBytes = (size_t)2 * 2 * M4 * 32 * P16 * sizeof(_Float16);  // 139,264 B
+constexpr size_t kSmemBytes = (size_t)2 * 2 * M4 * 32 * P16 * sizeof(_Float16)  // X tiles 139,264 B
+                              + (size_t)M4 * 32 * VP * sizeof(float)             // + Ritz vectors 16,896 B
+                              + (size_t)M4 * 16 * GK * sizeof(float);            // + gains of one layer (<= 16 channels) 6,144 B
 
 }  // namespace
 
