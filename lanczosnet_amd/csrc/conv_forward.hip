@@ -1,31 +1,34 @@
 // R7 (second half) + R9 + R10: the fused LanczosNet forward.
 //
-// One workgroup (dhid/32 wavefronts) per PAIR of 32-row node tiles runs the WHOLE network on chip:
+// One workgroup = two halves of dhid/32 wavefronts; a half runs the WHOLE network on chip for up
+// to two 32-row node tiles (lnz_plan_tiles deals the batch's tiles over one workgroup per CU):
 // embedding -> num_layer x [ X' = relu( sum_c M_c X W_c^T + b ) ] -> gated head -> masked mean.
-// A tile holds one molecule, or (lnz_plan_tiles) two molecules of <= 16 nodes each in rows 0..15
-// and 16..31 with block-diagonal operators M_c — the per-lane molecule id is all that differs.
+// A tile holds one molecule, or two small ones (8|24 or 16|16 rows) with block-diagonal operators
+// — the per-lane molecule id is all that differs.
 //
-// Per layer and message channel c two chained matrix-core GEMMs (v_mfma_f32_32x32x2_f32, exact
-// fp32 fma chains), evaluated as  M_c (X W_c^T)  instead of the reference's  (M_c X) W_c^T :
+// Node-space channels (edge types, short diffusion) are two chained matrix-core GEMMs
+// (v_mfma_f32_32x32x2_f32, exact fp32 fma chains), evaluated as  M_c (X W_c^T)  instead of the
+// reference's  (M_c X) W_c^T :
 //
 //   GEMM1  Z_c [32 nodes x dhid] = X [32 x din] * W_c^T
 //          A = X from LDS (row-major, pitch 132 floats, one ds_read_b128 = 4 k-steps),
-//          B = W_c pre-packed in fragment order (one global_load_dwordx4 = 4 k-steps, L2 hits),
-//          wave w owns output-feature tile w for both molecules: each weight fragment feeds
-//          2 x 4 MFMAs (the per-CU vector-memory path, not L2, limits a 1-molecule tiling).
+//          B = W_c pre-packed in fragment order (one global_load_dwordx4 = 4 k-steps, L2 hits)
+//              through a register ring; wave w owns output-feature tile w for all its tiles, so
+//              each weight fragment feeds MT x 4 MFMAs.
 //   GEMM2  out += M_c [32 x 32] * Z_c
 //          B = the C/D registers of GEMM1 *as they are*: register r of lane (j, hh) holds
 //              Z_c[cd_row(r,hh)][j], which is exactly what k-step r needs when the contraction
 //              index is visited in the order m(r,hh) = cd_row(r,hh);
-//          A = M_c in the matching order: edge/short channels from the packed Laplacian
-//              (4 coalesced dwordx4 per channel), spectral channels built in registers:
-//              L_s = V diag(g_s) V^T by 10 MFMAs, whose C/D registers are — L_s being
-//              symmetric — already the A fragments.
+//          A = M_c in the matching order from the packed Laplacian (4 coalesced dwordx4).
 //   short-diffusion channels apply M = L_0 p times to Z_c in registers (same chaining).
 //
+// The long-scale spectral channels  sum_s V diag(g_s) V^T X W_s^T  run in EIGEN SPACE (see the
+// comment above forward_half): Y = V^T X once per layer, GEMM1 of every channel on Y
+// with the slot rows scaled by the gains, one lift back through V — the filters L_s never exist.
+//
 // So `cat(msg)` (model/lanczos_net.py:180), the [B,N,N,S] filter stack (:123) and the strided
-// `L[:,:,:,ii]` clones (:172-178) never exist; per layer the only LDS traffic is X (written once
-// by the epilogue, read by both waves) and the only barrier is one __syncthreads per layer.
+// `L[:,:,:,ii]` clones (:172-178) never exist; per layer the only LDS traffic is X / Y and there
+// are three __syncthreads per layer (one without spectral channels).
 // HBM bytes per molecule: Lp 28,672 + V 2,560 + G 4,480 + ids 256 + mask 32 in, 64 out; the
 // 7.4 MB of packed weights are shared by all workgroups and stay L2 / Infinity-Cache resident.
 #include "common.hpp"
