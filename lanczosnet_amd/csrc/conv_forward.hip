@@ -99,6 +99,57 @@ __device__ __forceinline__ int pick(const int (&v)[MT], int m) {
 // row rho >= split is slot k = rho - split of molecule B (a molecule has <= min(n, K) live slots and
 // n <= its row extent), so V^T and V are block-diagonal exactly like the Laplacians and the
 // summation order of a molecule's terms never depends on its tile partner.
+// Slot `slot` of the tile plan (or, without a plan, molecule `slot` as a single tile).
+__device__ __forceinline__ TileDesc load_tile_desc(KArgs& a, int slot) {
+  TileDesc t;
+  if (a.plan) {
+    t.ta = a.plan[3 * slot + 0];
+    t.tb = a.plan[3 * slot + 1];
+    t.split = a.plan[3 * slot + 2];
+  } else {
+    t.ta = slot < a.B ? slot : -1;
+    t.tb = -1;
+    t.split = 32;
+  }
+  t.ta = __builtin_amdgcn_readfirstlane(t.ta);
+  t.tb = __builtin_amdgcn_readfirstlane(t.tb);
+  t.split = __builtin_amdgcn_readfirstlane(t.split);
+  return t;
+}
+
+// Node extents (last real node + 1) of the one or two molecules of a tile, wave uniform.
+__device__ __forceinline__ void tile_extents(KArgs& a, const TileDesc& t, int lane, int& nA, int& nB) {
+  const bool pr = t.tb >= 0;
+  int la = 0, lb = 0;
+  for (int i = lane; i < a.N; i += 64) {
+    la = a.mask[(int64_t)t.ta * a.N + i] ? i + 1 : la;
+    if (pr) lb = a.mask[(int64_t)t.tb * a.N + i] ? i + 1 : lb;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    la = max(la, __shfl_xor(la, off, 64));
+    lb = max(lb, __shfl_xor(lb, off, 64));
+  }
+  nA = __builtin_amdgcn_readfirstlane(la);
+  nB = __builtin_amdgcn_readfirstlane(lb);
+}
+
+// 8-row groups of the tile that hold real nodes (bit g: rows 8g..8g+7): A from row 0, B from `split`.
+__device__ __forceinline__ int row_group_mask(int nA, int nB, int split) {
+  return ((1 << ((nA + 7) >> 3)) - 1) | (((1 << ((nB + 7) >> 3)) - 1) << (split >> 3));
+}
+
+// Ritz tile [node row][slot row] of one node tile, block diagonal: element (jj, rho) belongs to
+// the molecule owning BOTH rows, V[mol][local node][local slot] (zero elsewhere / beyond N, K).
+__device__ __forceinline__ float ritz_tile_elem(KArgs& a, const TileDesc& t, int jj, int rho) {
+  const bool first = jj < t.split, sfirst = rho < t.split;
+  const int row = first ? jj : jj - t.split;
+  const int k = sfirst ? rho : rho - t.split;
+  const int mol = first ? t.ta : t.tb;
+  const bool ok = sfirst == first && k < a.K && row < a.N && mol >= 0;
+  return ok ? a.V[((int64_t)mol * a.N + row) * a.K + k] : 0.0f;
+}
+
 // MODE 0 = forward; MODE 3 = forward that also stores every layer's activations (training);
 // MODE 1 = input-gradient pass (lnz_lanczosnet_input_grad): the same two chained GEMMs run on dY
 //          with per-channel transposed weights, kernel layer t = conv layer num_layer-1-t, the
@@ -173,25 +224,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   int g2mask[MT], smask[MT], nA[MT], nB[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const bool pr = td[m].tb >= 0;
-    int la = 0, lb = 0;
-    for (int i = lane; i < N; i += 64) {
-      la = a.mask[(int64_t)td[m].ta * N + i] ? i + 1 : la;
-      if (pr) lb = a.mask[(int64_t)td[m].tb * N + i] ? i + 1 : lb;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      la = max(la, __shfl_xor(la, off, 64));
-      lb = max(lb, __shfl_xor(lb, off, 64));
-    }
-    la = __builtin_amdgcn_readfirstlane(la);
-    lb = __builtin_amdgcn_readfirstlane(lb);
-    const int g0 = td[m].split >> 3;
-    nA[m] = la;
-    nB[m] = lb;
-    g2mask[m] = ((1 << ((la + 7) >> 3)) - 1) | (((1 << ((lb + 7) >> 3)) - 1) << g0);
-    const int sa = la < K ? la : K, sb = lb < K ? lb : K;
-    smask[m] = ((1 << ((sa + 7) >> 3)) - 1) | (((1 << ((sb + 7) >> 3)) - 1) << g0);
+    tile_extents(a, td[m], lane, nA[m], nB[m]);
+    g2mask[m] = row_group_mask(nA[m], nB[m], td[m].split);
+    smask[m] = row_group_mask(nA[m] < K ? nA[m] : K, nB[m] < K ? nB[m] : K, td[m].split);
   }
 
   // ---- edge-type channels that are identities on every molecule of a tile (a bond type the
@@ -215,13 +250,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   if (FK == 0) {
     for (int idx = htid; idx < MT * 32 * 32; idx += 64 * NWV) {
       const int m = idx >> 10, jj = (idx >> 5) & 31, rho = idx & 31;
-      const TileDesc t = pick(td, m);
-      const bool first = jj < t.split, sfirst = rho < t.split;
-      const int row = first ? jj : jj - t.split;
-      const int k = sfirst ? rho : rho - t.split;
-      const int mol = first ? t.ta : t.tb;
-      const bool ok = sfirst == first && k < K && row < N && mol >= 0;
-      Vm[m][jj][rho] = ok ? a.V[((int64_t)mol * N + row) * K + k] : 0.0f;
+      Vm[m][jj][rho] = ritz_tile_elem(a, pick(td, m), jj, rho);
     }
   } else {
 #pragma unroll
@@ -799,19 +828,7 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
   int nt = 0;
 #pragma unroll
   for (int m = 0; m < MOLS; ++m) {
-    const int slot = (int)blockIdx.x * 4 + 2 * half + m;
-    if (a.plan) {
-      td[m].ta = a.plan[3 * slot + 0];
-      td[m].tb = a.plan[3 * slot + 1];
-      td[m].split = a.plan[3 * slot + 2];
-    } else {
-      td[m].ta = slot < a.B ? slot : -1;
-      td[m].tb = -1;
-      td[m].split = 32;
-    }
-    td[m].ta = __builtin_amdgcn_readfirstlane(td[m].ta);
-    td[m].tb = __builtin_amdgcn_readfirstlane(td[m].tb);
-    td[m].split = __builtin_amdgcn_readfirstlane(td[m].split);
+    td[m] = load_tile_desc(a, (int)blockIdx.x * 4 + 2 * half + m);
     nt += td[m].ta >= 0 ? 1 : 0;  // slots fill from 0: a used slot 1 implies a used slot 0
   }
   if (nt == 2) {
@@ -849,31 +866,13 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
   int g2mask[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const bool pr = td[m].tb >= 0;
-    int la = 0, lb = 0;
-    for (int i = lane; i < N; i += 64) {
-      la = a.mask[(int64_t)td[m].ta * N + i] ? i + 1 : la;
-      if (pr) lb = a.mask[(int64_t)td[m].tb * N + i] ? i + 1 : lb;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      la = max(la, __shfl_xor(la, off, 64));
-      lb = max(lb, __shfl_xor(lb, off, 64));
-    }
-    la = __builtin_amdgcn_readfirstlane(la);
-    lb = __builtin_amdgcn_readfirstlane(lb);
-    g2mask[m] = ((1 << ((la + 7) >> 3)) - 1) | (((1 << ((lb + 7) >> 3)) - 1) << (td[m].split >> 3));
+    int nA, nB;
+    tile_extents(a, td[m], lane, nA, nB);
+    g2mask[m] = row_group_mask(nA, nB, td[m].split);
   }
-  // Ritz tile [node row][slot row], block diagonal (as in forward_half)
   for (int idx = htid; idx < MT * 32 * 32; idx += 64 * NWV) {
     const int m = idx >> 10, jj = (idx >> 5) & 31, rho = idx & 31;
-    const TileDesc t = pick(td, m);
-    const bool first = jj < t.split, sfirst = rho < t.split;
-    const int row = first ? jj : jj - t.split;
-    const int k = sfirst ? rho : rho - t.split;
-    const int mol = first ? t.ta : t.tb;
-    const bool ok = sfirst == first && k < K && row < N && mol >= 0;
-    Vm[m][jj][rho] = ok ? a.V[((int64_t)mol * N + row) * K + k] : 0.0f;
+    Vm[m][jj][rho] = ritz_tile_elem(a, pick(td, m), jj, rho);
   }
 
   for (int la = 0; la < a.num_layer; ++la) {
@@ -1031,19 +1030,7 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const l
   int nt = 0;
 #pragma unroll
   for (int m = 0; m < MOLS; ++m) {
-    const int slot = (int)blockIdx.x * 4 + 2 * half + m;
-    if (a.plan) {
-      td[m].ta = a.plan[3 * slot + 0];
-      td[m].tb = a.plan[3 * slot + 1];
-      td[m].split = a.plan[3 * slot + 2];
-    } else {
-      td[m].ta = slot < a.B ? slot : -1;
-      td[m].tb = -1;
-      td[m].split = 32;
-    }
-    td[m].ta = __builtin_amdgcn_readfirstlane(td[m].ta);
-    td[m].tb = __builtin_amdgcn_readfirstlane(td[m].tb);
-    td[m].split = __builtin_amdgcn_readfirstlane(td[m].split);
+    td[m] = load_tile_desc(a, (int)blockIdx.x * 4 + 2 * half + m);
     nt += td[m].ta >= 0 ? 1 : 0;
   }
   if (nt == 2) {
