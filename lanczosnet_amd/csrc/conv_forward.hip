@@ -860,7 +860,7 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
                                                const int htid, const int wave) {
   const int lane = htid & 63;
   const int j = lane & 31, hh = lane >> 5;
-  const int N = a.N, K = a.K, B = a.B, dhid = a.dhid, S = a.n_long;
+  const int K = a.K, B = a.B, dhid = a.dhid, S = a.n_long;
   const int C = a.n_short + a.n_long + a.n_edge;
 
   int g2mask[MT];
@@ -1113,22 +1113,18 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                                 (int)gs_bytes);                                                  \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(128 * NWV_), gs_bytes, s, a);                       \
   } while (0)
-  const bool k20 = a.K <= 20;  // QM8 config: 10 eigen slots per lane half
+  // diagonal gains (filter_kind 0) run in eigen space for any K <= 32: the KHT parameter only
+  // sizes the dense-filter variant's register arrays
   if (mode == 1) {
-    if (k20) LNZ_LAUNCH(4, 10, 0, 1);
-    else LNZ_LAUNCH(4, KHMAX, 0, 1);
+    LNZ_LAUNCH(4, 10, 0, 1);
   } else if (mode == 2) {
-    if (k20) LNZ_LAUNCH(4, 10, 0, 2);
-    else LNZ_LAUNCH(4, KHMAX, 0, 2);
+    LNZ_LAUNCH(4, 10, 0, 2);
   } else if (a.filter_kind == 0 && a.act_out) {
     LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
-    if (k20) LNZ_LAUNCH(4, 10, 0, 3);
-    else LNZ_LAUNCH(4, KHMAX, 0, 3);
+    LNZ_LAUNCH(4, 10, 0, 3);
   } else if (a.filter_kind == 0) {
-    if (a.dhid == 128 && k20) LNZ_LAUNCH(4, 10, 0, 0);
-    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 0, 0);
-    else if (k20) LNZ_LAUNCH(2, 10, 0, 0);
-    else LNZ_LAUNCH(2, KHMAX, 0, 0);
+    if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
+    else LNZ_LAUNCH(2, 10, 0, 0);
   } else {
     const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
     if (a.dhid == 128 && k24) LNZ_LAUNCH(4, 12, 1, 0);
