@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
   __syncthreads();
 
 #ifdef LNZ_PROFILE_PHASES
-  long long t_g1 = 0, t_g2 = 0, t_ep = 0, t_all = clock64();
+  long long t_g1 = 0, t_g2 = 0, t_ep = 0, t_pr = 0, t_all = clock64();
 #define LNZ_T0 long long _t0 = clock64();
 #define LNZ_ACC(x) { long long _t1 = clock64(); x += _t1 - _t0; _t0 = _t1; }
 #else
@@ -170,7 +170,20 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
     //   B: X rows rebuilt from their fp16 pieces; Y (rows = eigen slots) goes, split, into the
     //   other X buffer — free until this layer's epilogue
     const float* vsl = Vs;
-    if (a.n_long > 0) {
+    // gains of conv layer `ll` for the four molecules -> LDS
+    auto stage_gains = [&](int ll) {
+      for (int idx = tid; idx < M4 * a.n_long * GK; idx += 256) {
+        const int m = idx / (a.n_long * GK);
+        const int rem = idx - m * a.n_long * GK;
+        const int sc = rem / GK, k = rem - sc * GK;
+        const int mol = m == 0 ? mb[0] : m == 1 ? mb[1] : m == 2 ? mb[2] : mb[3];
+        Gl[idx] = k < K ? a.G[(((int64_t)ll * B + mol) * a.n_long + sc) * K + k] : 0.0f;
+      }
+    };
+    // Layer 0: X_0 sits in LDS only (embedding gather) -> project from its fp16 pieces.  Later
+    // layers are projected by the previous layer's epilogue from the C/D registers.
+    if (a.n_long > 0 && l == 0) {
+      LNZ_T0
 #pragma unroll
       for (int m = 0; m < M4; ++m) {
         f32x16 Y = lnz::splat16(0.0f);
@@ -200,14 +213,9 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
         // reads to the top and spills their addresses
         __builtin_amdgcn_sched_barrier(0);
       }
-      for (int idx = tid; idx < M4 * a.n_long * GK; idx += 256) {
-        const int m = idx / (a.n_long * GK);
-        const int rem = idx - m * a.n_long * GK;
-        const int sc = rem / GK, k = rem - sc * GK;
-        const int mol = m == 0 ? mb[0] : m == 1 ? mb[1] : m == 2 ? mb[2] : mb[3];
-        Gl[idx] = k < K ? a.G[(((int64_t)l * B + mol) * a.n_long + sc) * K + k] : 0.0f;
-      }
+      stage_gains(0);
       __syncthreads();
+      LNZ_ACC(t_pr)
     }
     f32x16 Tsum[M4];
 #pragma unroll
@@ -330,7 +338,6 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
               }
             }
           }
-          __syncthreads();  // every wave is done reading Y before the epilogue overwrites it
         }
         LNZ_ACC(t_g2)
         continue;
@@ -400,26 +407,54 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
       LNZ_ACC(t_g2)
     }
 
-    // ---------------- epilogue: ReLU, split, X' -> LDS (other buffer), one barrier per layer ----
+    // ---------------- epilogue ----------------------------------------------------------------
+    //   barrier: every wave is done with X (cur) and Y (nxt).  Then X' = relu(out) -> nxt (split)
+    //   and, from the same C/D registers (exact fp32, they are the B operand as they stand), the
+    //   next layer's projection Y' = V^T X' -> cur (split); its gains -> LDS; barrier.
     LNZ_T0
+    __syncthreads();
+    const bool more = l + 1 < a.num_layer && a.n_long > 0;
 #pragma unroll
     for (int m = 0; m < M4; ++m) {
       _Float16* xh = Xp(nxt, 0, m) + 32 * wave + j;
       _Float16* xl = Xp(nxt, 1, m) + 32 * wave + j;
+      f32x16 Y = lnz::splat16(0.0f);
+      const float* vp = vsl + m * 32 * VP + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int r = 4 * g; r < 4 * g + 4; ++r) out[m][r] = fmaxf(out[m][r], 0.0f);
+        if (more && 4 * g < g2steps[m]) {  // node rows beyond the molecule have zero Ritz rows
+#pragma unroll
+          for (int r = 4 * g; r < 4 * g + 4; ++r)
+            Y = lnz::mfma32(vp[lnz::cd_row(r, hh) * VP], out[m][r], Y);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int row = lnz::cd_row(r, hh);
-        split_store(xh + row * P16, xl + row * P16, fmaxf(out[m][r], 0.0f));
+        const int row = lnz::cd_row(r, hh);
+        split_store(xh + row * P16, xl + row * P16, out[m][r]);
+      }
+      if (more) {
+        _Float16* yh = Xp(cur, 0, m) + 32 * wave + j;
+        _Float16* yl = Xp(cur, 1, m) + 32 * wave + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = lnz::cd_row(r, hh);
+          split_store(yh + row * P16, yl + row * P16, Y[r]);
+        }
       }
     }
+    if (more) stage_gains(l + 1);
     __syncthreads();
     cur = nxt;
     LNZ_ACC(t_ep)
   }
 #ifdef LNZ_PROFILE_PHASES
   if (a.state_out && lane == 0 && blockIdx.x < 8) {
-    float* d = a.state_out + ((int64_t)B * 32 * 128) + (blockIdx.x * 4 + wave) * 4;
+    float* d = a.state_out + ((int64_t)B * 32 * 128) + (blockIdx.x * 8 + wave) * 8;  // tools/phase_probe.py layout
     d[0] = (float)t_g1; d[1] = (float)t_g2; d[2] = (float)t_ep; d[3] = (float)(clock64() - t_all);
+    d[4] = (float)t_pr;
   }
 #endif
 
