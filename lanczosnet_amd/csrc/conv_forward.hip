@@ -23,12 +23,13 @@
 //   short-diffusion channels apply M = L_0 p times to Z_c in registers (same chaining).
 //
 // The long-scale spectral channels  sum_s V diag(g_s) V^T X W_s^T  run in EIGEN SPACE (see the
-// comment above forward_half): Y = V^T X once per layer, GEMM1 of every channel on Y
+// comment above forward_half): Y = V^T X once per layer (from the previous epilogue's C/D
+// registers; from LDS for the first layer), GEMM1 of every channel on Y
 // with the slot rows scaled by the gains, one lift back through V — the filters L_s never exist.
 //
 // So `cat(msg)` (model/lanczos_net.py:180), the [B,N,N,S] filter stack (:123) and the strided
 // `L[:,:,:,ii]` clones (:172-178) never exist; per layer the only LDS traffic is X / Y and there
-// are three __syncthreads per layer (one without spectral channels).
+// are two __syncthreads per layer (one without spectral channels).
 // HBM bytes per molecule: Lp 28,672 + V 2,560 + G 4,480 + ids 256 + mask 32 in, 64 out; the
 // 7.4 MB of packed weights are shared by all workgroups and stay L2 / Infinity-Cache resident.
 #include "common.hpp"
@@ -359,13 +360,14 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 
     // ---------------- eigen-space projection Y = V^T X (long channels, FK = 0) ----------------
     //   A operand: V^T fragments, lane (slot row j, hh) step r = Vm[node row cd_row(r,hh)][slot j];
-    //   B operand: X rows in the same order.  Forward modes put
-    //   Y where the layer's output will go (the other X buffer is free until the epilogue) so the
-    //   long channels' GEMM1 reads it as A operand; MODE 2 keeps this wave's block in registers.
+    //   B operand: X rows in the same order.  Y lives in the other X buffer (free until the
+    //   epilogue), where the long channels' GEMM1 reads it as A operand.  Only the FIRST layer is
+    //   projected here, from LDS: every later layer's Y is produced by the previous epilogue
+    //   straight from its C/D registers.  MODE 2 keeps this wave's block in registers.
     const int nxt = cur ^ 1;
     LNZ_T0
     f32x16 Yblk[(ES && MODE == 2) ? MT : 1];
-    if (es) {
+    if (es && (MODE == 2 || l == 0)) {
       if (32 * wave < din || MODE == 2) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -571,8 +573,6 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
               }
             }
           }
-          // every wave is done reading Y before the epilogue overwrites it
-          __syncthreads();
           LNZ_ACC(t_mb)
         } else {
           // messages g_s * Y lifted back through V, one per channel
@@ -685,8 +685,11 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     // ---------------- epilogue: X' -> LDS (other buffer), one barrier per layer -------------
     //   MODE 0: ReLU (+ the activation store training asks for)
     //   MODE 1: dY_{la-1} = dX_la * [X_la > 0] -> LDS and dy[la-1]; the last iteration writes dX_0
+    //   eigen space: a barrier first (every wave is done with X and Y), then X' goes where Y was
+    //   and the NEXT layer's projection Y' = V^T X' — computed from the same C/D registers, which
+    //   are its B operand as they stand — goes where X was.
     LNZ_TR
-    if (es && MODE != 2 && !active) __syncthreads();
+    if (es && MODE != 2) __syncthreads();
     if (MODE != 2 && active) {
       const int col = 32 * wave + j;
 #pragma unroll
@@ -723,7 +726,23 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             for (int u = 0; u < 4; ++u) p[u * a.bwd_din0] = v[u];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) Xs[nxt][m][8 * g + 4 * hh + u][col] = v[u];
+          for (int u = 0; u < 4; ++u) {
+            Xs[nxt][m][8 * g + 4 * hh + u][col] = v[u];
+            out[m][4 * g + u] = v[u];
+          }
+        }
+        if (es && l + 1 < n_iter) {
+          f32x16 Y = lnz::splat16(0.0f);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if ((g2mask[m] >> g) & 1) {
+#pragma unroll
+              for (int r = 4 * g; r < 4 * g + 4; ++r)
+                Y = lnz::mfma32(Vm[m][lnz::cd_row(r, hh)][j], out[m][r], Y);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Xs[cur][m][lnz::cd_row(r, hh)][col] = Y[r];
         }
       }
     }
@@ -837,9 +856,10 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
     const TileDesc t1[1] = {td[0]};
     forward_half<NWV, KHT, FK, 1, MODE>(a, t1, Xs[half], Vm[half], Gs, htid, wave);
   } else {
-    // keep the barrier count of the other half (eigen-space layers have three barriers)
-    const int per = (FK == 0 && a.n_long > 0) ? 3 : 1;
-    const int nb = MODE == 2 ? 2 : per * a.num_layer + 1;
+    // keep the barrier count of the other half: setup, (eigen space: the first layer's
+    // projection,) and per layer one barrier (eigen space: two)
+    const bool es = FK == 0 && a.n_long > 0;
+    const int nb = MODE == 2 ? 2 : (es ? 2 : 1) * a.num_layer + 1 + (es ? 1 : 0);
     for (int l = 0; l < nb; ++l) __syncthreads();
   }
 }
