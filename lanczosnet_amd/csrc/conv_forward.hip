@@ -471,11 +471,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     };
 
     // GEMM1 of one channel into Z: Z_m (+)= [diag(g)] A_m W_c^T, A rows from `rows` (X or Y).
-    // SC: scale this lane's A-operand row by gl[m] (eigen-space long channels).
     f32x16 Z[MT];
-    float gl[MT];
-    auto gemm1_rd = [&](auto scaled, auto depth, const lds_cptr (&rows)[MT]) {
-      constexpr bool SC = decltype(scaled)::value;
+    auto gemm1_rd = [&](auto depth, const lds_cptr (&rows)[MT]) {
       constexpr int RD = decltype(depth)::value;  // ring slots = steps per unrolled body
       lds_cptr xq[MT];
       float4 acur[MT];
@@ -500,15 +497,6 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           // the unrolled body to its end and waits vmcnt(0) at the top of the next iteration)
           __builtin_amdgcn_sched_barrier(0);
           const float4 bv = ring[u4];
-          if (SC) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              acur[m].x *= gl[m];
-              acur[m].y *= gl[m];
-              acur[m].z *= gl[m];
-              acur[m].w *= gl[m];
-            }
-          }
 #pragma unroll
           for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
 #pragma unroll
@@ -526,9 +514,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         wp += RD * 64;
       }
     };
-    auto gemm1 = [&](auto scaled, const lds_cptr (&rows)[MT]) {
-      if (deep) gemm1_rd(scaled, std::integral_constant<int, 8>{}, rows);
-      else gemm1_rd(scaled, std::integral_constant<int, 4>{}, rows);
+    auto gemm1 = [&](const lds_cptr (&rows)[MT]) {
+      if (deep) gemm1_rd(std::integral_constant<int, 8>{}, rows);
+      else gemm1_rd(std::integral_constant<int, 4>{}, rows);
     };
 
     // ---------------- eigen-space block: all long channels of the layer ----------------
@@ -546,16 +534,30 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     if (es && active) {
       LNZ_T0
       if (MODE != 2 && a.n_short > 0) prime_ring(a.n_short * Q);
-        const float* gp = gsl + j;
         if (MODE != 2) {
-          // Z_m = sum_s diag(g_s) Y_m W_s^T: the A-operand rows (slots) carry the gains, one
-          // accumulator runs over the channels; then out_m += V_m Z_m and the Y buffer is released
+          // T_m = sum_s diag(g_s) (Y_m W_s^T): each channel's GEMM1 runs unscaled — a VALU
+          // multiply in front of every MFMA costs ~40 cycles per MFMA (tools/mfma_issue_probe.hip)
+          // — and its C/D rows (= eigen slots) are scaled into T by 16 FMAs per tile; then
+          // out_m += V_m T_m
+          f32x16 T[MT];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
+          for (int m = 0; m < MT; ++m) T[m] = lnz::splat16(0.0f);
           for (int s = 0; s < a.n_long; ++s) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) gl[m] = gp[(m * a.n_long + s) * 32];
-            gemm1(std::true_type{}, yrow);
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
+            gemm1(yrow);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float* g4 = gsl + (m * a.n_long + s) * 32 + 4 * hh;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 gv = *reinterpret_cast<const float4*>(g4 + 8 * g);
+                T[m][4 * g + 0] = fmaf(gv.x, Z[m][4 * g + 0], T[m][4 * g + 0]);
+                T[m][4 * g + 1] = fmaf(gv.y, Z[m][4 * g + 1], T[m][4 * g + 1]);
+                T[m][4 * g + 2] = fmaf(gv.z, Z[m][4 * g + 2], T[m][4 * g + 2]);
+                T[m][4 * g + 3] = fmaf(gv.w, Z[m][4 * g + 3], T[m][4 * g + 3]);
+              }
+            }
           }
           LNZ_ACC(t_g1)
 #pragma unroll
@@ -566,10 +568,10 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             for (int t4 = 0; t4 < 4; ++t4) {
               if ((smask[m] >> t4) & 1) {
                 const float4 v = *reinterpret_cast<const float4*>(vs + 8 * t4);
-                out[m] = lnz::mfma32(v.x, Z[m][4 * t4 + 0], out[m]);
-                out[m] = lnz::mfma32(v.y, Z[m][4 * t4 + 1], out[m]);
-                out[m] = lnz::mfma32(v.z, Z[m][4 * t4 + 2], out[m]);
-                out[m] = lnz::mfma32(v.w, Z[m][4 * t4 + 3], out[m]);
+                out[m] = lnz::mfma32(v.x, T[m][4 * t4 + 0], out[m]);
+                out[m] = lnz::mfma32(v.y, T[m][4 * t4 + 1], out[m]);
+                out[m] = lnz::mfma32(v.z, T[m][4 * t4 + 2], out[m]);
+                out[m] = lnz::mfma32(v.w, T[m][4 * t4 + 3], out[m]);
               }
             }
           }
@@ -615,7 +617,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       // ---------------- GEMM1: Z_m = X_m W_c^T ----------------
 #pragma unroll
       for (int m = 0; m < MT; ++m) Z[m] = MODE == 2 ? Xblk[MODE == 2 ? m : 0] : lnz::splat16(0.0f);
-      if (MODE != 2) gemm1(std::false_type{}, xrow);
+      if (MODE != 2) gemm1(xrow);
 
       LNZ_ACC(t_g1)
       // ---------------- per tile: M_c fragments, next operands, GEMM2 ----------------

@@ -6,7 +6,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
 
-// MODE bit0: global ring loads (prefetch distance 3), bit1: ds_read of next A, bit2: sched_barriers
+// MODE bit0: global ring loads (prefetch distance 3), bit1: ds_read of next A, bit2: sched_barriers,
+// bit3: A operand scaled on the VALU before every MFMA (the eigen-space GEMM1's gain scaling)
 template <int MODE>
 __global__ __launch_bounds__(128) void probe(const float4* __restrict__ w, float* out, long long* cyc, int iters) {
   __shared__ __attribute__((aligned(16))) float xs[32 * 132];
@@ -34,10 +35,23 @@ __global__ __launch_bounds__(128) void probe(const float4* __restrict__ w, float
       }
       if (MODE & 2) anext = *reinterpret_cast<const float4*>(xr + 8 * ((it + u4 + 1) & 15));
       if (MODE & 4) __builtin_amdgcn_sched_barrier(0);
+      float4 acur2 = acur;
+      if (MODE & 8) {
+        const float g0 = out[lane], g1 = out[lane + 64];  // two "gains" (tile 0, tile 1)
+        acur.x *= g0; acur.y *= g0; acur.z *= g0; acur.w *= g0;
+        acur2.x *= g1; acur2.y *= g1; acur2.z *= g1; acur2.w *= g1;
+      }
+      if (MODE & 8) {
+        Z[0] = MF(acur.x, ring[u4][0].x, Z[0]); Z[1] = MF(acur2.x, ring[u4][0].x, Z[1]);
+        Z[0] = MF(acur.y, ring[u4][0].y, Z[0]); Z[1] = MF(acur2.y, ring[u4][0].y, Z[1]);
+        Z[0] = MF(acur.z, ring[u4][0].z, Z[0]); Z[1] = MF(acur2.z, ring[u4][0].z, Z[1]);
+        Z[0] = MF(acur.w, ring[u4][0].w, Z[0]); Z[1] = MF(acur2.w, ring[u4][0].w, Z[1]);
+      } else {
       Z[0] = MF(acur.x, ring[u4][0].x, Z[0]); Z[1] = MF(acur.x, ring[u4][1].x, Z[1]);
       Z[0] = MF(acur.y, ring[u4][0].y, Z[0]); Z[1] = MF(acur.y, ring[u4][1].y, Z[1]);
       Z[0] = MF(acur.z, ring[u4][0].z, Z[0]); Z[1] = MF(acur.z, ring[u4][1].z, Z[1]);
       Z[0] = MF(acur.w, ring[u4][0].w, Z[0]); Z[1] = MF(acur.w, ring[u4][1].w, Z[1]);
+      }
       acur = anext;
       if (MODE & 4) __builtin_amdgcn_sched_barrier(0);
     }
@@ -77,6 +91,8 @@ int main() {
     run<6>("ds_read, sched_barrier", blocks, w, out, cyc);
     run<7>("ring + ds_read, sched_barrier", blocks, w, out, cyc);
     run<4>("mfma only, sched_barrier", blocks, w, out, cyc);
+    run<15>("ring + ds_read + scaled A, sched_b", blocks, w, out, cyc);
+    run<14>("ds_read + scaled A, sched_barrier", blocks, w, out, cyc);
   }
   return 0;
 }
