@@ -583,17 +583,27 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             for (int m = 0; m < MT; ++m) {
               const float* g4 = gsl + (m * a.n_long + s) * 32 + 4 * hh;
               const float* vs = &Vm[m][j][4 * hh];
+              // scale first, then the MFMA chain: a VALU multiply in front of every MFMA stalls
+              // the matrix pipe (tools/mfma_issue_probe.hip)
+              const f32x16& Y = Yblk[(ES && MODE == 2) ? m : 0];
+              f32x16 T;
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) {
+                const float4 g = *reinterpret_cast<const float4*>(g4 + 8 * t4);
+                T[4 * t4 + 0] = g.x * Y[4 * t4 + 0];
+                T[4 * t4 + 1] = g.y * Y[4 * t4 + 1];
+                T[4 * t4 + 2] = g.z * Y[4 * t4 + 2];
+                T[4 * t4 + 3] = g.w * Y[4 * t4 + 3];
+              }
               f32x16 P = lnz::splat16(0.0f);
 #pragma unroll
               for (int t4 = 0; t4 < 4; ++t4) {
                 if ((smask[m] >> t4) & 1) {
                   const float4 v = *reinterpret_cast<const float4*>(vs + 8 * t4);
-                  const float4 g = *reinterpret_cast<const float4*>(g4 + 8 * t4);
-                  const f32x16& Y = Yblk[(ES && MODE == 2) ? m : 0];
-                  P = lnz::mfma32(v.x, g.x * Y[4 * t4 + 0], P);
-                  P = lnz::mfma32(v.y, g.y * Y[4 * t4 + 1], P);
-                  P = lnz::mfma32(v.z, g.z * Y[4 * t4 + 2], P);
-                  P = lnz::mfma32(v.w, g.w * Y[4 * t4 + 3], P);
+                  P = lnz::mfma32(v.x, T[4 * t4 + 0], P);
+                  P = lnz::mfma32(v.y, T[4 * t4 + 1], P);
+                  P = lnz::mfma32(v.z, T[4 * t4 + 2], P);
+                  P = lnz::mfma32(v.w, T[4 * t4 + 3], P);
                 }
               }
               store_message(a.n_short + s, m, P);

@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256) void lanczosnet_forward_f16x3_kernel(const lnz
       f32x16 Y = lnz::splat16(0.0f);
       const float* vp = vsl + m * 32 * VP + j;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int r = 0; r < 16; ++r) out[m][r] = fmaxf(out[m][r], 0.0f);
 #pragma unroll
-        for (int r = 4 * g; r < 4 * g + 4; ++r) out[m][r] = fmaxf(out[m][r], 0.0f);
+      for (int g = 0; g < 4; ++g) {
         if (more && 4 * g < g2steps[m]) {  // node rows beyond the molecule have zero Ritz rows
 #pragma unroll
           for (int r = 4 * g; r < 4 * g + 4; ++r)
