@@ -488,16 +488,27 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
                                    rows=rows)
         act = torch.zeros((module.num_layer, B, 32, plan['dhid']), dtype=torch.float32,
                           device=Vc.device)
+        # node extents and their total: the backward sizes its compact message matrix by the
+        # number of real node rows.  The count travels to the host asynchronously, under the
+        # forward kernel, so the backward never has to drain the GPU to learn a shape.
+        N = Vc.shape[1]
+        n_mol = ((mask_u8 != 0).long() *
+                 torch.arange(1, N + 1, device=Vc.device).view(1, N)).amax(dim=1)
+        rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
+        rtot.copy_(n_mol.sum().view(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
         score = ops.lanczosnet_forward(plan, node_feat, Lp, Vc, G, mask_u8, tiling=tiles,
                                        act_out=act)
         ctx.module, ctx.cap = module, tiles[1]
-        ctx.save_for_backward(node_feat, D, Vc, mask_u8, Lp, G, act, tiles[0])
+        ctx.rtot, ctx.rtot_ready = rtot, ev
+        ctx.save_for_backward(node_feat, D, Vc, mask_u8, Lp, G, act, tiles[0], n_mol)
         return score
 
     @staticmethod
     def backward(ctx, grad_score):
         m = ctx.module
-        node_feat, D, V, mask_u8, Lp, G, act, tile_buf = ctx.saved_tensors
+        node_feat, D, V, mask_u8, Lp, G, act, tile_buf, n_mol = ctx.saved_tensors
         tiles = (tile_buf, ctx.cap)
         plan = m._plan_backward()
         B, N, K = V.shape
@@ -535,11 +546,14 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l, over
         #      the REAL node rows only (half of the padded rows are empty): compact row numbering
         # node extent (last real node + 1) — what the kernels size a molecule by
-        n_mol = ((mask_u8 != 0).long() * torch.arange(1, N + 1, device=dev).view(1, N)).amax(dim=1)
-        row_off = (torch.cumsum(n_mol, 0) - n_mol).contiguous()                  # int64 [B]
-        node = torch.arange(32, device=dev).view(1, 32)
-        real = (node < n_mol.view(B, 1)).view(-1).nonzero().view(-1)             # sync: row count
-        R_tot = real.numel()
+        row_end = torch.cumsum(n_mol, 0)
+        row_off = (row_end - n_mol).contiguous()                                 # int64 [B]
+        ctx.rtot_ready.synchronize()       # recorded before the forward kernel: long complete
+        R_tot = int(ctx.rtot[0])
+        # compact row r -> padded row (molecule * 32 + node), without a data-dependent shape
+        r = torch.arange(R_tot, device=dev)
+        mol_of_r = torch.searchsorted(row_end, r, right=True)
+        real = mol_of_r * 32 + (r - row_off[mol_of_r])
         msg_buf = torch.empty((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
         for la in range(Lnum):
             d = din0p if la == 0 else dh
