@@ -299,7 +299,9 @@ def main():
         'metric': 'molecules/sec LanczosNet forward, QM8 batch=1024',
         'value': round(value, 1), 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32' if args.gemm == 'fp32' else 'f16x3 (split fp16 products, f32 accumulate)',
+        'data': 'synthetic',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
                                'fp32, 7x128 layers, 1xMI355X per rank; step = [pack L + batch plan + '
                                'Lanczos/QL Ritz pairs + spectral gains] (one launch) + fused forward' % (B, L.shape[1]),
