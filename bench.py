@@ -304,7 +304,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
                                'fp32, 7x128 layers, 1xMI355X per rank; step = [pack L + batch plan + '
-                               'Lanczos/QL Ritz pairs + spectral gains] (one launch) + fused forward' % (B, L.shape[1]),
+                               'Lanczos + tridiagonal eigensolver (Ritz pairs)] (one launch) + spectral gains + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, async score all-gather per step)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
         'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',
