@@ -329,7 +329,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     // 7 steps: with one tile a step is only 4 MFMAs, and three steps do not cover an L2 miss);
     // the narrow first layer keeps the 4-slot rotation.
     float4 ring[8];
-    const bool deep = MODE == 0 && (Q & 7) == 0;  // the other modes have no registers to spare
+    const bool deep = (MODE == 0 || MODE == 3) && (Q & 7) == 0;  // the backward modes have no registers to spare
     if (MODE != 2 && active) {
 #pragma unroll
       for (int sl = 0; sl < 7; ++sl)
@@ -636,8 +636,15 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         // M_c is the identity on this tile's molecules: out += Z_c (bit-identical on their nodes)
         const bool idc = FWD && !is_long && c >= a.n_short &&
                          ((idm[m] >> (c - a.n_short - a.n_long)) & 1);
+        // FK = 0: the fragments fetched one channel ahead are used in place and the next
+        // channel's are fetched once this tile's MFMAs are issued (no register copy in front of
+        // the GEMM2 chain; they still have a whole GEMM1 to land)
+        constexpr bool INPLACE = FK == 0;
         f32x16 Mf;
-        if (is_long) {
+        if (INPLACE) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Mf[r] = 0.0f;  // unused (keeps the type uniform below)
+        } else if (is_long) {
           // FK = 1: R[k1][n] = sum_k2 DD[k1][k2] Q[n][k2], L_s[i][n] = sum_k1 Q[i][k1] R[k1][n]
           f32x16 acc = lnz::splat16(0.0f);
           f32x16 R = lnz::splat16(0.0f);
@@ -650,10 +657,11 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 #pragma unroll
           for (int r = 0; r < 16; ++r) Mf[r] = mop[m][r];
         }
-        {
+        if (!INPLACE) {
           const int cn = (es && c + 1 == a.n_short) ? c_end : c + 1;
           if (cn < C) fetch_m_operands(cn, m);
         }
+#define LNZ_MF(r) (INPLACE ? mop[m][r] : Mf[r])
 
         // short diffusion: Z <- L_0^(p-1) Z
         if (c < a.n_short) {
@@ -662,7 +670,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
             f32x16 T = lnz::splat16(0.0f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              if ((g2mask[m] >> (r >> 2)) & 1) T = lnz::mfma32(Mf[r], Z[m][r], T);
+              if ((g2mask[m] >> (r >> 2)) & 1) T = lnz::mfma32(LNZ_MF(r), Z[m][r], T);
             }
             Z[m] = T;
           }
@@ -677,17 +685,22 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         for (int r = 0; r < 16; r += 4) {
           if (!idc && ((g2mask[m] >> (r >> 2)) & 1)) {
             if (MODE == 2) {
-              P = lnz::mfma32(Mf[r + 0], Z[m][r + 0], P);
-              P = lnz::mfma32(Mf[r + 1], Z[m][r + 1], P);
-              P = lnz::mfma32(Mf[r + 2], Z[m][r + 2], P);
-              P = lnz::mfma32(Mf[r + 3], Z[m][r + 3], P);
+              P = lnz::mfma32(LNZ_MF(r + 0), Z[m][r + 0], P);
+              P = lnz::mfma32(LNZ_MF(r + 1), Z[m][r + 1], P);
+              P = lnz::mfma32(LNZ_MF(r + 2), Z[m][r + 2], P);
+              P = lnz::mfma32(LNZ_MF(r + 3), Z[m][r + 3], P);
             } else {
-              out[m] = lnz::mfma32(Mf[r + 0], Z[m][r + 0], out[m]);
-              out[m] = lnz::mfma32(Mf[r + 1], Z[m][r + 1], out[m]);
-              out[m] = lnz::mfma32(Mf[r + 2], Z[m][r + 2], out[m]);
-              out[m] = lnz::mfma32(Mf[r + 3], Z[m][r + 3], out[m]);
+              out[m] = lnz::mfma32(LNZ_MF(r + 0), Z[m][r + 0], out[m]);
+              out[m] = lnz::mfma32(LNZ_MF(r + 1), Z[m][r + 1], out[m]);
+              out[m] = lnz::mfma32(LNZ_MF(r + 2), Z[m][r + 2], out[m]);
+              out[m] = lnz::mfma32(LNZ_MF(r + 3), Z[m][r + 3], out[m]);
             }
           }
+        }
+#undef LNZ_MF
+        if (INPLACE) {
+          const int cn = (es && c + 1 == a.n_short) ? c_end : c + 1;
+          if (cn < C) fetch_m_operands(cn, m);
         }
         if (MODE == 2) store_message(c, m, P);
       }
