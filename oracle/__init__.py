@@ -24,3 +24,4 @@ from .collate import collate_packed, dense_from_edges  # noqa: F401
 from .segment_sum import (unsorted_segment_sum_forward_gpu_semantics,  # noqa: F401
                           unsorted_segment_sum_backward_gpu_semantics,
                           unsorted_segment_sum_forward_cpu_semantics)
+from .baselines import baseline_forward  # noqa: F401
