@@ -136,26 +136,47 @@ def forward_sharded(forward_fn, batch, n_global, label_key='label', group=None):
     return full, loss
 
 
-def all_reduce_gradients(params, local_count, group=None):
+def all_reduce_gradients(params, local_count, group=None, bucket_bytes=256 << 20):
     """Data-parallel gradient exchange for training (runner/qm8_runner.py:216-248 under
     `nn.DataParallel`, :62): every rank holds d(mean loss over ITS shard)/dθ; the gradient of the
-    mean over the whole batch is the shard-size-weighted average.  All gradients travel as ONE flat
-    fp32 bucket (LanczosNet: 7.4 MB) — a single ring all-reduce, which on point-to-point xGMI is
-    bound by one link, instead of one latency-bound collective per parameter.
+    mean over the whole batch is the shard-size-weighted average.  Gradients travel as flat fp32
+    buckets of at most `bucket_bytes` (LanczosNet: 7.4 MB, one bucket; AdaLanczosNet: ~1.4 GB,
+    six) — few large ring all-reduces, which on point-to-point xGMI are bound by one link, instead
+    of one latency-bound collective per parameter; the buckets are issued asynchronously and
+    collected in order, so the copy-back of bucket i overlaps the wire time of bucket i+1.
 
     params: iterable of parameters whose `.grad` is replaced in place; local_count: number of
     molecules (rows of the loss mean) this rank contributed."""
     params = [p for p in params if p.grad is not None]
     if not params:
         return
-    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
-    cnt = torch.tensor([float(local_count)], dtype=torch.float32, device=flat.device)
-    buf = torch.cat([flat * cnt, cnt])
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    flat = buf[:-1] / buf[-1]
-    off = 0
+    dev = params[0].grad.device
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    cnt = torch.tensor([float(local_count)], dtype=torch.float32, device=dev)
+    total = cnt.clone()
+    if multi:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    # greedy buckets in parameter order
+    buckets, cur, cur_bytes = [], [], 0
     for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+        nb = p.grad.numel() * 4
+        if cur and cur_bytes + nb > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nb
+    buckets.append(cur)
+    pending = []
+    for bk in buckets:
+        flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in bk]) * cnt
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) if multi else None
+        pending.append((bk, flat, work))
+    for bk, flat, work in pending:
+        if work is not None:
+            work.wait()
+        flat = flat / total
+        off = 0
+        for p in bk:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
