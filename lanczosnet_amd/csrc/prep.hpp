@@ -64,7 +64,8 @@ __device__ __forceinline__ void pack_laplacian_body(
 // ---- tile plan: pairing of small molecules + per-workgroup dealing ------------------------------
 // The forward kernels work on 32-row node tiles.  Small molecules share a tile (block-diagonal
 // operators): an (<= 8)-node molecule rides with a 17..24-node one (split row 8), two (<= 16)-node
-// molecules split at row 16.  For a QM8-like size range that turns B molecules into ~0.74 B tiles.
+// molecules split at row 16.  For a QM8-like size range that turns B molecules into ~0.74 B tiles
+// (only when that shortens the busiest CU's queue: see depth_for below).
 //
 // A forward launch is ONE round of workgroups when B <= 4 tiles x CUs, so it lasts as long as the
 // busiest CU: the plan therefore fixes the number of workgroups W (one per CU while the tiles fit
@@ -117,13 +118,22 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
   }
   __syncthreads();
   const int c8 = cls[0], c16 = cls[1] - cls[0], c24 = cls[2] - cls[1], c32 = cls[3] - cls[2];
-  const int X = allow_pairs ? (c8 < c24 ? c8 : c24) : 0;       // 8|24 pairs
+  // rounds R = ceil(T / (4 CUs)); R workgroups per CU hold floor/ceil(T / W) <= 4 tiles each
+  auto n_wg_for = [&](int t) { return t < n_cu ? t : ((t + 4 * n_cu - 1) / (4 * n_cu)) * n_cu; };
+  // tiles a CU runs one after the other: rounds x the fullest workgroup of a round
+  auto depth_for = [&](int t) {
+    const int w = n_wg_for(t);
+    return ((w + n_cu - 1) / n_cu) * ((t + w - 1) / w);
+  };
+  int X = allow_pairs ? (c8 < c24 ? c8 : c24) : 0;             // 8|24 pairs
+  int P2 = allow_pairs ? (c8 - X + c16) / 2 : 0;               // 16|16 pairs
+  // A pair tile costs more than a single one (more node-row groups and eigen slots are live),
+  // so pairing only pays when it takes a tile off the busiest CU's queue
+  if (depth_for(B - X - P2) >= depth_for(B)) X = 0, P2 = 0;
   const int pool = c8 - X + c16;                               // remaining (<= 16)-node molecules
-  const int P2 = allow_pairs ? pool / 2 : 0;                   // 16|16 pairs
   const int lone = pool - 2 * P2;                              // small singles (0/1, or all)
   const int T = B - X - P2;
-  // rounds R = ceil(T / (4 CUs)); R workgroups per CU hold floor/ceil(T / W) <= 4 tiles each
-  const int W = T < n_cu ? T : ((T + 4 * n_cu - 1) / (4 * n_cu)) * n_cu;
+  const int W = n_wg_for(T);
   if (tid == 0) *n_wg = W;
   // ascending cost order: small singles, 17..24 singles, >= 25 singles, 16|16 pairs, 8|24 pairs
   const int o24 = lone, o32 = o24 + (c24 - X), oP2 = o32 + c32, oX = oP2 + P2;
