@@ -534,28 +534,33 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
                                             const int n, const int r, const int h) {
   constexpr int LD = Ritz32Smem::LD;
   // ---- d, e -> LDS (broadcast reads); negligible couplings split the matrix
-  {
-    const double dn = __shfl_down(dreg, 1, 64);
-    const bool live = r < n - 1 && fabs(ereg) > kEps * (fabs(dreg) + fabs(dn));
-    if (h == 0) {
-      sm.za[r] = r < n ? dreg : 0.0;
-      sm.zb[r] = live ? ereg : 0.0;
-      sm.ca[r] = live ? ereg * ereg : 0.0;
-    }
+  const double dn = __shfl_down(dreg, 1, 64);
+  const bool live = r < n - 1 && fabs(ereg) > kEps * (fabs(dreg) + fabs(dn));
+  if (h == 0) {
+    sm.za[r] = r < n ? dreg : 0.0;
+    sm.zb[r] = live ? ereg : 0.0;
+    sm.ca[r] = live ? ereg * ereg : 0.0;
   }
   __syncthreads();
   const bool act = r < n;
-  // block [s, t] of this lane's index; the lane owns the (r - s)-th eigenvalue of that block
+  // block [s, t] of this lane's index; the lane owns the (r - s)-th eigenvalue of that block.
+  // Bit i of `cut` = coupling e_i (between rows i and i+1) is dead: s is one past the highest cut
+  // below r, t the lowest cut at or above r (bit n-1 is always set) — bit scans, not LDS walks.
+  const unsigned cut = (unsigned)__ballot(h == 0 && !live);
   int s = r, t = r;
   if (act) {
-    while (s > 0 && sm.zb[s - 1] != 0.0) --s;
-    while (t < n - 1 && sm.zb[t] != 0.0) ++t;
+    const unsigned below = cut & ((1u << r) - 1u);          // cuts at e_0 .. e_{r-1}
+    s = below ? 32 - __clz(below) : 0;
+    const unsigned above = cut & ~((1u << r) - 1u);         // cuts at e_r ..
+    t = above ? __ffs(above) - 1 : n - 1;
+    t = t > n - 1 ? n - 1 : t;
   }
-  double gmax = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double el = i > 0 ? fabs(sm.zb[i - 1]) : 0.0;
-    gmax = fmax(gmax, fabs(sm.za[i]) + el + fabs(sm.zb[i]));
-  }
+  // Gershgorin bound of the spectrum: one row per lane, wave maximum
+  const double e_live = live ? fabs(ereg) : 0.0;
+  const double e_prev = __shfl_up(e_live, 1, 64);
+  double gmax = act ? fabs(dreg) + ((r & 31) > 0 ? e_prev : 0.0) + e_live : 0.0;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
   const double gsc = gmax > 0.0 ? gmax : 1.0;
   bool bail = false;
   double blo = 0.0, bhi = 0.0;
