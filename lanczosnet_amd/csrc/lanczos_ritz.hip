@@ -805,19 +805,18 @@ __device__ __forceinline__ void lanczos_ritz32_body(
         double colsq[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) colsq[t] = sm.Qt[(16 * h + t) * LD + r];
-        double res = 1.0 - xhalf_sum(dot16(colsq, colsq));
-        sm.zb[r] = r < n ? res : -1.0;
-        __syncthreads();
-        int cand = 0;
-        double best = sm.zb[0];
-        for (int x = 1; x < n; ++x) {
-          double vv = sm.zb[x];
-          if (vv > best) {
-            best = vv;
-            cand = x;
-          }
+        const double res = 1.0 - xhalf_sum(dot16(colsq, colsq));
+        // arg max over the rows (lowest index on ties), by lane shuffles inside each half
+        double best = r < n ? res : -1.0;
+        int cand = r;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          const double ob = __shfl_xor(best, off, 64);
+          const int oc = __shfl_xor(cand, off, 64);
+          const bool take = ob > best || (ob == best && oc < cand);
+          best = take ? ob : best;
+          cand = take ? oc : cand;
         }
-        __syncthreads();
         w = (r == cand) ? 1.0 : 0.0;
         (void)cgs2_32(sm, w, 0, r, h);
         fresh = true;
