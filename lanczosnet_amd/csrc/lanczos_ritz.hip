@@ -931,15 +931,16 @@ __device__ __forceinline__ void lanczos_ritz32_body(
 #endif
 
     // ---- order by descending |lambda| (ties: ascending lambda, then index) — see generic kernel
-    if (lane < n) {
-      double di = sm.dd[lane], ai = fabs(di);
+    {
+      // every lane compares its eigenvalue with the others' through lane reads (no LDS walk)
+      const double di = lane < n ? sm.dd[lane] : 0.0, ai = fabs(di);
       int rank = 0;
       for (int jj = 0; jj < n; ++jj) {
-        double dj = sm.dd[jj], aj = fabs(dj);
-        bool before = (aj > ai) || (aj == ai && (dj < di || (dj == di && jj < lane)));
+        const double dj = readlane_f64(di, jj), aj = fabs(dj);
+        const bool before = (aj > ai) || (aj == ai && (dj < di || (dj == di && jj < lane)));
         rank += before ? 1 : 0;
       }
-      sm.perm[rank] = lane;
+      if (lane < n) sm.perm[rank] = lane;
     }
     __syncthreads();
     if (lane < kk) {
@@ -960,11 +961,18 @@ __device__ __forceinline__ void lanczos_ritz32_body(
 
   for (int k = lane; k < K; k += 64) D[(int64_t)b * K + k] = k < kk ? (float)sm.dd[sm.perm[k]] : 0.0f;
   float* Vb = V + (int64_t)b * N * K;
-  for (int idx = lane; idx < N * K; idx += 64) {
-    int rr = idx / K, k = idx - rr * K;
-    float v = 0.0f;
-    if (rr < n && k < kk) v = sm.sgn[k] * (float)sm.Qt[sm.perm[k] * LD + rr];
-    Vb[idx] = v;
+  {
+    // idx = rr * K + k walks by 64 per pass: one division up front, then carries
+    const int dq = 64 / K, dr = 64 - dq * K;
+    int rr = lane / K, k = lane - rr * K;
+    for (int idx = lane; idx < N * K; idx += 64) {
+      float v = 0.0f;
+      if (rr < n && k < kk) v = sm.sgn[k] * (float)sm.Qt[sm.perm[k] * LD + rr];
+      Vb[idx] = v;
+      rr += dq;
+      k += dr;
+      if (k >= K) k -= K, ++rr;
+    }
   }
   if (info && lane == 0) info[b] = nrestart;
 #ifdef LNZ_PROFILE_PHASES
