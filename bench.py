@@ -4,11 +4,16 @@
 One "step" = one pass of the hot path over one batch of B synthetic QM8-schema molecules that
 is already resident in HBM (the channels-last Laplacian L, atom ids, mask):
 
-    pack L into MFMA fragment order                      (lnz_pack_laplacian)
-    Lanczos tridiagonalisation + QL eigensolve + select   (lnz_lanczos_ritz)      -> D, V
-    spectral filter gains, all 7 layers                   (lnz_spectral_gains)
+    batch preparation, ONE launch                         (lnz_prepare_batch)      -> Lp, D, V
+      = tile plan + live eigen slots, pack L into MFMA fragment order, Lanczos
+        tridiagonalisation + tridiagonal eigensolve (Sturm / twisted factorisation) + select
+    spectral filter gains, all 7 layers                   (lnz_spectral_gains_rows)
     fused 7-layer spectral conv + mix + head + readout    (lnz_lanczosnet_forward) -> score
     [N > 1 ranks only] RCCL all-gather of the per-shard scores
+
+i.e. three launches per step.  The JSON line is self-verifying: `parity_rel_err` is the score of
+the timed seed-0 batch against the CPU oracle's score of the same batch (the `cpu_baseline` leg
+computes it anyway) and the run FAILS if it exceeds 1e-5.
 
 Workload = BASELINE.json configs[1]: QM8 LanczosNet, batch 1024 per GPU, N <= 32 dense L,
 K = 20, fp32, config/qm8_lanczos_net.yaml architecture.  Molecules are independent, so ranks
@@ -65,6 +70,11 @@ def cpu_baseline(cfg, params, batch_size, reps):
     nb = int(batch['n_nodes'][b])
     L[b, :nb, :nb] = oracle.laplacian_multi_l4(batch['adjs'][b, :nb, :nb])
   times = []
+  K = cfg['num_eig_vec']
+  # a top-K cut through a degenerate |lambda| cluster (n > K) keeps an arbitrary vector of the
+  # cluster: basis dependent in the reference itself (LAPACK's choice), excluded from the parity
+  # figure as SURVEY.md 8(c) prescribes — and counted
+  ambiguous = np.zeros(B, bool)
   for _ in range(reps):
     t0 = time.perf_counter()
     Dl, Vl = [], []
@@ -74,10 +84,151 @@ def cpu_baseline(cfg, params, batch_size, reps):
       idx = np.argsort(-np.abs(e), kind='mergesort')
       Dl.append(e[idx])
       Vl.append(V[:, idx])
+      if nb > K:
+        ambiguous[b] = abs(abs(e[idx[K - 1]]) - abs(e[idx[K]])) < 1e-9
     D, V = oracle.collate_eigs(Dl, Vl, N, cfg['num_eig_vec'])
-    oracle.lanczos_net_forward(params, cfg, batch['node_feat'], L, D, V, batch['node_mask'])
+    score = oracle.lanczos_net_forward(params, cfg, batch['node_feat'], L, D, V,
+                                       batch['node_mask'])
     times.append(time.perf_counter() - t0)
-  return batch_size / min(times), times
+  return batch_size / min(times), times, score, ambiguous
+
+
+def forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, sizes, reps=5):
+  """Fused-forward launch time at growing batch (the bench batch repeated r times, so the size
+  mix — and with it the tile plan's pairing rate — is the same): separates tile quantisation
+  (B=1024 is 2.9 tiles per CU, rounded up to 3) from in-loop stalls.  Forward launch only."""
+  out = []
+  B0 = L.shape[0]
+  K = cfg['num_eig_vec']
+  with torch.no_grad():
+    for Bs in sizes:
+      r = max(1, Bs // B0)
+      Lr, nf, mk, nn_ = (x.repeat(*([r] + [1] * (x.dim() - 1))).contiguous()
+                         for x in (L, node_feat, mask_u8, n_nodes))
+      Lp, tiles, rows, D, V = ops.prepare_batch(plan, Lr, mk, nn_, K)
+      G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
+                             rows=rows, zero_fill=not ops.pairing_supported(plan))
+      buf, cap = tiles
+      n_tiles = int((buf[:12 * cap].view(cap, 4, 3)[:, :, 0] >= 0).sum().item())
+      n_wg = int(buf[12 * cap].item())
+      ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+      e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+      e[0].record()
+      for _ in range(reps):
+        ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+      e[1].record()
+      torch.cuda.synchronize()
+      ms = e[0].elapsed_time(e[1]) / reps
+      tf = FWD_FLOP_EXECUTED * n_tiles / (ms * 1e-3) / 1e12
+      out.append({'batch': B0 * r, 'tiles': n_tiles, 'workgroups': n_wg, 'forward_ms': round(ms, 4),
+                  'executed_tflops': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                  'molecules_per_s_forward_only': round(B0 * r / ms * 1e3, 1)})
+      del Lr, Lp, V, G
+  return out
+
+
+def lanczos_large_leg(dev, B=256, N=2048, M=64, reps=3):
+  """BASELINE configs[4] Lanczos stage, the HBM-bound regime north_star's ">= 40 % of HBM roofline
+  on the Lanczos SpMV" is about: lnz_lanczos_ritz_large on B dense graphs of N nodes, M = K steps.
+  Algorithmic bytes per graph (large-N regime): A re-streamed every step M*4N^2, +
+  basis traffic M^2*N*4 + N*M*4 (SURVEY's fp32 accounting; this kernel keeps an fp64 basis and
+  moves more)."""
+  g = torch.Generator(device=dev)
+  g.manual_seed(0)
+  A = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+  eye = torch.eye(N, device=dev)
+  for b in range(B):  # G(n, p = 0.01) + self loops, symmetric normalisation (L4)
+    adj = (torch.rand((N, N), generator=g, device=dev) < 0.01).float().triu(1)
+    adj = adj + adj.t() + eye
+    d = adj.sum(1).rsqrt()
+    A[b] = d[:, None] * adj * d[None, :]
+  from lanczosnet_amd import _lib
+  ws = torch.empty((_lib.load().lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8,
+                   device=dev)
+  ops.lanczos_ritz_large(A, M, M, workspace=ws)
+  torch.cuda.synchronize()
+  ts = []
+  for _ in range(reps):
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record()
+    D, V, info = ops.lanczos_ritz_large(A, M, M, workspace=ws, return_info=True)
+    e[1].record()
+    torch.cuda.synchronize()
+    ts.append(e[0].elapsed_time(e[1]))
+  t = float(np.mean(ts)) * 1e-3
+  # Ritz residual of the leading pair (lambda_max = 1 of L4): a correctness witness in the line
+  r0 = torch.linalg.norm(torch.bmm(A[:4], V[:4, :, :1]) - V[:4, :, :1] * D[:4, None, :1], dim=1).max()
+  bytes_A = M * 4 * N * N
+  bytes_survey = bytes_A + M * M * N * 4 + N * M * 4
+  del A, ws
+  return {'workload': 'lnz_lanczos_ritz_large: B=%d dense graphs, N=%d, M=K=%d Lanczos steps, fp32 A, '
+                      'fp64 arithmetic, G(n,0.01) + I, L4 normalised' % (B, N, M),
+          'kernel': 'lanczos_ritz_large_kernel', 'ms': round(t * 1e3, 3),
+          'graphs_per_s': round(B / t, 1), 'bound': 'hbm',
+          'algorithmic_bytes_per_graph': bytes_survey,
+          'achieved': round(B * bytes_survey / t / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+          'frac': round(B * bytes_survey / t / 8e12, 4),
+          'A_stream_only_GBps': round(B * bytes_A / t / 1e9, 1),
+          'frac_A_stream_only': round(B * bytes_A / t / 8e12, 4),
+          'leading_pair_residual': float(r0), 'min_steps_taken': int(info.min()),
+          'reps_ms': [round(x, 3) for x in ts]}
+
+
+def ada_leg(dev, L, node_feat, mask_u8, reps=5):
+  """BASELINE configs[3]: AdaLanczosNet forward (config/qm8_ada_lanczos_net.yaml architecture:
+  short [1,2,3], long [5,7,10,20,30], K=20, 7 x 128) on the bench batch.  Per-stage HIP-event
+  times; the filter MLPs (2000-4096-4096-4096-2000 per layer, M = batch) are library GEMMs and
+  are priced against the fp32 MFMA peak."""
+  from lanczosnet_amd.model import AdaLanczosNet
+  cfg = dict(QM8_CFG, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30])
+  torch.manual_seed(1234)
+  net = AdaLanczosNet(make_model_config(cfg, name='AdaLanczosNet')).eval().to(dev)
+  B, N = node_feat.shape
+  K, S, nl = cfg['num_eig_vec'], 5, cfg['num_layer']
+  names = ['learned_laplacian', 'lanczos_layer', 't_powers', 'filter_mlp_gemms+symmetrize',
+           'pack_L', 'fused_forward']
+  acc = np.zeros(6)
+  tot = []
+  with torch.no_grad():
+    plan = net._plan()
+    for it in range(reps + 2):
+      q1 = torch.randn(B, N, 1).to(dev)
+      ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+      ev[0].record()
+      Le = ops.ada_graph_laplacian(node_feat, net.embedding.weight, L[:, :, :, 0])
+      ev[1].record()
+      T, Q = ops.ada_lanczos_layer(Le, mask_u8, q1, K)
+      ev[2].record()
+      tcat = ops.ada_t_powers(T, cfg['long_diffusion_dist']).view(B, -1)
+      ev[3].record()
+      DDp = torch.empty((nl, B, S, K, K), dtype=torch.float32, device=dev)
+      for l, seq in enumerate(net.spectral_filter):
+        ops.ada_symmetrize_filters(seq(tcat), K, S, out=DDp[l])
+      ev[4].record()
+      Lp = ops.pack_laplacian(L)
+      ev[5].record()
+      score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask_u8)
+      ev[6].record()
+      torch.cuda.synchronize()
+      if it >= 2:
+        acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(6)]
+        tot.append(ev[0].elapsed_time(ev[6]))
+  acc /= reps
+  ms = float(np.mean(tot))
+  mlp_flops = nl * 2 * B * (2000 * 4096 + 2 * 4096 * 4096 + 4096 * 2000)
+  mlp_tf = mlp_flops / (acc[3] * 1e-3) / 1e12
+  finite = bool(torch.isfinite(score).all())
+  del net, plan
+  torch.cuda.empty_cache()
+  return {'workload': 'AdaLanczosNet forward, QM8 batch=%d, N<=32, K=20, short [1,2,3], long '
+                      '[5,7,10,20,30], 7 x 128, fp32, 351 M parameters' % B,
+          'ms_per_step': round(ms, 4), 'value': round(B / ms * 1e3, 1), 'unit': 'molecules/s',
+          'stage_ms': {k: round(float(v), 4) for k, v in zip(names, acc)},
+          'filter_mlp_gemm': {'library': 'hipBLASLt via torch.nn.functional.linear', 'flops': mlp_flops,
+                              'achieved': round(mlp_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                              'unit': 'TFLOP/s', 'frac': round(mlp_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                              'note': 'stage time includes the 7 symmetrize launches'},
+          'finite': finite}
 
 
 def main():
@@ -91,6 +242,8 @@ def main():
                   help='software pipeline over the stream of batches: one launch prepares batch k+1 '
                        'and computes the spectral gains of batch k')
   ap.add_argument('--cpu-reps', type=int, default=5)
+  ap.add_argument('--no-secondary', action='store_true',
+                  help='skip the secondary legs (batch sweep, large-graph Lanczos, AdaLanczosNet)')
   ap.add_argument('--gemm', default='fp32', choices=['fp32', 'f16x3'],
                   help="fp32 = exact fp32 MFMA (headline); f16x3 = opt-in split-precision GEMM1")
   ap.add_argument('--zero-params', action='store_true',
@@ -210,6 +363,7 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
+  timed_score = score.clone()
 
   # secondary measurement (N = 1 only, never `value`): software pipeline over the stream of batches
   pipe = None
@@ -280,6 +434,14 @@ def main():
   stage_ms['lanczosnet_forward'] = float(
       np.mean([ev[i][4].elapsed_time(ev[i][5]) for i in range(args.steps)]))
 
+  # secondary measurements (N = 1 only, never `value`)
+  sweep = large = ada = None
+  if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.no_secondary:
+    sweep = forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, (1024, 4096, 16384)
+                                if B == 1024 else (B,))
+    large = lanczos_large_leg(dev)
+    ada = ada_leg(dev, L, node_feat, mask_u8)
+
   if rank == 0:
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
@@ -287,12 +449,16 @@ def main():
     # executed matrix-core work: the kernel runs 32-row node tiles; small molecules share one
     buf, cap = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
     n_tiles = int((buf[:12 * cap].view(cap, 4, 3)[:, :, 0] >= 0).sum().item())
-    achieved = FWD_FLOP_PER_MOL * n_tiles / fwd_s / 1e12
-    traffic = None
+    flops_exec = FWD_FLOP_EXECUTED * n_tiles
+    achieved = flops_exec / fwd_s / 1e12
+    traffic, traffic_source = None, None
     prof = os.path.join(ROOT, 'profiles', 'pmc_forward_hbm_bytes.json')
     if os.path.exists(prof) and B == 1024:
       try:
         traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+        traffic_source = ('profiles/pmc_forward_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE '
+                          'of this kernel on this workload, separate counter run (not measured in '
+                          'this process), gfx950 corrections of MI355X_MICROARCH.md applied')
       except Exception:
         traffic = None
     out = {
@@ -307,29 +473,37 @@ def main():
                                'Lanczos + tridiagonal eigensolver (Ritz pairs)] (one launch) + spectral gains + fused forward' % (B, L.shape[1]),
                    'global_batch': world * B, 'parallelism': 'dp%d (batch shards, async score all-gather per step)'
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
+        # frac = flops the kernel ISSUES / launch time / peak: the long-scale
+        # channels run in eigen space, 9.5 % fewer flops than the reference's association
         'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',
                      'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                     'traffic': traffic,
-                     'flops_per_launch': FWD_FLOP_PER_MOL * n_tiles,
+                     'traffic': traffic, 'traffic_source': traffic_source,
+                     'flops_per_launch_executed': flops_exec,
                      'tiles_per_launch': n_tiles,
-                     'executed_tflops': round(FWD_FLOP_EXECUTED * n_tiles / fwd_s / 1e12, 2),
-                     'note': 'achieved = 32-row tiles executed x the per-tile figure of SURVEY 8(d) '
-                             '(the reference association: filter build + L_s Z per long channel); '
-                             'the kernel runs the long channels in eigen space and issues 9.5 %% '
-                             'fewer flops (executed_tflops); %d molecules ride in %d tiles '
-                             '(lnz_plan_tiles); counting every molecule as its own padded tile '
-                             'would give %.1f TFLOP/s'
-                             % (B, n_tiles, FWD_FLOP_PER_MOL * B / fwd_s / 1e12),
-                     'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4)},
+                     'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4),
+                     'reference_association_tflops': round(FWD_FLOP_PER_MOL * n_tiles / fwd_s / 1e12, 2),
+                     'note': 'achieved = frac * peak = flops_per_launch_executed / avg_launch_ms: '
+                             '%d executed 32-row tiles x %d flop issued per tile; '
+                             'reference_association_tflops prices the same tiles at SURVEY 8(d)\'s '
+                             '%d flop (filter build + L_s Z per long channel, which the kernel '
+                             'replaces by one projection and one lift per layer); %d molecules '
+                             'ride in %d tiles (lnz_plan_tiles)'
+                             % (n_tiles, FWD_FLOP_EXECUTED, FWD_FLOP_PER_MOL, B, n_tiles)},
     }
     if split is not None:
       out['config']['split_precision_mode'] = split
     if pipe is not None:
       out['config']['pipelined_stream_mode'] = pipe
+    if sweep is not None:
+      out['config']['forward_batch_sweep'] = sweep
+    if large is not None:
+      out['config']['lanczos_large_mode'] = large
+    if ada is not None:
+      out['config']['ada_mode'] = ada
     if world == 1 and not args.no_cpu_baseline:
       torch.set_num_threads(os.cpu_count() or 1)
-      v, times = cpu_baseline(cfg, params, B, args.cpu_reps)
+      v, times, ref_score, ambiguous = cpu_baseline(cfg, params, B, args.cpu_reps)
       try:  # threads the numpy BLAS pool really runs (the per-molecule eigh loop is one thread)
         from threadpoolctl import threadpool_info
         blas_threads = max([int(p_['num_threads']) for p_ in threadpool_info()
@@ -343,7 +517,27 @@ def main():
                                        'cores), B=%d, best of %d runs (%.2f s each, %.1f s in all)' %
                                        (blas_threads, os.cpu_count() or 1, B, args.cpu_reps,
                                         min(times), sum(times))}
+      # self-verification: the scores of the timed batch (rank 0's seed-0 batch, same parameters)
+      # against the oracle's scores of the same batch, all B molecules
+      if not args.zero_params:
+        got = timed_score.cpu().numpy().astype(np.float64)
+        ref = ref_score.astype(np.float64)
+        dev_mol = np.abs(got - ref).max(axis=1) / np.abs(ref).max()
+        keep = ~ambiguous
+        out['parity_rel_err'] = float(dev_mol[keep].max())
+        out['parity'] = {'against': 'oracle (numpy port of the reference pipeline, fp32) on the timed '
+                                    'batch: %d of %d molecules x %d outputs'
+                                    % (int(keep.sum()), ref.shape[0], ref.shape[1]),
+                         'metric': 'max |score - ref| / max |ref|', 'bar': 1e-5,
+                         'excluded': int(ambiguous.sum()),
+                         'excluded_why': 'n > K and the top-K cut splits a degenerate |lambda| '
+                                         'cluster (gap < 1e-9): the reference keeps a LAPACK-chosen '
+                                         'vector of the cluster (SURVEY.md 8c)',
+                         'excluded_max_rel_dev': float(dev_mol[ambiguous].max()) if ambiguous.any()
+                         else None}
     print(json.dumps(out))
+    if out.get('parity_rel_err', 0.0) > 1e-5:
+      raise SystemExit('bench.py: parity_rel_err %.3e exceeds 1e-5' % out['parity_rel_err'])
   if dist:
     dist.destroy_process_group()
 

@@ -48,9 +48,16 @@ int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B, int N, in
 
 /* ---- R2 + R6: Lanczos tridiagonalisation -> tridiagonal eigensolve -> Ritz select ----
  * Per molecule: full-length (m = n) Lanczos with twice-iterated classical Gram-Schmidt and
- * restart on breakdown on the n x n leading block of A, implicit-shift QL on T with the
- * rotations applied to Q (so the Ritz vectors V = Q*B come out directly), stable ordering
- * by descending |lambda| (ties: ascending lambda), cut / zero-pad to K.  Produces exactly
+ * restart on breakdown on the n x n leading block of A; then the eigendecomposition of T:
+ *   N <= 32 (the QM8 regime): lane-parallel — T split into unreduced blocks, one eigenvalue per
+ *            lane by section search on Sturm counts, its eigenvector by the twisted factorisation
+ *            of T - lambda (dlar1v / MRRR vector), near-degenerate copies re-orthogonalised in
+ *            lane order, Ritz vectors V = Q*S; the implicit-shift QL sweep only as the fallback
+ *            (info += 256);
+ *   32 < N <= 64: implicit-shift QL (tql2 recurrences) with the rotations applied to Q, so the
+ *            Ritz vectors come out directly;
+ * then stable ordering by descending |lambda| (ties: ascending lambda), cut / zero-pad to K.
+ * Produces exactly
  * the (D, V) that utils/data_helper.py:197-223 (np.linalg.eigh + mergesort on -|eig|)
  * followed by dataset/qm8.py:264-291 (pad rows to N, cut/pad to K, cast fp32) produce,
  * up to the basis of degenerate eigenspaces and eigenvector sign.  fp64 arithmetic.

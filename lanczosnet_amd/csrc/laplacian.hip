@@ -66,39 +66,118 @@ extern "C" int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B
 }
 
 // ---------------------------------------------------------------------------------------
-// unsorted_segment_sum.  data [B, D1, D2]; ids [B, D1]; out [B, S, D2] (pre-zeroed).
-// One thread per float4 (or scalar tail) of `data`; consecutive threads walk dim2, so loads
-// and the atomics of one source row are contiguous.  fp32 atomicAdd returns nothing ->
-// fire-and-forget L2 atomics (operators/src/cuda/segment_reduction.cu:39-53 semantics).
+// unsorted_segment_sum.  data [B, D1, D2]; ids [B, D1]; out [B, S, D2].
+//   forward : out[b, ids[b,c], x] += data[b, c, x]      (operators/src/cuda/segment_reduction.cu:39-53)
+//   backward: gdata[b, c, x] = gout[b, ids[b,c], x]     (:55-69)
+// The reference is one thread per ELEMENT with a global atomicAdd each.  Here a scatter-add is a
+// privatised reduction: a workgroup owns (batch b, a block of VEC*64 feature columns) and every
+// lane owns VEC columns of it for ALL segments, so the accumulators — [S][VEC*64] floats in LDS —
+// have exactly one writer per address: plain ds_read/ds_write read-modify-write, no atomics, a
+// fixed summation order (source-row order within a wave's row range: bit-reproducible, and for
+// one wave identical to the CPU loop of operators/src/segment_reduction.cpp:6-30).  The segment
+// id of a source row is wave uniform (one scalar load per row instead of one per element); the
+// row's data is one coalesced dwordx4 (VEC = 4) or dword load per lane, software-pipelined UNR
+// rows deep because consecutive rows of one segment form a dependent LDS chain.  With few
+// workgroups (small B) the D1 rows are split over NW waves, each with a private accumulator
+// copy, combined in wave order at the end; `out` is read-modify-written once per element, so the
+// "+=" onto the caller's pre-zeroed (or not) buffer is kept.  Fallback when S*VEC*64*4 B does
+// not fit LDS: the element-wise fp32 atomics (fire-and-forget L2 atomics).
 // ---------------------------------------------------------------------------------------
-__global__ void segsum_fwd_kernel(const float* __restrict__ data, const int64_t* __restrict__ ids,
-                                  int64_t total, int D1, int D2, int S, float* __restrict__ out) {
+template <int VEC>
+__global__ __launch_bounds__(256) void segsum_fwd_lds_kernel(
+    const float* __restrict__ data, const int64_t* __restrict__ ids, int D1, int D2, int S,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sacc[];  // [NW][S][VEC*64]
+  constexpr int CW = VEC * 64, UNR = 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int b = blockIdx.y;
+  const int x0 = blockIdx.x * CW + lane * VEC;
+  const bool live = x0 < D2;  // D2 % VEC == 0 on the VEC = 4 path: a lane is all in or all out
+  float* acc = sacc + (size_t)w * S * CW + lane * VEC;
+  for (int sgm = 0; sgm < S; ++sgm)
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) acc[(size_t)sgm * CW + u] = 0.0f;
+  const int per = (D1 + NW - 1) / NW;
+  const int c0 = w * per, c1 = min(D1, c0 + per);
+  const int64_t* idb = ids + (int64_t)b * D1;
+  const float* db = data + (int64_t)b * D1 * D2 + x0;
+  for (int c = c0; c < c1; c += UNR) {
+    float v[UNR][VEC];
+    int sg[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const int cc = c + k;
+      int64_t s64 = cc < c1 ? idb[cc] : -1;
+      sg[k] = __builtin_amdgcn_readfirstlane((s64 < 0 || s64 >= S) ? -1 : (int)s64);
+      if (sg[k] >= 0 && live) {
+        if constexpr (VEC == 4) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(db + (int64_t)cc * D2);
+          v[k][0] = t[0]; v[k][1] = t[1]; v[k][2] = t[2]; v[k][3] = t[3];
+        } else {
+          v[k][0] = db[(int64_t)cc * D2];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      if (sg[k] < 0 || !live) continue;  // out-of-range ids are dropped, never written OOB
+      float* a = acc + (size_t)sg[k] * CW;
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) a[u] += v[k][u];
+    }
+  }
+  __syncthreads();
+  // combine the NW private copies in wave order; one read-modify-write of `out` per element
+  float* ob = out + (int64_t)b * S * D2 + blockIdx.x * CW;
+  const int width = min(CW, D2 - blockIdx.x * CW);
+  for (int t = threadIdx.x; t < S * CW; t += blockDim.x) {
+    const int sgm = t / CW, x = t % CW;
+    if (x >= width) continue;
+    float sum = sacc[t];
+    for (int k = 1; k < NW; ++k) sum += sacc[(size_t)k * S * CW + t];
+    ob[(int64_t)sgm * D2 + x] += sum;
+  }
+}
+
+__global__ void segsum_fwd_atomic_kernel(const float* __restrict__ data,
+                                         const int64_t* __restrict__ ids, int64_t total, int D1,
+                                         int D2, int S, float* __restrict__ out) {
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     int x = (int)(idx % D2);
     int64_t bc = idx / D2;
     int b = (int)(bc / D1);
     int64_t seg = ids[bc];
-    if (seg < 0 || seg >= S) continue;  // out-of-range ids are dropped, never written OOB
+    if (seg < 0 || seg >= S) continue;
     atomicAdd(out + ((int64_t)b * S + seg) * D2 + x, data[idx]);
   }
 }
 
-__global__ void segsum_bwd_kernel(const float* __restrict__ gout, const int64_t* __restrict__ ids,
-                                  int64_t total, int D1, int D2, int S, float* __restrict__ gdata) {
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int x = (int)(idx % D2);
-    int64_t bc = idx / D2;
-    int b = (int)(bc / D1);
-    int64_t seg = ids[bc];
-    gdata[idx] = (seg < 0 || seg >= S) ? 0.0f : gout[((int64_t)b * S + seg) * D2 + x];
+// Gather: one wave per source row (its id is one scalar load), VEC columns per lane.
+template <int VEC>
+__global__ __launch_bounds__(256) void segsum_bwd_kernel(const float* __restrict__ gout,
+                                                         const int64_t* __restrict__ ids,
+                                                         int64_t rows, int D1, int D2, int S,
+                                                         float* __restrict__ gdata) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwave = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t bc = wave; bc < rows; bc += nwave) {
+    const int64_t s64 = ids[bc];
+    const int seg = __builtin_amdgcn_readfirstlane((s64 < 0 || s64 >= S) ? -1 : (int)s64);
+    const int64_t b = bc / D1;
+    const float* src = gout + (b * S + (seg < 0 ? 0 : seg)) * D2;
+    float* dst = gdata + bc * D2;
+    for (int x = lane * VEC; x < D2; x += 64 * VEC) {
+      if constexpr (VEC == 4) {
+        f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (seg >= 0) t = *reinterpret_cast<const f32x4*>(src + x);
+        *reinterpret_cast<f32x4*>(dst + x) = t;
+      } else {
+        dst[x] = seg >= 0 ? src[x] : 0.0f;
+      }
+    }
   }
-}
-
-static int segsum_grid(int64_t total) {
-  int64_t g = (total + 255) / 256;
-  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));  // grid-stride beyond 256 CUs x 8
 }
 
 extern "C" int lnz_unsorted_segment_sum_forward(const float* data, const int64_t* segment_ids,
@@ -106,9 +185,30 @@ extern "C" int lnz_unsorted_segment_sum_forward(const float* data, const int64_t
                                                 float* out, lnz_stream_t stream) {
   LNZ_REQUIRE(data && segment_ids && out && B > 0 && dim1 > 0 && dim2 > 0 && num_segments > 0,
               LNZ_EINVAL, "lnz_unsorted_segment_sum_forward: bad arguments");
-  int64_t total = (int64_t)B * dim1 * dim2;
-  hipLaunchKernelGGL(segsum_fwd_kernel, dim3(segsum_grid(total)), dim3(256), 0,
-                     (hipStream_t)stream, data, segment_ids, total, dim1, dim2, num_segments, out);
+  const bool vec4 = dim2 % 4 == 0 && dim2 >= 128 && (((uintptr_t)data | (uintptr_t)out) & 15) == 0;
+  const int cw = vec4 ? 256 : 64;
+  const size_t copy = (size_t)num_segments * cw * sizeof(float);
+  const size_t lds_max = 64 * 1024;
+  if (copy <= lds_max) {
+    const int blocks = (dim2 + cw - 1) / cw;
+    // row-split waves only while the grid does not fill the 256 CUs and a copy each still fits
+    int nw = 1;
+    while (nw < 4 && (int64_t)B * blocks * nw < 512 && copy * (nw * 2) <= lds_max &&
+           dim1 >= 16 * nw * 2)
+      nw *= 2;
+    dim3 grid(blocks, B);
+    if (vec4)
+      hipLaunchKernelGGL(segsum_fwd_lds_kernel<4>, grid, dim3(64 * nw), copy * nw,
+                         (hipStream_t)stream, data, segment_ids, dim1, dim2, num_segments, out);
+    else
+      hipLaunchKernelGGL(segsum_fwd_lds_kernel<1>, grid, dim3(64 * nw), copy * nw,
+                         (hipStream_t)stream, data, segment_ids, dim1, dim2, num_segments, out);
+  } else {
+    int64_t total = (int64_t)B * dim1 * dim2;
+    int64_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(segsum_fwd_atomic_kernel, dim3((int)(g > 2048 ? 2048 : g)), dim3(256), 0,
+                       (hipStream_t)stream, data, segment_ids, total, dim1, dim2, num_segments, out);
+  }
   return lnz::check_launch("lnz_unsorted_segment_sum_forward");
 }
 
@@ -118,9 +218,15 @@ extern "C" int lnz_unsorted_segment_sum_backward(const float* grad_out, const in
   LNZ_REQUIRE(grad_out && segment_ids && grad_data && B > 0 && dim1 > 0 && dim2 > 0 &&
                   num_segments > 0,
               LNZ_EINVAL, "lnz_unsorted_segment_sum_backward: bad arguments");
-  int64_t total = (int64_t)B * dim1 * dim2;
-  hipLaunchKernelGGL(segsum_bwd_kernel, dim3(segsum_grid(total)), dim3(256), 0,
-                     (hipStream_t)stream, grad_out, segment_ids, total, dim1, dim2, num_segments,
-                     grad_data);
+  const int64_t rows = (int64_t)B * dim1;
+  const bool vec4 = dim2 % 4 == 0 && (((uintptr_t)grad_out | (uintptr_t)grad_data) & 15) == 0;
+  int64_t g = (rows + 3) / 4;
+  const int grid = (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+  if (vec4)
+    hipLaunchKernelGGL(segsum_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       segment_ids, rows, dim1, dim2, num_segments, grad_data);
+  else
+    hipLaunchKernelGGL(segsum_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       segment_ids, rows, dim1, dim2, num_segments, grad_data);
   return lnz::check_launch("lnz_unsorted_segment_sum_backward");
 }

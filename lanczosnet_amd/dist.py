@@ -44,7 +44,7 @@ def all_gather_scores(local_score, n_global, group=None):
     """Gather the per-shard scores [b_r, P] into the full [n_global, P] on every rank.
     Shards may be uneven (sizes follow shard_bounds): shorter shards are zero-padded for the
     collective and trimmed afterwards."""
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return local_score
     sizes = [shard_bounds(n_global, r, world)[1] - shard_bounds(n_global, r, world)[0]
@@ -126,8 +126,11 @@ def forward_sharded(forward_fn, batch, n_global, label_key='label', group=None):
     sliced or sliced here when it still has n_global rows) and return (full_score, loss|None)."""
     first = next(v for v in (batch.values() if isinstance(batch, dict) else batch)
                  if v is not None)
-    shard = shard_batch(batch) if first.shape[0] == n_global and dist.get_world_size(group) > 1 \
-        else batch
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    # slice by the GROUP's rank / size: with a sub-group the default-group rank would cut the
+    # wrong rows
+    shard = shard_batch(batch, dist.get_rank(group), dist.get_world_size(group)) \
+        if multi and first.shape[0] == n_global else batch
     local = forward_fn(shard)
     full = all_gather_scores(local, n_global, group)
     loss = None
@@ -146,11 +149,17 @@ def all_reduce_gradients(params, local_count, group=None, bucket_bytes=256 << 20
     collected in order, so the copy-back of bucket i overlaps the wire time of bucket i+1.
 
     params: iterable of parameters whose `.grad` is replaced in place; local_count: number of
-    molecules (rows of the loss mean) this rank contributed."""
-    params = [p for p in params if p.grad is not None]
+    molecules (rows of the loss mean) this rank contributed.  The bucket layout is a function of
+    the parameter list alone (every `requires_grad` parameter, a missing `.grad` travels as zeros
+    and is materialised): ranks whose shards left different parameters without a gradient still
+    issue identically shaped collectives."""
+    params = [p for p in params if p.requires_grad]
     if not params:
         return
-    dev = params[0].grad.device
+    dev = params[0].device
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
     cnt = torch.tensor([float(local_count)], dtype=torch.float32, device=dev)
     total = cnt.clone()

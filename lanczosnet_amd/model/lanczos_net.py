@@ -7,12 +7,14 @@ Drop-in surface of reference `model/lanczos_net.py:13-199` and
 `att_func.0.*`), same parameter creation and init order, so `torch.manual_seed(s)` yields
 the reference's weights and `utils/train_helper.py:28-32` checkpoints load unchanged.
 
-The forward itself is three HIP launches (Laplacian pack, spectral gains, fused network) on
-the current torch stream; parameters are re-packed into MFMA fragment order only when they
-change.  Training through `loss.backward()` (runner/qm8_runner.py:247) works for LanczosNet /
-LanczosNetGeneral: the forward values are the HIP kernels', the parameter gradients come from an
-autograd recomputation in torch ops on the GPU (hand-written backward kernels are SURVEY.md §8(f)
-rank 2).
+The forward itself is three HIP launches (Laplacian pack + tile plan, spectral gains, fused
+network) on the current torch stream; parameters are re-packed into MFMA fragment order only
+when they change.  Training through `loss.backward()` (runner/qm8_runner.py:247): for LanczosNet /
+LanczosNetGeneral at hidden width 128 the backward is HIP too (`_LanczosNetFusedFunction`:
+input-gradient, message and gain-gradient kernels in the forward's tile structure + library GEMMs
+for dW).  Architectures outside the fused kernels (other widths, N > 32, dropout
+> 0 in training, AdaLanczosNet's backward) differentiate a device-side torch restatement of the
+same math (`_torch_forward`) — still GPU only; there is no CPU path.
 """
 import os
 import warnings
@@ -123,13 +125,48 @@ class _LanczosNetBase(nn.Module):
     def _guard_forward(self, L, mask):
         if mask is None:
             raise ValueError('forward needs `mask` (model/lanczos_net.py:192)')
-        if not L.is_cuda:
+        dev = self.filter[0].weight.device
+        if dev.type != 'cuda':
             raise RuntimeError('lanczosnet_amd models run on the AMD GPU only: move the '
                                'module and its inputs to cuda (no CPU fallback)')
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError('dropout > 0 in training mode is not built in the HIP path')
+        return dev
+
+    def _to_module_device(self, dev, **tensors):
+        """`QM8Runner.test` moves only `D, V` to the GPU and hands over a HOST `L` (and, like every
+        loop of the runner, host-side nothing else) — runner/qm8_runner.py:301-302; the reference
+        model then fails inside `bmm`.  A drop-in should not: inputs that are not on the module's
+        device are moved there, with one warning per module."""
+        out, moved = {}, []
+        for k, t in tensors.items():
+            if isinstance(t, torch.Tensor) and t.device != dev:
+                moved.append(k)
+                t = t.to(dev, non_blocking=True)
+            out[k] = t
+        if moved and not getattr(self, '_warned_host_inputs', False):
+            warnings.warn('lanczosnet_amd: input(s) %s were not on %s and were moved there '
+                          '(reference runner/qm8_runner.py:301-302 leaves L on the host); keep the '
+                          'batch resident on the GPU to avoid the copy' % (', '.join(moved), dev))
+            self._warned_host_inputs = True
+        return out
+
     def _needs_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def invalidate_plan(self):
+        """Drop the packed-parameter plans.  They are keyed on (data_ptr, tensor version) of every
+        parameter, which in-place writes through `.data` (`p.data.clamp_()`, EMA copies, the
+        reference's own `_init_param` idiom) do NOT bump: call this after such a write.
+        `load_state_dict` and `.to()/.cuda()/.float()` call it themselves."""
+        self._plan_cache = None
+        self._plan_large_cache = None
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_plan()
+        return super().load_state_dict(*a, **kw)
 
     def _read_dataset(self, ds):
         self.num_atom = ds.num_atom
@@ -284,8 +321,6 @@ class _LanczosNetBase(nn.Module):
         hipBLASLt through torch.bmm; the spectral gains are the HIP kernel and the Ritz pairs come
         from `lnz_lanczos_ritz_large`.  `gemm_dtype=torch.bfloat16` runs the edge-type GEMMs with
         bf16 operands / fp32 accumulate (config 5's "bf16 MFMA filter GEMM"); default fp32."""
-        if self._needs_grad():
-            raise NotImplementedError('large-graph path is forward only')
         B, N = L.shape[0], L.shape[1]
         S = self.num_scale_long
         plan_mlp = None
@@ -395,10 +430,14 @@ class _LanczosNetBase(nn.Module):
         plan['wt_off'] = offs
         return plan
 
-    def _torch_forward(self, node_feat, L, D, V, mask):
+    def _torch_forward(self, node_feat, L, D, V, mask, dropout=False):
         """Differentiable torch restatement of the same math (device tensors, channel-major L,
-        `M_c (X W_c^T)` association) — used ONLY inside backward to obtain parameter gradients;
-        the values returned to the caller always come from the HIP kernels."""
+        `M_c (X W_c^T)` association).  Used inside backward to obtain parameter gradients where no
+        HIP backward is built, and as the training forward of architectures outside the fused
+        kernels (widths other than a uniform 64/128, N > 32, dropout > 0).  `dropout=True` applies
+        `F.dropout(state, p)` after every conv layer exactly where the reference does
+        (model/lanczos_net.py:182): same call, same shape, same order, so the device generator
+        is consumed like the reference consumes it on this device."""
         B, N = L.shape[0], L.shape[1]
         Lc = L.float().permute(0, 3, 1, 2).contiguous()          # [B, E+1, N, N]
         Vf, Vt = V.float(), V.float().transpose(1, 2)
@@ -431,26 +470,39 @@ class _LanczosNetBase(nn.Module):
                 out = out + torch.bmm(Lc[:, e], Z[:, c])
                 c += 1
             state = torch.relu(out)
+            if dropout:
+                state = torch.nn.functional.dropout(state, self.dropout, training=True)
         y = self.filter[-1](state)
         att = self.att_func(state)
         y = att * y
         m = (mask != 0).float().unsqueeze(2)
         return (y * m).sum(dim=1) / m.sum(dim=1)
+
     def forward(self, node_feat, L, D, V, label=None, mask=None):
         """Shapes as the reference docstring (model/lanczos_net.py:125-141): node_feat B x N
         (long) [General: B x N x D float], L B x N x N x (E+1), D B x K, V B x N x K,
         label B x P, mask B x N.  Returns score, or (score, loss) when `label` is given."""
-        self._guard_forward(L, mask)
+        dev = self._guard_forward(L, mask)
+        t = self._to_module_device(dev, node_feat=node_feat, L=L, D=D, V=V, label=label, mask=mask)
+        node_feat, L, D, V, label, mask = (t[k] for k in ('node_feat', 'L', 'D', 'V', 'label', 'mask'))
         if any(d == 'inf' for d in self.short_diffusion_dist + self.long_diffusion_dist):
             raise NotImplementedError("diffusion distance 'inf' is not built in the HIP path")
-        if L.shape[1] > 32 or not self._fused_supported():
+        drop = self.training and self.dropout > 0.0
+        if L.shape[1] > 32 or not self._fused_supported() or drop:
             if L.shape[1] <= 32 and not getattr(self, '_warned_library_path', False):
-                warnings.warn('lanczosnet_amd: hidden_dim=%r / input_dim=%r is outside the fused MFMA '
-                              'kernel (uniform width 64 or 128): using the device library-GEMM path '
-                              '(hipBLASLt conv + HIP spectral gains), which is slower'
-                              % (self.hidden_dim, self.input_dim))
+                warnings.warn('lanczosnet_amd: %s is outside the fused MFMA kernel (uniform width 64 '
+                              'or 128, no training dropout): using the device library-GEMM path '
+                              '(hipBLASLt conv + HIP spectral gains; differentiable torch ops when '
+                              'gradients or dropout are needed), which is slower'
+                              % ('dropout=%r in training' % self.dropout if drop else
+                                 'hidden_dim=%r / input_dim=%r' % (self.hidden_dim, self.input_dim)))
                 self._warned_library_path = True
-            score = self._large_graph_forward(node_feat, L, D, V, mask)
+            if self._needs_grad() or drop:
+                # the reference trains arbitrary widths / sizes: differentiate the device-side
+                # torch restatement (same association as the kernels)
+                score = self._torch_forward(node_feat, L, D, V, mask, dropout=drop)
+            else:
+                score = self._large_graph_forward(node_feat, L, D, V, mask)
         elif self._needs_grad():
             # training (runner/qm8_runner.py:216-248): forward = HIP kernels; backward = the HIP
             # input-gradient and message kernels + library GEMMs (_LanczosNetFusedFunction) where
@@ -691,7 +743,11 @@ class AdaLanczosNet(_LanczosNetBase):
     def forward(self, node_feat, L, label=None, mask=None):
         if mask is None:
             mask = torch.ones(node_feat.shape[:2], dtype=torch.uint8, device=L.device)
-        self._guard_forward(L, mask)
+        dev = self._guard_forward(L, mask)
+        t = self._to_module_device(dev, node_feat=node_feat, L=L, label=label, mask=mask)
+        node_feat, L, label, mask = (t[k] for k in ('node_feat', 'L', 'label', 'mask'))
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError('AdaLanczosNet: dropout > 0 in training mode is not built')
         if self.num_scale_long == 0:
             raise NotImplementedError('AdaLanczosNet without long-diffusion scales is not built')
         if not self._fused_supported() or L.shape[1] > 32:

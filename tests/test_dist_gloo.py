@@ -121,6 +121,67 @@ def _gather_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _subgroup_worker(rank, world, port, out_dir):
+  """forward_sharded / all_reduce_gradients on a SUB-group (ranks 1, 2 of 3) and with a parameter
+  that has no gradient on one rank only: the slices follow the group's rank, and the bucket layout
+  does not depend on which gradients exist."""
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    grp = dist.new_group([1, 2])
+    ok = True
+    if rank in (1, 2):
+      P = oracle.make_lanczosnet_params(CFG, 3)
+      batch = _make_batch()
+      n = batch['L'].shape[0]
+      full, loss = lnz_dist.forward_sharded(_oracle_forward(P), batch, n, group=grp)
+      ref = _oracle_forward(P)(batch)
+      ok = bool(torch.equal(full, ref)) and \
+          abs(float(loss) - float(torch.mean((ref - batch['label']) ** 2))) < 1e-6
+      # gradients: rank 2's shard never touches the second head -> its grad is None there
+      torch.manual_seed(0)
+      a, b2 = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+      x, y = torch.randn(8, 5), torch.randn(8, 3)
+      gr = dist.get_rank(grp)
+      lo, hi = lnz_dist.shard_bounds(8, gr, 2)
+      out = a(x[lo:hi]) + (b2(x[lo:hi]) if gr == 0 else 0.0)
+      torch.nn.functional.mse_loss(out, y[lo:hi]).backward()
+      params = list(a.parameters()) + list(b2.parameters())
+      assert (b2.weight.grad is None) == (gr == 1)
+      lnz_dist.all_reduce_gradients(params, hi - lo, group=grp, bucket_bytes=64)
+      # reference: the same two-shard loss in one process
+      a2, b3 = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
+      a2.load_state_dict(a.state_dict())
+      b3.load_state_dict(b2.state_dict())
+      l0 = torch.nn.functional.mse_loss(a2(x[:4]) + b3(x[:4]), y[:4], reduction='sum')
+      l1 = torch.nn.functional.mse_loss(a2(x[4:]), y[4:], reduction='sum')
+      ((l0 + l1) / y.numel()).backward()
+      for p_, q_ in zip(params, list(a2.parameters()) + list(b3.parameters())):
+        ok = ok and torch.allclose(p_.grad, q_.grad, rtol=1e-5, atol=1e-7)
+    np.save(os.path.join(out_dir, 's%d.npy' % rank), np.array([ok], dtype=np.int64))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_subgroup_sharding_and_missing_gradients(tmp_path):
+  mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+  for r in range(3):
+    assert np.load(os.path.join(str(tmp_path), 's%d.npy' % r))[0] == 1
+
+
+def test_helpers_without_process_group():
+  """Single process, torch.distributed not initialised: the helpers degrade to the local result
+  instead of raising."""
+  assert not dist.is_initialized()
+  P = oracle.make_lanczosnet_params(CFG, 3)
+  batch = _make_batch()
+  full, loss = lnz_dist.forward_sharded(_oracle_forward(P), batch, batch['L'].shape[0])
+  ref = _oracle_forward(P)(batch)
+  assert torch.equal(full, ref)
+  assert abs(float(loss) - float(torch.mean((ref - batch['label']) ** 2))) < 1e-6
+
+
 @pytest.mark.parametrize('world', [2, 3])
 def test_async_score_gather_streams_batches(world, tmp_path):
   """AsyncScoreGather (bench.py's per-step exchange): every submitted shard score arrives in
