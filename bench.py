@@ -73,19 +73,21 @@ def cpu_baseline(cfg, params, batch_size, reps):
   K = cfg['num_eig_vec']
   # a top-K cut through a degenerate |lambda| cluster (n > K) keeps an arbitrary vector of the
   # cluster: basis dependent in the reference itself (LAPACK's choice), excluded from the parity
-  # figure as SURVEY.md 8(c) prescribes — and counted
+  # figure as SURVEY.md 8(c) prescribes — and counted.  Gap threshold 1e-7 = the rounding of the
+  # fp32 Laplacian the device path is handed (dataset/qm8.py:262 casts L to fp32; the reference's
+  # offline eigh sees the fp64 one): a cluster tighter than that cannot be ordered from fp32 L.
   ambiguous = np.zeros(B, bool)
   for _ in range(reps):
     t0 = time.perf_counter()
     Dl, Vl = [], []
-    for b in range(B):  # (D, V) producer: utils/data_helper.py:197-223 per molecule
+    for b in range(B):  # (D, V) producer: utils/data_helper.py:169-223 per molecule, fp64 L4 -> eigh
       nb = int(batch['n_nodes'][b])
-      e, V = np.linalg.eigh(L[b, :nb, :nb, 0].astype(np.float64))
-      idx = np.argsort(-np.abs(e), kind='mergesort')
-      Dl.append(e[idx])
-      Vl.append(V[:, idx])
+      e, V, _ = oracle.graph_laplacian_eigs(batch['adjs'][b, :nb, :nb].sum(axis=2),
+                                            graph_laplacian_type='L4')
+      Dl.append(e)
+      Vl.append(V)
       if nb > K:
-        ambiguous[b] = abs(abs(e[idx[K - 1]]) - abs(e[idx[K]])) < 1e-9
+        ambiguous[b] = abs(abs(e[K - 1]) - abs(e[K])) < 1e-7
     D, V = oracle.collate_eigs(Dl, Vl, N, cfg['num_eig_vec'])
     score = oracle.lanczos_net_forward(params, cfg, batch['node_feat'], L, D, V,
                                        batch['node_mask'])
@@ -96,7 +98,9 @@ def cpu_baseline(cfg, params, batch_size, reps):
 def forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, sizes, reps=5):
   """Fused-forward launch time at growing batch (the bench batch repeated r times, so the size
   mix — and with it the tile plan's pairing rate — is the same): separates tile quantisation
-  (B=1024 is 2.9 tiles per CU, rounded up to 3) from in-loop stalls.  Forward launch only."""
+  (B=1024 is 2.9 tiles per CU, rounded up to 3) from in-loop stalls.  Forward launch only,
+  `reps` launches back to back (sustained matrix-core clock: the B=1024 entry is slower than the
+  timed loop's `avg_launch_ms`, where the short preparation/gains launches sit between forwards)."""
   out = []
   B0 = L.shape[0]
   K = cfg['num_eig_vec']
@@ -531,7 +535,7 @@ def main():
                          'metric': 'max |score - ref| / max |ref|', 'bar': 1e-5,
                          'excluded': int(ambiguous.sum()),
                          'excluded_why': 'n > K and the top-K cut splits a degenerate |lambda| '
-                                         'cluster (gap < 1e-9): the reference keeps a LAPACK-chosen '
+                                         'cluster (gap < 1e-7, the fp32 rounding of L): the reference keeps a LAPACK-chosen '
                                          'vector of the cluster (SURVEY.md 8c)',
                          'excluded_max_rel_dev': float(dev_mol[ambiguous].max()) if ambiguous.any()
                          else None}

@@ -188,3 +188,29 @@ class PackedQM8:
         D, V = ops.lanczos_ritz(out['L'][:, :, :, 0], out['n_nodes'], num_eigs)
         out['D'], out['V'] = D, V
         return out
+
+
+
+class PackedQM8Data(object):
+    """Dataset-class surface of the runner (`eval(loader_name)(config, split=...)`,
+    runner/qm8_runner.py:40-56) over packed shards: `config.dataset.data_path/QM8_packed_{split}.bin`.
+    `__getitem__` returns a molecule id, `collate_fn` is the device-side collate, so a DataLoader
+    (num_workers = 0: the collate launches kernels) yields device-resident batches with the
+    reference's keys — Laplacians and Ritz pairs computed on the GPU, nothing pickled."""
+
+    def __init__(self, config, split='train', device='cuda'):
+        import os
+        assert split in ('train', 'dev', 'test'), 'no such split'
+        self.split, self.config = split, config
+        self.num_eigs = config.model.num_eig_vec if hasattr(config.model, 'num_eig_vec') else 1
+        self.shard = PackedQM8(os.path.join(config.dataset.data_path,
+                                            'QM8_packed_%s.bin' % split)).to(device)
+
+    def __len__(self):
+        return len(self.shard)
+
+    def __getitem__(self, index):
+        return int(index)
+
+    def collate_fn(self, batch):
+        return self.shard.collate(batch, self.num_eigs)

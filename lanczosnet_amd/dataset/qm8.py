@@ -11,6 +11,10 @@ Two entry points:
   (`lnz_lanczos_ritz`, replacing utils/data_helper.py:197-223 + the pad/cut of qm8.py:264-291) are
   computed ON THE DEVICE — no offline eigendecomposition pickles.
 
+`QM8Data(config, split)` is the reference's dataset class surface (`dataset/qm8.py:11-55`:
+constructor, `__getitem__`, `__len__`, `collate_fn`) over the same per-molecule pickles, for the
+runner's `eval(config.dataset.loader_name)(config, split=...)` (runner/qm8_runner.py:40-56).
+
 Both return the reference's dict keys: node_feat [B,N] int64, node_mask [B,N] uint8,
 label [B,P] float32, L [B,N,N,E+1] float32, D [B,K], V [B,N,K].
 """
@@ -65,3 +69,43 @@ def collate_adjacency(items, num_eigs, device='cuda'):
     return dict(node_feat=torch.from_numpy(node_feat).to(dev),
                 node_mask=torch.from_numpy(mask).to(dev), label=torch.from_numpy(label).to(dev),
                 L=L, D=D, V=V, n_nodes=n_nodes)
+
+
+class QM8Data(object):
+    """Drop-in for reference `dataset/qm8.py:11-293` (LanczosNet / default branch): globs
+    `QM8_preprocess_{split}_*.p` under `config.dataset.data_path`, one pickle per molecule
+    (`dataset/get_qm8_data.py:86-96`), `collate_fn` pads a list of them to the batch maximum.
+    The file lists are SORTED (the reference keeps `glob.glob`'s directory order, :29-34, which
+    is file-system dependent)."""
+
+    def __init__(self, config, split='train'):
+        import glob
+        import os
+        assert split in ('train', 'dev', 'test'), 'no such split'
+        self.split, self.config = split, config
+        self.data_path = config.dataset.data_path
+        self.num_edgetype = config.dataset.num_bond_type
+        self.model_name = config.model.name
+        self.use_eigs = hasattr(config.model, 'num_eig_vec')
+        self.num_eigs = config.model.num_eig_vec if self.use_eigs else 0
+        self.files = sorted(glob.glob(os.path.join(self.data_path,
+                                                   'QM8_preprocess_%s_*.p' % split)))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, index):
+        import pickle
+        with open(self.files[index], 'rb') as f:
+            return pickle.load(f)
+
+    def collate_fn(self, batch):
+        assert isinstance(batch, list)
+        if self.model_name in ('GPNN', 'GraphSAGE', 'DCNN', 'ChebyNet'):
+            raise NotImplementedError('QM8Data mirrors the default collate branch (LanczosNet, '
+                                      'AdaLanczosNet, GCN); got %s' % self.model_name)
+        out = collate_preprocessed(batch, self.num_eigs if self.use_eigs else 1)
+        if not self.use_eigs:
+            out.pop('D')
+            out.pop('V')
+        return out
