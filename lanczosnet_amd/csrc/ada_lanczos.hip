@@ -1,9 +1,19 @@
 // AdaLanczosNet stages:
 //   lnz_ada_graph_laplacian   model/ada_lanczos_net.py:101-137  Gaussian-kernel learned Laplacian
-//   lnz_ada_lanczos_layer     model/ada_lanczos_net.py:139-247  in-model Lanczos layer, reference
-//                             exact ("ada_ref"): fp32, sequential Gram-Schmidt twice, the 1e-4
-//                             breakdown mask and the three quirks of SURVEY.md F6 / §A.3
-//   lnz_ada_t_powers          model/ada_lanczos_net.py:262-270  T^p by sequential TT = TT T
+//   lnz_ada_lanczos_layer     model/ada_lanczos_net.py:139-247  in-model Lanczos layer, the
+//                             reference's algorithm step for step ("ada_ref"): sequential
+//                             Gram-Schmidt twice, the 1e-4 breakdown mask and the three quirks of
+//                             SURVEY.md F6 / §A.3.  fp32 in / fp32 out, fp64 inside: an fp32
+//                             Lanczos recurrence drifts from exact arithmetic by 1e-6 (median) to
+//                             2e-4 (worst of 512 QM8-sized molecules, the reference's own torch
+//                             CPU run measured against an fp64 restatement), in a way that depends
+//                             on the summation order of every dot product — no second fp32
+//                             implementation can reproduce that noise.  Computing the recurrence in
+//                             fp64 puts this kernel at the exact-arithmetic result, so its distance
+//                             to the reference IS the reference's own rounding noise
+//                             (tests/test_gpu_ada.py asserts exactly that, per molecule).
+//   lnz_ada_t_powers          model/ada_lanczos_net.py:262-270  T^p by sequential TT = TT T (fp64
+//                             products, rounded to fp32 on output)
 //   lnz_ada_symmetrize_filters :276-278 (DD + DD^T)/2, relaid out [B,K,K,S] -> [B,S,K,K]
 #include "common.hpp"
 
@@ -36,6 +46,47 @@ __device__ inline float wave_sum(float v) {
   float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
   float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
   return (r0 + r1) + (r2 + r3);
+}
+
+// fp64 variant: the same tree on the two 32-bit halves of every partial sum
+__device__ inline double dpp_add(double v, int ctrl_sel) {
+  union { double d; int i[2]; } x, y;
+  x.d = v;
+  switch (ctrl_sel) {
+    case 0:
+      y.i[0] = __builtin_amdgcn_update_dpp(0, x.i[0], 0xB1, 0xF, 0xF, false);
+      y.i[1] = __builtin_amdgcn_update_dpp(0, x.i[1], 0xB1, 0xF, 0xF, false);
+      break;
+    case 1:
+      y.i[0] = __builtin_amdgcn_update_dpp(0, x.i[0], 0x4E, 0xF, 0xF, false);
+      y.i[1] = __builtin_amdgcn_update_dpp(0, x.i[1], 0x4E, 0xF, 0xF, false);
+      break;
+    case 2:
+      y.i[0] = __builtin_amdgcn_update_dpp(0, x.i[0], 0x141, 0xF, 0xF, false);
+      y.i[1] = __builtin_amdgcn_update_dpp(0, x.i[1], 0x141, 0xF, 0xF, false);
+      break;
+    default:
+      y.i[0] = __builtin_amdgcn_update_dpp(0, x.i[0], 0x140, 0xF, 0xF, false);
+      y.i[1] = __builtin_amdgcn_update_dpp(0, x.i[1], 0x140, 0xF, 0xF, false);
+      break;
+  }
+  return v + y.d;
+}
+
+__device__ inline double readlane_d(double v, int l) {
+  union { double d; int i[2]; } x, y;
+  x.d = v;
+  y.i[0] = __builtin_amdgcn_readlane(x.i[0], l);
+  y.i[1] = __builtin_amdgcn_readlane(x.i[1], l);
+  return y.d;
+}
+
+__device__ inline double wave_sum(double v) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  v = dpp_add(v, 3);
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -108,19 +159,22 @@ __global__ __launch_bounds__(256) void ada_graph_laplacian_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// R5: reference-exact Lanczos layer.  One wavefront per molecule, lane = node row (N <= 64),
-// fp32.  A tile and the basis live in LDS; alpha / beta / MGS coefficients are wave reductions.
+// R5: the reference's Lanczos layer.  One wavefront per molecule, lane = node row (N <= 64).
+// A tile (fp32, as given) and the basis (fp64) live in LDS; alpha / beta / Gram-Schmidt
+// coefficients are fp64 wave reductions (DPP tree, identical in every lane).
 // ---------------------------------------------------------------------------------------------
 template <int NMAX, int KMAX>
 __global__ __launch_bounds__(64) void ada_lanczos_layer_kernel(
     const float* __restrict__ A, const uint8_t* __restrict__ mask, const float* __restrict__ q1,
     int N, int K, float* __restrict__ T, float* __restrict__ Q) {
   __shared__ float As[NMAX * (NMAX + 1)];
-  __shared__ float Qs[(KMAX + 2) * NMAX];  // Q[0] = 0, Q[1..Tit+1]
-  __shared__ float zb[NMAX];
-  __shared__ float alpha_s[KMAX + 1], beta_s[KMAX + 1], valid_s[KMAX + 1], qq_s[KMAX + 2];
+  __shared__ double Qs[(KMAX + 2) * NMAX];  // Q[0] = 0, Q[1..Tit+1]
+  __shared__ double zb[NMAX];
+  __shared__ double alpha_s[KMAX + 1], beta_s[KMAX + 1], qq_s[KMAX + 2];
+  __shared__ float valid_s[KMAX + 1];
   const int b = blockIdx.x, lane = threadIdx.x;
   const int Tit = N < K ? N : K;
+  const double eps = (double)kEpsF;
   const float* Ab = A + (int64_t)b * N * N;
   for (int idx = lane; idx < N * N; idx += 64) {
     int r = idx / N, c = idx - r * N;
@@ -128,47 +182,48 @@ __global__ __launch_bounds__(64) void ada_lanczos_layer_kernel(
   }
   const bool row = lane < N;
   const float mk = (row && (mask == nullptr || mask[(int64_t)b * N + lane] != 0)) ? 1.0f : 0.0f;
-  float q = row ? q1[(int64_t)b * N + lane] * mk : 0.0f;  // :161-165
+  double q = row ? (double)(q1[(int64_t)b * N + lane] * mk) : 0.0;  // :161-165
   {
-    float nrm = sqrtf(wave_sum(q * q));
+    double nrm = sqrt(wave_sum(q * q));
     q = q / nrm;  // :167 (no EPS: an all-masked molecule is NaN in the reference too)
   }
   if (lane < NMAX) {
-    Qs[0 * NMAX + lane] = 0.0f;
+    Qs[0 * NMAX + lane] = 0.0;
     Qs[1 * NMAX + lane] = q;
   }
-  float q_prev = 0.0f, beta_prev = 0.0f, valid_prev = 1.0f;
+  double q_prev = 0.0, beta_prev = 0.0;
+  float valid_prev = 1.0f;
   const float nmask = wave_sum(mk);
   __syncthreads();
   for (int ii = 1; ii <= Tit; ++ii) {
     if (lane < NMAX) zb[lane] = q;
     __syncthreads();
-    float z = 0.0f;
+    double z = 0.0;
     if (row) {
       const float* ar = &As[lane * (NMAX + 1)];
-      for (int c = 0; c < N; ++c) z = fmaf(ar[c], zb[c], z);  // :173
+      for (int c = 0; c < N; ++c) z = fma((double)ar[c], zb[c], z);  // :173
     }
-    const float alpha = wave_sum(q * z);               // :174
+    const double alpha = wave_sum(q * z);              // :174
     z = z - alpha * q - beta_prev * q_prev;            // :175
     if (ii > 1) {                                      // :177-189, use_reorthogonalization (F7)
       for (int pass = 0; pass < 2; ++pass) {
         for (int jj = 1; jj < ii; ++jj) {
-          const float qj = lane < NMAX ? Qs[jj * NMAX + lane] : 0.0f;
-          const float num = wave_sum(z * qj);
-          z = z - num / (qq_s[jj] + kEpsF) * qj;
+          const double qj = lane < NMAX ? Qs[jj * NMAX + lane] : 0.0;
+          const double num = wave_sum(z * qj);
+          z = z - num / (qq_s[jj] + eps) * qj;
         }
       }
     }
-    const float beta = sqrtf(wave_sum(z * z));         // :191
-    const float ok = beta >= 1.0e-4f ? 1.0f : 0.0f;    // :195
+    const double beta = sqrt(wave_sum(z * z));         // :191
+    const float ok = beta >= (double)1.0e-4f ? 1.0f : 0.0f;  // :195 (the fp32 constant lb)
     const float valid = (ii == 1) ? ok : valid_prev * ok;  // :196-199
-    const float qn = (z * valid) / (beta + kEpsF);     // :202
+    const double qn = (z * (double)valid) / (beta + eps);  // :202
     if (lane == 0) {
       alpha_s[ii] = alpha;
       beta_s[ii] = beta;
       valid_s[ii] = valid;
     }
-    const float qq_cur = wave_sum(q * q);              // <Q[ii], Q[ii]> for later projections
+    const double qq_cur = wave_sum(q * q);             // <Q[ii], Q[ii]> for later projections
     if (lane == 0) qq_s[ii] = qq_cur;
     if (lane < NMAX) Qs[(ii + 1) * NMAX + lane] = qn;
     q_prev = q;
@@ -192,9 +247,9 @@ __global__ __launch_bounds__(64) void ada_lanczos_layer_kernel(
     float v = 0.0f;
     if (i < Tit && jn < Tit) {
       auto vm = [&](int t0) { return (t0 < idx_mask) ? valid_s[t0 + 1] : 0.0f; };  // 0-based step
-      if (i == jn) v = alpha_s[i + 1] * vm(i);
-      else if (jn == i + 1 && i < Tit - 1) v = beta_s[i + 1] * vm(i);
-      else if (i == jn + 1 && jn < Tit - 1) v = beta_s[jn + 1] * vm(jn);
+      if (i == jn) v = (float)alpha_s[i + 1] * vm(i);
+      else if (jn == i + 1 && i < Tit - 1) v = (float)beta_s[i + 1] * vm(i);
+      else if (i == jn + 1 && jn < Tit - 1) v = (float)beta_s[jn + 1] * vm(jn);
     }
     Tb[idx] = v;
   }
@@ -206,7 +261,7 @@ __global__ __launch_bounds__(64) void ada_lanczos_layer_kernel(
     if (k < Tit) {
       float vmk = (k < idx_mask) ? valid_s[k + 1] : 0.0f;
       float rowkeep = (idx_mask < N && r >= idx_mask) ? 0.0f : 1.0f;
-      v = Qs[(k + 1) * NMAX + r] * (vmk * rowkeep);  // Q * Q_mask (:237)
+      v = (float)Qs[(k + 1) * NMAX + r] * (vmk * rowkeep);  // Q * Q_mask (:237)
     }
     Qb[idx] = v;
   }
@@ -222,13 +277,13 @@ struct PowArr {
 __global__ __launch_bounds__(256) void ada_t_powers_kernel(const float* __restrict__ T, int K,
                                                             PowArr dist, int S, int pmax,
                                                             float* __restrict__ Tcat) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ts = smem;            // [K][K]
-  float* TT = Ts + K * K;      // current power
-  float* TN = TT + K * K;      // next
+  extern __shared__ __attribute__((aligned(16))) double dsmem[];
+  double* Ts = dsmem;           // [K][K]
+  double* TT = Ts + K * K;      // current power
+  double* TN = TT + K * K;      // next
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < K * K; i += 256) {
-    float v = T[(int64_t)b * K * K + i];
+    double v = (double)T[(int64_t)b * K * K + i];
     Ts[i] = v;
     TT[i] = v;
   }
@@ -239,19 +294,19 @@ __global__ __launch_bounds__(256) void ada_t_powers_kernel(const float* __restri
       if (dist.v[s] == ii) {
         for (int i = tid; i < K * K; i += 256) {
           int r = i / K, c = i - r * K;
-          out[(int64_t)r * S * K + s * K + c] = TT[i];
+          out[(int64_t)r * S * K + s * K + c] = (float)TT[i];
         }
       }
     }
     if (ii == pmax) break;
     for (int i = tid; i < K * K; i += 256) {
       int r = i / K, c = i - r * K;
-      float acc = 0.0f;
-      for (int k = 0; k < K; ++k) acc = fmaf(TT[r * K + k], Ts[k * K + c], acc);
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) acc = fma(TT[r * K + k], Ts[k * K + c], acc);
       TN[i] = acc;
     }
     __syncthreads();
-    float* t = TT;
+    double* t = TT;
     TT = TN;
     TN = t;
   }
@@ -318,7 +373,7 @@ extern "C" int lnz_ada_t_powers(const float* T, int B, int K, const int32_t* dis
     if (i < S && dist_host[i] > pmax) pmax = dist_host[i];
   }
   LNZ_REQUIRE(pmax >= 1 && pmax <= 4096, LNZ_EINVAL, "lnz_ada_t_powers: bad exponents");
-  size_t lds = (size_t)3 * K * K * sizeof(float);
+  size_t lds = (size_t)3 * K * K * sizeof(double);
   hipLaunchKernelGGL(ada_t_powers_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, K, d, S,
                      pmax, Tcat);
   return lnz::check_launch("lnz_ada_t_powers");

@@ -789,21 +789,27 @@ class AdaLanczosNet(_LanczosNetBase):
         K, S = self.num_eig_vec, self.num_scale_long
         Lf = L.float()
         state = self.embedding(node_feat)
+        # The learned Laplacian and the Lanczos recurrence run in fp64, like the forward kernel
+        # (lnz_ada_lanczos_layer): an fp32 recurrence — and its backward — carries rounding noise
+        # of 1e-6 .. 1e-4 that depends on the summation order; fp64 gives the exact-arithmetic
+        # gradient, which is what the reference's own autograd approximates.  (B, N, K) are tiny.
+        dd = torch.float64
+        st = state.to(dd)
         # learned Laplacian (:101-137)
-        adj = (Lf[:, :, :, 0] != 0).float()
-        diff = state.unsqueeze(1) - state.unsqueeze(2)          # [B, i, j, D] = x_j - x_i
+        adj = (Lf[:, :, :, 0] != 0).to(dd)
+        diff = st.unsqueeze(1) - st.unsqueeze(2)                # [B, i, j, D] = x_j - x_i
         dist2 = (diff * diff).sum(dim=3)
         sigma2 = dist2.reshape(B, -1).mean(dim=1).view(B, 1, 1)
         A = torch.exp(-dist2 / sigma2) * adj
         row_sum = A.sum(dim=2, keepdim=True)
-        Dg = 1.0 / (row_sum + (row_sum == 0).float()).pow(0.5)
+        Dg = 1.0 / (row_sum + (row_sum == 0).to(dd)).pow(0.5)
         Le = Dg * A * Dg.transpose(1, 2)
         # Lanczos layer (:139-247)
-        m = (mask != 0).float().unsqueeze(2)
+        m = (mask != 0).to(dd).unsqueeze(2)
         Tit = min(N, K)
-        q = q1.float() * m
+        q = q1.to(dd) * m
         q = q / torch.norm(q, 2, dim=1, keepdim=True)
-        Qs, alphas, betas, valids = [torch.zeros_like(q), q], [], [torch.zeros(B, 1, 1, device=L.device)], []
+        Qs, alphas, betas, valids = [torch.zeros_like(q), q], [], [torch.zeros(B, 1, 1, dtype=dd, device=L.device)], []
         for ii in range(1, Tit + 1):
             z = torch.bmm(Le, Qs[ii])
             alpha = (Qs[ii] * z).sum(dim=1, keepdim=True)
@@ -814,7 +820,7 @@ class AdaLanczosNet(_LanczosNetBase):
                         z = z - (z * Qs[jj]).sum(dim=1, keepdim=True) / (
                             (Qs[jj] * Qs[jj]).sum(dim=1, keepdim=True) + eps) * Qs[jj]
             beta = torch.norm(z, p=2, dim=1, keepdim=True)
-            ok = (beta >= 1.0e-4).float()
+            ok = (beta >= 1.0e-4).to(dd)
             valids.append(ok if ii == 1 else valids[-1] * ok)
             Qs.append((z * valids[-1]) / (beta + eps))
             alphas.append(alpha)
@@ -823,22 +829,24 @@ class AdaLanczosNet(_LanczosNetBase):
         beta = torch.cat(betas[1:-1], dim=1).squeeze(2) if Tit > 1 else alpha[:, :0]
         valid = torch.cat(valids, dim=1).squeeze(2)
         idx = torch.minimum(valid.sum(dim=1), m.squeeze(2).sum(dim=1)).long()
-        valid = valid * (torch.arange(Tit, device=L.device)[None, :] < idx[:, None]).float()
+        valid = valid * (torch.arange(Tit, device=L.device)[None, :] < idx[:, None]).to(dd)
         alpha = alpha * valid
         beta = beta * valid[:, :-1]
         T = torch.diag_embed(alpha) + torch.diag_embed(beta, offset=1) + torch.diag_embed(beta, offset=-1)
         Q = torch.cat(Qs[1:-1], dim=2) * valid.unsqueeze(1)
-        Q = Q * (torch.arange(N, device=L.device)[None, :] < idx[:, None]).float().unsqueeze(2)
+        Q = Q * (torch.arange(N, device=L.device)[None, :] < idx[:, None]).to(dd).unsqueeze(2)
         if Tit < K:
             T = torch.nn.functional.pad(T, (0, K - Tit, 0, K - Tit))
             Q = torch.nn.functional.pad(Q, (0, K - Tit))
+        m = m.float()
         # T powers (:262-270)
         T_list, TT = [], T
         for ii in range(1, self.max_long_diffusion_dist + 1):
             if ii in self.long_diffusion_dist:
                 T_list.append(TT)
             TT = torch.bmm(TT, T)
-        tcat = torch.cat(T_list, dim=2).view(B, -1)
+        tcat = torch.cat(T_list, dim=2).view(B, -1).float()   # fp64 products like lnz_ada_t_powers
+        Q = Q.float()
         Lc = Lf.permute(0, 3, 1, 2).contiguous()
         Qt = Q.transpose(1, 2)
         for t in range(self.num_layer):

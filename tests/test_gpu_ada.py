@@ -32,6 +32,96 @@ def test_ada_graph_laplacian_matches_reference():
   assert rel_err(a, oracle.ada_graph_laplacian(emb[ids], g['adj'])) < 1e-5
 
 
+LB = 1.0e-4  # the reference's breakdown threshold (model/ada_lanczos_net.py:170)
+
+
+def _separation(betas):
+  """a molecule is "well separated" when no raw beta of its Lanczos run lies within
+  10x of the 1e-4 threshold: min_i max(beta_i / 1e-4, 1e-4 / beta_i) >= 10 (beta = 0 after a
+  breakdown is infinitely far)."""
+  with np.errstate(divide='ignore'):
+    r = np.maximum(betas / LB, LB / np.maximum(betas, 1e-300))
+  return r.min(axis=1)
+
+
+def _mol_err(X, Xref):
+  B = len(X)
+  d = np.abs(np.asarray(X, np.float64) - np.asarray(Xref, np.float64)).reshape(B, -1).max(axis=1)
+  return d / np.maximum(np.abs(np.asarray(Xref, np.float64)).reshape(B, -1).max(axis=1), 1e-30)
+
+
+def _tri(alpha, beta, K=20):
+  B, T = alpha.shape
+  out = np.zeros((B, K, K), alpha.dtype)
+  i = np.arange(T)
+  out[:, i, i] = alpha
+  out[:, i[:-1], i[:-1] + 1] = beta
+  out[:, i[:-1] + 1, i[:-1]] = beta
+  return out
+
+
+def _protocol(tag, ours, ref, exact, sep, min_strict=64):
+  """The parity protocol for the fp32 in-model Lanczos.
+
+  ours / ref / exact: tuples of per-molecule arrays (our kernel, the unmodified reference's fp32
+  torch run, the fp64 restatement = exact arithmetic).  An fp32 Lanczos recurrence is a noisy
+  function: the reference's own output sits 1e-6 (median) .. 2e-4 from exact arithmetic, in a way
+  no second implementation can reproduce.  So molecules are classified by two reference-side
+  numbers, both independent of our kernel:
+     sep    the 10x beta separation of SURVEY 8(c) (decides whether the breakdown mask is stable),
+     e_ref  the reference's own distance from the exact-arithmetic result.
+  STRICT = sep >= 10 and e_ref <= 2e-6: asserted at north_star's 1e-5, element-wise, per molecule.
+  REST of sep >= 10: asserted to be no further from the reference than 3x the reference's own
+  noise (+1e-5) — a kernel cannot be asked to reproduce rounding noise, but it must not add any.
+  sep < 10: reported (the breakdown decision itself is a coin flip of rounding there)."""
+  e_ref = np.max([_mol_err(r, x) for r, x in zip(ref, exact)], axis=0)
+  e_our = np.max([_mol_err(o, r) for o, r in zip(ours, ref)], axis=0)
+  strict = (sep >= 10) & (e_ref <= 2e-6)
+  rest = (sep >= 10) & ~strict
+  near = sep < 10
+  print('%s: strict %d molecules, worst %.2e | rest of sep>=10: %d, worst %.2e (reference noise '
+        'there up to %.2e) | within 10x of the threshold: %d, worst %.2e' %
+        (tag, strict.sum(), e_our[strict].max(), rest.sum(),
+         e_our[rest].max() if rest.any() else 0.0, e_ref[rest].max() if rest.any() else 0.0,
+         near.sum(), e_our[near].max() if near.any() else 0.0))
+  assert strict.sum() >= min_strict, strict.sum()
+  bad = np.where(strict & (e_our > 1e-5))[0]
+  assert len(bad) == 0, (tag, bad[:8], e_our[bad][:8])
+  bad = np.where(rest & (e_our > 3.0 * e_ref + 1e-5))[0]
+  assert len(bad) == 0, (tag, bad[:8], e_our[bad][:8], e_ref[bad][:8])
+  return strict
+
+
+def test_ada_lanczos_layer_parity_protocol():
+  """R5 on 192 QM8-sized molecules, both operand classes (the simple-graph L4 and the learned
+  Gaussian-kernel Laplacian), against the unmodified reference's `_lanczos_layer`."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  g = load_golden('ada_protocol.npz')
+  b = draw_batch(len(g['n_nodes']), seed=int(g['seed']), n_min=int(g['n_min']),
+                 n_max=int(g['n_max']))
+  np.testing.assert_array_equal(b['n_nodes'], g['n_nodes'])
+  B, N = b['node_mask'].shape
+  A = np.zeros((B, N, N), np.float32)
+  for i in range(B):
+    n = int(b['n_nodes'][i])
+    A[i, :n, :n] = oracle.laplacian_l4(b['adjs'][i, :n, :n].sum(axis=2))
+  for tag, M, al, be, Qref, braw in (('L4', A, g['alpha'], g['beta'], g['Q'], g['betas_raw']),
+                                     ('learned', g['Le'], g['alpha2'], g['beta2'], g['Q2'],
+                                      g['betas_raw2'])):
+    Tref = _tri(al, be)
+    T, Q = ops.ada_lanczos_layer(_t(M), _t(b['node_mask']), _t(g['q1']), 20)
+    T, Q = T.cpu().numpy(), Q.cpu().numpy()
+    T64, Q64 = oracle.ada_lanczos_layer(M, b['node_mask'], g['q1'], 20, dtype=np.float64)
+    sep = _separation(braw)
+    # the quirk structure (which alpha / beta / columns / node rows are zeroed) is exact wherever
+    # the breakdown decisions are stable
+    ok = sep >= 10
+    np.testing.assert_array_equal((T != 0)[ok], (Tref != 0)[ok])
+    np.testing.assert_array_equal((Q != 0)[ok], (Qref != 0)[ok])
+    _protocol('lanczos layer / ' + tag, (T, Q), (Tref, Qref), (T64, Q64), sep)
+
+
 def test_ada_lanczos_layer_matches_reference_incl_quirks():
   from lanczosnet_amd import ops
   g = load_golden('ada_lanczos.npz')
@@ -41,11 +131,7 @@ def test_ada_lanczos_layer_matches_reference_incl_quirks():
     # quirk structure (which alpha / beta / columns / node rows are zeroed) must match exactly
     np.testing.assert_array_equal(T != 0, Tref != 0)
     np.testing.assert_array_equal(Q != 0, Qref != 0)
-    # values: fp32 Lanczos amplifies summation-order noise near breakdown (the numpy oracle
-    # itself differs from torch by up to 2e-4 / 2e-3 here, tests/test_oracle_golden.py)
-    per_mol_T = np.abs(T - Tref).reshape(len(T), -1).max(axis=1)
-    assert np.median(per_mol_T) < 1e-5 and rel_err(T, Tref) < 5e-4
-    assert rel_err(Q, Qref) < 5e-3
+    # values: see test_ada_lanczos_layer_parity_protocol (per-molecule, 192 molecules)
   # 6-node fixture of SURVEY.md §A.3 (probe values from the unmodified reference, N=8 tile)
   s = load_golden('six_node.npz')
   A = np.zeros((1, 8, 8), np.float32)
@@ -112,24 +198,60 @@ def test_ada_dense_filter_conv_matches_oracle_given_TQ():
   assert rel_err(score, ref) < 1e-5
 
 
-def test_ada_lanczos_net_end_to_end_vs_reference():
-  g = load_golden('ada_full.npz')
-  c = load_golden('collate_batch.npz')
-  cfg = ast.literal_eval(str(g['cfg_json']))
+class _fixed_randn(object):
+  """The reference draws torch.randn(B,N,1) on the CPU generator (:161); hand both the same."""
+
+  def __init__(self, q1):
+    self.q1 = torch.from_numpy(np.ascontiguousarray(q1[:, :, None]))
+
+  def __enter__(self):
+    self.real = torch.randn
+    torch.randn = lambda *a, **k: self.q1.clone()
+
+  def __exit__(self, *exc):
+    torch.randn = self.real
+
+
+def _e2e_inputs(g):
+  from lanczosnet_amd.synthetic import draw_batch
+  p = load_golden('ada_protocol.npz')
   nb = int(g['nb'])
+  b = draw_batch(len(p['n_nodes']), seed=int(p['seed']), n_min=int(p['n_min']),
+                 n_max=int(p['n_max']))
+  B, N = b['node_mask'].shape
+  L = np.zeros((B, N, N, 7), np.float32)
+  for i in range(nb):
+    n = int(b['n_nodes'][i])
+    L[i, :n, :n] = oracle.laplacian_multi_l4(b['adjs'][i, :n, :n])
+  return b['node_feat'][:nb], L[:nb], b['node_mask'][:nb], b['label'][:nb]
+
+
+def test_ada_lanczos_net_end_to_end_parity_protocol():
+  """Full AdaLanczosNet (2 layers, 4096-wide filter MLPs) on 96 molecules against the unmodified
+  reference class: scores under the same protocol as the Lanczos layer."""
+  g = load_golden('ada_e2e.npz')
+  cfg = ast.literal_eval(str(g['cfg_json']))
   P = oracle.make_ada_params(cfg, int(g['param_seed']))
   net = _ada_model(cfg, P)
-  real_randn = torch.randn
-  q1 = torch.from_numpy(g['q1'][:, :, None].copy())
-  torch.randn = lambda *a, **k: q1.clone()  # the reference draws torch.randn(B,N,1) (:161)
-  try:
-    with torch.no_grad():
-      score = net(_t(c['node_feat'][:nb]), _t(c['L'][:nb]), mask=_t(c['node_mask'][:nb]))
-  finally:
-    torch.randn = real_randn
-  score = score.cpu().numpy()
-  e = np.abs(score - g['score']).max(axis=1) / np.abs(g['score']).max()
-  assert np.median(e) < 2e-4 and e.max() < 5e-3, e  # same bar as the oracle-vs-reference pin
+  nf, L, mask, _ = _e2e_inputs(g)
+  with _fixed_randn(g['q1']), torch.no_grad():
+    score = net(_t(nf), _t(L), mask=_t(mask)).cpu().numpy()
+  s64, _ = oracle.ada_lanczos_net_forward(P, cfg, nf, L, mask, g['q1'], dtype=np.float64)
+  scale = np.abs(s64).max()
+  # scores are compared relative to the batch maximum (as everywhere else for scores)
+  e_ref = np.abs(g['score'] - s64).max(axis=1) / scale
+  e_our = np.abs(score - g['score']).max(axis=1) / scale
+  sep = _separation(g['betas_raw'])
+  strict = (sep >= 10) & (e_ref <= 2e-6)
+  rest = (sep >= 10) & ~strict
+  near = sep < 10
+  print('e2e: strict %d molecules, worst %.2e | rest %d, worst %.2e | near threshold %d, worst '
+        '%.2e (reference noise there %.2e)' %
+        (strict.sum(), e_our[strict].max(), rest.sum(), e_our[rest].max() if rest.any() else 0,
+         near.sum(), e_our[near].max(), e_ref[near].max()))
+  assert strict.sum() >= 64
+  assert e_our[strict].max() < 1e-5
+  assert (e_our[rest] <= 3 * e_ref[rest] + 1e-5).all()
 
 
 def test_ada_module_surface():
@@ -146,32 +268,46 @@ def test_ada_module_surface():
 
 
 def test_ada_training_gradients_match_reference_autograd():
-  """AdaLanczosNet loss.backward() (HIP forward + torch recomputation backward, same q1) against
-  the reference's parameter-gradient statistics (tests/golden/ada_full.npz)."""
-  g = load_golden('ada_full.npz')
-  c = load_golden('collate_batch.npz')
+  """AdaLanczosNet `loss.backward()` (HIP forward; backward = autograd through the device-side
+  restatement with the SAME q1, Lanczos part in fp64) against the reference's own autograd on a
+  batch of 32 molecules of the strict set (tests/golden/ada_e2e.npz `grad_idx`).
+
+  Same protocol as the forward: the reference's fp32 autograd through the Lanczos recurrence is
+  itself 4e-5 (abs-sum) .. 1.5e-4 (max entry) away from the SAME reference class run in float64
+  (`make_golden_ada.py` stores both), so per parameter tensor and statistic
+     - against the reference's float64 gradient (exact arithmetic): 1e-5;
+     - against the reference's fp32 gradient: no further than 3x the reference's own fp32-vs-fp64
+       deviation (+1e-5)."""
+  g = load_golden('ada_e2e.npz')
   cfg = ast.literal_eval(str(g['cfg_json']))
-  nb = int(g['nb'])
   P = oracle.make_ada_params(cfg, int(g['param_seed']))
   net = _ada_model(cfg, P).train()
-  real_randn = torch.randn
-  q1 = torch.from_numpy(g['q1'][:, :, None].copy())
-  torch.randn = lambda *a, **k: q1.clone()
-  try:
-    score, loss = net(_t(c['node_feat'][:nb]), _t(c['L'][:nb]), label=_t(c['label'][:nb]),
-                      mask=_t(c['node_mask'][:nb]))
-  finally:
-    torch.randn = real_randn
-  assert abs(float(loss.detach()) - float(g['loss'])) < 5e-3 * abs(float(g['loss']))
+  nf, L, mask, lab = _e2e_inputs(g)
+  gi = g['grad_idx']
+  with _fixed_randn(g['q1'][gi]):
+    score, loss = net(_t(nf[gi]), _t(L[gi]), label=_t(lab[gi]), mask=_t(mask[gi]))
+  rel_loss = abs(float(loss.detach()) - float(g['loss'])) / abs(float(g['loss']))
   loss.backward()
   gd = dict(net.named_parameters())
-  worst = 0.0
-  for k, gs, ga in zip(g['gnames'], g['gsum'], g['gabs']):
+  worst64, worst32, noise = (0.0, None), (0.0, None), 0.0
+  for i, k in enumerate(g['gnames']):
     gr = gd[str(k)].grad
     assert gr is not None, k
-    # fp32 Lanczos noise floor (see the forward tests): gradients agree to ~1e-3 of their mass
-    e = abs(float(gr.double().abs().sum()) - float(ga)) / (float(ga) + 1e-12)
-    worst = max(worst, e)
-    assert e < 2e-2, (k, e)
-    assert abs(float(gr.double().sum()) - float(gs)) < 2e-2 * float(ga) + 1e-9, k
-  print('worst relative gradient-mass deviation %.2e' % worst)
+    grd = gr.double()
+    ours = dict(gsum=float(grd.sum()), gabs=float(grd.abs().sum()), gmax=float(grd.abs().max()))
+    for stat in ('gsum', 'gabs', 'gmax'):
+      den = float(g['gmax64'][i]) if stat == 'gmax' else float(g['gabs64'][i])
+      e64 = abs(ours[stat] - float(g[stat + '64'][i])) / den
+      e32 = abs(ours[stat] - float(g[stat][i])) / den
+      eref = abs(float(g[stat][i]) - float(g[stat + '64'][i])) / den
+      noise = max(noise, eref)
+      if e64 > worst64[0]:
+        worst64 = (e64, '%s %s' % (k, stat))
+      if e32 - 3 * eref > worst32[0]:
+        worst32 = (e32 - 3 * eref, '%s %s' % (k, stat))
+  print('loss rel dev %.2e; vs reference float64 gradients: worst %.2e (%s); vs reference fp32 '
+        'beyond 3x its own noise: %.2e; reference fp32-vs-float64 noise up to %.2e' %
+        (rel_loss, worst64[0], worst64[1], worst32[0], noise))
+  assert rel_loss < 1e-5
+  assert worst64[0] < 1e-5, worst64
+  assert worst32[0] < 1e-5, worst32
