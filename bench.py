@@ -247,7 +247,12 @@ def main():
                        'and computes the spectral gains of batch k')
   ap.add_argument('--cpu-reps', type=int, default=5)
   ap.add_argument('--no-secondary', action='store_true',
-                  help='skip the secondary legs (batch sweep, large-graph Lanczos, AdaLanczosNet)')
+                  help='skip the secondary legs (large-graph Lanczos, AdaLanczosNet)')
+  ap.add_argument('--sweep', action='store_true',
+                  help='add config.forward_batch_sweep (fused forward at B = 1024 / 4096 / 16384); '
+                       'opt-in because its launches are the SAME kernel as the roofline one and '
+                       'would mix into a rocprofv3 --stats average of the default command '
+                       '(profiles/r02_c_bench.json holds a run with it)')
   ap.add_argument('--gemm', default='fp32', choices=['fp32', 'f16x3'],
                   help="fp32 = exact fp32 MFMA (headline); f16x3 = opt-in split-precision GEMM1")
   ap.add_argument('--zero-params', action='store_true',
@@ -440,9 +445,10 @@ def main():
 
   # secondary measurements (N = 1 only, never `value`)
   sweep = large = ada = None
-  if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.no_secondary:
+  if world == 1 and args.gemm == 'fp32' and not args.zero_params and args.sweep:
     sweep = forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, (1024, 4096, 16384)
                                 if B == 1024 else (B,))
+  if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.no_secondary:
     large = lanczos_large_leg(dev)
     ada = ada_leg(dev, L, node_feat, mask_u8)
 
