@@ -69,6 +69,44 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
                      const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                      int32_t* info, lnz_stream_t stream);
 
+/* ---- R9 / R11 beyond the 32-node tile: streamed spectral convolution for large dense graphs ----
+ * (BASELINE config 5: LanczosNetGeneral, N = 2048, K = 64, batch 256, bf16 operands / fp32
+ * accumulate).  One conv layer of model/lanczos_net_general.py:157-182,
+ *     X' = relu( sum_e L_e (X W_e^T) + V [ sum_s diag(g_s) (V^T X) W_s^T ] + b ),
+ * as four launches; hidden width 128, input width <= 128, K <= 64, any N.
+ * planes = 1: bf16 operands (8-bit mantissa: ~1e-2 after 7 layers).  planes = 3: every fp32
+ * operand travels as three bf16 pieces and every product as its six piece products of order
+ * <= 2, fp32 accumulate: fp32-grade results from the same kernels (the parity mode).
+ *   Nk = lnz_large_nk(N) = N rounded up to 64 (the k extent of the packed operands).
+ *   lnz_large_pack_operators  once per batch.  L [B,N,N,C] fp32 addressed by element strides
+ *                             (channels-last collate layout, dataset/graph_data.py collate) ->
+ *                             Lb [planes][B][C][N][Nk] bf16;  V [B,N,K] -> Vb [planes][B][N][64].
+ *   lnz_large_gemm1           Zt [planes][B][C][128][Nk] bf16 = (X W_c^T)^T for the C node-space
+ *                             channels; X [B,N,ldx] fp32 (first din columns used);
+ *                             Wb [planes][C*128][dinp] bf16, dinp = din rounded up to 16, zero
+ *                             padded.  Columns n >= N of Zt are NOT written: the caller provides a
+ *                             zero-initialised buffer (it can be reused for every layer).
+ *   lnz_large_spectral        Tt [planes][B][128][64] bf16 = (sum_s diag(g_s) (V^T X) W_s^T)^T;
+ *                             exact fp32 inside.  G [B,S,K] = this layer's gains (one [B,S,K]
+ *                             slice of lnz_spectral_gains' output); Wt [S*dinp][128] fp32 = the
+ *                             long-scale column blocks of the mix weight, transposed, rows i >= din
+ *                             of every block zero.
+ *   lnz_large_conv            Xout [B,N,128] fp32 = act( sum_c Lb_c Zt_c^T + Vb Tt^T + bias ).
+ * Replaces the per-slice bmm / cat / Linear of model/lanczos_net_general.py:161-182 (and
+ * model/lanczos_net.py:157-182 for N > 32). */
+int64_t lnz_large_nk(int N);
+int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                             int64_t stride_ch, const float* V, int B, int N, int C, int K,
+                             int planes, uint16_t* Lb, uint16_t* Vb, lnz_stream_t stream);
+int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wb, int B, int N, int C,
+                    int planes, uint16_t* Zt, lnz_stream_t stream);
+int lnz_large_spectral(const float* X, int ldx, int din, const float* V, const float* G,
+                       const float* Wt, int B, int N, int K, int S, int planes, uint16_t* Tt,
+                       lnz_stream_t stream);
+int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt, const uint16_t* Tt,
+                   const float* bias, int B, int N, int C, int planes, int relu, float* Xout,
+                   lnz_stream_t stream);
+
 /* ---- R6 standalone: batched symmetric tridiagonal eigensolver --------------------------------
  * The step the reference leaves to LAPACK (inside np.linalg.eigh, utils/data_helper.py:201) /
  * ARPACK (:208).  diag [B,M], offdiag [B,M-1] (fp64) -> R [B,M] ascending, Bm [B,M,M] with

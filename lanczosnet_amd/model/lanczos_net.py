@@ -291,8 +291,8 @@ class _LanczosNetBase(nn.Module):
             plan['din0'] = din0  # this kernel pads columns itself
             if emb is not None:
                 plan['embedding'] = self.embedding.weight.detach().float().contiguous()
-        elif self.gemm_mode != 'fp32':
-            raise ValueError("gemm_mode must be 'fp32' or 'f16x3'")
+        elif self.gemm_mode not in ('fp32', 'bf16'):
+            raise ValueError("gemm_mode must be 'fp32', 'f16x3' (N <= 32) or 'bf16' (N > 32)")
         if self._has_mlp() and self.filter_kind == 0:
             plan['mlp_pack'] = ops.pack_spectral_mlp_layers(
                 [[(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
@@ -376,17 +376,68 @@ class _LanczosNetBase(nn.Module):
         return (y * m).sum(dim=1) / m.sum(dim=1)
 
     @torch.no_grad()
-    def _plan_large(self):
+    def _plan_large(self, planes=None):
         sig = self._param_signature()
         cache = getattr(self, '_plan_large_cache', None)
-        if cache is not None and cache['sig'] == sig:
-            return cache
-        dev = self.filter[0].weight.device
-        buf = ops.pack_spectral_mlp_layers(
-            [[(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)] for seq in self.spectral_filter],
-            self.num_scale_long)
-        self._plan_large_cache = dict(sig=sig, mlp_pack=buf)
-        return self._plan_large_cache
+        if cache is None or cache['sig'] != sig:
+            buf = None
+            if self._has_mlp():
+                buf = ops.pack_spectral_mlp_layers(
+                    [[(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
+                     for seq in self.spectral_filter], self.num_scale_long)
+            cache = self._plan_large_cache = dict(sig=sig, mlp_pack=buf, conv={})
+        if planes is not None and planes not in cache['conv']:
+            # per layer: the node-space (edge-type) column blocks of the mix weight as bf16 pieces
+            # [planes, C*128, dinp] (the A image of lnz_large_gemm1) and the long-scale blocks
+            # transposed, fp32 [S*dinp, 128] (lnz_large_spectral)
+            S, E1 = self.num_scale_long, self.num_edgetype + 1
+            layers = []
+            for t in range(self.num_layer):
+                W = self._mix_weight(t).detach().float()
+                dout = W.shape[0]
+                d_in = W.shape[1] // (S + E1)
+                dinp = (d_in + 15) // 16 * 16
+                Wc = torch.nn.functional.pad(W.view(dout, S + E1, d_in), (0, dinp - d_in))
+                Wb = ops.split_bf16_planes(Wc[:, S:].permute(1, 0, 2).reshape(E1 * dout, dinp), planes)
+                Wt = Wc[:, :S].permute(1, 2, 0).reshape(S * dinp, dout).contiguous() if S else None
+                layers.append(dict(Wb=Wb, Wt=Wt, bias=self.filter[t].bias.detach().float().contiguous(),
+                                   din=d_in))
+            cache['conv'][planes] = layers
+        return cache
+
+    def _large_hip_supported(self, K):
+        """lnz_large_*: uniform hidden width 128, input width <= 128, no short-diffusion powers,
+        K <= 64."""
+        return (set(self.hidden_dim[:self.num_layer]) == {128} and self.input_dim <= 128
+                and self.num_scale_short == 0 and K <= 64)
+
+    @torch.no_grad()
+    def _large_graph_forward_hip(self, node_feat, L, D, V, mask, planes=3):
+        """Graphs beyond the 32-node MFMA tile on the hand-written streaming kernels
+        (csrc/conv_large.hip; BASELINE config 5: N = 2048, K = 64, batch 256): the operators are
+        packed once (channel-major bf16 planes), every layer is gemm1 + eigen-space spectral block
+        + streamed conv.  planes = 3: fp32-grade split products (default, the 1e-5 parity mode);
+        planes = 1: plain bf16 operands / fp32 accumulate (`gemm_mode = 'bf16'`, config 5's mode)."""
+        S = self.num_scale_long
+        plan = self._plan_large(planes)
+        Lf = L if L.dtype == torch.float32 else L.float()
+        Vf = V.float().contiguous()
+        G = None
+        if S > 0:
+            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
+        Lb, Vb = ops.large_pack_operators(Lf, Vf, planes)
+        Zt, Tt = ops.large_work_buffers(Lb)
+        state = node_feat.float().contiguous() if self.general else \
+            self.embedding(node_feat).float().contiguous()
+        bufs = [None, None]
+        for t, lay in enumerate(plan['conv'][planes]):
+            state = ops.large_conv_layer(state, lay['din'], Lb, Vb, Vf, lay['Wb'], lay['Wt'],
+                                         G[t] if G is not None else None, lay['bias'], Zt, Tt,
+                                         relu=True, out=bufs[t & 1])
+            bufs[t & 1] = state
+        y = self.filter[-1](state) * self.att_func(state)
+        m = (mask != 0).float().unsqueeze(2)
+        return (y * m).sum(dim=1) / m.sum(dim=1)
 
     def _fused_backward_supported(self):
         """The HIP backward (lnz_lanczosnet_input_grad / _messages) is built for the exact-fp32
@@ -501,6 +552,10 @@ class _LanczosNetBase(nn.Module):
                 # the reference trains arbitrary widths / sizes: differentiate the device-side
                 # torch restatement (same association as the kernels)
                 score = self._torch_forward(node_feat, L, D, V, mask, dropout=drop)
+            elif L.shape[1] > 32 and self._large_hip_supported(V.shape[2]):
+                # hand-written streaming kernels; 'bf16' = config 5's bf16-operand mode
+                score = self._large_graph_forward_hip(node_feat, L, D, V, mask,
+                                                      planes=1 if self.gemm_mode == 'bf16' else 3)
             else:
                 score = self._large_graph_forward(node_feat, L, D, V, mask)
         elif self._needs_grad():

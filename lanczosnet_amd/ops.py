@@ -110,6 +110,75 @@ def lanczos_ritz_large(A, M, K, workspace=None, return_info=False):
   return (D, V, info) if return_info else (D, V)
 
 
+# --------------------------------------------------------------- R9 / R11 for graphs beyond 32 nodes
+def split_bf16_planes(x, planes):
+  """fp32 tensor -> [planes, ...] bf16 pieces with x ~= sum of the pieces (each piece the bf16
+  rounding of the remainder; planes = 1 is the plain bf16 cast)."""
+  r = x.to(torch.float32)
+  out = []
+  for _ in range(planes):
+    p = r.to(torch.bfloat16)
+    out.append(p)
+    r = r - p.to(torch.float32)
+  return torch.stack(out).contiguous()
+
+
+def large_pack_operators(L, V, planes=1):
+  """lnz_large_pack_operators: L [B,N,N,C] fp32 (any strides), V [B,N,K] ->
+  Lb [planes,B,C,N,Nk] bf16, Vb [planes,B,N,64] bf16 (Nk = N rounded up to 64)."""
+  _need_cuda(L, V)
+  assert L.dim() == 4 and L.dtype == torch.float32 and V.dim() == 3
+  V = _f32c(V)
+  B, N, _, Cn = L.shape
+  K = V.shape[2]
+  lib = _lib.load()
+  Nk = lib.lnz_large_nk(N)
+  Lb = torch.empty((planes, B, Cn, N, Nk), dtype=torch.bfloat16, device=L.device)
+  Vb = torch.empty((planes, B, N, 64), dtype=torch.bfloat16, device=L.device)
+  sb, sr, sc, sch = L.stride()
+  with torch.cuda.device(L.device):
+    _lib.check(lib.lnz_large_pack_operators(_ptr(L), sb, sr, sc, sch, _ptr(V), B, N, Cn, K, planes,
+                                            _ptr(Lb), _ptr(Vb), _stream()))
+  return Lb, Vb
+
+
+def large_conv_layer(X, din, Lb, Vb, V, Wb, Wt, G, bias, Zt, Tt, relu=True, out=None):
+  """One conv layer on packed large-graph operators: lnz_large_gemm1 + lnz_large_spectral +
+  lnz_large_conv.  X [B,N,ldx] fp32 (first `din` columns are the layer input); V [B,N,K] fp32 (the
+  Ritz vectors Vb was packed from); Wb [planes, C*128, dinp] bf16; Wt [S*dinp,128] fp32 and
+  G [B,S,K] fp32 (or None without long scales); Zt / Tt:
+  work buffers from large_work_buffers() (Zt zero-initialised once).  Returns X' [B,N,128]."""
+  _need_cuda(X, Lb, Vb, V, Wb, Wt, G, bias, Zt, Tt)
+  planes, B, Cn, N, Nk = Lb.shape
+  K = V.shape[2]
+  assert V.dtype == torch.float32 and V.is_contiguous()
+  assert X.dtype == torch.float32 and X.is_contiguous() and X.shape[0] == B and X.shape[1] == N
+  ldx = X.shape[2]
+  lib = _lib.load()
+  if out is None:
+    out = torch.empty((B, N, 128), dtype=torch.float32, device=X.device)
+  with torch.cuda.device(X.device):
+    _lib.check(lib.lnz_large_gemm1(_ptr(X), ldx, din, _ptr(Wb), B, N, Cn, planes, _ptr(Zt),
+                                   _stream()))
+    if G is not None:
+      S = G.shape[1]
+      assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
+      _lib.check(lib.lnz_large_spectral(_ptr(X), ldx, din, _ptr(V), _ptr(G), _ptr(Wt), B, N, K,
+                                        S, planes, _ptr(Tt), _stream()))
+    _lib.check(lib.lnz_large_conv(_ptr(Lb), _ptr(Vb), _ptr(Zt), _ptr(Tt), _ptr(bias), B, N, Cn,
+                                  planes, int(bool(relu)), _ptr(out), _stream()))
+  return out
+
+
+def large_work_buffers(Lb):
+  """(Zt, Tt) work buffers for large_conv_layer: Zt [planes,B,C,128,Nk] and Tt [planes,B,128,64]
+  bf16, zero-initialised (gemm1 never writes the k padding; Tt stays zero without long scales)."""
+  planes, B, Cn, N, Nk = Lb.shape
+  Zt = torch.zeros((planes, B, Cn, 128, Nk), dtype=torch.bfloat16, device=Lb.device)
+  Tt = torch.zeros((planes, B, 128, 64), dtype=torch.bfloat16, device=Lb.device)
+  return Zt, Tt
+
+
 # ------------------------------------------------------------------------------------- packing
 def pack_rows_k8(W):
   """[rows, cols] -> MFMA fragment order (see include/lanczosnet_hip.h)."""
