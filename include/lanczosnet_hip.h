@@ -80,17 +80,26 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
  *   Nk = lnz_large_nk(N) = N rounded up to 64 (the k extent of the packed operands).
  *   lnz_large_pack_operators  once per batch.  L [B,N,N,C] fp32 addressed by element strides
  *                             (channels-last collate layout, dataset/graph_data.py collate) ->
- *                             Lb [planes][B][C][N][Nk] bf16;  V [B,N,K] -> Vb [planes][B][N][64].
+ *                             Lb [planes][B][C][RT][Nk/64][4][64][8] bf16 in fragment-tile order
+ *                             (RT = ceil(N/32) row groups; chunk (rg, kb) = 32 rows x 64 k as the
+ *                             four v_mfma_f32_16x16x32_bf16 A fragments f = 2 rt + ks, lane =
+ *                             16 kq + r15 holding row 32 rg + 16 rt + r15, k 64 kb + 32 ks + 8 kq
+ *                             .. + 7);  V [B,N,K] -> Vb [planes][B][RT][4][64][8] likewise.
  *   lnz_large_gemm1           Zt [planes][B][C][128][Nk] bf16 = (X W_c^T)^T for the C node-space
  *                             channels; X [B,N,ldx] fp32 (first din columns used);
- *                             Wb [planes][C*128][dinp] bf16, dinp = din rounded up to 16, zero
- *                             padded.  Columns n >= N of Zt are NOT written: the caller provides a
+ *                             Wf [planes][C][4][dinp/16][64][8] bf16 = the channel blocks of the
+ *                             mix weight (dinp = din rounded up to 16, zero padded) in
+ *                             v_mfma_f32_32x32x16_bf16 A-fragment order: fragment (c, mt, ks),
+ *                             lane l holds W_c[32 mt + (l & 31)][16 ks + 8 (l >> 5) .. + 7].
+ *                             Columns n >= N of Zt are NOT written: the caller provides a
  *                             zero-initialised buffer (it can be reused for every layer).
  *   lnz_large_spectral        Tt [planes][B][128][64] bf16 = (sum_s diag(g_s) (V^T X) W_s^T)^T;
- *                             exact fp32 inside.  G [B,S,K] = this layer's gains (one [B,S,K]
- *                             slice of lnz_spectral_gains' output); Wt [S*dinp][128] fp32 = the
- *                             long-scale column blocks of the mix weight, transposed, rows i >= din
- *                             of every block zero.
+ *                             exact fp32 inside (two launches: row-chunked projection V^T X with
+ *                             fp32 atomics into Ybuf, then the per-graph mix).  G [B,S,K] = this
+ *                             layer's gains (one [B,S,K] slice of lnz_spectral_gains' output);
+ *                             Wt = lnz_pack_rows_k8 of W_long [128][S*dinp] fp32, the long-scale
+ *                             column blocks of the mix weight, each zero padded to dinp columns;
+ *                             Ybuf [B][64][128] fp32 work buffer, ZERO on entry, zero on return.
  *   lnz_large_conv            Xout [B,N,128] fp32 = act( sum_c Lb_c Zt_c^T + Vb Tt^T + bias ).
  * Replaces the per-slice bmm / cat / Linear of model/lanczos_net_general.py:161-182 (and
  * model/lanczos_net.py:157-182 for N > 32). */
@@ -98,11 +107,11 @@ int64_t lnz_large_nk(int N);
 int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                              int64_t stride_ch, const float* V, int B, int N, int C, int K,
                              int planes, uint16_t* Lb, uint16_t* Vb, lnz_stream_t stream);
-int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wb, int B, int N, int C,
+int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wf, int B, int N, int C,
                     int planes, uint16_t* Zt, lnz_stream_t stream);
 int lnz_large_spectral(const float* X, int ldx, int din, const float* V, const float* G,
-                       const float* Wt, int B, int N, int K, int S, int planes, uint16_t* Tt,
-                       lnz_stream_t stream);
+                       const float* Wt, int B, int N, int K, int S, int planes, float* Ybuf,
+                       uint16_t* Tt, lnz_stream_t stream);
 int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt, const uint16_t* Tt,
                    const float* bias, int B, int N, int C, int planes, int relu, float* Xout,
                    lnz_stream_t stream);

@@ -9,10 +9,17 @@
 // 128 flop/B on packed bf16 — the bf16 matrix pipe needs 320 flop/B to saturate), so the design
 // is a streaming one:
 //
-//   lnz_large_pack_operators   once per batch: channels-last fp32 L [B,N,N,C] -> channel-major
-//                              bf16 planes Lb [P][B][C][N][Nk] (k padded to 64), V -> Vb.  The
-//                              channels-last layout would make every per-channel read strided;
-//                              packed bf16 halves the bytes all num_layer passes stream.
+//   lnz_large_pack_operators   once per batch: channels-last fp32 L [B,N,N,C] -> bf16 planes in
+//                              FRAGMENT-TILE order Lb [P][B][C][RT][nkb][4][64][8]: the 32 rows x
+//                              64 k block a wavefront consumes per k-block is one contiguous
+//                              4 KiB chunk laid out as its four A fragments (row tile, k-step) x
+//                              lane x 8 bf16, consecutive k-blocks consecutive — every wave
+//                              streams ONE sequential 4 KiB-granular region (128 KiB per channel
+//                              at N = 2048), every global_load_dwordx4 is 1 KiB contiguous.
+//                              (Row-major bf16 rows made the 256 rows of a workgroup a 4 KiB-
+//                              stride gather that leaned on a few HBM channels: 3.9 TB/s.)
+//                              V -> Vb [P][B][RT][4][64][8] likewise.  Packed bf16 also halves
+//                              the bytes all num_layer passes stream.
 //   lnz_large_gemm1            per layer: Z_e = X W_e^T on the matrix pipe, written TRANSPOSED
 //                              (Zt [P][B][C][128][Nk] bf16) — exactly the B-operand image the
 //                              conv kernel stages.
@@ -48,7 +55,7 @@ typedef unsigned short u16;
 
 constexpr int DH = 128;        // hidden width (output columns of every layer)
 constexpr int KB = 64;         // k-block of the conv loop (bf16 elements = one 128 B line per row)
-constexpr int BP = 72;         // LDS pitch of a staged B row in bf16 (144 B: conflict-free b128)
+constexpr int BP = 64;         // LDS pitch of a staged B row in bf16: 128 B, 16 B chunks XOR-swizzled
 
 __device__ inline __bf16 to_bf16(float x) {  // round to nearest even (v_cvt_pk_bf16_f32)
   bf16x2 p = __builtin_convertvector(f32x2{x, 0.0f}, bf16x2);
@@ -71,180 +78,350 @@ __device__ inline void split_bf16(float x, __bf16* p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// pack: L [B,N,N,C] fp32 (any strides) -> Lb [P][B][C][N][Nk];  V [B,N,K] -> Vb [P][B][N][64]
-// One workgroup per (graph, row): reads the row's N*C floats (channels-last: contiguous),
-// writes C bf16 rows.  Columns k in [N, Nk) and eigen slots in [K, 64) are zero.
+// pack: L [B,N,N,C] fp32 (any strides) -> Lb [P][B][C][RT][nkb][4][64][8];  V [B,N,K] -> Vb
+// [P][B][RT][4][64][8].  Chunk (row group rg of 32 rows, k-block kb of 64): fragment f = 2 rt +
+// ks (rt: rows 16 rt .. + 15 of the group, ks: k 32 ks .. + 31 of the block), lane = 16 kq + r15
+// holds A[row = 32 rg + 16 rt + r15][k = 64 kb + 32 ks + 8 kq .. + 7] — the A operand of
+// v_mfma_f32_16x16x32_bf16 as it is loaded.  Rows >= N, columns >= N and eigen slots >= K: zero.
+// One workgroup per (graph, row group): thread (row = t / 8, j = t % 8) owns 8 consecutive k of
+// its row for ALL channels per k-block — 32 C contiguous bytes of a channels-last row — and
+// writes one 16 B fragment piece per channel and plane; the workgroup emits whole 4 KiB chunks.
 // ------------------------------------------------------------------------------------------
+__device__ inline int frag_slot(int row32, int j) {  // 16 B slot of (row in group, k-octet j) in a chunk
+  return (((row32 >> 4) * 2 + (j >> 2)) * 64 + (j & 3) * 16 + (row32 & 15));
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void large_pack_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch,
-    const float* __restrict__ V, int B, int N, int Nk, int C, int K, u16* __restrict__ Lb,
+    const float* __restrict__ V, int B, int N, int nkb, int C, int K, u16* __restrict__ Lb,
     u16* __restrict__ Vb) {
-  const int r = blockIdx.x, b = blockIdx.y;
-  const float* Lr = L + (int64_t)b * sb + (int64_t)r * sr;
-  const int64_t plane_l = (int64_t)B * C * N * Nk;
-  // thread = (8 consecutive k, channel c): channels-last source -> the C threads of a k-group read
-  // one contiguous 32*C-byte piece; one 16 B store per plane into the channel-major bf16 row
-  for (int idx = threadIdx.x; idx < C * (Nk / 8); idx += 256) {
-    const int j = idx / C, c = idx - j * C;
+  const int rg = blockIdx.x, b = blockIdx.y, RT = gridDim.x;
+  const int row32 = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const int r = 32 * rg + row32;
+  const bool rv = r < N;
+  const float* Lr = L + (int64_t)b * sb + (int64_t)(rv ? r : 0) * sr;
+  const int64_t plane_l = (int64_t)B * C * RT * nkb * 2048;
+  const int slot = frag_slot(row32, j);
+  const bool fast = sch == 1 && sc == C && C == 2 && (((uintptr_t)Lr) & 15) == 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int k0 = 64 * kb + 8 * j;
+    for (int c0 = 0; c0 < C; c0 += 2) {
+      float x[2][8];
+      if (fast && rv && k0 + 8 <= N) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Lr + (int64_t)k0 * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 a = src[q];
+          x[0][2 * q] = a[0]; x[1][2 * q] = a[1]; x[0][2 * q + 1] = a[2]; x[1][2 * q + 1] = a[3];
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u, c = c0 + cc;
+            x[cc][u] = (rv && k < N && c < C) ? Lr[(int64_t)k * sc + (int64_t)c * sch] : 0.0f;
+          }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c = c0 + cc;
+        if (c < C) {
+          bf16x8 out[P];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            __bf16 p[P];
+            split_bf16<P>(x[cc][u], p);
+#pragma unroll
+            for (int i = 0; i < P; ++i) out[i][u] = p[i];
+          }
+          const int64_t o = ((((int64_t)b * C + c) * RT + rg) * nkb + kb) * 2048 + (int64_t)slot * 8;
+#pragma unroll
+          for (int i = 0; i < P; ++i) *reinterpret_cast<bf16x8*>(Lb + i * plane_l + o) = out[i];
+        }
+      }
+    }
+  }
+  // the Ritz vectors: one chunk per row group
+  {
+    const int64_t plane_v = (int64_t)B * RT * 2048;
     bf16x8 out[P];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int k = 8 * j + u;
-      const float x = k < N ? Lr[(int64_t)k * sc + (int64_t)c * sch] : 0.0f;
+      const float x = (rv && k < K) ? V[((int64_t)b * N + r) * K + k] : 0.0f;
       __bf16 p[P];
       split_bf16<P>(x, p);
 #pragma unroll
       for (int i = 0; i < P; ++i) out[i][u] = p[i];
     }
-    const int64_t o = (((int64_t)b * C + c) * N + r) * Nk + 8 * j;
+    const int64_t o = ((int64_t)b * RT + rg) * 2048 + (int64_t)slot * 8;
 #pragma unroll
-    for (int i = 0; i < P; ++i) *reinterpret_cast<bf16x8*>(Lb + i * plane_l + o) = out[i];
-  }
-  const int64_t plane_v = (int64_t)B * N * 64;
-  for (int k = threadIdx.x; k < 64; k += 256) {
-    const float x = k < K ? V[((int64_t)b * N + r) * K + k] : 0.0f;
-    __bf16 p[P];
-    split_bf16<P>(x, p);
-#pragma unroll
-    for (int i = 0; i < P; ++i) Vb[i * plane_v + ((int64_t)b * N + r) * 64 + k] = bits(p[i]);
+    for (int i = 0; i < P; ++i) *reinterpret_cast<bf16x8*>(Vb + i * plane_v + o) = out[i];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // GEMM1: Zt[c][o][n] = sum_i W_c[o][i] X[n][i]   (= (X W_c^T)^T, the conv kernel's B image)
-// Workgroup = 4 waves x 32 node rows; per channel the weight block Wb[c] (128 x dinp bf16 per
-// plane) is staged in LDS and is the A operand of v_mfma_f32_32x32x16_bf16, the node rows are
-// the B operand (fp32 X converted / split in registers).
+// Workgroup = 128 node rows; the X tile is read ONCE, coalesced, converted (split) to bf16 and
+// staged in LDS (B operand of v_mfma_f32_32x32x16_bf16 for all channels and all four waves);
+// wave w owns the 32 outputs o = 32 w .. + 31 and keeps their weight fragments in registers per
+// channel (Wf is stored in fragment order: one 1 KiB wave load per fragment); the 128 x 128
+// output tile of a channel goes through LDS so that Zt rows are written as 256 B runs.
 // ------------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(256) void large_gemm1_kernel(
-    const float* __restrict__ X, int ldx, int din, int dinp, const u16* __restrict__ Wb,
+    const float* __restrict__ X, int ldx, int din, int dinp, const u16* __restrict__ Wf,
     int B, int N, int Nk, int C, u16* __restrict__ Zt) {
-  extern __shared__ __attribute__((aligned(16))) u16 Ws[];  // [P][128][dinp + 8]
-  const int wp = dinp + 8;
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int n0 = blockIdx.x * 128 + 32 * w;
-  const int n = n0 + (lane & 31), h = lane >> 5;
-  const int nc = n < N ? n : N - 1;
-  const float* xr = X + ((int64_t)b * N + nc) * ldx;
+  extern __shared__ __attribute__((aligned(16))) u16 smem_g1[];
+  const int xp = dinp + 8;                      // LDS pitch of an X row (bf16): conflict-free b128
+  u16* Xs = smem_g1;                            // [P][128][xp]
+  u16* Zs = smem_g1 + (size_t)P * 128 * xp;     // [128 o][136]
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n0 = blockIdx.x * 128;
+  const int l31 = lane & 31, h = lane >> 5;
   const int nks = dinp / 16;
-  const int64_t plane_w = (int64_t)C * DH * dinp;
-  const int64_t plane_z = (int64_t)B * C * DH * Nk;
-  for (int c = 0; c < C; ++c) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < P * DH * (dinp / 8); idx += 256) {
-      const int q = idx % (dinp / 8), o = (idx / (dinp / 8)) % DH, p = idx / ((dinp / 8) * DH);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Wb + p * plane_w + ((int64_t)c * DH + o) * dinp + 8 * q);
-      *reinterpret_cast<f32x4*>(Ws + ((int64_t)p * DH + o) * wp + 8 * q) = v;
+  // ---- stage the X tile: 4 consecutive columns per thread and step
+  {
+    const int qn = dinp / 4;
+    const bool vec = (din == dinp) && (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+    for (int idx = tid; idx < 128 * qn; idx += 256) {
+      const int n = idx / qn, q = idx - n * qn;
+      const int row = n0 + n;
+      float x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (row < N) {
+        const float* src = X + ((int64_t)b * N + row) * ldx + 4 * q;
+        if (vec) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+          x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = (4 * q + u < din) ? src[u] : 0.0f;
+        }
+      }
+      u16 o[P][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        __bf16 p[P];
+        split_bf16<P>(x[u], p);
+#pragma unroll
+        for (int i = 0; i < P; ++i) o[i][u] = bits(p[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        uint2 v;
+        v.x = (unsigned)o[i][0] | ((unsigned)o[i][1] << 16);
+        v.y = (unsigned)o[i][2] | ((unsigned)o[i][3] << 16);
+        *reinterpret_cast<uint2*>(Xs + ((size_t)i * 128 + n) * xp + 4 * q) = v;
+      }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  const int64_t plane_z = (int64_t)B * C * DH * Nk;
+  const int64_t plane_w = (int64_t)C * 4 * nks * 512;     // fragment-ordered weights per plane
+  for (int c = 0; c < C; ++c) {
+    // this wave's weight fragments (A operand): [P][nks] x 8 bf16 per lane
+    bf16x8 af[P][8];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        if (ks < nks)
+          af[p][ks] = *reinterpret_cast<const bf16x8*>(
+              Wf + p * plane_w + (((int64_t)c * 4 + w) * nks + ks) * 512 + lane * 8);
     f32x16 acc[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = lnz::splat16(0.0f);
-    for (int ks = 0; ks < nks; ++ks) {
-      // B fragment: X[n][16 ks + 8 h .. + 7]
-      bf16x8 bf[P];
+    for (int nt = 0; nt < 4; ++nt) {
+      acc[nt] = lnz::splat16(0.0f);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = 16 * ks + 8 * h + u;
-        const float x = i < din ? xr[i] : 0.0f;
-        __bf16 p[P];
-        split_bf16<P>(x, p);
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < nks) {
+          bf16x8 bf[P];
 #pragma unroll
-        for (int q = 0; q < P; ++q) bf[q][u] = p[q];
-      }
+          for (int p = 0; p < P; ++p)
+            bf[p] = *reinterpret_cast<const bf16x8*>(Xs + ((size_t)p * 128 + 32 * nt + l31) * xp +
+                                                     16 * ks + 8 * h);
+          // small terms first: (order 2), (order 1), (order 0)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        bf16x8 af[P];
+          for (int ord = P - 1; ord >= 0; --ord)
 #pragma unroll
-        for (int q = 0; q < P; ++q)
-          af[q] = *reinterpret_cast<const bf16x8*>(Ws + ((int64_t)q * DH + 32 * mt + (lane & 31)) * wp +
-                                                   16 * ks + 8 * h);
-        // small terms first: (order 2), (order 1), (order 0)
-#pragma unroll
-        for (int ord = P - 1; ord >= 0; --ord)
-#pragma unroll
-          for (int i = 0; i <= ord; ++i)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[ord - i], acc[mt], 0, 0, 0);
+            for (int i = 0; i <= ord; ++i)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bf[ord - i], acc[nt], 0, 0, 0);
+        }
       }
     }
-    if (n < N) {
+    // ---- output, plane by plane through LDS: Zs[o][n] <- piece p of the tile, then 256 B runs
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+    for (int p = 0; p < P; ++p) {
+      __syncthreads();  // Zs free (previous plane / channel copied out)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int o = 32 * mt + lnz::cd_row(r, h);
-          __bf16 p[P];
-          split_bf16<P>(acc[mt][r], p);
-          const int64_t off = (((int64_t)b * C + c) * DH + o) * Nk + n;
-#pragma unroll
-          for (int q = 0; q < P; ++q) Zt[q * plane_z + off] = bits(p[q]);
+          const __bf16 pc = to_bf16(acc[nt][r]);
+          acc[nt][r] -= bf16_float(pc);
+          Zs[(32 * w + lnz::cd_row(r, h)) * 136 + 32 * nt + l31] = bits(pc);
         }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i, o = q >> 4, part = q & 15;
+        const int n = n0 + 8 * part;
+        u16* dst = Zt + p * plane_z + (((int64_t)b * C + c) * DH + o) * Nk + n;
+        const u16* src = Zs + o * 136 + 8 * part;
+        if (n + 8 <= N) {
+          *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          for (int u = 0; u < 8; ++u)
+            if (n + u < N) dst[u] = src[u];
+        }
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// Spectral block, one workgroup (8 waves) per graph, exact fp32 (v_mfma_f32_32x32x2_f32):
-//   phase 1  Y[k][i] = sum_n V[n][k] X[n][i]            wave (kt, it): 32 slots x 32 columns
-//   phase 2  T[k][o] = sum_s g_s[k] * sum_i Y[k][i] W_s[o][i]   wave (kt, ot); per scale the
-//            unscaled product accumulates in its own C tile and its rows are scaled into T
-//            (16 FMAs) — a VALU multiply in front of every MFMA costs ~40 cycles each
-// Wt: [S * dinp][128] fp32 = the long-scale column blocks of the mix weight, transposed.
+// Spectral block, exact fp32 (v_mfma_f32_32x32x2_f32), two launches:
+//   large_project_kernel   Y[k][i] += sum_{n in this workgroup's row chunk} V[n][k] X[n][i]
+//                          grid (B, row chunks): wave (kt, it) = 32 slots x 32 columns; partial
+//                          tiles are added into Ybuf [B][64][128] with fp32 atomics (Ybuf is zero
+//                          on entry: large_spectral_kernel leaves it zeroed for the next layer)
+//   large_spectral_kernel  one workgroup per graph: T[k][o] = sum_s g_s[k] * sum_i Y[k][i]
+//                          W_s[o][i]; wave (kt, ot); per scale the unscaled product accumulates
+//                          in its own C tile and its rows are scaled into T (16 FMAs) — a VALU
+//                          multiply in front of every MFMA costs ~40 cycles each
+// Wt: pack_rows_k8 image of W_long [128][S * dinp] (the long-scale column blocks of the mix weight,
+// each zero padded to dinp columns): [4][S * dinp / 8][64][4] fp32.
 // Output Tt [P][B][128][64] bf16 (the B image of the conv kernel's lift block).
 // ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void large_project_kernel(
+    const float* __restrict__ X, int ldx, int din, int dinp, const float* __restrict__ V, int N,
+    int K, int rows_per_wg, float* __restrict__ Ybuf) {
+  // 64-row steps: the V [64 x 64] and X [64 x 128] pieces are read once per workgroup with
+  // coalesced 16 B loads into LDS (double buffered) and feed all eight wave tiles from there —
+  // straight from global, every wave re-read its 128 B column slice of every row (2 x 4 B loads
+  // per MFMA): the load path, not the matrix pipe, bounded it.
+  __shared__ __attribute__((aligned(16))) float Vs[2][64][64 + 4];
+  __shared__ __attribute__((aligned(16))) float Xs[2][64][DH + 4];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int kt = w >> 2, qt = w & 3;
+  const int nbeg = blockIdx.x * rows_per_wg;
+  const int nend = min(N, nbeg + rows_per_wg);
+  const bool work = 32 * qt < dinp;  // wave tile inside the (padded) input width
+  const float* Vg = V + (int64_t)b * N * K;
+  const float* Xg = X + (int64_t)b * N * ldx;
+  const bool vecv = (K % 4 == 0) && ((((uintptr_t)V) & 15) == 0);
+  const bool vecx = (ldx % 4 == 0) && ((((uintptr_t)X) & 15) == 0);
+  f32x4 rv[2], rx[4];
+  auto fetch = [&](int n0) {  // rows n0 .. n0 + 63 -> registers (zeros beyond nend / K / din)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 512 * i, r = q >> 4, c4 = (q & 15) * 4;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (n0 + r < nend) {
+        const float* src = Vg + (int64_t)(n0 + r) * K + c4;
+        if (vecv && c4 + 4 <= K) v = *reinterpret_cast<const f32x4*>(src);
+        else
+          for (int u = 0; u < 4; ++u) v[u] = c4 + u < K ? src[u] : 0.0f;
+      }
+      rv[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 512 * i, r = q >> 5, c4 = (q & 31) * 4;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (n0 + r < nend && c4 < dinp) {
+        const float* src = Xg + (int64_t)(n0 + r) * ldx + c4;
+        if (vecx && c4 + 4 <= din) v = *reinterpret_cast<const f32x4*>(src);
+        else
+          for (int u = 0; u < 4; ++u) v[u] = c4 + u < din ? src[u] : 0.0f;
+      }
+      rx[i] = v;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = tid + 512 * i;
+      *reinterpret_cast<f32x4*>(&Vs[buf][q >> 4][(q & 15) * 4]) = rv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 512 * i;
+      *reinterpret_cast<f32x4*>(&Xs[buf][q >> 5][(q & 31) * 4]) = rx[i];
+    }
+  };
+  f32x16 acc = lnz::splat16(0.0f);
+  fetch(nbeg);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int n0 = nbeg; n0 < nend; n0 += 64) {
+    const bool more = n0 + 64 < nend;
+    if (more) fetch(n0 + 64);
+    if (work) {
+#pragma unroll 4
+      for (int u = 0; u < 32; u += 8) {
+        float a[8], x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          a[t] = Vs[buf][2 * (u + t) + h][32 * kt + l31];
+          x[t] = Xs[buf][2 * (u + t) + h][32 * qt + l31];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc = lnz::mfma32(a[t], x[t], acc);
+      }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (!work) return;
+  float* y = Ybuf + (int64_t)b * 64 * DH;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    atomicAdd(y + (32 * kt + lnz::cd_row(r, h)) * DH + 32 * qt + l31, acc[r]);
+}
+
 template <int P>
 __global__ __launch_bounds__(512) void large_spectral_kernel(
-    const float* __restrict__ X, int ldx, int din, int dinp, const float* __restrict__ V,
-    const float* __restrict__ G, const float* __restrict__ Wt, int B, int N, int K, int S,
-    u16* __restrict__ Tt) {
+    int dinp, float* __restrict__ Ybuf, const float* __restrict__ G, const float* __restrict__ Wt,
+    int B, int K, int S, u16* __restrict__ Tt) {
   __shared__ float Ys[64][DH + 4];
   const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int kt = w >> 2, qt = w & 3;
-  // ---- phase 1
   {
-    const int slot = 32 * kt + l31, col = 32 * qt + l31;
-    const bool va = slot < K, vb = col < din;
-    f32x16 acc = lnz::splat16(0.0f);
-    if (32 * qt < dinp) {
-      const float* vp = V + (int64_t)b * N * K + slot;
-      const float* xp = X + (int64_t)b * N * ldx + col;
-      for (int n = 0; n < N; n += 16) {
-        float a[8], x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int nn = n + 2 * u + h;
-          const bool in = nn < N;
-          a[u] = (va && in) ? vp[(int64_t)nn * K] : 0.0f;
-          x[u] = (vb && in) ? xp[(int64_t)nn * ldx] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = lnz::mfma32(a[u], x[u], acc);
-      }
+    float* y = Ybuf + (int64_t)b * 64 * DH;
+    for (int idx = threadIdx.x; idx < 64 * DH; idx += 512) {
+      Ys[idx / DH][idx % DH] = y[idx];
+      y[idx] = 0.0f;  // ready for the next layer's projection
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Ys[32 * kt + lnz::cd_row(r, h)][32 * qt + l31] = acc[r];
   }
   __syncthreads();
-  // ---- phase 2
   {
     const int o = 32 * qt + l31;
     f32x16 T = lnz::splat16(0.0f);
-    const float* yrow = &Ys[32 * kt + l31][0];
+    // k-steps visit the input columns in the order i = 8 q + 4 h + t (t = 0..3 per quad of MFMAs):
+    // this lane's A values are 4 consecutive floats of its Y row (one ds_read_b128), its B values
+    // one dwordx4 of the pack_rows_k8 image of the long-scale weight block (1 KiB per wave load)
+    const float* yrow = &Ys[32 * kt + l31][4 * h];
+    const int Q = S * dinp / 8;
+    const f32x4* wq = reinterpret_cast<const f32x4*>(Wt) + ((int64_t)qt * Q) * 64 + lane;
     for (int s = 0; s < S; ++s) {
       f32x16 U = lnz::splat16(0.0f);
-      const float* wp = Wt + (int64_t)s * dinp * DH + o;
-      for (int i = 0; i < dinp; i += 16) {
-        float a[8], x[8];
+      const f32x4* ws = wq + (int64_t)s * (dinp / 8) * 64;
+      for (int qq = 0; qq < dinp / 8; qq += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(yrow + 8 * qq);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(yrow + 8 * qq + 8);
+        const f32x4 b0 = ws[(int64_t)qq * 64];
+        const f32x4 b1 = ws[(int64_t)(qq + 1) * 64];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          a[u] = yrow[i + 2 * u + h];
-          x[u] = wp[(int64_t)(i + 2 * u + h) * DH];
-        }
+        for (int t = 0; t < 4; ++t) U = lnz::mfma32(a0[t], b0[t], U);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) U = lnz::mfma32(a[u], x[u], U);
+        for (int t = 0; t < 4; ++t) U = lnz::mfma32(a1[t], b1[t], U);
       }
       const float* g = G + ((int64_t)b * S + s) * K;
 #pragma unroll
@@ -268,12 +445,21 @@ __global__ __launch_bounds__(512) void large_spectral_kernel(
 // ------------------------------------------------------------------------------------------
 // conv: Xout[rows][0..127] = relu( sum_c Lb_c[rows][:] Zt_c^T + Vb[rows][:] Tt^T + bias )
 // ------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(512) void large_conv_kernel(
+// B image in LDS: row n (output column) = 8 chunks of 16 B (64 k); chunk j of row n is stored at
+// chunk position j ^ (n & 7).  ds_read_b128 is serviced in the four lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): with lane = 16 kq + column, a group holds
+// 8 columns at chunk j and the other 8 at chunk j + 1, and the XOR key makes their sixteen 16 B
+// slots cover the 256 B bank row exactly once; the 8-lane groups of the staging ds_write_b128
+// (one row's 8 chunks) are conflict free as well.  (A 144 B row pitch looked conflict free for
+// contiguous 16-lane groups and measured 44 % conflict cycles.)
+template <int P, int NW>
+__global__ __launch_bounds__(64 * NW) void large_conv_kernel(
     const u16* __restrict__ Lb, const u16* __restrict__ Vb, const u16* __restrict__ Zt,
     const u16* __restrict__ Tt, const float* __restrict__ bias, int B, int N, int Nk, int C,
     int tiles, int relu, float* __restrict__ Xout) {
   extern __shared__ __attribute__((aligned(16))) u16 Bs[];  // [2 buffers][P][128][BP]
+  constexpr int NT = 64 * NW;            // threads
+  constexpr int NPC = 1024 / NT;         // 16 B pieces of the B image per thread and plane
   // blockIdx -> (graph, row tile): workgroup i runs on XCD i % 8; the `tiles` row tiles of a
   // graph are consecutive workgroups of ONE XCD, so they share that L2's copy of the graph's Zt
   const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
@@ -281,79 +467,124 @@ __global__ __launch_bounds__(512) void large_conv_kernel(
   if (b >= B) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
-  const int r0 = tile * 256 + 32 * w;
-  const int64_t plane_l = (int64_t)B * C * N * Nk, plane_v = (int64_t)B * N * 64;
-  const int64_t plane_z = (int64_t)B * C * DH * Nk, plane_t = (int64_t)B * DH * 64;
+  // rows per wave: NRT row tiles of 16
+  constexpr int NRT = 2, NG = NRT / 2;   // (NRT = 4 for P = 1 was measured: spills, 7 % slower)
+  const int r0 = tile * (16 * NRT * NW) + 16 * NRT * w;
+  const int RT = (N + 31) / 32;
   const int nkb = Nk / KB;
+  const int64_t plane_l = (int64_t)B * C * RT * nkb * 2048, plane_v = (int64_t)B * RT * 2048;
+  const int64_t plane_z = (int64_t)B * C * DH * Nk, plane_t = (int64_t)B * DH * 64;
   const int total = C * nkb + 1;  // + the lift block (V T)
-  // this lane's two A rows (row tiles of 16), clamped: rows >= N are computed and dropped
-  int ra[2];
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int r = r0 + 16 * rt + l15;
-    ra[rt] = r < N ? r : N - 1;
-  }
-  // staging role of this thread for the B image: row tid >> 2 (0..127), 32 B part tid & 3
-  const int srow = tid >> 2, spart = tid & 3;
+  // this wave's first 32-row group (clamped: groups past the last compute a copy that is dropped)
+  const int rg = (tile * NW + w) * NG < RT ? (tile * NW + w) * NG : RT - 1;
+  const int g1 = (NG > 1 && rg + 1 < RT) ? 1 : 0;   // second group of a 64-row wave (or a copy)
+  // staging role of this thread for the B image: pieces q = tid + NT i, row q >> 3, chunk q & 7
+  // (the 8 chunks of a row = 128 contiguous bytes of Zt are 8 consecutive lanes)
+  const int srow = tid >> 3, schunk = tid & 7;
 
-  auto a_ptr = [&](int g, int rt, int ks, int p) -> const u16* {
-    if (g < C * nkb) {
-      const int c = g / nkb, kb = g - c * nkb;
-      return Lb + p * plane_l + (((int64_t)b * C + c) * N + ra[rt]) * Nk + kb * KB + 32 * ks + 8 * kq;
-    }
-    return Vb + p * plane_v + ((int64_t)b * N + ra[rt]) * 64 + 32 * ks + 8 * kq;
-  };
-  auto b_ptr = [&](int g, int p) -> const u16* {
-    if (g < C * nkb) {
-      const int c = g / nkb, kb = g - c * nkb;
-      return Zt + p * plane_z + (((int64_t)b * C + c) * DH + srow) * Nk + kb * KB + 16 * spart;
-    }
-    return Tt + p * plane_t + ((int64_t)b * DH + srow) * 64 + 16 * spart;
-  };
+  // Load streams.  Every lane walks two pointers block by block (uniform increments): its 16 B
+  // piece of the wave's A chunks and its 32 B piece of the B image.  Node-space blocks: channel c,
+  // k-block kb of Lb / Zt; the last block is the lift (Vb / Tt).  `la` / `lb` count the blocks
+  // the A / B stream has issued (they run DEPTH - 1 resp. BDIST blocks ahead of the MFMAs).
+  // The k-blocks of a channel are visited in a ROTATED order (start kb0, wrap around) that differs
+  // from graph to graph, so the chip is spread over the k range at any moment, but is the SAME for
+  // the row tiles of one graph: they run side by side on one XCD and walk the graph's Zt image in
+  // step, so each of its k-blocks is fetched into that L2 once and hit by the other tiles (with a
+  // per-workgroup start the counters showed 1.45 GB of Zt re-fetch per launch next to 4.3 GB of
+  // operator stream).
+  const int kb0 = (int)(((unsigned)b * 7u + ((unsigned)b >> 3)) % (unsigned)nkb);
+  const u16* pa = Lb + (((int64_t)b * C * RT + rg) * nkb + kb0) * 2048 + lane * 8;
+  const u16* pb = Zt + ((int64_t)b * C * DH + srow) * Nk + (int64_t)kb0 * KB + 8 * schunk;
+  const int64_t wrap_step = -(int64_t)(nkb - 1) * KB;       // physical last k-block -> first
+  const int64_t a_chan_step = (int64_t)RT * nkb * 2048;     // same row group, next channel
+  const int64_t b_chan_step = (int64_t)DH * Nk;
+  const int nnode = C * nkb;
+  int la = 0, la_kb = 0, la_pos = kb0, lb = 0, lb_kb = 0, lb_pos = kb0;
 
-  f32x4 acc[2][8];
+  f32x4 acc[NRT][8];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) acc[rt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-  bf16x8 A[2][P][2][2];  // [buffer][plane][row tile][k-step]; buffer index always a constant
-  f32x4 st[P][2];        // B staging registers (32 B per thread and plane)
-  auto load_a = [&](int g, auto bufc) {
-    constexpr int buf = decltype(bufc)::value;
+  // Software pipeline over the k-blocks, DEPTH - 1 blocks ahead: a k-block is only ~0.45 us of
+  // matrix work per SIMD (P = 1) while an HBM load under load returns after ~2 us, and a CU must
+  // keep >= 25 KB in flight for its share of 8 TB/s.  A fragments: register ring of DEPTH slots
+  // (loaded straight from HBM); B image: register ring of DEPTH slots, written to the double-
+  // buffered LDS tile one block before its use.  All ring indices are compile-time constants
+  // (the loop is unrolled DEPTH times).
+  constexpr int DEPTH = P == 1 ? 4 : 2;  // A ring: prefetch distance DEPTH - 1 blocks
+  constexpr int DB = 2;                  // B ring: 2 register slots; distance 2 (P = 1) / 1 (P = 3)
+  constexpr int BDIST = P == 1 ? 2 : 1;
+  bf16x8 A[DEPTH][P][NRT][2];  // [slot][plane][row tile][k-step]
+  f32x4 st[DB][P][NPC];      // B staging registers (16 B pieces per thread, plane and slot)
+  // The streams are branch free: past the last block they keep re-reading it (valid memory, the
+  // data is never used) — conditional loads would turn every ring register into a phi of two
+  // definitions and cost the kernel its register allocation.
+  auto load_a = [&](auto slotc) {  // next block of the A stream -> ring slot
+    constexpr int slot = decltype(slotc)::value;
+    const bool lift = la == nnode;
+    pa = lift ? Vb + ((int64_t)b * RT + rg) * 2048 + lane * 8 : pa;
+    const int64_t pl = la >= nnode ? plane_v : plane_l;
+    // the wave's second row group: its chunks follow the first group's nkb chunks (one chunk for Vb)
+    const int64_t goff = (int64_t)g1 * (la >= nnode ? 2048 : (int64_t)nkb * 2048);
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-          A[buf][p][rt][ks] = *reinterpret_cast<const bf16x8*>(a_ptr(g, rt, ks, p));
+          A[slot][p][rt][ks] = *reinterpret_cast<const bf16x8*>(
+              pa + p * pl + (rt >> 1) * goff + ((rt & 1) * 2 + ks) * 512);
+    ++la_kb;
+    int64_t step = la_pos == nkb - 1 ? -(int64_t)(nkb - 1) * 2048 : (int64_t)2048;
+    la_pos = la_pos == nkb - 1 ? 0 : la_pos + 1;
+    step += la_kb == nkb ? a_chan_step : (int64_t)0;
+    step = la >= nnode ? (int64_t)0 : step;
+    la_kb = la_kb == nkb ? 0 : la_kb;
+    ++la;
+    pa += step;
   };
-  auto load_b = [&](int g) {
+  auto load_b = [&](auto slotc) {  // next block of the B stream -> register slot
+    constexpr int slot = decltype(slotc)::value;
+    pb = lb == nnode ? Tt + ((int64_t)b * DH + srow) * 64 + 8 * schunk : pb;
+    const int64_t pl = lb >= nnode ? plane_t : plane_z;
+    const int64_t rstep = (int64_t)(NT / 8) * (lb >= nnode ? 64 : Nk);  // NT / 8 rows further
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const f32x4* s = reinterpret_cast<const f32x4*>(b_ptr(g, p));
-      st[p][0] = s[0];
-      st[p][1] = s[1];
-    }
-  };
-  auto store_b = [&](int buf) {
+    for (int p = 0; p < P; ++p)
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      f32x4* d = reinterpret_cast<f32x4*>(Bs + ((int64_t)(buf * P + p) * DH + srow) * BP + 16 * spart);
-      d[0] = st[p][0];
-      d[1] = st[p][1];
-    }
+      for (int i = 0; i < NPC; ++i)
+        st[slot][p][i] = *reinterpret_cast<const f32x4*>(pb + p * pl + i * rstep);
+    ++lb_kb;
+    int64_t step = lb_pos == nkb - 1 ? wrap_step : (int64_t)KB;
+    lb_pos = lb_pos == nkb - 1 ? 0 : lb_pos + 1;
+    step += lb_kb == nkb ? b_chan_step : (int64_t)0;
+    step = lb >= nnode ? (int64_t)0 : step;
+    lb_kb = lb_kb == nkb ? 0 : lb_kb;
+    ++lb;
+    pb += step;
   };
-  // one k-block: prefetch block g + 1 (A fragments from HBM, B image into registers), run the
-  // MFMAs of block g from A[cur] and LDS buffer cur, publish the next B image, one barrier
-  auto block = [&](int g, auto curc) {
-    constexpr int cur = decltype(curc)::value;
-    if (g + 1 < total) {
-      load_a(g + 1, std::integral_constant<int, cur ^ 1>{});
-      load_b(g + 1);
-    }
-    const u16* bt = Bs + (int64_t)cur * P * DH * BP;
+  auto store_b = [&](int g, auto slotc) {  // (past the last block: an image nobody reads)
+    constexpr int slot = decltype(slotc)::value;
+    const int buf = g & 1;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int i = 0; i < NPC; ++i) {
+        const int row = srow + (NT / 8) * i;  // (NT / 8) % 8 == 0: same swizzle key as srow
+        *reinterpret_cast<f32x4*>(Bs + ((int64_t)(buf * P + p) * DH + row) * BP +
+                                  8 * (schunk ^ (srow & 7))) = st[slot][p][i];
+      }
+  };
+  // one k-block (gs = g mod 4, compile time): issue the loads of the blocks ahead, run the MFMAs
+  // of block g from A[slot] and LDS buffer g & 1, publish the B image of block g + 1, one barrier.
+  // The B registers of block g were written to LDS during block g - 1, so slot g % 2 is free for
+  // block g + 2 from the start of block g.
+  auto block = [&](int g, auto gsc) {
+    constexpr int gs = decltype(gsc)::value;
+    load_a(std::integral_constant<int, (gs + DEPTH - 1) % DEPTH>{});
+    if constexpr (BDIST == 2) load_b(std::integral_constant<int, gs % 2>{});
+    const u16* bt = Bs + (int64_t)(g & 1) * P * DH * BP;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -361,27 +592,44 @@ __global__ __launch_bounds__(512) void large_conv_kernel(
         bf16x8 bf[P];
 #pragma unroll
         for (int p = 0; p < P; ++p)
-          bf[p] = *reinterpret_cast<const bf16x8*>(bt + ((int64_t)p * DH + 16 * nt + l15) * BP + 32 * ks + 8 * kq);
+          bf[p] = *reinterpret_cast<const bf16x8*>(bt + ((int64_t)p * DH + 16 * nt + l15) * BP +
+                                                   8 * ((4 * ks + kq) ^ (l15 & 7)));
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
           for (int ord = P - 1; ord >= 0; --ord)
 #pragma unroll
             for (int i = 0; i <= ord; ++i)
-              acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cur][i][rt][ks], bf[ord - i],
+              acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[gs % DEPTH][i][rt][ks], bf[ord - i],
                                                                    acc[rt][nt], 0, 0, 0);
       }
-    if (g + 1 < total) store_b(cur ^ 1);
+    if constexpr (BDIST == 1) load_b(std::integral_constant<int, (gs + 1) % 2>{});
+    store_b(g + 1, std::integral_constant<int, (gs + 1) % 2>{});
     __syncthreads();
   };
 
-  load_a(0, std::integral_constant<int, 0>{});
-  load_b(0);
-  store_b(0);
+  load_a(std::integral_constant<int, 0>{});
+  load_b(std::integral_constant<int, 0>{});
+  if constexpr (DEPTH > 2) {
+    load_a(std::integral_constant<int, 1>{});
+    load_a(std::integral_constant<int, 2 % DEPTH>{});
+  }
+  if constexpr (BDIST == 2) load_b(std::integral_constant<int, 1>{});
+  store_b(0, std::integral_constant<int, 0>{});
   __syncthreads();
-  for (int g = 0; g < total; g += 2) {
+  int g = 0;
+  for (; g + 4 <= total; g += 4) {  // steady state: no conditionals
     block(g, std::integral_constant<int, 0>{});
-    if (g + 1 < total) block(g + 1, std::integral_constant<int, 1>{});
+    block(g + 1, std::integral_constant<int, 1>{});
+    block(g + 2, std::integral_constant<int, 2>{});
+    block(g + 3, std::integral_constant<int, 3>{});
+  }
+  if (g < total) {  // 1..3 remaining blocks
+    block(g, std::integral_constant<int, 0>{});
+    if (g + 1 < total) {
+      block(g + 1, std::integral_constant<int, 1>{});
+      if (g + 2 < total) block(g + 2, std::integral_constant<int, 2>{});
+    }
   }
   // epilogue: C/D layout of 16x16: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -389,7 +637,7 @@ __global__ __launch_bounds__(512) void large_conv_kernel(
     const int col = 16 * nt + l15;
     const float bv = bias[col];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = r0 + 16 * rt + 4 * kq + r;
@@ -414,58 +662,73 @@ extern "C" int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_
               "lnz_large_pack_operators: bad arguments (B=%d N=%d C=%d K=%d)", B, N, C, K);
   LNZ_REQUIRE(K <= 64, LNZ_ENOTSUP, "lnz_large_pack_operators: K=%d > 64", K);
   LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_pack_operators: planes must be 1 or 3");
-  const int Nk = (int)lnz_large_nk(N);
-  dim3 grid(N, B);
+  const int nkb = (int)(lnz_large_nk(N) / KB);
+  dim3 grid((N + 31) / 32, B);
   if (planes == 1)
     hipLaunchKernelGGL(large_pack_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
-                       stride_r, stride_c, stride_ch, V, B, N, Nk, C, K, Lb, Vb);
+                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
   else
     hipLaunchKernelGGL(large_pack_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
-                       stride_r, stride_c, stride_ch, V, B, N, Nk, C, K, Lb, Vb);
+                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
   return lnz::check_launch("lnz_large_pack_operators");
 }
 
-extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wb, int B, int N,
+extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wf, int B, int N,
                                int C, int planes, uint16_t* Zt, lnz_stream_t stream) {
-  LNZ_REQUIRE(X && Wb && Zt && B > 0 && N > 0 && C > 0 && din > 0 && ldx >= din, LNZ_EINVAL,
+  LNZ_REQUIRE(X && Wf && Zt && B > 0 && N > 0 && C > 0 && din > 0 && ldx >= din, LNZ_EINVAL,
               "lnz_large_gemm1: bad arguments");
   LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_gemm1: planes must be 1 or 3");
   const int dinp = (din + 15) / 16 * 16;
   LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_gemm1: input width %d > 128", din);
   const int Nk = (int)lnz_large_nk(N);
-  const size_t lds = (size_t)planes * DH * (dinp + 8) * sizeof(uint16_t);
+  const size_t lds = ((size_t)planes * 128 * (dinp + 8) + 128 * 136) * sizeof(uint16_t);
   dim3 grid((N + 127) / 128, B);
   if (planes == 1) {
     hipLaunchKernelGGL(large_gemm1_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, din,
-                       dinp, Wb, B, N, Nk, C, Zt);
+                       dinp, Wf, B, N, Nk, C, Zt);
   } else {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<3>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 3 * DH * 136 * 2);
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (3 * 128 * 136 + 128 * 136) * 2);
       attr = true;
     }
     hipLaunchKernelGGL(large_gemm1_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, din,
-                       dinp, Wb, B, N, Nk, C, Zt);
+                       dinp, Wf, B, N, Nk, C, Zt);
   }
   return lnz::check_launch("lnz_large_gemm1");
 }
 
 extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float* V, const float* G,
                                   const float* Wt, int B, int N, int K, int S, int planes,
-                                  uint16_t* Tt, lnz_stream_t stream) {
-  LNZ_REQUIRE(X && V && G && Wt && Tt && B > 0 && N > 0 && K > 0 && S > 0 && din > 0 && ldx >= din,
+                                  float* Ybuf, uint16_t* Tt, lnz_stream_t stream) {
+  LNZ_REQUIRE(X && V && G && Wt && Ybuf && Tt && B > 0 && N > 0 && K > 0 && S > 0 && din > 0 &&
+                  ldx >= din,
               LNZ_EINVAL, "lnz_large_spectral: bad arguments");
   LNZ_REQUIRE(K <= 64, LNZ_ENOTSUP, "lnz_large_spectral: K=%d > 64", K);
   LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_spectral: planes must be 1 or 3");
   const int dinp = (din + 15) / 16 * 16;
   LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_spectral: input width %d > 128", din);
+  // row chunks: enough workgroups to fill the chip, at least 128 rows each (multiple of 16)
+  static int target_wgs = 0;
+  if (target_wgs == 0) {
+    const char* e = getenv("LNZ_LARGE_PROJECT_WGS");
+    target_wgs = e ? atoi(e) : 2048;
+    if (target_wgs < 1) target_wgs = 2048;
+  }
+  int chunks = (target_wgs + B - 1) / B;
+  int rows = ((N + chunks - 1) / chunks + 63) / 64 * 64;
+  if (rows < 128) rows = 128;
+  chunks = (N + rows - 1) / rows;
+  hipLaunchKernelGGL(large_project_kernel, dim3(chunks, B), dim3(512), 0, (hipStream_t)stream, X,
+                     ldx, din, dinp, V, N, K, rows, Ybuf);
   if (planes == 1)
-    hipLaunchKernelGGL(large_spectral_kernel<1>, dim3(B), dim3(512), 0, (hipStream_t)stream, X, ldx,
-                       din, dinp, V, G, Wt, B, N, K, S, Tt);
+    hipLaunchKernelGGL(large_spectral_kernel<1>, dim3(B), dim3(512), 0, (hipStream_t)stream, dinp,
+                       Ybuf, G, Wt, B, K, S, Tt);
   else
-    hipLaunchKernelGGL(large_spectral_kernel<3>, dim3(B), dim3(512), 0, (hipStream_t)stream, X, ldx,
-                       din, dinp, V, G, Wt, B, N, K, S, Tt);
+    hipLaunchKernelGGL(large_spectral_kernel<3>, dim3(B), dim3(512), 0, (hipStream_t)stream, dinp,
+                       Ybuf, G, Wt, B, K, S, Tt);
   return lnz::check_launch("lnz_large_spectral");
 }
 
@@ -476,21 +739,26 @@ extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint
               "lnz_large_conv: bad arguments");
   LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_conv: planes must be 1 or 3");
   const int Nk = (int)lnz_large_nk(N);
-  const int tiles = (N + 255) / 256;
-  const int grid = 8 * tiles * ((B + 7) / 8);
   const size_t lds = (size_t)2 * planes * DH * BP * sizeof(uint16_t);
-  if (planes == 1) {
-    hipLaunchKernelGGL(large_conv_kernel<1>, dim3(grid), dim3(512), lds, (hipStream_t)stream, Lb, Vb,
-                       Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout);
-  } else {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)large_conv_kernel<3>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * DH * BP * 2);
-      attr = true;
-    }
-    hipLaunchKernelGGL(large_conv_kernel<3>, dim3(grid), dim3(512), lds, (hipStream_t)stream, Lb, Vb,
-                       Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout);
+  // 8-wave workgroups = 256-row tiles.  (LNZ_LARGE_CONV_WAVES=4: 128-row tiles, two workgroups per
+  // CU that drift apart — measured 12 % slower: twice the B-image staging per operator byte.)
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("LNZ_LARGE_CONV_WAVES");
+    nw = (e && atoi(e) == 4) ? 4 : 8;
+    (void)hipFuncSetAttribute((const void*)large_conv_kernel<3, 8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * DH * BP * 2);
   }
+  const int nwp = planes == 3 ? 8 : nw;  // the 3-plane B image (96 KB) leaves room for one workgroup
+  const int tile_rows = 32 * nwp;
+  const int tiles = (N + tile_rows - 1) / tile_rows;
+  const int grid = 8 * tiles * ((B + 7) / 8);
+#define LNZ_LAUNCH_CONV(PP, WW)                                                                     \
+  hipLaunchKernelGGL((large_conv_kernel<PP, WW>), dim3(grid), dim3(64 * WW), lds,                   \
+                     (hipStream_t)stream, Lb, Vb, Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout)
+  if (planes == 1 && nwp == 4) LNZ_LAUNCH_CONV(1, 4);
+  else if (planes == 1) LNZ_LAUNCH_CONV(1, 8);
+  else LNZ_LAUNCH_CONV(3, 8);
+#undef LNZ_LAUNCH_CONV
   return lnz::check_launch("lnz_large_conv");
 }

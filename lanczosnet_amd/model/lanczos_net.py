@@ -388,8 +388,8 @@ class _LanczosNetBase(nn.Module):
             cache = self._plan_large_cache = dict(sig=sig, mlp_pack=buf, conv={})
         if planes is not None and planes not in cache['conv']:
             # per layer: the node-space (edge-type) column blocks of the mix weight as bf16 pieces
-            # [planes, C*128, dinp] (the A image of lnz_large_gemm1) and the long-scale blocks
-            # transposed, fp32 [S*dinp, 128] (lnz_large_spectral)
+            # in MFMA fragment order (the Wf of lnz_large_gemm1) and the long-scale blocks
+            # as their pack_rows_k8 image, fp32 (lnz_large_spectral)
             S, E1 = self.num_scale_long, self.num_edgetype + 1
             layers = []
             for t in range(self.num_layer):
@@ -398,8 +398,9 @@ class _LanczosNetBase(nn.Module):
                 d_in = W.shape[1] // (S + E1)
                 dinp = (d_in + 15) // 16 * 16
                 Wc = torch.nn.functional.pad(W.view(dout, S + E1, d_in), (0, dinp - d_in))
-                Wb = ops.split_bf16_planes(Wc[:, S:].permute(1, 0, 2).reshape(E1 * dout, dinp), planes)
-                Wt = Wc[:, :S].permute(1, 2, 0).reshape(S * dinp, dout).contiguous() if S else None
+                Wb = ops.large_weight_fragments(ops.split_bf16_planes(
+                    Wc[:, S:].permute(1, 0, 2).reshape(E1 * dout, dinp), planes))
+                Wt = ops.pack_rows_k8(Wc[:, :S].reshape(dout, S * dinp).contiguous()) if S else None
                 layers.append(dict(Wb=Wb, Wt=Wt, bias=self.filter[t].bias.detach().float().contiguous(),
                                    din=d_in))
             cache['conv'][planes] = layers
@@ -426,13 +427,13 @@ class _LanczosNetBase(nn.Module):
         if S > 0:
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
         Lb, Vb = ops.large_pack_operators(Lf, Vf, planes)
-        Zt, Tt = ops.large_work_buffers(Lb)
+        work = ops.large_work_buffers(Lb)
         state = node_feat.float().contiguous() if self.general else \
             self.embedding(node_feat).float().contiguous()
         bufs = [None, None]
         for t, lay in enumerate(plan['conv'][planes]):
             state = ops.large_conv_layer(state, lay['din'], Lb, Vb, Vf, lay['Wb'], lay['Wt'],
-                                         G[t] if G is not None else None, lay['bias'], Zt, Tt,
+                                         G[t] if G is not None else None, lay['bias'], work,
                                          relu=True, out=bufs[t & 1])
             bufs[t & 1] = state
         y = self.filter[-1](state) * self.att_func(state)

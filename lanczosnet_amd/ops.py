@@ -123,9 +123,20 @@ def split_bf16_planes(x, planes):
   return torch.stack(out).contiguous()
 
 
+def large_weight_fragments(Wb):
+  """[planes, C*128, dinp] bf16 (row-major channel blocks of the mix weight) -> [planes, C, 4,
+  dinp/16, 64, 8]: v_mfma_f32_32x32x16_bf16 A-fragment order (the Wf of lnz_large_gemm1): lane l of
+  fragment (c, mt, ks) holds W_c[32 mt + (l & 31)][16 ks + 8 (l >> 5) .. + 7]."""
+  P, rows, dinp = Wb.shape
+  Cn = rows // 128
+  x = Wb.view(P, Cn, 4, 32, dinp // 16, 2, 8)        # p, c, mt, l31, ks, h, u
+  return x.permute(0, 1, 2, 4, 5, 3, 6).contiguous()  # p, c, mt, ks, h, l31, u
+
+
 def large_pack_operators(L, V, planes=1):
-  """lnz_large_pack_operators: L [B,N,N,C] fp32 (any strides), V [B,N,K] ->
-  Lb [planes,B,C,N,Nk] bf16, Vb [planes,B,N,64] bf16 (Nk = N rounded up to 64)."""
+  """lnz_large_pack_operators: L [B,N,N,C] fp32 (any strides), V [B,N,K] -> Lb [planes,B,C,RT,
+  Nk/64,4,64,8] bf16 and Vb [planes,B,RT,4,64,8] bf16 in fragment-tile order (RT = ceil(N/32),
+  Nk = N rounded up to 64; see include/lanczosnet_hip.h).  Lb.dims = (N, Nk)."""
   _need_cuda(L, V)
   assert L.dim() == 4 and L.dtype == torch.float32 and V.dim() == 3
   V = _f32c(V)
@@ -133,8 +144,10 @@ def large_pack_operators(L, V, planes=1):
   K = V.shape[2]
   lib = _lib.load()
   Nk = lib.lnz_large_nk(N)
-  Lb = torch.empty((planes, B, Cn, N, Nk), dtype=torch.bfloat16, device=L.device)
-  Vb = torch.empty((planes, B, N, 64), dtype=torch.bfloat16, device=L.device)
+  RT = (N + 31) // 32
+  Lb = torch.empty((planes, B, Cn, RT, Nk // 64, 4, 64, 8), dtype=torch.bfloat16, device=L.device)
+  Vb = torch.empty((planes, B, RT, 4, 64, 8), dtype=torch.bfloat16, device=L.device)
+  Lb.dims = (N, Nk)
   sb, sr, sc, sch = L.stride()
   with torch.cuda.device(L.device):
     _lib.check(lib.lnz_large_pack_operators(_ptr(L), sb, sr, sc, sch, _ptr(V), B, N, Cn, K, planes,
@@ -142,41 +155,80 @@ def large_pack_operators(L, V, planes=1):
   return Lb, Vb
 
 
-def large_conv_layer(X, din, Lb, Vb, V, Wb, Wt, G, bias, Zt, Tt, relu=True, out=None):
-  """One conv layer on packed large-graph operators: lnz_large_gemm1 + lnz_large_spectral +
-  lnz_large_conv.  X [B,N,ldx] fp32 (first `din` columns are the layer input); V [B,N,K] fp32 (the
-  Ritz vectors Vb was packed from); Wb [planes, C*128, dinp] bf16; Wt [S*dinp,128] fp32 and
-  G [B,S,K] fp32 (or None without long scales); Zt / Tt:
-  work buffers from large_work_buffers() (Zt zero-initialised once).  Returns X' [B,N,128]."""
-  _need_cuda(X, Lb, Vb, V, Wb, Wt, G, bias, Zt, Tt)
-  planes, B, Cn, N, Nk = Lb.shape
-  K = V.shape[2]
-  assert V.dtype == torch.float32 and V.is_contiguous()
+def large_gemm1(X, din, Lb, Wf, Zt):
+  """lnz_large_gemm1 on the current stream: Zt <- (X W_c^T)^T for the node-space channels."""
+  _need_cuda(X, Lb, Wf, Zt)
+  planes, B, Cn = Lb.shape[:3]
+  N, _ = Lb.dims
   assert X.dtype == torch.float32 and X.is_contiguous() and X.shape[0] == B and X.shape[1] == N
-  ldx = X.shape[2]
   lib = _lib.load()
-  if out is None:
-    out = torch.empty((B, N, 128), dtype=torch.float32, device=X.device)
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_large_gemm1(_ptr(X), ldx, din, _ptr(Wb), B, N, Cn, planes, _ptr(Zt),
+    _lib.check(lib.lnz_large_gemm1(_ptr(X), X.shape[2], din, _ptr(Wf), B, N, Cn, planes, _ptr(Zt),
                                    _stream()))
-    if G is not None:
-      S = G.shape[1]
-      assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
-      _lib.check(lib.lnz_large_spectral(_ptr(X), ldx, din, _ptr(V), _ptr(G), _ptr(Wt), B, N, K,
-                                        S, planes, _ptr(Tt), _stream()))
+
+
+def large_spectral(X, din, Lb, V, G, Wt, Ybuf, Tt):
+  """lnz_large_spectral on the current stream: Tt <- (sum_s diag(g_s) (V^T X) W_s^T)^T."""
+  _need_cuda(X, Lb, V, G, Wt, Ybuf, Tt)
+  planes, B = Lb.shape[:2]
+  N, _ = Lb.dims
+  K, S = V.shape[2], G.shape[1]
+  assert V.dtype == torch.float32 and V.is_contiguous()
+  assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
+  lib = _lib.load()
+  with torch.cuda.device(X.device):
+    _lib.check(lib.lnz_large_spectral(_ptr(X), X.shape[2], din, _ptr(V), _ptr(G), _ptr(Wt), B, N, K,
+                                      S, planes, _ptr(Ybuf), _ptr(Tt), _stream()))
+
+
+def large_conv(Lb, Vb, Zt, Tt, bias, relu=True, out=None):
+  """lnz_large_conv on the current stream: X' [B,N,128] = act(sum_c Lb_c Zt_c^T + Vb Tt^T + bias)."""
+  _need_cuda(Lb, Vb, Zt, Tt, bias)
+  planes, B, Cn = Lb.shape[:3]
+  N, _ = Lb.dims
+  if out is None:
+    out = torch.empty((B, N, 128), dtype=torch.float32, device=Lb.device)
+  lib = _lib.load()
+  with torch.cuda.device(Lb.device):
     _lib.check(lib.lnz_large_conv(_ptr(Lb), _ptr(Vb), _ptr(Zt), _ptr(Tt), _ptr(bias), B, N, Cn,
                                   planes, int(bool(relu)), _ptr(out), _stream()))
   return out
 
 
+def large_conv_layer(X, din, Lb, Vb, V, Wf, Wt, G, bias, work, relu=True, out=None, side=None):
+  """One conv layer on packed large-graph operators: lnz_large_gemm1 + lnz_large_spectral +
+  lnz_large_conv.  X [B,N,ldx] fp32 (first `din` columns are the layer input); V [B,N,K] fp32 (the
+  Ritz vectors Vb was packed from); Wf = large_weight_fragments(...) of the channel blocks;
+  Wt = pack_rows_k8 of the long-scale blocks [128, S*dinp] and G [B,S,K] fp32 (or None without
+  long scales); work = (Zt, Tt, Ybuf) from large_work_buffers().  side: optional torch.cuda.Stream —
+  the eigen-space block (which only needs X) is then issued beside gemm1 instead of after it
+  (measured: no gain at config 5's size, both launches fill the chip; off by default).
+  Returns X' [B,N,128]."""
+  Zt, Tt, Ybuf = work
+  if G is not None and side is not None:
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+      large_spectral(X, din, Lb, V, G, Wt, Ybuf, Tt)
+    large_gemm1(X, din, Lb, Wf, Zt)
+    main.wait_stream(side)
+  else:
+    large_gemm1(X, din, Lb, Wf, Zt)
+    if G is not None:
+      large_spectral(X, din, Lb, V, G, Wt, Ybuf, Tt)
+  return large_conv(Lb, Vb, Zt, Tt, bias, relu=relu, out=out)
+
+
 def large_work_buffers(Lb):
-  """(Zt, Tt) work buffers for large_conv_layer: Zt [planes,B,C,128,Nk] and Tt [planes,B,128,64]
-  bf16, zero-initialised (gemm1 never writes the k padding; Tt stays zero without long scales)."""
-  planes, B, Cn, N, Nk = Lb.shape
+  """(Zt, Tt, Ybuf) work buffers for large_conv_layer: Zt [planes,B,C,128,Nk] and Tt [planes,B,128,
+  64] bf16 and Ybuf [B,64,128] fp32, zero-initialised (gemm1 never writes the k padding; Tt stays
+  zero without long scales; the spectral kernels keep Ybuf zero between layers)."""
+  planes, B, Cn = Lb.shape[:3]
+  N, Nk = Lb.dims
   Zt = torch.zeros((planes, B, Cn, 128, Nk), dtype=torch.bfloat16, device=Lb.device)
   Tt = torch.zeros((planes, B, 128, 64), dtype=torch.bfloat16, device=Lb.device)
-  return Zt, Tt
+  Ybuf = torch.zeros((B, 64, 128), dtype=torch.float32, device=Lb.device)
+  return Zt, Tt, Ybuf
 
 
 # ------------------------------------------------------------------------------------- packing

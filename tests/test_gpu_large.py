@@ -69,6 +69,18 @@ def _pieces_sum(t):
   return t.float().double().sum(dim=0).cpu().numpy()
 
 
+def _untile(x):
+  """Fragment-tile order [..., RT, nkb, 4, 64, 8] (include/lanczosnet_hip.h) -> dense
+  [..., 32 RT rows, 64 nkb columns]: f = 2 rt + ks, lane = 16 kq + r15 holds row 16 rt + r15,
+  k 32 ks + 8 kq + u."""
+  lead = x.shape[:-5]
+  RT, nkb = x.shape[-5], x.shape[-4]
+  x = x.reshape(lead + (RT, nkb, 2, 2, 4, 16, 8))          # rg, kb, rt, ks, kq, r15, u
+  nl = len(lead)
+  x = np.transpose(x, tuple(range(nl)) + (nl, nl + 2, nl + 5, nl + 1, nl + 3, nl + 4, nl + 6))
+  return x.reshape(lead + (RT * 32, nkb * 64))              # rg, rt, r15 | kb, ks, kq, u
+
+
 @pytest.mark.parametrize('planes', [1, 3])
 @pytest.mark.parametrize('B,N,C,K,din,S', [(2, 200, 2, 40, 10, 3), (3, 300, 3, 64, 128, 8),
                                            (1, 64, 1, 7, 33, 1)])
@@ -88,26 +100,33 @@ def test_large_conv_stages_match_numpy(planes, B, N, C, K, din, S):
   bias = rs.randn(128).astype(np.float32)
   dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
   Lb, Vb = ops.large_pack_operators(dev(L), dev(V), planes)
-  Nk = Lb.shape[-1]
-  assert Nk % 64 == 0 and Nk >= N and tuple(Lb.shape) == (planes, B, C, N, Nk)
+  Nk = Lb.dims[1]
+  RT = (N + 31) // 32
+  assert Nk % 64 == 0 and Nk >= N and tuple(Lb.shape) == (planes, B, C, RT, Nk // 64, 4, 64, 8)
   # pack: pieces sum to the input (exactly for planes = 3 up to 2^-24, bf16 rounding for 1)
-  Lsum = _pieces_sum(Lb)
+  Lsum = _untile(_pieces_sum(Lb))
+  assert (Lsum[:, :, N:] == 0).all()
+  Lsum = Lsum[:, :, :N]
   Lref = L.transpose(0, 3, 1, 2).astype(np.float64)
   if planes == 1:
     np.testing.assert_array_equal(Lsum[..., :N], _bf16_round(L).transpose(0, 3, 1, 2))
   else:
     assert np.abs(Lsum[..., :N] - Lref).max() <= 2.0 ** -22 * np.abs(Lref).max()
   assert (Lsum[..., N:] == 0).all()
-  Vsum = _pieces_sum(Vb)
-  assert (Vsum[..., K:] == 0).all()
+  Vsum = _untile(_pieces_sum(Vb)[:, :, None])
+  assert (Vsum[..., K:] == 0).all() and (Vsum[:, N:] == 0).all()
+  Vsum = Vsum[:, :N]
   # weights as the model packs them
   dinp = (din + 15) // 16 * 16
   Wc = np.zeros((128, S + C, dinp), np.float32)
   Wc[:, :, :din] = W.reshape(128, S + C, din)
-  Wb = ops.split_bf16_planes(dev(Wc[:, S:].transpose(1, 0, 2).reshape(C * 128, dinp)), planes)
-  Wt = dev(Wc[:, :S].transpose(1, 2, 0).reshape(S * dinp, 128))
-  Zt, Tt = ops.large_work_buffers(Lb)
-  out = ops.large_conv_layer(dev(X), din, Lb, Vb, dev(V), Wb, Wt, dev(G), dev(bias), Zt, Tt)
+  Wb = ops.large_weight_fragments(ops.split_bf16_planes(
+      dev(Wc[:, S:].transpose(1, 0, 2).reshape(C * 128, dinp)), planes))
+  Wt = ops.pack_rows_k8(dev(np.ascontiguousarray(Wc[:, :S].reshape(128, S * dinp))))
+  work = ops.large_work_buffers(Lb)
+  Zt, Tt, Ybuf = work
+  out = ops.large_conv_layer(dev(X), din, Lb, Vb, dev(V), Wb, Wt, dev(G), dev(bias), work)
+  assert (Ybuf == 0).all()  # left zeroed for the next layer
   out = out.cpu().numpy().astype(np.float64)
   # ---- stage references in float64 on the operands the kernels saw
   rnd = _bf16_round if planes == 1 else (lambda a: np.asarray(a, np.float64))

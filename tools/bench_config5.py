@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """BASELINE.json configs[4]: LanczosNetGeneral (config/graph_lanczos_net.yaml architecture),
-N = 2048 nodes, K = 64, batch 256, 1 x MI355X.  Lanczos (HIP, HBM bound) + gains (HIP) + conv
-(hipBLASLt batched GEMMs, fp32 or bf16 operands)."""
+N = 2048 nodes, K = 64, batch 256, 1 x MI355X.  Lanczos (HIP, HBM bound) + gains (HIP) + conv:
+the streamed HIP kernels of csrc/conv_large.hip (bf16 operands, and the 3-piece split-precision
+parity mode) beside the library-GEMM path they replaced (hipBLASLt via torch.bmm)."""
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import oracle
 from lanczosnet_amd import ops
 from lanczosnet_amd.model import LanczosNetGeneral
 from lanczosnet_amd.utils.arg_helper import make_model_config
@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--nodes', type=int, default=2048)
 ap.add_argument('--reps', type=int, default=3)
+ap.add_argument('--library', action='store_true', help='also time the hipBLASLt path')
 args = ap.parse_args()
 B, N, K = args.batch, args.nodes, 64
 cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
@@ -36,19 +37,52 @@ A0 = L[:, :, :, 0].contiguous()
 ws = torch.empty((ops._lib.load().lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 res = {}
-for name, dt in (('fp32', None), ('bf16_edge_gemm', torch.bfloat16)):
+modes = [('hip_bf16', 1), ('hip_split3', 3)] + ([('library_fp32', None)] if args.library else [])
+D, V = ops.lanczos_ritz_large(A0, K, K, workspace=ws)
+ref = None
+for name, planes in modes:
   best = None
   for it in range(args.reps + 1):
     ev[0].record()
     D, V = ops.lanczos_ritz_large(A0, K, K, workspace=ws)
     ev[1].record()
     with torch.no_grad():
-      score = net._large_graph_forward(X, L, D, V, mask, gemm_dtype=dt)
+      if planes is None:
+        score = net._large_graph_forward(X, L, D, V, mask)
+      else:
+        score = net._large_graph_forward_hip(X, L, D, V, mask, planes=planes)
     ev[2].record()
     torch.cuda.synchronize()
     t = (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
     if it > 0 and (best is None or sum(t) < sum(best)):
       best = t
+  if name == 'hip_split3':
+    ref = score
   res[name] = {'lanczos_ms': round(best[0], 2), 'forward_ms': round(best[1], 2),
                'graphs_per_s': round(B / (sum(best) * 1e-3), 1), 'finite': bool(torch.isfinite(score).all())}
+  if name == 'hip_bf16':
+    s1 = score
+if ref is not None:
+  res['bf16_vs_split3_rel'] = float((s1 - ref).abs().max() / ref.abs().max())
+# per-stage breakdown of the bf16 mode
+with torch.no_grad():
+  plan = net._plan_large(1)
+  G = ops.spectral_gains(D, net.long_diffusion_dist, net.num_layer, plan['mlp_pack'])
+  e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+  e[0].record()
+  Lb, Vb = ops.large_pack_operators(L, V, 1)
+  e[1].record()
+  work = ops.large_work_buffers(Lb)
+  state = X.contiguous()
+  e[1].record()
+  for t, lay in enumerate(plan['conv'][1]):
+    state = ops.large_conv_layer(state, lay['din'], Lb, Vb, V, lay['Wb'], lay['Wt'], G[t], lay['bias'], work)
+  e[2].record()
+  torch.cuda.synchronize()
+Nk = Lb.dims[1]
+layer_bytes = B * (2 * N * Nk * 2 + N * 64 * 2 + 2 * 128 * Nk * 2 + N * 128 * 4 * 2)
+res['bf16_stages'] = {'pack_ms': round(e[0].elapsed_time(e[1]), 3),
+                      'pack_GBps': round(B * (N * N * 2 * 4 + 2 * N * Nk * 2) / e[0].elapsed_time(e[1]) / 1e6, 1),
+                      'layers_ms': round(e[1].elapsed_time(e[2]), 3),
+                      'layer_stream_GBps': round(7 * layer_bytes / e[1].elapsed_time(e[2]) / 1e6, 1)}
 print(json.dumps({'workload': 'LanczosNetGeneral N=%d K=%d batch=%d' % (N, K, B), **res}))
