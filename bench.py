@@ -164,8 +164,9 @@ def lanczos_large_leg(dev, B=256, N=2048, M=64, reps=3):
   r0 = torch.linalg.norm(torch.bmm(A[:4], V[:4, :, :1]) - V[:4, :, :1] * D[:4, None, :1], dim=1).max()
   bytes_A = M * 4 * N * N
   bytes_survey = bytes_A + M * M * N * 4 + N * M * 4
-  del A, ws
-  return {'workload': 'lnz_lanczos_ritz_large: B=%d dense graphs, N=%d, M=K=%d Lanczos steps, fp32 A, '
+  del ws
+  keep = (A, D, V)
+  return keep, {'workload': 'lnz_lanczos_ritz_large: B=%d dense graphs, N=%d, M=K=%d Lanczos steps, fp32 A, '
                       'fp64 arithmetic, G(n,0.01) + I, L4 normalised' % (B, N, M),
           'kernel': 'lanczos_ritz_large_kernel', 'ms': round(t * 1e3, 3),
           'graphs_per_s': round(B / t, 1), 'bound': 'hbm',
@@ -176,6 +177,79 @@ def lanczos_large_leg(dev, B=256, N=2048, M=64, reps=3):
           'frac_A_stream_only': round(B * bytes_A / t / 8e12, 4),
           'leading_pair_residual': float(r0), 'min_steps_taken': int(info.min()),
           'reps_ms': [round(x, 3) for x in ts]}
+
+
+def large_graph_leg(dev, A, D, V, reps=3):
+  """BASELINE configs[4] conv stage: LanczosNetGeneral (config/graph_lanczos_net.yaml widths:
+  input 10, 7 x 128, output 2, E+1 = 2 channels, S = 8 long scales, K = 64) on B dense graphs of
+  N = 2048 nodes through the streamed kernels of csrc/conv_large.hip, bf16 operands / fp32
+  accumulate; the Ritz pairs are the ones lnz_lanczos_ritz_large just produced.  The dominant
+  kernel (lnz_large_conv) is HBM bound on the packed-operator stream: algorithmic bytes per launch
+  = B * (C N Nk + N 64 + C 128 Nk + 128 64) * 2 (bf16 Lb, Vb, Zt, Tt read once) + B N 128 * 4
+  (X' written)."""
+  from lanczosnet_amd.model import LanczosNetGeneral
+  B, N, _ = A.shape
+  K = V.shape[2]
+  cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
+             num_eig_vec=K, spectral_filter_kind='MLP', input_dim=10, hidden_dim=[128] * 7,
+             output_dim=2, num_layer=7, num_atom=0)
+  torch.manual_seed(1234)
+  net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval().to(dev)
+  L = torch.stack([A, A], dim=3)          # channels-last collate layout [B,N,N,E+1]
+  g = torch.Generator(device=dev)
+  g.manual_seed(1)
+  X = torch.randn((B, N, 10), generator=g, device=dev)
+  mask = torch.ones((B, N), dtype=torch.uint8, device=dev)
+  out = {}
+  with torch.no_grad():
+    for name, planes in (('bf16', 1), ('split3', 3)):
+      ts = []
+      for it in range(reps + 1):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        e[0].record()
+        score = net._large_graph_forward_hip(X, L, D, V, mask, planes=planes)
+        e[1].record()
+        torch.cuda.synchronize()
+        if it:
+          ts.append(e[0].elapsed_time(e[1]))
+      out[name] = (float(np.mean(ts)), score)
+    # the dominant kernel alone: 7 launches on the packed operators (the last layer's buffers)
+    plan = net._plan_large(1)
+    Lb, Vb = ops.large_pack_operators(L, V, 1)
+    work = ops.large_work_buffers(Lb)
+    Zt, Tt, _ = work
+    Gs = ops.spectral_gains(D, net.long_diffusion_dist, net.num_layer, plan['mlp_pack'])
+    lay = plan['conv'][1][1]
+    state = torch.randn((B, N, 128), generator=g, device=dev)
+    ops.large_gemm1(state, 128, Lb, lay['Wb'], Zt)
+    ops.large_spectral(state, 128, Lb, V, Gs[1], lay['Wt'], work[2], Tt)
+    buf = torch.empty((B, N, 128), dtype=torch.float32, device=dev)
+    ops.large_conv(Lb, Vb, Zt, Tt, lay['bias'], out=buf)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record()
+    for _ in range(7):
+      ops.large_conv(Lb, Vb, Zt, Tt, lay['bias'], out=buf)
+    e[1].record()
+    torch.cuda.synchronize()
+    conv_ms = e[0].elapsed_time(e[1]) / 7
+  Nk = Lb.dims[1]
+  Cn = 2
+  alg = B * (Cn * N * Nk + N * 64 + Cn * 128 * Nk + 128 * 64) * 2 + B * N * 128 * 4
+  dev_rel = float((out['bf16'][1] - out['split3'][1]).abs().max() / out['split3'][1].abs().max())
+  res = {'workload': 'LanczosNetGeneral conv stack on the graphs of lanczos_large_mode: B=%d, N=%d, '
+                     'K=%d, E+1=2, S=8, 10 -> 7 x 128 -> 2, bf16 operands / fp32 accumulate '
+                     '(pack + 7 x [gemm1, eigen-space block, streamed conv] + head)' % (B, N, K),
+         'forward_ms': round(out['bf16'][0], 3),
+         'graphs_per_s_forward': round(B / out['bf16'][0] * 1e3, 1),
+         'split_precision_forward_ms': round(out['split3'][0], 3),
+         'bf16_vs_split_precision_rel': dev_rel,
+         'roofline': {'kernel': 'large_conv_kernel<1, 8>', 'bound': 'hbm',
+                      'algorithmic_bytes_per_launch': alg, 'avg_launch_ms': round(conv_ms, 4),
+                      'achieved': round(alg / conv_ms / 1e6, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                      'frac': round(alg / conv_ms / 1e6 / 8000.0, 4)}}
+  del net, L, Lb, Vb, work
+  torch.cuda.empty_cache()
+  return res
 
 
 def ada_leg(dev, L, node_feat, mask_u8, reps=5):
@@ -444,12 +518,15 @@ def main():
       np.mean([ev[i][4].elapsed_time(ev[i][5]) for i in range(args.steps)]))
 
   # secondary measurements (N = 1 only, never `value`)
-  sweep = large = ada = None
+  sweep = large = large_conv = ada = None
   if world == 1 and args.gemm == 'fp32' and not args.zero_params and args.sweep:
     sweep = forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, (1024, 4096, 16384)
                                 if B == 1024 else (B,))
   if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.no_secondary:
-    large = lanczos_large_leg(dev)
+    (Ag, Dg, Vg), large = lanczos_large_leg(dev)
+    large_conv = large_graph_leg(dev, Ag, Dg, Vg)
+    del Ag, Dg, Vg
+    torch.cuda.empty_cache()
     ada = ada_leg(dev, L, node_feat, mask_u8)
 
   if rank == 0:
@@ -509,6 +586,8 @@ def main():
       out['config']['forward_batch_sweep'] = sweep
     if large is not None:
       out['config']['lanczos_large_mode'] = large
+    if large_conv is not None:
+      out['config']['large_graph_conv_mode'] = large_conv
     if ada is not None:
       out['config']['ada_mode'] = ada
     if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,133 @@
+"""The training step of the reference runner as a replayed HIP graph.
+
+`QM8Runner.train` (runner/qm8_runner.py:189-250) runs, per batch,
+`optimizer.zero_grad(); _, loss = model(...); loss.backward(); optimizer.step()`.  On the HIP
+module that is ~6 ms of GPU work at B = 1024 issued through ~400 Python-level operations (kernel
+launches through ctypes, small torch ops of the backward, the optimizer's foreach kernels): the
+eager step is bound by the host.  `GraphedTrainStep` captures exactly that
+sequence — the fused forward (activations stored), the HIP input-gradient / message /
+gain-gradient kernels, the library GEMMs, the parameter re-packing and the optimizer update —
+into one HIP graph per batch shape and replays it: one launch per step, no Python on the critical
+path, same kernels, same arithmetic, same parameter trajectory.
+
+Nothing in the captured region may touch the host, so the module's backward switches to its
+static-shape variant while capturing (message matrix sized by the padded row count, tail masked
+on the device; `_LanczosNetFusedFunction`).  The optimizer must keep its step counters on the
+device: build it with `capturable=True` (`make_adam` does).
+
+    step = GraphedTrainStep(model, make_adam(model.parameters(), lr=1e-4))
+    for data in loader:                      # device-resident batches (PackedQM8Data, or .cuda())
+        loss = step(data['node_feat'], data['L'], data['D'], data['V'], data['label'],
+                    data['node_mask'])       # 0-dim tensor, valid until the next call
+"""
+import torch
+
+__all__ = ['GraphedTrainStep', 'make_adam']
+
+
+def make_adam(params, lr=1e-4, weight_decay=0.0, **kw):
+    """torch.optim.Adam as the runner builds it (runner/qm8_runner.py:72-74), with the step
+    counters on the device so that `optimizer.step()` can be captured."""
+    params = list(params)
+    # lr as a device tensor: an LR scheduler then changes it in place and the captured step sees it
+    lr_t = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
+    return torch.optim.Adam(params, lr=lr_t, weight_decay=weight_decay, capturable=True, **kw)
+
+
+class GraphedTrainStep(object):
+    """Callable `(node_feat, L, D, V, label, mask) -> loss` for LanczosNet-signature modules
+    (`names=('node_feat', 'L', 'label', 'mask')`-style modules pass `D = V = None`).
+
+    The first `warmup` calls for a new input shape run eagerly (they are ordinary training steps);
+    the next call captures the step into a graph for that shape and every later call with the same
+    shapes replays it.  QM8 batches differ in their padded node count N, so a handful of graphs
+    (one per N) coexist; they share one memory pool.
+
+    If the module was trained eagerly before, drop every reference to those steps' losses first
+    (`loss = float(loss)`): a live autograd graph keeps the parameters' AccumulateGrad nodes bound
+    to the stream they were created on, and they must be re-created on the capture stream."""
+
+    def __init__(self, model, optimizer, warmup=2, scheduler=None):
+        for group in optimizer.param_groups:
+            # optimizers with host-side step counters (Adam & co.) expose the flag; plain SGD has
+            # no such state and captures as it is
+            if 'capturable' in group and not group['capturable']:
+                raise ValueError('GraphedTrainStep needs an optimizer built with capturable=True '
+                                 '(see lanczosnet_amd.train.make_adam)')
+        self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
+        self.scheduler = scheduler
+        self._graphs = {}
+        self._seen = {}
+        self._pool = None
+        # warm-up steps and captures share one side stream (autograd's AccumulateGrad nodes
+        # remember the stream they were created on)
+        self._stream = torch.cuda.Stream()
+
+    @staticmethod
+    def _key(tensors):
+        return tuple((tuple(t.shape), t.dtype) if t is not None else None for t in tensors)
+
+    def _eager(self, *inputs):
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self._eager_body(*inputs)
+        cur.wait_stream(self._stream)
+        return loss
+
+    def _capture(self, key, inputs):
+        static = [t.clone() if t is not None else None for t in inputs]
+        graph = torch.cuda.CUDAGraph()
+        # gradients must be allocated inside the graph's pool: drop the eager ones first
+        self.optimizer.zero_grad(set_to_none=True)
+        if hasattr(self.model, 'invalidate_plan'):
+            self.model.invalidate_plan()
+        kw = {'pool': self._pool} if self._pool is not None else {}
+        with torch.cuda.graph(graph, stream=self._stream, **kw):
+            loss = self._eager_body(*static)
+        if self._pool is None:
+            self._pool = graph.pool()
+        self._graphs[key] = (graph, static, loss)
+
+    def _eager_body(self, node_feat, L, D, V, label, mask):
+        # (no zero_grad inside: backward writes fresh .grad tensors in the pool at capture and the
+        # replays overwrite the same memory)
+        if D is None:
+            _, loss = self.model(node_feat, L, label=label, mask=mask)
+        else:
+            _, loss = self.model(node_feat, L, D, V, label=label, mask=mask)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, node_feat, L, D, V, label, mask):
+        inputs = (node_feat, L, D, V, label, mask)
+        key = self._key(inputs)
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._seen.get(key, 0)
+            if n < self.warmup:
+                self._seen[key] = n + 1
+                loss = self._eager(*inputs)
+                self._after_step()
+                return loss
+            # capture records the step without running it; the replay below executes it
+            torch.cuda.synchronize()
+            self._capture(key, inputs)
+            entry = self._graphs[key]
+        graph, static, loss = entry
+        for dst, src in zip(static, inputs):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        graph.replay()
+        self._after_step()
+        return loss
+
+    def _after_step(self):
+        # the packed-parameter plans are keyed on tensor versions, which a replay does not bump:
+        # whoever runs the module eagerly next (validation, another shape's warm-up) must re-pack
+        if hasattr(self.model, 'invalidate_plan'):
+            self.model.invalidate_plan()
+        if self.scheduler is not None:
+            self.scheduler.step()

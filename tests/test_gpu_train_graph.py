@@ -1,0 +1,83 @@
+"""The training step replayed from a HIP graph (lanczosnet_amd.train.GraphedTrainStep) against the
+same steps launched eagerly: same kernels, same parameter trajectory."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from lanczosnet_amd.synthetic import draw_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _t(x):
+  return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def _setup(seed):
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNet
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net = LanczosNet(make_model_config(cfg)).train()
+  net.load_state_dict({k: torch.from_numpy(v)
+                       for k, v in oracle.make_lanczosnet_params(cfg, seed).items()})
+  net = net.to(DEV)
+  batches = []
+  for s, nmax in ((1, 26), (2, 19), (3, 26), (4, 19), (5, 26), (6, 26), (7, 19), (8, 26)):
+    b = draw_batch(96, seed=s, n_min=6, n_max=nmax)
+    n = _t(b['n_nodes'])
+    L = ops.laplacian_l4(_t(b['adjs']), n)
+    D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+    batches.append((_t(b['node_feat']), L, D, V, _t(b['label']), _t(b['node_mask'])))
+  return net, batches
+
+
+@pytest.mark.parametrize('optim', ['sgd', 'adam'])
+def test_graphed_train_step_follows_the_eager_trajectory(optim):
+  from lanczosnet_amd.train import GraphedTrainStep, make_adam
+  net_e, batches = _setup(3)
+  net_g, _ = _setup(3)
+  lr = 1e-2 if optim == 'sgd' else 1e-3
+  mk = (lambda p: torch.optim.SGD(p, lr=lr)) if optim == 'sgd' else (lambda p: make_adam(p, lr=lr))
+  opt_e, opt_g = mk(net_e.parameters()), mk(net_g.parameters())
+  step = GraphedTrainStep(net_g, opt_g, warmup=1)
+  le, lg = [], []
+  for bt in batches:
+    opt_e.zero_grad(set_to_none=True)
+    _, loss = net_e(bt[0], bt[1], bt[2], bt[3], label=bt[4], mask=bt[5])
+    loss.backward()
+    opt_e.step()
+    le.append(float(loss.detach()))
+    lg.append(float(step(*bt)))
+  assert len(step._graphs) == 2          # two padded sizes -> two graphs, replayed 4 and 2 times
+  le, lg = np.array(le), np.array(lg)
+  assert np.abs(le - lg).max() <= 2e-5 * np.abs(le).max(), (le, lg)
+  worst, worst_k = 0.0, None
+  for (k, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
+    d = (pe - pg).abs().max().item()
+    if d / max(pe.abs().max().item(), 1e-12) > worst:
+      worst, worst_k = d / max(pe.abs().max().item(), 1e-12), k
+    if optim == 'adam':
+      # Adam normalises every element's update to ~lr whatever the gradient's size: elements whose
+      # gradient is rounding noise move by +-lr per step in either run — bounded, not comparable
+      assert d <= 2.5 * lr * len(batches), k
+  print('%s: loss dev %.2e, worst relative parameter deviation after %d steps: %.2e (%s)' %
+        (optim, np.abs(le - lg).max() / np.abs(le).max(), len(batches), worst, worst_k))
+  if optim == 'sgd':
+    assert worst < 2e-5     # SGD is linear in the gradients: the two runs stay together
+  # the module stays usable eagerly after replays (plans re-packed from the updated parameters)
+  net_e.eval(), net_g.eval()
+  with torch.no_grad():
+    bt = batches[0]
+    se = net_e(bt[0], bt[1], bt[2], bt[3], mask=bt[5])
+    sg = net_g(bt[0], bt[1], bt[2], bt[3], mask=bt[5])
+  assert (se - sg).abs().max().item() <= (1e-5 if optim == 'sgd' else 1e-2) * se.abs().max().item()
+
+
+def test_graphed_step_needs_a_capturable_optimizer():
+  from lanczosnet_amd.train import GraphedTrainStep
+  net, _ = _setup(1)
+  with pytest.raises(ValueError):
+    GraphedTrainStep(net, torch.optim.Adam(net.parameters(), lr=1e-3))

@@ -44,6 +44,25 @@ for _ in range(K):
   with torch.no_grad():
     net(nf, L, D, V, mask=mask)
 e1.record(); torch.cuda.synchronize()
+# the same step replayed from a HIP graph (lanczosnet_amd.train.GraphedTrainStep)
+from lanczosnet_amd.train import GraphedTrainStep, make_adam
+loss = float(loss)   # drop the last eager autograd graph (its AccumulateGrad nodes belong to the
+opt.zero_grad(set_to_none=True)  # default stream and must not be alive during the capture)
+del opt
+net.train()
+opt_g = make_adam(net.parameters(), lr=1e-4)
+gstep = GraphedTrainStep(net, opt_g, warmup=2)
+for _ in range(4):
+  gstep(nf, L, D, V, label, mask)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+  gl = gstep(nf, L, D, V, label, mask)
+torch.cuda.synchronize()
+dtg = (time.perf_counter() - t0) / K
 print(json.dumps({'workload': 'LanczosNet QM8 train step (fwd + bwd + Adam), B=%d' % B,
                   'train_step_ms': round(dt * 1e3, 3), 'molecules_per_s': round(B / dt, 1),
-                  'forward_only_ms': round(e0.elapsed_time(e1) / K, 3), 'loss': float(loss)}))
+                  'graphed_train_step_ms': round(dtg * 1e3, 3),
+                  'graphed_molecules_per_s': round(B / dtg, 1),
+                  'forward_only_ms': round(e0.elapsed_time(e1) / K, 3), 'loss': loss,
+                  'graphed_loss': float(gl)}))
