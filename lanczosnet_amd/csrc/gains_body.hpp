@@ -19,7 +19,13 @@ constexpr int OFF_B6 = OFF_B4 + HT * 1024;      // [1][64][16]
 constexpr int OFF_W2 = OFF_B6 + 1024;           // rows_k8(128,128): [HT][16][64] float4
 constexpr int OFF_W4 = OFF_W2 + HT * 16 * 256;
 constexpr int OFF_W6 = OFF_W4 + HT * 16 * 256;  // rows_k8(32,128) (S rows zero padded to 32)
-constexpr int RING = 8;                         // prefetch ring slots (distance RING-2 steps)
+#ifndef LNZ_GAINS_RING
+#define LNZ_GAINS_RING 8
+#endif
+#ifndef LNZ_GAINS_DIST
+#define LNZ_GAINS_DIST (LNZ_GAINS_RING - 2)
+#endif
+constexpr int RING = LNZ_GAINS_RING;             // prefetch ring slots (distance LNZ_GAINS_DIST steps)
 constexpr int PACK_SIZE = OFF_W6 + 16 * 256 + RING * 256;
 constexpr int NSTEP = 2 * HT * 16 + 16;         // float4 steps of the W2|W4|W6 stream (144)
 
@@ -69,7 +75,7 @@ __device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (
   f32x16 acc = lnz::splat16(0.0f), acc1 = lnz::splat16(0.0f);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    constexpr int D = RING - 2;
+    constexpr int D = LNZ_GAINS_DIST;
     ring[(F0 + q + D) % RING] = wstream[(F0 + q + D) * 64];  // over-read lands in the slack
     __builtin_amdgcn_sched_barrier(0);
     const float4 a = ring[(F0 + q) % RING];
@@ -104,7 +110,7 @@ __device__ __forceinline__ void gains_mlp_tile(const float* __restrict__ D, cons
   const float4* __restrict__ wstream = reinterpret_cast<const float4*>(pk + OFF_W2) + lane;
   float4 ring[RING];
 #pragma unroll
-  for (int f = 0; f < RING - 2; ++f) ring[f] = wstream[f * 64];
+  for (int f = 0; f < LNZ_GAINS_DIST; ++f) ring[f] = wstream[f * 64];
 
   // first-layer A scalars (32 per lane) and features of this lane's k-half: f = 8 hh + t
   float w0[HT][8];
