@@ -1,7 +1,11 @@
 """Oracle (test infrastructure): unsorted_segment_sum.
 
-The reference op cannot be compiled here (`operators/src/segment_reduction.cpp:1`
-needs THC/THC.h, removed from modern torch) so this file restates it:
+Restatement of the reference op.  Pin: the reference's CPU source
+(`operators/src/segment_reduction.cpp`) is compiled UNMODIFIED where it lies by
+`oracle/ref_build.py` (an empty `THC/THC.h` shim satisfies its one dead include) into
+`oracle/_ref/`, and `tests/test_segment_sum_reference.py` checks this restatement — and the HIP
+operator — against that binary.  The CUDA file cannot be built here; its semantics are restated
+from the source:
 
   * GPU semantics  — `operators/src/cuda/segment_reduction.cu:39-53` (forward,
     atomicAdd scatter) and `:55-69` (backward, gather).  NOTE the reference quirk
