@@ -221,3 +221,40 @@ def test_large_graph_forward_config5_shape_matches_library_path():
   print('N=2048: split-precision vs library %.2e, bf16 vs library %.2e' % (e3, e1))
   assert e3 < 1e-5
   assert e1 < 2e-2
+
+
+def test_qm8_schema_molecules_beyond_the_32_node_tile():
+  """LanczosNet (atom embedding, 7 bond-type channels, full QM8 widths) on molecules of up to 44
+  atoms: beyond the fused 32-row kernel the module takes the streamed kernels (general channel
+  count, ragged N, K = 48 < 64) — against the fp64 oracle on the reference pipeline's (D, V)."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNet
+  from lanczosnet_amd.synthetic import draw_batch
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  K = 48   # >= n: no top-K cut, so no molecule's (D, V) is basis dependent
+  cfg = dict(oracle.DEFAULT_QM8_CFG, num_eig_vec=K)
+  b = draw_batch(12, seed=9, n_min=20, n_max=44)
+  B, N = b['node_mask'].shape
+  assert N > 32
+  P = oracle.make_lanczosnet_params(cfg, 4)
+  net = LanczosNet(make_model_config(cfg)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  net = net.to(DEV)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)  # noqa: E731
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, K)
+  with torch.no_grad():
+    score = net(t(b['node_feat']), L, D, V, mask=t(b['node_mask'])).cpu().numpy()
+  Lo = np.zeros((B, N, N, 7), np.float32)
+  Dl, Vl = [], []
+  for i in range(B):
+    nb = int(b['n_nodes'][i])
+    Lo[i, :nb, :nb] = oracle.laplacian_multi_l4(b['adjs'][i, :nb, :nb])
+    e, v, _ = oracle.graph_laplacian_eigs(b['adjs'][i, :nb, :nb].sum(axis=2), graph_laplacian_type='L4')
+    Dl.append(e)
+    Vl.append(v)
+  Do, Vo = oracle.collate_eigs(Dl, Vl, N, K)
+  ref = oracle.lanczos_net_forward(P, cfg, b['node_feat'], Lo, Do, Vo, b['node_mask'], dtype=np.float64)
+  per = np.abs(score - ref).max(axis=1) / np.abs(ref).max()
+  assert per.max() < 1e-5, per
