@@ -1025,6 +1025,32 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
 constexpr int kPrepLds = 20480;  // static LDS of the fused preparation launch (>= sizeof(Ritz32Smem))
 static_assert(sizeof(Ritz32Smem) <= kPrepLds, "Ritz scratch must fit the shared block");
 
+// The same launch with ONE static LDS block per workgroup, used according to its role (Ritz
+// scratch or pack staging tile), for staging tiles up to kPrepLds (QM8: 26 x 26 x 7 floats =
+// 18.9 KB).  With the separate dynamic tile above every workgroup carries ~29 KB: the four
+// resident Ritz workgroups of a CU (one per SIMD, the long pole) leave room for ONE more, and the
+// B pack workgroups trickle through behind them instead of running in their shadow.
+__global__ __launch_bounds__(256) void prepare_batch_union_kernel(
+    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
+    float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
+    int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
+    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
+    const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
+    int32_t* __restrict__ info, uint32_t* __restrict__ ident) {
+  __shared__ __attribute__((aligned(16))) unsigned char ubuf[kPrepLds];
+  const int blk = blockIdx.x;
+  if (blk == 0) {
+    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+  } else if (blk <= B) {
+    if (threadIdx.x >= 64) return;
+    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x,
+                        *reinterpret_cast<Ritz32Smem*>(ubuf));
+  } else {
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, reinterpret_cast<float*>(ubuf), blk - 1 - B,
+                        ident);
+  }
+}
+
 // Software pipeline over a stream of batches, ONE launch of 256-thread workgroups: workgroup 0
 // plans batch k+1, workgroups 1..B are its Lanczos / eigensolve wavefronts (one live wave each,
 // raised issue priority), the next n_cons workgroups run the spectral-gains MLP of batch k (whose
@@ -1097,10 +1123,16 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
   size_t lds = (size_t)N * N * C * sizeof(float);
   LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
-  hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(256), lds, (hipStream_t)stream,
-                     L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
-                     allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
-                     n_nodes, D, V, info, ident);
+  if (lds <= (size_t)kPrepLds)
+    hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(2 * B + 1), dim3(256), 0,
+                       (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
+                       (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
+                       K, gain_rows, n_gain_rows, n_nodes, D, V, info, ident);
+  else
+    hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(256), lds, (hipStream_t)stream,
+                       L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
+                       allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
+                       n_nodes, D, V, info, ident);
   return lnz::check_launch("lnz_prepare_batch");
 }
 
