@@ -338,10 +338,19 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
   dist = None
+  # LNZ_BENCH_ONE_DEVICE=1 (functional test of the N > 1 path on a box with ONE GPU): every rank
+  # uses cuda:0 and the exchange runs on gloo — RCCL refuses two ranks on one device.  Not a
+  # measurement mode.
+  one_dev = os.environ.get('LNZ_BENCH_ONE_DEVICE', '0') == '1'
+  if one_dev:
+    local_rank = 0
   if world > 1:
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if one_dev:
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
   dev = torch.device('cuda', local_rank)
   torch.cuda.set_device(dev)
 
@@ -554,7 +563,7 @@ def main():
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32' if args.gemm == 'fp32' else 'f16x3 (split fp16 products, f32 accumulate)',
-        'data': 'synthetic',
+        'data': 'synthetic' if not one_dev else 'synthetic (LNZ_BENCH_ONE_DEVICE functional test: all ranks on one GPU, gloo)',
         'config': {'workload': 'QM8 LanczosNet batch=%d/GPU, N<=32 dense L (tile N=%d), K=20, '
                                'fp32, 7x128 layers, 1xMI355X per rank; step = [pack L + batch plan + '
                                'Lanczos + tridiagonal eigensolver (Ritz pairs)] (one launch) + spectral gains + fused forward' % (B, L.shape[1]),
