@@ -501,12 +501,15 @@ class _LanczosNetBase(nn.Module):
             W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)                       # [dout, C, d_in]
-            Z = torch.einsum('bnd,ocd->bcno', state, Wc)             # X W_c^T  [B, C, N, dout]
+            # X W_c^T per channel.  unbind, not `Z[:, c]`: the backward of a select allocates and adds a
+            # zero tensor of the WHOLE [B, C, N, dout] block per channel (15 x 200 MB per layer at
+            # B = 1024), the backward of unbind is one stack
+            Z = torch.einsum('bnd,ocd->bcno', state, Wc).unbind(1)   # C x [B, N, dout]
             out = bias.view(1, 1, -1).expand(B, N, -1)
             c = 0
             if self.num_scale_short > 0:
                 for p in self.short_diffusion_dist:
-                    z = Z[:, c]
+                    z = Z[c]
                     for _ in range(p):
                         z = torch.bmm(Lc[:, 0], z)
                     out = out + z
@@ -515,11 +518,11 @@ class _LanczosNetBase(nn.Module):
                 G = pows if self.spectral_filter_kind != 'MLP' else \
                     self.spectral_filter[t](pows.view(-1, S)).view(B, -1, S)   # [B, K, S]
                 for s_ in range(S):
-                    y = torch.bmm(Vt, Z[:, c])                                   # [B, K, dout]
+                    y = torch.bmm(Vt, Z[c])                                   # [B, K, dout]
                     out = out + torch.bmm(Vf, G[:, :, s_].unsqueeze(2) * y)
                     c += 1
             for e in range(self.num_edgetype + 1):
-                out = out + torch.bmm(Lc[:, e], Z[:, c])
+                out = out + torch.bmm(Lc[:, e], Z[c])
                 c += 1
             state = torch.relu(out)
             if dropout:
@@ -891,15 +894,23 @@ class AdaLanczosNet(_LanczosNetBase):
         q = q1.to(dd) * m
         q = q / torch.norm(q, 2, dim=1, keepdim=True)
         Qs, alphas, betas, valids = [torch.zeros_like(q), q], [], [torch.zeros(B, 1, 1, dtype=dd, device=L.device)], []
+        # The reference's Gram-Schmidt (:177-189) subtracts the projections on q_1 .. q_{ii-1} ONE
+        # AFTER THE OTHER from the running z, twice: z <- P_{ii-1} ... P_1 z with P_j = I - q_j q_j^T
+        # / (q_j^T q_j + EPS).  The product M_ii = P_{ii-1} M_{ii-1} is carried along instead of
+        # replaying 2 (ii-1) vector updates per step: the same map (and the same derivative), one
+        # batched N x N product per step instead of ~2000 tiny launches per forward in fp64.
+        eye = torch.eye(N, dtype=dd, device=L.device).unsqueeze(0)
+        M = None
         for ii in range(1, Tit + 1):
             z = torch.bmm(Le, Qs[ii])
             alpha = (Qs[ii] * z).sum(dim=1, keepdim=True)
             z = z - alpha * Qs[ii] - betas[ii - 1] * Qs[ii - 1]
             if ii > 1:
-                for _ in range(2):
-                    for jj in range(1, ii):
-                        z = z - (z * Qs[jj]).sum(dim=1, keepdim=True) / (
-                            (Qs[jj] * Qs[jj]).sum(dim=1, keepdim=True) + eps) * Qs[jj]
+                qp = Qs[ii - 1]
+                Pj = eye - torch.bmm(qp, qp.transpose(1, 2)) / (
+                    (qp * qp).sum(dim=1, keepdim=True) + eps)
+                M = Pj if M is None else torch.bmm(Pj, M)
+                z = torch.bmm(M, torch.bmm(M, z))
             beta = torch.norm(z, p=2, dim=1, keepdim=True)
             ok = (beta >= 1.0e-4).to(dd)
             valids.append(ok if ii == 1 else valids[-1] * ok)
@@ -936,20 +947,20 @@ class AdaLanczosNet(_LanczosNetBase):
             W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)
-            Z = torch.einsum('bnd,ocd->bcno', state, Wc)
+            Z = torch.einsum('bnd,ocd->bcno', state, Wc).unbind(1)   # C x [B, N, dout] (see _torch_forward)
             out = bias.view(1, 1, -1).expand(B, N, -1)
             c = 0
             for p in self.short_diffusion_dist:
-                z = Z[:, c]
+                z = Z[c]
                 for _ in range(p):
                     z = torch.bmm(Lc[:, 0], z)
                 out = out + z
                 c += 1
             for s_ in range(S):
-                out = out + torch.bmm(Q, torch.bmm(DD[:, :, :, s_], torch.bmm(Qt, Z[:, c])))
+                out = out + torch.bmm(Q, torch.bmm(DD[:, :, :, s_], torch.bmm(Qt, Z[c])))
                 c += 1
             for e in range(self.num_edgetype + 1):
-                out = out + torch.bmm(Lc[:, e], Z[:, c])
+                out = out + torch.bmm(Lc[:, e], Z[c])
                 c += 1
             state = torch.relu(out)
         y = self.filter[-1](state) * self.att_func(state)

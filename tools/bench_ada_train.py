@@ -1,0 +1,32 @@
+"""AdaLanczosNet training step (HIP forward, torch-restatement backward, Adam), B=1024."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle
+from lanczosnet_amd import ops
+from lanczosnet_amd.model import AdaLanczosNet
+from lanczosnet_amd.synthetic import draw_batch
+from lanczosnet_amd.utils.arg_helper import make_model_config
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30])
+torch.manual_seed(1234)
+net = AdaLanczosNet(make_model_config(cfg, name='AdaLanczosNet')).train().cuda()
+opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+b = draw_batch(B, seed=0)
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+n = t(b['n_nodes']); nf, mask, label = t(b['node_feat']), t(b['node_mask']), t(b['label'])
+L = ops.laplacian_l4(t(b['adjs']), n)
+def step():
+  opt.zero_grad(set_to_none=True)
+  _, loss = net(nf, L, label=label, mask=mask)
+  loss.backward(); opt.step(); return loss
+for _ in range(2): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): loss = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+with torch.no_grad():
+  net.eval(); net(nf, L, mask=mask); torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(5): net(nf, L, mask=mask)
+  torch.cuda.synchronize(); df = (time.perf_counter() - t0) / 5
+print(json.dumps({'workload': 'AdaLanczosNet train step B=%d' % B, 'train_step_ms': round(dt * 1e3, 2),
+                  'forward_ms': round(df * 1e3, 2), 'loss': float(loss)}))
