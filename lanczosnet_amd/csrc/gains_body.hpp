@@ -66,13 +66,20 @@ __device__ inline f32x16 relu_bias16(f32x16 v, f32x16 b) {
   return v;
 }
 
-// One 32-row output tile of a 128-wide layer: 16 stream steps (4 MFMAs each).  F0 = index of the
-// tile's first step in the W2|W4|W6 stream (compile time => static ring slots / registers).
-template <int F0>
-__device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (&ring)[RING],
-                                    const f32x16 (&Hin)[HT]) {
-  // two accumulator chains (even / odd k-steps): consecutive MFMAs never depend on each other
-  f32x16 acc = lnz::splat16(0.0f), acc1 = lnz::splat16(0.0f);
+// One 32-row output tile of a 128-wide layer for RT row tiles at once: 16 stream steps, each
+// weight fragment feeding 4 MFMAs per row tile.  F0 = index of the tile's first step in the
+// W2|W4|W6 stream (compile time => static ring slots / registers).
+template <int F0, int RT>
+__device__ inline void dense_tile(const float4* __restrict__ wstream, float4 (&ring)[RING],
+                                  const f32x16 (&Hin)[RT][HT], f32x16 (&res)[RT]) {
+  // two accumulator chains per row tile (even / odd k-steps): consecutive MFMAs never depend on
+  // each other
+  f32x16 acc[RT], acc1[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    acc[t] = lnz::splat16(0.0f);
+    acc1[t] = lnz::splat16(0.0f);
+  }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     constexpr int D = LNZ_GAINS_DIST;
@@ -80,30 +87,37 @@ __device__ inline f32x16 dense_tile(const float4* __restrict__ wstream, float4 (
     __builtin_amdgcn_sched_barrier(0);
     const float4 a = ring[(F0 + q) % RING];
     const int ti = q >> 2, g = q & 3;
-    acc = lnz::mfma32(a.x, Hin[ti][4 * g + 0], acc);
-    acc1 = lnz::mfma32(a.y, Hin[ti][4 * g + 1], acc1);
-    acc = lnz::mfma32(a.z, Hin[ti][4 * g + 2], acc);
-    acc1 = lnz::mfma32(a.w, Hin[ti][4 * g + 3], acc1);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = lnz::mfma32(a.x, Hin[t][ti][4 * g + 0], acc[t]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc1[t] = lnz::mfma32(a.y, Hin[t][ti][4 * g + 1], acc1[t]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = lnz::mfma32(a.z, Hin[t][ti][4 * g + 2], acc[t]);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc1[t] = lnz::mfma32(a.w, Hin[t][ti][4 * g + 3], acc1[t]);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
-  return acc;
+  for (int t = 0; t < RT; ++t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) res[t][i] = acc[t][i] + acc1[t][i];
+  }
 }
 
 // rows / n_rows (optional): compact list of the (b*K + k) eigen slots that carry a Ritz pair
 // (k < min(n_b, K), lnz_plan_batch) — the slots of zero-padded eigen columns are skipped: their
 // gains never reach an output (the V column is zero, model/lanczos_net.py:114-117).
-// One wavefront = one 32-row tile of eigen slots through the MLP of conv layer l.  `row` is this
-// lane's eigen slot b*K + k (both lane halves hold the same 32 rows), `valid` masks the ragged tail.
-__device__ __forceinline__ void gains_mlp_tile(const float* __restrict__ D, const int row,
-                                               const bool valid, const int l, const int lane,
-                                               int B, int K, const DistArr& dist, int S,
-                                               const float* __restrict__ mlp_pack,
-                                               float* __restrict__ G) {
-  const int j = lane & 31, hh = lane >> 5;
-  (void)j;
-  const float dval = valid ? D[row] : 0.0f;
+// One wavefront = RT 32-row tiles of eigen slots through the MLP of conv layer l (every weight
+// fragment it streams feeds all RT tiles; a row's arithmetic does not depend on RT).  `row[t]` is
+// this lane's eigen slot b*K + k in tile t (both lane halves hold the same 32 rows), `valid[t]`
+// masks the ragged tail.
+template <int RT>
+__device__ __forceinline__ void gains_mlp_tiles(const float* __restrict__ D, const int (&row)[RT],
+                                                const bool (&valid)[RT], const int l,
+                                                const int lane, int B, int K, const DistArr& dist,
+                                                int S, const float* __restrict__ mlp_pack,
+                                                float* __restrict__ G) {
+  const int hh = lane >> 5;
   const float* pk = mlp_pack + (int64_t)l * PACK_SIZE;
 
   // start the 128-wide weight stream right away: it is independent of the first layer
@@ -112,65 +126,81 @@ __device__ __forceinline__ void gains_mlp_tile(const float* __restrict__ D, cons
 #pragma unroll
   for (int f = 0; f < LNZ_GAINS_DIST; ++f) ring[f] = wstream[f * 64];
 
-  // first-layer A scalars (32 per lane) and features of this lane's k-half: f = 8 hh + t
-  float w0[HT][8];
-#pragma unroll
-  for (int ot = 0; ot < HT; ++ot) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) w0[ot][t] = pk[OFF_W0 + (ot * 8 + t) * 64 + lane];
-  }
-  float feat[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    float lo = t < S ? powi(dval, dist.v[t]) : 0.0f;
-    float hi = (8 + t) < S ? powi(dval, dist.v[8 + t]) : 0.0f;
-    feat[t] = hh ? hi : lo;
-  }
   const int steps0 = S < 8 ? S : 8;
-
-  f32x16 h1[HT], h2[HT];
-  // Linear(S -> 128) + ReLU
-#pragma unroll
-  for (int ot = 0; ot < HT; ++ot) {
-    f32x16 acc = lnz::splat16(0.0f);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (t < steps0) acc = lnz::mfma32(w0[ot][t], feat[t], acc);
-    }
-    h1[ot] = relu_bias16(acc, load_bias_frag(pk + OFF_B0 + ot * 1024, lane));
-  }
-  // Linear(128 -> 128) + ReLU, twice (stream steps 0..63 and 64..127)
+  f32x16 h1[RT][HT], h2[RT][HT];
   {
-    f32x16 b0 = load_bias_frag(pk + OFF_B2 + 0 * 1024, lane);
-    f32x16 b1 = load_bias_frag(pk + OFF_B2 + 1 * 1024, lane);
-    h2[0] = relu_bias16(dense_tile<0>(wstream, ring, h1), b0);
-    b0 = load_bias_frag(pk + OFF_B2 + 2 * 1024, lane);
-    h2[1] = relu_bias16(dense_tile<16>(wstream, ring, h1), b1);
-    b1 = load_bias_frag(pk + OFF_B2 + 3 * 1024, lane);
-    h2[2] = relu_bias16(dense_tile<32>(wstream, ring, h1), b0);
-    b0 = load_bias_frag(pk + OFF_B4 + 0 * 1024, lane);
-    h2[3] = relu_bias16(dense_tile<48>(wstream, ring, h1), b1);
-    b1 = load_bias_frag(pk + OFF_B4 + 1 * 1024, lane);
-    h1[0] = relu_bias16(dense_tile<64>(wstream, ring, h2), b0);
-    b0 = load_bias_frag(pk + OFF_B4 + 2 * 1024, lane);
-    h1[1] = relu_bias16(dense_tile<80>(wstream, ring, h2), b1);
-    b1 = load_bias_frag(pk + OFF_B4 + 3 * 1024, lane);
-    h1[2] = relu_bias16(dense_tile<96>(wstream, ring, h2), b0);
-    b0 = load_bias_frag(pk + OFF_B6, lane);
-    h1[3] = relu_bias16(dense_tile<112>(wstream, ring, h2), b1);
-    // Linear(128 -> S), no activation (stream steps 128..143)
-    f32x16 acc = dense_tile<128>(wstream, ring, h1);
-    if (valid) {
-      const int b = row / K, k = row - b * K;
-      float* Gb = G + (((int64_t)l * B + b) * S) * K + k;
+    // first-layer A scalars (32 per lane) and features of this lane's k-half: f = 8 hh + t
+    float w0[HT][8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int sidx = lnz::cd_row(r, hh);
-        if (sidx < S) Gb[(int64_t)sidx * K] = acc[r] + b0[r];
+    for (int ot = 0; ot < HT; ++ot) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) w0[ot][t] = pk[OFF_W0 + (ot * 8 + t) * 64 + lane];
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const float dval = valid[rt] ? D[row[rt]] : 0.0f;
+      float feat[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float lo = t < S ? powi(dval, dist.v[t]) : 0.0f;
+        float hi = (8 + t) < S ? powi(dval, dist.v[8 + t]) : 0.0f;
+        feat[t] = hh ? hi : lo;
+      }
+      // Linear(S -> 128) + ReLU
+#pragma unroll
+      for (int ot = 0; ot < HT; ++ot) {
+        f32x16 acc = lnz::splat16(0.0f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < steps0) acc = lnz::mfma32(w0[ot][t], feat[t], acc);
+        }
+        h1[rt][ot] = relu_bias16(acc, load_bias_frag(pk + OFF_B0 + ot * 1024, lane));
+      }
+    }
+  }
+  // Linear(128 -> 128) + ReLU, twice (stream steps 0..63 and 64..127), then Linear(128 -> S)
+  f32x16 res[RT];
+#define LNZ_DENSE(F0, IN, OUT, OT, BOFF)                                   \
+  {                                                                        \
+    const f32x16 bb = load_bias_frag(pk + (BOFF), lane);                   \
+    dense_tile<F0, RT>(wstream, ring, IN, res);                            \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) OUT[rt][OT] = relu_bias16(res[rt], bb); \
+  }
+  LNZ_DENSE(0, h1, h2, 0, OFF_B2 + 0 * 1024)
+  LNZ_DENSE(16, h1, h2, 1, OFF_B2 + 1 * 1024)
+  LNZ_DENSE(32, h1, h2, 2, OFF_B2 + 2 * 1024)
+  LNZ_DENSE(48, h1, h2, 3, OFF_B2 + 3 * 1024)
+  LNZ_DENSE(64, h2, h1, 0, OFF_B4 + 0 * 1024)
+  LNZ_DENSE(80, h2, h1, 1, OFF_B4 + 1 * 1024)
+  LNZ_DENSE(96, h2, h1, 2, OFF_B4 + 2 * 1024)
+  LNZ_DENSE(112, h2, h1, 3, OFF_B4 + 3 * 1024)
+#undef LNZ_DENSE
+  {
+    const f32x16 b6 = load_bias_frag(pk + OFF_B6, lane);
+    dense_tile<128, RT>(wstream, ring, h1, res);  // no activation (stream steps 128..143)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      if (valid[rt]) {
+        const int b = row[rt] / K, k = row[rt] - b * K;
+        float* Gb = G + (((int64_t)l * B + b) * S) * K + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int sidx = lnz::cd_row(r, hh);
+          if (sidx < S) Gb[(int64_t)sidx * K] = res[rt][r] + b6[r];
+        }
       }
     }
   }
 }
 
+__device__ __forceinline__ void gains_mlp_tile(const float* __restrict__ D, const int row,
+                                               const bool valid, const int l, const int lane,
+                                               int B, int K, const DistArr& dist, int S,
+                                               const float* __restrict__ mlp_pack,
+                                               float* __restrict__ G) {
+  const int rows1[1] = {row};
+  const bool valid1[1] = {valid};
+  gains_mlp_tiles<1>(D, rows1, valid1, l, lane, B, K, dist, S, mlp_pack, G);
+}
 
 }  // namespace lnz_gains

@@ -12,6 +12,7 @@
 // per row.  grid = (row tiles, conv layers): B*K/32 * L workgroups (4480 for B=1024) >> 256 CUs.
 #include "common.hpp"
 #include "gains_body.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -40,6 +41,27 @@ __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
   const bool valid = idx < R;
   const int row = valid ? (rows ? rows[idx] : idx) : 0;
   gains_mlp_tile(D, row, valid, blockIdx.y, lane, B, K, dist, S, mlp_pack, G);
+}
+
+// Two row tiles per wavefront: every weight fragment streamed from L2 feeds 8 MFMAs instead of 4
+// (the one-tile kernel pulls 144 KB per 592 MFMAs through the CU's vector-memory path), four
+// independent accumulator chains, one wave per SIMD (the whole 512-register file).
+__global__ __launch_bounds__(64) void spectral_gains_mlp2_kernel(
+    const float* __restrict__ D, int R, int B, int K, DistArr dist, int S,
+    const float* __restrict__ mlp_pack, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ n_rows, float* __restrict__ G) {
+  const int lane = threadIdx.x;
+  if (rows) R = *n_rows;
+  if ((int)blockIdx.x * 64 >= R) return;
+  int row[2];
+  bool valid[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int idx = blockIdx.x * 64 + 32 * t + (lane & 31);
+    valid[t] = idx < R;
+    row[t] = valid[t] ? (rows ? rows[idx] : idx) : 0;
+  }
+  gains_mlp_tiles<2>(D, row, valid, blockIdx.y, lane, B, K, dist, S, mlp_pack, G);
 }
 
 // non-MLP branch (model/lanczos_net.py:118-121): G[l][b][s][k] = D[b,k]^p_s for every layer
@@ -163,9 +185,22 @@ extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32
   if (kind == 0) {
     LNZ_REQUIRE(mlp_pack, LNZ_EINVAL, "lnz_spectral_gains: kind=MLP needs mlp_pack");
     int R = B * K;
-    dim3 grid((R + 31) / 32, num_layer);
-    hipLaunchKernelGGL(spectral_gains_mlp_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
-                       mlp_pack, rows, n_rows, G);
+    // two row tiles per wave once the launch fills every SIMD twice over (a two-tile wave lasts
+    // twice as long: on a part-filled chip the one-tile kernel finishes first)
+    static const int forced = [] {
+      const char* e = getenv("LNZ_GAINS_TILES");
+      return e ? atoi(e) : 0;
+    }();
+    const bool two = forced ? forced == 2 : (int64_t)((R + 31) / 32) * num_layer >= 2048;
+    if (two) {
+      dim3 grid((R + 63) / 64, num_layer);
+      hipLaunchKernelGGL(spectral_gains_mlp2_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
+                         mlp_pack, rows, n_rows, G);
+    } else {
+      dim3 grid((R + 31) / 32, num_layer);
+      hipLaunchKernelGGL(spectral_gains_mlp_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
+                         mlp_pack, rows, n_rows, G);
+    }
   } else {
     int64_t total = (int64_t)num_layer * B * S * K;
     hipLaunchKernelGGL(spectral_gains_pow_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
