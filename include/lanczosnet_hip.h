@@ -131,12 +131,20 @@ int lnz_tridiag_eigh(const double* diag, const double* offdiag, int B, int M, do
  * The reference's counterpart is scipy.sparse.linalg.eigsh(L, k, which='LM')
  * (utils/data_helper.py:205-208, ARPACK, implicitly restarted): converged leading pairs agree,
  * unconverged ones are a different function — see oracle/lanczos_kstep.py.
- * workspace: lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes of device memory (Krylov basis,
- * fp64).  D [B,K], V [B,N,K]; info [B] (optional) = Lanczos steps actually taken. */
+ * workspace: lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes of device memory (Krylov basis
+ * and the symmetric variant's contribution slots, fp64).  D [B,K], V [B,N,K]; info [B] (optional) = Lanczos steps actually taken. */
 int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N);
 int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B, int N,
                            int M, int K, void* workspace, float* D, float* V, int32_t* info,
                            lnz_stream_t stream);
+/* The same for a SYMMETRIC A (every Laplacian of utils/data_helper.py:92-130 is), reading only
+ * the 256 x 256 chunk blocks (I, J >= I): an off-diagonal block serves w_I += A_IJ q_J and
+ * w_J += A_IJ^T q_I, 56 %% of the bytes per Lanczos step at N = 2048.  What lies below the diagonal
+ * chunk blocks is never read (numpy.linalg.eigh's UPLO convention, upper).  Deterministic (no
+ * atomics); same workspace. */
+int lnz_lanczos_ritz_large_sym(const float* A, int64_t stride_b, int64_t stride_r, int B, int N,
+                               int M, int K, void* workspace, float* D, float* V, int32_t* info,
+                               lnz_stream_t stream);
 
 /* ---- operand packing (MFMA fragment order) -------------------------------------------
  * W [rows, cols] (leading dimension ld) -> Wp[rt][q][lane][u] =

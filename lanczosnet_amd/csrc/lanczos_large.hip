@@ -15,6 +15,14 @@
 // + 4 N K (V) : 1.074 GB + 0.133 GB + 0.5 MB at N = 2048, M = K = 64.
 #include "common.hpp"
 
+// A (16.8 MB per graph at N = 2048, re-streamed every Lanczos step) never survives in a cache
+// until its next use: non-temporal loads leave L2 / Infinity Cache to the fp64 Krylov basis.
+__device__ __forceinline__ float4 lnz_stream_f4(const float* p) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 namespace {
 
 constexpr int TPB = 512;
@@ -91,15 +99,91 @@ __device__ inline double block_sum(LargeSmem& sm, double part, int tid) {
   return t;
 }
 
+// ---- symmetric SpMV (SYM): only the 256 x 256 chunk blocks (I, J >= I) of A are streamed -------
+// An off-diagonal block serves both  w_I += A_IJ q_J  (row dots)  and  w_J += A_IJ^T q_I  (column
+// sums, accumulated in the registers of the lane that owns the column), a diagonal block its row
+// dots over the full chunk: 36 of 64 blocks = 56 % of the bytes at N = 2048.  A block (or a
+// 64-row quarter of a diagonal block) is one job of one wave; the job lists are dealt once so that
+// every wave streams the same number of bytes.  Every (contribution slot s, chunk I) pair is
+// written by exactly one job — slot s > I: row dots of block (I, s); s == I: the diagonal block;
+// s < I: column sums of block (s, I) — into part[s][.] (HBM workspace, L2 resident), and w is
+// their sum in slot order: deterministic, no atomics.
+struct SymJob {
+  short I, J, row0, nrow;  // rows [row0, row0 + nrow) of chunk block (I, J); J == I: row dots only
+};
+constexpr int SYM_MAXJOBS = 16;
+constexpr int SYM_RG = 16;  // rows per group: one float4 per lane and row in flight
+
+struct SymSched {
+  SymJob jobs[NWAVE][SYM_MAXJOBS];
+  int njobs[NWAVE];
+};
+
+__device__ inline void sym_deal(SymSched& sc, int N) {  // one thread
+  const int nch = (N + 255) >> 8;
+  int load[NWAVE];
+  for (int w = 0; w < NWAVE; ++w) {
+    load[w] = 0;
+    sc.njobs[w] = 0;
+  }
+  auto give = [&](int I, int J, int row0, int nrow, int cost) {
+    int best = 0;
+    for (int w = 1; w < NWAVE; ++w)
+      if (load[w] < load[best]) best = w;
+    SymJob jb;
+    jb.I = (short)I; jb.J = (short)J; jb.row0 = (short)row0; jb.nrow = (short)nrow;
+    sc.jobs[best][sc.njobs[best]++] = jb;
+    load[best] += cost;
+  };
+  for (int I = 0; I < nch; ++I)
+    for (int J = I + 1; J < nch; ++J) give(I, J, 256 * I, min(256, N - 256 * I), 4);
+  for (int I = 0; I < nch; ++I)
+    for (int q = 0; q < 4; ++q) {
+      const int r0 = 256 * I + 64 * q;
+      if (r0 < N) give(I, I, r0, min(64, N - r0), 1);
+    }
+}
+
+// 16 per-lane partial sums -> the 16 wave totals: after the two half / row swaps each lane of
+// 16-lane row rho holds the partials of rows 4 rho .. 4 rho + 3, reduced over its row by DPP.
+// Returns v[k] = total of row 4 * (lane >> 4) + k (all 16 lanes of the row).
+__device__ inline void reduce16_f64(const double (&p)[16], double (&v)[4]) {
+  double h8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // lanes l, l ^ 32: lower half keeps rows 0..7, upper rows 8..15
+    unsigned xl = (unsigned)__double2loint(p[i]), xh = (unsigned)__double2hiint(p[i]);
+    unsigned yl = (unsigned)__double2loint(p[i + 8]), yh = (unsigned)__double2hiint(p[i + 8]);
+    auto rl = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+    auto rh = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+    h8[i] = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // 16-lane rows 2a, 2a + 1: even rows keep i, odd rows i + 4
+    unsigned xl = (unsigned)__double2loint(h8[i]), xh = (unsigned)__double2hiint(h8[i]);
+    unsigned yl = (unsigned)__double2loint(h8[i + 4]), yh = (unsigned)__double2hiint(h8[i + 4]);
+    auto rl = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+    double t = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    t = dpp_xadd_f64(t, 0);
+    t = dpp_xadd_f64(t, 1);
+    t = dpp_xadd_f64(t, 2);
+    v[i] = dpp_xadd_f64(t, 3);
+  }
+}
+
+template <bool SYM>
 __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int N, int M, int K,
-    double* __restrict__ work, float* __restrict__ D, float* __restrict__ V,
-    int32_t* __restrict__ info) {
+    double* __restrict__ work, double* __restrict__ part_all, float* __restrict__ D,
+    float* __restrict__ V, int32_t* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) LargeSmem sm;
+  __shared__ SymSched sched;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const float* Ab = A + (int64_t)b * sb;
   double* Qg = work + (int64_t)b * MMAX * N;
+  double* cpart = SYM ? part_all + (int64_t)b * NCH * NCH * 256 : nullptr;  // [slot][NCH * 256]
+  if (SYM && tid == 0) sym_deal(sched, N);
 
   // start vector (same hash as the small-graph kernel)
   double part = 0.0;
@@ -131,50 +215,134 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     }
     __syncthreads();
 
+    if constexpr (SYM) {
+      // ---- SpMV, symmetric: this wave's jobs in groups of SYM_RG rows.  A ring of SYM_RG row
+      //      slots (one float4 per lane): the slot of a consumed row is refilled at once with the
+      //      same row of the NEXT group, so SYM_RG rows (16 KiB per wave) stay in flight.
+      const int nj = sched.njobs[wave];
+      const SymJob* jl = sched.jobs[wave];
+      int pj = 0, pg = 0;  // prefetch cursor: job, first row of the group inside the job
+      const float* psrc = Ab;
+      int pvalid = 0;      // rows of the prefetch group (0: nothing left)
+      bool pcol = false;   // this lane's columns of the prefetch group exist
+      auto next_prefetch = [&]() {
+        pvalid = 0;
+        if (pj < nj) {
+          const SymJob jb = jl[pj];
+          const int c0 = 256 * jb.J + 4 * lane;
+          pcol = c0 < N;
+          psrc = Ab + (int64_t)(jb.row0 + pg) * sr + c0;
+          pvalid = min(SYM_RG, jb.nrow - pg);
+          pg += SYM_RG;
+          if (pg >= jb.nrow) {
+            pg = 0;
+            ++pj;
+          }
+        }
+      };
+      float4 buf[SYM_RG];
+      auto fetch = [&](int i) {
+        buf[i] = (i < pvalid && pcol) ? lnz_stream_f4(psrc + (int64_t)i * sr)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      };
+      next_prefetch();
+#pragma unroll
+      for (int i = 0; i < SYM_RG; ++i) fetch(i);
+      double qJ[4], colacc[4];
+      for (int cj = 0; cj < nj; ++cj) {
+        const SymJob jb = jl[cj];
+        const bool offd = jb.J != jb.I;
+        {
+          const double2* qp = reinterpret_cast<const double2*>(&sm.qs[256 * jb.J + 4 * lane]);
+          const double2 x = qp[0], y = qp[1];
+          qJ[0] = x.x; qJ[1] = x.y; qJ[2] = y.x; qJ[3] = y.y;
+          colacc[0] = colacc[1] = colacc[2] = colacc[3] = 0.0;
+        }
+        for (int cg = 0; cg < jb.nrow; cg += SYM_RG) {
+          const int r0 = jb.row0 + cg;
+          next_prefetch();
+          double p[SYM_RG];
+#pragma unroll
+          for (int i = 0; i < SYM_RG; ++i) {
+            const double ax = (double)buf[i].x, ay = (double)buf[i].y, az = (double)buf[i].z,
+                         aw = (double)buf[i].w;
+            fetch(i);
+            p[i] = fma(ax, qJ[0], ay * qJ[1]) + fma(az, qJ[2], aw * qJ[3]);
+            if (offd) {
+              const double qr = sm.qs[r0 + i];  // rows past the job's end were loaded as zeros
+              colacc[0] = fma(ax, qr, colacc[0]);
+              colacc[1] = fma(ay, qr, colacc[1]);
+              colacc[2] = fma(az, qr, colacc[2]);
+              colacc[3] = fma(aw, qr, colacc[3]);
+            }
+          }
+          double v[4];
+          reduce16_f64(p, v);
+          if ((lane & 15) == 0) {
+            double* dst = cpart + (int64_t)jb.J * (NCH * 256) + r0 + 4 * (lane >> 4);
+            *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
+          }
+        }
+        if (offd) {
+          double* dst = cpart + (int64_t)jb.I * (NCH * 256) + 256 * jb.J + 4 * lane;
+          *reinterpret_cast<double2*>(dst) = make_double2(colacc[0], colacc[1]);
+          *reinterpret_cast<double2*>(dst + 2) = make_double2(colacc[2], colacc[3]);
+        }
+      }
+      __syncthreads();
+      const int nch = (N + 255) >> 8;
+      for (int r = tid; r < NCH * 256; r += TPB) {
+        double acc = 0.0;
+        if (r < N)
+          for (int sl = 0; sl < nch; ++sl) acc += cpart[(int64_t)sl * (NCH * 256) + r];
+        sm.ws[r] = acc;
+      }
+    } else {
     // ---- SpMV: w = A q; q slice in registers, A streamed once ------------------------------
-    double qreg[NCH][4];
-#pragma unroll
-    for (int s = 0; s < NCH; ++s) {
-      const double2* p = reinterpret_cast<const double2*>(&sm.qs[256 * s + 4 * lane]);
-      double2 x = p[0], y = p[1];
-      qreg[s][0] = x.x;
-      qreg[s][1] = x.y;
-      qreg[s][2] = y.x;
-      qreg[s][3] = y.y;
-    }
-    auto load_row = [&](int r, float4 (&a)[NCH]) {
-      const float* row = Ab + (int64_t)r * sr;
+      double qreg[NCH][4];
 #pragma unroll
       for (int s = 0; s < NCH; ++s) {
-        int c0 = 256 * s + 4 * lane;
-        a[s] = (c0 < N) ? *reinterpret_cast<const float4*>(row + c0)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        const double2* p = reinterpret_cast<const double2*>(&sm.qs[256 * s + 4 * lane]);
+        double2 x = p[0], y = p[1];
+        qreg[s][0] = x.x;
+        qreg[s][1] = x.y;
+        qreg[s][2] = y.x;
+        qreg[s][3] = y.y;
       }
-    };
-    auto dot_row = [&](const float4 (&a)[NCH]) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      auto load_row = [&](int r, float4 (&a)[NCH]) {
+        const float* row = Ab + (int64_t)r * sr;
 #pragma unroll
-      for (int s = 0; s < NCH; ++s) {
-        s0 = fma((double)a[s].x, qreg[s][0], s0);
-        s1 = fma((double)a[s].y, qreg[s][1], s1);
-        s2 = fma((double)a[s].z, qreg[s][2], s2);
-        s3 = fma((double)a[s].w, qreg[s][3], s3);
-      }
-      return (s0 + s1) + (s2 + s3);
-    };
-    {
-      float4 a0[NCH], a1[NCH];
-      int r = wave;
-      if (r < N) load_row(r, a0);
-      for (; r < N; r += 2 * NWAVE) {
-        const int r1 = r + NWAVE, r2 = r + 2 * NWAVE;
-        if (r1 < N) load_row(r1, a1);
-        double t0 = wave_sum_f64(dot_row(a0));
-        if (lane == 0) sm.ws[r] = t0;
-        if (r2 < N) load_row(r2, a0);
-        if (r1 < N) {
-          double t1 = wave_sum_f64(dot_row(a1));
-          if (lane == 0) sm.ws[r1] = t1;
+        for (int s = 0; s < NCH; ++s) {
+          int c0 = 256 * s + 4 * lane;
+          a[s] = (c0 < N) ? lnz_stream_f4(row + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      };
+      auto dot_row = [&](const float4 (&a)[NCH]) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NCH; ++s) {
+          s0 = fma((double)a[s].x, qreg[s][0], s0);
+          s1 = fma((double)a[s].y, qreg[s][1], s1);
+          s2 = fma((double)a[s].z, qreg[s][2], s2);
+          s3 = fma((double)a[s].w, qreg[s][3], s3);
+        }
+        return (s0 + s1) + (s2 + s3);
+      };
+      {
+        float4 a0[NCH], a1[NCH];
+        int r = wave;
+        if (r < N) load_row(r, a0);
+        for (; r < N; r += 2 * NWAVE) {
+          const int r1 = r + NWAVE, r2 = r + 2 * NWAVE;
+          if (r1 < N) load_row(r1, a1);
+          double t0 = wave_sum_f64(dot_row(a0));
+          if (lane == 0) sm.ws[r] = t0;
+          if (r2 < N) load_row(r2, a0);
+          if (r1 < N) {
+            double t1 = wave_sum_f64(dot_row(a1));
+            if (lane == 0) sm.ws[r1] = t1;
+          }
         }
       }
     }
@@ -365,23 +533,43 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
 
 }  // namespace
 
+// Krylov basis [B][MMAX][N] fp64, then the symmetric kernel's contribution slots [B][NCH][NCH*256]
 extern "C" int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N) {
-  return (int64_t)B * MMAX * N * (int64_t)sizeof(double);
+  return ((int64_t)B * MMAX * N + (int64_t)B * NCH * NCH * 256) * (int64_t)sizeof(double);
+}
+
+static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int B, int N, int M,
+                        int K, void* workspace, float* D, float* V, int32_t* info,
+                        lnz_stream_t stream, bool sym, const char* who) {
+  LNZ_REQUIRE(A && workspace && D && V && B > 0 && N > 0 && M > 0 && K > 0, LNZ_EINVAL,
+              "%s: bad arguments (B=%d N=%d M=%d K=%d)", who, B, N, M, K);
+  LNZ_REQUIRE(N <= NCH * 256 && M <= MMAX && K <= M, LNZ_ENOTSUP,
+              "%s: N=%d <= 2048, K=%d <= M=%d <= 64 required", who, N, K, M);
+  LNZ_REQUIRE(N % 4 == 0 && stride_r % 4 == 0 && stride_b % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(A) & 15) == 0,
+              LNZ_ENOTSUP, "%s: rows must be contiguous, 16-byte aligned, N %% 4 == 0", who);
+  LNZ_REQUIRE(M <= N, LNZ_EINVAL, "%s: M=%d > N=%d", who, M, N);
+  double* basis = (double*)workspace;
+  double* part = basis + (int64_t)B * MMAX * N;
+  if (sym)
+    hipLaunchKernelGGL(lanczos_ritz_large_kernel<true>, dim3(B), dim3(TPB), 0,
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
+  else
+    hipLaunchKernelGGL(lanczos_ritz_large_kernel<false>, dim3(B), dim3(TPB), 0,
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
+  return lnz::check_launch(who);
 }
 
 extern "C" int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B,
                                       int N, int M, int K, void* workspace, float* D, float* V,
                                       int32_t* info, lnz_stream_t stream) {
-  LNZ_REQUIRE(A && workspace && D && V && B > 0 && N > 0 && M > 0 && K > 0, LNZ_EINVAL,
-              "lnz_lanczos_ritz_large: bad arguments (B=%d N=%d M=%d K=%d)", B, N, M, K);
-  LNZ_REQUIRE(N <= NCH * 256 && M <= MMAX && K <= M, LNZ_ENOTSUP,
-              "lnz_lanczos_ritz_large: N=%d <= 2048, K=%d <= M=%d <= 64 required", N, K, M);
-  LNZ_REQUIRE(N % 4 == 0 && stride_r % 4 == 0 && stride_b % 4 == 0 &&
-                  (reinterpret_cast<uintptr_t>(A) & 15) == 0,
-              LNZ_ENOTSUP,
-              "lnz_lanczos_ritz_large: rows must be contiguous, 16-byte aligned, N %% 4 == 0");
-  LNZ_REQUIRE(M <= N, LNZ_EINVAL, "lnz_lanczos_ritz_large: M=%d > N=%d", M, N);
-  hipLaunchKernelGGL(lanczos_ritz_large_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, A,
-                     stride_b, stride_r, N, M, K, (double*)workspace, D, V, info);
-  return lnz::check_launch("lnz_lanczos_ritz_large");
+  return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, false,
+                      "lnz_lanczos_ritz_large");
+}
+
+extern "C" int lnz_lanczos_ritz_large_sym(const float* A, int64_t stride_b, int64_t stride_r,
+                                          int B, int N, int M, int K, void* workspace, float* D,
+                                          float* V, int32_t* info, lnz_stream_t stream) {
+  return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, true,
+                      "lnz_lanczos_ritz_large_sym");
 }

@@ -89,10 +89,11 @@ def tridiag_eigh(diag, offdiag):
   return R, Bm
 
 
-def lanczos_ritz_large(A, M, K, workspace=None, return_info=False):
+def lanczos_ritz_large(A, M, K, workspace=None, return_info=False, symmetric=False):
   """M-step Lanczos Ritz pairs for large dense graphs (N <= 2048, rows contiguous).
   A [B,N,N] float32 -> D [B,K], V [B,N,K].  `workspace`: optional reusable uint8 CUDA tensor of
-  lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes."""
+  lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes.  symmetric=True reads only the upper
+  256 x 256 chunk blocks of A (lnz_lanczos_ritz_large_sym: A must equal its transpose)."""
   _need_cuda(A, workspace)
   assert A.dim() == 3 and A.dtype == torch.float32 and A.stride(2) == 1
   B, N, _ = A.shape
@@ -104,9 +105,9 @@ def lanczos_ritz_large(A, M, K, workspace=None, return_info=False):
   V = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
   info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
   with torch.cuda.device(A.device):
-    _lib.check(lib.lnz_lanczos_ritz_large(_ptr(A), A.stride(0), A.stride(1), B, N, M, K,
-                                          _ptr(workspace), _ptr(D), _ptr(V), _ptr(info),
-                                          _stream()))
+    fn = lib.lnz_lanczos_ritz_large_sym if symmetric else lib.lnz_lanczos_ritz_large
+    _lib.check(fn(_ptr(A), A.stride(0), A.stride(1), B, N, M, K, _ptr(workspace), _ptr(D),
+                  _ptr(V), _ptr(info), _stream()))
   return (D, V, info) if return_info else (D, V)
 
 
