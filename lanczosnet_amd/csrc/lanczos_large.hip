@@ -41,6 +41,7 @@ struct LargeSmem {
     };
     double Zt[MMAX * ZLD];  // QL eigenvector accumulator, transposed: Zt[i][r] = S[r][i]
   };
+  double ub[NWAVE / 2][NCH * 256];  // partial CGS updates on their way down the wave tree
   double dd[MMAX];
   double ee[MMAX];
   double cs[MMAX];
@@ -169,6 +170,81 @@ __device__ inline void reduce16_f64(const double (&p)[16], double (&v)[4]) {
     t = dpp_xadd_f64(t, 2);
     v[i] = dpp_xadd_f64(t, 3);
   }
+}
+
+// One classical Gram-Schmidt pass of w (sm.ws) against q_0..q_j, reading the basis ONCE: the wave
+// that forms c_i = <q_i, w> keeps q_i in registers and adds c_i q_i to its own partial update u
+// (the lane's 32 columns); the eight partial updates are summed in a fixed tree through LDS
+// (4 + 2 + 1 buffers) and wave 0 subtracts.  Leaves c_i in sm.cs[i].  (Symmetric kernel only.)
+__device__ __forceinline__ void cgs_pass(LargeSmem& sm, const double* __restrict__ Qg, const int N,
+                                         const int j, const int wave, const int lane) {
+  double wreg[NCH][4], u[NCH][4];
+#pragma unroll
+  for (int s = 0; s < NCH; ++s) {
+    const double2* w = reinterpret_cast<const double2*>(&sm.ws[256 * s + 4 * lane]);
+    const double2 w0 = w[0], w1 = w[1];
+    wreg[s][0] = w0.x; wreg[s][1] = w0.y; wreg[s][2] = w1.x; wreg[s][3] = w1.y;
+    u[s][0] = u[s][1] = u[s][2] = u[s][3] = 0.0;
+  }
+  for (int i = wave; i <= j; i += NWAVE) {
+    const double* qi = Qg + (int64_t)i * N;
+    double qv[NCH][4];
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      const int c0 = 256 * s + 4 * lane;
+      double2 g0 = make_double2(0.0, 0.0), g1 = g0;
+      if (c0 < N) {
+        const double2* g = reinterpret_cast<const double2*>(qi + c0);
+        g0 = g[0];
+        g1 = g[1];
+      }
+      qv[s][0] = g0.x; qv[s][1] = g0.y; qv[s][2] = g1.x; qv[s][3] = g1.y;
+      s0 = fma(g0.x, wreg[s][0], s0);
+      s1 = fma(g0.y, wreg[s][1], s1);
+      s0 = fma(g1.x, wreg[s][2], s0);
+      s1 = fma(g1.y, wreg[s][3], s1);
+    }
+    const double c = wave_sum_f64(s0 + s1);
+    if (lane == 0) sm.cs[i] = c;
+#pragma unroll
+    for (int s = 0; s < NCH; ++s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[s][k] = fma(c, qv[s][k], u[s][k]);
+  }
+  // tree sum of the partial updates: waves 4..7 -> 0..3, 2..3 -> 0..1, 1 -> 0
+#pragma unroll
+  for (int half = NWAVE / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      double* dst = &sm.ub[wave - half][0];
+#pragma unroll
+      for (int s = 0; s < NCH; ++s) {
+        double2* d = reinterpret_cast<double2*>(dst + 256 * s + 4 * lane);
+        d[0] = make_double2(u[s][0], u[s][1]);
+        d[1] = make_double2(u[s][2], u[s][3]);
+      }
+    }
+    __syncthreads();
+    if (wave < half) {
+      const double* src = &sm.ub[wave][0];
+#pragma unroll
+      for (int s = 0; s < NCH; ++s) {
+        const double2* d = reinterpret_cast<const double2*>(src + 256 * s + 4 * lane);
+        const double2 a = d[0], b2 = d[1];
+        u[s][0] += a.x; u[s][1] += a.y; u[s][2] += b2.x; u[s][3] += b2.y;
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      double2* w = reinterpret_cast<double2*>(&sm.ws[256 * s + 4 * lane]);
+      w[0] = make_double2(wreg[s][0] - u[s][0], wreg[s][1] - u[s][1]);
+      w[1] = make_double2(wreg[s][2] - u[s][2], wreg[s][3] - u[s][3]);
+    }
+  }
+  __syncthreads();
 }
 
 template <bool SYM>
@@ -351,38 +427,44 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     // ---- CGS2 against q_0..q_j -------------------------------------------------------------
     double coef = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
-      for (int i = wave; i <= j; i += NWAVE) {
-        const double* qi = Qg + (int64_t)i * N;
-        double s0 = 0.0, s1 = 0.0;
+      if constexpr (SYM) {
+        cgs_pass(sm, Qg, N, j, wave, lane);
+      } else {
+        // full-stream kernel (its SpMV holds q in 64 registers; the single-read pass spills
+        // there): dots "one wave per basis vector", update "thread owns rows" — two reads of Q
+        for (int i = wave; i <= j; i += NWAVE) {
+          const double* qi = Qg + (int64_t)i * N;
+          double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int s = 0; s < NCH; ++s) {
-          int c0 = 256 * s + 4 * lane;
-          if (c0 < N) {
-            const double2* g = reinterpret_cast<const double2*>(qi + c0);
-            const double2* w = reinterpret_cast<const double2*>(&sm.ws[c0]);
-            double2 g0 = g[0], g1 = g[1], w0 = w[0], w1 = w[1];
-            s0 = fma(g0.x, w0.x, s0);
-            s1 = fma(g0.y, w0.y, s1);
-            s0 = fma(g1.x, w1.x, s0);
-            s1 = fma(g1.y, w1.y, s1);
+          for (int s = 0; s < NCH; ++s) {
+            int c0 = 256 * s + 4 * lane;
+            if (c0 < N) {
+              const double2* g = reinterpret_cast<const double2*>(qi + c0);
+              const double2* w = reinterpret_cast<const double2*>(&sm.ws[c0]);
+              double2 g0 = g[0], g1 = g[1], w0 = w[0], w1 = w[1];
+              s0 = fma(g0.x, w0.x, s0);
+              s1 = fma(g0.y, w0.y, s1);
+              s0 = fma(g1.x, w1.x, s0);
+              s1 = fma(g1.y, w1.y, s1);
+            }
           }
+          double c = wave_sum_f64(s0 + s1);
+          if (lane == 0) sm.cs[i] = c;
         }
-        double c = wave_sum_f64(s0 + s1);
-        if (lane == 0) sm.cs[i] = c;
-      }
-      __syncthreads();
-      for (int r = tid; r < N; r += TPB) {
-        double acc0 = 0.0, acc1 = 0.0;
-        int i = 0;
-        for (; i + 1 <= j; i += 2) {
-          acc0 = fma(sm.cs[i], Qg[(int64_t)i * N + r], acc0);
-          acc1 = fma(sm.cs[i + 1], Qg[(int64_t)(i + 1) * N + r], acc1);
+        __syncthreads();
+        for (int r = tid; r < N; r += TPB) {
+          double acc0 = 0.0, acc1 = 0.0;
+          int i = 0;
+          for (; i + 1 <= j; i += 2) {
+            acc0 = fma(sm.cs[i], Qg[(int64_t)i * N + r], acc0);
+            acc1 = fma(sm.cs[i + 1], Qg[(int64_t)(i + 1) * N + r], acc1);
+          }
+          if (i <= j) acc0 = fma(sm.cs[i], Qg[(int64_t)i * N + r], acc0);
+          sm.ws[r] -= (acc0 + acc1);
         }
-        if (i <= j) acc0 = fma(sm.cs[i], Qg[(int64_t)i * N + r], acc0);
-        sm.ws[r] -= (acc0 + acc1);
+        __syncthreads();
       }
       coef += sm.cs[j];
-      __syncthreads();
     }
     if (tid == 0) sm.dd[j] = coef;
     part = 0.0;
