@@ -163,6 +163,40 @@ def test_ada_t_powers_and_symmetrize():
   np.testing.assert_allclose(got, ref, rtol=0, atol=1e-7)
 
 
+def test_ada_folded_filter_mlp_equals_plain_evaluation():
+  """`_ada_dense_filters` evaluates the filter MLPs on the non-redundant inputs (i <= j inside the
+  band of T^p) and outputs (i <= j) with folded first / last weights: same filters as the plain
+  Sequential + symmetrisation (model/ada_lanczos_net.py:271-278) to fp32 rounding."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import AdaLanczosNet
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  g = load_golden('ada_lanczos.npz')
+  cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3],
+             long_diffusion_dist=[5, 7, 10, 20, 30], hidden_dim=[128, 128], num_layer=2)
+  torch.manual_seed(3)
+  net = AdaLanczosNet(make_model_config(cfg, name='AdaLanczosNet')).eval().to(DEV)
+  with torch.no_grad():
+    plan = net._plan()
+    fp = net._ada_filter_plan(plan)
+    assert fp is not None and fp['n_in'] == 822 and fp['n_out'] == 1050
+    T = _t(g['T'])
+    tcat = ops.ada_t_powers(T, cfg['long_diffusion_dist']).view(T.shape[0], -1)
+    got = net._ada_dense_filters(plan, tcat)
+    ref = torch.stack([ops.ada_symmetrize_filters(seq(tcat), 20, 5) for seq in net.spectral_filter])
+    # the same in float64 (what both approximate)
+    t64 = tcat.double()
+    ex = []
+    for seq in net.spectral_filter:
+      DD = seq.double()(t64).view(-1, 20, 20, 5)
+      ex.append((0.5 * (DD + DD.transpose(1, 2))).permute(0, 3, 1, 2))
+      seq.float()
+    ex = torch.stack(ex)
+  scale = ex.abs().max()
+  assert (got.double() - ex).abs().max() < 2e-6 * scale
+  assert (ref.double() - ex).abs().max() < 2e-6 * scale
+  assert torch.equal(got, got.transpose(3, 4))          # exactly symmetric by construction
+
+
 def _ada_model(cfg, P):
   from lanczosnet_amd.model import AdaLanczosNet
   from lanczosnet_amd.utils.arg_helper import make_model_config
