@@ -124,7 +124,8 @@ int lnz_tridiag_eigh(const double* diag, const double* offdiag, int B, int M, do
                      double* Bm, lnz_stream_t stream);
 
 /* ---- R2 + R6, large graphs (BASELINE config 5: N = 2048, K = 64) -------------------------------
- * M-step Lanczos (full re-orthogonalisation, CGS2; stops early if the Krylov space becomes
+ * M-step Lanczos (full re-orthogonalisation: classical Gram-Schmidt against every previous vector,
+ * a second pass when the first cancelled |w| below 1e-3; stops early if the Krylov space becomes
  * invariant) -> QL on the M x M tridiagonal -> Ritz vectors V = Q S, top-K by |theta|, zero
  * padded.  The dense A (rows contiguous, 16-byte aligned, row stride stride_r, N %% 4 == 0,
  * N <= 2048) is re-streamed from HBM every step: this is the HBM-bound regime of the path.

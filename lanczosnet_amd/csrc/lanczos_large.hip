@@ -9,7 +9,8 @@
 //   * wave v owns rows v, v+8, ...: 8 x global_load_dwordx4 per row (one fully coalesced 8 KiB
 //     row), two rows software-pipelined, fp64 FMAs, one DPP wave reduction per row.
 // The Krylov basis (M x N fp64 = 1 MB per graph) lives in a caller-provided HBM workspace: the
-// CGS2 dot products are "one wave per basis vector", the update is "thread owns rows".
+// Gram-Schmidt dot products are "one wave per basis vector", the update is "thread owns rows"
+// (full stream) / one read of the basis per pass (symmetric kernel).
 //
 // Algorithmic bytes per graph: M * 4 N^2 (A) + basis traffic ~ 4 * 8 N * M(M+1)/2
 // + 4 N K (V) : 1.074 GB + 0.133 GB + 0.5 MB at N = 2048, M = K = 64.
@@ -31,6 +32,7 @@ constexpr int NCH = 8;          // 256-column chunks -> N <= 2048
 constexpr int MMAX = 64;        // Lanczos steps
 constexpr int ZLD = MMAX;      // QL accumulator rows (aliases the q/w vectors, dead by then)
 constexpr double kTol = 1e-8;
+constexpr double kReorth = 1e-6;  // second Gram-Schmidt pass when |w1|^2 < kReorth |w0|^2
 constexpr double kEpsD = 2.220446049250313e-16;
 
 struct LargeSmem {
@@ -424,9 +426,22 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     }
     __syncthreads();
 
-    // ---- CGS2 against q_0..q_j -------------------------------------------------------------
+    // ---- Gram-Schmidt against q_0..q_j: one classical pass; a second one only when the first
+    //      cancelled more than kReorth of w's norm (the projection's rounding error relative to
+    //      what is left is eps * |w0| / |w1|: below 1e-3 that is still < 3e-13, far inside the
+    //      fp32 outputs; near an invariant subspace |w1| collapses and the second pass runs).
+    //      oracle/lanczos_kstep.py states the same rule.
     double coef = 0.0;
+    part = 0.0;
+    for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
+    const double nrm2_before = block_sum(sm, part, tid);
     for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {
+        part = 0.0;
+        for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
+        nrm2 = block_sum(sm, part, tid);
+        if (nrm2 >= kReorth * nrm2_before) break;
+      }
       if constexpr (SYM) {
         cgs_pass(sm, Qg, N, j, wave, lane);
       } else {
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     if (tid == 0) sm.dd[j] = coef;
     part = 0.0;
     for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
-    nrm2 = block_sum(sm, part, tid);
+    nrm2 = block_sum(sm, part, tid);  // (after a skipped second pass: the same sum again)
     steps = j + 1;
   }
   __syncthreads();

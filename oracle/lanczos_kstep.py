@@ -6,7 +6,7 @@ here).  The HIP kernel `lnz_lanczos_ritz_large` is a plain M-step Lanczos with f
 re-orthogonalisation (no implicit restarts) — a different function from ARPACK for unconverged
 pairs (SURVEY.md F8, §8d "Config 5").  Its parity is therefore pinned two ways:
   * `lanczos_kstep_fp64` below: fp64 restatement of the SAME M-step algorithm (same start vector,
-    CGS2, early stop on breakdown) — Ritz values / Ritz-vector subspace compared directly;
+    classical Gram-Schmidt with a second pass on cancellation, early stop on breakdown) — Ritz values / Ritz-vector subspace compared directly;
   * `eigsh` (the reference's call): the converged leading Ritz pairs must agree with it, and every
     Ritz pair must satisfy the Lanczos residual bound |A v - theta v| = beta_M |e_M^T s|.
 """
@@ -19,7 +19,7 @@ def start_vector(n):
   return 1.0 + ((h >> np.uint64(8)) & np.uint64(0xffff)).astype(np.float64) / 65536.0
 
 
-def lanczos_kstep_fp64(A, M, K, tol=1e-8):
+def lanczos_kstep_fp64(A, M, K, tol=1e-8, reorth=1e-6):
   """A [n,n] symmetric (float32 values, promoted), M Lanczos steps, top-K Ritz pairs by |theta|.
   Returns D [K], V [n,K], (alpha, beta, steps_done)."""
   A = np.asarray(A, dtype=np.float32).astype(np.float64)
@@ -40,7 +40,13 @@ def lanczos_kstep_fp64(A, M, K, tol=1e-8):
     Q[j] = q
     w = A @ q
     coef = 0.0
-    for _ in range(2):
+    n0 = w @ w
+    for p in range(2):
+      # second classical Gram-Schmidt pass only when the first cancelled more than 1 - 1e-3 of
+      # |w| (the kernel's kReorth rule: the rounding error of one projection relative to what is
+      # left is eps |w0| / |w1|)
+      if p == 1 and w @ w >= reorth * n0:
+        break
       c = Q[:j + 1] @ w
       w = w - Q[:j + 1].T @ c
       coef += c[j]
