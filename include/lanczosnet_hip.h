@@ -389,6 +389,15 @@ int lnz_ada_t_powers(const float* T, int B, int K, const int32_t* dist_host, int
 int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, float* DDp,
                                lnz_stream_t stream);
 
+/* Opt-in split-precision operand of the filter MLPs' GEMMs (model/ada_lanczos_net.py:271-272):
+ * v = [relu](alpha * X[m][k] + bias[k]), X [M, K] fp32 (leading dimension ldx) ->
+ * out [M, 3 Kp] fp16 = [ hi | hi | lo ], hi = fp16(v), lo = fp16(v - hi), columns >= K zero.
+ * Against weights laid out [ w_hi | w_lo | w_hi ] ONE fp16 GEMM of depth 3 Kp (fp32 accumulate)
+ * gives hi w_hi + hi w_lo + lo w_hi = v w to ~2^-22 relative. */
+int lnz_split_f16x3(const float* X, int M, int K, int ldx, const float* bias, float alpha, int relu,
+                    int Kp, void* out, lnz_stream_t stream);
+
+
 /* ---- next row (SURVEY.md 8f rank 1 + 3): device-side collate from a packed molecule shard ----
  * Replaces the per-molecule pickles of dataset/get_qm8_data.py:56-96 (dense float64 Laplacians +
  * offline eigendecomposition), their loading (dataset/qm8.py:41-47) and the Python pad/concat of

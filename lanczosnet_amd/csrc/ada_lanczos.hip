@@ -327,6 +327,41 @@ __global__ void ada_symmetrize_kernel(const float* __restrict__ DD, int64_t tota
   DDp[idx] = (x + y) * 0.5f;
 }
 
+
+// ---- split-precision operand of the filter MLP's library GEMMs (opt-in, R8) ---------------------
+// v = [relu](alpha * X[m][k] + bias[k])  ->  out[m] = [ hi | hi | lo ] (3 Kp halfs),
+// hi = fp16(v), lo = fp16(v - hi): against weights stored as [ w_hi | w_lo | w_hi ] one fp16 GEMM
+// of depth 3 Kp accumulates  hi w_hi + hi w_lo + lo w_hi  in fp32 — v w to ~2^-22 relative.
+__global__ void split_f16x3_kernel(const float* __restrict__ X, int M, int K, int ldx,
+                                   const float* __restrict__ bias, float alpha, int relu, int Kp,
+                                   _Float16* __restrict__ out) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 columns
+  const int m = blockIdx.y;
+  if (4 * c4 >= Kp) return;
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = 4 * c4 + u;
+    float x = 0.0f;
+    if (k < K) {
+      x = X[(int64_t)m * ldx + k] * alpha + (bias ? bias[k] : 0.0f);
+      if (relu) x = fmaxf(x, 0.0f);
+    }
+    v[u] = x;
+  }
+  h4 hi, lo;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    hi[u] = (_Float16)v[u];
+    lo[u] = (_Float16)(v[u] - (float)hi[u]);
+  }
+  _Float16* o = out + (int64_t)m * 3 * Kp + 4 * c4;
+  *reinterpret_cast<h4*>(o) = hi;
+  *reinterpret_cast<h4*>(o + Kp) = hi;
+  *reinterpret_cast<h4*>(o + 2 * Kp) = lo;
+}
+
 }  // namespace
 
 extern "C" int lnz_ada_graph_laplacian(const int64_t* node_feat, const float* embedding,
@@ -387,4 +422,15 @@ extern "C" int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, 
   hipLaunchKernelGGL(ada_symmetrize_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, DD, total, K, S, DDp);
   return lnz::check_launch("lnz_ada_symmetrize_filters");
+}
+
+extern "C" int lnz_split_f16x3(const float* X, int M, int K, int ldx, const float* bias, float alpha,
+                               int relu, int Kp, void* out, lnz_stream_t stream) {
+  LNZ_REQUIRE(X && out && M > 0 && K > 0 && ldx >= K && Kp >= K && Kp % 4 == 0, LNZ_EINVAL,
+              "lnz_split_f16x3: bad arguments (M=%d K=%d ldx=%d Kp=%d)", M, K, ldx, Kp);
+  LNZ_REQUIRE(M <= 65535, LNZ_ENOTSUP, "lnz_split_f16x3: M=%d > 65535", M);
+  dim3 grid((Kp / 4 + 255) / 256, M);
+  hipLaunchKernelGGL(split_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, ldx,
+                     bias, alpha, relu, Kp, (_Float16*)out);
+  return lnz::check_launch("lnz_split_f16x3");
 }

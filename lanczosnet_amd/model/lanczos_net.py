@@ -810,6 +810,10 @@ class AdaLanczosNet(_LanczosNetBase):
     config (:35-38)."""
     filter_kind = 1
     _spectral_hidden = 4096
+    # 'fp32': the filter MLPs' GEMMs in fp32 (hipBLASLt);  'f16x3' (opt-in): each operand split
+    # into two fp16 pieces, hi w_hi + hi w_lo + lo w_hi as ONE fp16 GEMM of three times the depth
+    # with fp32 accumulation (needs |activations| < 6.5e4; parity-tested at the same 1e-5 bar)
+    filter_gemm_mode = os.environ.get('LANCZOSNET_ADA_FILTER_GEMM', 'fp32')
 
     def _spectral_io(self):
         return self.num_eig_vec * self.num_eig_vec * self.num_scale_long
@@ -860,7 +864,8 @@ class AdaLanczosNet(_LanczosNetBase):
         unfolded evaluation by fp32 rounding of the folded weights (and by the last-bit asymmetry
         of an fp32 T^p).  Returns None (plain evaluation) unless every filter is the reference's
         4-Linear Sequential."""
-        if 'ada_filters' in plan:
+        if 'ada_filters' in plan and (plan['ada_filters'] is None or
+                                      plan['ada_filters']['mode'] == self.filter_gemm_mode):
             return plan['ada_filters']
         K, S = self.num_eig_vec, self.num_scale_long
         ok = all(len(seq) == 7 and all(isinstance(seq[i], nn.Linear) for i in (0, 2, 4, 6)) and
@@ -903,7 +908,15 @@ class AdaLanczosNet(_LanczosNetBase):
                 b4.append(torch.nn.functional.pad(0.5 * (bb[r_ij.reshape(-1)] + bb[r_ji.reshape(-1)]),
                                                   (0, out_pad)).contiguous())
             fp = dict(in_idx=a_cols, in_pad=in_pad, out_idx=out_idx, W1=W1, W4=W4, b4=b4,
-                      n_in=n_in, n_out=n_out)
+                      n_in=n_in, n_out=n_out, mode=self.filter_gemm_mode)
+            if self.filter_gemm_mode == 'f16x3':
+                fp['W16'] = [[ops.split_weight_f16x3(W1[t]),
+                              ops.split_weight_f16x3(seq[2].weight),
+                              ops.split_weight_f16x3(seq[4].weight),
+                              ops.split_weight_f16x3(W4[t])]
+                             for t, seq in enumerate(self.spectral_filter)]
+            elif self.filter_gemm_mode != 'fp32':
+                raise ValueError("filter_gemm_mode must be 'fp32' or 'f16x3'")
         plan['ada_filters'] = fp
         return fp
 
@@ -923,6 +936,18 @@ class AdaLanczosNet(_LanczosNetBase):
         x = tcat.index_select(1, fp['in_idx'])
         if fp['in_pad']:
             x = torch.nn.functional.pad(x, (0, fp['in_pad']))
+        if fp['mode'] == 'f16x3':
+            inv = 1.0 / 1024.0   # the weights' power-of-two scale (ops.split_weight_f16x3)
+            x3 = ops.split_f16x3(x)
+            for t, seq in enumerate(self.spectral_filter):
+                w = fp['W16'][t]
+                h = torch.mm(x3, w[0].t(), out_dtype=torch.float32)
+                for i, li in ((1, 0), (2, 2), (3, 4)):
+                    h3 = ops.split_f16x3(h, bias=seq[li].bias, alpha=inv, relu=True)
+                    h = torch.mm(h3, w[i].t(), out_dtype=torch.float32)
+                o = torch.addcmul(fp['b4'][t], h, h.new_full((), inv))
+                torch.index_select(o, 1, fp['out_idx'], out=DDp[t].view(B, S * K * K))
+            return DDp
         for t, seq in enumerate(self.spectral_filter):
             h = torch.relu_(lin(x, fp['W1'][t], seq[0].bias))
             h = torch.relu_(lin(h, seq[2].weight, seq[2].bias))

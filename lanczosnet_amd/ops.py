@@ -771,6 +771,39 @@ def ada_symmetrize_filters(DD, K, S, out=None):
   return out
 
 
+def split_f16x3(X, bias=None, alpha=1.0, relu=False, Kp=None, out=None):
+  """[relu](alpha * X + bias), X [M, K] fp32 -> [M, 3 Kp] fp16 = [hi | hi | lo] (lnz_split_f16x3):
+  the activation operand of a split-precision fp16 GEMM against weights [w_hi | w_lo | w_hi]."""
+  _need_cuda(X, bias)
+  assert X.dim() == 2 and X.dtype == torch.float32 and X.stride(1) == 1
+  M, K = X.shape
+  Kp = Kp or (K + 3) // 4 * 4
+  if out is None:
+    out = torch.empty((M, 3 * Kp), dtype=torch.float16, device=X.device)
+  b = None if bias is None else _f32c(bias)
+  lib = _lib.load()
+  with torch.cuda.device(X.device):
+    _lib.check(lib.lnz_split_f16x3(_ptr(X), M, K, X.stride(0), _ptr(b), float(alpha), int(relu), Kp,
+                                   _ptr(out), _stream()))
+  return out
+
+
+def split_weight_f16x3(W, scale=1024.0, Kp=None):
+  """W [N, K] fp32 -> [N, 3 Kp] fp16 = [w_hi | w_lo | w_hi] of scale * W (a power-of-two scale
+  keeps the low pieces of Xavier-sized weights out of fp16's subnormal range; undo it with
+  alpha = 1 / scale in the next split_f16x3)."""
+  W = W.detach().float() * scale
+  N, K = W.shape
+  Kp = Kp or (K + 3) // 4 * 4
+  hi = W.half()
+  lo = (W - hi.float()).half()
+  out = torch.zeros((N, 3 * Kp), dtype=torch.float16, device=W.device)
+  out[:, :K] = hi
+  out[:, Kp:Kp + K] = lo
+  out[:, 2 * Kp:2 * Kp + K] = hi
+  return out
+
+
 # ----------------------------------------------------------------------------------------- R12
 def unsorted_segment_sum_forward(data, segment_ids, num_segments):
   _need_cuda(data, segment_ids)

@@ -195,6 +195,33 @@ def test_ada_folded_filter_mlp_equals_plain_evaluation():
   assert (got.double() - ex).abs().max() < 2e-6 * scale
   assert (ref.double() - ex).abs().max() < 2e-6 * scale
   assert torch.equal(got, got.transpose(3, 4))          # exactly symmetric by construction
+  # opt-in split-precision GEMMs (two fp16 pieces per operand, fp32 accumulation): same bar
+  net.filter_gemm_mode = 'f16x3'
+  with torch.no_grad():
+    got16 = net._ada_dense_filters(plan, tcat)
+  assert net._ada_filter_plan(plan)['mode'] == 'f16x3'
+  assert (got16.double() - ex).abs().max() < 2e-6 * scale
+  assert torch.equal(got16, got16.transpose(3, 4))
+
+
+def test_split_f16x3_operand():
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(0)
+  X = _t((rs.randn(37, 50) * 3).astype(np.float32))
+  b = _t(rs.randn(50).astype(np.float32))
+  out = ops.split_f16x3(X, bias=b, alpha=0.5, relu=True, Kp=52)
+  v = torch.relu(X * 0.5 + b)
+  hi = v.half()
+  lo = (v - hi.float()).half()
+  assert out.shape == (37, 156)
+  assert torch.equal(out[:, :50], hi) and torch.equal(out[:, 52:102], hi)
+  assert torch.equal(out[:, 104:154], lo)
+  assert (out[:, 50:52] == 0).all() and (out[:, 102:104] == 0).all() and (out[:, 154:] == 0).all()
+  W = _t((rs.randn(20, 50) * 0.02).astype(np.float32))
+  w3 = ops.split_weight_f16x3(W, Kp=52)
+  y = torch.mm(out, w3.t(), out_dtype=torch.float32) / 1024.0
+  ref = v.double() @ W.double().t()
+  assert (y.double() - ref).abs().max() < 2e-6 * ref.abs().max()
 
 
 def _ada_model(cfg, P):
@@ -260,13 +287,15 @@ def _e2e_inputs(g):
   return b['node_feat'][:nb], L[:nb], b['node_mask'][:nb], b['label'][:nb]
 
 
-def test_ada_lanczos_net_end_to_end_parity_protocol():
+@pytest.mark.parametrize('filter_gemm', ['fp32', 'f16x3'])
+def test_ada_lanczos_net_end_to_end_parity_protocol(filter_gemm):
   """Full AdaLanczosNet (2 layers, 4096-wide filter MLPs) on 96 molecules against the unmodified
-  reference class: scores under the same protocol as the Lanczos layer."""
+  reference class: scores under the same protocol as the Lanczos layer (both filter GEMM modes)."""
   g = load_golden('ada_e2e.npz')
   cfg = ast.literal_eval(str(g['cfg_json']))
   P = oracle.make_ada_params(cfg, int(g['param_seed']))
   net = _ada_model(cfg, P)
+  net.filter_gemm_mode = filter_gemm
   nf, L, mask, _ = _e2e_inputs(g)
   with _fixed_randn(g['q1']), torch.no_grad():
     score = net(_t(nf), _t(L), mask=_t(mask)).cpu().numpy()
