@@ -77,6 +77,11 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
  * planes = 1: bf16 operands (8-bit mantissa: ~1e-2 after 7 layers).  planes = 3: every fp32
  * operand travels as three bf16 pieces and every product as its six piece products of order
  * <= 2, fp32 accumulate: fp32-grade results from the same kernels (the parity mode).
+ * planes = 2: two fp16 pieces per operand and the three products hi hi + hi lo + lo hi (~2^-22;
+ * 2/3 of the bytes and half the matrix work of planes = 3).  In this mode the A operands carry a
+ * factor 2^10 (lnz_large_pack_operators applies it to L and V; the caller applies it to the
+ * weight pieces of Wf) which lnz_large_gemm1 / lnz_large_conv divide out; B operands (X, Zt, Tt)
+ * are plain fp16 pieces: |activations| must stay below 65504.
  *   Nk = lnz_large_nk(N) = N rounded up to 64 (the k extent of the packed operands).
  *   lnz_large_pack_operators  once per batch.  L [B,N,N,C] fp32 addressed by element strides
  *                             (channels-last collate layout, dataset/graph_data.py collate) ->

@@ -42,6 +42,8 @@
 // fp32 operand is split into three bf16 pieces x = x0 + x1 + x2 (24 mantissa bits) and every
 // product is the six piece products of order <= 2, accumulated in fp32: fp32-grade results
 // (1e-6) from the same kernels at 6x the matrix work and 3x the operand bytes — the parity mode.
+// P = 2: the cheaper parity mode — two fp16 pieces per operand (22 mantissa bits), three piece
+// products, 2x the operand bytes (see ElemTraits).
 #include "common.hpp"
 
 #include <type_traits>
@@ -71,15 +73,53 @@ __device__ inline float bf16_float(__bf16 b) {
 }
 __device__ inline u16 bits(__bf16 b) { return __builtin_bit_cast(u16, b); }
 
-// x -> pieces p[0..P-1] with x ~= sum p[i] (each piece the bf16 rounding of the remainder)
+// ---- element type by plane count: P = 1, 3 -> bf16 pieces; P = 2 -> fp16 pieces -----------------
+// P = 2 is the cheaper parity mode: x = hi + lo in fp16 (22 mantissa bits), products hi hi + hi lo
+// + lo hi, 2/3 of the operand bytes and half the matrix work of P = 3.  fp16 has 5 exponent bits:
+// the A operands (Laplacian entries, Ritz vectors, mix weights — all <= 1 in magnitude and often
+// ~1e-2) are scaled by 2^10 before the split so that their low pieces stay out of the subnormal
+// range, and the consumer multiplies its accumulator by 2^-10 (exact); B operands (activations)
+// are split as they are.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int P>
-__device__ inline void split_bf16(float x, __bf16* p) {
+struct ElemTraits {
+  static constexpr bool kHalf = P == 2;
+  static constexpr float kAScale = P == 2 ? 1024.0f : 1.0f;   // applied to A operands
+  static constexpr float kAInv = P == 2 ? 1.0f / 1024.0f : 1.0f;
+};
+template <int P>
+__device__ inline u16 to_piece(float x) {
+  if (ElemTraits<P>::kHalf) return __builtin_bit_cast(u16, (_Float16)x);
+  return bits(to_bf16(x));
+}
+template <int P>
+__device__ inline float piece_float(u16 b) {
+  if (ElemTraits<P>::kHalf) return (float)__builtin_bit_cast(_Float16, b);
+  return __uint_as_float((unsigned)b << 16);
+}
+// x -> pieces p[0..P-1] with x ~= sum p[i] (each piece the rounding of the remainder)
+template <int P>
+__device__ inline void split_pieces(float x, u16* p) {
   float r = x;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
-    p[i] = to_bf16(r);
-    r -= bf16_float(p[i]);
+    p[i] = to_piece<P>(r);
+    r -= piece_float<P>(p[i]);
   }
+}
+template <int P>
+__device__ inline f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if (ElemTraits<P>::kHalf)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int P>
+__device__ inline f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  if (ElemTraits<P>::kHalf)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -136,10 +176,10 @@ __global__ __launch_bounds__(256) void large_pack_kernel(
           bf16x8 out[P];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            __bf16 p[P];
-            split_bf16<P>(x[cc][u], p);
+            u16 p[P];
+            split_pieces<P>(x[cc][u] * ElemTraits<P>::kAScale, p);
 #pragma unroll
-            for (int i = 0; i < P; ++i) out[i][u] = p[i];
+            for (int i = 0; i < P; ++i) out[i][u] = __builtin_bit_cast(__bf16, p[i]);
           }
           const int64_t o = ((((int64_t)b * C + c) * RT + rg) * nkb + kb) * 2048 + (int64_t)slot * 8;
 #pragma unroll
@@ -156,10 +196,10 @@ __global__ __launch_bounds__(256) void large_pack_kernel(
     for (int u = 0; u < 8; ++u) {
       const int k = 8 * j + u;
       const float x = (rv && k < K) ? V[((int64_t)b * N + r) * K + k] : 0.0f;
-      __bf16 p[P];
-      split_bf16<P>(x, p);
+      u16 p[P];
+      split_pieces<P>(x * ElemTraits<P>::kAScale, p);
 #pragma unroll
-      for (int i = 0; i < P; ++i) out[i][u] = p[i];
+      for (int i = 0; i < P; ++i) out[i][u] = __builtin_bit_cast(__bf16, p[i]);
     }
     const int64_t o = ((int64_t)b * RT + rg) * 2048 + (int64_t)slot * 8;
 #pragma unroll
@@ -208,10 +248,10 @@ __global__ __launch_bounds__(256) void large_gemm1_kernel(
       u16 o[P][4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        __bf16 p[P];
-        split_bf16<P>(x[u], p);
+        u16 p[P];
+        split_pieces<P>(x[u], p);
 #pragma unroll
-        for (int i = 0; i < P; ++i) o[i][u] = bits(p[i]);
+        for (int i = 0; i < P; ++i) o[i][u] = p[i];
       }
 #pragma unroll
       for (int i = 0; i < P; ++i) {
@@ -252,9 +292,15 @@ __global__ __launch_bounds__(256) void large_gemm1_kernel(
           for (int ord = P - 1; ord >= 0; --ord)
 #pragma unroll
             for (int i = 0; i <= ord; ++i)
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bf[ord - i], acc[nt], 0, 0, 0);
+              acc[nt] = mfma_32x32x16<P>(af[i][ks], bf[ord - i], acc[nt]);
         }
       }
+    }
+    if (ElemTraits<P>::kHalf) {  // the weight fragments carry the 2^10 scale of the A operands
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] *= ElemTraits<P>::kAInv;
     }
     // ---- output, plane by plane through LDS: Zs[o][n] <- piece p of the tile, then 256 B runs
 #pragma unroll
@@ -264,9 +310,9 @@ __global__ __launch_bounds__(256) void large_gemm1_kernel(
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const __bf16 pc = to_bf16(acc[nt][r]);
-          acc[nt][r] -= bf16_float(pc);
-          Zs[(32 * w + lnz::cd_row(r, h)) * 136 + 32 * nt + l31] = bits(pc);
+          const u16 pc = to_piece<P>(acc[nt][r]);
+          acc[nt][r] -= piece_float<P>(pc);
+          Zs[(32 * w + lnz::cd_row(r, h)) * 136 + 32 * nt + l31] = pc;
         }
       __syncthreads();
 #pragma unroll
@@ -439,10 +485,10 @@ __global__ __launch_bounds__(512) void large_spectral_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int slot = 32 * kt + lnz::cd_row(r, h);
-      __bf16 p[P];
-      split_bf16<P>(T[r], p);
+      u16 p[P];
+      split_pieces<P>(T[r], p);
 #pragma unroll
-      for (int q = 0; q < P; ++q) Tt[q * plane + ((int64_t)b * DH + o) * 64 + slot] = bits(p[q]);
+      for (int q = 0; q < P; ++q) Tt[q * plane + ((int64_t)b * DH + o) * 64 + slot] = p[q];
     }
   }
 }
@@ -518,7 +564,7 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
   // (loaded straight from HBM); B image: register ring of DEPTH slots, written to the double-
   // buffered LDS tile one block before its use.  All ring indices are compile-time constants
   // (the loop is unrolled DEPTH times).
-  constexpr int DEPTH = P == 1 ? 4 : 2;  // A ring: prefetch distance DEPTH - 1 blocks
+  constexpr int DEPTH = P == 1 ? 4 : 2;  // A ring: prefetch distance DEPTH - 1 blocks (P = 2: 4 measured, no gain)
   constexpr int DB = 2;                  // B ring: 2 register slots; distance 2 (P = 1) / 1 (P = 3)
   constexpr int BDIST = P == 1 ? 2 : 1;
   bf16x8 A[DEPTH][P][NRT][2];  // [slot][plane][row tile][k-step]
@@ -605,8 +651,7 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
           for (int ord = P - 1; ord >= 0; --ord)
 #pragma unroll
             for (int i = 0; i <= ord; ++i)
-              acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[gs % DEPTH][i][rt][ks], bf[ord - i],
-                                                                   acc[rt][nt], 0, 0, 0);
+              acc[rt][nt] = mfma_16x16x32<P>(A[gs % DEPTH][i][rt][ks], bf[ord - i], acc[rt][nt]);
       }
     if constexpr (BDIST == 1) load_b(std::integral_constant<int, (gs + 1) % 2>{});
     store_b(g + 1, std::integral_constant<int, (gs + 1) % 2>{});
@@ -647,7 +692,7 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
       for (int r = 0; r < 4; ++r) {
         const int row = r0 + 16 * rt + 4 * kq + r;
         if (row < N) {
-          float v = acc[rt][nt][r] + bv;
+          float v = acc[rt][nt][r] * ElemTraits<P>::kAInv + bv;   // (2^-10: fp16 mode's A scale)
           if (relu) v = v > 0.0f ? v : 0.0f;
           Xout[((int64_t)b * N + row) * DH + col] = v;
         }
@@ -666,11 +711,14 @@ extern "C" int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_
   LNZ_REQUIRE(L && V && Lb && Vb && B > 0 && N > 0 && C > 0 && K > 0, LNZ_EINVAL,
               "lnz_large_pack_operators: bad arguments (B=%d N=%d C=%d K=%d)", B, N, C, K);
   LNZ_REQUIRE(K <= 64, LNZ_ENOTSUP, "lnz_large_pack_operators: K=%d > 64", K);
-  LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_pack_operators: planes must be 1 or 3");
+  LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_pack_operators: planes must be 1, 2 or 3");
   const int nkb = (int)(lnz_large_nk(N) / KB);
   dim3 grid((N + 31) / 32, B);
   if (planes == 1)
     hipLaunchKernelGGL(large_pack_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
+                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
+  else if (planes == 2)
+    hipLaunchKernelGGL(large_pack_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
                        stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
   else
     hipLaunchKernelGGL(large_pack_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
@@ -682,7 +730,7 @@ extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t*
                                int C, int planes, uint16_t* Zt, lnz_stream_t stream) {
   LNZ_REQUIRE(X && Wf && Zt && B > 0 && N > 0 && C > 0 && din > 0 && ldx >= din, LNZ_EINVAL,
               "lnz_large_gemm1: bad arguments");
-  LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_gemm1: planes must be 1 or 3");
+  LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_gemm1: planes must be 1, 2 or 3");
   const int dinp = (din + 15) / 16 * 16;
   LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_gemm1: input width %d > 128", din);
   const int Nk = (int)lnz_large_nk(N);
@@ -697,10 +745,17 @@ extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t*
       (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<3>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (3 * 128 * 136 + 128 * 136) * 2);
+      (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (2 * 128 * 136 + 128 * 136) * 2);
       attr = true;
     }
-    hipLaunchKernelGGL(large_gemm1_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, din,
-                       dinp, Wf, B, N, Nk, C, Zt);
+    if (planes == 2)
+      hipLaunchKernelGGL(large_gemm1_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx,
+                         din, dinp, Wf, B, N, Nk, C, Zt);
+    else
+      hipLaunchKernelGGL(large_gemm1_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx,
+                         din, dinp, Wf, B, N, Nk, C, Zt);
   }
   return lnz::check_launch("lnz_large_gemm1");
 }
@@ -712,7 +767,7 @@ extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float*
                   ldx >= din,
               LNZ_EINVAL, "lnz_large_spectral: bad arguments");
   LNZ_REQUIRE(K <= 64, LNZ_ENOTSUP, "lnz_large_spectral: K=%d > 64", K);
-  LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_spectral: planes must be 1 or 3");
+  LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_spectral: planes must be 1, 2 or 3");
   const int dinp = (din + 15) / 16 * 16;
   LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_spectral: input width %d > 128", din);
   // row chunks: enough workgroups to fill the chip, at least 128 rows each (multiple of 16)
@@ -731,6 +786,9 @@ extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float*
   if (planes == 1)
     hipLaunchKernelGGL(large_spectral_kernel<1>, dim3(B), dim3(512), 0, (hipStream_t)stream, dinp,
                        Ybuf, G, Wt, B, K, S, Tt);
+  else if (planes == 2)
+    hipLaunchKernelGGL(large_spectral_kernel<2>, dim3(B), dim3(512), 0, (hipStream_t)stream, dinp,
+                       Ybuf, G, Wt, B, K, S, Tt);
   else
     hipLaunchKernelGGL(large_spectral_kernel<3>, dim3(B), dim3(512), 0, (hipStream_t)stream, dinp,
                        Ybuf, G, Wt, B, K, S, Tt);
@@ -742,7 +800,7 @@ extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint
                               int relu, float* Xout, lnz_stream_t stream) {
   LNZ_REQUIRE(Lb && Vb && Zt && Tt && bias && Xout && B > 0 && N > 0 && C > 0, LNZ_EINVAL,
               "lnz_large_conv: bad arguments");
-  LNZ_REQUIRE(planes == 1 || planes == 3, LNZ_EINVAL, "lnz_large_conv: planes must be 1 or 3");
+  LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_conv: planes must be 1, 2 or 3");
   const int Nk = (int)lnz_large_nk(N);
   const size_t lds = (size_t)2 * planes * DH * BP * sizeof(uint16_t);
   // 8-wave workgroups = 256-row tiles.  (LNZ_LARGE_CONV_WAVES=4: 128-row tiles, two workgroups per
@@ -753,8 +811,10 @@ extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint
     nw = (e && atoi(e) == 4) ? 4 : 8;
     (void)hipFuncSetAttribute((const void*)large_conv_kernel<3, 8>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * DH * BP * 2);
+    (void)hipFuncSetAttribute((const void*)large_conv_kernel<2, 8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * DH * BP * 2);
   }
-  const int nwp = planes == 3 ? 8 : nw;  // the 3-plane B image (96 KB) leaves room for one workgroup
+  const int nwp = planes >= 2 ? 8 : nw;  // the multi-plane B images (64 / 96 KB): one workgroup per CU
   const int tile_rows = 32 * nwp;
   const int tiles = (N + tile_rows - 1) / tile_rows;
   const int grid = 8 * tiles * ((B + 7) / 8);
@@ -763,6 +823,7 @@ extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint
                      (hipStream_t)stream, Lb, Vb, Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout)
   if (planes == 1 && nwp == 4) LNZ_LAUNCH_CONV(1, 4);
   else if (planes == 1) LNZ_LAUNCH_CONV(1, 8);
+  else if (planes == 2) LNZ_LAUNCH_CONV(2, 8);
   else LNZ_LAUNCH_CONV(3, 8);
 #undef LNZ_LAUNCH_CONV
   return lnz::check_launch("lnz_large_conv");

@@ -40,6 +40,9 @@ class _LanczosNetBase(nn.Module):
     # 'fp32' (default): exact fp32 MFMA.  'f16x3': opt-in split-precision GEMM1 (x_hi w_hi + x_hi w_lo
     # + x_lo w_hi on fp16 MFMA, fp32 accumulate; 6e-7 vs fp64, parity bar 1e-5) — see DESIGN.md §4.7
     gemm_mode = os.environ.get('LANCZOSNET_GEMM', 'fp32')
+    # graphs beyond 32 nodes, fp32-grade mode of the streamed kernels: 3 = three bf16 pieces per
+    # operand (six products), 2 = two fp16 pieces (three products, 2/3 of the operand bytes)
+    large_split_planes = int(os.environ.get('LANCZOSNET_LARGE_PLANES', '3'))
     # 'hip' = HIP backward kernels where built (LanczosNet, width 128); 'torch' = autograd through
     # the torch recomputation everywhere (the gradient oracle the HIP backward is tested against)
     backward_impl = os.environ.get('LANCZOSNET_BACKWARD', 'hip')
@@ -559,7 +562,8 @@ class _LanczosNetBase(nn.Module):
             elif L.shape[1] > 32 and self._large_hip_supported(V.shape[2]):
                 # hand-written streaming kernels; 'bf16' = config 5's bf16-operand mode
                 score = self._large_graph_forward_hip(node_feat, L, D, V, mask,
-                                                      planes=1 if self.gemm_mode == 'bf16' else 3)
+                                                      planes=1 if self.gemm_mode == 'bf16'
+                                                      else self.large_split_planes)
             else:
                 score = self._large_graph_forward(node_feat, L, D, V, mask)
         elif self._needs_grad():

@@ -112,13 +112,23 @@ def lanczos_ritz_large(A, M, K, workspace=None, return_info=False, symmetric=Fal
 
 
 # --------------------------------------------------------------- R9 / R11 for graphs beyond 32 nodes
+LARGE_F16_A_SCALE = 1024.0   # csrc/conv_large.hip ElemTraits<2>::kAScale
+
+
+def large_plane_dtype(planes):
+  """Element type of the lnz_large_* operand planes: two planes are fp16 pieces, one / three bf16."""
+  return torch.float16 if planes == 2 else torch.bfloat16
+
+
 def split_bf16_planes(x, planes):
-  """fp32 tensor -> [planes, ...] bf16 pieces with x ~= sum of the pieces (each piece the bf16
-  rounding of the remainder; planes = 1 is the plain bf16 cast)."""
-  r = x.to(torch.float32)
+  """fp32 tensor -> [planes, ...] pieces with x ~= sum of the pieces (each piece the rounding of
+  the remainder).  planes = 1: the plain bf16 cast; 3: bf16 pieces; 2: fp16 pieces of
+  LARGE_F16_A_SCALE * x (the A-operand convention of the two-plane mode, csrc/conv_large.hip)."""
+  dt = large_plane_dtype(planes)
+  r = x.to(torch.float32) * (LARGE_F16_A_SCALE if planes == 2 else 1.0)
   out = []
   for _ in range(planes):
-    p = r.to(torch.bfloat16)
+    p = r.to(dt)
     out.append(p)
     r = r - p.to(torch.float32)
   return torch.stack(out).contiguous()
@@ -136,8 +146,9 @@ def large_weight_fragments(Wb):
 
 def large_pack_operators(L, V, planes=1):
   """lnz_large_pack_operators: L [B,N,N,C] fp32 (any strides), V [B,N,K] -> Lb [planes,B,C,RT,
-  Nk/64,4,64,8] bf16 and Vb [planes,B,RT,4,64,8] bf16 in fragment-tile order (RT = ceil(N/32),
-  Nk = N rounded up to 64; see include/lanczosnet_hip.h).  Lb.dims = (N, Nk)."""
+  Nk/64,4,64,8] and Vb [planes,B,RT,4,64,8] (bf16 pieces; planes = 2: fp16 pieces of 1024 x the
+  entries) in fragment-tile order (RT = ceil(N/32), Nk = N rounded up to 64; see
+  include/lanczosnet_hip.h).  Lb.dims = (N, Nk)."""
   _need_cuda(L, V)
   assert L.dim() == 4 and L.dtype == torch.float32 and V.dim() == 3
   V = _f32c(V)
@@ -146,8 +157,9 @@ def large_pack_operators(L, V, planes=1):
   lib = _lib.load()
   Nk = lib.lnz_large_nk(N)
   RT = (N + 31) // 32
-  Lb = torch.empty((planes, B, Cn, RT, Nk // 64, 4, 64, 8), dtype=torch.bfloat16, device=L.device)
-  Vb = torch.empty((planes, B, RT, 4, 64, 8), dtype=torch.bfloat16, device=L.device)
+  dt = large_plane_dtype(planes)
+  Lb = torch.empty((planes, B, Cn, RT, Nk // 64, 4, 64, 8), dtype=dt, device=L.device)
+  Vb = torch.empty((planes, B, RT, 4, 64, 8), dtype=dt, device=L.device)
   Lb.dims = (N, Nk)
   sb, sr, sc, sch = L.stride()
   with torch.cuda.device(L.device):
@@ -226,8 +238,8 @@ def large_work_buffers(Lb):
   zero without long scales; the spectral kernels keep Ybuf zero between layers)."""
   planes, B, Cn = Lb.shape[:3]
   N, Nk = Lb.dims
-  Zt = torch.zeros((planes, B, Cn, 128, Nk), dtype=torch.bfloat16, device=Lb.device)
-  Tt = torch.zeros((planes, B, 128, 64), dtype=torch.bfloat16, device=Lb.device)
+  Zt = torch.zeros((planes, B, Cn, 128, Nk), dtype=Lb.dtype, device=Lb.device)
+  Tt = torch.zeros((planes, B, 128, 64), dtype=Lb.dtype, device=Lb.device)
   Ybuf = torch.zeros((B, 64, 128), dtype=torch.float32, device=Lb.device)
   return Zt, Tt, Ybuf
 

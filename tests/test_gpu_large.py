@@ -102,7 +102,7 @@ def _untile(x):
   return x.reshape(lead + (RT * 32, nkb * 64))              # rg, rt, r15 | kb, ks, kq, u
 
 
-@pytest.mark.parametrize('planes', [1, 3])
+@pytest.mark.parametrize('planes', [1, 2, 3])
 @pytest.mark.parametrize('B,N,C,K,din,S', [(2, 200, 2, 40, 10, 3), (3, 300, 3, 64, 128, 8),
                                            (1, 64, 1, 7, 33, 1)])
 def test_large_conv_stages_match_numpy(planes, B, N, C, K, din, S):
@@ -124,17 +124,20 @@ def test_large_conv_stages_match_numpy(planes, B, N, C, K, din, S):
   Nk = Lb.dims[1]
   RT = (N + 31) // 32
   assert Nk % 64 == 0 and Nk >= N and tuple(Lb.shape) == (planes, B, C, RT, Nk // 64, 4, 64, 8)
-  # pack: pieces sum to the input (exactly for planes = 3 up to 2^-24, bf16 rounding for 1)
-  Lsum = _untile(_pieces_sum(Lb))
+  # pack: pieces sum to the input (exactly for planes = 3 up to 2^-24, bf16 rounding for 1; the
+  # two-plane mode stores fp16 pieces of 1024 x the A operands)
+  ascale = ops.LARGE_F16_A_SCALE if planes == 2 else 1.0
+  assert Lb.dtype == (torch.float16 if planes == 2 else torch.bfloat16)
+  Lsum = _untile(_pieces_sum(Lb)) / ascale
   assert (Lsum[:, :, N:] == 0).all()
   Lsum = Lsum[:, :, :N]
   Lref = L.transpose(0, 3, 1, 2).astype(np.float64)
   if planes == 1:
     np.testing.assert_array_equal(Lsum[..., :N], _bf16_round(L).transpose(0, 3, 1, 2))
   else:
-    assert np.abs(Lsum[..., :N] - Lref).max() <= 2.0 ** -22 * np.abs(Lref).max()
+    assert np.abs(Lsum[..., :N] - Lref).max() <= 2.0 ** (-22 if planes == 3 else -20) * np.abs(Lref).max()
   assert (Lsum[..., N:] == 0).all()
-  Vsum = _untile(_pieces_sum(Vb)[:, :, None])
+  Vsum = _untile(_pieces_sum(Vb)[:, :, None]) / ascale
   assert (Vsum[..., K:] == 0).all() and (Vsum[:, N:] == 0).all()
   Vsum = Vsum[:, :N]
   # weights as the model packs them
@@ -154,7 +157,7 @@ def test_large_conv_stages_match_numpy(planes, B, N, C, K, din, S):
   X64, W64 = rnd(X), rnd(Wc)
   Z = np.einsum('bni,oci->bcon', X64[..., :din], W64[:, S:, :din])            # [B,C,128,N]
   Zt_got = _pieces_sum(Zt)
-  tol = 2e-6 if planes == 3 else 1e-5
+  tol = 2e-6 if planes == 3 else 4e-6 if planes == 2 else 1e-5
   assert (Zt_got[..., N:] == 0).all()
   Zt_ref = rnd(Z) if planes == 1 else Z
   zden = np.abs(Z).max()
@@ -202,7 +205,10 @@ def test_large_graph_general_forward_matches_oracle():
   Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(mask).to(DEV)
   D, V = ops.lanczos_ritz_large(Ld[:, :, :, 0].contiguous(), K, K)
   with torch.no_grad():
-    score = net(Xd, Ld, D, V, mask=md)                       # default: HIP kernels, 3 planes
+    net.large_split_planes = 3
+    score = net(Xd, Ld, D, V, mask=md)                       # HIP kernels, 3 bf16 planes
+    net.large_split_planes = 2
+    score2 = net(Xd, Ld, D, V, mask=md)                      # HIP kernels, 2 fp16 planes
     score_lib = net._large_graph_forward(Xd, Ld, D, V, md)   # hipBLASLt path
     net.gemm_mode = 'bf16'
     score_bf16 = net(Xd, Ld, D, V, mask=md)
@@ -214,7 +220,10 @@ def test_large_graph_general_forward_matches_oracle():
   eb = np.abs(score_bf16.cpu().numpy() - ref).max() / np.abs(ref).max()
   print('large-graph forward rel err: split-precision kernels %.2e, library path %.2e, bf16 '
         'operands %.2e' % (e, el, eb))
+  e2 = np.abs(score2.cpu().numpy() - ref).max() / np.abs(ref).max()
+  print('two fp16 planes %.2e' % e2)
   assert e < 1e-5
+  assert e2 < 1e-5
   assert el < 1e-5
   assert eb < 2e-2  # bf16 operands: 8-bit mantissa (config 5's mode, opt-in)
 
@@ -231,7 +240,10 @@ def test_large_graph_forward_config5_shape_matches_library_path():
   Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(mask).to(DEV)
   D, V = ops.lanczos_ritz_large(Ld[:, :, :, 0].contiguous(), K, K)
   with torch.no_grad():
+    net.large_split_planes = 3
     s3 = net(Xd, Ld, D, V, mask=md)
+    net.large_split_planes = 2
+    s2 = net(Xd, Ld, D, V, mask=md)
     sl = net._large_graph_forward(Xd, Ld, D, V, md)
     net.gemm_mode = 'bf16'
     s1 = net(Xd, Ld, D, V, mask=md)
@@ -240,7 +252,10 @@ def test_large_graph_forward_config5_shape_matches_library_path():
   e3 = (s3 - sl).abs().max().item() / den
   e1 = (s1 - sl).abs().max().item() / den
   print('N=2048: split-precision vs library %.2e, bf16 vs library %.2e' % (e3, e1))
+  e2 = (s2 - sl).abs().max().item() / den
+  print('two fp16 planes vs library %.2e' % e2)
   assert e3 < 1e-5
+  assert e2 < 1e-5 and torch.isfinite(s2).all()
   assert e1 < 2e-2
 
 

@@ -38,7 +38,7 @@ A0 = L[:, :, :, 0].contiguous()
 ws = torch.empty((ops._lib.load().lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 res = {}
-modes = [('hip_bf16', 1), ('hip_split3', 3)] + ([('library_fp32', None)] if args.library else [])
+modes = [('hip_bf16', 1), ('hip_split3', 3), ('hip_f16x2', 2)] + ([('library_fp32', None)] if args.library else [])
 SYM = not args.full_stream
 D, V = ops.lanczos_ritz_large(A0, K, K, workspace=ws, symmetric=SYM)
 ref = None
@@ -64,8 +64,11 @@ for name, planes in modes:
                'graphs_per_s': round(B / (sum(best) * 1e-3), 1), 'finite': bool(torch.isfinite(score).all())}
   if name == 'hip_bf16':
     s1 = score
+  if name == 'hip_f16x2':
+    s2 = score
 if ref is not None:
   res['bf16_vs_split3_rel'] = float((s1 - ref).abs().max() / ref.abs().max())
+  res['f16x2_vs_split3_rel'] = float((s2 - ref).abs().max() / ref.abs().max())
 # per-stage breakdown of the bf16 mode
 with torch.no_grad():
   plan = net._plan_large(1)
