@@ -1174,7 +1174,7 @@ extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride
   LNZ_REQUIRE(A && n_nodes && D && V && B > 0 && N > 0 && K > 0, LNZ_EINVAL,
               "lnz_lanczos_ritz: bad arguments (B=%d N=%d K=%d)", B, N, K);
   LNZ_REQUIRE(N <= 64, LNZ_ENOTSUP,
-              "lnz_lanczos_ritz: N=%d > 64 needs the streamed large-graph kernel (not built yet)",
+              "lnz_lanczos_ritz: N=%d > 64: use lnz_lanczos_ritz_large / _sym (streamed kernels)",
               N);
   hipStream_t s = (hipStream_t)stream;
   if (N <= 32) {
