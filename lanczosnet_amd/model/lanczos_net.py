@@ -958,7 +958,7 @@ class AdaLanczosNet(_LanczosNetBase):
         if fp['in_pad']:
             x = torch.nn.functional.pad(x, (0, fp['in_pad']))
         if fp['mode'] == 'f16x3':
-            inv = 1.0 / 1024.0   # the weights' power-of-two scale (ops.split_weight_f16x3)
+            inv = 1.0 / ops.F16X3_WEIGHT_SCALE   # the weights' power-of-two scale
             x3 = ops.split_f16x3(x)
             for t, seq in enumerate(self.spectral_filter):
                 w = fp['W16'][t]

@@ -800,7 +800,10 @@ def split_f16x3(X, bias=None, alpha=1.0, relu=False, Kp=None, out=None):
   return out
 
 
-def split_weight_f16x3(W, scale=1024.0, Kp=None):
+F16X3_WEIGHT_SCALE = 1024.0
+
+
+def split_weight_f16x3(W, scale=F16X3_WEIGHT_SCALE, Kp=None):
   """W [N, K] fp32 -> [N, 3 Kp] fp16 = [w_hi | w_lo | w_hi] of scale * W (a power-of-two scale
   keeps the low pieces of Xavier-sized weights out of fp16's subnormal range; undo it with
   alpha = 1 / scale in the next split_f16x3)."""
