@@ -16,15 +16,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_two_ranks_one_json_line():
-  s = socket.socket()
-  s.bind(('127.0.0.1', 0))
-  port = s.getsockname()[1]
-  s.close()
   env = dict(os.environ, LNZ_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
-  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-         '--gpus', '2', '--steps', '6', '--warmup', '2']
-  out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+  for attempt in range(3):   # a port taken between the probe and the rendezvous: try another
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '6', '--warmup', '2']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    if out.returncode == 0 or 'ddress already in use' not in out.stderr:
+      break
   assert out.returncode == 0, out.stderr[-2000:]
   lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
   assert len(lines) == 1, out.stdout[-2000:]          # rank 0 only

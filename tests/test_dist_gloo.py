@@ -72,6 +72,24 @@ def _free_port():
   return p
 
 
+def _spawn(worker, world, out_dir, attempts=3):
+  """mp.spawn on a fresh port; a rendezvous that fails (the port was taken between the probe and
+  the bind, or a loaded host missed the store timeout) is retried on another port."""
+  last = None
+  for _ in range(attempts):
+    try:
+      mp.spawn(worker, args=(world, _free_port(), out_dir), nprocs=world, join=True)
+      return
+    except Exception as e:  # ProcessRaisedException / ProcessExitedException
+      msg = str(e)
+      if not any(k in msg for k in ('Address already in use', 'address already in use', 'timed out',
+                                    'Timed out', 'Connection refused', 'Connection reset',
+                                    'DistNetworkError', 'DistStoreError')):
+        raise
+      last = e
+  raise last
+
+
 def _grad_worker(rank, world, port, out_dir):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
@@ -165,7 +183,7 @@ def _subgroup_worker(rank, world, port, out_dir):
 
 
 def test_subgroup_sharding_and_missing_gradients(tmp_path):
-  mp.spawn(_subgroup_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+  _spawn(_subgroup_worker, 3, str(tmp_path))
   for r in range(3):
     assert np.load(os.path.join(str(tmp_path), 's%d.npy' % r))[0] == 1
 
@@ -186,7 +204,7 @@ def test_helpers_without_process_group():
 def test_async_score_gather_streams_batches(world, tmp_path):
   """AsyncScoreGather (bench.py's per-step exchange): every submitted shard score arrives in
   rank order in its own result buffer, `depth` steps stay readable, older tickets are refused."""
-  mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  _spawn(_gather_worker, world, str(tmp_path))
   for r in range(world):
     assert np.load(os.path.join(str(tmp_path), 'a%d.npy' % r))[0] == 1
 
@@ -194,15 +212,14 @@ def test_async_score_gather_streams_batches(world, tmp_path):
 @pytest.mark.parametrize('world', [2, 3])
 def test_gradient_all_reduce_is_the_full_batch_gradient(world, tmp_path):
   """Shard-size-weighted flat-bucket all-reduce == gradient of the unsharded mean loss."""
-  port = _free_port()
-  mp.spawn(_grad_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  _spawn(_grad_worker, world, str(tmp_path))
   for r in range(world):
     assert np.load(os.path.join(str(tmp_path), 'g%d.npy' % r))[0] == 1
 
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_forward_matches_single_process(world, tmp_path):
-  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  _spawn(_worker, world, str(tmp_path))
   covered = []
   for r in range(world):
     ok, lo, hi = np.load(tmp_path / ('r%d.npy' % r))
