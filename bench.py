@@ -604,11 +604,23 @@ def main():
     sweep = forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, (1024, 4096, 16384)
                                 if B == 1024 else (B,))
   if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.no_secondary:
-    (Ag, Dg, Vg), large = lanczos_large_leg(dev)
-    large_conv = large_graph_leg(dev, Ag, Dg, Vg)
-    del Ag, Dg, Vg
+    # a failing secondary leg must not take the headline line with it: it is reported as an error
+    def _leg(fn, *a_):
+      try:
+        return fn(*a_)
+      except Exception as e:  # noqa: BLE001
+        sys.stderr.write('bench: secondary leg %s failed: %r\n' % (fn.__name__, e))
+        torch.cuda.synchronize()
+        return {'error': repr(e)[:300]}
+    r_ = _leg(lanczos_large_leg, dev)
+    if isinstance(r_, tuple):
+      (Ag, Dg, Vg), large = r_
+      large_conv = _leg(large_graph_leg, dev, Ag, Dg, Vg)
+      del Ag, Dg, Vg
+    else:
+      large = r_
     torch.cuda.empty_cache()
-    ada = ada_leg(dev, L, node_feat, mask_u8)
+    ada = _leg(ada_leg, dev, L, node_feat, mask_u8)
 
   if rank == 0:
     ms_per_step = 1e3 * elapsed / args.steps
