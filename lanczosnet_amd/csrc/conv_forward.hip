@@ -157,7 +157,12 @@ __device__ __forceinline__ float ritz_tile_elem(KArgs& a, const TileDesc& t, int
 //          epilogue masks with the stored activation instead of bias + ReLU;
 // MODE 2 = message pass (lnz_lanczosnet_messages): GEMM1 is skipped — Z is the stored X_l block in
 //          C/D order — and every channel's M_c X_l is written out instead of accumulated.
-template <int NWV, int KHT, int FK, int MT, int MODE>
+// DEEPK: which weight-ring loop the GEMM1 uses — 1: the 8-slot ring in every layer (all input
+//   widths multiples of 64: the QM8 model), 0: the 4-slot ring, -1: chosen per layer at run time.
+//   With both loops present the register allocator gives their rings different registers and the
+//   join behind EVERY channel copies one ring into the other behind an s_waitcnt vmcnt(0): the
+//   whole prefetch is drained fourteen times a layer.
+template <int NWV, int KHT, int FK, int MT, int MODE, int DEEPK = -1>
 __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                                              float (*Xs)[2][32][PITCH],  // [2 buffers][tile][..]
                                              float (*Vm)[32][VPITCH],      // [tile][node row][slot row]
@@ -329,7 +334,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     // 7 steps: with one tile a step is only 4 MFMAs, and three steps do not cover an L2 miss);
     // the narrow first layer keeps the 4-slot rotation.
     float4 ring[8];
-    const bool deep = (MODE == 0 || MODE == 3) && (Q & 7) == 0;  // the backward modes have no registers to spare
+    const bool deep = DEEPK >= 0 ? DEEPK == 1  // (the backward modes have no registers to spare)
+                                 : (MODE == 0 || MODE == 3) && (Q & 7) == 0;
     if (MODE != 2 && active) {
 #pragma unroll
       for (int sl = 0; sl < 7; ++sl)
@@ -533,7 +539,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       }
     };
     auto gemm1 = [&](const lds_cptr (&rows)[MT]) {
-      if (deep) gemm1_rd(std::integral_constant<int, 8>{}, rows);
+      if constexpr (DEEPK == 1) gemm1_rd(std::integral_constant<int, 8>{}, rows);
+      else if constexpr (DEEPK == 0) gemm1_rd(std::integral_constant<int, 4>{}, rows);
+      else if (deep) gemm1_rd(std::integral_constant<int, 8>{}, rows);
       else gemm1_rd(std::integral_constant<int, 4>{}, rows);
     };
 
@@ -633,12 +641,21 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         }
       if (MODE != 2 && a.n_short > 0) prime_ring(0);
     }
-    for (int c = es ? c_first : 0; active && c < C; ++c) {
-      if (es && c == a.n_short && c < c_end) {  // past the short channels: skip the long block
-        c = c_end;
-        if (MODE != 2) prime_ring(c_end * Q);
-        if (c >= C) break;
+    // The node-space channels, in one or two contiguous ranges of the weight stream: without
+    // eigen space all of [0, C); in eigen space (the long block is done) the short channels
+    // [0, n_short) and then, behind the long block, the edge channels [c_end, C) — the ring is
+    // re-primed BETWEEN the ranges, outside the channel loop: with the jump inside it the loop had
+    // three ways in, and hipcc's s_waitcnt placement drained the weight ring (vmcnt(1)) at the top
+    // of every 8-step iteration of the GEMM1 loop.
+    for (int range = 0; range < 2; ++range) {
+      int c_lo = es ? c_first : 0, c_hi = (es && a.n_short > 0) ? a.n_short : C;
+      if (range == 1) {
+        if (!(es && a.n_short > 0) || c_end >= C) break;
+        c_lo = c_end;
+        c_hi = C;
+        if (MODE != 2 && active) prime_ring(c_end * Q);
       }
+    for (int c = c_lo; active && c < c_hi; ++c) {
       const bool is_long = (c >= a.n_short) && (c < a.n_short + a.n_long);
 
       LNZ_T0
@@ -723,6 +740,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         if (MODE == 2) store_message(c, m, P);
       }
       LNZ_ACC(t_g2)
+    }
     }
 
     // ---------------- epilogue: X' -> LDS (other buffer), one barrier per layer -------------
@@ -872,7 +890,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 // One workgroup = 2 halves x NWV wavefronts; half h works on slots 2h, 2h+1 of the workgroup's
 // plan entry (0, 1 or 2 node tiles).  With the plan of lnz_plan_tiles there is one workgroup per
 // CU while the batch fits in one round, holding floor/ceil of (tiles / CUs) tiles.
-template <int NWV, int KHT, int FK, int MODE>
+template <int NWV, int KHT, int FK, int MODE, int DEEPK = -1>
 __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) float Xs[2][2][MOLS][32][PITCH];  // [half][buffer][tile]
@@ -894,10 +912,10 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
     nt += td[m].ta >= 0 ? 1 : 0;  // slots fill from 0: a used slot 1 implies a used slot 0
   }
   if (nt == 2) {
-    forward_half<NWV, KHT, FK, 2, MODE>(a, td, Xs[half], Vm[half], Gs, htid, wave);
+    forward_half<NWV, KHT, FK, 2, MODE, DEEPK>(a, td, Xs[half], Vm[half], Gs, htid, wave);
   } else if (nt == 1) {
     const TileDesc t1[1] = {td[0]};
-    forward_half<NWV, KHT, FK, 1, MODE>(a, t1, Xs[half], Vm[half], Gs, htid, wave);
+    forward_half<NWV, KHT, FK, 1, MODE, DEEPK>(a, t1, Xs[half], Vm[half], Gs, htid, wave);
   } else {
     // keep the barrier count of the other half: setup, (eigen space: the first layer's
     // projection,) and per layer one barrier (eigen space: two)
@@ -1200,7 +1218,13 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
     LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
     LNZ_LAUNCH(4, 10, 0, 3);
   } else if (a.filter_kind == 0) {
-    if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
+    if (a.dhid == 128 && a.din0 % 64 == 0) {  // every layer: a multiple of 8 k-steps per channel
+      auto kfn = lanczosnet_forward_kernel<4, 10, 0, 0, 1>;
+      if (gs_bytes)
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)gs_bytes);
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), gs_bytes, s, a);
+    } else if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
     else LNZ_LAUNCH(2, 10, 0, 0);
   } else {
     const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
