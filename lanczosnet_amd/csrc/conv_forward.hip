@@ -170,6 +170,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                                              const int htid, const int wave) {
   constexpr bool FWD = MODE == 0 || MODE == 3;
   constexpr bool ES = FK == 0;  // long channels in eigen space
+  // Laplacian fragments of a node-space channel: fetched in front of the LAST ring-depth steps of
+  // the channel's own GEMM1 (kernels with one ring loop), else one channel ahead
+  constexpr bool PEEL = DEEPK >= 0 && FK == 0 && MODE != 2;
 #ifdef LNZ_EXP_PRIO
   // the two-tile half is the critical path of a 3-tile workgroup: let it issue first, the
   // one-tile half fills the matrix-pipe slots it leaves
@@ -452,7 +455,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         }
       }
     };
-    if (active && !es) {
+    if (active && !es && !PEEL) {  // (PEEL: fetched inside the channel's GEMM1)
 #pragma unroll
       for (int m = 0; m < MT; ++m) fetch_m_operands(0, m);
     }
@@ -478,7 +481,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 
     // GEMM1 of one channel into Z: Z_m (+)= [diag(g)] A_m W_c^T, A rows from `rows` (X or Y).
     f32x16 Z[MT];
-    auto gemm1_rd = [&](auto depth, const lds_cptr (&rows)[MT]) {
+    auto gemm1_rd = [&](auto depth, const lds_cptr (&rows)[MT], auto&& before_last) {
       constexpr int RD = decltype(depth)::value;  // ring slots = steps per unrolled body
       lds_cptr xq[MT];
       float4 acur[MT];
@@ -487,8 +490,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         xq[m] = rows[m];
         acur[m] = lds_f4(xq[m]);
       }
-#pragma unroll 1
-      for (int q0 = 0; q0 < Q; q0 += RD) {
+      auto rd_steps = [&]() {
 #pragma unroll
         for (int u4 = 0; u4 < RD; ++u4) {
 #ifndef LNZ_EXP_NO_WLOAD
@@ -536,13 +538,29 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 #pragma unroll
         for (int m = 0; m < MT; ++m) xq[m] += 8 * RD;
         wp += RD * 64;
+      };
+      // all but the last RD steps in the loop, the last RD straight-line behind `before_last`:
+      // vector loads issued there (the channel's Laplacian fragments) are followed by a KNOWN
+      // number of ring loads, so their s_waitcnt does not have to drain the weight ring — a load
+      // carried across a loop of unknown trip count can only be waited for with vmcnt(0)
+      // (kernels that carry both ring loops — DEEPK < 0, odd widths — keep one body per loop:
+      // four bodies per call site spill; there `before_last` is empty)
+      if constexpr (DEEPK >= 0) {
+#pragma unroll 1
+        for (int q0 = RD; q0 < Q; q0 += RD) rd_steps();
+        before_last();
+        rd_steps();
+      } else {
+        before_last();
+#pragma unroll 1
+        for (int q0 = 0; q0 < Q; q0 += RD) rd_steps();
       }
     };
-    auto gemm1 = [&](const lds_cptr (&rows)[MT]) {
-      if constexpr (DEEPK == 1) gemm1_rd(std::integral_constant<int, 8>{}, rows);
-      else if constexpr (DEEPK == 0) gemm1_rd(std::integral_constant<int, 4>{}, rows);
-      else if (deep) gemm1_rd(std::integral_constant<int, 8>{}, rows);
-      else gemm1_rd(std::integral_constant<int, 4>{}, rows);
+    auto gemm1 = [&](const lds_cptr (&rows)[MT], auto&& before_last) {
+      if constexpr (DEEPK == 1) gemm1_rd(std::integral_constant<int, 8>{}, rows, before_last);
+      else if constexpr (DEEPK == 0) gemm1_rd(std::integral_constant<int, 4>{}, rows, before_last);
+      else if (deep) gemm1_rd(std::integral_constant<int, 8>{}, rows, before_last);
+      else gemm1_rd(std::integral_constant<int, 4>{}, rows, before_last);
     };
 
     // ---------------- eigen-space block: all long channels of the layer ----------------
@@ -571,7 +589,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           for (int s = 0; s < a.n_long; ++s) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
-            gemm1(yrow);
+            gemm1(yrow, [] {});
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
               const float* g4 = gsl + (m * a.n_long + s) * 32 + 4 * hh;
@@ -588,7 +606,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           LNZ_ACC(t_g1)
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            if (c_first < C) fetch_m_operands(c_first, m);
+            if (!PEEL && c_first < C) fetch_m_operands(c_first, m);
             const float* vs = &Vm[m][j][4 * hh];
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
@@ -662,7 +680,16 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
       // ---------------- GEMM1: Z_m = X_m W_c^T ----------------
 #pragma unroll
       for (int m = 0; m < MT; ++m) Z[m] = MODE == 2 ? Xblk[MODE == 2 ? m : 0] : lnz::splat16(0.0f);
-      if (MODE != 2) gemm1(xrow);
+      if (MODE != 2) {
+        // FK = 0: this channel's Laplacian fragments are fetched in front of the LAST ring-depth
+        // steps of its GEMM1 (>= 32 MFMAs to land)
+        gemm1(xrow, [&] {
+          if (PEEL) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) fetch_m_operands(c, m);
+          }
+        });
+      }
 
       LNZ_ACC(t_g1)
       // ---------------- per tile: M_c fragments, next operands, GEMM2 ----------------
@@ -733,7 +760,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           }
         }
 #undef LNZ_MF
-        if (INPLACE) {
+        if (INPLACE && !PEEL) {  // one channel ahead
           const int cn = (es && c + 1 == a.n_short) ? c_end : c + 1;
           if (cn < C) fetch_m_operands(cn, m);
         }
@@ -1200,31 +1227,32 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
   LNZ_REQUIRE(gs_bytes <= 12288, LNZ_ENOTSUP,
               "%s: %d long-diffusion channels exceed the 12 whose gains fit in LDS next to the node "
               "tiles", who, a.n_long);
-#define LNZ_LAUNCH(NWV_, KHT_, FK_, MODE_)                                                       \
+#define LNZ_LAUNCH_D(NWV_, KHT_, FK_, MODE_, DEEPK_)                                             \
   do {                                                                                           \
-    auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_, MODE_>;                                \
+    auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_, MODE_, DEEPK_>;                        \
     if (gs_bytes)                                                                                \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 (int)gs_bytes);                                                  \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(128 * NWV_), gs_bytes, s, a);                       \
   } while (0)
+#define LNZ_LAUNCH(NWV_, KHT_, FK_, MODE_) LNZ_LAUNCH_D(NWV_, KHT_, FK_, MODE_, -1)
   // diagonal gains (filter_kind 0) run in eigen space for any K <= 32: the KHT parameter only
-  // sizes the dense-filter variant's register arrays
+  // sizes the dense-filter variant's register arrays.  The weight-ring depth is a template
+  // constant wherever it is known on the host (forward_half DEEPK): every layer of a width-128
+  // model with an input width that is a multiple of 64 takes the 8-slot ring in the forward
+  // modes; the backward modes always take the 4-slot ring.
+  const bool all_deep = a.dhid == 128 && a.din0 % 64 == 0;
   if (mode == 1) {
-    LNZ_LAUNCH(4, 10, 0, 1);
+    LNZ_LAUNCH_D(4, 10, 0, 1, 0);
   } else if (mode == 2) {
-    LNZ_LAUNCH(4, 10, 0, 2);
+    LNZ_LAUNCH_D(4, 10, 0, 2, 0);
   } else if (a.filter_kind == 0 && a.act_out) {
     LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
-    LNZ_LAUNCH(4, 10, 0, 3);
+    if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 3, 1);
+    else LNZ_LAUNCH(4, 10, 0, 3);
   } else if (a.filter_kind == 0) {
-    if (a.dhid == 128 && a.din0 % 64 == 0) {  // every layer: a multiple of 8 k-steps per channel
-      auto kfn = lanczosnet_forward_kernel<4, 10, 0, 0, 1>;
-      if (gs_bytes)
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)gs_bytes);
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), gs_bytes, s, a);
-    } else if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
+    if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 0, 1);
+    else if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
     else LNZ_LAUNCH(2, 10, 0, 0);
   } else {
     const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
@@ -1233,6 +1261,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
     else if (k24) LNZ_LAUNCH(2, 12, 1, 0);
     else LNZ_LAUNCH(2, KHMAX, 1, 0);
   }
+#undef LNZ_LAUNCH_D
 #undef LNZ_LAUNCH
   return lnz::check_launch(who);
 }
