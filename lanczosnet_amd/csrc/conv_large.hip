@@ -635,6 +635,10 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
     constexpr int gs = decltype(gsc)::value;
     load_a(std::integral_constant<int, (gs + DEPTH - 1) % DEPTH>{});
     if constexpr (BDIST == 2) load_b(std::integral_constant<int, gs % 2>{});
+    // the block's loads go out BEFORE its MFMAs: left free, hipcc sinks them to the end of the
+    // first block of the unrolled body and waits vmcnt(0) there — the A ring drained once per
+    // four blocks
+    __builtin_amdgcn_sched_barrier(0);
     const u16* bt = Bs + (int64_t)(g & 1) * P * DH * BP;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -658,13 +662,21 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
     __syncthreads();
   };
 
+  // (the prologue's loads in program order: hipcc otherwise reorders them, the s_waitcnt of the
+  // loop head has to cover the reordered entry state as well, and block 0 of every 4-block
+  // iteration drained the whole A ring with vmcnt(0))
   load_a(std::integral_constant<int, 0>{});
+  __builtin_amdgcn_sched_barrier(0);
   load_b(std::integral_constant<int, 0>{});
+  __builtin_amdgcn_sched_barrier(0);
   if constexpr (DEPTH > 2) {
     load_a(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
     load_a(std::integral_constant<int, 2 % DEPTH>{});
+    __builtin_amdgcn_sched_barrier(0);
   }
   if constexpr (BDIST == 2) load_b(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_sched_barrier(0);
   store_b(0, std::integral_constant<int, 0>{});
   __syncthreads();
   int g = 0;
