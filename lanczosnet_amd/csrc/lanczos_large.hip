@@ -15,6 +15,7 @@
 // Algorithmic bytes per graph: M * 4 N^2 (A) + basis traffic ~ 4 * 8 N * M(M+1)/2
 // + 4 N K (V) : 1.074 GB + 0.133 GB + 0.5 MB at N = 2048, M = K = 64.
 #include "common.hpp"
+#include <cstdlib>
 
 // A (16.8 MB per graph at N = 2048, re-streamed every Lanczos step) never survives in a cache
 // until its next use: non-temporal loads leave L2 / Infinity Cache to the fp64 Krylov basis.
@@ -48,6 +49,7 @@ struct LargeSmem {
   double ee[MMAX];
   double cs[MMAX];
   double red[NWAVE];
+  double zero16[16];  // the symmetric SpMV's diagonal jobs read their row vector here
   int perm[MMAX];
   float sgn[MMAX];
 };
@@ -91,6 +93,14 @@ __device__ inline double wave_sum_f64(double v) {
   return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
+// orders the LDS accesses of ONE wavefront (they execute in program order; this keeps the compiler
+// from moving them across the point) — the single-wave replacement for __syncthreads()
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ inline double block_sum(LargeSmem& sm, double part, int tid) {
   double w = wave_sum_f64(part);
   if ((tid & 63) == 0) sm.red[tid >> 6] = w;
@@ -111,10 +121,13 @@ __device__ inline double block_sum(LargeSmem& sm, double part, int tid) {
 // written by exactly one job — slot s > I: row dots of block (I, s); s == I: the diagonal block;
 // s < I: column sums of block (s, I) — into part[s][.] (HBM workspace, L2 resident), and w is
 // their sum in slot order: deterministic, no atomics.
-struct SymJob {
-  short I, J, row0, nrow;  // rows [row0, row0 + nrow) of chunk block (I, J); J == I: row dots only
+struct alignas(8) SymJob {
+  unsigned short I, J, row0, nrow;  // rows [row0, row0 + nrow) of chunk block (I, J); J == I: row dots only
 };
 constexpr int SYM_MAXJOBS = 16;
+constexpr unsigned kOob = 0xffffffffu;  // buffer-load offset past every graph: reads as zeros
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 constexpr int SYM_RG = 16;  // rows per group: one float4 per lane and row in flight
 
 struct SymSched {
@@ -134,7 +147,8 @@ __device__ inline void sym_deal(SymSched& sc, int N) {  // one thread
     for (int w = 1; w < NWAVE; ++w)
       if (load[w] < load[best]) best = w;
     SymJob jb;
-    jb.I = (short)I; jb.J = (short)J; jb.row0 = (short)row0; jb.nrow = (short)nrow;
+    jb.I = (unsigned short)I; jb.J = (unsigned short)J; jb.row0 = (unsigned short)row0;
+    jb.nrow = (unsigned short)nrow;
     sc.jobs[best][sc.njobs[best]++] = jb;
     load[best] += cost;
   };
@@ -249,11 +263,25 @@ __device__ __forceinline__ void cgs_pass(LargeSmem& sm, const double* __restrict
   __syncthreads();
 }
 
+#ifdef LNZ_LARGE_PROBE
+__device__ unsigned long long g_large_probe[16];
+#define LNZ_PROBE(k)                                                  \
+  do {                                                                \
+    if (tid == 0) {                                                   \
+      const unsigned long long t_ = wall_clock64();                   \
+      atomicAdd(&g_large_probe[k], t_ - t_last);                      \
+      t_last = t_;                                                    \
+    }                                                                 \
+  } while (0)
+#else
+#define LNZ_PROBE(k)
+#endif
+
 template <bool SYM>
 __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int N, int M, int K,
     double* __restrict__ work, double* __restrict__ part_all, float* __restrict__ D,
-    float* __restrict__ V, int32_t* __restrict__ info) {
+    float* __restrict__ V, int32_t* __restrict__ info, int stagger_ticks, int stagger_wgs) {
   __shared__ __attribute__((aligned(16))) LargeSmem sm;
   __shared__ SymSched sched;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -262,6 +290,24 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
   double* Qg = work + (int64_t)b * MMAX * N;
   double* cpart = SYM ? part_all + (int64_t)b * NCH * NCH * 256 : nullptr;  // [slot][NCH * 256]
   if (SYM && tid == 0) sym_deal(sched, N);
+  // the graph's matrix as a buffer: 32-bit byte offsets, out-of-range offsets read as zeros
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(Ab), 0, (unsigned)(((int64_t)(N - 1) * sr + N) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      cpart, 0, SYM ? (unsigned)(NCH * NCH * 256 * sizeof(double)) : 0u, 0x00020000);
+  // Stagger: the workgroups of the first wave over the chip start together and take the same time
+  // per Lanczos step, so their serial phases (slot sums, Gram-Schmidt, norms) would coincide for
+  // the whole launch and HBM would idle through each of them.  Sixteen start offsets spread over
+  // one step period keep the chip streaming while some workgroups are in a serial phase.  (XCD =
+  // blockIdx % 8: every XCD gets every offset.)  Results do not depend on it.
+  if (stagger_ticks > 0 && (int)blockIdx.x < stagger_wgs) {
+    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 15) * stagger_ticks;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+  }
+#ifdef LNZ_LARGE_PROBE
+  unsigned long long t_last = wall_clock64();
+#endif
 
   // start vector (same hash as the small-graph kernel)
   double part = 0.0;
@@ -278,6 +324,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     sm.dd[tid] = 0.0;
     sm.ee[tid] = 0.0;
   }
+  if (tid < 16) sm.zero16[tid] = 0.0;
   double nrm2 = block_sum(sm, part, tid);
 
   int steps = 0;
@@ -292,27 +339,39 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       if (r < N) Qg[(int64_t)j * N + r] = q;
     }
     __syncthreads();
+    LNZ_PROBE(0);
 
     if constexpr (SYM) {
       // ---- SpMV, symmetric: this wave's jobs in groups of SYM_RG rows.  A ring of SYM_RG row
       //      slots (one float4 per lane): the slot of a consumed row is refilled at once with the
-      //      same row of the NEXT group, so SYM_RG rows (16 KiB per wave) stay in flight.
-      const int nj = sched.njobs[wave];
+      //      same row of the NEXT group, so SYM_RG rows (16 KiB per wave) stay in flight.  The
+      //      loads are buffer loads issued unconditionally — a row or column that does not exist
+      //      gets an out-of-range offset and comes back as zeros without touching memory — so
+      //      the loop has no branch around a load and every row waits for exactly its own
+      //      (predicated flat loads made hipcc drain the whole ring once per group).
+      const int nj = __builtin_amdgcn_readfirstlane(sched.njobs[wave]);
       const SymJob* jl = sched.jobs[wave];
-      int pj = 0, pg = 0;  // prefetch cursor: job, first row of the group inside the job
-      const float* psrc = Ab;
-      int pvalid = 0;      // rows of the prefetch group (0: nothing left)
-      bool pcol = false;   // this lane's columns of the prefetch group exist
+      auto job_at = [&](int k, int& I, int& J, int& row0, int& nrow) {  // wave-uniform, in SGPRs
+        const uint2 raw = *reinterpret_cast<const uint2*>(&jl[k]);
+        const unsigned lo = __builtin_amdgcn_readfirstlane(raw.x);
+        const unsigned hi = __builtin_amdgcn_readfirstlane(raw.y);
+        I = (int)(lo & 0xffffu); J = (int)(lo >> 16); row0 = (int)(hi & 0xffffu); nrow = (int)(hi >> 16);
+      };
+      const unsigned srb = (unsigned)sr * 4u;  // row stride in bytes (the launcher checked the range)
+      int pj = 0, pg = 0;        // prefetch cursor: job, first row of the group inside the job
+      unsigned poff = kOob;      // this lane's byte offset of row 0 of the prefetch group
+      int pvalid = 0;            // rows of the prefetch group (0: nothing left)
       auto next_prefetch = [&]() {
         pvalid = 0;
+        poff = kOob;
         if (pj < nj) {
-          const SymJob jb = jl[pj];
-          const int c0 = 256 * jb.J + 4 * lane;
-          pcol = c0 < N;
-          psrc = Ab + (int64_t)(jb.row0 + pg) * sr + c0;
-          pvalid = min(SYM_RG, jb.nrow - pg);
+          int I, J, row0, nrow;
+          job_at(pj, I, J, row0, nrow);
+          const int c0 = 256 * J + 4 * lane;
+          if (c0 < N) poff = (unsigned)(row0 + pg) * srb + 4u * (unsigned)c0;
+          pvalid = min(SYM_RG, nrow - pg);
           pg += SYM_RG;
-          if (pg >= jb.nrow) {
+          if (pg >= nrow) {
             pg = 0;
             ++pj;
           }
@@ -320,25 +379,47 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       };
       float4 buf[SYM_RG];
       auto fetch = [&](int i) {
-        buf[i] = (i < pvalid && pcol) ? lnz_stream_f4(psrc + (int64_t)i * sr)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned off = (i < pvalid && poff != kOob) ? poff + (unsigned)i * srb : kOob;
+        const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, /*nt*/ 2);
+        buf[i] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z),
+                             __uint_as_float(raw.w));
       };
       next_prefetch();
 #pragma unroll
-      for (int i = 0; i < SYM_RG; ++i) fetch(i);
-      double qJ[4], colacc[4];
+      for (int i = 0; i < SYM_RG; ++i) {
+        fetch(i);
+        // the ring is filled in the order the loop consumes it: hipcc's vmcnt bookkeeping takes
+        // the worst case over the loop's entries, and a shuffled fill would cost a drain per group
+        __builtin_amdgcn_sched_barrier(0);
+      }
       for (int cj = 0; cj < nj; ++cj) {
-        const SymJob jb = jl[cj];
-        const bool offd = jb.J != jb.I;
+        int I, J, row0, nrow;
+        job_at(cj, I, J, row0, nrow);
+        // one code path for both kinds of job: a diagonal block reads its "q of the rows" from a
+        // line of zeros, so its column sums stay zero and are not stored
+        const bool offd = J != I;
+        double qJ[4], colacc[4];
         {
-          const double2* qp = reinterpret_cast<const double2*>(&sm.qs[256 * jb.J + 4 * lane]);
+          const double2* qp = reinterpret_cast<const double2*>(&sm.qs[256 * J + 4 * lane]);
           const double2 x = qp[0], y = qp[1];
           qJ[0] = x.x; qJ[1] = x.y; qJ[2] = y.x; qJ[3] = y.y;
           colacc[0] = colacc[1] = colacc[2] = colacc[3] = 0.0;
         }
-        for (int cg = 0; cg < jb.nrow; cg += SYM_RG) {
-          const int r0 = jb.row0 + cg;
+        for (int cg = 0; cg < nrow; cg += SYM_RG) {
+          const int r0 = row0 + cg;
           next_prefetch();
+          // q of the group's rows, fetched ahead of the row loop (broadcast reads; rows past N
+          // hold zeros)
+          double qr[SYM_RG];
+          {
+            const double2* qp = reinterpret_cast<const double2*>(offd ? &sm.qs[r0] : sm.zero16);
+#pragma unroll
+            for (int i = 0; i < SYM_RG; i += 2) {
+              const double2 t = qp[i >> 1];
+              qr[i] = t.x;
+              qr[i + 1] = t.y;
+            }
+          }
           double p[SYM_RG];
 #pragma unroll
           for (int i = 0; i < SYM_RG; ++i) {
@@ -346,35 +427,51 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
                          aw = (double)buf[i].w;
             fetch(i);
             p[i] = fma(ax, qJ[0], ay * qJ[1]) + fma(az, qJ[2], aw * qJ[3]);
-            if (offd) {
-              const double qr = sm.qs[r0 + i];  // rows past the job's end were loaded as zeros
-              colacc[0] = fma(ax, qr, colacc[0]);
-              colacc[1] = fma(ay, qr, colacc[1]);
-              colacc[2] = fma(az, qr, colacc[2]);
-              colacc[3] = fma(aw, qr, colacc[3]);
-            }
+            colacc[0] = fma(ax, qr[i], colacc[0]);
+            colacc[1] = fma(ay, qr[i], colacc[1]);
+            colacc[2] = fma(az, qr[i], colacc[2]);
+            colacc[3] = fma(aw, qr[i], colacc[3]);
+            // row by row, the column sums pinned to their row: left alone hipcc sinks all 64 of
+            // their FMAs behind the reduction, keeps every row's fp64 copy alive until then and
+            // spills — and a scratch reload in this loop costs a full vmcnt(0) drain
+            asm volatile("" : "+v"(colacc[0]), "+v"(colacc[1]), "+v"(colacc[2]), "+v"(colacc[3]));
+            __builtin_amdgcn_sched_barrier(0);
           }
           double v[4];
           reduce16_f64(p, v);
           if ((lane & 15) == 0) {
-            double* dst = cpart + (int64_t)jb.J * (NCH * 256) + r0 + 4 * (lane >> 4);
+            double* dst = cpart + (int64_t)J * (NCH * 256) + r0 + 4 * (lane >> 4);
             *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
             *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
           }
         }
         if (offd) {
-          double* dst = cpart + (int64_t)jb.I * (NCH * 256) + 256 * jb.J + 4 * lane;
+          double* dst = cpart + (int64_t)I * (NCH * 256) + 256 * J + 4 * lane;
           *reinterpret_cast<double2*>(dst) = make_double2(colacc[0], colacc[1]);
           *reinterpret_cast<double2*>(dst + 2) = make_double2(colacc[2], colacc[3]);
         }
       }
+      LNZ_PROBE(1);
       __syncthreads();
+      LNZ_PROBE(2);
+      // w = sum of the contribution slots in slot order; every load of a thread in flight at once
       const int nch = (N + 255) >> 8;
-      for (int r = tid; r < NCH * 256; r += TPB) {
+      part = 0.0;
+#pragma unroll
+      for (int k = 0; k < NCH * 256 / TPB; ++k) {
+        const int r = tid + k * TPB;
+        double c[NCH];
+#pragma unroll
+        for (int sl = 0; sl < NCH; ++sl) {  // (buffer loads: one offset register, no pointer table)
+          const unsigned off = (r < N && sl < nch) ? 8u * (unsigned)r : kOob;
+          const u2v raw = __builtin_amdgcn_raw_buffer_load_b64(c_rsrc, off, sl * (NCH * 256 * 8), 0);
+          c[sl] = __hiloint2double((int)raw.y, (int)raw.x);
+        }
         double acc = 0.0;
-        if (r < N)
-          for (int sl = 0; sl < nch; ++sl) acc += cpart[(int64_t)sl * (NCH * 256) + r];
+#pragma unroll
+        for (int sl = 0; sl < NCH; ++sl) acc += c[sl];
         sm.ws[r] = acc;
+        part = fma(acc, acc, part);  // |w|^2 on the way (rows past N are zeros)
       }
     } else {
     // ---- SpMV: w = A q; q slice in registers, A streamed once ------------------------------
@@ -425,6 +522,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       }
     }
     __syncthreads();
+    LNZ_PROBE(3);
 
     // ---- Gram-Schmidt against q_0..q_j: one classical pass; a second one only when the first
     //      cancelled more than kReorth of w's norm (the projection's rounding error relative to
@@ -432,9 +530,12 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     //      fp32 outputs; near an invariant subspace |w1| collapses and the second pass runs).
     //      oracle/lanczos_kstep.py states the same rule.
     double coef = 0.0;
-    part = 0.0;
-    for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
+    if constexpr (!SYM) {
+      part = 0.0;
+      for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
+    }
     const double nrm2_before = block_sum(sm, part, tid);
+    LNZ_PROBE(4);
     for (int pass = 0; pass < 2; ++pass) {
       if (pass == 1) {
         part = 0.0;
@@ -480,12 +581,14 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
         __syncthreads();
       }
       coef += sm.cs[j];
+      LNZ_PROBE(5 + pass);
     }
     if (tid == 0) sm.dd[j] = coef;
     part = 0.0;
     for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
     nrm2 = block_sum(sm, part, tid);  // (after a skipped second pass: the same sum again)
     steps = j + 1;
+    LNZ_PROBE(7);
   }
   __syncthreads();
 
@@ -496,7 +599,10 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     sm.Zt[idx] = (i == r) ? 1.0 : 0.0;
   }
   __syncthreads();
-  {
+  // One wavefront runs the whole sweep (lane r owns row r of the accumulator, the scalars are
+  // recomputed by every lane): its LDS traffic is ordered by the wave itself, so a rotation costs
+  // no workgroup barrier.
+  if (wave == 0) {
     double f = 0.0, tst1 = 0.0;
     for (int l = 0; l < n; ++l) {
       tst1 = fmax(tst1, fabs(sm.dd[l]) + fabs(sm.ee[l]));
@@ -515,19 +621,19 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
           const double dl = el / (p + rr);
           const double dl1 = el * (p + rr);
           const double hh = g - dl;
-          __syncthreads();
+          wave_lds_sync();
           if (tid == 0) {
             sm.dd[l] = dl;
             sm.dd[l + 1] = dl1;
           }
           if (tid >= l + 2 && tid < n) sm.dd[tid] -= hh;
-          __syncthreads();
+          wave_lds_sync();
           f += hh;
           p = sm.dd[m];
           double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
           const double el1 = sm.ee[l + 1];
           double carry = tid < MMAX ? sm.Zt[m * ZLD + tid] : 0.0;
-          __syncthreads();
+          wave_lds_sync();
           for (int i = m - 1; i >= l; --i) {
             c3 = c2;
             c2 = c;
@@ -543,7 +649,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
             c = p * rinv;
             p = c * di - s * g;
             const double d_next = hp + s * (c * g + s * di);
-            __syncthreads();  // all threads have read ee[i], dd[i] (and ee[i+1] earlier)
+            wave_lds_sync();  // all threads have read ee[i], dd[i] (and ee[i+1] earlier)
             if (tid == 0) {
               sm.ee[i + 1] = e_next;
               sm.dd[i + 1] = d_next;
@@ -555,26 +661,28 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
             }
           }
           if (tid < MMAX) sm.Zt[l * ZLD + tid] = carry;
-          __syncthreads();
+          wave_lds_sync();
           p = -s * s2 * c3 * el1 * sm.ee[l] / dl1;
           el = s * p;
-          __syncthreads();
+          wave_lds_sync();
           if (tid == 0) {
             sm.ee[l] = el;
             sm.dd[l] = c * p;
           }
-          __syncthreads();
+          wave_lds_sync();
         } while (fabs(el) > kEpsD * tst1 && iter < 60);
       }
-      __syncthreads();
+      wave_lds_sync();
       if (tid == 0) {
         sm.dd[l] = sm.dd[l] + f;
         sm.ee[l] = 0.0;
       }
-      __syncthreads();
+      wave_lds_sync();
     }
   }
+  __syncthreads();
 
+  LNZ_PROBE(8);
   // ---- order by descending |theta| (ties: ascending theta, then index) ----------------------
   if (tid < n) {
     double di = sm.dd[tid], ai = fabs(di);
@@ -625,6 +733,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       Vb[(int64_t)r * K + k] = out;
     }
   }
+  LNZ_PROBE(9);
   if (info && tid == 0) info[b] = steps;
 }
 
@@ -646,14 +755,33 @@ static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int 
                   (reinterpret_cast<uintptr_t>(A) & 15) == 0,
               LNZ_ENOTSUP, "%s: rows must be contiguous, 16-byte aligned, N %% 4 == 0", who);
   LNZ_REQUIRE(M <= N, LNZ_EINVAL, "%s: M=%d > N=%d", who, M, N);
+  LNZ_REQUIRE(!sym || (stride_r > 0 && ((int64_t)(N - 1) * stride_r + N) * 4 < (int64_t)0xffffffff),
+              LNZ_ENOTSUP, "%s: one graph must span less than 4 GiB (row stride %lld)", who,
+              (long long)stride_r);
   double* basis = (double*)workspace;
   double* part = basis + (int64_t)B * MMAX * N;
+  // start offsets of the first wave of workgroups (see the kernel): one sixteenth of the time one
+  // Lanczos step of all resident graphs takes at ~6.5 TB/s, in ticks of the 100 MHz wall clock
+  int dev = 0, n_cu = 256;
+  if (hipGetDevice(&dev) == hipSuccess)
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int resident = B < n_cu ? B : n_cu;
+  const int nch = (N + 255) / 256;
+  const double step_bytes = (sym ? 0.5 * nch * (nch + 1) : (double)nch * nch) * 256.0 * 256.0 * 4.0;
+  // (measured neutral so far — 26.3 vs 26.5 ms — so off unless LNZ_LARGE_STAGGER_US asks: a
+  // negative value selects one sixteenth of the estimated step time)
+  double stagger_us = 0.0;
+  if (const char* e = getenv("LNZ_LARGE_STAGGER_US")) stagger_us = atof(e);
+  if (stagger_us < 0) stagger_us = resident * step_bytes / 6.5e6 / 16.0;
+  const int ticks = stagger_us < 0 ? 0 : stagger_us > 1e4 ? 1000000 : (int)(stagger_us * 100.0);
   if (sym)
     hipLaunchKernelGGL(lanczos_ritz_large_kernel<true>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info,
+                       ticks, resident);
   else
     hipLaunchKernelGGL(lanczos_ritz_large_kernel<false>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info,
+                       ticks, resident);
   return lnz::check_launch(who);
 }
 
@@ -670,3 +798,15 @@ extern "C" int lnz_lanczos_ritz_large_sym(const float* A, int64_t stride_b, int6
   return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, true,
                       "lnz_lanczos_ritz_large_sym");
 }
+
+#ifdef LNZ_LARGE_PROBE
+extern "C" int lnz_debug_large_probe(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_large_probe), sizeof(unsigned long long) * 16) != hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_large_probe), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -14,10 +14,13 @@ ap.add_argument('--nodes', type=int, default=2048)
 ap.add_argument('--steps', type=int, default=64)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--sym', action='store_true', help='lnz_lanczos_ritz_large_sym (upper chunk blocks only)')
+ap.add_argument('--row-pad', type=int, default=0,
+                help='floats of padding behind every row of A (row stride N + pad): probes the '
+                     'sensitivity of the 1 KiB-segment stream to a power-of-two row stride')
 args = ap.parse_args()
 B, N, M = args.batch, args.nodes, args.steps
 g = torch.Generator(device='cuda'); g.manual_seed(0)
-A = torch.empty((B, N, N), dtype=torch.float32, device='cuda')
+A = torch.zeros((B, N, N + args.row_pad), dtype=torch.float32, device='cuda')[:, :, :N]
 for b in range(B):  # G(n, p = 0.01) + self loops, symmetric GCN normalisation (L4)
   adj = (torch.rand((N, N), generator=g, device='cuda') < 0.01).float().triu(1)
   adj = adj + adj.t() + torch.eye(N, device='cuda')
@@ -43,4 +46,4 @@ print(json.dumps({'workload': 'lanczos_ritz_large%s B=%d N=%d M=K=%d fp32 A, fp6
                   'algorithmic_GB': round(alg / 1e9, 2), 'achieved_GBps': round(alg / t / 1e9, 1),
                   'A_only_GBps': round(B * bytes_A / t / 1e9, 1), 'peak_GBps': 8000,
                   'frac_of_hbm_peak': round(alg / t / 8e12, 4), 'steps_taken_min': int(info.min()),
-                  'all_ms': [round(x, 2) for x in ts]}))
+                  'row_pad': args.row_pad, 'all_ms': [round(x, 2) for x in ts]}))
