@@ -15,7 +15,6 @@
 // Algorithmic bytes per graph: M * 4 N^2 (A) + basis traffic ~ 4 * 8 N * M(M+1)/2
 // + 4 N K (V) : 1.074 GB + 0.133 GB + 0.5 MB at N = 2048, M = K = 64.
 #include "common.hpp"
-#include <cstdlib>
 
 // A (16.8 MB per graph at N = 2048, re-streamed every Lanczos step) never survives in a cache
 // until its next use: non-temporal loads leave L2 / Infinity Cache to the fp64 Krylov basis.
@@ -44,7 +43,12 @@ struct LargeSmem {
     };
     double Zt[MMAX * ZLD];  // QL eigenvector accumulator, transposed: Zt[i][r] = S[r][i]
   };
-  double ub[NWAVE / 2][NCH * 256];  // partial CGS updates on their way down the wave tree
+  union {
+    double ub[NWAVE / 2][NCH * 256];  // partial CGS updates on their way down the wave tree
+    // symmetric SpMV: the contributions to chunk c from the blocks it shares with chunk s != c,
+    // cslot[s - (s > c)][256 c ..] (the diagonal block's go straight to ws)
+    double cslot[NCH - 1][NCH * 256];
+  };
   double dd[MMAX];
   double ee[MMAX];
   double cs[MMAX];
@@ -93,14 +97,6 @@ __device__ inline double wave_sum_f64(double v) {
   return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
-// orders the LDS accesses of ONE wavefront (they execute in program order; this keeps the compiler
-// from moving them across the point) — the single-wave replacement for __syncthreads()
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ inline double block_sum(LargeSmem& sm, double part, int tid) {
   double w = wave_sum_f64(part);
   if ((tid & 63) == 0) sm.red[tid >> 6] = w;
@@ -116,49 +112,127 @@ __device__ inline double block_sum(LargeSmem& sm, double part, int tid) {
 // An off-diagonal block serves both  w_I += A_IJ q_J  (row dots)  and  w_J += A_IJ^T q_I  (column
 // sums, accumulated in the registers of the lane that owns the column), a diagonal block its row
 // dots over the full chunk: 36 of 64 blocks = 56 % of the bytes at N = 2048.  A block (or a
-// 64-row quarter of a diagonal block) is one job of one wave; the job lists are dealt once so that
-// every wave streams the same number of bytes.  Every (contribution slot s, chunk I) pair is
-// written by exactly one job — slot s > I: row dots of block (I, s); s == I: the diagonal block;
-// s < I: column sums of block (s, I) — into part[s][.] (HBM workspace, L2 resident), and w is
-// their sum in slot order: deterministic, no atomics.
-struct alignas(8) SymJob {
-  unsigned short I, J, row0, nrow;  // rows [row0, row0 + nrow) of chunk block (I, J); J == I: row dots only
-};
-constexpr int SYM_MAXJOBS = 16;
+// 64-row quarter of a diagonal block) is one job of one wave (claimed from a list, see SymSched).
+// Every (contribution slot s, chunk I) pair is written by exactly one job — slot s > I: row dots
+// of block (I, s); s == I: the diagonal block; s < I: column sums of block (s, I) — into LDS
+// (LargeSmem::cslot, 112 KB; the diagonal block's straight into ws), and w is their sum in slot
+// order: deterministic, no atomics, no memory traffic besides A itself.  (Until late in round 2
+// the slots were an HBM workspace: 4 GB of extra traffic per launch that thrashed L2 against the A
+// stream, and the launch took 26.3 or 29.2 ms depending on where the two allocations had landed.)
+constexpr int SYM_MAXJOBS = 64;  // 28 off-diagonal blocks + 32 diagonal quarters at N = 2048
 constexpr unsigned kOob = 0xffffffffu;  // buffer-load offset past every graph: reads as zeros
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
 constexpr int SYM_RG = 16;  // rows per group: one float4 per lane and row in flight
 
+// A job = rows [row0, row0 + nrow) of chunk block (I, J), packed {I | J << 16, row0 | nrow << 16};
+// J == I: row dots only.  The jobs of a Lanczos step sit in one list, large ones first, and the
+// waves claim them one by one (an LDS counter): the eight waves of a workgroup do not stream at
+// the same rate — the older wave of a SIMD wins the arbitration — and a static split left the
+// slow ones streaming alone for the last quarter of every step.  Who runs a job does not matter to
+// the result: its contribution slots are its own.
 struct SymSched {
-  SymJob jobs[NWAVE][SYM_MAXJOBS];
-  int njobs[NWAVE];
+  uint2 all[SYM_MAXJOBS];
+  uint2 mine[NWAVE][SYM_MAXJOBS];  // the jobs a wave has claimed in this step, in order
+  int total;
+  int next;
 };
 
-__device__ inline void sym_deal(SymSched& sc, int N) {  // one thread
+__device__ inline void sym_list(SymSched& sc, int N) {  // one thread
   const int nch = (N + 255) >> 8;
-  int load[NWAVE];
-  for (int w = 0; w < NWAVE; ++w) {
-    load[w] = 0;
-    sc.njobs[w] = 0;
-  }
-  auto give = [&](int I, int J, int row0, int nrow, int cost) {
-    int best = 0;
-    for (int w = 1; w < NWAVE; ++w)
-      if (load[w] < load[best]) best = w;
-    SymJob jb;
-    jb.I = (unsigned short)I; jb.J = (unsigned short)J; jb.row0 = (unsigned short)row0;
-    jb.nrow = (unsigned short)nrow;
-    sc.jobs[best][sc.njobs[best]++] = jb;
-    load[best] += cost;
+  int n = 0;
+  auto add = [&](int I, int J, int row0, int nrow) {
+    sc.all[n++] = make_uint2((unsigned)I | ((unsigned)J << 16), (unsigned)row0 | ((unsigned)nrow << 16));
   };
   for (int I = 0; I < nch; ++I)
-    for (int J = I + 1; J < nch; ++J) give(I, J, 256 * I, min(256, N - 256 * I), 4);
+    for (int J = I + 1; J < nch; ++J) add(I, J, 256 * I, min(256, N - 256 * I));
   for (int I = 0; I < nch; ++I)
     for (int q = 0; q < 4; ++q) {
       const int r0 = 256 * I + 64 * q;
-      if (r0 < N) give(I, I, r0, min(64, N - r0), 1);
+      if (r0 < N) add(I, I, r0, min(64, N - r0));
     }
+  sc.total = n;
+  sc.next = 0;
+}
+
+// value of lane i (wave-uniform i) of a per-lane double
+__device__ __forceinline__ double lane_f64(double v, int i) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), i);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
+  return __hiloint2double(hi, lo);
+}
+
+// Implicit-shift QL (tql2 recurrences) on the n x n tridiagonal (sm.dd, sm.ee), n <= 64, by ONE
+// wavefront; sm.Zt (identity on entry) receives the eigenvectors transposed, sm.dd the eigenvalues.
+__device__ inline void tql2_wave(LargeSmem& sm, const int n, const int lane) {
+  double d = sm.dd[lane], e = sm.ee[lane];  // (MMAX == 64 entries, zero past n)
+  double f = 0.0, tst1 = 0.0;
+  for (int l = 0; l < n; ++l) {
+    tst1 = fmax(tst1, fabs(lane_f64(d, l)) + fabs(lane_f64(e, l)));
+    // first m >= l with m == n - 1 or a negligible coupling e_m
+    unsigned long long stop = __ballot(lane >= n - 1 || !(fabs(e) > kEpsD * tst1));
+    stop &= ~0ull << l;
+    const int m = __builtin_ctzll(stop);
+    if (m > l) {
+      int iter = 0;
+      double el;
+      do {
+        ++iter;
+        double g = lane_f64(d, l);
+        el = lane_f64(e, l);
+        double p = (lane_f64(d, l + 1) - g) / (2.0 * el);
+        double rr = sqrt(p * p + 1.0);
+        if (p < 0) rr = -rr;
+        const double dl = el / (p + rr);
+        const double dl1 = el * (p + rr);
+        const double hh = g - dl;
+        if (lane == l) d = dl;
+        if (lane == l + 1) d = dl1;
+        if (lane >= l + 2 && lane < n) d -= hh;
+        f += hh;
+        p = lane_f64(d, m);
+        double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+        const double el1 = lane_f64(e, l + 1);
+        double carry = sm.Zt[m * ZLD + lane];
+        double znext = sm.Zt[(m - 1) * ZLD + lane];  // (m > l >= 0)
+        for (int i = m - 1; i >= l; --i) {
+          const double z0 = znext;
+          if (i > l) znext = sm.Zt[(i - 1) * ZLD + lane];  // the next rotation's row, ahead of time
+          c3 = c2;
+          c2 = c;
+          s2 = s;
+          const double ei = lane_f64(e, i), di = lane_f64(d, i);
+          g = c * ei;
+          const double hp = c * p;
+          const double tt = fma(p, p, ei * ei);
+          const double rinv = rsqrt(tt);
+          const double rad = tt * rinv;
+          const double e_next = s * rad;
+          s = ei * rinv;
+          c = p * rinv;
+          p = c * di - s * g;
+          const double d_next = hp + s * (c * g + s * di);
+          if (lane == i + 1) {
+            e = e_next;
+            d = d_next;
+          }
+          sm.Zt[(i + 1) * ZLD + lane] = s * z0 + c * carry;
+          carry = c * z0 - s * carry;
+        }
+        sm.Zt[l * ZLD + lane] = carry;
+        p = -s * s2 * c3 * el1 * lane_f64(e, l) / dl1;
+        el = s * p;
+        if (lane == l) {
+          e = el;
+          d = c * p;
+        }
+      } while (fabs(el) > kEpsD * tst1 && iter < 60);
+    }
+    if (lane == l) {
+      d += f;
+      e = 0.0;
+    }
+  }
+  sm.dd[lane] = d;
 }
 
 // 16 per-lane partial sums -> the 16 wave totals: after the two half / row swaps each lane of
@@ -281,30 +355,17 @@ template <bool SYM>
 __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int N, int M, int K,
     double* __restrict__ work, double* __restrict__ part_all, float* __restrict__ D,
-    float* __restrict__ V, int32_t* __restrict__ info, int stagger_ticks, int stagger_wgs) {
+    float* __restrict__ V, int32_t* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) LargeSmem sm;
   __shared__ SymSched sched;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const float* Ab = A + (int64_t)b * sb;
   double* Qg = work + (int64_t)b * MMAX * N;
-  double* cpart = SYM ? part_all + (int64_t)b * NCH * NCH * 256 : nullptr;  // [slot][NCH * 256]
-  if (SYM && tid == 0) sym_deal(sched, N);
+  if (SYM && tid == 0) sym_list(sched, N);
   // the graph's matrix as a buffer: 32-bit byte offsets, out-of-range offsets read as zeros
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(Ab), 0, (unsigned)(((int64_t)(N - 1) * sr + N) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      cpart, 0, SYM ? (unsigned)(NCH * NCH * 256 * sizeof(double)) : 0u, 0x00020000);
-  // Stagger: the workgroups of the first wave over the chip start together and take the same time
-  // per Lanczos step, so their serial phases (slot sums, Gram-Schmidt, norms) would coincide for
-  // the whole launch and HBM would idle through each of them.  Sixteen start offsets spread over
-  // one step period keep the chip streaming while some workgroups are in a serial phase.  (XCD =
-  // blockIdx % 8: every XCD gets every offset.)  Results do not depend on it.
-  if (stagger_ticks > 0 && (int)blockIdx.x < stagger_wgs) {
-    const unsigned long long wait = (unsigned long long)((blockIdx.x >> 3) & 15) * stagger_ticks;
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(64);
-  }
 #ifdef LNZ_LARGE_PROBE
   unsigned long long t_last = wall_clock64();
 #endif
@@ -338,6 +399,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       sm.qs[r] = q;
       if (r < N) Qg[(int64_t)j * N + r] = q;
     }
+    if (SYM && tid == 0) sched.next = 0;  // this step's job list is unclaimed again
     __syncthreads();
     LNZ_PROBE(0);
 
@@ -349,10 +411,23 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       //      gets an out-of-range offset and comes back as zeros without touching memory — so
       //      the loop has no branch around a load and every row waits for exactly its own
       //      (predicated flat loads made hipcc drain the whole ring once per group).
-      const int nj = __builtin_amdgcn_readfirstlane(sched.njobs[wave]);
-      const SymJob* jl = sched.jobs[wave];
+      const int total = __builtin_amdgcn_readfirstlane(sched.total);
+      uint2* mine = sched.mine[wave];
+      int ngrab = 0;     // jobs claimed so far
+      bool more = true;  // the list may have unclaimed jobs
+      auto grab = [&]() {
+        int id = 0;
+        if (lane == 0) id = atomicAdd(&sched.next, 1);
+        id = __builtin_amdgcn_readfirstlane(id);
+        if (id < total) {
+          if (lane == 0) mine[ngrab] = sched.all[id];
+          ++ngrab;
+        } else {
+          more = false;
+        }
+      };
       auto job_at = [&](int k, int& I, int& J, int& row0, int& nrow) {  // wave-uniform, in SGPRs
-        const uint2 raw = *reinterpret_cast<const uint2*>(&jl[k]);
+        const uint2 raw = mine[k];
         const unsigned lo = __builtin_amdgcn_readfirstlane(raw.x);
         const unsigned hi = __builtin_amdgcn_readfirstlane(raw.y);
         I = (int)(lo & 0xffffu); J = (int)(lo >> 16); row0 = (int)(hi & 0xffffu); nrow = (int)(hi >> 16);
@@ -364,7 +439,8 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       auto next_prefetch = [&]() {
         pvalid = 0;
         poff = kOob;
-        if (pj < nj) {
+        if (pj == ngrab && more) grab();
+        if (pj < ngrab) {
           int I, J, row0, nrow;
           job_at(pj, I, J, row0, nrow);
           const int c0 = 256 * J + 4 * lane;
@@ -392,7 +468,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
         // the worst case over the loop's entries, and a shuffled fill would cost a drain per group
         __builtin_amdgcn_sched_barrier(0);
       }
-      for (int cj = 0; cj < nj; ++cj) {
+      for (int cj = 0; cj < ngrab; ++cj) {  // (ngrab grows as the prefetch cursor claims jobs)
         int I, J, row0, nrow;
         job_at(cj, I, J, row0, nrow);
         // one code path for both kinds of job: a diagonal block reads its "q of the rows" from a
@@ -439,14 +515,14 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
           }
           double v[4];
           reduce16_f64(p, v);
-          if ((lane & 15) == 0) {
-            double* dst = cpart + (int64_t)J * (NCH * 256) + r0 + 4 * (lane >> 4);
+          if ((lane & 15) == 0) {  // row dots: slot J of chunk I (J > I), the diagonal block's to ws
+            double* dst = (offd ? sm.cslot[J - 1] : sm.ws) + r0 + 4 * (lane >> 4);
             *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
             *reinterpret_cast<double2*>(dst + 2) = make_double2(v[2], v[3]);
           }
         }
-        if (offd) {
-          double* dst = cpart + (int64_t)I * (NCH * 256) + 256 * J + 4 * lane;
+        if (offd) {  // column sums: slot I of chunk J (I < J)
+          double* dst = &sm.cslot[I][256 * J + 4 * lane];
           *reinterpret_cast<double2*>(dst) = make_double2(colacc[0], colacc[1]);
           *reinterpret_cast<double2*>(dst + 2) = make_double2(colacc[2], colacc[3]);
         }
@@ -454,22 +530,19 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
       LNZ_PROBE(1);
       __syncthreads();
       LNZ_PROBE(2);
-      // w = sum of the contribution slots in slot order; every load of a thread in flight at once
+      // w = the contributions of the eight blocks that touch a chunk, in block order (the
+      // diagonal block's is already in ws)
       const int nch = (N + 255) >> 8;
       part = 0.0;
-#pragma unroll
-      for (int k = 0; k < NCH * 256 / TPB; ++k) {
-        const int r = tid + k * TPB;
-        double c[NCH];
-#pragma unroll
-        for (int sl = 0; sl < NCH; ++sl) {  // (buffer loads: one offset register, no pointer table)
-          const unsigned off = (r < N && sl < nch) ? 8u * (unsigned)r : kOob;
-          const u2v raw = __builtin_amdgcn_raw_buffer_load_b64(c_rsrc, off, sl * (NCH * 256 * 8), 0);
-          c[sl] = __hiloint2double((int)raw.y, (int)raw.x);
-        }
+      for (int r = tid; r < NCH * 256; r += TPB) {
+        const int c = r >> 8;
+        const double diag = sm.ws[r];
         double acc = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < NCH; ++sl) acc += c[sl];
+        for (int sl = 0; sl < NCH; ++sl) {
+          const double x = sl == c ? diag : sm.cslot[sl - (sl > c ? 1 : 0)][r];
+          if (sl < nch && c < nch) acc += x;
+        }
         sm.ws[r] = acc;
         part = fma(acc, acc, part);  // |w|^2 on the way (rows past N are zeros)
       }
@@ -599,87 +672,11 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     sm.Zt[idx] = (i == r) ? 1.0 : 0.0;
   }
   __syncthreads();
-  // One wavefront runs the whole sweep (lane r owns row r of the accumulator, the scalars are
-  // recomputed by every lane): its LDS traffic is ordered by the wave itself, so a rotation costs
-  // no workgroup barrier.
-  if (wave == 0) {
-    double f = 0.0, tst1 = 0.0;
-    for (int l = 0; l < n; ++l) {
-      tst1 = fmax(tst1, fabs(sm.dd[l]) + fabs(sm.ee[l]));
-      int m = l;
-      while (m < n - 1 && fabs(sm.ee[m]) > kEpsD * tst1) ++m;
-      if (m > l) {
-        int iter = 0;
-        double el;
-        do {
-          ++iter;
-          double g = sm.dd[l];
-          el = sm.ee[l];
-          double p = (sm.dd[l + 1] - g) / (2.0 * el);
-          double rr = sqrt(p * p + 1.0);
-          if (p < 0) rr = -rr;
-          const double dl = el / (p + rr);
-          const double dl1 = el * (p + rr);
-          const double hh = g - dl;
-          wave_lds_sync();
-          if (tid == 0) {
-            sm.dd[l] = dl;
-            sm.dd[l + 1] = dl1;
-          }
-          if (tid >= l + 2 && tid < n) sm.dd[tid] -= hh;
-          wave_lds_sync();
-          f += hh;
-          p = sm.dd[m];
-          double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
-          const double el1 = sm.ee[l + 1];
-          double carry = tid < MMAX ? sm.Zt[m * ZLD + tid] : 0.0;
-          wave_lds_sync();
-          for (int i = m - 1; i >= l; --i) {
-            c3 = c2;
-            c2 = c;
-            s2 = s;
-            const double ei = sm.ee[i], di = sm.dd[i];
-            g = c * ei;
-            const double hp = c * p;
-            const double tt = fma(p, p, ei * ei);
-            const double rinv = rsqrt(tt);
-            const double rad = tt * rinv;
-            const double e_next = s * rad;
-            s = ei * rinv;
-            c = p * rinv;
-            p = c * di - s * g;
-            const double d_next = hp + s * (c * g + s * di);
-            wave_lds_sync();  // all threads have read ee[i], dd[i] (and ee[i+1] earlier)
-            if (tid == 0) {
-              sm.ee[i + 1] = e_next;
-              sm.dd[i + 1] = d_next;
-            }
-            if (tid < MMAX) {
-              const double z0 = sm.Zt[i * ZLD + tid];
-              sm.Zt[(i + 1) * ZLD + tid] = s * z0 + c * carry;
-              carry = c * z0 - s * carry;
-            }
-          }
-          if (tid < MMAX) sm.Zt[l * ZLD + tid] = carry;
-          wave_lds_sync();
-          p = -s * s2 * c3 * el1 * sm.ee[l] / dl1;
-          el = s * p;
-          wave_lds_sync();
-          if (tid == 0) {
-            sm.ee[l] = el;
-            sm.dd[l] = c * p;
-          }
-          wave_lds_sync();
-        } while (fabs(el) > kEpsD * tst1 && iter < 60);
-      }
-      wave_lds_sync();
-      if (tid == 0) {
-        sm.dd[l] = sm.dd[l] + f;
-        sm.ee[l] = 0.0;
-      }
-      wave_lds_sync();
-    }
-  }
+  // One wavefront runs the whole sweep: lane r holds d_r and e_r in registers (a wave-uniform
+  // element is a v_readlane away: no LDS on the rotation chain) and owns column r of the
+  // accumulator rows in LDS (nobody else touches it: no barrier, no fence); the rotation scalars
+  // are recomputed by every lane.  Same recurrences as before, rotation for rotation.
+  if (wave == 0) tql2_wave(sm, n, lane);
   __syncthreads();
 
   LNZ_PROBE(8);
@@ -760,28 +757,12 @@ static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int 
               (long long)stride_r);
   double* basis = (double*)workspace;
   double* part = basis + (int64_t)B * MMAX * N;
-  // start offsets of the first wave of workgroups (see the kernel): one sixteenth of the time one
-  // Lanczos step of all resident graphs takes at ~6.5 TB/s, in ticks of the 100 MHz wall clock
-  int dev = 0, n_cu = 256;
-  if (hipGetDevice(&dev) == hipSuccess)
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-  const int resident = B < n_cu ? B : n_cu;
-  const int nch = (N + 255) / 256;
-  const double step_bytes = (sym ? 0.5 * nch * (nch + 1) : (double)nch * nch) * 256.0 * 256.0 * 4.0;
-  // (measured neutral so far — 26.3 vs 26.5 ms — so off unless LNZ_LARGE_STAGGER_US asks: a
-  // negative value selects one sixteenth of the estimated step time)
-  double stagger_us = 0.0;
-  if (const char* e = getenv("LNZ_LARGE_STAGGER_US")) stagger_us = atof(e);
-  if (stagger_us < 0) stagger_us = resident * step_bytes / 6.5e6 / 16.0;
-  const int ticks = stagger_us < 0 ? 0 : stagger_us > 1e4 ? 1000000 : (int)(stagger_us * 100.0);
   if (sym)
     hipLaunchKernelGGL(lanczos_ritz_large_kernel<true>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info,
-                       ticks, resident);
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
   else
     hipLaunchKernelGGL(lanczos_ritz_large_kernel<false>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info,
-                       ticks, resident);
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
   return lnz::check_launch(who);
 }
 

@@ -88,6 +88,62 @@ void run(const float* A, float* out, int B) {
          bytes / best / 1e6);
 }
 
+// Interleaved rows: wave w reads rows w, w + 8, w + 16, ... — the eight waves of a workgroup
+// cover 64 KiB of consecutive memory at any time (the full-stream kernel's order).  TRI: only
+// the columns from the row's own 256-column chunk on (the upper block triangle, 56 % of the bytes).
+template <bool TRI>
+__global__ __launch_bounds__(512) void rows_kernel(const float* __restrict__ A, float* out, int reps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* Ab = A + (size_t)blockIdx.x * N * N;
+  float acc = 0.f;
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int I = 0; I < 8; ++I) {
+      const int c0 = TRI ? I : 0;
+      float4 a0[8], a1[8];
+      auto load_row = [&](int r, float4 (&a)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c >= c0) a[c] = ld_nt(Ab + (size_t)r * N + 256 * c + 4 * lane);
+      };
+      auto use_row = [&](const float4 (&a)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c >= c0) acc += a[c].x + a[c].y + a[c].z + a[c].w;
+      };
+      int r = 256 * I + wave;
+      load_row(r, a0);
+      for (; r < 256 * I + 256; r += 16) {
+        load_row(r + 8, a1);
+        use_row(a0);
+        if (r + 16 < 256 * I + 256) load_row(r + 16, a0);
+        use_row(a1);
+      }
+    }
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
+
+template <bool TRI>
+void run_rows(const float* A, float* out, int B) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 4;
+  hipLaunchKernelGGL((rows_kernel<TRI>), dim3(B), dim3(512), 0, 0, A, out, 1);
+  CK(hipDeviceSynchronize());
+  float best = 1e9f;
+  for (int t = 0; t < 3; ++t) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((rows_kernel<TRI>), dim3(B), dim3(512), 0, 0, A, out, reps);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  const double bytes = (double)B * N * N * 4 * reps * (TRI ? 36.0 / 64.0 : 1.0);
+  printf("interleaved rows, %s: %.3f ms  %.0f GB/s\n", TRI ? "upper block triangle" : "full rows", best,
+         bytes / best / 1e6);
+}
+
 int main() {
   const int B = 256;
   float *A, *out;
@@ -107,5 +163,7 @@ int main() {
   run<8, false, 2>(A, out, B);
   run<1, true, 2, true>(A, out, B);
   run<1, true, 0, true>(A, out, B);
+  run_rows<false>(A, out, B);
+  run_rows<true>(A, out, B);
   return 0;
 }
