@@ -137,8 +137,8 @@ int lnz_tridiag_eigh(const double* diag, const double* offdiag, int B, int M, do
  * The reference's counterpart is scipy.sparse.linalg.eigsh(L, k, which='LM')
  * (utils/data_helper.py:205-208, ARPACK, implicitly restarted): converged leading pairs agree,
  * unconverged ones are a different function — see oracle/lanczos_kstep.py.
- * workspace: lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes of device memory (Krylov basis
- * and the symmetric variant's contribution slots, fp64).  D [B,K], V [B,N,K]; info [B] (optional) = Lanczos steps actually taken. */
+ * workspace: lnz_lanczos_ritz_large_workspace_bytes(B, N) bytes of device memory (the fp64 Krylov
+ * basis, B x 64 x N).  D [B,K], V [B,N,K]; info [B] (optional) = Lanczos steps actually taken. */
 int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N);
 int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B, int N,
                            int M, int K, void* workspace, float* D, float* V, int32_t* info,

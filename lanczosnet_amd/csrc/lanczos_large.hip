@@ -354,7 +354,7 @@ __device__ unsigned long long g_large_probe[16];
 template <bool SYM>
 __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int N, int M, int K,
-    double* __restrict__ work, double* __restrict__ part_all, float* __restrict__ D,
+    double* __restrict__ work, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info) {
   __shared__ __attribute__((aligned(16))) LargeSmem sm;
   __shared__ SymSched sched;
@@ -736,9 +736,9 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
 
 }  // namespace
 
-// Krylov basis [B][MMAX][N] fp64, then the symmetric kernel's contribution slots [B][NCH][NCH*256]
+// Krylov basis [B][MMAX][N] fp64
 extern "C" int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N) {
-  return ((int64_t)B * MMAX * N + (int64_t)B * NCH * NCH * 256) * (int64_t)sizeof(double);
+  return (int64_t)B * MMAX * N * (int64_t)sizeof(double);
 }
 
 static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int B, int N, int M,
@@ -756,13 +756,12 @@ static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int 
               LNZ_ENOTSUP, "%s: one graph must span less than 4 GiB (row stride %lld)", who,
               (long long)stride_r);
   double* basis = (double*)workspace;
-  double* part = basis + (int64_t)B * MMAX * N;
   if (sym)
     hipLaunchKernelGGL(lanczos_ritz_large_kernel<true>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, D, V, info);
   else
     hipLaunchKernelGGL(lanczos_ritz_large_kernel<false>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, part, D, V, info);
+                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, D, V, info);
   return lnz::check_launch(who);
 }
 
