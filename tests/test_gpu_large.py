@@ -69,6 +69,26 @@ def test_symmetric_stream_reads_only_the_upper_chunk_blocks():
   assert (P0 - P1).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize('sym', [False, True])
+def test_large_lanczos_strided_view_equals_contiguous(sym):
+  """Row and graph strides come through the ABI (the symmetric kernel addresses A through a buffer
+  descriptor with 32-bit offsets): a view into a wider, NaN-padded allocation gives the very same
+  Ritz pairs as the contiguous copy — and so does a second call (no atomics anywhere)."""
+  from lanczosnet_amd import ops
+  N, M, B = 772, 24, 3
+  A = torch.from_numpy(_graphs(B, N, 8.0 / N, seed=9)).to(DEV)
+  wide = torch.full((B + 1, N + 3, N + 20), float('nan'), dtype=torch.float32, device=DEV)
+  view = wide[:B, :N, 4:4 + N]
+  view.copy_(A)
+  assert not view.is_contiguous() and view.stride(1) == N + 20
+  D0, V0 = ops.lanczos_ritz_large(A, M, M, symmetric=sym)
+  D1, V1 = ops.lanczos_ritz_large(view, M, M, symmetric=sym)
+  D2, V2 = ops.lanczos_ritz_large(view, M, M, symmetric=sym)
+  assert torch.isfinite(D1).all() and torch.isfinite(V1).all()
+  assert torch.equal(D0, D1) and torch.equal(V0, V1)
+  assert torch.equal(D1, D2) and torch.equal(V1, V2)
+
+
 def test_large_lanczos_early_stop_on_invariant_subspace():
   from lanczosnet_amd import ops
   # block-diagonal graph whose start vector's Krylov space is tiny: A = I (no edges)
