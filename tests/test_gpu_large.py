@@ -89,6 +89,42 @@ def test_large_lanczos_strided_view_equals_contiguous(sym):
   assert torch.equal(D1, D2) and torch.equal(V1, V2)
 
 
+def test_large_lanczos_config5_full_size_properties():
+  """BASELINE configs[4] at its full size (B = 256 graphs of N = 2048 nodes, M = K = 64), where the
+  fp64 restatement is too slow to be the checker: what must hold for ANY correct M-step Lanczos —
+  orthonormal Ritz vectors, Ritz values inside the spectrum's interval [-1, 1] in the canonical
+  order, lambda_max = 1 of the L4 Laplacian found with a vanishing residual, every Ritz pair a
+  Rayleigh-Ritz pair (V^T A V = diag(D)), and the symmetric stream equal to the full stream."""
+  from lanczosnet_amd import ops
+  B, N, M = 256, 2048, 64
+  g = torch.Generator(device=DEV)
+  g.manual_seed(11)
+  A = torch.empty((B, N, N), dtype=torch.float32, device=DEV)
+  for b in range(B):
+    adj = (torch.rand((N, N), generator=g, device=DEV) < 0.01).float().triu(1)
+    adj = adj + adj.t() + torch.eye(N, device=DEV)
+    d = adj.sum(1).rsqrt()
+    A[b] = d[:, None] * adj * d[None, :]
+  D, V, info = ops.lanczos_ritz_large(A, M, M, return_info=True, symmetric=True)
+  assert (info == M).all() and torch.isfinite(D).all() and torch.isfinite(V).all()
+  Vd = V.double()
+  eye = torch.eye(M, dtype=torch.float64, device=DEV)
+  assert (Vd.transpose(1, 2) @ Vd - eye).abs().max() < 1e-5           # orthonormal
+  assert D.abs().max() <= 1.0 + 1e-6
+  assert (D.abs()[:, :-1] >= D.abs()[:, 1:] - 1e-7).all()              # descending |theta|
+  assert (D[:, 0] - 1.0).abs().max() < 1e-6                            # lambda_max of L4
+  AV = torch.bmm(A, V)                                                 # fp32 is enough here
+  res0 = (AV[:, :, 0] - V[:, :, 0] * D[:, None, 0]).norm(dim=1)
+  assert res0.max() < 1e-5                                             # the converged leading pair
+  H = torch.bmm(V.transpose(1, 2), AV).double()                        # Rayleigh-Ritz: V^T A V = diag(D)
+  assert (H - torch.diag_embed(D.double())).abs().max() < 2e-5
+  del AV, H, Vd
+  D0, V0 = ops.lanczos_ritz_large(A, M, M)                             # full stream: same pairs
+  assert (D0 - D).abs().max() < 1e-6
+  sgn = torch.sign((V0 * V).sum(dim=1, keepdim=True))
+  assert (V0 * sgn - V).abs().max() < 1e-4
+
+
 def test_large_lanczos_early_stop_on_invariant_subspace():
   from lanczosnet_amd import ops
   # block-diagonal graph whose start vector's Krylov space is tiny: A = I (no edges)
