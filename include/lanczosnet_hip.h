@@ -55,19 +55,36 @@ int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B, int N, in
  *            lane order, Ritz vectors V = Q*S; the implicit-shift QL sweep only as the fallback
  *            (info += 256);
  *   32 < N <= 64: implicit-shift QL (tql2 recurrences) with the rotations applied to Q, so the
- *            Ritz vectors come out directly;
+ *            Ritz vectors come out directly; one wavefront per graph, everything in LDS;
+ *   64 < N <= 192 (the reference's synthetic-graph configuration, dataset/get_graph_data.py:15-49
+ *            with config/graph_lanczos_net.yaml: n in [20,100]): one 256-thread workgroup per
+ *            graph, A staged once into LDS, the fp64 basis in LDS up to N = 113 and in a workspace
+ *            above (lnz_lanczos_ritz_workspace_bytes; without one lnz_lanczos_ritz takes a
+ *            stream-ordered allocation for the launch), the same QL sweep run barrier-free;
  * then stable ordering by descending |lambda| (ties: ascending lambda), cut / zero-pad to K.
  * Produces exactly
  * the (D, V) that utils/data_helper.py:197-223 (np.linalg.eigh + mergesort on -|eig|)
  * followed by dataset/qm8.py:264-291 (pad rows to N, cut/pad to K, cast fp32) produce,
  * up to the basis of degenerate eigenspaces and eigenvector sign.  fp64 arithmetic.
  * A is addressed as A[b*stride_b + r*stride_r + c*stride_c] (elements) so channel 0 of a
- * channels-last L [B,N,N,E+1] can be passed without a copy.  N <= 64.
+ * channels-last L [B,N,N,E+1] can be passed without a copy.  N <= 192 (LNZ_ENOTSUP above: only
+ * the K-step streamed kernels below apply there, a different function — SURVEY.md F8).
  * D [B,K], V [B,N,K].  info [B] (optional, may be NULL): number of Lanczos restarts, + 256 when
  * the N <= 32 kernel fell back from its parallel tridiagonal eigensolver to the QL sweep. */
 int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                      const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                      int32_t* info, lnz_stream_t stream);
+
+/* The same with an explicit workspace for the fp64 Krylov basis of graphs too large to keep it in
+ * LDS next to A (N > 113): lnz_lanczos_ritz_workspace_bytes(B, N) bytes (0 when none is needed).
+ * Always takes the workgroup-per-graph kernel (any N <= 192); flags bit 0 places the basis in the
+ * workspace even when it would fit in LDS (used by the tests to cover both variants at one size). */
+int64_t lnz_lanczos_ritz_workspace_bytes(int B, int N);
+int lnz_lanczos_ritz_ws(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                        const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
+                        int32_t* info, void* workspace, int64_t workspace_bytes, int flags,
+                        lnz_stream_t stream);
+
 
 /* ---- R9 / R11 beyond the 32-node tile: streamed spectral convolution for large dense graphs ----
  * (BASELINE config 5: LanczosNetGeneral, N = 2048, K = 64, batch 256, bf16 operands / fp32

@@ -54,6 +54,8 @@ SIGNATURES = {
     'lnz_last_error': (C.c_char_p, []),
     'lnz_laplacian_l4': (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     'lnz_lanczos_ritz': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'lnz_lanczos_ritz_workspace_bytes': (C.c_int64, [_I, _I]),
+    'lnz_lanczos_ritz_ws': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P, _L, _I, _P]),
     'lnz_tridiag_eigh': (C.c_int, [_P, _P, _I, _I, _P, _P, _P]),
     'lnz_lanczos_ritz_large_workspace_bytes': (C.c_int64, [_I, _I]),
     'lnz_lanczos_ritz_large': (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

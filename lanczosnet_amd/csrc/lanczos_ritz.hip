@@ -1168,15 +1168,22 @@ extern "C" int lnz_prepare_batch_prev_gains(
   return lnz::check_launch("lnz_prepare_batch_prev_gains");
 }
 
+int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                       const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
+                       int32_t* info, void* workspace, int64_t workspace_bytes, int flags,
+                       hipStream_t s);  // lanczos_ritz_wg.hip
+
 extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r,
                                 int64_t stride_c, const int32_t* n_nodes, int B, int N, int K,
                                 float* D, float* V, int32_t* info, lnz_stream_t stream) {
   LNZ_REQUIRE(A && n_nodes && D && V && B > 0 && N > 0 && K > 0, LNZ_EINVAL,
               "lnz_lanczos_ritz: bad arguments (B=%d N=%d K=%d)", B, N, K);
-  LNZ_REQUIRE(N <= 64, LNZ_ENOTSUP,
-              "lnz_lanczos_ritz: N=%d > 64: use lnz_lanczos_ritz_large / _sym (streamed kernels)",
-              N);
   hipStream_t s = (hipStream_t)stream;
+  // 64 < N <= 192: one workgroup per graph (lanczos_ritz_wg.hip); beyond that only the K-step
+  // streamed kernels apply (a different function)
+  if (N > 64)
+    return lnz_launch_ritz_wg(A, stride_b, stride_r, stride_c, n_nodes, B, N, K, D, V, info, nullptr,
+                              0, 0, s);
   if (N <= 32) {
     hipLaunchKernelGGL(lanczos_ritz32_kernel, dim3(B), dim3(64), 0, s, A, stride_b, stride_r,
                        stride_c, n_nodes, N, K, D, V, info);

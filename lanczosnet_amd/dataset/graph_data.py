@@ -1,0 +1,119 @@
+"""Dataset surface of the reference's synthetic-graph experiment (`dataset/graph_data.py:11-293`,
+`config/graph_lanczos_net.yaml`, pickles written by `dataset/get_graph_data.py:51-92`).
+
+Graphs of 20..100 nodes with float node embeddings `X [n, node_emb_dim]`, ONE edge type and a
+graph-level label `Y [1, graph_emb_dim]`; the model is `LanczosNetGeneral`.  Same two entry points as
+`dataset/qm8.py` here:
+
+* `collate_graph_preprocessed(items, num_eigs)` — items are the reference's per-graph pickle dicts
+  (node_feat, L_multi, L_simple_4, D_simple, V_simple, label); the host-side padding of the
+  reference's default branch (`dataset/graph_data.py:222-291`);
+* `collate_graph_adjacency(items, num_eigs, device)` — items carry only the RAW graph (`adjs [n,n,E]`,
+  `node_feat [n,D]`, `label [1,P]`); the Laplacians (`lnz_laplacian_l4`, replacing
+  get_graph_data.py:61-72) and the Ritz pairs (`lnz_lanczos_ritz`, workgroup-per-graph kernel for
+  N > 64, replacing utils/data_helper.py:197-223 and the pad / cut of graph_data.py:262-287) are
+  computed ON THE DEVICE.
+
+`GraphData(config, split)` is the class the runner instantiates with
+`eval(config.dataset.loader_name)(config, split=...)` (runner/graph_runner.py:38-40).
+
+Returned keys (reference dict): node_feat [B,N,D] float32, node_mask [B,N] uint8, label [B,P] float32,
+L [B,N,N,E+1] float32, D [B,K], V [B,N,K].
+"""
+import numpy as np
+import torch
+
+
+def _pad_common(items):
+    sizes = [int(np.asarray(it['node_feat']).shape[0]) for it in items]
+    B, N = len(items), max(sizes)
+    dim = int(np.asarray(items[0]['node_feat']).shape[1])
+    node_feat = np.zeros((B, N, dim), dtype=np.float32)
+    mask = np.zeros((B, N), dtype=np.uint8)
+    for b, (it, n) in enumerate(zip(items, sizes)):
+        node_feat[b, :n] = np.asarray(it['node_feat'])   # float64 pickles -> .float() (:68-75)
+        mask[b, :n] = 1
+    label = np.concatenate([np.asarray(it['label'], dtype=np.float64).reshape(1, -1)
+                            for it in items], axis=0).astype(np.float32)
+    return sizes, B, N, node_feat, mask, label
+
+
+def collate_graph_preprocessed(items, num_eigs, simple_key='L_simple_4', negate_simple=False):
+    """Host-side restatement of the reference's default branch (dataset/graph_data.py:222-291)."""
+    sizes, B, N, node_feat, mask, label = _pad_common(items)
+    E = np.asarray(items[0]['L_multi']).shape[2]
+    L = np.zeros((B, N, N, E + 1), dtype=np.float32)
+    for b, (it, n) in enumerate(zip(items, sizes)):
+        ls = np.asarray(it[simple_key])
+        L[b, :n, :n, 0] = -ls if negate_simple else ls
+        L[b, :n, :n, 1:] = it['L_multi']
+    out = dict(node_feat=torch.from_numpy(node_feat), node_mask=torch.from_numpy(mask),
+               label=torch.from_numpy(label), L=torch.from_numpy(L))
+    if num_eigs:
+        D = np.zeros((B, num_eigs), dtype=np.float32)
+        V = np.zeros((B, N, num_eigs), dtype=np.float32)
+        for b, (it, n) in enumerate(zip(items, sizes)):
+            d, v = np.asarray(it['D_simple']), np.asarray(it['V_simple'])
+            kk = min(num_eigs, d.shape[0])
+            D[b, :kk] = d[:kk]
+            V[b, :n, :kk] = v[:, :kk]
+        out['D'], out['V'] = torch.from_numpy(D), torch.from_numpy(V)
+    return out
+
+
+def collate_graph_adjacency(items, num_eigs, device='cuda'):
+    """Raw graphs in, device-resident batch out (L4 and Ritz pairs by the HIP kernels)."""
+    from .. import ops
+    sizes, B, N, node_feat, mask, label = _pad_common(items)
+    E = np.asarray(items[0]['adjs']).shape[2]
+    adjs = np.zeros((B, N, N, E), dtype=np.float32)
+    for b, (it, n) in enumerate(zip(items, sizes)):
+        adjs[b, :n, :n, :] = it['adjs']
+    dev = torch.device(device)
+    n_nodes = torch.tensor(sizes, dtype=torch.int32, device=dev)
+    L = ops.laplacian_l4(torch.from_numpy(adjs).to(dev), n_nodes)
+    D, V = ops.lanczos_ritz(L[:, :, :, 0], n_nodes, num_eigs)
+    return dict(node_feat=torch.from_numpy(node_feat).to(dev),
+                node_mask=torch.from_numpy(mask).to(dev), label=torch.from_numpy(label).to(dev),
+                L=L, D=D, V=V, n_nodes=n_nodes)
+
+
+class GraphData(object):
+    """Drop-in for reference `dataset/graph_data.py:11-293`: globs `synthetic_{split}_*.p` under
+    `config.dataset.data_path`, one pickle per graph, `collate_fn` pads a list of them to the batch
+    maximum.  The file lists are SORTED (the reference keeps `glob.glob`'s directory order,
+    :28-33).  Branches built: the default one (LanczosNetGeneral, GCN, ... with `L_simple_4`),
+    DCNN (`L_simple_7`) and ChebyNet (`-L_simple_6`), :247-260; GPNN / GraphSAGE / GAT build
+    partition, neighbour-sampling and attention-bias tensors for models outside this path."""
+
+    def __init__(self, config, split='train'):
+        import glob
+        import os
+        assert split in ('train', 'dev', 'test'), 'no such split'
+        self.split, self.config = split, config
+        self.seed = config.seed
+        self.data_path = config.dataset.data_path
+        self.num_edgetype = config.dataset.num_edge_type
+        self.model_name = config.model.name
+        self.use_eigs = hasattr(config.model, 'num_eig_vec')
+        self.num_eigs = config.model.num_eig_vec if self.use_eigs else 0
+        self.files = sorted(glob.glob(os.path.join(self.data_path, 'synthetic_%s_*.p' % split)))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, index):
+        import pickle
+        with open(self.files[index], 'rb') as f:
+            return pickle.load(f)
+
+    def collate_fn(self, batch):
+        assert isinstance(batch, list)
+        if self.model_name in ('GPNN', 'GraphSAGE', 'GAT'):
+            raise NotImplementedError('GraphData mirrors the default collate branch '
+                                      '(LanczosNetGeneral, GCN, DCNN, ChebyNet); got %s'
+                                      % self.model_name)
+        key = {'DCNN': 'L_simple_7', 'ChebyNet': 'L_simple_6'}.get(self.model_name, 'L_simple_4')
+        return collate_graph_preprocessed(batch, self.num_eigs if self.use_eigs else 0,
+                                          simple_key=key,
+                                          negate_simple=self.model_name == 'ChebyNet')

@@ -53,14 +53,19 @@ def laplacian_l4(adjs, n_nodes):
 
 
 # ------------------------------------------------------------------------------------- R2 + R6
-def lanczos_ritz(A, n_nodes, K, return_info=False):
+def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   """Batched Lanczos -> tridiagonal eigensolve -> Ritz select.
 
   A: [B,N,N] float32 symmetric (any strides: pass `L[..., 0]` of a channels-last Laplacian
-  without copying).  n_nodes: [B] real node counts (rows/cols >= n are ignored).
-  Returns D [B,K], V [B,N,K] exactly like the collated `D`, `V` of dataset/qm8.py:264-291."""
+  without copying), N <= 192.  n_nodes: [B] real node counts (rows/cols >= n are ignored).
+  Returns D [B,K], V [B,N,K] exactly like the collated `D`, `V` of dataset/qm8.py:264-291 /
+  dataset/graph_data.py:262-287.
+  kernel: 'auto' (wavefront per graph up to N = 64, workgroup per graph above), 'workgroup'
+  (workgroup per graph at any N), 'workgroup_ws' (the same with the fp64 basis in a device
+  workspace instead of LDS — what 'auto' does for N > 113)."""
   _need_cuda(A, n_nodes)
   assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
+  assert kernel in ('auto', 'workgroup', 'workgroup_ws')
   B, N, _ = A.shape
   n_nodes = n_nodes.to(torch.int32).contiguous()
   D = torch.empty((B, K), dtype=torch.float32, device=A.device)
@@ -69,8 +74,16 @@ def lanczos_ritz(A, n_nodes, K, return_info=False):
   sb, sr, sc = A.stride()
   lib = _lib.load()
   with torch.cuda.device(A.device):
-    _lib.check(lib.lnz_lanczos_ritz(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D), _ptr(V),
-                                    _ptr(info), _stream()))
+    if kernel == 'auto' and N <= 64:
+      _lib.check(lib.lnz_lanczos_ritz(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D),
+                                      _ptr(V), _ptr(info), _stream()))
+    else:
+      # the workspace (if any) comes from torch's caching allocator, not from a hipMallocAsync
+      flags = 1 if kernel == 'workgroup_ws' else 0
+      need = B * N * (N | 1) * 8 if flags else lib.lnz_lanczos_ritz_workspace_bytes(B, N)
+      ws = torch.empty((need,), dtype=torch.uint8, device=A.device) if need else None
+      _lib.check(lib.lnz_lanczos_ritz_ws(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D),
+                                         _ptr(V), _ptr(info), _ptr(ws), need, flags, _stream()))
   return (D, V, info) if return_info else (D, V)
 
 

@@ -1,0 +1,180 @@
+"""GPU parity on the reference's OWN graph configuration (config/graph_lanczos_net.yaml: graphs of
+20..100 nodes, K = 20, one edge type, LanczosNetGeneral 10 -> 7 x 128 -> 2; batch sizes 10 and 64).
+
+Fixture: tests/golden/graph_config.npz — the unmodified reference run end to end in the build
+container (dataset/get_graph_data.py -> dataset/graph_data.py -> model/lanczos_net_general.py), see
+tests/golden/make_golden_graph.py.  Everything here goes through the C ABI:
+
+  raw adjacency --lnz_laplacian_l4--> L --lnz_lanczos_ritz (workgroup-per-graph kernel)--> (D, V)
+               --LanczosNetGeneral (lnz_large_* streamed kernels, split-precision planes)--> score
+
+Tolerances: L 1e-7 abs, sorted D 1e-6 abs, V diag(D^p) V^T 1e-5 rel for
+p in {1, 5, 30}, score 1e-5 rel per graph.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from graph_fixture import GRAPH_CFG, check_ritz, load_split, pad_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+K = GRAPH_CFG['num_eig_vec']
+
+
+def _t(x):
+  return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def _net(seed):
+  from lanczosnet_amd.model import LanczosNetGeneral
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  P = oracle.make_lanczosnet_params(GRAPH_CFG, seed, general=True)
+  net = LanczosNetGeneral(make_model_config(GRAPH_CFG, general=True)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  return net.to(DEV)
+
+
+def _eigh_ref(A, ns, N, Kk):
+  Dl, Vl, full = [], [], np.zeros((len(ns), N))
+  for b, n in enumerate(ns):
+    e, v = np.linalg.eigh(A[b, :n, :n].astype(np.float64))
+    idx = np.argsort(-np.abs(e), kind='mergesort')
+    Dl.append(e[idx])
+    Vl.append(v[:, idx])
+    full[b, :n] = e[idx]
+  Dr, Vr = oracle.collate_eigs(Dl, Vl, N, Kk)
+  return Dr, Vr, full
+
+
+@pytest.mark.parametrize('split', ['train', 'test'])
+def test_graph_config_device_pipeline_matches_reference(split):
+  from lanczosnet_amd import ops
+  items, ref, seed, _ = load_split(split)
+  adjs, X, mask, n = pad_batch(items)
+  N = mask.shape[1]
+  assert N > 64   # the regime the wavefront-per-graph kernels do not cover
+  nd = _t(n)
+  L = ops.laplacian_l4(_t(adjs), nd)
+  if split == 'train':
+    assert np.abs(L[..., 0].cpu().numpy() - ref['L0']).max() < 1e-7
+  assert torch.equal(L[..., 0], L[..., 1])
+  D, V, info = ops.lanczos_ritz(L[:, :, :, 0], nd, K, return_info=True)   # strided view, no copy
+  Dn, Vn = D.cpu().numpy(), V.cpu().numpy()
+  wd, wp, checked = check_ritz(Dn, Vn, ref['D'], ref['V'], n, ref['D_full'], K)
+  assert checked == len(n)
+  print('graph config %s: B=%d N=%d  max|dD| %.2e  worst projector %.2e  restarts %d'
+        % (split, len(n), N, wd, wp, int(info.sum())))
+  net = _net(seed)
+  lab = _t(ref['label'])
+  with torch.no_grad():
+    score, loss = net(_t(X), L, D, V, label=lab, mask=_t(mask))
+    score_ref_dv = net(_t(X), L, _t(ref['D']), _t(ref['V']), mask=_t(mask))
+  for s in (score, score_ref_dv):
+    per = np.abs(s.cpu().numpy() - ref['score']).max(axis=1) / np.abs(ref['score']).max(axis=1)
+    assert per.max() < 1e-5, per
+  assert abs(float(loss) - ref['loss']) < 1e-5 * ref['loss']
+
+
+def test_graph_collate_adjacency_is_the_device_pipeline():
+  from lanczosnet_amd.dataset.graph_data import collate_graph_adjacency
+  items, ref, seed, _ = load_split('train')
+  data = collate_graph_adjacency(items, K, device=DEV)
+  n = ref['n_nodes']
+  np.testing.assert_array_equal(data['n_nodes'].cpu().numpy(), n)
+  np.testing.assert_array_equal(data['label'].cpu().numpy(), ref['label'])
+  assert np.abs(data['L'][..., 0].cpu().numpy() - ref['L0']).max() < 1e-7
+  check_ritz(data['D'].cpu().numpy(), data['V'].cpu().numpy(), ref['D'], ref['V'], n,
+             ref['D_full'], K)
+  net = _net(seed)
+  with torch.no_grad():
+    score = net(data['node_feat'], data['L'], data['D'], data['V'], mask=data['node_mask'])
+  per = np.abs(score.cpu().numpy() - ref['score']).max(axis=1) / np.abs(ref['score']).max(axis=1)
+  assert per.max() < 1e-5, per
+
+
+def _random_laplacians(rs, B, N, n_lo, n_hi, p):
+  A = np.zeros((B, N, N), np.float32)
+  ns = rs.randint(n_lo, n_hi + 1, size=B).astype(np.int32)
+  ns[0] = N
+  for b in range(B):
+    n = ns[b]
+    adj = np.triu((rs.rand(n, n) < p).astype(np.float64), 1)
+    A[b, :n, :n] = oracle.laplacian_l4(adj + adj.T)
+  return A, ns
+
+
+@pytest.mark.parametrize('N,p', [(70, 0.5), (100, 0.08), (113, 0.3), (114, 0.3), (150, 0.5),
+                                 (192, 0.012)])
+def test_workgroup_ritz_kernel_matches_eigh(N, p):
+  """Both placements of the basis (LDS up to N = 113, device workspace above) against
+  numpy.linalg.eigh + the reference's |lambda| sort, incl. sparse graphs with isolated nodes /
+  several components (exactly degenerate eigenvalues -> Lanczos restarts)."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(N)
+  Kk = 24
+  A, ns = _random_laplacians(rs, 5, N, max(2, N // 3), N, p)
+  Dr, Vr, full = _eigh_ref(A, ns, N, Kk)
+  D, V, info = ops.lanczos_ritz(_t(A), _t(ns), Kk, return_info=True)
+  wd, wp, c = check_ritz(D.cpu().numpy(), V.cpu().numpy(), Dr, Vr, ns, full, Kk, powers=(1, 5))
+  assert c >= 3
+  if p < 0.1:
+    assert int(info.sum()) > 0   # the restart branch ran
+  # the workspace variant is the same arithmetic in the same order: bit-identical results
+  D2, V2 = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel='workgroup_ws')
+  assert torch.equal(D, D2) and torch.equal(V, V2)
+  # K >= n (nothing cut): every slot is checked, zero padded beyond n
+  D3, V3 = ops.lanczos_ritz(_t(A[:2]), _t(ns[:2]), N)
+  Dr3, Vr3, full3 = _eigh_ref(A[:2], ns[:2], N, N)
+  assert np.abs(D3.cpu().numpy() - Dr3).max() < 1e-6
+  assert (V3.cpu().numpy()[1, :, ns[1]:] == 0).all()
+
+
+def test_workgroup_ritz_kernel_small_graphs_and_edge_cases():
+  """The workgroup kernel at the sizes the wavefront kernels own (cross-check of two independent
+  implementations of the same function), with an empty graph, single nodes, a star, a ring, a
+  complete graph and disconnected pieces."""
+  from lanczosnet_amd import ops
+  N = 40
+  mats, ns = [], []
+
+  def add(adj):
+    n = adj.shape[0]
+    A = np.zeros((N, N), np.float32)
+    A[:n, :n] = oracle.laplacian_l4(adj)
+    mats.append(A)
+    ns.append(n)
+  n = 33
+  star = np.zeros((n, n)); star[0, 1:] = 1; star[1:, 0] = 1
+  ring = np.zeros((n, n))
+  for i in range(n):
+    ring[i, (i + 1) % n] = ring[(i + 1) % n, i] = 1
+  two = np.zeros((n, n)); two[:16, :16] = ring[:16, :16]; two[16:, 16:] = star[:17, :17]
+  add(star); add(ring); add(np.ones((n, n)) - np.eye(n)); add(np.zeros((7, 7))); add(two)
+  add(np.zeros((1, 1))); add(np.ones((2, 2)) - np.eye(2))
+  rs = np.random.RandomState(3)
+  for _ in range(4):
+    m = int(rs.randint(5, N + 1))
+    a = np.triu((rs.rand(m, m) < 0.2).astype(np.float64), 1)
+    add(a + a.T)
+  A = np.stack(mats + [np.zeros((N, N), np.float32)])
+  ns = np.array(ns + [0], np.int32)
+  Kk = 20
+  for kern in ('workgroup', 'workgroup_ws'):
+    D, V = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel=kern)
+    D, V = D.cpu().numpy(), V.cpu().numpy()
+    assert np.isfinite(D).all() and np.isfinite(V).all()
+    assert (D[-1] == 0).all() and (V[-1] == 0).all()
+    Dr, Vr, full = _eigh_ref(A[:-1], ns[:-1], N, Kk)
+    check_ritz(D[:-1], V[:-1], Dr, Vr, ns[:-1], full, Kk, powers=(1, 5, 30))
+  # against the wavefront-per-graph kernel (N <= 64): same function, independent schedule
+  Dw, Vw = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel='auto')
+  assert np.abs(Dw.cpu().numpy() - D).max() < 1e-6
+
+
+def test_lanczos_ritz_rejects_graphs_beyond_one_workgroup():
+  from lanczosnet_amd import ops, _lib
+  A = torch.zeros((1, 200, 200), device=DEV)
+  with pytest.raises(_lib.NotSupported):
+    ops.lanczos_ritz(A, torch.tensor([200], dtype=torch.int32, device=DEV), 20)
