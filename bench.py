@@ -401,6 +401,11 @@ def main():
                        '(profiles/r02_c_bench.json holds a run with it)')
   ap.add_argument('--gemm', default='fp32', choices=['fp32', 'f16x3'],
                   help="fp32 = exact fp32 MFMA (headline); f16x3 = opt-in split-precision GEMM1")
+  ap.add_argument('--dist', default='auto', choices=['auto', 'nccl'],
+                  help="auto: a process group only for --gpus > 1; nccl: initialise the RCCL group "
+                       "even at world size 1 (launched through torch.distributed.run) and send every "
+                       "step's scores through the real all-gather — how the exchange is exercised on "
+                       "a box with one GPU")
   ap.add_argument('--zero-params', action='store_true',
                   help='diagnostic only (power/DVFS probe): all-zero weights; never reported')
   args = ap.parse_args()
@@ -423,6 +428,14 @@ def main():
       dist.init_process_group('gloo')
     else:
       dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  force_rccl = False
+  if world == 1 and args.dist == 'nccl':
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+    force_rccl = True
   dev = torch.device('cuda', local_rank)
   torch.cuda.set_device(dev)
 
@@ -448,7 +461,7 @@ def main():
   # per-step score all-gather (the path's one exchange), issued asynchronously so that
   # the next batch's kernels do not queue behind a latency-bound 64 KiB collective
   from lanczosnet_amd.dist import AsyncScoreGather
-  gather = AsyncScoreGather(B, cfg['output_dim'], dev) if dist else None
+  gather = AsyncScoreGather(B, cfg['output_dim'], dev, force_collective=force_rccl) if dist else None
 
   ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(6)] for k in range(args.steps)}
   mask_u8 = mask.to(torch.uint8).contiguous()
@@ -528,6 +541,9 @@ def main():
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
   timed_score = score.clone()
+  # the last step's gathered scores carry this rank's shard unchanged
+  gather_ok = bool(torch.equal(gather.result(gather.issued - 1)[rank * B:(rank + 1) * B],
+                               timed_score)) if gather else None
 
   # secondary measurement (N = 1 only, never `value`): software pipeline over the stream of batches
   pipe = None
@@ -626,21 +642,41 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     fwd_s = stage_ms['lanczosnet_forward'] * 1e-3
-    # executed matrix-core work: the kernel runs 32-row node tiles; small molecules share one
-    buf, cap = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
-    n_tiles = int((buf[:12 * cap].view(cap, 4, 3)[:, :, 0] >= 0).sum().item())
-    flops_exec = FWD_FLOP_EXECUTED * n_tiles
+    # matrix-core work the kernel ISSUES for this batch's tile plan: the kernel runs 32-row node
+    # tiles (small molecules share one) and skips the GEMM2 / lift-back / projection k-groups of
+    # padded rows and the GEMM2 of identity bond-type channels — counted instruction by
+    # instruction from the plan (lanczosnet_amd/utils/flop_model.py; agrees with rocprofv3's
+    # SQ_INSTS_VALU_MFMA_MOPS_F32 of this kernel, tests/test_flop_model.py)
+    from lanczosnet_amd.utils.flop_model import tiles_from_plan, forward_mfma_issued
+    with torch.no_grad():
+      Lp_m, (buf, cap), _, _, _ = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
+    torch.cuda.synchronize()
+    mk = mask_u8.cpu().numpy()
+    extents = np.where(mk.any(axis=1), mk.shape[1] - np.argmax(mk[:, ::-1] != 0, axis=1), 0)
+    tile_list = tiles_from_plan(buf[:12 * cap].cpu().numpy(), extents,
+                                Lp_m.ident.cpu().numpy() if hasattr(Lp_m, 'ident') else None, K)
+    fm = forward_mfma_issued(tile_list, cfg)
+    n_tiles = fm['tiles']
+    flops_exec = fm['flops_issued']
     achieved = flops_exec / fwd_s / 1e12
+    if os.environ.get('LNZ_BENCH_DUMP_PLAN'):
+      np.savez_compressed(os.environ['LNZ_BENCH_DUMP_PLAN'],
+                          **{k_: np.array([t_[k_] for t_ in tile_list]) for k_ in tile_list[0]})
+    # HBM bytes per launch of the roofline kernel: PMC counters cannot be read from inside this
+    # process, so `traffic` cites the committed counter run of the SAME command and workload
+    # (tools/pmc_forward_profile.py -> profiles/), never a number measured in this run
     traffic, traffic_source = None, None
-    prof = os.path.join(ROOT, 'profiles', 'pmc_forward_hbm_bytes.json')
-    if os.path.exists(prof) and B == 1024:
-      try:
-        traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
-        traffic_source = ('profiles/pmc_forward_hbm_bytes.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE '
-                          'of this kernel on this workload, separate counter run (not measured in '
-                          'this process), gfx950 corrections of MI355X_MICROARCH.md applied')
-      except Exception:
-        traffic = None
+    for name in ('r03_forward_pmc.json', 'pmc_forward_hbm_bytes.json'):
+      prof = os.path.join(ROOT, 'profiles', name)
+      if os.path.exists(prof) and B == 1024:
+        try:
+          traffic = json.load(open(prof)).get('hbm_bytes_per_launch')
+          traffic_source = ('profiles/%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE of this kernel '
+                            'on this workload, separate counters-only passes (a committed profile, not '
+                            'measured in this process), FETCH_SIZE x 2 per MI355X_MICROARCH.md' % name)
+          break
+        except Exception:
+          traffic = None
     out = {
         'metric': 'molecules/sec LanczosNet forward, QM8 batch=1024',
         'value': round(value, 1), 'unit': 'molecules/s', 'n_gpus': world, 'steps': args.steps,
@@ -660,17 +696,33 @@ def main():
                      'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                      'traffic': traffic, 'traffic_source': traffic_source,
                      'flops_per_launch_executed': flops_exec,
+                     'mfma_instructions_per_launch': fm['mfma_issued'],
+                     'flops_per_launch_without_skips': fm['flops_unskipped'],
                      'tiles_per_launch': n_tiles,
+                     'useful_row_frac': round(fm['useful_row_frac'], 4),
+                     'useful_frac': round(achieved / PEAK_FP32_MFMA_TFLOPS * fm['useful_row_frac'], 4),
                      'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4),
                      'reference_association_tflops': round(FWD_FLOP_PER_MOL * n_tiles / fwd_s / 1e12, 2),
-                     'note': 'achieved = frac * peak = flops_per_launch_executed / avg_launch_ms: '
-                             '%d executed 32-row tiles x %d flop issued per tile; '
-                             'reference_association_tflops prices the same tiles at SURVEY 8(d)\'s '
-                             '%d flop (filter build + L_s Z per long channel, which the kernel '
-                             'replaces by one projection and one lift per layer); %d molecules '
-                             'ride in %d tiles (lnz_plan_tiles)'
-                             % (n_tiles, FWD_FLOP_EXECUTED, FWD_FLOP_PER_MOL, B, n_tiles)},
+                     'note': 'achieved = frac * peak = flops_per_launch_executed / avg_launch_ms. '
+                             'flops_per_launch_executed = 4096 flop x the v_mfma_f32_32x32x2_f32 '
+                             'instructions the kernel issues for THIS batch\'s tile plan (k-groups of '
+                             'padded rows / empty eigen slots and identity bond-type channels are '
+                             'skipped; utils/flop_model.py, checked against the PMC counter '
+                             'SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/); without the skips the same '
+                             '%d tiles would issue flops_per_launch_without_skips. useful_row_frac = '
+                             'real node rows / tile rows (%d molecules ride in %d 32-row tiles, '
+                             'lnz_plan_tiles); useful_frac = frac x useful_row_frac. '
+                             'reference_association_tflops prices the tiles at SURVEY 8(d)\'s %d flop '
+                             '(filter build + L_s Z per long channel, which the kernel replaces by one '
+                             'projection and one lift per layer)'
+                             % (n_tiles, B, n_tiles, FWD_FLOP_PER_MOL)},
     }
+    if dist:
+      out['config']['exchange'] = {
+          'backend': dist.get_backend(), 'world': world,
+          'collective': 'all_gather_into_tensor of the [%d,%d] f32 shard scores, every step, async '
+                        '(AsyncScoreGather)' % (B, cfg['output_dim']),
+          'gathered_equals_local': gather_ok}
     if split is not None:
       out['config']['split_precision_mode'] = split
     if pipe is not None:

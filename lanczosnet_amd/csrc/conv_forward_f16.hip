@@ -516,15 +516,15 @@ int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s) {
               "lnz_lanczosnet_forward(gemm_mode=1): needs dhid=128, filter_kind=0, K<=20, din0<=128");
   LNZ_REQUIRE(a.Wp16 && a.Wp16_head && a.Lp16, LNZ_EINVAL,
               "lnz_lanczosnet_forward(gemm_mode=1): Wp16 / Wp16_head / Lp16 missing");
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
+    // the attribute is PER DEVICE (one process may drive several: nn.DataParallel,
+    // runner/qm8_runner.py:62) — set it on the current device at every launch, no cached flag
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lanczosnet_forward_f16x3_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemBytes);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(max dynamic LDS %zu): %s", kSmemBytes, hipGetErrorString(e));
       return LNZ_ELAUNCH;
     }
-    attr_set = true;
   }
   const int grid = a.plan ? a.plan_wg_cap : (a.B + M4 - 1) / M4;
   hipLaunchKernelGGL(lanczosnet_forward_f16x3_kernel, dim3(grid), dim3(256), kSmemBytes, s, a);

@@ -748,27 +748,19 @@ extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t*
   const int Nk = (int)lnz_large_nk(N);
   const size_t lds = ((size_t)planes * 128 * (dinp + 8) + 128 * 136) * sizeof(uint16_t);
   dim3 grid((N + 127) / 128, B);
-  if (planes == 1) {
-    hipLaunchKernelGGL(large_gemm1_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx, din,
-                       dinp, Wf, B, N, Nk, C, Zt);
-  } else {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<3>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (3 * 128 * 136 + 128 * 136) * 2);
-      (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<2>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (2 * 128 * 136 + 128 * 136) * 2);
-      attr = true;
-    }
-    if (planes == 2)
-      hipLaunchKernelGGL(large_gemm1_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx,
-                         din, dinp, Wf, B, N, Nk, C, Zt);
-    else
-      hipLaunchKernelGGL(large_gemm1_kernel<3>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx,
-                         din, dinp, Wf, B, N, Nk, C, Zt);
-  }
+  // the dynamic-LDS limit is a PER-DEVICE attribute (one process may drive several devices:
+  // nn.DataParallel, runner/qm8_runner.py:62): set on the current device at every launch
+#define LNZ_LAUNCH_GEMM1(PP)                                                                        \
+  do {                                                                                              \
+    (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<PP>,                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+    hipLaunchKernelGGL(large_gemm1_kernel<PP>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx,   \
+                       din, dinp, Wf, B, N, Nk, C, Zt);                                             \
+  } while (0)
+  if (planes == 1) LNZ_LAUNCH_GEMM1(1);
+  else if (planes == 2) LNZ_LAUNCH_GEMM1(2);
+  else LNZ_LAUNCH_GEMM1(3);
+#undef LNZ_LAUNCH_GEMM1
   return lnz::check_launch("lnz_large_gemm1");
 }
 
@@ -783,12 +775,11 @@ extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float*
   const int dinp = (din + 15) / 16 * 16;
   LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_spectral: input width %d > 128", din);
   // row chunks: enough workgroups to fill the chip, at least 128 rows each (multiple of 16)
-  static int target_wgs = 0;
-  if (target_wgs == 0) {
+  static const int target_wgs = [] {  // read once (thread-safe static initialisation)
     const char* e = getenv("LNZ_LARGE_PROJECT_WGS");
-    target_wgs = e ? atoi(e) : 2048;
-    if (target_wgs < 1) target_wgs = 2048;
-  }
+    const int v = e ? atoi(e) : 2048;
+    return v < 1 ? 2048 : v;
+  }();
   int chunks = (target_wgs + B - 1) / B;
   int rows = ((N + chunks - 1) / chunks + 63) / 64 * 64;
   if (rows < 128) rows = 128;
@@ -817,22 +808,22 @@ extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint
   const size_t lds = (size_t)2 * planes * DH * BP * sizeof(uint16_t);
   // 8-wave workgroups = 256-row tiles.  (LNZ_LARGE_CONV_WAVES=4: 128-row tiles, two workgroups per
   // CU that drift apart — measured 12 % slower: twice the B-image staging per operator byte.)
-  static int nw = 0;
-  if (nw == 0) {
+  static const int nw = [] {  // read once (thread-safe static initialisation)
     const char* e = getenv("LNZ_LARGE_CONV_WAVES");
-    nw = (e && atoi(e) == 4) ? 4 : 8;
-    (void)hipFuncSetAttribute((const void*)large_conv_kernel<3, 8>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * DH * BP * 2);
-    (void)hipFuncSetAttribute((const void*)large_conv_kernel<2, 8>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * DH * BP * 2);
-  }
+    return (e && atoi(e) == 4) ? 4 : 8;
+  }();
   const int nwp = planes >= 2 ? 8 : nw;  // the multi-plane B images (64 / 96 KB): one workgroup per CU
   const int tile_rows = 32 * nwp;
   const int tiles = (N + tile_rows - 1) / tile_rows;
   const int grid = 8 * tiles * ((B + 7) / 8);
+  // (the dynamic-LDS limit is a per-device attribute: set on the current device at every launch)
 #define LNZ_LAUNCH_CONV(PP, WW)                                                                     \
-  hipLaunchKernelGGL((large_conv_kernel<PP, WW>), dim3(grid), dim3(64 * WW), lds,                   \
-                     (hipStream_t)stream, Lb, Vb, Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout)
+  do {                                                                                              \
+    (void)hipFuncSetAttribute((const void*)large_conv_kernel<PP, WW>,                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+    hipLaunchKernelGGL((large_conv_kernel<PP, WW>), dim3(grid), dim3(64 * WW), lds,                 \
+                       (hipStream_t)stream, Lb, Vb, Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout);  \
+  } while (0)
   if (planes == 1 && nwp == 4) LNZ_LAUNCH_CONV(1, 4);
   else if (planes == 1) LNZ_LAUNCH_CONV(1, 8);
   else if (planes == 2) LNZ_LAUNCH_CONV(2, 8);

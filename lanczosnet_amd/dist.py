@@ -72,9 +72,13 @@ class AsyncScoreGather:
     every step.  `result(ticket)` / `drain()` wait for the gathers.  Equal shards (the bench and
     the runner's full batches); `all_gather_scores` handles a ragged tail batch."""
 
-    def __init__(self, shard_rows, width, device, dtype=torch.float32, depth=2, group=None):
+    def __init__(self, shard_rows, width, device, dtype=torch.float32, depth=2, group=None,
+                 force_collective=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collective: issue the collective even in a one-rank group (a legal RCCL
+        # communicator): how the exchange is exercised on its real backend on a one-GPU box
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.bufs = [torch.empty((self.world * shard_rows, width), dtype=dtype, device=device)
                      for _ in range(depth)]
         self.work = [None] * depth
@@ -85,7 +89,7 @@ class AsyncScoreGather:
         if self.work[i] is not None:
             self.work[i].wait()  # this buffer's previous gather (depth steps ago) has landed
             self.work[i] = None
-        if self.world == 1:
+        if not self.collective:
             self.bufs[i].copy_(local_score)
         else:
             self.work[i] = dist.all_gather_into_tensor(self.bufs[i], local_score.contiguous(),
@@ -139,7 +143,8 @@ def forward_sharded(forward_fn, batch, n_global, label_key='label', group=None):
     return full, loss
 
 
-def all_reduce_gradients(params, local_count, group=None, bucket_bytes=256 << 20):
+def all_reduce_gradients(params, local_count, group=None, bucket_bytes=256 << 20,
+                         force_collective=False):
     """Data-parallel gradient exchange for training (runner/qm8_runner.py:216-248 under
     `nn.DataParallel`, :62): every rank holds d(mean loss over ITS shard)/dθ; the gradient of the
     mean over the whole batch is the shard-size-weighted average.  Gradients travel as flat fp32
@@ -150,21 +155,30 @@ def all_reduce_gradients(params, local_count, group=None, bucket_bytes=256 << 20
 
     params: iterable of parameters whose `.grad` is replaced in place; local_count: number of
     molecules (rows of the loss mean) this rank contributed.  The bucket layout is a function of
-    the parameter list alone (every `requires_grad` parameter, a missing `.grad` travels as zeros
-    and is materialised): ranks whose shards left different parameters without a gradient still
-    issue identically shaped collectives."""
+    the parameter list alone (every `requires_grad` parameter; a missing `.grad` travels as
+    zeros): ranks whose shards left different parameters without a gradient still issue
+    identically shaped collectives.  A parameter that NO rank has a gradient for keeps
+    `.grad = None` afterwards, as in the single-process run (torch optimizers skip such
+    parameters: no weight decay, no momentum update, no step count) — a has-gradient mask rides
+    with the shard counts.  With one process (no group, or world size 1) the function leaves
+    every gradient as it is — unless `force_collective` asks for the exchange in a one-rank group
+    (the RCCL test on a one-GPU box)."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return
+    multi = dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
+    if not multi:
+        return
     dev = params[0].device
+    had = torch.tensor([1.0 if p.grad is not None else 0.0 for p in params], dtype=torch.float32,
+                       device=dev)
     for p in params:
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
     cnt = torch.tensor([float(local_count)], dtype=torch.float32, device=dev)
-    total = cnt.clone()
-    if multi:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    head = torch.cat([cnt, had])
+    dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group)
+    total, had_any = head[:1], (head[1:] > 0).tolist()
     # greedy buckets in parameter order
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
@@ -189,3 +203,6 @@ def all_reduce_gradients(params, local_count, group=None, bucket_bytes=256 << 20
             n = p.grad.numel()
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
+    for p, any_rank in zip(params, had_any):
+        if not any_rank:
+            p.grad = None

@@ -45,17 +45,28 @@ class GraphedTrainStep(object):
 
     If the module was trained eagerly before, drop every reference to those steps' losses first
     (`loss = float(loss)`): a live autograd graph keeps the parameters' AccumulateGrad nodes bound
-    to the stream they were created on, and they must be re-created on the capture stream."""
+    to the stream they were created on, and they must be re-created on the capture stream.
 
-    def __init__(self, model, optimizer, warmup=2, scheduler=None):
+    Learning-rate schedules stay with the caller: the reference runner steps its MultiStepLR once
+    per EPOCH (runner/qm8_runner.py:190, milestones = `lr_decay_steps` in epochs), never per batch.
+    With `make_adam` the learning rate is a device tensor that the scheduler updates in place, so
+    a replayed graph sees the new value (tests/test_gpu_train_graph.py).
+
+    warmup >= 1: the first step must run eagerly — it creates the optimizer state (Adam's moments
+    and step counter); captured inside the graph, that initialisation would be replayed, resetting
+    the state at every step."""
+
+    def __init__(self, model, optimizer, warmup=2):
         for group in optimizer.param_groups:
             # optimizers with host-side step counters (Adam & co.) expose the flag; plain SGD has
             # no such state and captures as it is
             if 'capturable' in group and not group['capturable']:
                 raise ValueError('GraphedTrainStep needs an optimizer built with capturable=True '
                                  '(see lanczosnet_amd.train.make_adam)')
+        if int(warmup) < 1:
+            raise ValueError('GraphedTrainStep: warmup must be >= 1 (the optimizer state is created '
+                             'by the first eager step; capturing it would reset it on every replay)')
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
-        self.scheduler = scheduler
         self._graphs = {}
         self._seen = {}
         self._pool = None
@@ -129,5 +140,3 @@ class GraphedTrainStep(object):
         # whoever runs the module eagerly next (validation, another shape's warm-up) must re-pack
         if hasattr(self.model, 'invalidate_plan'):
             self.model.invalidate_plan()
-        if self.scheduler is not None:
-            self.scheduler.step()

@@ -165,9 +165,12 @@ def _subgroup_worker(rank, world, port, out_dir):
       lo, hi = lnz_dist.shard_bounds(8, gr, 2)
       out = a(x[lo:hi]) + (b2(x[lo:hi]) if gr == 0 else 0.0)
       torch.nn.functional.mse_loss(out, y[lo:hi]).backward()
-      params = list(a.parameters()) + list(b2.parameters())
+      unused = torch.nn.Linear(5, 3)   # no rank's loss touches it: stays without a gradient
+      params = list(a.parameters()) + list(b2.parameters()) + list(unused.parameters())
       assert (b2.weight.grad is None) == (gr == 1)
       lnz_dist.all_reduce_gradients(params, hi - lo, group=grp, bucket_bytes=64)
+      ok = ok and unused.weight.grad is None and unused.bias.grad is None
+      params = params[:4]
       # reference: the same two-shard loss in one process
       a2, b3 = torch.nn.Linear(5, 3), torch.nn.Linear(5, 3)
       a2.load_state_dict(a.state_dict())
@@ -198,6 +201,13 @@ def test_helpers_without_process_group():
   ref = _oracle_forward(P)(batch)
   assert torch.equal(full, ref)
   assert abs(float(loss) - float(torch.mean((ref - batch['label']) ** 2))) < 1e-6
+  # all_reduce_gradients leaves a single process's gradients exactly as they are: no zeros for
+  # parameters the backward did not touch (the optimizer skips .grad = None, as the reference's does)
+  lin, idle = torch.nn.Linear(4, 2), torch.nn.Linear(4, 2)
+  lin(torch.ones(3, 4)).sum().backward()
+  g0 = lin.weight.grad.clone()
+  lnz_dist.all_reduce_gradients(list(lin.parameters()) + list(idle.parameters()), 3)
+  assert torch.equal(lin.weight.grad, g0) and idle.weight.grad is None
 
 
 @pytest.mark.parametrize('world', [2, 3])
