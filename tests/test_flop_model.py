@@ -1,0 +1,46 @@
+"""bench.py's `roofline` prices the fused forward at the matrix-core instructions it ISSUES for the
+batch's tile plan (lanczosnet_amd/utils/flop_model.py).  This test holds that model against the
+hardware counter: profiles/r03_forward_pmc.json is `rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32` of
+the bench command on an MI355X (tools/pmc_forward_profile.py), profiles/r03_forward_tile_plan.npz
+the tile plan (per tile: node counts, split row, identity-channel bits) of the same run."""
+import json
+import os
+
+import numpy as np
+
+from lanczosnet_amd.utils.flop_model import forward_mfma_issued, tiles_from_plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+QM8_CFG = dict(num_atom=70, num_bond_type=6, short_diffusion_dist=[],
+               long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30], num_eig_vec=20,
+               spectral_filter_kind='MLP', input_dim=64, hidden_dim=[128] * 7, output_dim=16,
+               num_layer=7)
+
+
+def test_issued_mfma_model_agrees_with_the_pmc_counter():
+  pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r03_forward_pmc.json')))
+  plan = np.load(os.path.join(ROOT, 'profiles', 'r03_forward_tile_plan.npz'))
+  tiles = [dict(nA=int(a), nB=int(b), split=int(s), ident=int(i), pg=int(pg), ps=int(ps))
+           for a, b, s, i, pg, ps in zip(plan['nA'], plan['nB'], plan['split'], plan['ident'],
+                                         plan['pg'], plan['ps'])]
+  fm = forward_mfma_issued(tiles, QM8_CFG)
+  measured = pmc['SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch']
+  assert abs(fm['mops_counts'] - measured) <= 0.01 * measured, (fm['mops_counts'], measured)
+  assert abs(fm['flops_issued'] - pmc['mfma_flops_per_launch']) <= 0.01 * pmc['mfma_flops_per_launch']
+  # the skipped k-groups and identity channels are real: the unskipped count is what r02 priced
+  assert fm['mfma_unskipped'] > fm['mfma_issued']
+  assert 0.5 < fm['useful_row_frac'] < 1.0
+
+
+def test_tile_masks_follow_row_group_mask():
+  """tiles_from_plan: 8-row groups of A from row 0 and of B from the split row
+  (conv_forward.hip:139 row_group_mask), eigen-slot groups capped at K."""
+  plan = np.array([[0, -1, 32], [1, 2, 8], [3, 4, 16], [-1, -1, -1]])
+  ext = np.array([26, 7, 20, 16, 9])
+  t = tiles_from_plan(plan, ext, ident=np.array([0b0111000, 0b1111110, 0b0011110, 0, 0]), K=20)
+  assert [x['pg'] for x in t] == [4, 1 + 3, 2 + 2]
+  assert [x['ps'] for x in t] == [3, 1 + 3, 2 + 2]
+  assert t[0]['ident'] == 0b0111000 and t[1]['ident'] == 0b0011110 and t[2]['ident'] == 0
+  fm = forward_mfma_issued(t, QM8_CFG)
+  assert fm['tiles'] == 3 and fm['mfma_issued'] < fm['mfma_unskipped']
+  assert abs(fm['useful_row_frac'] - (26 + 7 + 20 + 16 + 9) / 96.0) < 1e-12

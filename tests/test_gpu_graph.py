@@ -113,7 +113,9 @@ def test_workgroup_ritz_kernel_matches_eigh(N, p):
   several components (exactly degenerate eigenvalues -> Lanczos restarts)."""
   from lanczosnet_amd import ops
   rs = np.random.RandomState(N)
-  Kk = 24
+  # sparse graphs are full of exactly degenerate eigenvalues (isolated nodes, twin leaves): a top-K
+  # cut would split a cluster in nearly every graph, so nothing is cut there
+  Kk = 24 if p >= 0.1 else N
   A, ns = _random_laplacians(rs, 5, N, max(2, N // 3), N, p)
   Dr, Vr, full = _eigh_ref(A, ns, N, Kk)
   D, V, info = ops.lanczos_ritz(_t(A), _t(ns), Kk, return_info=True)
