@@ -61,7 +61,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 
 
 def cpu_baseline(cfg, params, batch_size, reps):
-  """The oracle (numpy port of the reference pipeline) on the host cores, bounded sample."""
+  """The oracle on the host cores, bounded sample: per-molecule numpy eigh + |lambda| sort (the
+  reference's (D, V) producer) and the torch-CPU restatement of LanczosNet.forward — the
+  reference's own operator sequence on the same library, hence its rate
+  (profiles/cpu_port_vs_reference.json: port / reference on one host)."""
   import oracle
   batch = draw_batch(batch_size, seed=0)
   B, N = batch['node_mask'].shape
@@ -89,8 +92,8 @@ def cpu_baseline(cfg, params, batch_size, reps):
       if nb > K:
         ambiguous[b] = abs(abs(e[K - 1]) - abs(e[K])) < 1e-7
     D, V = oracle.collate_eigs(Dl, Vl, N, cfg['num_eig_vec'])
-    score = oracle.lanczos_net_forward(params, cfg, batch['node_feat'], L, D, V,
-                                       batch['node_mask'])
+    score = oracle.lanczos_net_forward_torch(params, cfg, batch['node_feat'], L, D, V,
+                                             batch['node_mask'])
     times.append(time.perf_counter() - t0)
   return batch_size / min(times), times, score, ambiguous
 
@@ -736,21 +739,37 @@ def main():
     if ada is not None:
       out['config']['ada_mode'] = ada
     if world == 1 and not args.no_cpu_baseline:
-      torch.set_num_threads(os.cpu_count() or 1)
-      v, times, ref_score, ambiguous = cpu_baseline(cfg, params, B, args.cpu_reps)
-      try:  # threads the numpy BLAS pool really runs (the per-molecule eigh loop is one thread)
-        from threadpoolctl import threadpool_info
-        blas_threads = max([int(p_['num_threads']) for p_ in threadpool_info()
-                            if p_.get('user_api') == 'blas'] or [1])
+      # the reference's CPU path with every core and, on many-core hosts, with 32
+      # intra-op threads (tiny batched GEMMs stop scaling long before 256 threads): best of the two
+      ncpu = os.cpu_count() or 1
+      best = None
+      for nthr in ([ncpu, 32] if ncpu > 32 else [ncpu]):
+        torch.set_num_threads(nthr)
+        r_ = cpu_baseline(cfg, params, B, max(2, args.cpu_reps // 2) if ncpu > 32 else args.cpu_reps)
+        if best is None or r_[0] > best[0][0]:
+          best = (r_, nthr)
+      (v, times, ref_score, ambiguous), nthr = best
+      torch.set_num_threads(nthr)
+      ratio_note = ''
+      try:
+        pr = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_port_vs_reference.json')))
+        ratio_note = ('; on the build container\'s %d cores the same port runs at %.2fx the rate of the '
+                      'UNMODIFIED reference (get_graph_laplacian_eigs loop + collate_fn + '
+                      'LanczosNet.forward: %.0f molecules/s) with identical scores '
+                      '(profiles/cpu_port_vs_reference.json, tools/cpu_port_vs_reference.py)'
+                      % (pr['host']['cpu_count'], pr['port_over_reference'],
+                         pr['reference']['molecules_per_s']))
       except Exception:
-        blas_threads = os.cpu_count() or 1
+        pass
       out['cpu_baseline'] = {'value': round(v, 1), 'unit': 'molecules/s',
-                             'cores': blas_threads, 'kind': 'port',
-                             'sample': 'numpy oracle (single-thread LAPACK eigh per molecule + '
-                                       'LanczosNet forward on a %d-thread BLAS pool; host has %d '
-                                       'cores), B=%d, best of %d runs (%.2f s each, %.1f s in all)' %
-                                       (blas_threads, os.cpu_count() or 1, B, args.cpu_reps,
-                                        min(times), sum(times))}
+                             'cores': torch.get_num_threads(), 'kind': 'port',
+                             'sample': 'oracle port of the reference CPU path: single-thread LAPACK '
+                                       'eigh + |lambda| sort per molecule (numpy), then the '
+                                       'reference\'s LanczosNet.forward operator sequence restated on '
+                                       'torch CPU tensors (%d intra-op threads; host has %d cores), '
+                                       'B=%d, best of %d runs (%.2f s each, %.1f s in all)%s' %
+                                       (torch.get_num_threads(), os.cpu_count() or 1, B, args.cpu_reps,
+                                        min(times), sum(times), ratio_note)}
       # self-verification: the scores of the timed batch (rank 0's seed-0 batch, same parameters)
       # against the oracle's scores of the same batch, all B molecules
       if not args.zero_params:
@@ -758,11 +777,16 @@ def main():
         ref = ref_score.astype(np.float64)
         dev_mol = np.abs(got - ref).max(axis=1) / np.abs(ref).max()
         keep = ~ambiguous
+        own = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
         out['parity_rel_err'] = float(dev_mol[keep].max())
+        out['parity_rel_err_per_molecule'] = float(own[keep].max())
         out['parity'] = {'against': 'oracle (numpy port of the reference pipeline, fp32) on the timed '
                                     'batch: %d of %d molecules x %d outputs'
                                     % (int(keep.sum()), ref.shape[0], ref.shape[1]),
-                         'metric': 'max |score - ref| / max |ref|', 'bar': 1e-5,
+                         'metric': 'parity_rel_err = max |score - ref| / max |ref| over the batch; '
+                                   'parity_rel_err_per_molecule = max over molecules of '
+                                   'max |score_b - ref_b| / max |ref_b| (each molecule on its own scale)',
+                         'bar': 1e-5,
                          'excluded': int(ambiguous.sum()),
                          'excluded_why': 'n > K and the top-K cut splits a degenerate |lambda| '
                                          'cluster (gap < 1e-7, the fp32 rounding of L): the reference keeps a LAPACK-chosen '
@@ -770,8 +794,9 @@ def main():
                          'excluded_max_rel_dev': float(dev_mol[ambiguous].max()) if ambiguous.any()
                          else None}
     print(json.dumps(out))
-    if out.get('parity_rel_err', 0.0) > 1e-5:
-      raise SystemExit('bench.py: parity_rel_err %.3e exceeds 1e-5' % out['parity_rel_err'])
+    if max(out.get('parity_rel_err', 0.0), out.get('parity_rel_err_per_molecule', 0.0)) > 1e-5:
+      raise SystemExit('bench.py: parity_rel_err %.3e / per molecule %.3e exceeds 1e-5'
+                       % (out['parity_rel_err'], out['parity_rel_err_per_molecule']))
   if dist:
     dist.destroy_process_group()
 

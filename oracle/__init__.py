@@ -19,6 +19,7 @@ from .lanczos_net import (lanczos_net_forward, spectral_gains, make_lanczosnet_p
                           lanczosnet_dims, DEFAULT_QM8_CFG)
 from .ada_lanczos import (ada_lanczos_layer, ada_graph_laplacian, ada_t_powers,  # noqa: F401
                           ada_spectral_filter_dd, ada_lanczos_net_forward, make_ada_params)
+from .lanczos_net_torch import lanczos_net_forward_torch  # noqa: F401
 from .lanczos_kstep import lanczos_kstep_fp64  # noqa: F401
 from .collate import collate_packed, dense_from_edges  # noqa: F401
 from .segment_sum import (unsorted_segment_sum_forward_gpu_semantics,  # noqa: F401

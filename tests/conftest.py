@@ -39,3 +39,12 @@ def rel_err(a, b):
   a = np.asarray(a, dtype=np.float64)
   b = np.asarray(b, dtype=np.float64)
   return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rel_err_rows(a, b):
+  """max over rows (molecules) of max|a_row - b_row| / max|b_row|: a molecule whose outputs are
+  100x smaller than the batch maximum is held to the same relative bar as the largest one
+  (rel_err above normalises by the batch maximum)."""
+  a = np.asarray(a, dtype=np.float64).reshape(len(a), -1)
+  b = np.asarray(b, dtype=np.float64).reshape(len(b), -1)
+  return float((np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-30)).max())

@@ -374,3 +374,22 @@ def test_ada_training_gradients_match_reference_autograd():
   assert rel_loss < 1e-5
   assert worst64[0] < 1e-5, worst64
   assert worst32[0] < 1e-5, worst32
+  # element level: 16 fixed +-1 projections per parameter tensor (tests/gradproj.py) against the
+  # reference class's float64 gradient at 1e-5 |g|, and against its fp32 gradient within 3x that
+  # gradient's own distance from the float64 one (same protocol as the statistics above)
+  from gradproj import project_torch
+  gp = load_golden('grad_projections.npz')
+  w64, w32, noise_p = (0.0, None), (0.0, None), 0.0
+  for i, k in enumerate(gp['ada64_names']):
+    assert str(gp['ada_names'][i]) == str(k)
+    pr = project_torch(gd[str(k)].grad, i)
+    nrm = float(gp['ada64_norm'][i])
+    e64 = float(np.abs(pr - gp['ada64_proj'][i]).max() / nrm)
+    eref = float(np.abs(gp['ada_proj'][i] - gp['ada64_proj'][i]).max() / nrm)
+    e32 = float(np.abs(pr - gp['ada_proj'][i]).max() / nrm) - 3 * eref
+    noise_p = max(noise_p, eref)
+    w64, w32 = max(w64, (e64, str(k))), max(w32, (e32, str(k)))
+  print('gradient projections: vs reference float64 worst %.2e of |g| (%s); vs reference fp32 beyond '
+        '3x its own noise %.2e; reference fp32-vs-float64 up to %.2e' % (w64[0], w64[1], w32[0], noise_p))
+  assert w64[0] < 1e-5, w64
+  assert w32[0] < 1e-5, w32

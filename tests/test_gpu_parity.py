@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, rel_err_rows
 from lanczosnet_amd.synthetic import draw_batch
 
 pytestmark = pytest.mark.gpu
@@ -214,6 +214,11 @@ def test_forward_full_config_matches_reference_and_oracle():
   print('forward rel err vs reference fp32 %.3e, vs fp64 oracle %.3e (reference vs fp64 %.3e)' %
         (e_ref, e_64, rel_err(g['score'], s64)))
   assert e_ref < 1e-5 and e_64 < 1e-5
+  # per molecule, normalised by that molecule's own largest output (not the batch maximum)
+  r_ref, r_64 = rel_err_rows(score, g['score']), rel_err_rows(score, s64)
+  print('per-molecule-normalised: vs reference %.3e, vs fp64 oracle %.3e (reference vs fp64 %.3e)'
+        % (r_ref, r_64, rel_err_rows(g['score'], s64)))
+  assert r_ref < 1e-5 and r_64 < 1e-5
   assert abs(float(loss) - float(g['loss'])) < 1e-5 * abs(float(g['loss']))
   # final node state of real nodes
   from lanczosnet_amd import ops
@@ -418,6 +423,11 @@ def test_full_size_properties_batch_1024():
   per_mol = np.abs(got - ref).max(axis=1) / np.abs(ref).max()
   worst = int(np.where(ambiguous, 0, per_mol).argmax())
   assert per_mol[~ambiguous].max() < 1e-5, 'molecule %d: %.3e' % (worst, per_mol[worst])
+  # the same, each molecule normalised by ITS OWN largest output
+  own = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+  print('B=1024 per-molecule-normalised worst %.2e (smallest molecule scale %.2e of the batch max)'
+        % (own[~ambiguous].max(), np.abs(ref).max(axis=1).min() / np.abs(ref).max()))
+  assert own[~ambiguous].max() < 1e-5, int(np.where(ambiguous, 0, own).argmax())
   print('B=1024 vs oracle: %d molecules compared, worst %.2e; %d excluded (degenerate cut), worst '
         '%.2e' % ((~ambiguous).sum(), per_mol[~ambiguous].max(), ambiguous.sum(),
                   per_mol[ambiguous].max() if ambiguous.any() else 0.0))
@@ -470,6 +480,18 @@ def test_training_gradients_match_reference_autograd(impl):
     assert abs(float(gr.double().sum()) - float(gs)) < tol, (k, float(gr.double().sum()), gs)
     assert abs(float(gr.double().abs().sum()) - float(ga)) < tol, k
     assert abs(float(gr.reshape(-1)[0]) - float(gf)) < 2e-4 * float(gm) + 1e-9, k
+  # element level: 16 fixed +-1 projections of every parameter tensor's gradient against the
+  # REFERENCE's (tests/golden/grad_projections.npz, tests/gradproj.py), relative to |g|
+  from gradproj import project_torch
+  gp = load_golden('grad_projections.npz')
+  worst = (0.0, None)
+  for i, k in enumerate(gp['lnet_names']):
+    pr = project_torch(gd[str(k)].grad, i)
+    e = float(np.abs(pr - gp['lnet_proj'][i]).max() / gp['lnet_norm'][i])
+    worst = max(worst, (e, str(k)))
+    assert abs(float(gd[str(k)].grad.double().norm()) - gp['lnet_norm'][i]) < 1e-5 * gp['lnet_norm'][i], k
+  print('gradient projections vs reference (%s): worst %.2e of |g| (%s)' % (impl, worst[0], worst[1]))
+  assert worst[0] < 1e-5, worst
   opt = torch.optim.Adam(net.parameters(), lr=1e-4)
   opt.step()
   with torch.no_grad():
