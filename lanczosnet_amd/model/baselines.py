@@ -20,6 +20,11 @@ class _NoSpectrum(_LanczosNetBase):
     """No Ritz pairs in the signature: the kernel gets an empty (K = 1, all-zero) spectrum."""
 
     def forward(self, node_feat, L, label=None, mask=None):
+        # inputs may arrive on the host (runner/qm8_runner.py:301-302 leaves L there): move them
+        # to the module's device BEFORE anything is built from them
+        dev = self._guard_forward(L, mask)
+        t = self._to_module_device(dev, node_feat=node_feat, L=L, label=label, mask=mask)
+        node_feat, L, label, mask = t['node_feat'], t['L'], t['label'], t['mask']
         B, N = L.shape[0], L.shape[1]
         D = torch.zeros((B, 1), dtype=torch.float32, device=L.device)
         V = torch.zeros((B, N, 1), dtype=torch.float32, device=L.device)
@@ -107,6 +112,9 @@ class ChebyNet(_NoSpectrum):
     def forward(self, node_feat, L, label=None, mask=None):
         if mask is None:
             raise ValueError('forward needs `mask` (model/cheby_net.py:106)')
+        dev = self._guard_forward(L, mask)
+        t = self._to_module_device(dev, L=L, mask=mask)         # host L / device mask must not meet in cat
+        L, mask = t['L'], t['mask']
         eye = torch.diag_embed((mask != 0).to(L.dtype))         # identity on the real nodes
         return super().forward(node_feat, torch.cat([L, eye.unsqueeze(3)], dim=3), label=label,
                                mask=mask)

@@ -30,3 +30,33 @@ def project_torch(grad, tensor_index):
     s = torch.from_numpy(signs(tensor_index, j, g.numel())).to(g.device)
     out.append(float((g * s.double()).sum()))
   return np.array(out)
+
+
+class deterministic_dropout(object):
+  """Replace `torch.nn.functional.dropout` by a seed-free stand-in while a training forward runs, on
+  BOTH sides of a parity test: call number i on a tensor x zeroes the elements whose flat index j
+  has hash(j, i) % 10 < 10 p and scales the rest by 1 / (1 - p).  A generator-based mask cannot be
+  compared (the reference consumes the CPU generator, the HIP module the device's); this one checks
+  what matters for a drop-in: WHERE dropout is applied, on WHICH tensor shape, HOW OFTEN and in
+  which order (model/lanczos_net.py:182).  `calls` records (shape, p) per call."""
+
+  def __enter__(self):
+    import torch
+    self.F = torch.nn.functional
+    self.real = self.F.dropout
+    self.calls = []
+
+    def fake(x, p=0.5, training=True, inplace=False):
+      if not training or p == 0.0:
+        return x
+      i = len(self.calls)
+      self.calls.append((tuple(x.shape), float(p)))
+      j = torch.arange(x.numel(), device=x.device, dtype=torch.int64)
+      h = ((j * 2654435761 + 40503 * (i + 1)) >> 7) % 10
+      keep = (h >= int(round(10 * p))).to(x.dtype).view(x.shape)
+      return x * keep / (1.0 - p)
+    self.F.dropout = fake
+    return self
+
+  def __exit__(self, *exc):
+    self.F.dropout = self.real
