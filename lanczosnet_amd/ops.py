@@ -12,7 +12,22 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+import os
+
+from . import _lib, _torch_ext
+
+# The forward step's ops (laplacian_l4, lanczos_ritz, prepare_batch, spectral_gains, the exact-fp32
+# lanczosnet_forward, unsorted_segment_sum_*) go through the torch extension
+# (torch.ops.lanczosnet.*: ATen checks, device guard, current stream, caching-allocator outputs, no
+# ctypes marshalling).  LNZ_OPS_BINDING=ctypes keeps them on the raw C ABI (A/B diagnostics; also
+# what a host without torch, like examples/ritz_pairs.c, uses).  Everything else — packing,
+# training launches, the large-graph and Ada ops — calls the C ABI through ctypes.
+_USE_EXT = os.environ.get('LNZ_OPS_BINDING', 'torch') != 'ctypes'
+
+
+def _ext():
+  _torch_ext.load()   # ImportError (loud) if the extension is not built
+  return torch.ops.lanczosnet
 
 
 def _stream():
@@ -45,6 +60,8 @@ def laplacian_l4(adjs, n_nodes):
   n_nodes = n_nodes.to(torch.int32).contiguous()
   B, N, N2, E = adjs.shape
   assert N == N2 and n_nodes.shape == (B,)
+  if _USE_EXT:
+    return _ext().laplacian_l4(adjs, n_nodes)
   L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=adjs.device)
   lib = _lib.load()
   with torch.cuda.device(adjs.device):
@@ -68,6 +85,9 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   assert kernel in ('auto', 'workgroup', 'workgroup_ws')
   B, N, _ = A.shape
   n_nodes = n_nodes.to(torch.int32).contiguous()
+  if _USE_EXT and kernel == 'auto':
+    D, V, info = _ext().lanczos_ritz(A, n_nodes, K)
+    return (D, V, info) if return_info else (D, V)
   D = torch.empty((B, K), dtype=torch.float32, device=A.device)
   V = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
   info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
@@ -374,8 +394,16 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
     D, V = lanczos_ritz(Lf[:, :, :, 0], n_nodes, K)
     return Lp, tiles, rows, D, V
   _need_cuda(Lf, mask_u8, n_nodes)
-  lib = _lib.load()
   n_cu = n_cu or _n_cu(Lf.device)
+  if _USE_EXT:
+    nn = n_nodes if n_nodes.dtype == torch.int32 and n_nodes.is_contiguous() else \
+        n_nodes.to(torch.int32).contiguous()
+    Lp, ident, buf, D, V = _ext().prepare_batch(Lf, mask_u8, nn, K, n_cu,
+                                                bool(pairing_supported(plan)))
+    Lp.ident = ident
+    cap = (buf.numel() - 2 - B * K) // 12
+    return Lp, (buf, cap), (buf[12 * cap + 2:], buf[12 * cap + 1:12 * cap + 2]), D, V
+  lib = _lib.load()
   cap = lib.lnz_plan_wg_cap(B, n_cu)
   dev = Lf.device
   Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=dev)
@@ -477,6 +505,10 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True)
   B, K = D.shape
   S = len(dist)
   use_rows = rows is not None and mlp_pack is not None
+  if _USE_EXT:
+    return _ext().spectral_gains(D, [int(x) for x in dist], num_layer, mlp_pack,
+                                 rows[0] if use_rows else None, rows[1] if use_rows else None,
+                                 bool(zero_fill))
   # + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
   alloc = torch.zeros if (use_rows and zero_fill) else torch.empty
   Gbuf = alloc((num_layer * B * S * K + 16,), dtype=torch.float32, device=D.device)
@@ -568,6 +600,9 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   channel goes through its Laplacian fragments)."""
   _need_cuda(node_feat, Lp, V, G, mask)
   B, N, K = V.shape
+  if _USE_EXT and Lp.dtype == torch.float32 and plan.get('Wp16') is None and act_out is None \
+      and not return_state:
+    return _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident)
   a = _lib.ForwardArgs()
   a.B, a.N, a.K = B, N, K
   a.num_layer = plan['num_layer']
@@ -639,6 +674,44 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   with torch.cuda.device(V.device):
     _lib.check(lib.lnz_lanczosnet_forward(C.byref(a), _stream()))
   return (score, state) if return_state else score
+
+
+def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
+  """lanczosnet_forward through torch.ops.lanczosnet.forward (exact-fp32 kernel, scores only)."""
+  B, N, K = V.shape
+  mask_u8 = mask if mask.dtype == torch.uint8 and mask.is_contiguous() else \
+      mask.to(torch.uint8).contiguous()
+  emb = None
+  if node_feat.dtype == torch.int64:
+    nf, emb = node_feat.contiguous(), plan['embedding']
+  else:
+    nf = node_feat.to(torch.float32)
+    if nf.shape[-1] != plan['din0']:  # zero-pad feature columns to the kernel's 32-column groups
+      assert nf.shape[-1] == plan['din0_raw']
+      nf = torch.nn.functional.pad(nf, (0, plan['din0'] - nf.shape[-1]))
+    nf = nf.contiguous()
+  fk = int(plan.get('filter_kind', 0))
+  if G is not None:
+    want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if fk == 1 else ())
+    assert tuple(G.shape) == want and G.is_contiguous() and G.dtype == torch.float32, \
+        (tuple(G.shape), want)
+  tiles, cap = None, 0
+  if isinstance(tiling, tuple):
+    tiles, cap = tiling
+  elif tiling != 'none':
+    assert tiling in ('auto', 'single')
+    tiles, cap = plan_tiles(mask_u8, allow_pairs=(tiling == 'auto' and pairing_supported(plan)))
+  consts = plan.get('_ext_consts')
+  if consts is None:   # static per plan: built once
+    consts = plan['_ext_consts'] = (
+        [int(x) for x in plan['w_off'][:plan['num_layer']]],
+        [int(x) for x in plan['b_off'][:plan['num_layer']]],
+        [plan['num_layer'], plan['din0'], plan['dhid'], plan['dout'], plan['n_long'], plan['n_edge'], fk],
+        [int(p) for p in plan['short']])
+  w_off, b_off, dims, short = consts
+  ident = getattr(Lp, 'ident', None) if use_ident else None
+  return _ext().forward(nf, emb, Lp, ident, _f32c(V), G, mask_u8, plan['Wp'], plan['bias'], w_off,
+                        b_off, plan['Wp_head'], plan['bias_head'], tiles, cap, dims, short)
 
 
 def _training_args(plan, Lp, V, G, mask_u8, tiling):
@@ -838,6 +911,8 @@ def unsorted_segment_sum_forward(data, segment_ids, num_segments):
   data = _f32c(data)
   ids = segment_ids.to(torch.int64).contiguous()
   B, D1, D2 = data.shape
+  if _USE_EXT:
+    return _ext().unsorted_segment_sum_forward(data, ids, num_segments)
   out = torch.zeros((B, num_segments, D2), dtype=torch.float32, device=data.device)
   lib = _lib.load()
   with torch.cuda.device(data.device):
@@ -851,6 +926,8 @@ def unsorted_segment_sum_backward(grad_out, segment_ids, dim1):
   g = _f32c(grad_out)
   ids = segment_ids.to(torch.int64).contiguous()
   B, S, D2 = g.shape
+  if _USE_EXT:
+    return _ext().unsorted_segment_sum_backward(g, ids, dim1)
   out = torch.empty((B, dim1, D2), dtype=torch.float32, device=g.device)
   lib = _lib.load()
   with torch.cuda.device(g.device):

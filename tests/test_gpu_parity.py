@@ -980,3 +980,45 @@ def test_gain_grad_kernel_matches_the_eigen_space_formula(B, pairs):
   assert (dG - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
   dead = (torch.arange(K, device=DEV)[None, :] >= n[:, None])
   assert (dG[:, dead] == 0).all()
+
+
+def test_torch_extension_ops_equal_the_ctypes_binding_bitwise():
+  """The same C ABI behind two bindings: torch.ops.lanczosnet.* (csrc/torch_ext.cpp, the default of
+  lanczosnet_amd.ops) and raw ctypes — identical launches, so identical bits, for every op of the
+  forward step; and a non-default stream is honoured (the extension takes ATen's current stream)."""
+  from lanczosnet_amd import ops
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  P = oracle.make_lanczosnet_params(cfg, 77)
+  net = _model(cfg, P)
+  plan = net._plan()
+  b = draw_batch(96, seed=21)
+  n = _t(b['n_nodes'])
+  adjs, nf, mk = _t(b['adjs']), _t(b['node_feat']), _t(b['node_mask'])
+  K = cfg['num_eig_vec']
+
+  def run():
+    L = ops.laplacian_l4(adjs, n)
+    D0, V0, info = ops.lanczos_ritz(L[:, :, :, 0], n, K, return_info=True)
+    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mk, n, K)
+    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
+                           rows=rows, zero_fill=True)
+    score = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+    seg = ops.unsorted_segment_sum_forward(V, (nf % 5), 5)
+    return dict(L=L, D0=D0, V0=V0, info=info, Lp=Lp, ident=Lp.ident, plan=tiles[0], D=D, V=V, G=G,
+                score=score, seg=seg)
+  assert ops._USE_EXT
+  with torch.no_grad():
+    a = run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      c = run()
+    torch.cuda.current_stream().wait_stream(side)
+    ops._USE_EXT = False
+    try:
+      r = run()
+    finally:
+      ops._USE_EXT = True
+  for k in a:
+    assert torch.equal(a[k], r[k]), k
+    assert torch.equal(a[k], c[k]), k

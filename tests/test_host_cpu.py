@@ -39,7 +39,17 @@ def test_argument_validation_without_gpu():
   assert lib.lnz_pack_rows_k8(null, 4, 4, 4, null, null) == _lib.LNZ_EINVAL
   assert lib.lnz_pack_laplacian(one, 1, 1, 1, 1, 2, 40, 7, one, null) == _lib.LNZ_ENOTSUP
   assert b'32-node tile' in lib.lnz_last_error() or b'exceeds' in lib.lnz_last_error()
-  assert lib.lnz_lanczos_ritz(one, 1, 1, 1, one, 4, 100, 20, one, one, null, null) == _lib.LNZ_ENOTSUP
+  # one workgroup owns a graph of up to 192 nodes; beyond that only the streamed K-step kernels apply
+  assert lib.lnz_lanczos_ritz(one, 1, 1, 1, one, 4, 193, 20, one, one, null, null) == _lib.LNZ_ENOTSUP
+  assert b'lnz_lanczos_ritz_large' in lib.lnz_last_error()
+  assert lib.lnz_lanczos_ritz_ws(one, 1, 1, 1, one, 4, 193, 20, one, one, null, null, 0, 0, null) == \
+      _lib.LNZ_ENOTSUP
+  # the fp64 basis sits in LDS next to A up to N = 113; above, N (N|1) 8 bytes per graph of workspace
+  assert lib.lnz_lanczos_ritz_workspace_bytes(64, 100) == 0
+  assert lib.lnz_lanczos_ritz_workspace_bytes(64, 113) == 0
+  assert lib.lnz_lanczos_ritz_workspace_bytes(64, 114) == 64 * 114 * 115 * 8
+  assert lib.lnz_lanczos_ritz_workspace_bytes(3, 192) == 3 * 192 * 193 * 8
+  assert lib.lnz_lanczos_ritz_workspace_bytes(3, 193) == 0 and lib.lnz_lanczos_ritz_workspace_bytes(3, 32) == 0
   assert lib.lnz_lanczos_ritz(null, 1, 1, 1, one, 4, 10, 20, one, one, null, null) == _lib.LNZ_EINVAL
   assert lib.lnz_spectral_gains(one, 4, 20, (C.c_int32 * 20)(), 20, 7, 0, one, one, null) == _lib.LNZ_ENOTSUP
   a = _lib.ForwardArgs()
@@ -52,6 +62,26 @@ def test_argument_validation_without_gpu():
     _lib.check(_lib.LNZ_ENOTSUP)
   assert lib.lnz_packed_rows_k8_size(128, 1920) == 128 * 1920
   assert lib.lnz_packed_rows_k8_size(17, 20) == 32 * 24
+
+
+def test_torch_extension_registers_the_ops_and_refuses_cpu_tensors():
+  """liblanczosnet_torch.so (csrc/torch_ext.cpp): the forward step's ops live in the dispatcher as
+  torch.ops.lanczosnet.*, implemented for the HIP ("CUDA") key only — a CPU tensor finds no kernel."""
+  from lanczosnet_amd import _lib, _torch_ext
+  _torch_ext.load()
+  ns = torch.ops.lanczosnet
+  assert ns.abi_version() == _lib.ABI_VERSION
+  for name in ('laplacian_l4', 'lanczos_ritz', 'prepare_batch', 'spectral_gains', 'forward',
+               'unsorted_segment_sum_forward', 'unsorted_segment_sum_backward'):
+    assert hasattr(ns, name), name
+  with pytest.raises((NotImplementedError, RuntimeError)):
+    ns.laplacian_l4(torch.zeros(1, 4, 4, 1), torch.zeros(1, dtype=torch.int32))
+  with pytest.raises((NotImplementedError, RuntimeError)):
+    ns.unsorted_segment_sum_forward(torch.zeros(1, 4, 2), torch.zeros(1, 4, dtype=torch.int64), 3)
+  # the front end (lanczosnet_amd.ops) refuses before it gets there, with the module's message
+  from lanczosnet_amd import ops
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    ops.laplacian_l4(torch.zeros(1, 4, 4, 1), torch.zeros(1, dtype=torch.int32))
 
 
 def _qm8_config():
