@@ -80,7 +80,10 @@ def cpu_baseline(cfg, params, batch_size, reps):
   # fp32 Laplacian the device path is handed (dataset/qm8.py:262 casts L to fp32; the reference's
   # offline eigh sees the fp64 one): a cluster tighter than that cannot be ordered from fp32 L.
   ambiguous = np.zeros(B, bool)
+  t_start = time.perf_counter()
   for _ in range(reps):
+    if times and time.perf_counter() - t_start > 30.0:
+      break  # bounded sample: about 30 s of CPU work at most
     t0 = time.perf_counter()
     Dl, Vl = [], []
     for b in range(B):  # (D, V) producer: utils/data_helper.py:169-223 per molecule, fp64 L4 -> eigh
@@ -739,17 +742,12 @@ def main():
     if ada is not None:
       out['config']['ada_mode'] = ada
     if world == 1 and not args.no_cpu_baseline:
-      # the reference's CPU path with every core and, on many-core hosts, with 32
-      # intra-op threads (tiny batched GEMMs stop scaling long before 256 threads): best of the two
+      # the reference's CPU path on the host cores, at most 32 intra-op threads: the batched GEMMs
+      # of a 32-node tile stop scaling long before that, and a 256-thread pool on them does not
+      # finish in minutes (measured: the r03 run with every core of the 256-core box timed out)
       ncpu = os.cpu_count() or 1
-      best = None
-      for nthr in ([ncpu, 32] if ncpu > 32 else [ncpu]):
-        torch.set_num_threads(nthr)
-        r_ = cpu_baseline(cfg, params, B, max(2, args.cpu_reps // 2) if ncpu > 32 else args.cpu_reps)
-        if best is None or r_[0] > best[0][0]:
-          best = (r_, nthr)
-      (v, times, ref_score, ambiguous), nthr = best
-      torch.set_num_threads(nthr)
+      torch.set_num_threads(min(ncpu, 32))
+      v, times, ref_score, ambiguous = cpu_baseline(cfg, params, B, args.cpu_reps)
       ratio_note = ''
       try:
         pr = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_port_vs_reference.json')))
@@ -768,7 +766,7 @@ def main():
                                        'reference\'s LanczosNet.forward operator sequence restated on '
                                        'torch CPU tensors (%d intra-op threads; host has %d cores), '
                                        'B=%d, best of %d runs (%.2f s each, %.1f s in all)%s' %
-                                       (torch.get_num_threads(), os.cpu_count() or 1, B, args.cpu_reps,
+                                       (torch.get_num_threads(), os.cpu_count() or 1, B, len(times),
                                         min(times), sum(times), ratio_note)}
       # self-verification: the scores of the timed batch (rank 0's seed-0 batch, same parameters)
       # against the oracle's scores of the same batch, all B molecules

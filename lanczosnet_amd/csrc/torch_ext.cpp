@@ -8,9 +8,8 @@
 // Reference native op surface mirrored here as well: `unsorted_segment_sum_forward/_backward`
 // taking tensors (operators/src/segment_reduction_cuda.cpp:8-38).
 #include <ATen/ATen.h>
-#include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
 #include <tuple>
@@ -26,7 +25,11 @@ void check(int code, const char* what) {
   TORCH_CHECK(code == LNZ_OK, what, ": lanczosnet_hip error ", code, ": ", lnz_last_error());
 }
 
-lnz_stream_t cur_stream() { return (lnz_stream_t)c10::hip::getCurrentHIPStream().stream(); }
+// A ROCm build of torch presents its HIP devices under the "cuda" device type: the current stream
+// of the calling thread is the masquerading one, the guard the type-erased c10::DeviceGuard.
+lnz_stream_t cur_stream() {
+  return (lnz_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+}
 
 void need(const Tensor& t, at::ScalarType dt, const char* name, bool contiguous = true) {
   TORCH_CHECK(t.is_cuda(), "lanczosnet: ", name, " must be a HIP (cuda) tensor; there is no CPU path");
@@ -41,7 +44,7 @@ Tensor laplacian_l4(const Tensor& adjs, const Tensor& n_nodes) {
   need(adjs, at::kFloat, "adjs");
   need(n_nodes, at::kInt, "n_nodes");
   TORCH_CHECK(adjs.dim() == 4 && adjs.size(1) == adjs.size(2) && n_nodes.numel() == adjs.size(0));
-  const c10::hip::HIPGuard guard(adjs.device());
+  const c10::DeviceGuard guard(adjs.device());
   const int B = adjs.size(0), N = adjs.size(1), E = adjs.size(3);
   Tensor L = at::empty({B, N, N, E + 1}, adjs.options());
   check(lnz_laplacian_l4(adjs.data_ptr<float>(), n_nodes.data_ptr<int32_t>(), B, N, E,
@@ -54,7 +57,7 @@ std::tuple<Tensor, Tensor, Tensor> lanczos_ritz(const Tensor& A, const Tensor& n
   need(A, at::kFloat, "A", /*contiguous=*/false);  // any strides: channel 0 of a channels-last L
   need(n_nodes, at::kInt, "n_nodes");
   TORCH_CHECK(A.dim() == 3 && A.size(1) == A.size(2) && n_nodes.numel() == A.size(0) && K > 0);
-  const c10::hip::HIPGuard guard(A.device());
+  const c10::DeviceGuard guard(A.device());
   const int B = A.size(0), N = A.size(1);
   Tensor D = at::empty({B, K}, A.options());
   Tensor V = at::empty({B, N, K}, A.options());
@@ -87,7 +90,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> prepare_batch(const Tensor& L
   need(n_nodes, at::kInt, "n_nodes");
   TORCH_CHECK(L.dim() == 4 && L.size(1) == L.size(2) && mask.size(0) == L.size(0) &&
               mask.size(1) == L.size(1));
-  const c10::hip::HIPGuard guard(L.device());
+  const c10::DeviceGuard guard(L.device());
   const int B = L.size(0), N = L.size(1), C = L.size(3);
   const int cap = lnz_plan_wg_cap(B, (int)n_cu);
   auto iopt = n_nodes.options();
@@ -119,7 +122,7 @@ Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
     need(*rows, at::kInt, "rows");
     need(*n_rows, at::kInt, "n_rows");
   }
-  const c10::hip::HIPGuard guard(D.device());
+  const c10::DeviceGuard guard(D.device());
   const int B = D.size(0), K = D.size(1), S = dist.size();
   const int64_t n = num_layer * (int64_t)B * S * K;
   // + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
@@ -154,7 +157,7 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
   need(bias_head, at::kFloat, "bias_head");
   TORCH_CHECK(V.dim() == 3 && (int64_t)w_off.size() >= dims[0] && (int64_t)b_off.size() >= dims[0] &&
               dims[0] <= 16 && short_dist.size() <= 8);
-  const c10::hip::HIPGuard guard(V.device());
+  const c10::DeviceGuard guard(V.device());
   lnz_forward_args a = {};
   a.B = V.size(0), a.N = V.size(1), a.K = V.size(2);
   a.num_layer = dims[0], a.din0 = dims[1], a.dhid = dims[2], a.dout = dims[3];
@@ -206,7 +209,7 @@ Tensor segment_sum_forward(const Tensor& data, const Tensor& segment_ids, int64_
   need(segment_ids, at::kLong, "segment_ids");
   TORCH_CHECK(data.dim() == 3 && segment_ids.dim() == 2 && segment_ids.size(0) == data.size(0) &&
               segment_ids.size(1) == data.size(1));
-  const c10::hip::HIPGuard guard(data.device());
+  const c10::DeviceGuard guard(data.device());
   Tensor out = at::zeros({data.size(0), num_segments, data.size(2)}, data.options());
   check(lnz_unsorted_segment_sum_forward(data.data_ptr<float>(), segment_ids.data_ptr<int64_t>(),
                                          data.size(0), data.size(1), data.size(2), (int)num_segments,
@@ -219,7 +222,7 @@ Tensor segment_sum_backward(const Tensor& grad_out, const Tensor& segment_ids, i
   need(grad_out, at::kFloat, "grad_out");
   need(segment_ids, at::kLong, "segment_ids");
   TORCH_CHECK(grad_out.dim() == 3 && segment_ids.dim() == 2);
-  const c10::hip::HIPGuard guard(grad_out.device());
+  const c10::DeviceGuard guard(grad_out.device());
   Tensor gd = at::zeros({grad_out.size(0), dim1, grad_out.size(2)}, grad_out.options());
   check(lnz_unsorted_segment_sum_backward(grad_out.data_ptr<float>(), segment_ids.data_ptr<int64_t>(),
                                           grad_out.size(0), (int)dim1, grad_out.size(2),

@@ -25,9 +25,30 @@ from . import _lib, _torch_ext
 _USE_EXT = os.environ.get('LNZ_OPS_BINDING', 'torch') != 'ctypes'
 
 
+class _ExtNamespace(object):
+  """torch.ops.lanczosnet with the C ABI's error codes mapped back to the binding's exception
+  types (the extension raises RuntimeError('... lanczosnet_hip error <code>: <message>'))."""
+
+  def __getattr__(self, name):
+    op = getattr(torch.ops.lanczosnet, name)
+
+    def call(*args):
+      try:
+        return op(*args)
+      except RuntimeError as e:
+        msg = str(e)
+        if 'lanczosnet_hip error %d:' % _lib.LNZ_ENOTSUP in msg:
+          raise _lib.NotSupported(_lib.LNZ_ENOTSUP, msg.split('lanczosnet_hip error', 1)[1]) from None
+        raise
+    return call
+
+
+_EXT_NS = _ExtNamespace()
+
+
 def _ext():
   _torch_ext.load()   # ImportError (loud) if the extension is not built
-  return torch.ops.lanczosnet
+  return _EXT_NS
 
 
 def _stream():

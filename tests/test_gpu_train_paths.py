@@ -33,7 +33,8 @@ def _check(net, loss, g, tag):
     assert gr is not None, k
     nrm = float(g[tag + '_norm'][i])
     e = float(np.abs(project_torch(gr, i) - g[tag + '_proj'][i]).max() / nrm)
-    worst = max(worst, (e, str(k)))
+    if e >= worst[0]:
+      worst = (e, str(k))
     assert abs(float(gr.double().norm()) - nrm) < 1e-5 * nrm, k
   print('%s: gradient projections vs reference autograd, worst %.2e of |g| (%s)' % (tag, worst[0], worst[1]))
   assert worst[0] < 1e-5, worst
