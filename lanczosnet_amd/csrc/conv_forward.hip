@@ -78,7 +78,12 @@ struct TileDesc {
 // per-CU vector-memory path, not L2, limits a 1-tile tiling).  The two halves of a workgroup share
 // nothing but the CU and the per-layer barrier.
 // FK = filter kind: 0 = diagonal gains on Ritz vectors (LanczosNet), 1 = dense K x K filters on
-// the Lanczos basis (AdaLanczosNet: M = Q DD Q^T, model/ada_lanczos_net.py:280-281; single tiles).
+// the Lanczos basis built in NODE space (AdaLanczosNet: M = Q DD Q^T,
+// model/ada_lanczos_net.py:280-281; single tiles; kept for A/B runs), 2 = the same dense filters in
+// EIGEN space: sum_s Q DD_s Q^T X W_s^T = Q [ sum_s DD_s (Y W_s^T) ], Y = Q^T X — the diagonal
+// variant's structure with the 16 row-scaling FMAs of a channel replaced by one 32 x 32 MFMA chain
+// (A = DD_s fragments from global memory, B = the channel's GEMM1 result as it stands in its C/D
+// registers); pair tiles, identity-channel shortcut and the weight-ring schedule come with it.
 template <int MT>
 __device__ __forceinline__ TileDesc pick(const TileDesc (&td)[MT], int m) {
   static_assert(MT <= 2, "select written for two tiles");
@@ -169,10 +174,11 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                                              float* Gs,  // [2 buffers][tile][n_long][2 halves][16]
                                              const int htid, const int wave) {
   constexpr bool FWD = MODE == 0 || MODE == 3;
-  constexpr bool ES = FK == 0;  // long channels in eigen space
+  constexpr bool ES = FK == 0 || FK == 2;  // long channels in eigen space
+  constexpr bool DENSE = FK == 2;          // ... with dense K x K gains (block diagonal per tile)
   // Laplacian fragments of a node-space channel: fetched in front of the LAST ring-depth steps of
   // the channel's own GEMM1 (kernels with one ring loop), else one channel ahead
-  constexpr bool PEEL = DEEPK >= 0 && FK == 0 && MODE != 2;
+  constexpr bool PEEL = DEEPK >= 0 && ES && MODE != 2;
 #ifdef LNZ_EXP_PRIO
   // the two-tile half is the critical path of a 3-tile workgroup: let it issue first, the
   // one-tile half fills the matrix-pipe slots it leaves
@@ -255,8 +261,8 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
   //        chain as B operand), the projection reads column rho as A operand of V^T.
   //      FK = 1: vreg[m][r] = Q[mol m][j][cd_row(r,hh)] — the k-order that lets the same registers
   //        serve as B operand of R = DD Q^T and as A operand of L_s = Q R.
-  float vreg[MT][FK ? KHT : 1];
-  if (FK == 0) {
+  float vreg[MT][FK == 1 ? KHT : 1];
+  if (ES) {
     for (int idx = htid; idx < MT * 32 * 32; idx += 64 * NWV) {
       const int m = idx >> 10, jj = (idx >> 5) & 31, rho = idx & 31;
       Vm[m][jj][rho] = ritz_tile_elem(a, pick(td, m), jj, rho);
@@ -265,7 +271,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int t = 0; t < (FK ? KHT : 1); ++t) {
+      for (int t = 0; t < (FK == 1 ? KHT : 1); ++t) {
         int k = lnz::cd_row(t, hh);
         vreg[m][t] = (k < K && j < N) ? a.V[((int64_t)td[m].ta * N + j) * K + k] : 0.0f;
       }
@@ -420,14 +426,44 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
     auto fetch_m_operands = [&](int c, int m) {
       const bool lng = (c >= a.n_short) && (c < a.n_short + a.n_long);
       if (lng) {
-        if (FK != 0) {
+        if (FK == 1) {
           // row j of the symmetric K x K filter DD_s, columns in cd_row order
           const float* dp =
               a.G + ((((int64_t)l * B + td[m].ta) * a.n_long + (c - a.n_short)) * K + j) * K;
 #pragma unroll
-          for (int t = 0; t < (FK ? KHT : 1); ++t) {
+          for (int t = 0; t < (FK == 1 ? KHT : 1); ++t) {
             int k2 = lnz::cd_row(t, hh);
             mop[m][t] = (j < K && k2 < K) ? dp[k2] : 0.0f;
+          }
+        } else if (DENSE) {
+          // fragment group g of lane (rho = j, hh) = DDtile[rho][8g + 4hh + 0..3]: slot row rho of
+          // the tile belongs to molecule A (rho < split, its slot rho) or B (slot rho - split, its
+          // columns behind A's) — block diagonal like the Laplacian fragments below; rows /
+          // columns >= K are zero.  DD_s is [K][K] row major (symmetric): 16-byte loads when K % 4
+          // == 0 (QM8: K = 20), element loads otherwise.
+          const int g0 = td[m].split >> 3;
+          const bool rowA = j < td[m].split;
+          const int kr = jl[m];  // this lane's slot within its molecule
+          const float* dp = a.G + ((((int64_t)l * B + (molj[m] >= 0 ? molj[m] : 0)) * a.n_long +
+                                    (c - a.n_short)) * K + (kr < K ? kr : 0)) * K;
+          const bool live = kr < K && molj[m] >= 0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int k0 = 8 * (g - (rowA ? 0 : g0)) + 4 * hh;  // first column, molecule-local
+            const bool blk = live && (rowA ? g < g0 : g >= g0);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((K & 3) == 0) {
+              if (blk && k0 < K) v = *reinterpret_cast<const float4*>(dp + k0);
+            } else if (blk) {
+              v.x = k0 + 0 < K ? dp[k0 + 0] : 0.0f;
+              v.y = k0 + 1 < K ? dp[k0 + 1] : 0.0f;
+              v.z = k0 + 2 < K ? dp[k0 + 2] : 0.0f;
+              v.w = k0 + 3 < K ? dp[k0 + 3] : 0.0f;
+            }
+            mop[m][4 * g + 0] = v.x;
+            mop[m][4 * g + 1] = v.y;
+            mop[m][4 * g + 2] = v.z;
+            mop[m][4 * g + 3] = v.w;
           }
         }  // FK = 0: the eigen-space block below reads its gains from LDS itself
       } else if (c >= a.n_short && ((idm[m] >> (c - a.n_short - a.n_long)) & 1)) {
@@ -589,6 +625,28 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           for (int s = 0; s < a.n_long; ++s) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) Z[m] = lnz::splat16(0.0f);
+            if constexpr (DENSE) {
+              // this channel's DD fragments land under its own GEMM1 (fetched in front of its
+              // last ring-depth steps where the ring loop is peeled, else in front of the loop)
+              // (tile 0's under the GEMM1, tile 1's under tile 0's MFMA chain: with both sets live
+              // across the GEMM1 the kernel spills)
+              gemm1(yrow, [&] { fetch_m_operands(a.n_short + s, 0); });
+              // T_m += DD_s,m Z_m: GEMM2 with the DD fragments as M, on the live slot groups
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                if (m + 1 < MT) fetch_m_operands(a.n_short + s, m + 1);
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                  if ((smask[m] >> (r >> 2)) & 1) {
+                    T[m] = lnz::mfma32(mop[m][r + 0], Z[m][r + 0], T[m]);
+                    T[m] = lnz::mfma32(mop[m][r + 1], Z[m][r + 1], T[m]);
+                    T[m] = lnz::mfma32(mop[m][r + 2], Z[m][r + 2], T[m]);
+                    T[m] = lnz::mfma32(mop[m][r + 3], Z[m][r + 3], T[m]);
+                  }
+                }
+              }
+              continue;
+            }
             gemm1(yrow, [] {});
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -701,7 +759,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         // FK = 0: the fragments fetched one channel ahead are used in place and the next
         // channel's are fetched once this tile's MFMAs are issued (no register copy in front of
         // the GEMM2 chain; they still have a whole GEMM1 to land)
-        constexpr bool INPLACE = FK == 0;
+        constexpr bool INPLACE = ES;
         f32x16 Mf;
         if (INPLACE) {
 #pragma unroll
@@ -711,9 +769,9 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           f32x16 acc = lnz::splat16(0.0f);
           f32x16 R = lnz::splat16(0.0f);
 #pragma unroll
-          for (int t = 0; t < (FK ? KHT : 1); ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
+          for (int t = 0; t < (FK == 1 ? KHT : 1); ++t) R = lnz::mfma32(mop[m][t], vreg[m][t], R);
 #pragma unroll
-          for (int t = 0; t < (FK ? KHT : 1); ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
+          for (int t = 0; t < (FK == 1 ? KHT : 1); ++t) acc = lnz::mfma32(vreg[m][t], R[t], acc);
           Mf = acc;  // L_s[cd_row(r,hh)][j] == L_s[j][cd_row(r,hh)]  (symmetric)
         } else if (!idc) {
 #pragma unroll
@@ -946,7 +1004,7 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
   } else {
     // keep the barrier count of the other half: setup, (eigen space: the first layer's
     // projection,) and per layer one barrier (eigen space: two)
-    const bool es = FK == 0 && a.n_long > 0;
+    const bool es = (FK == 0 || FK == 2) && a.n_long > 0;
     const int nb = MODE == 2 ? 2 : (es ? 2 : 1) * a.num_layer + 1 + (es ? 1 : 0);
     for (int l = 0; l < nb; ++l) __syncthreads();
   }
@@ -1173,6 +1231,17 @@ int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_for
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
 
+// LNZ_DENSE_FILTER_NODE_SPACE=1: the r02 dense-filter kernel (L_s = Q DD_s Q^T built per channel in
+// node space, single tiles only) instead of the eigen-space one — A/B runs.  The Python side
+// (ops.pairing_supported) reads the same variable: the node-space kernel cannot take pair tiles.
+static bool dense_filters_in_node_space() {
+  static const bool v = [] {
+    const char* e = getenv("LNZ_DENSE_FILTER_NODE_SPACE");
+    return e && atoi(e) != 0;
+  }();
+  return v;
+}
+
 static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const char* who) {
   LNZ_REQUIRE(a.B > 0 && a.N > 0 && a.K > 0 && a.num_layer > 0, LNZ_EINVAL,
               "%s: bad sizes (B=%d N=%d K=%d L=%d)", who, a.B, a.N, a.K, a.num_layer);
@@ -1254,6 +1323,12 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
     if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 0, 1);
     else if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
     else LNZ_LAUNCH(2, 10, 0, 0);
+  } else if (!dense_filters_in_node_space()) {
+    // dense K x K filters (AdaLanczosNet) in eigen space: pair tiles, DD fragments as GEMM2 operand
+    // 4-slot weight ring in every layer: the DD fragments are live across the channel's GEMM1
+    // next to T, Z and out — the 8-slot ring does not fit in 256 registers beside them
+    if (a.dhid == 128) LNZ_LAUNCH_D(4, 10, 2, 0, 0);
+    else LNZ_LAUNCH_D(2, 10, 2, 0, 0);
   } else {
     const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
     if (a.dhid == 128 && k24) LNZ_LAUNCH(4, 12, 1, 0);

@@ -256,7 +256,16 @@ def test_ada_dense_filter_conv_matches_oracle_given_TQ():
     Lp = ops.pack_laplacian(_t(c['L'][:nb]))
     score = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(Q), DDp,
                                    _t(c['node_mask'][:nb])).cpu().numpy()
+    # the eigen-space dense-filter kernel takes pair tiles; one molecule per tile is the same sum
+    # per molecule in the same order: bit-identical
+    assert ops.pairing_supported(plan)
+    single = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(Q), DDp,
+                                    _t(c['node_mask'][:nb]), tiling='single').cpu().numpy()
+    unplanned = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(Q), DDp,
+                                       _t(c['node_mask'][:nb]), tiling='none').cpu().numpy()
   assert rel_err(score, ref) < 1e-5
+  np.testing.assert_array_equal(single, score)
+  np.testing.assert_array_equal(unplanned, score)
 
 
 class _fixed_randn(object):
