@@ -362,7 +362,44 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
              'max_rel_dev_filters_vs_fp32_mode': float((DDp - DD32).abs().max() / DD32.abs().max()),
              'max_rel_dev_scores_vs_fp32_mode': float((score - score32).abs().max() /
                                                       score32.abs().max())}
+    split_score = score
     score = score32
+  # self-verification of config 4 on a bounded sample of the timed batch: the scores of both filter
+  # GEMM modes against the fp64 oracle (exact arithmetic of the reference's formulas, same q1).
+  # An fp32 Lanczos recurrence is a noisy function (the reference's own fp32 run sits 1e-6 .. 2e-4
+  # from exact arithmetic), so molecules are classified by the oracle's RAW betas:
+  # "well separated" = every beta at least 10x away from the 1e-4 breakdown threshold;
+  # within 10x the breakdown decision itself is a coin flip of rounding — counted, not judged.
+  parity = None
+  try:
+    import oracle
+    ns_ = min(B, 128)
+    Pn = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    ref64, _, betas = oracle.ada_lanczos_net_forward(
+        Pn, cfg, node_feat[:ns_].cpu().numpy(), L[:ns_].cpu().numpy(), mask_u8[:ns_].cpu().numpy(),
+        q1[:ns_, :, 0].cpu().numpy(), dtype=np.float64, return_raw_betas=True)
+    with np.errstate(divide='ignore'):
+      sep = np.maximum(betas / 1e-4, 1e-4 / np.maximum(betas, 1e-300)).min(axis=1)
+    well = sep >= 10
+    parity = {'against': 'oracle.ada_lanczos_net_forward in float64 (exact arithmetic of '
+                         'model/ada_lanczos_net.py:289-368, same start vector) on the first %d '
+                         'molecules of the timed batch; per molecule max |score - ref| / max |ref_b|' % ns_,
+              'well_separated_n': int(well.sum()), 'near_threshold_n': int((~well).sum())}
+    for tag, sc in (('fp32', score32), ('f16x3', split_score)):
+      e = np.abs(sc[:ns_].cpu().numpy().astype(np.float64) - ref64).max(axis=1) / \
+          np.abs(ref64).max(axis=1)
+      parity[tag] = {'well_separated_within_1e-5': int((e[well] <= 1e-5).sum()),
+                     'well_separated_median': float(np.median(e[well])) if well.any() else None,
+                     'well_separated_worst': float(e[well].max()) if well.any() else None,
+                     'near_threshold_worst': float(e[~well].max()) if (~well).any() else None}
+    parity['note'] = ('the unmodified reference run in fp32 is itself up to ~2e-4 from exact arithmetic '
+                      'on well-separated molecules (tests/golden/ada_e2e.npz): the asserted protocol '
+                      '— 1e-5 where the reference is within 2e-6 of fp64, else 3x the reference\'s own '
+                      'noise — lives in tests/test_gpu_ada.py; these are the raw distances from '
+                      'exact arithmetic')
+    del Pn
+  except Exception as e:  # noqa: BLE001
+    parity = {'error': repr(e)[:300]}
   fp = net._ada_filter_plan(plan)  # folded first / last Linear (symmetry + band of T^p)
   n_in, n_out = fp['W1'][0].shape[1], fp['W4'][0].shape[0]
   mlp_flops = nl * 2 * B * (n_in * 4096 + 2 * 4096 * 4096 + 4096 * n_out)
@@ -384,7 +421,9 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
                                         'folded into the first / last weights)' % (n_in, n_out),
                               'note': 'achieved prices the flops executed; stage time includes '
                                       'the input gather and the 7 output scatters'},
-          'split_precision_mode': split, 'finite': finite}
+          'conv_kernel': 'lanczosnet_forward_kernel<4,10,2,0,0>: dense K x K filters in eigen space '
+                         '(Q [sum_s DD_s (Q^T X W_s^T)]), pair tiles',
+          'split_precision_mode': split, 'parity': parity, 'finite': finite}
 
 
 def main():

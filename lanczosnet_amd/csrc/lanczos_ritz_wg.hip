@@ -92,6 +92,9 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
   __syncthreads();
 
   int nrestart = 0;
+#ifdef LNZ_PROFILE_PHASES
+  long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
+#endif
   if (n > 0) {
     // (output row, segment) split of the length-n reductions with n outputs (A w; w -= Q c)
     const int row_n = tid % n, seg_n = tid / n;
@@ -250,6 +253,9 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       w = x;
     }
     __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+    tp1 = clock64();
+#endif
 
     // ---- implicit-shift QL (EISPACK tql2 recurrences) on per-wave copies of (d, e); the
     //      rotations are applied to rows i, i+1 of Qt at this thread's own element
@@ -265,8 +271,18 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       double f = 0.0, tst1 = 0.0;
       for (int l = 0; l < n; ++l) {
         tst1 = fmax(tst1, fabs(wd[l]) + fabs(we[l]));
-        int m = l;
-        while (m < n - 1 && fabs(we[m]) > kEps * tst1) ++m;
+        // first m >= l with a negligible coupling e_m (m = n-1 at the latest): 64 candidates per
+        // pass, one per lane, instead of a dependent LDS read per index
+        int m = n - 1;
+        for (int base = l; base < n - 1; base += 64) {
+          const int idx = base + lane;
+          const bool small = idx < n - 1 && !(fabs(we[idx]) > kEps * tst1);
+          const unsigned long long mk = __ballot(small);
+          if (mk) {
+            m = base + __builtin_ctzll(mk);
+            break;
+          }
+        }
         if (m > l) {
           int iter = 0;
           double el;
@@ -305,14 +321,34 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
               g = c * ei;
               const double hp = c * p;
               const double tt = fma(p, p, ei * ei);
-              const double rinv = 1.0 / sqrt(tt), rad = tt * rinv;
+              const double num = fma(p, di, -(ei * g));  // (p d_i - e_i g): off the rsqrt chain
+              // 1/sqrt(tt): hardware seed + two Newton steps (tt is a normal double here:
+              // |e_i| > eps * tst1 for l <= i < m).  The IEEE sqrt + divide expand to ~40 dependent
+              // fp64 instructions on the rotation-to-rotation critical path (n = 100: 4 ms per graph);
+              // v_rsq_f64's seed is good to ~2^-26, each step squares that.
+              double y = __builtin_amdgcn_rsq(tt);
+              {
+                const double hy = 0.5 * y;
+                const double er = fma(-(tt * y), hy, 0.5);
+                y = fma(y, er, y);
+              }
+              {
+                const double hy = 0.5 * y;
+                const double er = fma(-(tt * y), hy, 0.5);
+                y = fma(y, er, y);
+              }
+              const double rad = tt * y;
               const double e_next = s * rad;
-              s = ei * rinv;
-              c = p * rinv;
-              p = c * di - s * g;
+              s = ei * y;
+              c = p * y;
+              p = y * num;  // = c d_i - s g
               const double d_next = hp + s * (c * g + s * di);
-              we[i + 1] = e_next;  // every lane stores the same value
-              wd[i + 1] = d_next;
+              // ONE lane stores (64 lanes storing one address serialise in the LDS); the LDS
+              // operations of a wave execute in order, so every lane's later reads see the value
+              if (lane == 0) {
+                we[i + 1] = e_next;
+                wd[i + 1] = d_next;
+              }
               if (own) Qt[(size_t)(i + 1) * LD + tid] = s * z0 + c * carry;
               carry = c * z0 - s * carry;
               z0 = znext;
@@ -320,17 +356,29 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
               di = di_n;
             }
             if (own) Qt[(size_t)l * LD + tid] = carry;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             p = -s * s2 * c3 * el1 * we[l] / dl1;
             el = s * p;
-            we[l] = el;
-            wd[l] = c * p;
+            if (lane == 0) {
+              we[l] = el;
+              wd[l] = c * p;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           } while (fabs(el) > kEps * tst1 && iter < 60);
         }
-        wd[l] = wd[l] + f;
-        we[l] = 0.0;
+        const double dfin = wd[l] + f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) {
+          wd[l] = dfin;
+          we[l] = 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
     __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+    tp2 = clock64();
+#endif
     if (tid < n) sm.dd[tid] = wd[tid];  // wave 0's copy (identical in every active wave)
     __syncthreads();
 
@@ -381,6 +429,16 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     }
   }
   if (info && tid == 0) info[b] = nrestart;
+#ifdef LNZ_PROFILE_PHASES
+  __syncthreads();
+  if (tid == 0 && K >= 4) {  // cycles: Lanczos, QL, ordering + output; n
+    const long long tp3 = clock64();
+    D[(int64_t)b * K + 0] = (float)(tp1 - tp0);
+    D[(int64_t)b * K + 1] = (float)(tp2 - tp1);
+    D[(int64_t)b * K + 2] = (float)(tp3 - tp2);
+    D[(int64_t)b * K + 3] = (float)n;
+  }
+#endif
 }
 
 }  // namespace

@@ -10,10 +10,12 @@ import numpy as np
 EPS = float(np.finfo(np.float32).eps)  # model/ada_lanczos_net.py:8
 
 
-def ada_lanczos_layer(A, mask, q1, num_eig_vec, use_reorth=True, dtype=np.float32):
+def ada_lanczos_layer(A, mask, q1, num_eig_vec, use_reorth=True, dtype=np.float32,
+                      return_raw_betas=False):
   """A: [B,N,N] sym, mask: [B,N] (0/1) or None, q1: [B,N] raw start vector (before masking).
 
-  Returns T [B,K,K], Q [B,N,K]."""
+  Returns T [B,K,K], Q [B,N,K] (+ the RAW beta_1..beta_T of every step, [B,T], before the
+  breakdown mask is applied — what the parity protocol classifies molecules by)."""
   A = np.asarray(A, dtype=dtype)
   B, N = A.shape[0], A.shape[1]
   K = num_eig_vec
@@ -49,6 +51,7 @@ def ada_lanczos_layer(A, mask, q1, num_eig_vec, use_reorth=True, dtype=np.float3
     Q[ii + 1] = (z * valid[-1]) / (beta[ii] + eps)  # :202
 
   alpha = np.concatenate(alpha[1:], axis=1)[:, :, 0]  # B x T
+  raw_betas = np.concatenate(beta[1:], axis=1)[:, :, 0]
   beta = np.concatenate(beta[1:-1], axis=1)[:, :, 0] if T_it > 1 else np.zeros((B, 0), dtype)
   valid = np.concatenate(valid, axis=1)[:, :, 0]  # B x T
   idx_mask = valid.sum(axis=1).astype(np.int64)  # :209
@@ -76,6 +79,8 @@ def ada_lanczos_layer(A, mask, q1, num_eig_vec, use_reorth=True, dtype=np.float3
     Qp = np.zeros((B, N, K), dtype=dtype)
     Qp[:, :, :T_it] = Qm
     T, Qm = Tp, Qp
+  if return_raw_betas:
+    return T, Qm, raw_betas
   return T, Qm
 
 
@@ -155,7 +160,8 @@ def ada_spectral_filter_dd(P, cfg, T, layer_idx, dtype=np.float32):
   return (DD + DD.transpose(0, 2, 1, 3)) * dtype(0.5)
 
 
-def ada_lanczos_net_forward(P, cfg, node_feat, L, mask, q1, dtype=np.float32, TQ=None):
+def ada_lanczos_net_forward(P, cfg, node_feat, L, mask, q1, dtype=np.float32, TQ=None,
+                            return_raw_betas=False):
   """score [B,P] of AdaLanczosNet (eval mode).  q1: raw start vector [B,N] (the reference draws
   torch.randn(B,N,1) at :161).  TQ: optional precomputed (T, Q) to decouple stage tests."""
   P = {k: np.asarray(v, dtype=dtype) for k, v in P.items()}
@@ -168,8 +174,10 @@ def ada_lanczos_net_forward(P, cfg, node_feat, L, mask, q1, dtype=np.float32, TQ
   if TQ is None:
     adj = (L[:, :, :, 0] != 0).astype(dtype)  # :310-311
     Le = ada_graph_laplacian(state, adj, dtype)  # :312
-    T, Q = ada_lanczos_layer(Le, mask, q1, cfg['num_eig_vec'], True, dtype)  # :315 (F7: reorth on)
+    T, Q, raw_betas = ada_lanczos_layer(Le, mask, q1, cfg['num_eig_vec'], True, dtype,
+                                        return_raw_betas=True)  # :315 (F7: reorth on)
   else:
+    raw_betas = None
     T, Q = (np.asarray(x, dtype=dtype) for x in TQ)
   for tt in range(cfg['num_layer']):
     msg = []
@@ -194,4 +202,7 @@ def ada_lanczos_net_forward(P, cfg, node_feat, L, mask, q1, dtype=np.float32, TQ
   att = 1.0 / (1.0 + np.exp(-(flat @ P['att_func.0.weight'].T + P['att_func.0.bias'])))
   y = (att * y).reshape(B, N, -1)
   m = np.asarray(mask).astype(bool)
-  return np.stack([y[b, m[b], :].mean(axis=0) for b in range(B)]).astype(dtype), (T, Q)
+  score = np.stack([y[b, m[b], :].mean(axis=0) for b in range(B)]).astype(dtype)
+  if return_raw_betas:
+    return score, (T, Q), raw_betas
+  return score, (T, Q)
