@@ -216,6 +216,75 @@ def lanczos_large_leg(dev, B=256, N=2048, M=64, reps=3):
           'reps_ms': [round(x, 3) for x in ts], 'symmetric_stream': sym}
 
 
+def graph_config_leg(dev, B=64, reps=5):
+  """The reference's own graph configuration (config/graph_lanczos_net.yaml with
+  dataset/get_graph_data.py:15-49): G(n, 0.5) graphs, n ~ U{20..100}, K = 20, one edge type,
+  LanczosNetGeneral 10 -> 7 x 128 -> 2, test batch size 64.  Device pipeline from the raw adjacency:
+  L4 (lnz_laplacian_l4) -> full-length Lanczos + parallel tridiagonal eigensolver, one workgroup
+  per graph (lnz_lanczos_ritz, csrc/lanczos_ritz_wg.hip) -> forward (streamed kernels, split
+  precision).  Next to it the host's numpy.linalg.eigh + |lambda| sort on the same graphs (the
+  reference's (D, V) producer, utils/data_helper.py:197-223), 16 graphs."""
+  from lanczosnet_amd.model import LanczosNetGeneral
+  K = 20
+  cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
+             num_eig_vec=K, spectral_filter_kind='MLP', input_dim=10, hidden_dim=[128] * 7,
+             output_dim=2, num_layer=7, num_atom=0)
+  rs = np.random.RandomState(123)
+  ns = rs.randint(20, 101, size=B).astype(np.int32)
+  N = int(ns.max())
+  adjs = np.zeros((B, N, N, 1), np.float32)
+  for b in range(B):
+    a = np.triu((rs.rand(ns[b], ns[b]) < 0.5).astype(np.float32), 1)
+    adjs[b, :ns[b], :ns[b], 0] = a + a.T
+  X = rs.randn(B, N, 10).astype(np.float32)
+  mask = (np.arange(N)[None, :] < ns[:, None]).astype(np.uint8)
+  torch.manual_seed(1234)
+  net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval().to(dev)
+  t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+  ad, nd, Xd, md = t(adjs), t(ns), t(X), t(mask)
+  acc = np.zeros(3)
+  with torch.no_grad():
+    for it in range(reps + 2):
+      ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+      ev[0].record()
+      L = ops.laplacian_l4(ad, nd)
+      ev[1].record()
+      D, V, info = ops.lanczos_ritz(L[:, :, :, 0], nd, K, return_info=True)
+      ev[2].record()
+      score = net(Xd, L, D, V, mask=md)
+      ev[3].record()
+      torch.cuda.synchronize()
+      if it >= 2:
+        acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
+  acc /= reps
+  t0 = time.perf_counter()
+  Ln = L[:16, :, :, 0].cpu().numpy().astype(np.float64)
+  worst = 0.0
+  Dn = D[:16].cpu().numpy()
+  t0 = time.perf_counter()
+  for b in range(16):
+    e, v = np.linalg.eigh(Ln[b, :ns[b], :ns[b]])
+    idx = np.argsort(-np.abs(e), kind='mergesort')
+    worst = max(worst, float(np.abs(e[idx[:K]] - Dn[b]).max()))
+  eigh_ms = (time.perf_counter() - t0) / 16 * 1e3
+  bytes_ = float((4.0 * ns.astype(np.float64) ** 2).sum() + B * (4 * K + 4 * N * K))
+  return {'workload': 'config/graph_lanczos_net.yaml: B=%d graphs G(n,0.5), n~U{20..100} (N=%d), K=20, '
+                      'E+1=2, LanczosNetGeneral 10->7x128->2, fp32 (split-precision streamed conv)'
+                      % (B, N),
+          'stage_ms': {'laplacian_l4': round(acc[0], 4), 'lanczos_ritz(workgroup per graph)':
+                       round(acc[1], 4), 'forward': round(acc[2], 4)},
+          'ms_per_batch': round(float(acc.sum()), 4),
+          'graphs_per_s': round(B / float(acc.sum()) * 1e3, 1),
+          'ritz': {'kernel': 'lanczos_ritz_wg_kernel<false>', 'graphs_per_s': round(B / acc[1] * 1e3, 1),
+                   'algorithmic_GBps': round(bytes_ / acc[1] / 1e6, 3),
+                   'bound': 'latency (one workgroup per graph, %d of 256 CUs busy; serial Lanczos '
+                            'recurrence of n steps)' % B,
+                   'qL_fallbacks': int((info >= 256).sum().item()),
+                   'max_abs_dD_vs_numpy_eigh_16_graphs': worst,
+                   'host_numpy_eigh_ms_per_graph': round(eigh_ms, 4)},
+          'finite': bool(torch.isfinite(score).all())}
+
+
 def large_graph_leg(dev, A, D, V, reps=3):
   """BASELINE configs[4] conv stage: LanczosNetGeneral (config/graph_lanczos_net.yaml widths:
   input 10, 7 x 128, output 2, E+1 = 2 channels, S = 8 long scales, K = 64) on B dense graphs of
@@ -660,7 +729,7 @@ def main():
       np.mean([ev[i][4].elapsed_time(ev[i][5]) for i in range(args.steps)]))
 
   # secondary measurements (N = 1 only, never `value`)
-  sweep = large = large_conv = ada = None
+  sweep = large = large_conv = ada = graphcfg = None
   if world == 1 and args.gemm == 'fp32' and not args.zero_params and args.sweep:
     sweep = forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, (1024, 4096, 16384)
                                 if B == 1024 else (B,))
@@ -682,6 +751,7 @@ def main():
       large = r_
     torch.cuda.empty_cache()
     ada = _leg(ada_leg, dev, L, node_feat, mask_u8)
+    graphcfg = _leg(graph_config_leg, dev)
 
   if rank == 0:
     ms_per_step = 1e3 * elapsed / args.steps
@@ -780,6 +850,8 @@ def main():
       out['config']['large_graph_conv_mode'] = large_conv
     if ada is not None:
       out['config']['ada_mode'] = ada
+    if graphcfg is not None:
+      out['config']['graph_config_mode'] = graphcfg
     if world == 1 and not args.no_cpu_baseline:
       # the reference's CPU path on the host cores, at most 32 intra-op threads: the batched GEMMs
       # of a 32-node tile stop scaling long before that, and a 256-thread pool on them does not

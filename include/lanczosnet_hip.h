@@ -54,13 +54,13 @@ int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B, int N, in
  *            of T - lambda (dlar1v / MRRR vector), near-degenerate copies re-orthogonalised in
  *            lane order, Ritz vectors V = Q*S; the implicit-shift QL sweep only as the fallback
  *            (info += 256);
- *   32 < N <= 64: implicit-shift QL (tql2 recurrences) with the rotations applied to Q, so the
- *            Ritz vectors come out directly; one wavefront per graph, everything in LDS;
- *   64 < N <= 192 (the reference's synthetic-graph configuration, dataset/get_graph_data.py:15-49
- *            with config/graph_lanczos_net.yaml: n in [20,100]): one 256-thread workgroup per
- *            graph, A staged once into LDS, the fp64 basis in LDS up to N = 113 and in a workspace
+ *   32 < N <= 192 (the reference's synthetic-graph configuration, dataset/get_graph_data.py:15-49
+ *            with config/graph_lanczos_net.yaml: n in [20,100]): one 512-thread workgroup per
+ *            graph, A staged once into LDS, the fp64 basis in LDS up to N = 111 and in a workspace
  *            above (lnz_lanczos_ritz_workspace_bytes; without one lnz_lanczos_ritz takes a
- *            stream-ordered allocation for the launch), the same QL sweep run barrier-free;
+ *            stream-ordered allocation for the launch); eigenvalues by Sturm-count section search
+ *            (one per thread), the K selected eigenvectors by twisted factorisation, V = Q S;
+ *            the QL sweep, run barrier-free on per-wave copies of T, as the fallback (info += 256);
  * then stable ordering by descending |lambda| (ties: ascending lambda), cut / zero-pad to K.
  * Produces exactly
  * the (D, V) that utils/data_helper.py:197-223 (np.linalg.eigh + mergesort on -|eig|)
@@ -76,9 +76,15 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
                      int32_t* info, lnz_stream_t stream);
 
 /* The same with an explicit workspace for the fp64 Krylov basis of graphs too large to keep it in
- * LDS next to A (N > 113): lnz_lanczos_ritz_workspace_bytes(B, N) bytes (0 when none is needed).
+ * LDS next to A (N > 111): lnz_lanczos_ritz_workspace_bytes(B, N) bytes (0 when none is needed).
  * Always takes the workgroup-per-graph kernel (any N <= 192); flags bit 0 places the basis in the
- * workspace even when it would fit in LDS (used by the tests to cover both variants at one size). */
+ * workspace even when it would fit in LDS, bit 1 takes the QL sweep instead of the parallel
+ * tridiagonal eigensolver (both used by the tests to cover every variant at one size).
+ * The workgroup kernel's eigensolver: T split into unreduced blocks, one eigenvalue per thread by
+ * section search on Sturm counts, the eigenvectors of the K SELECTED eigenvalues by the twisted
+ * factorisation of T - lambda (one thread per vector), V = Q S; two eigenvalues of one block closer
+ * than 1e-8 |T| send the graph to the QL sweep (info += 256), as does K > ~N/2 (no room for the
+ * vectors next to T in LDS). */
 int64_t lnz_lanczos_ritz_workspace_bytes(int B, int N);
 int lnz_lanczos_ritz_ws(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                         const int32_t* n_nodes, int B, int N, int K, float* D, float* V,

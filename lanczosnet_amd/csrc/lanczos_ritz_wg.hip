@@ -11,12 +11,12 @@
 //   * A (fp32, n x n, row pitch N|1 floats) is staged ONCE into LDS: HBM traffic per graph stays
 //     the algorithmic 4 n^2 (A) + 4 K (D) + 4 N K (V) bytes;
 //   * the Krylov basis Qt[i][r] = q_i[r] (fp64, row pitch N|1 doubles) lives in LDS next to A while
-//     12 N (N|1) + 14 KB <= 160 KB, i.e. N <= 111 (every graph of the reference generator); for
+//     12 N (N|1) + 12 KB <= 158 KB, i.e. N <= 111 (every graph of the reference generator); for
 //     111 < N <= 192 A alone takes up to 148 KB and the basis moves to a caller-provided workspace
 //     (N (N|1) 8 bytes per graph, L2 / MALL resident: it is written and re-read by the one CU that
 //     owns the graph) — template parameter QG;
 //   * every reduction of a step (A w, the j+1 Gram-Schmidt dot products, the update w -= Q c) is
-//     split over all 256 threads as (output row) x (segment of the reduction range); partials are
+//     split over all 512 threads as (output row) x (segment of the reduction range); partials are
 //     combined through LDS in a fixed order, so alpha / beta are bit-identical in every thread and
 //     the breakdown / restart control flow stays workgroup-uniform.  No atomics, no shuffles;
 //   * QL runs barrier-free: thread r owns element r of every basis vector (the rotation of rows
@@ -28,10 +28,12 @@ namespace {
 
 constexpr double kBreakdownTol = 1e-8;  // see lanczos_ritz.hip
 constexpr double kEps = 2.220446049250313e-16;
-constexpr int kNT = 256;     // threads per workgroup
+constexpr int kNT = 512;     // threads per workgroup (the reductions of a Lanczos step are split over all of them)
 constexpr int kWaves = kNT / 64;
 constexpr int kNMax = 192;   // largest graph one workgroup owns
-constexpr int kLdsMax = 160 * 1024;
+// LDS a workgroup may ask for: the CU has 160 KB; a request of 163,712 B was refused by the runtime
+// (HSA_STATUS_ERROR_INVALID_ALLOCATION) where 163,020 B had launched — keep 2 KB clear
+constexpr int kLdsMax = 160 * 1024 - 2048;
 
 struct WgFixed {  // fixed part of the LDS block
   double zb[kNMax];    // broadcast of the current vector
@@ -55,11 +57,46 @@ inline size_t wg_lds_bytes(int N, bool qg) {
   return sizeof(WgFixed) + (qg ? 0 : (size_t)N * (size_t)(N | 1) * sizeof(double)) + wg_a_bytes(N);
 }
 
+__device__ __forceinline__ double rcp_nr(double x) {  // 1/x: hardware seed + one Newton step
+  double y = __builtin_amdgcn_rcp(x);
+  return fma(y, fma(-x, y, 1.0), y);
+}
+
+// Eigenvalues of rows s..t of T (an unreduced block: no coupling to its neighbours) below x — the
+// Sturm count in product form, p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: one dependent FMA per
+// row instead of a division (LAPACK dstebz's recurrence); the count is the number of sign changes.
+// Two probe points per call so that two independent chains are in flight.
+__device__ __forceinline__ void sturm2(const double* __restrict__ d, const double* __restrict__ e2,
+                                       const int s, const int t, const double xa, const double xb,
+                                       int& ca, int& cb) {
+  double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
+  unsigned na = 0u, nb = 0u;  // sign of the previous p (p_{-1} = 1 > 0)
+  ca = cb = 0;
+  for (int i = s; i <= t; ++i) {
+    const double di = d[i];
+    const double ep = i > s ? e2[i - 1] : 0.0;
+    const double pa = fma(di - xa, a1, -(ep * a2));
+    const double pb = fma(di - xb, b1, -(ep * b2));
+    const unsigned sa = (unsigned)__double2hiint(pa) >> 31, sb = (unsigned)__double2hiint(pb) >> 31;
+    ca += (int)(sa ^ na);
+    cb += (int)(sb ^ nb);
+    na = sa, nb = sb;
+    a2 = a1, a1 = pa, b2 = b1, b1 = pb;
+    if (((i - s) & 7) == 7) {  // keep |p| inside the exponent range
+      const double fa = fabs(a1), fb = fabs(b1);
+      const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
+      const double kb = fb < 1e-100 ? 1e100 : (fb > 1e100 ? 1e-100 : 1.0);
+      a1 *= ka, a2 *= ka, b1 *= kb, b2 *= kb;
+    }
+  }
+}
+
 template <bool QG>
 __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
-    float* __restrict__ V, int32_t* __restrict__ info, double* __restrict__ ws) {
+    float* __restrict__ V, int32_t* __restrict__ info, double* __restrict__ ws,
+    const bool force_ql) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   WgFixed& sm = *reinterpret_cast<WgFixed*>(smem_raw);
   const int LD = N | 1;  // doubles per basis row: odd -> "lane i reads row i" is conflict free
@@ -92,6 +129,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
   __syncthreads();
 
   int nrestart = 0;
+  bool solved_out = false;  // the parallel eigensolver ran: V = Q S is formed at the output
 #ifdef LNZ_PROFILE_PHASES
   long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
 #endif
@@ -133,14 +171,16 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         __syncthreads();
         if (ds < nsd) {
           const double* qi = Qt + (size_t)di * LD;
-          double p0 = 0.0, p1 = 0.0;
+          double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
           int c = dc0;
-          for (; c + 1 < dc1; c += 2) {
+          for (; c + 3 < dc1; c += 4) {   // four independent chains: the LDS latency overlaps
             p0 = fma(qi[c], sm.zb[c], p0);
             p1 = fma(qi[c + 1], sm.zb[c + 1], p1);
+            p2 = fma(qi[c + 2], sm.zb[c + 2], p2);
+            p3 = fma(qi[c + 3], sm.zb[c + 3], p3);
           }
-          if (c < dc1) p0 = fma(qi[c], sm.zb[c], p0);
-          sm.part[ds * cnt + di] = p0 + p1;
+          for (; c < dc1; ++c) p0 = fma(qi[c], sm.zb[c], p0);
+          sm.part[ds * cnt + di] = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
         if (tid < cnt) {
@@ -151,15 +191,17 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         __syncthreads();
         coef += sm.cb[jidx];
         if (seg_n < nsu) {
-          double p0 = 0.0, p1 = 0.0;
+          double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
           int i = ui0;
-          for (; i + 1 < ui1; i += 2) {
+          for (; i + 3 < ui1; i += 4) {
             p0 = fma(Qt[(size_t)i * LD + row_n], sm.cb[i], p0);
             p1 = fma(Qt[(size_t)(i + 1) * LD + row_n], sm.cb[i + 1], p1);
+            p2 = fma(Qt[(size_t)(i + 2) * LD + row_n], sm.cb[i + 2], p2);
+            p3 = fma(Qt[(size_t)(i + 3) * LD + row_n], sm.cb[i + 3], p3);
           }
-          if (i < ui1) p0 = fma(Qt[(size_t)i * LD + row_n], sm.cb[i], p0);
-          if (nsu == 1) x -= p0 + p1;
-          else sm.part[seg_n * n + row_n] = p0 + p1;
+          for (; i < ui1; ++i) p0 = fma(Qt[(size_t)i * LD + row_n], sm.cb[i], p0);
+          if (nsu == 1) x -= (p0 + p1) + (p2 + p3);
+          else sm.part[seg_n * n + row_n] = (p0 + p1) + (p2 + p3);
         }
         if (nsu > 1) {
           __syncthreads();
@@ -188,21 +230,25 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         __syncthreads();
         if (seg_n < nss) {
           const float* ar = As + row_n * LA;
-          double u0 = 0.0, u1 = 0.0, s0 = 0.0, s1 = 0.0;
+          double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, s0 = 0.0, s1 = 0.0;
           int c = sc0;
-          for (; c + 1 < sc1; c += 2) {
-            const double z0 = sm.zb[c], z1 = sm.zb[c + 1];
+          for (; c + 3 < sc1; c += 4) {
+            const double z0 = sm.zb[c], z1 = sm.zb[c + 1], z2 = sm.zb[c + 2], z3 = sm.zb[c + 3];
             u0 = fma((double)ar[c], z0, u0);
             u1 = fma((double)ar[c + 1], z1, u1);
+            u2 = fma((double)ar[c + 2], z2, u2);
+            u3 = fma((double)ar[c + 3], z3, u3);
             s0 = fma(z0, z0, s0);
             s1 = fma(z1, z1, s1);
+            s0 = fma(z2, z2, s0);
+            s1 = fma(z3, z3, s1);
           }
-          if (c < sc1) {
+          for (; c < sc1; ++c) {
             const double z0 = sm.zb[c];
             u0 = fma((double)ar[c], z0, u0);
             s0 = fma(z0, z0, s0);
           }
-          sm.part[seg_n * n + row_n] = u0 + u1;
+          sm.part[seg_n * n + row_n] = (u0 + u1) + (u2 + u3);
           if (row_n == 0) sm.pn[seg_n] = s0 + s1;
         }
         __syncthreads();
@@ -257,10 +303,75 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     tp1 = clock64();
 #endif
 
-    // ---- implicit-shift QL (EISPACK tql2 recurrences) on per-wave copies of (d, e); the
-    //      rotations are applied to rows i, i+1 of Qt at this thread's own element
+    // ---- eigenvalues of T with every thread working (the QL sweep below is one serial chain of
+    //      ~n^2 rotations at ~700 cycles each: 5 M cycles at n = 100):
+    //   1. T splits where Lanczos restarted (coupling exactly 0) or a coupling is negligible; thread
+    //      k owns the (k - s)-th eigenvalue of its unreduced block [s, t] — simple there, while equal
+    //      eigenvalues of different blocks get eigenvectors with disjoint support;
+    //   2. section search on Sturm counts, two probes per pass (the bracket shrinks 3x);
+    //   3. two eigenvalues of ONE block closer than 1e-8 |T| (a degenerate eigenvalue whose second
+    //      copy crept into the Krylov space through round-off instead of a clean breakdown): the
+    //      twisted-factorisation vectors further down would lose orthogonality like eps / gap — the
+    //      workgroup takes the QL sweep instead (info += 256; rare).
+    //   T's (d, e, e^2) move to the head of the dead A region; the eigenvectors of the kk SELECTED
+    //   eigenvalues are computed after the ordering (twisted factorisation, then V = Q S).
+    double* Td = reinterpret_cast<double*>(As);
+    double* Te = Td + N;
+    double* Te2 = Te + N;
+    double* zv = Te2 + N;  // [n][kk]: component i of selected vector q at zv[i * kk + q]
+    bool solved = (size_t)3 * N * sizeof(double) + (size_t)kk * n * sizeof(double) <= wg_a_bytes(N) &&
+                  !force_ql;
+    if (solved) {
+      if (tid < n) {
+        const double di = sm.dd[tid], ei = tid < n - 1 ? sm.ee[tid] : 0.0;
+        const double dn = tid < n - 1 ? sm.dd[tid + 1] : 0.0;
+        const bool live = tid < n - 1 && fabs(ei) > kEps * (fabs(di) + fabs(dn));
+        Td[tid] = di;
+        Te[tid] = live ? ei : 0.0;
+        Te2[tid] = live ? ei * ei : 0.0;
+      }
+      __syncthreads();
+      // Gershgorin bound of the spectrum
+      if (tid < n) sm.zb[tid] = fabs(Td[tid]) + (tid > 0 ? fabs(Te[tid - 1]) : 0.0) + fabs(Te[tid]);
+      __syncthreads();
+      double gmax = 0.0;
+      for (int i = 0; i < n; ++i) gmax = fmax(gmax, sm.zb[i]);
+      const double gsc = gmax > 0.0 ? gmax : 1.0;
+      int bs = tid, bt = tid;
+      double lam = 0.0;
+      if (tid < n) {
+        while (bs > 0 && Te[bs - 1] != 0.0) --bs;
+        while (bt < n - 1 && Te[bt] != 0.0) ++bt;
+        const int jloc = tid - bs;
+        double lo = -gsc * 1.0000001, hi = gsc * 1.0000001;
+        for (int it = 0; it < 48; ++it) {
+          const double w = (hi - lo) * (1.0 / 3.0);
+          const double xa = lo + w, xb = lo + 2.0 * w;
+          int ca, cb;
+          sturm2(Td, Te2, bs, bt, xa, xb, ca, cb);
+          if (ca > jloc) hi = xa;
+          else if (cb > jloc) lo = xa, hi = xb;
+          else lo = xb;
+          // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|
+          if ((hi - lo) <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc)) break;
+        }
+        lam = 0.5 * (lo + hi);
+      }
+      __syncthreads();  // zb (Gershgorin rows) is dead: reuse for the eigenvalues
+      if (tid < n) sm.zb[tid] = lam;
+      __syncthreads();
+      const bool cluster = tid < n && tid > bs && (lam - sm.zb[tid - 1]) <= 1e-8 * gsc;
+      solved = !__syncthreads_or(cluster ? 1 : 0);
+      if (solved && tid < n) sm.dd[tid] = lam;   // (T itself stays in Td / Te / Te2)
+      __syncthreads();
+    }
+
+    // ---- fallback: implicit-shift QL (EISPACK tql2 recurrences) on per-wave copies of (d, e);
+    //      the rotations are applied to rows i, i+1 of Qt at this thread's own element
     double* wd = reinterpret_cast<double*>(As) + (size_t)wave * 2 * N;
     double* we = wd + N;
+    if (!solved) {
+    nrestart += 256;  // diagnostic: the QL sweep ran (info = restarts + 256)
     for (int i = lane; i < n; i += 64) {
       wd[i] = sm.dd[i];
       we[i] = sm.ee[i];
@@ -376,11 +487,12 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       }
     }
     __syncthreads();
+    if (tid < n) sm.dd[tid] = wd[tid];  // wave 0's copy (identical in every active wave)
+    __syncthreads();
+    }  // !solved
 #ifdef LNZ_PROFILE_PHASES
     tp2 = clock64();
 #endif
-    if (tid < n) sm.dd[tid] = wd[tid];  // wave 0's copy (identical in every active wave)
-    __syncthreads();
 
     // ---- order by descending |lambda| (ties: ascending lambda, then index)
     // = np.argsort(-|eig|, kind='mergesort') on eigh's ascending output (utils/data_helper.py:218-223)
@@ -395,8 +507,62 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       sm.perm[rank] = tid;
     }
     __syncthreads();
+    if (solved) {
+      // ---- eigenvectors of the kk selected eigenvalues: twisted factorisation of T - lambda on the
+      //      eigenvalue's block (the dlar1v / MRRR vector: stationary and progressive qd transforms,
+      //      twist where |gamma| is smallest), one thread per vector, no pivoting, no iteration.
+      //      One array per vector: D+ in place, D- recomputed into the part above the twist.
+      if (tid < kk) {
+        const int q = tid, idx = sm.perm[q];
+        const double lamq = sm.dd[idx];
+        int s0 = idx, t0 = idx;
+        while (s0 > 0 && Te[s0 - 1] != 0.0) --s0;
+        while (t0 < n - 1 && Te[t0] != 0.0) ++t0;
+        double gs = 0.0;
+        for (int i = s0; i <= t0; ++i) gs = fmax(gs, fabs(Td[i]) + fabs(Te[i]));
+        const double tiny = kEps * (gs > 0.0 ? gs : 1.0);
+        auto guard = [&](double v) { return fabs(v) < tiny ? (v < 0.0 ? -tiny : tiny) : v; };
+        for (int i = 0; i < n; ++i) zv[(size_t)i * kk + q] = 0.0;
+        double Dp = 1.0;
+        for (int i = s0; i <= t0; ++i) {   // stationary transform, top down
+          const double di = Td[i] - lamq;
+          Dp = guard(i > s0 ? di - Te2[i - 1] * rcp_nr(Dp) : di);
+          zv[(size_t)i * kk + q] = Dp;
+        }
+        double Dn = 1.0, gbest = 1e300;
+        int tw = s0;
+        for (int i = t0; i >= s0; --i) {   // progressive transform, bottom up: find the twist
+          const double di = Td[i] - lamq;
+          Dn = guard(i < t0 ? di - Te2[i] * rcp_nr(Dn) : di);
+          const double g = fabs(zv[(size_t)i * kk + q] + Dn - di);
+          if (g < gbest) gbest = g, tw = i;
+        }
+        Dn = 1.0;
+        for (int i = t0; i > tw; --i) {    // D- again, kept where D+ is no longer needed
+          const double di = Td[i] - lamq;
+          Dn = guard(i < t0 ? di - Te2[i] * rcp_nr(Dn) : di);
+          zv[(size_t)i * kk + q] = Dn;
+        }
+        double zc = 1.0, nn = 1.0;
+        zv[(size_t)tw * kk + q] = 1.0;
+        for (int i = tw - 1; i >= s0; --i) {   // z_i = -(e_i / D+_i) z_{i+1}
+          zc = -(Te[i] * rcp_nr(zv[(size_t)i * kk + q])) * zc;
+          zv[(size_t)i * kk + q] = zc;
+          nn = fma(zc, zc, nn);
+        }
+        zc = 1.0;
+        for (int i = tw + 1; i <= t0; ++i) {   // z_i = -(e_{i-1} / D-_i) z_{i-1}
+          zc = -(Te[i - 1] * rcp_nr(zv[(size_t)i * kk + q])) * zc;
+          zv[(size_t)i * kk + q] = zc;
+          nn = fma(zc, zc, nn);
+        }
+        const double sc = rsqrt(nn);
+        for (int i = s0; i <= t0; ++i) zv[(size_t)i * kk + q] *= sc;
+      }
+      __syncthreads();
+    }
     // sign convention: largest-magnitude component (first one on ties) is positive
-    if (tid < kk) {
+    if (!solved && tid < kk) {
       const double* v = Qt + (size_t)sm.perm[tid] * LD;
       double best = 0.0;
       float sg = 1.0f;
@@ -410,13 +576,47 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       sm.sgn[tid] = sg;
     }
     __syncthreads();
+    solved_out = solved;
   }
 
   // ---- write D [K] and V [N, K] (dataset/graph_data.py:262-287: zero rows >= n, zero slots >= n)
   for (int k = tid; k < K; k += kNT)
     D[(int64_t)b * K + k] = k < kk ? (float)sm.dd[sm.perm[k]] : 0.0f;
   float* Vb = V + (int64_t)b * N * K;
-  {
+  if (solved_out) {
+    // ---- V = Q S for the selected vectors, fp32 to the output; the sign convention (largest
+    //      magnitude component positive, first one on ties) is applied in place afterwards
+    const double* zvp = reinterpret_cast<const double*>(As) + 3 * (size_t)N;
+    for (int idx = tid; idx < N * K; idx += kNT) {
+      const int rr = idx / K, k = idx - rr * K;
+      if (rr >= n || k >= kk) Vb[idx] = 0.0f;
+    }
+    const int row = tid % n, seg = tid / n, nseg = kNT / n;
+    if (seg < nseg) {
+      for (int q = seg; q < kk; q += nseg) {
+        double a0 = 0.0, a1 = 0.0;
+        int i = 0;
+        for (; i + 1 < n; i += 2) {
+          a0 = fma(Qt[(size_t)i * LD + row], zvp[(size_t)i * kk + q], a0);
+          a1 = fma(Qt[(size_t)(i + 1) * LD + row], zvp[(size_t)(i + 1) * kk + q], a1);
+        }
+        if (i < n) a0 = fma(Qt[(size_t)i * LD + row], zvp[(size_t)i * kk + q], a0);
+        Vb[(size_t)row * K + q] = (float)(a0 + a1);
+      }
+    }
+    __syncthreads();
+    if (tid < kk) {
+      float best = 0.0f, sg = 1.0f;
+      for (int r = 0; r < n; ++r) {
+        const float v = Vb[(size_t)r * K + tid], a = fabsf(v);
+        if (a > best) best = a, sg = v < 0.0f ? -1.0f : 1.0f;
+      }
+      sm.sgn[tid] = sg;
+    }
+    __syncthreads();
+    if (seg < nseg)
+      for (int q = seg; q < kk; q += nseg) Vb[(size_t)row * K + q] *= sm.sgn[q];
+  } else {
     const int dq = kNT / K, dr = kNT - dq * K;
     int rr = tid / K, k = tid - rr * K;
     for (int idx = tid; idx < N * K; idx += kNT) {
@@ -444,13 +644,14 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
 }  // namespace
 
 extern "C" int64_t lnz_lanczos_ritz_workspace_bytes(int B, int N) {
-  if (B <= 0 || N <= 64 || N > kNMax) return 0;
+  if (B <= 0 || N <= 32 || N > kNMax) return 0;
   if (wg_lds_bytes(N, false) <= (size_t)kLdsMax) return 0;
   return (int64_t)B * N * (N | 1) * (int64_t)sizeof(double);
 }
 
 // Shared by lnz_lanczos_ritz (lanczos_ritz.hip) and lnz_lanczos_ritz_ws.
-// flags: bit 0 = the basis goes to the workspace even if it would fit in LDS (testing).
+// flags: bit 0 = the basis goes to the workspace even if it would fit in LDS; bit 1 = the QL sweep
+// instead of the parallel tridiagonal eigensolver (both for testing).
 int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                        const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                        int32_t* info, void* workspace, int64_t workspace_bytes, int flags,
@@ -480,7 +681,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N,
-                       K, D, V, info, (double*)workspace);
+                       K, D, V, info, (double*)workspace, (flags & 2) != 0);
     const int rc = lnz::check_launch("lnz_lanczos_ritz");
     if (owned) (void)hipFreeAsync(owned, s);
     return rc;
@@ -488,7 +689,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
   auto kfn = lanczos_ritz_wg_kernel<false>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N, K,
-                     D, V, info, (double*)nullptr);
+                     D, V, info, (double*)nullptr, (flags & 2) != 0);
   return lnz::check_launch("lnz_lanczos_ritz");
 }
 

@@ -63,7 +63,7 @@ std::tuple<Tensor, Tensor, Tensor> lanczos_ritz(const Tensor& A, const Tensor& n
   Tensor V = at::empty({B, N, K}, A.options());
   Tensor info = at::empty({B}, n_nodes.options());
   const int64_t need_ws = lnz_lanczos_ritz_workspace_bytes(B, N);
-  if (N > 64) {
+  if (N > 32) {
     Tensor ws = at::empty({need_ws > 0 ? need_ws : 1}, A.options().dtype(at::kByte));
     check(lnz_lanczos_ritz_ws(A.data_ptr<float>(), A.stride(0), A.stride(1), A.stride(2),
                               n_nodes.data_ptr<int32_t>(), B, N, (int)K, D.data_ptr<float>(),

@@ -11,7 +11,7 @@ graph-level label `Y [1, graph_emb_dim]`; the model is `LanczosNetGeneral`.  Sam
 * `collate_graph_adjacency(items, num_eigs, device)` — items carry only the RAW graph (`adjs [n,n,E]`,
   `node_feat [n,D]`, `label [1,P]`); the Laplacians (`lnz_laplacian_l4`, replacing
   get_graph_data.py:61-72) and the Ritz pairs (`lnz_lanczos_ritz`, workgroup-per-graph kernel for
-  N > 64, replacing utils/data_helper.py:197-223 and the pad / cut of graph_data.py:262-287) are
+  N > 32, replacing utils/data_helper.py:197-223 and the pad / cut of graph_data.py:262-287) are
   computed ON THE DEVICE.
 
 `GraphData(config, split)` is the class the runner instantiates with

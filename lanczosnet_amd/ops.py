@@ -98,12 +98,13 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   without copying), N <= 192.  n_nodes: [B] real node counts (rows/cols >= n are ignored).
   Returns D [B,K], V [B,N,K] exactly like the collated `D`, `V` of dataset/qm8.py:264-291 /
   dataset/graph_data.py:262-287.
-  kernel: 'auto' (wavefront per graph up to N = 64, workgroup per graph above), 'workgroup'
+  kernel: 'auto' (wavefront per graph up to N = 32, workgroup per graph above), 'workgroup'
   (workgroup per graph at any N), 'workgroup_ws' (the same with the fp64 basis in a device
-  workspace instead of LDS — what 'auto' does for N > 113)."""
+  workspace instead of LDS — what 'auto' does for N > 111), 'workgroup_ql' (the workgroup kernel
+  with the QL sweep instead of its parallel tridiagonal eigensolver — its fallback, forced)."""
   _need_cuda(A, n_nodes)
   assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
-  assert kernel in ('auto', 'workgroup', 'workgroup_ws')
+  assert kernel in ('auto', 'workgroup', 'workgroup_ws', 'workgroup_ql')
   B, N, _ = A.shape
   n_nodes = n_nodes.to(torch.int32).contiguous()
   if _USE_EXT and kernel == 'auto':
@@ -115,13 +116,13 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   sb, sr, sc = A.stride()
   lib = _lib.load()
   with torch.cuda.device(A.device):
-    if kernel == 'auto' and N <= 64:
+    if kernel == 'auto' and N <= 32:
       _lib.check(lib.lnz_lanczos_ritz(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D),
                                       _ptr(V), _ptr(info), _stream()))
     else:
       # the workspace (if any) comes from torch's caching allocator, not from a hipMallocAsync
-      flags = 1 if kernel == 'workgroup_ws' else 0
-      need = B * N * (N | 1) * 8 if flags else lib.lnz_lanczos_ritz_workspace_bytes(B, N)
+      flags = {'workgroup_ws': 1, 'workgroup_ql': 2}.get(kernel, 0)
+      need = B * N * (N | 1) * 8 if flags & 1 else lib.lnz_lanczos_ritz_workspace_bytes(B, N)
       ws = torch.empty((need,), dtype=torch.uint8, device=A.device) if need else None
       _lib.check(lib.lnz_lanczos_ritz_ws(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D),
                                          _ptr(V), _ptr(info), _ptr(ws), need, flags, _stream()))

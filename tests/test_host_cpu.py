@@ -44,10 +44,14 @@ def test_argument_validation_without_gpu():
   assert b'lnz_lanczos_ritz_large' in lib.lnz_last_error()
   assert lib.lnz_lanczos_ritz_ws(one, 1, 1, 1, one, 4, 193, 20, one, one, null, null, 0, 0, null) == \
       _lib.LNZ_ENOTSUP
-  # the fp64 basis sits in LDS next to A up to N = 113; above, N (N|1) 8 bytes per graph of workspace
-  assert lib.lnz_lanczos_ritz_workspace_bytes(64, 100) == 0
-  assert lib.lnz_lanczos_ritz_workspace_bytes(64, 113) == 0
-  assert lib.lnz_lanczos_ritz_workspace_bytes(64, 114) == 64 * 114 * 115 * 8
+  # the fp64 basis sits in LDS next to A while both fit (every graph of the reference generator,
+  # n <= 100, does); above that boundary N (N|1) 8 bytes per graph of workspace
+  fit = max(N for N in range(33, 193) if lib.lnz_lanczos_ritz_workspace_bytes(64, N) == 0)
+  assert 100 <= fit < 128
+  for N in range(33, fit + 1):
+    assert lib.lnz_lanczos_ritz_workspace_bytes(64, N) == 0
+  for N in (fit + 1, 128, 150):
+    assert lib.lnz_lanczos_ritz_workspace_bytes(64, N) == 64 * N * (N | 1) * 8
   assert lib.lnz_lanczos_ritz_workspace_bytes(3, 192) == 3 * 192 * 193 * 8
   assert lib.lnz_lanczos_ritz_workspace_bytes(3, 193) == 0 and lib.lnz_lanczos_ritz_workspace_bytes(3, 32) == 0
   assert lib.lnz_lanczos_ritz(null, 1, 1, 1, one, 4, 10, 20, one, one, null, null) == _lib.LNZ_EINVAL
