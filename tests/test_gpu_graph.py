@@ -195,3 +195,77 @@ def test_lanczos_ritz_rejects_graphs_beyond_one_workgroup():
   A = torch.zeros((1, 200, 200), device=DEV)
   with pytest.raises(_lib.NotSupported):
     ops.lanczos_ritz(A, torch.tensor([200], dtype=torch.int32, device=DEV), 20)
+
+
+def _structured_graphs():
+  """Graphs whose Laplacians have highly degenerate spectra (every multiple eigenvalue is a Lanczos
+  breakdown + restart, and a stress test for the block splitting of the tridiagonal eigensolver)."""
+  import itertools
+  gs = {}
+  n = 64
+  a = np.zeros((n, n)); i = np.arange(n - 1); a[i, i + 1] = a[i + 1, i] = 1
+  gs['path64'] = a
+  c = a.copy(); c[0, n - 1] = c[n - 1, 0] = 1
+  gs['cycle64'] = c
+  g = np.zeros((81, 81))
+  for x, y in itertools.product(range(9), range(9)):
+    if x + 1 < 9: g[9 * x + y, 9 * (x + 1) + y] = g[9 * (x + 1) + y, 9 * x + y] = 1
+    if y + 1 < 9: g[9 * x + y, 9 * x + y + 1] = g[9 * x + y + 1, 9 * x + y] = 1
+  gs['grid9x9'] = g
+  h = np.zeros((64, 64))
+  for u in range(64):
+    for bit in range(6):
+      h[u, u ^ (1 << bit)] = 1
+  gs['hypercube6'] = h
+  kb = np.zeros((70, 70)); kb[:30, 30:] = 1; kb[30:, :30] = 1
+  gs['K30,40'] = kb
+  bb = np.zeros((90, 90)); bb[:40, :40] = 1; bb[50:, 50:] = 1; np.fill_diagonal(bb, 0)
+  for u in range(39, 50): bb[u, u + 1] = bb[u + 1, u] = 1
+  gs['barbell'] = bb
+  st = np.zeros((100, 100)); st[0, 1:] = st[1:, 0] = 1
+  gs['star100'] = st
+  pet = np.zeros((10, 10))
+  for u in range(5):
+    pet[u, (u + 1) % 5] = pet[(u + 1) % 5, u] = 1
+    pet[5 + u, 5 + (u + 2) % 5] = pet[5 + (u + 2) % 5, 5 + u] = 1
+    pet[u, 5 + u] = pet[5 + u, u] = 1
+  gs['8xpetersen'] = np.kron(np.eye(8), pet)
+  return gs
+
+
+@pytest.mark.parametrize('kernel', ['auto', 'workgroup_ws', 'workgroup_ql'])
+def test_workgroup_ritz_kernel_on_degenerate_spectra(kernel):
+  """Paths, cycles, grids, a hypercube, complete bipartite, barbell, star and disjoint Petersen
+  graphs: multiplicities up to 20.  K = N so that no top-K cut splits a cluster; eigenvalues to
+  1e-6, and the invariant subspaces through V diag(D^p) V^T; V^T V = I to 1e-5."""
+  from lanczosnet_amd import ops
+  gs = _structured_graphs()
+  N = max(a.shape[0] for a in gs.values())
+  B = len(gs)
+  A = np.zeros((B, N, N), np.float32)
+  ns = np.zeros(B, np.int32)
+  for b, (name, adj) in enumerate(gs.items()):
+    n = adj.shape[0]
+    A[b, :n, :n] = oracle.laplacian_l4(adj)
+    ns[b] = n
+  D, V, info = ops.lanczos_ritz(_t(A), _t(ns), N, return_info=True, kernel=kernel)
+  D, V = D.cpu().numpy(), V.cpu().numpy()
+  Dr, Vr, full = _eigh_ref(A, ns, N, N)
+  assert np.isfinite(D).all() and np.isfinite(V).all()
+  for b, name in enumerate(gs):
+    n = ns[b]
+    # as multisets: a bipartite graph's spectrum is symmetric, so +x and -x tie in |lambda| and the
+    # |lambda| ordering between them is decided by the last bit (in the reference's eigh as well)
+    assert np.abs(np.sort(D[b, :n]) - np.sort(Dr[b, :n])).max() < 1e-6, name
+    assert (D[b, n:] == 0).all() and (V[b, n:] == 0).all() and (V[b, :, n:] == 0).all()
+    assert np.abs(np.sort(np.abs(D[b, :n]))[::-1] - np.abs(D[b, :n])).max() < 1e-6, name  # |lambda| descending
+    Vb = V[b, :n, :n].astype(np.float64)
+    assert np.abs(Vb.T @ Vb - np.eye(n)).max() < 1e-5, name
+    for p in (1, 5):
+      a = oracle.spectral_projector(D[b], V[b], p)
+      r = oracle.spectral_projector(Dr[b], Vr[b], p)
+      assert np.abs(a - r).max() / np.abs(r).max() < 1e-5, (name, p)
+  restarts = info.cpu().numpy() % 256
+  assert restarts.sum() > 50   # the degenerate spectra really went through the restart path
+  print('structured graphs (%s): restarts %s, QL fallbacks %d of %d'
+        % (kernel, restarts.tolist(), int((info.cpu().numpy() >= 256).sum()), B))
