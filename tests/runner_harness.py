@@ -138,6 +138,27 @@ def qm8_config(data_dir, save_dir, use_gpu, max_epoch, batch_size=64, loader='QM
                 test_model=os.path.join(save_dir, 'model_snapshot_best.pth'))))
 
 
+def graph_config(data_path, save_dir, use_gpu, max_epoch, loader='GraphData', seed=1234):
+  """config/graph_lanczos_net.yaml with the paths and the epoch count overridden and a validation
+  every epoch (yaml: valid_epoch 100)."""
+  os.makedirs(save_dir, exist_ok=True)
+  return AttrDict(dict(
+      exp_name='graph_lanczos_net', exp_dir=save_dir, save_dir=save_dir, runner='GraphRunner',
+      use_gpu=use_gpu, gpus=[0], seed=seed,
+      dataset=dict(loader_name=loader, name='synthetic', data_path=data_path, node_emb_dim=10,
+                   graph_emb_dim=2, num_edge_type=1),
+      model=dict(name='LanczosNetGeneral', short_diffusion_dist=[],
+                 long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30], num_eig_vec=20,
+                 spectral_filter_kind='MLP', input_dim=10, hidden_dim=[128] * 7, output_dim=2,
+                 num_layer=7, loss='MSE', output_func='MLP'),
+      train=dict(optimizer='Adam', lr_decay=0.1, lr_decay_steps=[10000], num_workers=0,
+                 max_epoch=max_epoch, batch_size=10, display_iter=10, snapshot_epoch=10000,
+                 valid_epoch=1, lr=1.0e-4, wd=0.0, momentum=0.9, shuffle=True, is_resume=False,
+                 resume_model='None'),
+      test=dict(batch_size=64, num_workers=0,
+                test_model=os.path.join(save_dir, 'model_snapshot_best.pth'))))
+
+
 def seed_like_run_exp(seed):
   """run_exp.py:18-20."""
   import torch
