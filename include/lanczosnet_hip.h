@@ -425,6 +425,23 @@ int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, float* DDp,
 int lnz_split_f16x3(const float* X, int M, int K, int ldx, const float* bias, float alpha, int relu,
                     int Kp, void* out, lnz_stream_t stream);
 
+/* The same filter MLPs, hand-written (csrc/f16x3_linear.hip): one launch per Linear,
+ *   out = [relu]( alpha * (X W^T) + bias ),   X [M, K], W [N, K],
+ * both operands as (hi, lo) fp16 PLANES (x = x_hi + x_lo, w = w_hi + w_lo) and the product as
+ * x_hi w_hi + x_hi w_lo + x_lo w_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation — the four
+ * pieces of a k-slice are staged once (global_load_lds, two 64 KB LDS buffers) and feed all three
+ * products.  K %% 64 == 0; x planes hold ceil(M / 128) * 128 rows, w planes ceil(N / 128) * 128 rows
+ * (zero padded), leading dimensions ldx / ldw in elements (multiples of 8).  Output either as the
+ * next Linear's operand, (out_hi, out_lo) fp16 planes with leading dimension ldo (rows >= M are
+ * not written), or — the last Linear — as fp32 out_f32 [M, ldo].  lnz_f16x3_split writes the
+ * planes of an fp32 matrix (scale * X; rows >= M and columns >= K zero). */
+int lnz_f16x3_split(const float* X, int M, int K, int64_t ldx, float scale, int Mp, int Kp,
+                    uint16_t* hi, uint16_t* lo, lnz_stream_t stream);
+int lnz_f16x3_linear(const uint16_t* x_hi, const uint16_t* x_lo, int ldx, const uint16_t* w_hi,
+                     const uint16_t* w_lo, int ldw, const float* bias, float alpha, int relu, int M,
+                     int N, int K, uint16_t* out_hi, uint16_t* out_lo, float* out_f32, int ldo,
+                     lnz_stream_t stream);
+
 
 /* ---- next row (SURVEY.md 8f rank 1 + 3): device-side collate from a packed molecule shard ----
  * Replaces the per-molecule pickles of dataset/get_qm8_data.py:56-96 (dense float64 Laplacians +

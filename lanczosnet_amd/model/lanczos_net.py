@@ -832,8 +832,10 @@ class AdaLanczosNet(_LanczosNetBase):
     filter_kind = 1
     _spectral_hidden = 4096
     # 'fp32': the filter MLPs' GEMMs in fp32 (hipBLASLt);  'f16x3' (opt-in): each operand split
-    # into two fp16 pieces, hi w_hi + hi w_lo + lo w_hi as ONE fp16 GEMM of three times the depth
-    # with fp32 accumulation (needs |activations| < 6.5e4; parity-tested at the same 1e-5 bar)
+    # into two fp16 pieces and hi w_hi + hi w_lo + lo w_hi accumulated in fp32 by the hand-written
+    # lnz_f16x3_linear chain (csrc/f16x3_linear.hip; needs |activations| < 6.5e4; parity-tested at
+    # the same 1e-5 bar);  'f16x3_lib': the r02 form of the same arithmetic — ONE library fp16 GEMM
+    # of three times the depth per Linear, fed by lnz_split_f16x3 (kept for A/B runs)
     filter_gemm_mode = os.environ.get('LANCZOSNET_ADA_FILTER_GEMM', 'fp32')
 
     def _spectral_io(self):
@@ -930,14 +932,20 @@ class AdaLanczosNet(_LanczosNetBase):
                                                   (0, out_pad)).contiguous())
             fp = dict(in_idx=a_cols, in_pad=in_pad, out_idx=out_idx, W1=W1, W4=W4, b4=b4,
                       n_in=n_in, n_out=n_out, mode=self.filter_gemm_mode)
-            if self.filter_gemm_mode == 'f16x3':
+            if self.filter_gemm_mode == 'f16x3_lib':
                 fp['W16'] = [[ops.split_weight_f16x3(W1[t]),
                               ops.split_weight_f16x3(seq[2].weight),
                               ops.split_weight_f16x3(seq[4].weight),
                               ops.split_weight_f16x3(W4[t])]
                              for t, seq in enumerate(self.spectral_filter)]
+            elif self.filter_gemm_mode == 'f16x3':
+                fp['Wp'] = [[ops.f16x3_pack_weight(W1[t]),
+                             ops.f16x3_pack_weight(seq[2].weight),
+                             ops.f16x3_pack_weight(seq[4].weight),
+                             ops.f16x3_pack_weight(W4[t])]
+                            for t, seq in enumerate(self.spectral_filter)]
             elif self.filter_gemm_mode != 'fp32':
-                raise ValueError("filter_gemm_mode must be 'fp32' or 'f16x3'")
+                raise ValueError("filter_gemm_mode must be 'fp32', 'f16x3' or 'f16x3_lib'")
         plan['ada_filters'] = fp
         return fp
 
@@ -958,6 +966,22 @@ class AdaLanczosNet(_LanczosNetBase):
         if fp['in_pad']:
             x = torch.nn.functional.pad(x, (0, fp['in_pad']))
         if fp['mode'] == 'f16x3':
+            # hand-written chain: the input planes once, then per conv layer four launches whose
+            # epilogues hand the next Linear its (hi, lo) operand; two activation buffers ping-pong
+            xp = ops.f16x3_split(x)
+            hid = self._spectral_hidden
+            bufs = [torch.zeros((2, xp.shape[1], hid), dtype=torch.float16, device=x.device)
+                    for _ in range(2)]
+            o = torch.empty((B, fp['W4'][0].shape[0]), dtype=torch.float32, device=x.device)
+            for t, seq in enumerate(self.spectral_filter):
+                w = fp['Wp'][t]
+                h = ops.f16x3_linear(xp, w[0], seq[0].bias, B, hid, out_planes=bufs[0])
+                h = ops.f16x3_linear(h, w[1], seq[2].bias, B, hid, out_planes=bufs[1])
+                h = ops.f16x3_linear(h, w[2], seq[4].bias, B, hid, out_planes=bufs[0])
+                ops.f16x3_linear(h, w[3], fp['b4'][t], B, o.shape[1], relu=False, out_f32=o)
+                torch.index_select(o, 1, fp['out_idx'], out=DDp[t].view(B, S * K * K))
+            return DDp
+        if fp['mode'] == 'f16x3_lib':
             inv = 1.0 / ops.F16X3_WEIGHT_SCALE   # the weights' power-of-two scale
             x3 = ops.split_f16x3(x)
             for t, seq in enumerate(self.spectral_filter):

@@ -933,6 +933,66 @@ def split_weight_f16x3(W, scale=F16X3_WEIGHT_SCALE, Kp=None):
   return out
 
 
+# ------------------------------------------------- R8, hand-written split-precision Linear chain
+def f16x3_pack_weight(W, scale=F16X3_WEIGHT_SCALE):
+  """W [N, K] fp32 -> planes [2, Np, Kp] fp16 (hi, lo) of scale * W, Np = ceil(N / 128) * 128,
+  Kp = ceil(K / 64) * 64, zero padded: the weight operand of lnz_f16x3_linear."""
+  W = W.detach().float() * scale
+  N, K = W.shape
+  Np, Kp = (N + 127) // 128 * 128, (K + 63) // 64 * 64
+  out = torch.zeros((2, Np, Kp), dtype=torch.float16, device=W.device)
+  hi = W.half()
+  out[0, :N, :K] = hi
+  out[1, :N, :K] = (W - hi.float()).half()
+  return out
+
+
+def f16x3_split(X, Kp=None, scale=1.0, out=None):
+  """X [M, K] fp32 -> planes [2, Mp, Kp] fp16 (hi, lo), Mp = ceil(M / 128) * 128 (lnz_f16x3_split)."""
+  _need_cuda(X)
+  assert X.dim() == 2 and X.dtype == torch.float32 and X.stride(1) == 1
+  M, K = X.shape
+  Mp = (M + 127) // 128 * 128
+  Kp = Kp or (K + 63) // 64 * 64
+  if out is None:
+    out = torch.empty((2, Mp, Kp), dtype=torch.float16, device=X.device)
+  lib = _lib.load()
+  with torch.cuda.device(X.device):
+    _lib.check(lib.lnz_f16x3_split(_ptr(X), M, K, X.stride(0), float(scale), Mp, Kp, _ptr(out[0]),
+                                   _ptr(out[1]), _stream()))
+  return out
+
+
+def f16x3_linear(xp, wp, bias, M, N, alpha=1.0 / F16X3_WEIGHT_SCALE, relu=True, out_planes=None,
+                 out_f32=None):
+  """[relu](alpha * X W^T + bias) by lnz_f16x3_linear.  xp [2, Mp, K] / wp [2, Np, K] are (hi, lo)
+  fp16 planes; the result goes to `out_planes` [2, Mp, >= N] (the next Linear's operand; allocated
+  zeroed when None and out_f32 is None) or to the fp32 matrix `out_f32` [M, >= N]."""
+  _need_cuda(xp, wp, bias, out_planes, out_f32)
+  assert xp.dtype == torch.float16 and wp.dtype == torch.float16 and xp.shape[2] == wp.shape[2]
+  K = xp.shape[2]
+  assert xp.shape[1] >= (M + 127) // 128 * 128 and wp.shape[1] >= (N + 127) // 128 * 128
+  if out_f32 is None and out_planes is None:
+    out_planes = torch.zeros((2, xp.shape[1], (N + 63) // 64 * 64), dtype=torch.float16,
+                             device=xp.device)
+  b = None if bias is None else _f32c(bias)
+  lib = _lib.load()
+  with torch.cuda.device(xp.device):
+    if out_f32 is not None:
+      assert out_f32.dtype == torch.float32 and out_f32.stride(1) == 1 and out_f32.shape[1] >= N
+      _lib.check(lib.lnz_f16x3_linear(_ptr(xp[0]), _ptr(xp[1]), xp.stride(1), _ptr(wp[0]), _ptr(wp[1]),
+                                      wp.stride(1), _ptr(b), float(alpha), int(relu), M, N, K,
+                                      C.c_void_p(0), C.c_void_p(0), _ptr(out_f32), out_f32.stride(0),
+                                      _stream()))
+      return out_f32
+    assert out_planes.dtype == torch.float16 and out_planes.shape[2] >= N
+    _lib.check(lib.lnz_f16x3_linear(_ptr(xp[0]), _ptr(xp[1]), xp.stride(1), _ptr(wp[0]), _ptr(wp[1]),
+                                    wp.stride(1), _ptr(b), float(alpha), int(relu), M, N, K,
+                                    _ptr(out_planes[0]), _ptr(out_planes[1]), C.c_void_p(0),
+                                    out_planes.stride(1), _stream()))
+  return out_planes
+
+
 # ----------------------------------------------------------------------------------------- R12
 def unsorted_segment_sum_forward(data, segment_ids, num_segments):
   _need_cuda(data, segment_ids)

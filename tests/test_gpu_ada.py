@@ -202,6 +202,50 @@ def test_ada_folded_filter_mlp_equals_plain_evaluation():
   assert net._ada_filter_plan(plan)['mode'] == 'f16x3'
   assert (got16.double() - ex).abs().max() < 2e-6 * scale
   assert torch.equal(got16, got16.transpose(3, 4))
+  # ... and the r02 form of the same arithmetic (library GEMM of three times the depth)
+  net.filter_gemm_mode = 'f16x3_lib'
+  with torch.no_grad():
+    got16l = net._ada_dense_filters(plan, tcat)
+  assert net._ada_filter_plan(plan)['mode'] == 'f16x3_lib'
+  assert (got16l.double() - ex).abs().max() < 2e-6 * scale
+  assert (got16l - got16).abs().max() < 2e-6 * scale
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (1024, 256, 832), (300, 1056, 4096),
+                                   (77, 200, 192), (1024, 4096, 4096)])
+def test_f16x3_linear_kernel_matches_float64(M, N, K):
+  """lnz_f16x3_linear (hand-written split-precision Linear): fp32 output and (hi, lo)-plane output
+  against a float64 product, ragged M / N (partial 128-row tiles), chained through a second layer."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(M + N + K)
+  X = _t((rs.randn(M, K)).astype(np.float32))
+  W = _t((rs.randn(N, K) * (1.0 / np.sqrt(K))).astype(np.float32))
+  b = _t(rs.randn(N).astype(np.float32))
+  xp = ops.f16x3_split(X)
+  assert xp.shape == (2, (M + 127) // 128 * 128, (K + 63) // 64 * 64)
+  hi = X.half()
+  assert torch.equal(xp[0, :M, :K], hi) and torch.equal(xp[1, :M, :K], (X - hi.float()).half())
+  assert (xp[:, M:] == 0).all() and (xp[:, :, K:] == 0).all()
+  wp = ops.f16x3_pack_weight(W)
+  ref = X.double() @ W.double().t() + b.double()
+  out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+  ops.f16x3_linear(xp, wp, b, M, N, relu=False, out_f32=out)
+  assert (out.double() - ref).abs().max() < 2e-6 * ref.abs().max()
+  # plane output (bias + ReLU fused), then a second Linear on it
+  hp = ops.f16x3_linear(xp, wp, b, M, N, relu=True)
+  h = torch.relu(ref)
+  got = hp[0, :M, :N].double() + hp[1, :M, :N].double()
+  assert (got - h).abs().max() < 2e-6 * h.abs().max()
+  assert (hp[:, M:] == 0).all() and (hp[:, :, N:] == 0).all()
+  W2 = _t((rs.randn(96, N) * (1.0 / np.sqrt(N))).astype(np.float32))
+  out2 = torch.empty((M, 96), dtype=torch.float32, device=DEV)
+  ops.f16x3_linear(hp, ops.f16x3_pack_weight(W2), None, M, 96, relu=False, out_f32=out2)
+  ref2 = h @ W2.double().t()
+  assert (out2.double() - ref2).abs().max() < 4e-6 * ref2.abs().max()
+  # deterministic: a second launch gives the same bits
+  out3 = torch.empty_like(out)
+  ops.f16x3_linear(xp, wp, b, M, N, relu=False, out_f32=out3)
+  assert torch.equal(out, out3)
 
 
 def test_split_f16x3_operand():
@@ -296,7 +340,7 @@ def _e2e_inputs(g):
   return b['node_feat'][:nb], L[:nb], b['node_mask'][:nb], b['label'][:nb]
 
 
-@pytest.mark.parametrize('filter_gemm', ['fp32', 'f16x3'])
+@pytest.mark.parametrize('filter_gemm', ['fp32', 'f16x3', 'f16x3_lib'])
 def test_ada_lanczos_net_end_to_end_parity_protocol(filter_gemm):
   """Full AdaLanczosNet (2 layers, 4096-wide filter MLPs) on 96 molecules against the unmodified
   reference class: scores under the same protocol as the Lanczos layer (both filter GEMM modes)."""
