@@ -440,7 +440,12 @@ int lnz_f16x3_split(const float* X, int M, int K, int64_t ldx, float scale, int 
 int lnz_f16x3_linear(const uint16_t* x_hi, const uint16_t* x_lo, int ldx, const uint16_t* w_hi,
                      const uint16_t* w_lo, int ldw, const float* bias, float alpha, int relu, int M,
                      int N, int K, uint16_t* out_hi, uint16_t* out_lo, float* out_f32, int ldo,
-                     lnz_stream_t stream);
+                     float* partials, lnz_stream_t stream);
+/* Split-K for shapes with too few 128 x 128 output tiles to fill the chip (the last Linear, N =
+ * 1056: 72 tiles): with `partials` = lnz_f16x3_linear_splits(M, N, K) * M * N floats of scratch the K
+ * range is divided over that many workgroups per tile and a second kernel adds the partial tiles in
+ * a fixed order (bit-reproducible) before alpha / bias / ReLU; partials = NULL: no split. */
+int lnz_f16x3_linear_splits(int M, int N, int K);
 
 
 /* ---- next row (SURVEY.md 8f rank 1 + 3): device-side collate from a packed molecule shard ----

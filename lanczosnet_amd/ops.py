@@ -977,19 +977,21 @@ def f16x3_linear(xp, wp, bias, M, N, alpha=1.0 / F16X3_WEIGHT_SCALE, relu=True, 
                              device=xp.device)
   b = None if bias is None else _f32c(bias)
   lib = _lib.load()
+  ns = lib.lnz_f16x3_linear_splits(M, N, K)   # split-K scratch for shapes with few output tiles
+  part = torch.empty((ns, M, N), dtype=torch.float32, device=xp.device) if ns > 1 else None
   with torch.cuda.device(xp.device):
     if out_f32 is not None:
       assert out_f32.dtype == torch.float32 and out_f32.stride(1) == 1 and out_f32.shape[1] >= N
       _lib.check(lib.lnz_f16x3_linear(_ptr(xp[0]), _ptr(xp[1]), xp.stride(1), _ptr(wp[0]), _ptr(wp[1]),
                                       wp.stride(1), _ptr(b), float(alpha), int(relu), M, N, K,
                                       C.c_void_p(0), C.c_void_p(0), _ptr(out_f32), out_f32.stride(0),
-                                      _stream()))
+                                      _ptr(part), _stream()))
       return out_f32
     assert out_planes.dtype == torch.float16 and out_planes.shape[2] >= N
     _lib.check(lib.lnz_f16x3_linear(_ptr(xp[0]), _ptr(xp[1]), xp.stride(1), _ptr(wp[0]), _ptr(wp[1]),
                                     wp.stride(1), _ptr(b), float(alpha), int(relu), M, N, K,
                                     _ptr(out_planes[0]), _ptr(out_planes[1]), C.c_void_p(0),
-                                    out_planes.stride(1), _stream()))
+                                    out_planes.stride(1), _ptr(part), _stream()))
   return out_planes
 
 

@@ -208,7 +208,7 @@ def test_ada_folded_filter_mlp_equals_plain_evaluation():
     got16l = net._ada_dense_filters(plan, tcat)
   assert net._ada_filter_plan(plan)['mode'] == 'f16x3_lib'
   assert (got16l.double() - ex).abs().max() < 2e-6 * scale
-  assert (got16l - got16).abs().max() < 2e-6 * scale
+  assert (got16l - got16).abs().max() < 4e-6 * scale   # two roundings of the same exact product
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (1024, 256, 832), (300, 1056, 4096),
