@@ -421,10 +421,12 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
         t16.append(ev[0].elapsed_time(ev[3]))
         f16.append(ev[1].elapsed_time(ev[2]))
     net.filter_gemm_mode = 'fp32'
-    split = {'mode': "filter_gemm_mode='f16x3': each operand of the filter MLPs' GEMMs as two fp16 "
-                     'pieces, hi w_hi + hi w_lo + lo w_hi as one fp16 GEMM of three times the depth, '
-                     'fp32 accumulate (hipBLASLt); everything else as in the default mode (opt-in, '
-                     'parity-tested at the same 1e-5 bar)',
+    split = {'mode': "filter_gemm_mode='f16x3': each operand of the filter MLPs' Linears as two fp16 "
+                     'pieces, x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 by the hand-written '
+                     'lnz_f16x3_linear chain (csrc/f16x3_linear.hip: v_mfma_f32_32x32x16_f16, the four '
+                     'pieces of a k-slice staged once through LDS, bias + ReLU + split fused into the '
+                     'epilogue, split-K for the last Linear); everything else as in the default mode '
+                     '(opt-in, parity-tested at the same 1e-5 bar)',
              'ms_per_step': round(float(np.mean(t16)), 4),
              'value': round(B / float(np.mean(t16)) * 1e3, 1), 'unit': 'molecules/s',
              'filter_mlp_ms': round(float(np.mean(f16)), 4),
