@@ -29,7 +29,7 @@ int main(void) {
     n_nodes[b] = 4 + b;
     for (int i = 0; i + 1 < n_nodes[b]; ++i) adj[b][i][i + 1][0] = adj[b][i + 1][i][0] = 1.0f;
   }
-  if (lnz_abi_version() != 1) { fprintf(stderr, "unexpected ABI version\n"); return 1; }
+  if (lnz_abi_version() != LNZ_ABI_VERSION) { fprintf(stderr, "unexpected ABI version\n"); return 1; }
 
   float *d_adj, *d_L, *d_D, *d_V;
   int32_t* d_n;

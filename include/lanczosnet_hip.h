@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LNZ_ABI_VERSION 1
+#define LNZ_ABI_VERSION 2
 #define LNZ_OK 0
 #define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
 #define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */
