@@ -312,6 +312,47 @@ def test_ada_dense_filter_conv_matches_oracle_given_TQ():
   np.testing.assert_array_equal(unplanned, score)
 
 
+@pytest.mark.parametrize('n_cu', [1, 3])
+def test_ada_dense_filters_on_pair_tiles(n_cu):
+  """The eigen-space dense-filter kernel on PAIR tiles (8|24 and 16|16 rows, block-diagonal DD
+  fragments): a plan for few CUs makes the planner pair small molecules; every molecule's scores are
+  bit-identical to the one-molecule-per-tile plan and match the fp64 oracle fed the same (T, Q)."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30],
+             hidden_dim=[128, 128], num_layer=2)
+  P = oracle.make_ada_params(cfg, 5)
+  net = _ada_model(cfg, P)
+  b = draw_batch(48, seed=13, n_min=3, n_max=26)
+  B, N = b['node_mask'].shape
+  L = np.zeros((B, N, N, 7), np.float32)
+  for i in range(B):
+    n = int(b['n_nodes'][i])
+    L[i, :n, :n] = oracle.laplacian_multi_l4(b['adjs'][i, :n, :n])
+  q1 = np.random.RandomState(3).randn(B, N).astype(np.float32)
+  K, S = cfg['num_eig_vec'], 5
+  with torch.no_grad():
+    plan = net._plan()
+    Le = ops.ada_graph_laplacian(_t(b['node_feat']), net.embedding.weight, _t(L)[:, :, :, 0])
+    T, Q = ops.ada_lanczos_layer(Le, _t(b['node_mask']), _t(q1)[:, :, None], K)
+    tcat = ops.ada_t_powers(T, cfg['long_diffusion_dist']).view(B, -1)
+    DDp = net._ada_dense_filters(plan, tcat)
+    Lp = ops.pack_laplacian(_t(L))
+    mk = _t(b['node_mask'])
+    tiles = ops.plan_tiles(mk, allow_pairs=True, n_cu=n_cu)
+    buf, cap = tiles
+    ent = buf[:12 * cap].view(cap * 4, 3).cpu().numpy()
+    n_pairs = int(((ent[:, 0] >= 0) & (ent[:, 1] >= 0)).sum())
+    assert n_pairs >= 8, n_pairs
+    paired = ops.lanczosnet_forward(plan, _t(b['node_feat']), Lp, Q, DDp, mk, tiling=tiles).cpu().numpy()
+    single = ops.lanczosnet_forward(plan, _t(b['node_feat']), Lp, Q, DDp, mk, tiling='single').cpu().numpy()
+  np.testing.assert_array_equal(paired, single)
+  ref, _ = oracle.ada_lanczos_net_forward(P, cfg, b['node_feat'], L, b['node_mask'], None,
+                                          dtype=np.float64, TQ=(T.cpu().numpy(), Q.cpu().numpy()))
+  per = np.abs(paired - ref).max(axis=1) / np.abs(ref).max(axis=1)
+  assert per.max() < 1e-5, per.max()
+
+
 class _fixed_randn(object):
   """The reference draws torch.randn(B,N,1) on the CPU generator (:161); hand both the same."""
 
