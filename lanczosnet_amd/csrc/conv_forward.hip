@@ -429,7 +429,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
         if (FK == 1) {
           // row j of the symmetric K x K filter DD_s, columns in cd_row order
           const float* dp =
-              a.G + ((((int64_t)l * B + td[m].ta) * a.n_long + (c - a.n_short)) * K + j) * K;
+              a.G + ((((int64_t)la * B + td[m].ta) * a.n_long + (c - a.n_short)) * K + j) * K;
 #pragma unroll
           for (int t = 0; t < (FK == 1 ? KHT : 1); ++t) {
             int k2 = lnz::cd_row(t, hh);
@@ -444,7 +444,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           const int g0 = td[m].split >> 3;
           const bool rowA = j < td[m].split;
           const int kr = jl[m];  // this lane's slot within its molecule
-          const float* dp = a.G + ((((int64_t)l * B + (molj[m] >= 0 ? molj[m] : 0)) * a.n_long +
+          const float* dp = a.G + ((((int64_t)la * B + (molj[m] >= 0 ? molj[m] : 0)) * a.n_long +
                                     (c - a.n_short)) * K + (kr < K ? kr : 0)) * K;
           const bool live = kr < K && molj[m] >= 0;
 #pragma unroll
@@ -689,6 +689,20 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
               // the matrix pipe (tools/mfma_issue_probe.hip)
               const f32x16& Y = Yblk[(ES && MODE == 2) ? m : 0];
               f32x16 T;
+              if constexpr (DENSE) {
+                // T = DD_s Y: the dense filter's fragments as M operand of one MFMA chain
+                fetch_m_operands(a.n_short + s, m);
+                T = lnz::splat16(0.0f);
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                  if ((smask[m] >> (r >> 2)) & 1) {
+                    T = lnz::mfma32(mop[m][r + 0], Y[r + 0], T);
+                    T = lnz::mfma32(mop[m][r + 1], Y[r + 1], T);
+                    T = lnz::mfma32(mop[m][r + 2], Y[r + 2], T);
+                    T = lnz::mfma32(mop[m][r + 3], Y[r + 3], T);
+                  }
+                }
+              } else {
 #pragma unroll
               for (int t4 = 0; t4 < 4; ++t4) {
                 const float4 g = *reinterpret_cast<const float4*>(g4 + 8 * t4);
@@ -696,6 +710,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
                 T[4 * t4 + 1] = g.y * Y[4 * t4 + 1];
                 T[4 * t4 + 2] = g.z * Y[4 * t4 + 2];
                 T[4 * t4 + 3] = g.w * Y[4 * t4 + 3];
+              }
               }
               f32x16 P = lnz::splat16(0.0f);
 #pragma unroll
@@ -1266,6 +1281,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
               a.filter_kind);
   LNZ_REQUIRE(!a.plan || (a.n_wg && a.plan_wg_cap > 0), LNZ_EINVAL,
               "%s: plan without n_wg / plan_wg_cap", who);
+  const bool dense_es = a.filter_kind == 1 && !dense_filters_in_node_space();
   if (mode == 0) {
     LNZ_REQUIRE(a.dout >= 1 && a.dout <= 31, LNZ_ENOTSUP, "%s: output width %d not in 1..31", who,
                 a.dout);
@@ -1273,12 +1289,14 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: need node_feat+embedding or node_feat_f", who);
     LNZ_REQUIRE(a.Wp && a.bias && a.Wp_head && a.bias_head && a.score, LNZ_EINVAL,
                 "%s: null tensor pointer", who);
-    LNZ_REQUIRE(!a.act_out || (a.gemm_mode == 0 && a.filter_kind == 0), LNZ_ENOTSUP,
-                "%s: act_out needs gemm_mode 0 and filter_kind 0", who);
+    LNZ_REQUIRE(!a.act_out || (a.gemm_mode == 0 && (a.filter_kind == 0 || dense_es)), LNZ_ENOTSUP,
+                "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
+                who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
   } else {
-    LNZ_REQUIRE(a.gemm_mode == 0 && a.filter_kind == 0 && a.dhid == 128, LNZ_ENOTSUP,
-                "%s: built for gemm_mode 0, filter_kind 0, hidden width 128", who);
+    LNZ_REQUIRE(a.gemm_mode == 0 && (a.filter_kind == 0 || dense_es) && a.dhid == 128, LNZ_ENOTSUP,
+                "%s: built for gemm_mode 0, hidden width 128, diagonal gains or dense filters in "
+                "eigen space", who);
     LNZ_REQUIRE(a.act || a.num_layer == 1, LNZ_EINVAL, "%s: act missing", who);
     if (mode == 1) {
       LNZ_REQUIRE(a.Wp && a.dy && a.dx0 && a.din0 == a.dhid && a.bwd_din0 > 0 &&
@@ -1312,9 +1330,14 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
   // modes; the backward modes always take the 4-slot ring.
   const bool all_deep = a.dhid == 128 && a.din0 % 64 == 0;
   if (mode == 1) {
-    LNZ_LAUNCH_D(4, 10, 0, 1, 0);
+    if (a.filter_kind == 0) LNZ_LAUNCH_D(4, 10, 0, 1, 0);
+    else LNZ_LAUNCH_D(4, 10, 2, 1, 0);
   } else if (mode == 2) {
-    LNZ_LAUNCH_D(4, 10, 0, 2, 0);
+    if (a.filter_kind == 0) LNZ_LAUNCH_D(4, 10, 0, 2, 0);
+    else LNZ_LAUNCH_D(4, 10, 2, 2, 0);
+  } else if (a.filter_kind != 0 && a.act_out) {
+    LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
+    LNZ_LAUNCH_D(4, 10, 2, 3, 0);
   } else if (a.filter_kind == 0 && a.act_out) {
     LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
     if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 3, 1);

@@ -596,6 +596,90 @@ def _tn_split_k(a, b, splits=4):
     return out
 
 
+def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act, tiles, n_mol,
+                         static_rows, rtot, rtot_ready):
+    """The part of the HIP backward LanczosNet and AdaLanczosNet share: readout head by torch
+    autograd on the stored last state, node-state gradients of the conv stack
+    (lnz_lanczosnet_input_grad), conv weight / bias gradients (lnz_lanczosnet_messages + one
+    library GEMM per layer).  V, G: the basis and the filters the forward ran with (Ritz vectors +
+    diagonal gains, or Lanczos vectors + dense K x K filters).  Returns (grads by id(parameter),
+    dy [L,B,32,dh] pre-activation gradients, dx0 [B,32,din0p], x0 [B,32,din0p])."""
+    B, N, K = V.shape
+    Lnum, dh = m.num_layer, plan['dhid']
+    din0, din0p = plan['din0_raw'], plan['din0']
+    S, n_short = m.num_scale_long, m.num_scale_short
+    n_chan = n_short + S + m.num_edgetype + 1
+    dev = V.device
+    grads = {}
+    # ---- head (model/lanczos_net.py:185-194) on the stored last state
+    head_params = list(m.filter[-1].parameters()) + list(m.att_func.parameters())
+    with torch.enable_grad():
+        XL = act[Lnum - 1][:, :N].detach().requires_grad_(True)
+        y = m.filter[-1](XL) * m.att_func(XL)
+        mk = (mask_u8 != 0).float().unsqueeze(2)
+        score = (y * mk).sum(dim=1) / mk.sum(dim=1)
+        hg = torch.autograd.grad(score, [XL] + head_params, grad_score.contiguous())
+    for p_, g_ in zip(head_params, hg[1:]):
+        grads[id(p_)] = g_
+    dy = torch.zeros((Lnum, B, 32, dh), dtype=torch.float32, device=dev)
+    dy[Lnum - 1][:, :N] = hg[0] * (XL > 0).float()
+    dx0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
+
+    # ---- node-state gradients of the conv stack
+    ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles)
+
+    # ---- X_0
+    x0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
+    if m.general:
+        x0[:, :N, :din0] = node_feat.float()
+    else:
+        x0[:, :N, :din0] = m.embedding.weight.detach()[node_feat]
+
+    # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l, over
+    #      the REAL node rows only (half of the padded rows are empty): compact row numbering
+    # node extent (last real node + 1) — what the kernels size a molecule by
+    row_end = torch.cumsum(n_mol, 0)
+    row_off = (row_end - n_mol).contiguous()                                 # int64 [B]
+    valid = None
+    if static_rows:
+        # graph capture: no host round trip.  R_tot = B * N rows; rows past the real count are
+        # never written by the message kernel (zero-filled here) and their dY rows are masked.
+        R_tot = B * N
+        r = torch.arange(R_tot, device=dev)
+        valid = (r < row_end[-1]).to(torch.float32).unsqueeze(1)
+        mol_of_r = torch.searchsorted(row_end, r, right=True).clamp_(max=B - 1)
+        real = mol_of_r * 32 + (r - row_off[mol_of_r]).clamp_(min=0, max=31)
+        msg_buf = torch.zeros((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
+        msg_buf0 = msg_buf if din0p == dh else \
+            torch.zeros((R_tot * n_chan * din0p,), dtype=torch.float32, device=dev)
+    else:
+        rtot_ready.synchronize()   # recorded before the forward kernel: long complete
+        R_tot = int(rtot[0])
+        # compact row r -> padded row (molecule * 32 + node), without a data-dependent shape
+        r = torch.arange(R_tot, device=dev)
+        mol_of_r = torch.searchsorted(row_end, r, right=True)
+        real = mol_of_r * 32 + (r - row_off[mol_of_r])
+        msg_buf = msg_buf0 = torch.empty((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
+    for la in range(Lnum):
+        d = din0p if la == 0 else dh
+        msg = (msg_buf0 if la == 0 else msg_buf)[:R_tot * n_chan * d].view(R_tot, n_chan * d)
+        ops.lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, la, msg, tiles,
+                                row_off=row_off)
+        dyl = dy[la].view(B * 32, dh).index_select(0, real)
+        if valid is not None:
+            dyl = dyl * valid
+        dW = _tn_split_k(dyl, msg)
+        if la == 0 and din0p != din0:
+            dW = dW.view(dh, n_chan, din0p)[:, :, :din0].reshape(dh, n_chan * din0)
+        grads[id(m.filter[la].weight)] = m._to_reference_channel_order(dW)
+    # bias gradients: column sums of dY_l — rows of padded nodes are zero in `dy`, so one
+    # reduction over the padded layout serves all layers (7 strided reductions were 0.5 ms)
+    db_all = dy.view(Lnum, B * 32, dh).sum(dim=1)
+    for la in range(Lnum):
+        grads[id(m.filter[la].bias)] = db_all[la]
+    return grads, dy, dx0, x0
+
+
 class _LanczosNetFusedFunction(torch.autograd.Function):
     """Training through the HIP kernels.
 
@@ -655,74 +739,9 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         S, n_short = m.num_scale_long, m.num_scale_short
         n_chan = n_short + S + m.num_edgetype + 1
         dev = V.device
-        grads = {}
-
-        # ---- head (model/lanczos_net.py:185-194) on the stored last state
-        head_params = list(m.filter[-1].parameters()) + list(m.att_func.parameters())
-        with torch.enable_grad():
-            XL = act[Lnum - 1][:, :N].detach().requires_grad_(True)
-            y = m.filter[-1](XL) * m.att_func(XL)
-            mk = (mask_u8 != 0).float().unsqueeze(2)
-            score = (y * mk).sum(dim=1) / mk.sum(dim=1)
-            hg = torch.autograd.grad(score, [XL] + head_params, grad_score.contiguous())
-        for p_, g_ in zip(head_params, hg[1:]):
-            grads[id(p_)] = g_
-        dy = torch.zeros((Lnum, B, 32, dh), dtype=torch.float32, device=dev)
-        dy[Lnum - 1][:, :N] = hg[0] * (XL > 0).float()
-        dx0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
-
-        # ---- node-state gradients of the conv stack
-        ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles)
-
-        # ---- X_0
-        x0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
-        if m.general:
-            x0[:, :N, :din0] = node_feat.float()
-        else:
-            x0[:, :N, :din0] = m.embedding.weight.detach()[node_feat]
-
-        # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l, over
-        #      the REAL node rows only (half of the padded rows are empty): compact row numbering
-        # node extent (last real node + 1) — what the kernels size a molecule by
-        row_end = torch.cumsum(n_mol, 0)
-        row_off = (row_end - n_mol).contiguous()                                 # int64 [B]
-        valid = None
-        if ctx.static_rows:
-            # graph capture: no host round trip.  R_tot = B * N rows; rows past the real count are
-            # never written by the message kernel (zero-filled here) and their dY rows are masked.
-            R_tot = B * N
-            r = torch.arange(R_tot, device=dev)
-            valid = (r < row_end[-1]).to(torch.float32).unsqueeze(1)
-            mol_of_r = torch.searchsorted(row_end, r, right=True).clamp_(max=B - 1)
-            real = mol_of_r * 32 + (r - row_off[mol_of_r]).clamp_(min=0, max=31)
-            msg_buf = torch.zeros((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
-            msg_buf0 = msg_buf if din0p == dh else \
-                torch.zeros((R_tot * n_chan * din0p,), dtype=torch.float32, device=dev)
-        else:
-            ctx.rtot_ready.synchronize()   # recorded before the forward kernel: long complete
-            R_tot = int(ctx.rtot[0])
-            # compact row r -> padded row (molecule * 32 + node), without a data-dependent shape
-            r = torch.arange(R_tot, device=dev)
-            mol_of_r = torch.searchsorted(row_end, r, right=True)
-            real = mol_of_r * 32 + (r - row_off[mol_of_r])
-            msg_buf = msg_buf0 = torch.empty((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
-        for la in range(Lnum):
-            d = din0p if la == 0 else dh
-            msg = (msg_buf0 if la == 0 else msg_buf)[:R_tot * n_chan * d].view(R_tot, n_chan * d)
-            ops.lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, la, msg, tiles,
-                                    row_off=row_off)
-            dyl = dy[la].view(B * 32, dh).index_select(0, real)
-            if valid is not None:
-                dyl = dyl * valid
-            dW = _tn_split_k(dyl, msg)
-            if la == 0 and din0p != din0:
-                dW = dW.view(dh, n_chan, din0p)[:, :, :din0].reshape(dh, n_chan * din0)
-            grads[id(m.filter[la].weight)] = m._to_reference_channel_order(dW)
-        # bias gradients: column sums of dY_l — rows of padded nodes are zero in `dy`, so one
-        # reduction over the padded layout serves all layers (7 strided reductions were 0.5 ms)
-        db_all = dy.view(Lnum, B * 32, dh).sum(dim=1)
-        for la in range(Lnum):
-            grads[id(m.filter[la].bias)] = db_all[la]
+        grads, dy, dx0, x0 = _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp,
+                                                  act, tiles, n_mol, ctx.static_rows, ctx.rtot,
+                                                  ctx.rtot_ready)
 
         # ---- spectral filter MLPs (model/lanczos_net.py:95-123): dG, then autograd through the MLPs.
         #      All layers at once: one batched V^T [dY_0..dY_L-1 | X_0..X_L-1], one batched MLP.
@@ -837,6 +856,8 @@ class AdaLanczosNet(_LanczosNetBase):
     # the same 1e-5 bar);  'f16x3_lib': the r02 form of the same arithmetic — ONE library fp16 GEMM
     # of three times the depth per Linear, fed by lnz_split_f16x3 (kept for A/B runs)
     filter_gemm_mode = os.environ.get('LANCZOSNET_ADA_FILTER_GEMM', 'fp32')
+    # False: evaluate the filter MLPs on the full 2000 inputs / outputs (A/B runs and tests)
+    fold_filter_mlp = True
 
     def _spectral_io(self):
         return self.num_eig_vec * self.num_eig_vec * self.num_scale_long
@@ -868,13 +889,26 @@ class AdaLanczosNet(_LanczosNetBase):
         # same RNG consumption as the reference: CPU generator, shape (B, N, 1) (:161)
         q1 = torch.randn(B, N, 1).to(L.device)
         if self._needs_grad():
-            score = _AdaLanczosNetFunction.apply(self, node_feat, L, mask, q1,
-                                                 *[p for p in self.parameters()])
+            # forward = HIP kernels; backward = HIP conv-stack backward + library GEMMs for the
+            # filter MLPs + autograd through the fp64 Lanczos layer (_AdaLanczosNetFusedFunction)
+            # where built, else autograd through the whole torch restatement
+            fn = _AdaLanczosNetFusedFunction if self._fused_backward_supported() else \
+                _AdaLanczosNetFunction
+            score = fn.apply(self, node_feat, L, mask, q1, *[p for p in self.parameters()])
         else:
             score = self._hip_forward_ada(node_feat, L, mask, q1)
         if label is not None:
             return score, self.loss_func(score, label)
         return score
+
+    def _fused_backward_supported(self):
+        """The HIP conv-stack backward with dense filters is built for hidden width 128, the
+        eigen-space kernel (not LNZ_DENSE_FILTER_NODE_SPACE=1) and the reference's 4-Linear filter
+        MLPs."""
+        return (self._fused_supported() and self.hidden_dim[0] == 128 and self.backward_impl == 'hip'
+                and ops.pairing_supported({'filter_kind': 1}) and
+                all(len(seq) == 7 and all(isinstance(seq[i], nn.Linear) for i in (0, 2, 4, 6))
+                    for seq in self.spectral_filter))
 
     def _ada_filter_plan(self, plan):
         """The filter MLPs (model/ada_lanczos_net.py:271-278) on the NON-REDUNDANT part of their
@@ -887,9 +921,11 @@ class AdaLanczosNet(_LanczosNetBase):
         unfolded evaluation by fp32 rounding of the folded weights (and by the last-bit asymmetry
         of an fp32 T^p).  Returns None (plain evaluation) unless every filter is the reference's
         4-Linear Sequential."""
-        if 'ada_filters' in plan and (plan['ada_filters'] is None or
-                                      plan['ada_filters']['mode'] == self.filter_gemm_mode):
+        if 'ada_filters' in plan and self.fold_filter_mlp and (
+                plan['ada_filters'] is None or plan['ada_filters']['mode'] == self.filter_gemm_mode):
             return plan['ada_filters']
+        if not self.fold_filter_mlp:
+            return None
         K, S = self.num_eig_vec, self.num_scale_long
         ok = all(len(seq) == 7 and all(isinstance(seq[i], nn.Linear) for i in (0, 2, 4, 6)) and
                  seq[0].in_features == K * K * S and seq[6].out_features == K * K * S
@@ -950,9 +986,11 @@ class AdaLanczosNet(_LanczosNetBase):
         return fp
 
     @torch.no_grad()
-    def _ada_dense_filters(self, plan, tcat):
+    def _ada_dense_filters(self, plan, tcat, keep=None):
         """tcat [B, K*K*S] (the T powers, `cat(T_list, dim=2).view(B, -1)`) -> the symmetrised
-        dense filters DDp [num_layer, B, S, K, K] of every conv layer (:271-278)."""
+        dense filters DDp [num_layer, B, S, K, K] of every conv layer (:271-278).  keep: a list
+        that receives the hidden activations (h1, h2, h3) of every layer's MLP where the fp32 chain
+        produces them (training: the backward then needs no second MLP forward)."""
         B = tcat.shape[0]
         K, S = self.num_eig_vec, self.num_scale_long
         DDp = torch.empty((self.num_layer, B, S, K, K), dtype=torch.float32, device=tcat.device)
@@ -994,11 +1032,13 @@ class AdaLanczosNet(_LanczosNetBase):
                 torch.index_select(o, 1, fp['out_idx'], out=DDp[t].view(B, S * K * K))
             return DDp
         for t, seq in enumerate(self.spectral_filter):
-            h = torch.relu_(lin(x, fp['W1'][t], seq[0].bias))
-            h = torch.relu_(lin(h, seq[2].weight, seq[2].bias))
-            h = torch.relu_(lin(h, seq[4].weight, seq[4].bias))
-            o = lin(h, fp['W4'][t], fp['b4'][t])
+            h1 = torch.relu_(lin(x, fp['W1'][t], seq[0].bias))
+            h2 = torch.relu_(lin(h1, seq[2].weight, seq[2].bias))
+            h3 = torch.relu_(lin(h2, seq[4].weight, seq[4].bias))
+            o = lin(h3, fp['W4'][t], fp['b4'][t])
             torch.index_select(o, 1, fp['out_idx'], out=DDp[t].view(B, S * K * K))
+            if keep is not None:
+                keep.append((h1, h2, h3))
         return DDp
 
     @torch.no_grad()
@@ -1018,7 +1058,15 @@ class AdaLanczosNet(_LanczosNetBase):
     def _torch_forward_ada(self, node_feat, L, mask, q1):
         """Differentiable torch restatement (device tensors, batched, no Python loops over the
         batch) of model/ada_lanczos_net.py:101-368 incl. the quirks of `_lanczos_layer` — used ONLY
-        inside backward; forward values always come from the HIP kernels."""
+        inside backward; forward values always come from the HIP kernels.  Three stages:
+        `_torch_ada_spectrum` (learned Laplacian, Lanczos layer, T powers), `_torch_ada_filters`
+        (the filter MLPs) and `_torch_ada_conv` (conv stack + readout)."""
+        state, tcat, Q = self._torch_ada_spectrum(node_feat, L, mask, q1)
+        return self._torch_ada_conv(state, L, Q, self._torch_ada_filters(tcat), mask)
+
+    def _torch_ada_spectrum(self, node_feat, L, mask, q1):
+        """model/ada_lanczos_net.py:101-270 -> (embedded node state [B,N,D], cat of the T powers
+        [B, K*K*S] float32, Lanczos basis Q [B,N,K] float32)."""
         eps = 1.1920928955078125e-07
         B, N = node_feat.shape
         K, S = self.num_eig_vec, self.num_scale_long
@@ -1081,7 +1129,6 @@ class AdaLanczosNet(_LanczosNetBase):
         if Tit < K:
             T = torch.nn.functional.pad(T, (0, K - Tit, 0, K - Tit))
             Q = torch.nn.functional.pad(Q, (0, K - Tit))
-        m = m.float()
         # T powers (:262-270)
         T_list, TT = [], T
         for ii in range(1, self.max_long_diffusion_dist + 1):
@@ -1089,12 +1136,27 @@ class AdaLanczosNet(_LanczosNetBase):
                 T_list.append(TT)
             TT = torch.bmm(TT, T)
         tcat = torch.cat(T_list, dim=2).view(B, -1).float()   # fp64 products like lnz_ada_t_powers
-        Q = Q.float()
-        Lc = Lf.permute(0, 3, 1, 2).contiguous()
-        Qt = Q.transpose(1, 2)
+        return state, tcat, Q.float()
+
+    def _torch_ada_filters(self, tcat):
+        """model/ada_lanczos_net.py:271-278: the symmetrised dense filters [B, K, K, S] of every
+        conv layer."""
+        B, K, S = tcat.shape[0], self.num_eig_vec, self.num_scale_long
+        out = []
         for t in range(self.num_layer):
             DD = self.spectral_filter[t](tcat).view(B, K, K, S)
-            DD = (DD + DD.transpose(1, 2)) * 0.5
+            out.append((DD + DD.transpose(1, 2)) * 0.5)
+        return out
+
+    def _torch_ada_conv(self, state, L, Q, DDs, mask):
+        """model/ada_lanczos_net.py:289-368: conv stack on given filters + readout."""
+        B, N = state.shape[0], state.shape[1]
+        S = self.num_scale_long
+        Lc = L.float().permute(0, 3, 1, 2).contiguous()
+        Qt = Q.transpose(1, 2)
+        m = (mask != 0).float().unsqueeze(2)
+        for t in range(self.num_layer):
+            DD = DDs[t]
             W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)
@@ -1116,6 +1178,148 @@ class AdaLanczosNet(_LanczosNetBase):
             state = torch.relu(out)
         y = self.filter[-1](state) * self.att_func(state)
         return (y * m).sum(dim=1) / m.sum(dim=1)
+
+
+class _AdaLanczosNetFusedFunction(torch.autograd.Function):
+    """AdaLanczosNet training through the HIP kernels.
+
+    forward: the Lanczos layer has to be differentiated and its backward is autograd through the
+    fp64 restatement `_torch_ada_spectrum`, so in training that restatement IS the forward of the
+    learned Laplacian / Lanczos layer / T powers (graph kept for the backward; the HIP kernels of
+    these three stages work from the fp32 Laplacian like the reference's fp32 run, and a basis that
+    differs by the Lanczos recurrence's amplification of that rounding — 2.5e-5 on the test batch —
+    would put the same 1e-5 between the filter gradients and the reference's float64 ones); filter
+    MLPs (hidden activations kept where the fp32 chain produces them) and the fused conv kernel
+    storing every layer's activations run on its (T powers, Q).
+    backward:
+      * readout head, node-state gradients, conv weights / biases: `_fused_conv_backward` — the same
+        launches as LanczosNet, the kernels running their dense-filter eigen-space variant;
+      * filters and basis: with Yq = Q^T X_l, Cq = Q^T dY_l per layer,
+          dDD_{l,s} = Cq (Yq W_{l,s}^T)^T,
+          dQ += dY_l (sum_s DD_s Yq W_s^T)^T + X_l (sum_s DD_s Cq W_s)^T      (DD_s symmetric)
+        as batched library GEMMs on [B, K, .] blocks;
+      * filter MLPs (model/ada_lanczos_net.py:271-278): plain GEMMs on the stored activations (the
+        reference's unfolded weights), symmetrisation 0.5 (DD + DD^T) transposed onto dDD;
+      * learned Laplacian + Lanczos layer + T powers (:101-270): autograd through the graph the
+        forward kept, fed (dX_0, dT-powers, dQ)."""
+
+    @staticmethod
+    def forward(ctx, module, node_feat, L, mask, q1, *params):
+        m = module
+        plan = m._plan()
+        B, N = node_feat.shape[0], node_feat.shape[1]
+        K = m.num_eig_vec
+        Lf = L if L.dtype == torch.float32 else L.float()
+        mask_u8 = mask.to(torch.uint8).contiguous()
+        with torch.enable_grad():
+            spectrum = m._torch_ada_spectrum(node_feat, L, mask, q1)
+        tcat, Q = spectrum[1].detach(), spectrum[2].detach().contiguous()
+        keep = []
+        DDp = m._ada_dense_filters(plan, tcat, keep=keep)
+        Lp = ops.pack_laplacian(Lf)
+        tiles = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
+        act = torch.zeros((m.num_layer, B, 32, plan['dhid']), dtype=torch.float32, device=Q.device)
+        n_mol = ((mask_u8 != 0).long() *
+                 torch.arange(1, N + 1, device=Q.device).view(1, N)).amax(dim=1)
+        rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
+        rtot.copy_(n_mol.sum().view(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask_u8, tiling=tiles,
+                                       act_out=act)
+        ctx.module, ctx.cap, ctx.rtot, ctx.rtot_ready = m, tiles[1], rtot, ev
+        ctx.n_keep, ctx.spectrum = len(keep), spectrum
+        ctx.save_for_backward(node_feat, L, mask, q1, mask_u8, Lp, Q, DDp, act, tiles[0], n_mol, tcat,
+                              *[h for hs in keep for h in hs])
+        return score
+
+    @staticmethod
+    def backward(ctx, grad_score):
+        m = ctx.module
+        node_feat, L, mask, q1, mask_u8, Lp, Q, DDp, act, tile_buf, n_mol, tcat = ctx.saved_tensors[:12]
+        hs = ctx.saved_tensors[12:]
+        tiles = (tile_buf, ctx.cap)
+        plan = m._plan_backward()
+        B, N, K = Q.shape
+        Lnum, dh = m.num_layer, plan['dhid']
+        din0 = plan['din0_raw']
+        S, n_short = m.num_scale_long, m.num_scale_short
+        n_chan = n_short + S + m.num_edgetype + 1
+        # LNZ_ADA_DEBUG=1: stage timestamps (events) and intermediate gradients for tools/experiments
+        dbg = os.environ.get('LNZ_ADA_DEBUG') == '1'
+        marks = []
+
+        def mark(name):
+            if dbg:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+        mark('start')
+        grads, dy, dx0, x0 = _fused_conv_backward(m, plan, grad_score, node_feat, Q, DDp, mask_u8, Lp,
+                                                  act, tiles, n_mol, False, ctx.rtot, ctx.rtot_ready)
+        mark('conv_stack')
+
+        # ---- dense filters and Lanczos basis
+        cdt = torch.float64 if os.environ.get('LNZ_ADA_BWD_FP64') == '1' else torch.float32
+        Qt = Q.transpose(1, 2).to(cdt)
+        DDk = DDp.permute(0, 1, 3, 2, 4).reshape(Lnum, B, K, S * K).to(cdt)     # [l][b][k][(s, j)]
+        dDDp = torch.empty_like(DDp)
+        dQ = torch.zeros_like(Q)
+        for la in range(Lnum):
+            d = din0 if la == 0 else dh
+            X = (x0[:, :N, :din0] if la == 0 else act[la - 1][:, :N]).to(cdt)
+            dYl = dy[la][:, :N].to(cdt)
+            Wl = m._mix_weight(la).detach().view(dh, n_chan, d)[:, n_short:n_short + S, :].to(cdt)  # [o,s,i]
+            Yq = torch.bmm(Qt, X)                                               # [B,K,d]
+            Cq = torch.bmm(Qt, dYl)                                             # [B,K,dh]
+            Bq = (Yq.reshape(B * K, d) @ Wl.permute(2, 1, 0).reshape(d, S * dh)).view(B, K, S, dh)
+            CW = (Cq.reshape(B * K, dh) @ Wl.reshape(dh, S * d)).view(B, K, S, d)
+            # dDD[b,s,k,j] = sum_o Cq[b,k,o] Bq[b,j,s,o]
+            Bs = Bq.permute(0, 2, 1, 3).reshape(B, S * K, dh)                   # rows (s, j)
+            dDDp[la] = torch.bmm(Cq, Bs.transpose(1, 2)).view(B, K, S, K).permute(0, 2, 1, 3)
+            A = torch.bmm(DDk[la], Bs)                                          # [B,K,dh]
+            E = torch.bmm(DDk[la], CW.permute(0, 2, 1, 3).reshape(B, S * K, d)) # [B,K,d]
+            dQ += torch.bmm(dYl, A.transpose(1, 2)) + torch.bmm(X, E.transpose(1, 2))
+
+        mark('filters_basis')
+        # ---- filter MLPs: DD = 0.5 (raw + raw^T) with raw = MLP(tcat).view(B, K, K, S)
+        draw = 0.5 * (dDDp + dDDp.transpose(3, 4))                             # [L,B,S,K,K]
+        draw = draw.permute(0, 1, 3, 4, 2).reshape(Lnum, B, K * K * S)
+        dtcat = torch.zeros_like(tcat)
+        lin = torch.nn.functional.linear
+        for t, seq in enumerate(m.spectral_filter):
+            l1, l2, l3, l4 = seq[0], seq[2], seq[4], seq[6]
+            if ctx.n_keep:
+                h1, h2, h3 = hs[3 * t:3 * t + 3]
+            else:   # (no stored activations: plain evaluation / split-precision forward chains)
+                h1 = torch.relu_(lin(tcat, l1.weight.detach(), l1.bias.detach()))
+                h2 = torch.relu_(lin(h1, l2.weight.detach(), l2.bias.detach()))
+                h3 = torch.relu_(lin(h2, l3.weight.detach(), l3.bias.detach()))
+            g = draw[t]
+            for layer, h_in, h_prev in ((l4, h3, h3), (l3, h2, h2), (l2, h1, h1)):
+                grads[id(layer.weight)] = g.t() @ h_in
+                grads[id(layer.bias)] = g.sum(dim=0)
+                g = (g @ layer.weight.detach()) * (h_prev > 0).to(g.dtype)
+            grads[id(l1.weight)] = g.t() @ tcat
+            grads[id(l1.bias)] = g.sum(dim=0)
+            dtcat += g @ l1.weight.detach()
+
+        mark('filter_mlps')
+        if dbg:
+            m._dbg = dict(dDDp=dDDp, dQ=dQ, dtcat=dtcat, dx0=dx0[:, :N, :din0].clone(), Q=Q, DDp=DDp,
+                          tcat=tcat, act=act, dy=dy)
+        # ---- learned Laplacian, Lanczos layer, T powers: autograd through the forward's graph
+        st, tc, Qr = ctx.spectrum
+        ctx.spectrum = None
+        ge, = torch.autograd.grad([st, tc, Qr], [m.embedding.weight],
+                                  [dx0[:, :N, :din0].contiguous(), dtcat, dQ])
+        grads[id(m.embedding.weight)] = ge
+        mark('spectrum')
+        if dbg:
+            m._dbg['marks'] = marks
+
+        out = [grads.get(id(p_)) if p_.requires_grad else None for p_ in m.parameters()]
+        return (None, None, None, None, None) + tuple(out)
 
 
 class _AdaLanczosNetFunction(torch.autograd.Function):

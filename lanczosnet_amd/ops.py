@@ -754,7 +754,7 @@ def _training_args(plan, Lp, V, G, mask_u8, tiling):
     a.short_dist[i] = int(p)
   a.mask, a.V, a.Lp = mask_u8.data_ptr(), V.data_ptr(), Lp.data_ptr()
   a.G = G.data_ptr() if G is not None else None
-  a.filter_kind, a.gemm_mode = 0, 0
+  a.filter_kind, a.gemm_mode = int(plan.get('filter_kind', 0)), 0
   tiles, cap = tiling
   a.plan, a.n_wg, a.plan_wg_cap = tiles.data_ptr(), tiles.data_ptr() + 48 * cap, cap
   return a

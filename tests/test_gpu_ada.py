@@ -490,3 +490,76 @@ def test_ada_training_gradients_match_reference_autograd():
         '3x its own noise %.2e; reference fp32-vs-float64 up to %.2e' % (w64[0], w64[1], w32[0], noise_p))
   assert w64[0] < 1e-5, w64
   assert w32[0] < 1e-5, w32
+
+
+@pytest.mark.parametrize('chain', ['plain', 'fp32', 'f16x3'])
+def test_ada_hip_backward_equals_the_torch_restatement_elementwise(chain):
+  """`_AdaLanczosNetFusedFunction` (HIP conv-stack backward with dense filters on pair tiles, filter
+  / basis gradients as batched GEMMs, MLP backward by plain GEMMs) against autograd through the
+  whole torch restatement (`backward_impl = 'torch'`) on all 128 molecules of the protocol batch
+  (mixed sizes: pair tiles).  The pin on the REFERENCE's gradients is
+  test_ada_training_gradients_match_reference_autograd.
+
+  'plain' (unfolded fp32 filter MLPs) and 'f16x3' (split-precision forward chain): the backward
+  recomputes the hidden activations exactly like the restatement, both sides hold the same ReLU
+  masks: EVERY gradient element to 2e-5 of the tensor's largest.  'fp32' (folded weights,
+  activations stored by the forward — the default): a hidden unit whose pre-activation is within
+  rounding of zero takes the other side of the ReLU in the folded evaluation (a handful of the
+  11 M units of this batch: counted and printed below); that unit's row of one weight gradient then differs by a
+  molecule's whole contribution (1e-3 of the tensor's norm, 2e-2 of its largest element) and
+  everything upstream of it by a little.  There: the tensors that do not pass through the MLP
+  masks (conv weights, biases, readout) element by element as above, the filter MLPs' and the
+  embedding's gradients to 5e-3 in the Frobenius norm; the element-level pin of this path is the
+  reference-gradient test above (strict set: no unit that close to zero)."""
+  g = load_golden('ada_e2e.npz')
+  cfg = ast.literal_eval(str(g['cfg_json']))
+  P = oracle.make_ada_params(cfg, int(g['param_seed']))
+  nf, L, mask, lab = _e2e_inputs(g)
+  out = {}
+  for impl in ('hip', 'torch'):
+    net = _ada_model(cfg, P).train()
+    net.backward_impl = impl
+    net.filter_gemm_mode = 'fp32' if chain == 'plain' else chain
+    net.fold_filter_mlp = chain != 'plain'
+    assert net._fused_backward_supported() == (impl == 'hip')
+    with _fixed_randn(g['q1']):
+      _, loss = net(_t(nf), _t(L), label=_t(lab), mask=_t(mask))
+    loss.backward()
+    assert all(p.grad is not None for p in net.parameters())
+    out[impl] = {k: p.grad.double().cpu() for k, p in net.named_parameters()}
+  worst, worst_frac, worst_fro = (0.0, None), (0.0, None), (0.0, None)
+  for k, gt in out['torch'].items():
+    d = (out['hip'][k] - gt).abs() / gt.abs().max()
+    e, frac = float(d.max()), float((d > 2e-5).double().mean())
+    fro = float((out['hip'][k] - gt).norm() / gt.norm())
+    worst = (e, k) if e >= worst[0] else worst
+    worst_frac = (frac, k) if frac >= worst_frac[0] else worst_frac
+    worst_fro = (fro, k) if fro >= worst_fro[0] else worst_fro
+  print('Ada HIP backward vs torch restatement (%s): worst element %.2e of max|g| (%s); elements '
+        'beyond 2e-5: %.2e (%s); Frobenius %.2e (%s)' % ((chain,) + worst + worst_frac + worst_fro))
+  if chain != 'fp32':
+    assert worst[0] < 2e-5, worst
+  else:
+    # count the hidden units that sit on different sides of the ReLU in the two evaluations
+    lin = torch.nn.functional.linear
+    with torch.no_grad(), _fixed_randn(g['q1']):
+      q1 = torch.randn(1).to(DEV)
+      _, tcat, _ = net._torch_ada_spectrum(_t(nf), _t(L), _t(mask), q1)
+      fp = net._ada_filter_plan(net._plan())
+      x = torch.nn.functional.pad(tcat.index_select(1, fp['in_idx']), (0, fp['in_pad']))
+      flips = units = 0
+      for t, seq in enumerate(net.spectral_filter):
+        hf, hu = x, tcat
+        for i, w in ((0, fp['W1'][t]), (2, None), (4, None)):
+          hf = torch.relu(lin(hf, w if w is not None else seq[i].weight, seq[i].bias))
+          hu = torch.relu(lin(hu, seq[i].weight, seq[i].bias))
+          flips += int(((hf > 0) != (hu > 0)).sum())
+          units += hf.numel()
+    print('hidden units on the other side of the ReLU in the folded evaluation: %d of %d'
+          % (flips, units))
+    assert flips <= 64
+    for k, gt in out['torch'].items():
+      if not (k.startswith('spectral_filter') or k.startswith('embedding')):
+        e = float((out['hip'][k] - gt).abs().max() / gt.abs().max())
+        assert e < 2e-5, (k, e)
+    assert worst_fro[0] < 5e-3, worst_fro
