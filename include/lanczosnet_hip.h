@@ -447,6 +447,18 @@ int lnz_f16x3_linear(const uint16_t* x_hi, const uint16_t* x_lo, int ldx, const 
  * a fixed order (bit-reproducible) before alpha / bias / ReLU; partials = NULL: no split. */
 int lnz_f16x3_linear_splits(int M, int N, int K);
 
+/* The filter MLPs in the default exact-fp32 mode, hand-written (csrc/f32_linear.hip; replaces
+ * torch.nn.functional.linear + relu of model/ada_lanczos_net.py:271-272 = nn.Sequential of
+ * nn.Linear / nn.ReLU): one launch per Linear,
+ *   out = [relu]( X W^T + bias ),   X [M, K] (leading dimension ldx), W [N, K] (ldw), out [M, ldo],
+ * fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulation, bias + ReLU in the epilogue.
+ * K %% 32 == 0, ldx / ldw multiples of 4 and the base pointers 16-byte aligned (LNZ_ENOTSUP
+ * otherwise); any M, N (partial tiles re-read the last row, never store).  bias may be NULL.
+ * Split-K as for lnz_f16x3_linear: `partials` = lnz_f32_linear_splits(M, N, K) * M * N floats. */
+int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, const float* bias, int relu,
+                   int M, int N, int K, float* out, int ldo, float* partials, lnz_stream_t stream);
+int lnz_f32_linear_splits(int M, int N, int K);
+
 
 /* ---- next row (SURVEY.md 8f rank 1 + 3): device-side collate from a packed molecule shard ----
  * Replaces the per-molecule pickles of dataset/get_qm8_data.py:56-96 (dense float64 Laplacians +

@@ -40,6 +40,12 @@ __device__ inline f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// Wait until ALL of this wave's vector-memory operations have completed — including
+// global_load_lds copies, whose LDS writes the compiler does not connect to later ds_reads of a
+// different type (it then leaves vmcnt out of the s_waitcnt in front of a barrier: a wave could
+// pass the barrier with its copies still in flight).  gfx9 encoding: vmcnt(0) expcnt(7) lgkmcnt(15).
+__device__ inline void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 __device__ inline f32x16 splat16(float v) {
   f32x16 x;
 #pragma unroll

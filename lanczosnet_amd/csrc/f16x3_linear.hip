@@ -134,6 +134,7 @@ __global__ __launch_bounds__(128 * WN) void f16x3_linear_kernel(
   for (int kt = 0; kt < T; ++kt) {
     // slice kt has landed (the barrier's fence waits for this wave's copies) and every wave is done
     // with the other buffer, which slice kt + 1 overwrites while slice kt is multiplied
+    lnz::wait_vmcnt0();   // explicit: see common.hpp
     __syncthreads();
     const unsigned char* cur = smem + (kt & 1) * kStage;
     unsigned char* nxt = smem + ((kt + 1) & 1) * kStage + op * kSlice;

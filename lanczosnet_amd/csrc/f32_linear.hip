@@ -1,0 +1,305 @@
+// R8: the filter MLPs of AdaLanczosNet (model/ada_lanczos_net.py:271-272; per conv layer
+// Linear(K K S -> 4096) -> ReLU -> Linear(4096 -> 4096) -> ReLU -> Linear(4096 -> 4096) -> ReLU ->
+// Linear(4096 -> K K S), M = batch rows) in the default exact-fp32 mode, hand-written.
+//
+// One launch = one Linear:   out = [relu]( X W^T + bias ),  X [M, K], W [N, K] (torch's
+// nn.Linear layout), fp32 operands, v_mfma_f32_32x32x2_f32, fp32 accumulate.
+//
+// The fp32 matrix pipe does 256 flop / clk / CU, so a 128 x 128 x 32 slice of the product is 4096
+// cycles of MFMAs against 32 KB of operands to stage (8 B / clk / CU from L2) and 48-64 KB of
+// fragment reads (LDS: 128 B / clk): unlike the fp16 split-precision kernel (f16x3_linear.hip,
+// LDS bound) this one has only the matrix pipe to keep busy.  Same skeleton as that kernel:
+// 128 x 128 output tiles (M = 1024: 256 tiles, one per CU), K in slices of 32 floats = 128-byte
+// LDS rows filled by global_load_lds (16 B per lane, no staging registers) into one of two 32 KB
+// stages, one __syncthreads per slice, chunk c of row r in slot c ^ ((r >> 1) & 7) (conflict-free
+// ds_read_b128, see f16x3_linear.hip), XCD-aware tile order, bias + ReLU in the epilogue (the
+// library path runs them as a second elementwise launch per Linear), split-K with a fixed-order
+// reduction when the output has too few tiles to fill the chip.
+//
+// Fragments: lane (j, hh) reads the 16-byte chunk 2q + hh of its row = k-values 8q + 4hh + 0..3;
+// MFMA step u of the block multiplies element u of the A and B chunks — the two lane halves then
+// hold k = 8q + u and 8q + 4 + u, the same pairing on both operands.
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace {
+
+#ifndef LNZ_F32LIN_WN
+#define LNZ_F32LIN_WN 4
+#endif
+#ifndef LNZ_F32LIN_MI
+#define LNZ_F32LIN_MI 16
+#endif
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int RB = BK * 4;                  // bytes per LDS row
+constexpr int RPP = 1024 / RB;              // rows per 1 KB copy piece (one global_load_lds)
+constexpr int PPO = 128 / RPP;              // pieces per operand slice
+constexpr int kSlice = 128 * RB;            // one operand slice: 128 rows x BK floats
+constexpr int kStage = 2 * kSlice;          // x, w
+constexpr size_t kLds = 2 * (size_t)kStage; // two stages
+// chunk c of row r sits in slot c ^ swz(r): 128-byte rows share a 256-byte bank row in pairs
+__device__ __forceinline__ int swz(const int r) { return (r >> 1) & 7; }
+
+// global -> LDS copies of one K slice: pieces q0 .. q0 + NQ - 1 (8 rows x 128 B each) of one
+// operand; rows beyond the operand's extent re-read its last row (never stored)
+template <int NQ>
+__device__ __forceinline__ void stage_pieces(const float* __restrict__ src, const int ld,
+                                             const int rows_left, const int k0,
+                                             unsigned char* lds_op, const int lane, const int q0) {
+  constexpr int CPR = BK / 4;                         // 16-B chunks per row
+  const int rsub = lane / CPR, slot = lane % CPR;
+#pragma unroll
+  for (int qq = 0; qq < NQ; ++qq) {
+    const int q = q0 + qq;
+    const int r = RPP * q + rsub;                     // row of the 128-row slice
+    const int chunk = slot ^ swz(r);                  // which 16-B chunk of the row lands in `slot`
+    const int rr = r < rows_left ? r : rows_left - 1;
+    const float* g = src + (int64_t)rr * ld + k0 + 4 * chunk;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)g,
+        (__attribute__((address_space(3))) void*)(lds_op + q * 1024), 16, 0, 0);
+  }
+}
+
+// (a native vector type, not HIP's float4: that struct's union members give its loads the
+// may-alias-anything type tag, and the compiler then drains vmcnt — the global_load_lds copies in
+// flight — in front of every fragment read that follows a copy)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 frag(const unsigned char* lds_op, const int row, const int chunk) {
+  return *reinterpret_cast<const f32x4*>(lds_op + row * RB + ((chunk ^ swz(row)) << 4));
+}
+
+// The two fp32 MFMA shapes behind one interface: MI = 32: v_mfma_f32_32x32x2_f32 (16 accumulator
+// registers per tile, lane = (row j, k half)), MI = 16: v_mfma_f32_16x16x4_f32 (4 accumulator
+// registers per tile, lane = (row j, k quarter)).  Same flop rate; the 16 x 16 shape moves half the
+// accumulator bytes through the register file per flop (k = 4 per accumulator update instead of 2).
+template <int MI>
+struct Mfma;
+template <>
+struct Mfma<32> {
+  typedef f32x16 acc_t;
+  static constexpr int NR = 16;
+  static __device__ __forceinline__ acc_t zero() { return lnz::splat16(0.0f); }
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return lnz::mfma32(a, b, c); }
+  // row of accumulator register r within the tile, for lane group kq = lane / MI
+  static __device__ __forceinline__ int row(int r, int kq) { return lnz::cd_row(r, kq); }
+};
+template <>
+struct Mfma<16> {
+  typedef f32x4 acc_t;
+  static constexpr int NR = 4;
+  static __device__ __forceinline__ acc_t zero() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int r, int kq) { return 4 * kq + r; }
+};
+
+// WN = wavefronts along N: 4 = eight waves of 64 x 32 (two per SIMD), 2 = four waves of 64 x 64
+template <int WN, int MI>
+__global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
+    const float* __restrict__ X, const int ldx, const float* __restrict__ W, const int ldw,
+    const float* __restrict__ bias, const int relu, const int M, const int N, const int K,
+    const int tiles_n, const int bh, float* __restrict__ out, const int ldo,
+    float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int NW = 2 * WN;          // wavefronts
+  typedef Mfma<MI> MM;
+  constexpr int RT = 64 / MI;         // MFMA row tiles per wave (64 rows)
+  constexpr int CT = 128 / WN / MI;   // MFMA column tiles per wave
+  constexpr int KQ = 64 / MI;         // lane groups along k: a fragment group spans 4 KQ k-values
+  constexpr int NG = BK / (4 * KQ);   // fragment groups per slice
+  constexpr int PW = 2 * PPO / NW;    // copy pieces per wave and slice
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WN, wc = wave % WN;
+  // XCD-aware tile order (f16x3_linear.hip): an XCD's workgroups take a bh x bw block of tiles
+  int tm, tn;
+  {
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (bh > 0) {
+      const int bw = (nwg >> 3) / bh, bpr = tiles_n / bw;
+      tm = (xcd / bpr) * bh + slot % bh;
+      tn = (xcd % bpr) * bw + slot / bh;
+    } else {
+      tm = blockIdx.x / tiles_n;
+      tn = blockIdx.x - tm * tiles_n;
+    }
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // this wave's share of the copies: operand `op` (0 = x, 1 = w), pieces [pq0, pq0 + PW)
+  const int op = wave * PW / PPO, pq0 = (wave * PW) % PPO;
+  const float* src = op == 0 ? X + (int64_t)m0 * ldx : W + (int64_t)n0 * ldw;
+  const int ld = op == 0 ? ldx : ldw;
+  const int rows_left = op == 0 ? M - m0 : N - n0;
+
+  typename MM::acc_t acc[RT][CT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b) acc[a][b] = MM::zero();
+
+  // split-K (gridDim.y > 1): this workgroup multiplies slices [kt0, kt0 + T) and writes its raw
+  // partial tile; f32_linear_reduce_kernel adds the partials in a fixed order
+  const int Tall = K / BK, nsplit = gridDim.y;
+  const int kt0 = (int)((int64_t)blockIdx.y * Tall / nsplit);
+  const int T = (int)((int64_t)(blockIdx.y + 1) * Tall / nsplit) - kt0;
+  const int arow = wr * 64 + (lane % MI), brow = wc * (MI * CT) + (lane % MI), g = lane / MI;
+
+  // Software pipeline at slice granularity: ALL fragments of slice kt + 1 are read into registers
+  // (the other half of af / bf) and slice kt + 2 is copied into the stage slice kt was read from,
+  // while the 32 CT MFMAs of slice kt run from registers loaded one slice earlier.  A wave
+  // that leaves the barrier therefore has a whole slice of register-resident work in front of it:
+  // neither the LDS latency nor the copies' landing is ever waited for inside the MFMA stream
+  // (first version: fragments read one 8-k block ahead, barrier -> read -> wait -> MFMA at every
+  // slice: 0.282 ms at 1024 x 4096 x 4096).
+  f32x4 af[2][NG][RT], bf[2][NG][CT];
+  auto load_frags = [&](const unsigned char* stage, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+#pragma unroll
+      for (int u = 0; u < RT; ++u) af[buf][q][u] = frag(stage, arow + MI * u, KQ * q + g);
+#pragma unroll
+      for (int u = 0; u < CT; ++u) bf[buf][q][u] = frag(stage + kSlice, brow + MI * u, KQ * q + g);
+    }
+  };
+  auto clamp_k = [&](const int kt) { return (kt0 + (kt < T ? kt : T - 1)) * BK; };
+  stage_pieces<PW>(src, ld, rows_left, clamp_k(0), smem + op * kSlice, lane, pq0);
+  stage_pieces<PW>(src, ld, rows_left, clamp_k(1), smem + kStage + op * kSlice, lane, pq0);
+  lnz::wait_vmcnt0();
+  __syncthreads();
+  load_frags(smem, std::integral_constant<int, 0>{});
+
+  auto slice = [&](const int kt, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    // slice kt + 1 has landed in stage buf ^ 1 and every wave holds slice kt's fragments in
+    // registers: stage buf is free for slice kt + 2.  The copies' completion is waited for
+    // EXPLICITLY: the compiler does not see that the fragment reads depend on them (without the
+    // explicit wait one of the two unrolled barriers came out with lgkmcnt(0) only — intermittent
+    // wrong tiles at K >= 4064)
+    lnz::wait_vmcnt0();
+    __syncthreads();
+#ifndef LNZ_F32LIN_NOCOPY
+    stage_pieces<PW>(src, ld, rows_left, clamp_k(kt + 2), smem + buf * kStage + op * kSlice, lane, pq0);
+#endif
+    load_frags(smem + (buf ^ 1) * kStage, std::integral_constant<int, buf ^ 1>{});
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+#define LNZ_STEP(E)                                                               \
+  _Pragma("unroll") for (int a = 0; a < RT; ++a)                                  \
+  _Pragma("unroll") for (int b = 0; b < CT; ++b)                                  \
+      acc[a][b] = MM::run(af[buf][q][a].E, bf[buf][q][b].E, acc[a][b]);
+      LNZ_STEP(x)
+      LNZ_STEP(y)
+      LNZ_STEP(z)
+      LNZ_STEP(w)
+#undef LNZ_STEP
+    }
+    // issue order of a slice: one load per gap between MFMAs
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // global_load_lds
+    }
+#pragma unroll
+    for (int i = 0; i < NG * (RT + CT); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MI == 16 ? 2 : 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // fragment read
+    }
+  };
+  for (int kt = 0; kt < T; kt += 2) {
+    slice(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < T) slice(kt + 1, std::integral_constant<int, 1>{});
+  }
+
+  // ---- epilogue: register r of lane (j, kq) holds C[MM::row(r, kq)][j] of its MI x MI tile
+  const int j = lane % MI, kq = lane / MI;
+#pragma unroll
+  for (int b = 0; b < CT; ++b) {
+    const int col = n0 + wc * (MI * CT) + MI * b + j;
+    const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+#pragma unroll
+      for (int r = 0; r < MM::NR; ++r) {
+        const int row = m0 + wr * 64 + MI * a + MM::row(r, kq);
+        if (row >= M || col >= N) continue;
+        if (nsplit > 1) {
+          part[((int64_t)blockIdx.y * M + row) * N + col] = acc[a][b][r];
+        } else {
+          float v = acc[a][b][r] + bv;
+          if (relu) v = fmaxf(v, 0.0f);
+          out[(int64_t)row * ldo + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// out = [relu](sum_s part[s] + bias), partials added in split order (deterministic)
+__global__ __launch_bounds__(256) void f32_linear_reduce_kernel(const float* __restrict__ part,
+                                                                int nsplit, int M, int N,
+                                                                const float* __restrict__ bias,
+                                                                int relu, float* __restrict__ out,
+                                                                int ldo) {
+  const int64_t n = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    float a = part[i];
+    for (int s = 1; s < nsplit; ++s) a += part[(int64_t)s * n + i];
+    float v = a + (bias ? bias[col] : 0.0f);
+    if (relu) v = fmaxf(v, 0.0f);
+    out[(int64_t)row * ldo + col] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int lnz_f32_linear_splits(int M, int N, int K) {
+  // below half a chip's worth of 128 x 128 output tiles the K range is split so that about one
+  // workgroup per CU runs (N = 1056 at M = 1024: 72 tiles -> 3 splits), each with >= 16 slices
+  if (M <= 0 || N <= 0 || K < BK) return 1;
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int ns = 1;
+  if (tiles < 128) ns = 256 / tiles;
+  const int max_by_k = (K / BK) / 16;
+  ns = ns > max_by_k ? max_by_k : ns;
+  ns = ns > 8 ? 8 : ns;
+  return ns < 1 ? 1 : ns;
+}
+
+extern "C" int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, const float* bias,
+                              int relu, int M, int N, int K, float* out, int ldo, float* partials,
+                              lnz_stream_t stream) {
+  LNZ_REQUIRE(x && w && out && M > 0 && N > 0 && K > 0, LNZ_EINVAL,
+              "lnz_f32_linear: bad arguments (M=%d N=%d K=%d)", M, N, K);
+  LNZ_REQUIRE(K % BK == 0 && ldx >= K && ldw >= K && ldx % 4 == 0 && ldw % 4 == 0 && ldo >= N &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0,
+              LNZ_ENOTSUP,
+              "lnz_f32_linear: K=%d must be a multiple of %d and the operand rows 16-byte aligned",
+              K, BK);
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int grid = tiles_m * tiles_n;
+  // block height of an XCD's share of the tiles (0: plain row-major order)
+  int bh = 0;
+  if (grid % 8 == 0) {
+    const int per = grid / 8;
+    for (int h = 1; h <= tiles_m && h * h <= per; ++h)
+      if (tiles_m % h == 0 && per % h == 0 && tiles_n % (per / h) == 0 &&
+          (tiles_m / h) * (tiles_n / (per / h)) == 8)
+        bh = h;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nsplit = partials ? lnz_f32_linear_splits(M, N, K) : 1;
+  auto kfn = f32_linear_kernel<LNZ_F32LIN_WN, LNZ_F32LIN_MI>;
+  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+  hipLaunchKernelGGL(kfn, dim3(grid, nsplit), dim3(128 * LNZ_F32LIN_WN), kLds, s, x, ldx, w, ldw, bias,
+                     relu, M, N, K, tiles_n, bh, out, ldo, partials);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(f32_linear_reduce_kernel, dim3(1024), dim3(256), 0, s, partials, nsplit, M, N,
+                       bias, relu, out, ldo);
+  return lnz::check_launch("lnz_f32_linear");
+}

@@ -850,7 +850,9 @@ class AdaLanczosNet(_LanczosNetBase):
     config (:35-38)."""
     filter_kind = 1
     _spectral_hidden = 4096
-    # 'fp32': the filter MLPs' GEMMs in fp32 (hipBLASLt);  'f16x3' (opt-in): each operand split
+    # 'fp32': the filter MLPs' GEMMs in fp32 (hipBLASLt);  'fp32_hip': the same exact-fp32 arithmetic
+    # on the hand-written lnz_f32_linear (csrc/f32_linear.hip: bias + ReLU fused; 8 % slower than the
+    # library's 4096 x 4096 kernel, DESIGN.md §4.6 — kept selectable);  'f16x3' (opt-in): each operand split
     # into two fp16 pieces and hi w_hi + hi w_lo + lo w_hi accumulated in fp32 by the hand-written
     # lnz_f16x3_linear chain (csrc/f16x3_linear.hip; needs |activations| < 6.5e4; parity-tested at
     # the same 1e-5 bar);  'f16x3_lib': the r02 form of the same arithmetic — ONE library fp16 GEMM
@@ -980,8 +982,8 @@ class AdaLanczosNet(_LanczosNetBase):
                              ops.f16x3_pack_weight(seq[4].weight),
                              ops.f16x3_pack_weight(W4[t])]
                             for t, seq in enumerate(self.spectral_filter)]
-            elif self.filter_gemm_mode != 'fp32':
-                raise ValueError("filter_gemm_mode must be 'fp32', 'f16x3' or 'f16x3_lib'")
+            elif self.filter_gemm_mode not in ('fp32', 'fp32_hip'):
+                raise ValueError("filter_gemm_mode must be 'fp32', 'fp32_hip', 'f16x3' or 'f16x3_lib'")
         plan['ada_filters'] = fp
         return fp
 
@@ -1031,11 +1033,18 @@ class AdaLanczosNet(_LanczosNetBase):
                 o = torch.addcmul(fp['b4'][t], h, h.new_full((), inv))
                 torch.index_select(o, 1, fp['out_idx'], out=DDp[t].view(B, S * K * K))
             return DDp
+        hip = fp['mode'] == 'fp32_hip'   # hand-written exact-fp32 Linear, bias + ReLU in its epilogue
         for t, seq in enumerate(self.spectral_filter):
-            h1 = torch.relu_(lin(x, fp['W1'][t], seq[0].bias))
-            h2 = torch.relu_(lin(h1, seq[2].weight, seq[2].bias))
-            h3 = torch.relu_(lin(h2, seq[4].weight, seq[4].bias))
-            o = lin(h3, fp['W4'][t], fp['b4'][t])
+            if hip:
+                h1 = ops.f32_linear(x, fp['W1'][t], seq[0].bias, relu=True)
+                h2 = ops.f32_linear(h1, seq[2].weight, seq[2].bias, relu=True)
+                h3 = ops.f32_linear(h2, seq[4].weight, seq[4].bias, relu=True)
+                o = ops.f32_linear(h3, fp['W4'][t], fp['b4'][t])
+            else:
+                h1 = torch.relu_(lin(x, fp['W1'][t], seq[0].bias))
+                h2 = torch.relu_(lin(h1, seq[2].weight, seq[2].bias))
+                h3 = torch.relu_(lin(h2, seq[4].weight, seq[4].bias))
+                o = lin(h3, fp['W4'][t], fp['b4'][t])
             torch.index_select(o, 1, fp['out_idx'], out=DDp[t].view(B, S * K * K))
             if keep is not None:
                 keep.append((h1, h2, h3))

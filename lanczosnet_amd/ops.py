@@ -995,6 +995,34 @@ def f16x3_linear(xp, wp, bias, M, N, alpha=1.0 / F16X3_WEIGHT_SCALE, relu=True, 
   return out_planes
 
 
+def f32_linear_supported(x, w):
+  """Shapes lnz_f32_linear takes: fp32 row-major operands, K a multiple of 32, 16-byte rows."""
+  return (x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and w.dim() == 2 and
+          x.shape[1] == w.shape[1] and x.shape[1] % 32 == 0 and x.stride(1) == 1 and w.stride(1) == 1
+          and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and
+          w.data_ptr() % 16 == 0)
+
+
+def f32_linear(x, w, bias=None, relu=False, out=None):
+  """[relu](x w^T + bias) by lnz_f32_linear (hand-written exact-fp32 MFMA kernel): x [M, K],
+  w [N, K] (nn.Linear layout), result [M, N] fp32."""
+  _need_cuda(x, w, bias, out)
+  assert f32_linear_supported(x, w), (x.shape, w.shape, x.stride(), w.stride())
+  M, K = x.shape
+  N = w.shape[0]
+  if out is None:
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+  assert out.dtype == torch.float32 and out.stride(1) == 1 and tuple(out.shape) == (M, N)
+  b = None if bias is None else _f32c(bias)
+  lib = _lib.load()
+  ns = lib.lnz_f32_linear_splits(M, N, K)
+  part = torch.empty((ns, M, N), dtype=torch.float32, device=x.device) if ns > 1 else None
+  with torch.cuda.device(x.device):
+    _lib.check(lib.lnz_f32_linear(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(b), int(relu), M, N,
+                                  K, _ptr(out), out.stride(0), _ptr(part), _stream()))
+  return out
+
+
 # ----------------------------------------------------------------------------------------- R12
 def unsorted_segment_sum_forward(data, segment_ids, num_segments):
   _need_cuda(data, segment_ids)

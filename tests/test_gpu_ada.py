@@ -209,6 +209,63 @@ def test_ada_folded_filter_mlp_equals_plain_evaluation():
   assert net._ada_filter_plan(plan)['mode'] == 'f16x3_lib'
   assert (got16l.double() - ex).abs().max() < 2e-6 * scale
   assert (got16l - got16).abs().max() < 4e-6 * scale   # two roundings of the same exact product
+  # the hand-written exact-fp32 Linear (lnz_f32_linear, bias + ReLU fused): same bar
+  net.filter_gemm_mode = 'fp32_hip'
+  with torch.no_grad():
+    got32 = net._ada_dense_filters(plan, tcat)
+  assert net._ada_filter_plan(plan)['mode'] == 'fp32_hip'
+  assert (got32.double() - ex).abs().max() < 2e-6 * scale
+  assert torch.equal(got32, got32.transpose(3, 4))
+
+
+@pytest.mark.parametrize('M,N,K,relu', [(128, 128, 64, True), (1024, 256, 832, True),
+                                        (300, 1056, 4096, False), (77, 200, 192, True),
+                                        (1024, 4096, 4096, True), (1, 5, 32, False)])
+def test_f32_linear_kernel_matches_float64(M, N, K, relu):
+  """lnz_f32_linear = [relu](x w^T + bias) in exact fp32 (v_mfma_f32_16x16x4_f32): against float64
+  at the rounding level of an fp32 dot product of length K, no worse than the library GEMM on the
+  same operands; partial tiles in M and N, split-K shapes (N = 1056), bit-reproducible — five
+  repeats: the copies' completion in front of the barrier is an explicit wait (csrc/common.hpp
+  wait_vmcnt0), without it a K >= 4064 product came out with intermittent wrong tiles."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(M + N + K)
+  x = _t(rs.randn(M, K).astype(np.float32))
+  w = _t((rs.randn(N, K) / np.sqrt(K)).astype(np.float32))
+  b = _t(rs.randn(N).astype(np.float32))
+  ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+  lib = torch.nn.functional.linear(x, w, b)
+  if relu:
+    ref, lib = torch.relu(ref), torch.relu(lib)
+  scale = float(ref.abs().max())
+  first = None
+  for rep in range(5):
+    out = ops.f32_linear(x, w, b, relu=relu)
+    if first is None:
+      first = out
+    assert torch.equal(out, first)
+  e = float((first.double() - ref).abs().max()) / scale
+  e_lib = float((lib.double() - ref).abs().max()) / scale
+  assert e < max(2.0 * e_lib, 1e-6), (e, e_lib)
+  # non-contiguous operand views (row stride > K) and no bias
+  xp = torch.zeros((M, K + 32), device=DEV)
+  xp[:, :K] = x
+  out2 = ops.f32_linear(xp[:, :K], w, None, relu=relu)
+  ref2 = torch.nn.functional.linear(x.double(), w.double())
+  if relu:
+    ref2 = torch.relu(ref2)
+  assert float((out2.double() - ref2).abs().max()) / scale < max(2.0 * e_lib, 1e-6)
+
+
+def test_f32_linear_refuses_unsupported_shapes():
+  from lanczosnet_amd import ops, _lib
+  x = torch.zeros((4, 40), device=DEV)
+  w = torch.zeros((4, 40), device=DEV)
+  assert not ops.f32_linear_supported(x, w)          # K not a multiple of 32
+  lib = _lib.load()
+  out = torch.zeros((4, 4), device=DEV)
+  rc = lib.lnz_f32_linear(x.data_ptr(), 40, w.data_ptr(), 40, None, 0, 4, 4, 40, out.data_ptr(), 4, None,
+                          None)
+  assert rc == _lib.LNZ_ENOTSUP
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (1024, 256, 832), (300, 1056, 4096),
@@ -381,7 +438,7 @@ def _e2e_inputs(g):
   return b['node_feat'][:nb], L[:nb], b['node_mask'][:nb], b['label'][:nb]
 
 
-@pytest.mark.parametrize('filter_gemm', ['fp32', 'f16x3', 'f16x3_lib'])
+@pytest.mark.parametrize('filter_gemm', ['fp32', 'fp32_hip', 'f16x3', 'f16x3_lib'])
 def test_ada_lanczos_net_end_to_end_parity_protocol(filter_gemm):
   """Full AdaLanczosNet (2 layers, 4096-wide filter MLPs) on 96 molecules against the unmodified
   reference class: scores under the same protocol as the Lanczos layer (both filter GEMM modes)."""
