@@ -45,6 +45,12 @@ __device__ inline f32x16 mfma32(float a, float b, f32x16 c) {
 // different type (it then leaves vmcnt out of the s_waitcnt in front of a barrier: a wave could
 // pass the barrier with its copies still in flight).  gfx9 encoding: vmcnt(0) expcnt(7) lgkmcnt(15).
 __device__ inline void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// ... until at most N of them are still in flight (they complete in order): vmcnt(N)
+template <int N>
+__device__ inline void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
 
 __device__ inline f32x16 splat16(float v) {
   f32x16 x;

@@ -79,7 +79,7 @@ struct Mfma;
 template <>
 struct Mfma<32> {
   typedef f32x16 acc_t;
-  static constexpr int NR = 16;
+  [[maybe_unused]] static constexpr int NR = 16;
   static __device__ __forceinline__ acc_t zero() { return lnz::splat16(0.0f); }
   static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return lnz::mfma32(a, b, c); }
   // row of accumulator register r within the tile, for lane group kq = lane / MI
@@ -88,7 +88,7 @@ struct Mfma<32> {
 template <>
 struct Mfma<16> {
   typedef f32x4 acc_t;
-  static constexpr int NR = 4;
+  [[maybe_unused]] static constexpr int NR = 4;
   static __device__ __forceinline__ acc_t zero() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
   static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
