@@ -27,6 +27,8 @@
 // lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), each of which must hit 16 distinct 16-B slots
 // of the 256-B bank row = (row parity, slot): with (r >> 1) in the swizzle every group does (with
 // r & 7, rows 0 and 24 of a group collide: measured 2-way, 8.4 M conflict cycles per launch).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -35,6 +37,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef LNZ_F16X3_WN
 #define LNZ_F16X3_WN 4
+#endif
+// slices per workgroup from which the slice-pipelined kernel is used (0: never)
+#ifndef LNZ_F16X3_PIPE_MIN_SLICES
+#define LNZ_F16X3_PIPE_MIN_SLICES 16
 #endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kSlice = 128 * BK * 2;        // one operand slice: 128 rows x 64 fp16 = 16 KB
@@ -73,7 +79,9 @@ __device__ __forceinline__ f16x8 frag(const unsigned char* lds_op, const int row
 // WN = wavefronts along N (2: four waves of 64 x 64; 4: EIGHT waves of 64 x 32 — two per SIMD, so
 // one wave's barrier wait / fragment reads / copy issue overlap the other's MFMAs; with one wave
 // per SIMD the matrix pipe measured 40 % busy: 1400 of a slice's 3300 cycles)
-template <int SPLIT_OUT, int WN>
+// PIPE = 1 (with WN = 2: four waves of 64 x 64, one per SIMD, up to 512 registers each): the
+// slice-pipelined main loop — see the comment there.  Used for workgroups with >= 16 slices.
+template <int SPLIT_OUT, int WN, int PIPE>
 __global__ __launch_bounds__(128 * WN) void f16x3_linear_kernel(
     const uint16_t* __restrict__ Xh, const uint16_t* __restrict__ Xl, const int ldx,
     const uint16_t* __restrict__ Wh, const uint16_t* __restrict__ Wl, const int ldw,
@@ -129,8 +137,75 @@ __global__ __launch_bounds__(128 * WN) void f16x3_linear_kernel(
   const int Tall = K / BK, nsplit = gridDim.y;
   const int kt0 = (int)((int64_t)blockIdx.y * Tall / nsplit);
   const int T = (int)((int64_t)(blockIdx.y + 1) * Tall / nsplit) - kt0;
-  stage_pieces<PW>(src, ld, kt0 * BK, smem + op * kSlice, lane, pq0);
+  if constexpr (!PIPE) stage_pieces<PW>(src, ld, kt0 * BK, smem + op * kSlice, lane, pq0);
   const int arow = wr * 64 + (lane & 31), brow = wc * (32 * CT) + (lane & 31), g = lane >> 5;
+  if constexpr (PIPE) {
+    // ---- software pipeline at slice granularity (four waves of 64 x 64, one per SIMD) -----------
+    // ALL 32 fragments of slice kt + 1 are read into a second register set and slice kt + 2 is
+    // copied while the 48 MFMAs of slice kt run from registers loaded a slice earlier: 64 x 64 wave
+    // tiles read 128 KB of fragments per slice instead of 192 KB, and no MFMA waits for a fragment
+    // read issued in its own k-step.
+    constexpr int NS = BK / 16;   // k-steps per slice
+    f16x8 fa[2][NS][2][2], fb[2][NS][CT][2];   // [register set][k-step][tile][hi, lo]
+    auto load_slice = [&](const unsigned char* st, auto setc) {
+      constexpr int set = decltype(setc)::value;
+#pragma unroll
+      for (int sk = 0; sk < NS; ++sk) {
+        const int chunk = 2 * sk + g;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          fa[set][sk][u][0] = frag(st, arow + 32 * u, chunk);
+          fa[set][sk][u][1] = frag(st + kSlice, arow + 32 * u, chunk);
+        }
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+          fb[set][sk][u][0] = frag(st + 2 * kSlice, brow + 32 * u, chunk);
+          fb[set][sk][u][1] = frag(st + 3 * kSlice, brow + 32 * u, chunk);
+        }
+      }
+    };
+    auto clamp_k = [&](const int kt) { return (kt0 + (kt < T ? kt : T - 1)) * BK; };
+    stage_pieces<PW>(src, ld, clamp_k(0), smem + op * kSlice, lane, pq0);
+    stage_pieces<PW>(src, ld, clamp_k(1), smem + kStage + op * kSlice, lane, pq0);
+    lnz::wait_vmcnt0();
+    __syncthreads();
+    load_slice(smem, std::integral_constant<int, 0>{});
+    auto slice = [&](const int kt, auto setc) {
+      constexpr int set = decltype(setc)::value;
+      // slice kt + 1 has landed in stage set ^ 1, every wave holds slice kt in registers: stage
+      // `set` is free for slice kt + 2 (past the end: the last slice again, into the idle stage)
+      lnz::wait_vmcnt0();
+      __syncthreads();
+      stage_pieces<PW>(src, ld, clamp_k(kt + 2), smem + set * kStage + op * kSlice, lane, pq0);
+      load_slice(smem + (set ^ 1) * kStage, std::integral_constant<int, set ^ 1>{});
+#pragma unroll
+      for (int sk = 0; sk < NS; ++sk)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < CT; ++b)
+              acc[a][b] = mfma16(fa[set][sk][a][term == 0 ? 1 : 0], fb[set][sk][b][term == 1 ? 1 : 0],
+                                 acc[a][b]);
+      // issue order of a slice: one load per MFMA
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // global_load_lds
+      }
+#pragma unroll
+      for (int i = 0; i < NS * (4 + 2 * CT); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // fragment read
+      }
+    };
+    for (int kt = 0; kt < T; kt += 2) {
+      slice(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 < T) slice(kt + 1, std::integral_constant<int, 1>{});
+    }
+    lnz::wait_vmcnt0();   // (the copies past the end are still landing in the idle stage)
+  } else
   for (int kt = 0; kt < T; ++kt) {
     // slice kt has landed (the barrier's fence waits for this wave's copies) and every wave is done
     // with the other buffer, which slice kt + 1 overwrites while slice kt is multiplied
@@ -314,24 +389,28 @@ extern "C" int lnz_f16x3_linear(const uint16_t* x_hi, const uint16_t* x_lo, int 
   // rows allocated (the pack / the previous layer's output planes provide them)
   const int nsplit = partials ? lnz_f16x3_linear_splits(M, N, K) : 1;
   const dim3 g2(grid, nsplit);
+  const bool pipe = LNZ_F16X3_PIPE_MIN_SLICES > 0 && (K / BK) / nsplit >= LNZ_F16X3_PIPE_MIN_SLICES;
+#define LNZ_F16X3_LAUNCH(SO_, WN_, PIPE_, OH_, OL_, OF_)                                             \
+  do {                                                                                               \
+    auto kfn = f16x3_linear_kernel<SO_, WN_, PIPE_>;                                                 \
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                              (int)kLds);                                                            \
+    hipLaunchKernelGGL(kfn, g2, dim3(128 * WN_), kLds, s, x_hi, x_lo, ldx, w_hi, w_lo, ldw, bias,    \
+                       alpha, relu, M, N, K, tiles_n, bh, OH_, OL_, OF_, ldo, partials);             \
+  } while (0)
   if (out_f32) {
-    auto kfn = f16x3_linear_kernel<0, LNZ_F16X3_WN>;
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-    hipLaunchKernelGGL(kfn, g2, dim3(128 * LNZ_F16X3_WN), kLds, s, x_hi, x_lo, ldx, w_hi, w_lo, ldw,
-                       bias, alpha, relu, M, N, K, tiles_n, bh, (uint16_t*)nullptr, (uint16_t*)nullptr,
-                       out_f32, ldo, partials);
+    if (pipe) LNZ_F16X3_LAUNCH(0, 2, 1, (uint16_t*)nullptr, (uint16_t*)nullptr, out_f32);
+    else LNZ_F16X3_LAUNCH(0, LNZ_F16X3_WN, 0, (uint16_t*)nullptr, (uint16_t*)nullptr, out_f32);
     if (nsplit > 1)
       hipLaunchKernelGGL(f16x3_reduce_kernel<0>, dim3(1024), dim3(256), 0, s, partials, nsplit, M, N,
                          bias, alpha, relu, (uint16_t*)nullptr, (uint16_t*)nullptr, out_f32, ldo);
   } else {
-    auto kfn = f16x3_linear_kernel<1, LNZ_F16X3_WN>;
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
-    hipLaunchKernelGGL(kfn, g2, dim3(128 * LNZ_F16X3_WN), kLds, s, x_hi, x_lo, ldx, w_hi, w_lo, ldw,
-                       bias, alpha, relu, M, N, K, tiles_n, bh, out_hi, out_lo, (float*)nullptr, ldo,
-                       partials);
+    if (pipe) LNZ_F16X3_LAUNCH(1, 2, 1, out_hi, out_lo, (float*)nullptr);
+    else LNZ_F16X3_LAUNCH(1, LNZ_F16X3_WN, 0, out_hi, out_lo, (float*)nullptr);
     if (nsplit > 1)
       hipLaunchKernelGGL(f16x3_reduce_kernel<1>, dim3(1024), dim3(256), 0, s, partials, nsplit, M, N,
                          bias, alpha, relu, out_hi, out_lo, (float*)nullptr, ldo);
   }
+#undef LNZ_F16X3_LAUNCH
   return lnz::check_launch("lnz_f16x3_linear");
 }
