@@ -888,8 +888,7 @@ class AdaLanczosNet(_LanczosNetBase):
         if not self._fused_supported() or L.shape[1] > 32:
             raise NotImplementedError('AdaLanczosNet HIP path needs hidden width 64/128 and N <= 32')
         B, N = node_feat.shape[0], node_feat.shape[1]
-        # same RNG consumption as the reference: CPU generator, shape (B, N, 1) (:161)
-        q1 = torch.randn(B, N, 1).to(L.device)
+        q1 = self._draw_q1(B, N, L.device)
         if self._needs_grad():
             # forward = HIP kernels; backward = HIP conv-stack backward + library GEMMs for the
             # filter MLPs + autograd through the fp64 Lanczos layer (_AdaLanczosNetFusedFunction)
@@ -902,6 +901,19 @@ class AdaLanczosNet(_LanczosNetBase):
         if label is not None:
             return score, self.loss_func(score, label)
         return score
+
+    # set by lanczosnet_amd.train.GraphedTrainStep: a device buffer [B, N, 1] that the step object
+    # refills from the CPU generator before every replay (nothing may touch the host inside a HIP
+    # graph); None: draw here
+    _static_q1 = None
+
+    def _draw_q1(self, B, N, device):
+        """The Lanczos start vector: same RNG consumption as the reference — CPU generator, shape
+        (B, N, 1) (model/ada_lanczos_net.py:161)."""
+        q = self._static_q1
+        if q is not None and tuple(q.shape) == (B, N, 1) and q.device == device:
+            return q
+        return torch.randn(B, N, 1).to(device)
 
     def _fused_backward_supported(self):
         """The HIP conv-stack backward with dense filters is built for hidden width 128, the
@@ -935,38 +947,48 @@ class AdaLanczosNet(_LanczosNetBase):
         fp = None
         if ok:
             dev = self.spectral_filter[0][0].weight.device
-            iu, ju = torch.triu_indices(K, K, device=dev)
-            P = iu.numel()
-            a_cols, b_cols, offd = [], [], []
-            for sc, dist in enumerate(self.long_diffusion_dist):
-                keep = (ju - iu) <= int(dist)
-                i, j = iu[keep], ju[keep]
-                a_cols.append(i * (K * S) + sc * K + j)   # T_s[i][j] in cat(T_list, dim=2).view(B, -1)
-                b_cols.append(j * (K * S) + sc * K + i)
-                offd.append(i != j)
-            a_cols, b_cols, offd = torch.cat(a_cols), torch.cat(b_cols), torch.cat(offd)
+            # the index sets depend on (K, scales) only: built once per device and kept on the module
+            # (boolean-mask indexing is a host round trip — not allowed while a HIP graph of the
+            # training step is being captured, and the plan is rebuilt inside that graph)
+            st = getattr(self, '_ada_fold_idx', None)
+            if st is None or st['dev'] != dev:
+                iu, ju = torch.triu_indices(K, K, device=dev)
+                P = iu.numel()
+                a_cols, b_cols, offd = [], [], []
+                for sc, dist in enumerate(self.long_diffusion_dist):
+                    keep = (ju - iu) <= int(dist)
+                    i, j = iu[keep], ju[keep]
+                    a_cols.append(i * (K * S) + sc * K + j)   # T_s[i][j] in cat(T_list, dim=2).view(B, -1)
+                    b_cols.append(j * (K * S) + sc * K + i)
+                    offd.append(i != j)
+                a_cols, b_cols, offd = torch.cat(a_cols), torch.cat(b_cols), torch.cat(offd)
+                # output row (s, p) of the folded last Linear; DD.view(B, K, K, S): row (i, j, s)
+                sidx = torch.arange(S, device=dev).view(S, 1)
+                r_ij = ((iu * K + ju) * S).view(1, P) + sidx     # [S, P]
+                r_ji = ((ju * K + iu) * S).view(1, P) + sidx
+                pair = torch.zeros((K, K), dtype=torch.long, device=dev)
+                pair[iu, ju] = torch.arange(P, device=dev)
+                pair[ju, iu] = torch.arange(P, device=dev)
+                out_idx = (sidx.view(S, 1, 1) * P + pair.view(1, K, K)).reshape(-1)   # (s, i, j) -> row
+                st = self._ada_fold_idx = dict(dev=dev, a_cols=a_cols, b_cols=b_cols,
+                                               offd=offd.to(torch.float32), r_ij=r_ij.reshape(-1),
+                                               r_ji=r_ji.reshape(-1), out_idx=out_idx, P=int(P))
+            a_cols, b_cols, offd, out_idx, P = st['a_cols'], st['b_cols'], st['offd'], st['out_idx'], st['P']
+            r_ij, r_ji = st['r_ij'], st['r_ji']
             n_in = a_cols.numel()
             in_pad = (-n_in) % 32
-            # output row (s, p) of the folded last Linear; DD.view(B, K, K, S): row (i, j, s)
-            sidx = torch.arange(S, device=dev).view(S, 1)
-            r_ij = ((iu * K + ju) * S).view(1, P) + sidx     # [S, P]
-            r_ji = ((ju * K + iu) * S).view(1, P) + sidx
             n_out = S * P
             out_pad = (-n_out) % 32
-            pair = torch.zeros((K, K), dtype=torch.long, device=dev)
-            pair[iu, ju] = torch.arange(P, device=dev)
-            pair[ju, iu] = torch.arange(P, device=dev)
-            out_idx = (sidx.view(S, 1, 1) * P + pair.view(1, K, K)).reshape(-1)   # (s, i, j) -> row
             W1, W4, b4 = [], [], []
             for seq in self.spectral_filter:
                 w = seq[0].weight.detach().float()
-                w1 = w[:, a_cols] + w[:, b_cols] * offd.to(w.dtype)
+                w1 = w[:, a_cols] + w[:, b_cols] * offd
                 W1.append(torch.nn.functional.pad(w1, (0, in_pad)).contiguous())
                 w = seq[6].weight.detach().float()
-                w4 = 0.5 * (w[r_ij.reshape(-1)] + w[r_ji.reshape(-1)])
+                w4 = 0.5 * (w[r_ij] + w[r_ji])
                 W4.append(torch.nn.functional.pad(w4, (0, 0, 0, out_pad)).contiguous())
                 bb = seq[6].bias.detach().float()
-                b4.append(torch.nn.functional.pad(0.5 * (bb[r_ij.reshape(-1)] + bb[r_ji.reshape(-1)]),
+                b4.append(torch.nn.functional.pad(0.5 * (bb[r_ij] + bb[r_ji]),
                                                   (0, out_pad)).contiguous())
             fp = dict(in_idx=a_cols, in_pad=in_pad, out_idx=out_idx, W1=W1, W4=W4, b4=b4,
                       n_in=n_in, n_out=n_out, mode=self.filter_gemm_mode)
@@ -1230,10 +1252,15 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         act = torch.zeros((m.num_layer, B, 32, plan['dhid']), dtype=torch.float32, device=Q.device)
         n_mol = ((mask_u8 != 0).long() *
                  torch.arange(1, N + 1, device=Q.device).view(1, N)).amax(dim=1)
-        rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
-        rtot.copy_(n_mol.sum().view(1), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # (as _LanczosNetFusedFunction: under HIP-graph capture nothing may touch the host, the
+        # backward then sizes its message matrix by the padded row count)
+        ctx.static_rows = torch.cuda.is_current_stream_capturing()
+        rtot = ev = None
+        if not ctx.static_rows:
+            rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
+            rtot.copy_(n_mol.sum().view(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask_u8, tiling=tiles,
                                        act_out=act)
         ctx.module, ctx.cap, ctx.rtot, ctx.rtot_ready = m, tiles[1], rtot, ev
@@ -1265,7 +1292,8 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
                 marks.append((name, e))
         mark('start')
         grads, dy, dx0, x0 = _fused_conv_backward(m, plan, grad_score, node_feat, Q, DDp, mask_u8, Lp,
-                                                  act, tiles, n_mol, False, ctx.rtot, ctx.rtot_ready)
+                                                  act, tiles, n_mol, ctx.static_rows, ctx.rtot,
+                                                  ctx.rtot_ready)
         mark('conv_stack')
 
         # ---- dense filters and Lanczos basis

@@ -69,6 +69,7 @@ class GraphedTrainStep(object):
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
         self._graphs = {}
         self._seen = {}
+        self._q1 = {}
         self._pool = None
         # warm-up steps and captures share one side stream (autograd's AccumulateGrad nodes
         # remember the stream they were created on)
@@ -112,9 +113,24 @@ class GraphedTrainStep(object):
         self.optimizer.step()
         return loss.detach()
 
+    def _refresh_q1(self, node_feat):
+        """AdaLanczosNet draws its Lanczos start vector from the CPU generator in every forward
+        (model/ada_lanczos_net.py:161).  A HIP graph cannot: the draw happens HERE, once per step
+        like the reference's (same generator, same shape, same order), and is copied into the static
+        device buffer the captured forward reads."""
+        if not hasattr(self.model, '_draw_q1'):
+            return
+        B, N = int(node_feat.shape[0]), int(node_feat.shape[1])
+        buf = self._q1.get((B, N))
+        if buf is None:
+            buf = self._q1[(B, N)] = torch.empty((B, N, 1), device=node_feat.device)
+        buf.copy_(torch.randn(B, N, 1))   # (pageable source: the host side of the copy is synchronous)
+        self.model._static_q1 = buf
+
     def __call__(self, node_feat, L, D, V, label, mask):
         inputs = (node_feat, L, D, V, label, mask)
         key = self._key(inputs)
+        self._refresh_q1(node_feat)
         entry = self._graphs.get(key)
         if entry is None:
             n = self._seen.get(key, 0)
@@ -140,3 +156,5 @@ class GraphedTrainStep(object):
         # whoever runs the module eagerly next (validation, another shape's warm-up) must re-pack
         if hasattr(self.model, 'invalidate_plan'):
             self.model.invalidate_plan()
+        if hasattr(self.model, '_draw_q1'):
+            self.model._static_q1 = None   # eager forwards draw their own start vectors again

@@ -81,3 +81,55 @@ def test_graphed_step_needs_a_capturable_optimizer():
   net, _ = _setup(1)
   with pytest.raises(ValueError):
     GraphedTrainStep(net, torch.optim.Adam(net.parameters(), lr=1e-3))
+
+
+def test_graphed_ada_train_step_follows_the_eager_trajectory():
+  """AdaLanczosNet's training step (HIP forward kernels + _AdaLanczosNetFusedFunction backward +
+  the fp64 Lanczos-layer autograd, ~1500 launches) replayed from a HIP graph: the Lanczos start
+  vector is drawn by the step object from the CPU generator — one draw of shape (B, N, 1) per step,
+  exactly what the eager forward consumes (model/ada_lanczos_net.py:161) — so with the same seed
+  the two runs see the same vectors; SGD keeps them together."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import AdaLanczosNet
+  from lanczosnet_amd.train import GraphedTrainStep
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3],
+             long_diffusion_dist=[5, 7, 10, 20, 30], hidden_dim=[128, 128], num_layer=2)
+
+  def make():
+    torch.manual_seed(11)
+    return AdaLanczosNet(make_model_config(cfg, name='AdaLanczosNet')).train().to(DEV)
+
+  batches = []
+  for s in (1, 2, 3, 4, 5):
+    b = draw_batch(48, seed=s, n_min=10, n_max=26)
+    n = _t(b['n_nodes'])
+    L = ops.laplacian_l4(_t(b['adjs']), n)
+    batches.append((_t(b['node_feat']), L, None, None, _t(b['label']), _t(b['node_mask'])))
+  lr = 1e-3
+  net_e, net_g = make(), make()
+  opt_e = torch.optim.SGD(net_e.parameters(), lr=lr)
+  opt_g = torch.optim.SGD(net_g.parameters(), lr=lr)
+  le, lg = [], []
+  torch.manual_seed(77)
+  for bt in batches:
+    opt_e.zero_grad(set_to_none=True)
+    _, loss = net_e(bt[0], bt[1], label=bt[4], mask=bt[5])
+    loss.backward()
+    opt_e.step()
+    le.append(float(loss.detach()))
+  torch.manual_seed(77)
+  step = GraphedTrainStep(net_g, opt_g, warmup=1)
+  for bt in batches:
+    lg.append(float(step(*bt)))
+  assert len(step._graphs) == 1 and net_g._static_q1 is None
+  le, lg = np.array(le), np.array(lg)
+  assert np.abs(le - lg).max() <= 2e-5 * np.abs(le).max(), (le, lg)
+  worst, worst_k = 0.0, None
+  for (k, pe), (_, pg) in zip(net_e.named_parameters(), net_g.named_parameters()):
+    d = (pe - pg).abs().max().item() / max(pe.abs().max().item(), 1e-12)
+    if d >= worst:
+      worst, worst_k = d, k
+  print('Ada graphed vs eager: loss dev %.2e, worst relative parameter deviation after %d steps: '
+        '%.2e (%s)' % (np.abs(le - lg).max() / np.abs(le).max(), len(batches), worst, worst_k))
+  assert worst < 2e-5

@@ -68,6 +68,18 @@ hip_bwd['training_forward_ms'] = round(fe[0].elapsed_time(fe[1]), 2)
 hip_bwd['backward_total_ms'] = round(fe[1].elapsed_time(fe[2]), 2)
 del net._dbg
 os.environ['LNZ_ADA_DEBUG'] = '0'
-print(json.dumps({'workload': 'AdaLanczosNet train step B=%d' % B, 'hip_backward_stages': hip_bwd,
+# the same step replayed from a HIP graph (lanczosnet_amd.train.GraphedTrainStep)
+from lanczosnet_amd.train import GraphedTrainStep, make_adam
+loss = float(loss); loss2 = float(loss2)
+opt.zero_grad(set_to_none=True)
+del opt
+opt_g = make_adam(net.parameters(), lr=1e-4)
+gstep = GraphedTrainStep(net, opt_g, warmup=2)
+for _ in range(4): gstep(nf, L, None, None, label, mask)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(8): gl = gstep(nf, L, None, None, label, mask)
+torch.cuda.synchronize(); dtg = (time.perf_counter() - t0) / 8
+print(json.dumps({'workload': 'AdaLanczosNet train step B=%d' % B, 'graphed_train_step_ms': round(dtg * 1e3, 2),
+                  'graphed_loss': float(gl), 'hip_backward_stages': hip_bwd,
                   'restatement_stages': stages, 'train_step_ms': round(dt * 1e3, 2),
                   'forward_ms': round(df * 1e3, 2), 'loss': float(loss)}))
