@@ -477,6 +477,39 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
   mlp_flops_reference = nl * 2 * B * (2000 * 4096 + 2 * 4096 * 4096 + 4096 * 2000)
   mlp_tf = mlp_flops / (acc[3] * 1e-3) / 1e12
   finite = bool(torch.isfinite(score).all())
+  # training step (loss.backward() + Adam) on the same batch: HIP forward kernels, the HIP
+  # conv-stack backward with dense filters (_AdaLanczosNetFusedFunction), library GEMMs for the
+  # filter MLPs' gradients, autograd through the fp64 Lanczos-layer graph
+  train = None
+  try:
+    net.train()
+    label = torch.zeros((B, cfg['output_dim']), dtype=torch.float32, device=dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+
+    def train_step():
+      opt.zero_grad(set_to_none=True)
+      _, loss = net(node_feat, L, label=label, mask=mask_u8)
+      loss.backward()
+      opt.step()
+      return loss
+    for _ in range(3):
+      train_step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+      loss = train_step()
+    e1.record()
+    torch.cuda.synchronize()
+    tms = e0.elapsed_time(e1) / 4
+    train = {'ms_per_step': round(tms, 3), 'value': round(B / tms * 1e3, 1), 'unit': 'molecules/s',
+             'backward': 'hip' if net._fused_backward_supported() else 'torch restatement',
+             'what': 'forward + loss.backward() + torch.optim.Adam.step(), 351 M parameters',
+             'loss_finite': bool(torch.isfinite(loss))}
+    del opt, loss
+    net.zero_grad(set_to_none=True)
+  except Exception as e:  # noqa: BLE001
+    train = {'error': repr(e)[:300]}
   del net, plan
   torch.cuda.empty_cache()
   return {'workload': 'AdaLanczosNet forward, QM8 batch=%d, N<=32, K=20, short [1,2,3], long '
@@ -494,7 +527,7 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
                                       'the input gather and the 7 output scatters'},
           'conv_kernel': 'lanczosnet_forward_kernel<4,10,2,0,0>: dense K x K filters in eigen space '
                          '(Q [sum_s DD_s (Q^T X W_s^T)]), pair tiles',
-          'split_precision_mode': split, 'parity': parity, 'finite': finite}
+          'split_precision_mode': split, 'train_step': train, 'parity': parity, 'finite': finite}
 
 
 def main():
