@@ -1297,16 +1297,15 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         mark('conv_stack')
 
         # ---- dense filters and Lanczos basis
-        cdt = torch.float64 if os.environ.get('LNZ_ADA_BWD_FP64') == '1' else torch.float32
-        Qt = Q.transpose(1, 2).to(cdt)
-        DDk = DDp.permute(0, 1, 3, 2, 4).reshape(Lnum, B, K, S * K).to(cdt)     # [l][b][k][(s, j)]
+        Qt = Q.transpose(1, 2)
+        DDk = DDp.permute(0, 1, 3, 2, 4).reshape(Lnum, B, K, S * K)     # [l][b][k][(s, j)]
         dDDp = torch.empty_like(DDp)
         dQ = torch.zeros_like(Q)
         for la in range(Lnum):
             d = din0 if la == 0 else dh
-            X = (x0[:, :N, :din0] if la == 0 else act[la - 1][:, :N]).to(cdt)
-            dYl = dy[la][:, :N].to(cdt)
-            Wl = m._mix_weight(la).detach().view(dh, n_chan, d)[:, n_short:n_short + S, :].to(cdt)  # [o,s,i]
+            X = x0[:, :N, :din0] if la == 0 else act[la - 1][:, :N]
+            dYl = dy[la][:, :N]
+            Wl = m._mix_weight(la).detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]  # [o,s,i]
             Yq = torch.bmm(Qt, X)                                               # [B,K,d]
             Cq = torch.bmm(Qt, dYl)                                             # [B,K,dh]
             Bq = (Yq.reshape(B * K, d) @ Wl.permute(2, 1, 0).reshape(d, S * dh)).view(B, K, S, dh)
