@@ -132,6 +132,12 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
   bool solved_out = false;  // the parallel eigensolver ran: V = Q S is formed at the output
 #ifdef LNZ_PROFILE_PHASES
   long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
+  long long tl_mv = 0, tl_dot = 0, tl_red = 0, tl_upd = 0;   // Lanczos step parts (thread 0's clock)
+#define LNZ_LT0 long long _lt = clock64();
+#define LNZ_LACC(x) { const long long _l1 = clock64(); x += _l1 - _lt; _lt = _l1; }
+#else
+#define LNZ_LT0
+#define LNZ_LACC(x)
 #endif
   if (n > 0) {
     // (output row, segment) split of the length-n reductions with n outputs (A w; w -= Q c)
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       const int ui0 = seg_n * cnt / nsu, ui1 = (seg_n + 1) * cnt / nsu;
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
+        LNZ_LT0
         if (tid < n) sm.zb[tid] = x;
         __syncthreads();
         if (ds < nsd) {
@@ -183,12 +190,14 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           sm.part[ds * cnt + di] = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
+        LNZ_LACC(tl_dot)
         if (tid < cnt) {
           double c = sm.part[tid];
           for (int s = 1; s < nsd; ++s) c += sm.part[s * cnt + tid];
           sm.cb[tid] = c;
         }
         __syncthreads();
+        LNZ_LACC(tl_red)
         coef += sm.cb[jidx];
         if (seg_n < nsu) {
           double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
             x -= p;
           }
         }
+        LNZ_LACC(tl_upd)
       }
       return coef;
     };
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       double beta, u;
       for (;;) {
         // ---- one broadcast of w serves beta = |w| and u = A w
+        LNZ_LT0
         if (tid < n) sm.zb[tid] = w;
         __syncthreads();
         if (seg_n < nss) {
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         double nn = sm.pn[0];
         for (int s = 1; s < nss; ++s) nn += sm.pn[s];
         beta = sqrt(nn);
+        LNZ_LACC(tl_mv)
         if (fresh || beta > kBreakdownTol) break;
         // breakdown: span(q_0..q_{j-1}) is A-invariant.  Restart from the unit vector with the
         // largest residual against the basis (residual^2 >= (n-j)/n > 0); T[j-1][j] stays 0.
@@ -637,6 +649,12 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     D[(int64_t)b * K + 1] = (float)(tp2 - tp1);
     D[(int64_t)b * K + 2] = (float)(tp3 - tp2);
     D[(int64_t)b * K + 3] = (float)n;
+    if (K >= 8) {
+      D[(int64_t)b * K + 4] = (float)tl_mv;
+      D[(int64_t)b * K + 5] = (float)tl_dot;
+      D[(int64_t)b * K + 6] = (float)tl_red;
+      D[(int64_t)b * K + 7] = (float)tl_upd;
+    }
   }
 #endif
 }

@@ -14,6 +14,7 @@ for N in (48, 64, 100, 128, 192):
   A, ns = laplacians(rs, 8, N, N, N, 0.5)
   D, V = ops.lanczos_ritz(torch.from_numpy(A).cuda(), torch.from_numpy(ns).cuda(), 20,
                           kernel='workgroup' if N <= 113 else 'auto')
-  d = D.cpu().numpy()[:, :4].mean(axis=0)
+  d = D.cpu().numpy()[:, :8].mean(axis=0)
   print('N=%3d  Lanczos %9.0f cycles  QL %9.0f  order+output %8.0f   (QL %.0f cycles per n^2)'
         % (N, d[0], d[1], d[2], d[1] / (N * N)))
+  print('       Lanczos parts: A w + norm %8.0f  dots %8.0f  coefficient sums %8.0f  update %8.0f' % tuple(d[4:8]))
