@@ -45,6 +45,15 @@ const char* lnz_last_error(void);
  * Arithmetic in fp64 (the reference builds L4 in float64), stored as float32. */
 int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B, int N, int E,
                      float* L, lnz_stream_t stream);
+/* Every kind of get_laplacian (utils/data_helper.py:119-166 over normalize_adj :92-116), same
+ * layouts: kind 1 .. 7 = 'L1' .. 'L7' (L1 = D - A, L2 = I - D^-1/2 A D^-1/2, L3 = I - D^-1 A,
+ * L4 = D^-1/2 (I+A) D^-1/2, L5 = D^-1 (I+A), L6 = D^-alpha A D^-alpha, L7 = D^-1 A; D = row sums of
+ * the normalised matrix, D^-x of an isolated node = 0 like the reference's inf guard), alpha only
+ * for kind 6 (reference default 0.5).  The reference's offline scripts store L6 / L7 of the simple
+ * graph for the ChebyNet / DCNN baselines (dataset/get_qm8_data.py:73-77,
+ * dataset/get_graph_data.py:70-75).  kind 4 is lnz_laplacian_l4 bit for bit. */
+int lnz_laplacian(const float* adjs, const int32_t* n_nodes, int B, int N, int E, int kind,
+                  double alpha, float* L, lnz_stream_t stream);
 
 /* ---- R2 + R6: Lanczos tridiagonalisation -> tridiagonal eigensolve -> Ritz select ----
  * Per molecule: full-length (m = n) Lanczos with twice-iterated classical Gram-Schmidt and

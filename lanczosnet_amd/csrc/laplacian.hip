@@ -66,6 +66,87 @@ extern "C" int lnz_laplacian_l4(const float* adjs, const int32_t* n_nodes, int B
 }
 
 // ---------------------------------------------------------------------------------------
+// R1, every kind of utils/data_helper.py:119-166 (get_laplacian 'L1' .. 'L7' on normalize_adj
+// :92-116), same batch layout as the L4 kernel: channel 0 = simple graph (sum over bond types),
+// channel 1 + e = bond type e.  With M = A (kinds 1-3, 6, 7) or I + A (kinds 4, 5) and d = rowsum(M):
+//   L1 = diag(d) - A          L2 = I - d^-1/2 A d^-1/2      L3 = I - d^-1 A
+//   L4 = d^-1/2 M d^-1/2      L5 = d^-1 M                    L6 = d^-alpha A d^-alpha     L7 = d^-1 A
+// d^-x with the reference's guard: inf -> 0 (an isolated node's row is zero, :106).  fp64 inside.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void laplacian_kind_kernel(const float* __restrict__ adjs,
+                                                             const int32_t* __restrict__ n_nodes,
+                                                             int N, int E, int kind, double alpha,
+                                                             float* __restrict__ L) {
+  extern __shared__ __attribute__((aligned(16))) double sdeg[];  // [(E+1) * N]: d, then d^-x
+  const int b = blockIdx.x;
+  const int n = n_nodes[b];
+  const int E1 = E + 1;
+  const float* Ab = adjs + (int64_t)b * N * N * E;
+  float* Lb = L + (int64_t)b * N * N * E1;
+  const bool plus_identity = kind == 4 || kind == 5;
+  const double expo = (kind == 2 || kind == 4) ? 0.5 : (kind == 6 ? alpha : 1.0);
+  for (int t = threadIdx.x; t < E1 * N; t += blockDim.x) {
+    int i = t % N, ch = t / N;
+    double deg = plus_identity ? 1.0 : 0.0;
+    if (i < n) {
+      for (int j = 0; j < n; ++j) {
+        const float* a = Ab + ((int64_t)i * N + j) * E;
+        if (ch == 0) {
+          for (int e = 0; e < E; ++e) deg += (double)a[e];
+        } else {
+          deg += (double)a[ch - 1];
+        }
+      }
+    }
+    double s = deg;                              // L1 keeps the degree itself
+    if (kind != 1) {
+      s = pow(deg, -expo);                       // np.power(rowsum, -exponent)
+      if (isinf(s)) s = 0.0;                     // r_inv[np.isinf(r_inv)] = 0
+    }
+    sdeg[t] = s;
+  }
+  __syncthreads();
+  const bool sym = kind == 2 || kind == 4 || kind == 6;
+  for (int p = threadIdx.x; p < N * N; p += blockDim.x) {
+    int i = p / N, j = p % N;
+    const float* a = Ab + (int64_t)p * E;
+    float* out = Lb + (int64_t)p * E1;
+    if (i >= n || j >= n) {
+      for (int ch = 0; ch < E1; ++ch) out[ch] = 0.0f;
+      continue;
+    }
+    const double id = (i == j) ? 1.0 : 0.0;
+    double asum = 0.0;
+    for (int e = 0; e < E; ++e) asum += (double)a[e];
+    for (int ch = 0; ch < E1; ++ch) {
+      const double v = ch == 0 ? asum : (double)a[ch - 1];
+      const double si = sdeg[ch * N + i], sj = sdeg[ch * N + j];
+      double r;
+      if (kind == 1) {
+        r = id * si - v;                                   // np.diag(rowsum) - adj
+      } else {
+        const double m = plus_identity ? id + v : v;
+        r = sym ? (si * m) * sj : si * m;                  // R.dot(A).dot(R) / R.dot(A)
+        if (kind == 2 || kind == 3) r = id - r;
+      }
+      out[ch] = (float)r;
+    }
+  }
+}
+
+extern "C" int lnz_laplacian(const float* adjs, const int32_t* n_nodes, int B, int N, int E, int kind,
+                             double alpha, float* L, lnz_stream_t stream) {
+  LNZ_REQUIRE(adjs && n_nodes && L && B > 0 && N > 0 && E > 0, LNZ_EINVAL,
+              "lnz_laplacian: bad arguments (B=%d N=%d E=%d)", B, N, E);
+  LNZ_REQUIRE(kind >= 1 && kind <= 7, LNZ_EINVAL, "lnz_laplacian: kind %d not in 1..7", kind);
+  size_t lds = (size_t)(E + 1) * N * sizeof(double);
+  LNZ_REQUIRE(lds <= 64 * 1024, LNZ_ENOTSUP, "lnz_laplacian: (E+1)*N too large");
+  hipLaunchKernelGGL(laplacian_kind_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, adjs,
+                     n_nodes, N, E, kind, alpha, L);
+  return lnz::check_launch("lnz_laplacian");
+}
+
+// ---------------------------------------------------------------------------------------
 // unsorted_segment_sum.  data [B, D1, D2]; ids [B, D1]; out [B, S, D2].
 //   forward : out[b, ids[b,c], x] += data[b, c, x]      (operators/src/cuda/segment_reduction.cu:39-53)
 //   backward: gdata[b, c, x] = gout[b, ids[b,c], x]     (:55-69)

@@ -61,8 +61,11 @@ def collate_graph_preprocessed(items, num_eigs, simple_key='L_simple_4', negate_
     return out
 
 
-def collate_graph_adjacency(items, num_eigs, device='cuda'):
-    """Raw graphs in, device-resident batch out (L4 and Ritz pairs by the HIP kernels)."""
+def collate_graph_adjacency(items, num_eigs, device='cuda', model_name='LanczosNetGeneral'):
+    """Raw graphs in, device-resident batch out (Laplacians and Ritz pairs by the HIP kernels).
+    model_name picks the simple-graph channel like the reference's collate (graph_data.py:247-260):
+    L4 by default, the asymmetric diffusion map L7 for DCNN, MINUS the symmetric one (L6, alpha =
+    0.5) for ChebyNet — the bond-type channels are L4 in every branch (get_graph_data.py:61-72)."""
     from .. import ops
     sizes, B, N, node_feat, mask, label = _pad_common(items)
     E = np.asarray(items[0]['adjs']).shape[2]
@@ -71,11 +74,20 @@ def collate_graph_adjacency(items, num_eigs, device='cuda'):
         adjs[b, :n, :n, :] = it['adjs']
     dev = torch.device(device)
     n_nodes = torch.tensor(sizes, dtype=torch.int32, device=dev)
-    L = ops.laplacian_l4(torch.from_numpy(adjs).to(dev), n_nodes)
-    D, V = ops.lanczos_ritz(L[:, :, :, 0], n_nodes, num_eigs)
-    return dict(node_feat=torch.from_numpy(node_feat).to(dev),
-                node_mask=torch.from_numpy(mask).to(dev), label=torch.from_numpy(label).to(dev),
-                L=L, D=D, V=V, n_nodes=n_nodes)
+    adjs_d = torch.from_numpy(adjs).to(dev)
+    L = ops.laplacian_l4(adjs_d, n_nodes)
+    out = dict(node_feat=torch.from_numpy(node_feat).to(dev),
+               node_mask=torch.from_numpy(mask).to(dev), label=torch.from_numpy(label).to(dev),
+               n_nodes=n_nodes)
+    if num_eigs:
+        # (the Ritz pairs are those of the L4 simple graph in every branch, graph_data.py:262-287)
+        out['D'], out['V'] = ops.lanczos_ritz(L[:, :, :, 0], n_nodes, num_eigs)
+    if model_name == 'DCNN':
+        L[:, :, :, 0] = ops.laplacian(adjs_d, n_nodes, 'L7')[:, :, :, 0]
+    elif model_name == 'ChebyNet':
+        L[:, :, :, 0] = -ops.laplacian(adjs_d, n_nodes, 'L6')[:, :, :, 0]
+    out['L'] = L
+    return out
 
 
 class GraphData(object):

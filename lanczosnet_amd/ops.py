@@ -90,6 +90,26 @@ def laplacian_l4(adjs, n_nodes):
   return L
 
 
+def laplacian(adjs, n_nodes, kind='L4', alpha=0.5):
+  """get_laplacian of utils/data_helper.py:119-166 on the device, every kind 'L1' .. 'L7'
+  (alpha: the 'L6' exponent).  Same layouts as laplacian_l4: adjs [B,N,N,E], n_nodes [B] ->
+  L [B,N,N,E+1] float32, channel 0 = simple graph, 1 + e = bond type e."""
+  _need_cuda(adjs, n_nodes)
+  kinds = ('L1', 'L2', 'L3', 'L4', 'L5', 'L6', 'L7')
+  if kind not in kinds:
+    raise ValueError('Unsupported Graph Laplacian!')   # (the reference's message, :164)
+  adjs = _f32c(adjs)
+  n_nodes = n_nodes.to(torch.int32).contiguous()
+  B, N, N2, E = adjs.shape
+  assert N == N2 and n_nodes.shape == (B,)
+  L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=adjs.device)
+  lib = _lib.load()
+  with torch.cuda.device(adjs.device):
+    _lib.check(lib.lnz_laplacian(_ptr(adjs), _ptr(n_nodes), B, N, E, kinds.index(kind) + 1,
+                                 float(alpha), _ptr(L), _stream()))
+  return L
+
+
 # ------------------------------------------------------------------------------------- R2 + R6
 def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   """Batched Lanczos -> tridiagonal eigensolve -> Ritz select.

@@ -96,6 +96,26 @@ def test_graph_collate_adjacency_is_the_device_pipeline():
   assert per.max() < 1e-5, per
 
 
+@pytest.mark.parametrize('model_name,kind,sign', [('DCNN', 'L7', 1.0), ('ChebyNet', 'L6', -1.0)])
+def test_graph_collate_adjacency_baseline_branches(model_name, kind, sign):
+  """The DCNN / ChebyNet branches of the reference's graph collate (dataset/graph_data.py:247-260:
+  simple-graph channel = L_simple_7, resp. MINUS L_simple_6, both written by get_graph_data.py:70-75
+  with get_laplacian on the summed adjacency) from the raw graphs on the device; bond-type channels
+  and Ritz pairs stay those of the default branch."""
+  from lanczosnet_amd.dataset.graph_data import collate_graph_adjacency
+  items, ref, _, _ = load_split('train')
+  base = collate_graph_adjacency(items, K, device=DEV)
+  data = collate_graph_adjacency(items, K, device=DEV, model_name=model_name)
+  L = data['L'].cpu().numpy()
+  assert np.array_equal(L[..., 1:], base['L'][..., 1:].cpu().numpy())
+  assert torch.equal(data['D'], base['D']) and torch.equal(data['V'], base['V'])
+  for b, it in enumerate(items):
+    n = int(ref['n_nodes'][b])
+    want = sign * oracle.get_laplacian(np.asarray(it['adjs'], np.float64).sum(axis=2), kind)
+    assert np.abs(L[b, :n, :n, 0] - want).max() < 1e-7
+    assert (L[b, n:, :, 0] == 0).all() and (L[b, :, n:, 0] == 0).all()
+
+
 def _random_laplacians(rs, B, N, n_lo, n_hi, p):
   A = np.zeros((B, N, N), np.float32)
   ns = rs.randint(n_lo, n_hi + 1, size=B).astype(np.int32)

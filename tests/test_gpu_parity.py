@@ -91,6 +91,35 @@ def test_laplacian_l4_matches_oracle_and_reference():
   assert (L6[0, 6:] == 0).all() and (L6[0, :, 6:] == 0).all()
 
 
+def test_every_laplacian_kind_matches_the_reference_function():
+  """lnz_laplacian, kinds 'L1' .. 'L7' (+ 'L6' at alpha = 0.3), against the fixture the
+  UNMODIFIED get_laplacian wrote (tests/golden/make_golden_laplacians.py): molecule batches per
+  channel incl. an isolated atom (the inf -> 0 guard) and a weighted non-symmetric matrix; 1e-7
+  of the largest entry (the reference is float64, the output float32).  'L4' equals
+  lnz_laplacian_l4 bit for bit; padding is exact zeros."""
+  from lanczosnet_amd import ops
+  g = load_golden('laplacian_kinds.npz')
+  adjs, n = _t(g['adjs']), _t(g['n_nodes'])
+  W = g['weighted']
+  Wp = np.zeros((1, 12, 12, 1), np.float32)
+  Wp[0, :9, :9, 0] = W
+  for idx, (kind, alpha) in enumerate(zip(g['kinds'], g['alphas'])):
+    ref = g['L_%d' % idx]
+    L = ops.laplacian(adjs, n, str(kind), float(alpha)).cpu().numpy()
+    assert np.abs(L - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max()), (kind, alpha)
+    for m in range(adjs.shape[0]):
+      k = int(g['n_nodes'][m])
+      assert (L[m, k:] == 0).all() and (L[m, :, k:] == 0).all()
+    refw = g['Lw_%d' % idx]
+    Lw = ops.laplacian(_t(Wp), _t(np.array([9], np.int32)), str(kind), float(alpha)).cpu().numpy()
+    for ch in (0, 1):
+      assert np.abs(Lw[0, :9, :9, ch] - refw).max() <= 1e-7 * max(1.0, np.abs(refw).max()), (kind, ch)
+    if str(kind) == 'L4':
+      assert np.array_equal(L, ops.laplacian_l4(adjs, n).cpu().numpy())
+  with pytest.raises(ValueError):
+    ops.laplacian(adjs, n, 'L8')
+
+
 def _check_ritz(D, V, Dref, Vref, n_nodes, Dfull=None, K=20):
   worst = 0.0
   for b in range(D.shape[0]):
