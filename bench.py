@@ -484,7 +484,7 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
   try:
     net.train()
     label = torch.zeros((B, cfg['output_dim']), dtype=torch.float32, device=dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-5)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-5, fused=True)   # (one multi-tensor kernel per step)
 
     def train_step():
       opt.zero_grad(set_to_none=True)
@@ -504,7 +504,7 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
     tms = e0.elapsed_time(e1) / 4
     train = {'ms_per_step': round(tms, 3), 'value': round(B / tms * 1e3, 1), 'unit': 'molecules/s',
              'backward': 'hip' if net._fused_backward_supported() else 'torch restatement',
-             'what': 'forward + loss.backward() + torch.optim.Adam.step(), 351 M parameters',
+             'what': 'forward + loss.backward() + torch.optim.Adam(fused=True).step(), 351 M parameters',
              'loss_finite': bool(torch.isfinite(loss))}
     del opt, loss
     net.zero_grad(set_to_none=True)

@@ -31,6 +31,11 @@ def make_adam(params, lr=1e-4, weight_decay=0.0, **kw):
     params = list(params)
     # lr as a device tensor: an LR scheduler then changes it in place and the captured step sees it
     lr_t = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
+    # (not fused=True: with torch 2.10 / ROCm 7 the fused multi-tensor Adam replayed from a graph
+    # leaves the eager trajectory after the first step — loss off by 1e-3 at step 2 in
+    # tests/test_gpu_train_graph.py — while the foreach form follows it to rounding; eager loops can
+    # pass fused=True to torch.optim.Adam themselves: 2.3 instead of 5.6 ms per step for
+    # AdaLanczosNet's 351 M parameters)
     return torch.optim.Adam(params, lr=lr_t, weight_decay=weight_decay, capturable=True, **kw)
 
 

@@ -12,7 +12,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30])
 torch.manual_seed(1234)
 net = AdaLanczosNet(make_model_config(cfg, name='AdaLanczosNet')).train().cuda()
-opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=os.environ.get('ADAM_FUSED', '1') == '1')
 b = draw_batch(B, seed=0)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 n = t(b['n_nodes']); nf, mask, label = t(b['node_feat']), t(b['node_mask']), t(b['label'])
