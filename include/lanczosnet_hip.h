@@ -434,6 +434,20 @@ int lnz_ada_symmetrize_filters(const float* DD, int B, int K, int S, float* DDp,
 int lnz_split_f16x3(const float* X, int M, int K, int ldx, const float* bias, float alpha, int relu,
                     int Kp, void* out, lnz_stream_t stream);
 
+/* R5 for training (csrc/ada_lanczos_grad.hip): the same Lanczos layer on an fp64 Laplacian
+ * A [B,N,N] (N, K <= 32), outputs T [B,K,K] and Q [B,N,K] in fp64, plus the state its backward needs
+ * in `ws` (lnz_ada_lanczos_f64_workspace_doubles(B) doubles: basis vectors, alpha, beta, the valid
+ * flags and every Gram-Schmidt coefficient), and the backward: given dLoss/dT, dLoss/dQ (fp64,
+ * same shapes) the reverse sweep of the recurrence -> dA [B,N,N] = dLoss/dA.  Replaces torch
+ * autograd through model/ada_lanczos_net.py:139-247 (the reference differentiates its own loop of
+ * small ATen ops).  mask may be NULL (all nodes real); masks / flags are constants of the gradient. */
+int64_t lnz_ada_lanczos_f64_workspace_doubles(int B);
+int lnz_ada_lanczos_layer_f64(const double* A, const uint8_t* mask, const float* q1, int B, int N,
+                              int K, double* T, double* Q, double* ws, lnz_stream_t stream);
+int lnz_ada_lanczos_layer_f64_backward(const double* A, int B, int N, int K, const double* ws,
+                                       const double* dT, const double* dQ, double* dA,
+                                       lnz_stream_t stream);
+
 /* The same filter MLPs, hand-written (csrc/f16x3_linear.hip): one launch per Linear,
  *   out = [relu]( alpha * (X W^T) + bias ),   X [M, K], W [N, K],
  * both operands as (hi, lo) fp16 PLANES (x = x_hi + x_lo, w = w_hi + w_lo) and the product as

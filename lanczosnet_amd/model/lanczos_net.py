@@ -1108,39 +1108,50 @@ class AdaLanczosNet(_LanczosNetBase):
 
     def _torch_ada_spectrum(self, node_feat, L, mask, q1):
         """model/ada_lanczos_net.py:101-270 -> (embedded node state [B,N,D], cat of the T powers
-        [B, K*K*S] float32, Lanczos basis Q [B,N,K] float32)."""
-        eps = 1.1920928955078125e-07
-        B, N = node_feat.shape
-        K, S = self.num_eig_vec, self.num_scale_long
-        Lf = L.float()
-        state = self.embedding(node_feat)
-        # The learned Laplacian and the Lanczos recurrence run in fp64, like the forward kernel
-        # (lnz_ada_lanczos_layer): an fp32 recurrence — and its backward — carries rounding noise
-        # of 1e-6 .. 1e-4 that depends on the summation order; fp64 gives the exact-arithmetic
-        # gradient, which is what the reference's own autograd approximates.  (B, N, K) are tiny.
+        [B, K*K*S] float32, Lanczos basis Q [B,N,K] float32).  Three differentiable stages, all in
+        fp64: `_torch_ada_laplacian`, `_torch_ada_lanczos`, `_torch_ada_powers`."""
+        state, Le = self._torch_ada_laplacian(node_feat, L)
+        T, Q = self._torch_ada_lanczos(Le, mask, q1)
+        return state, self._torch_ada_powers(T), Q.float()
+
+    def _torch_ada_laplacian(self, node_feat, L):
+        """The learned Laplacian (model/ada_lanczos_net.py:101-137) -> (embedded node state
+        [B,N,D] float32, Le [B,N,N] float64).
+        The learned Laplacian and the Lanczos recurrence run in fp64, like the forward kernel
+        (lnz_ada_lanczos_layer): an fp32 recurrence — and its backward — carries rounding noise
+        of 1e-6 .. 1e-4 that depends on the summation order; fp64 gives the exact-arithmetic
+        gradient, which is what the reference's own autograd approximates.  (B, N, K) are tiny."""
+        B = node_feat.shape[0]
         dd = torch.float64
+        state = self.embedding(node_feat)
         st = state.to(dd)
-        # learned Laplacian (:101-137)
-        adj = (Lf[:, :, :, 0] != 0).to(dd)
+        adj = (L[:, :, :, 0] != 0).to(dd)
         diff = st.unsqueeze(1) - st.unsqueeze(2)                # [B, i, j, D] = x_j - x_i
         dist2 = (diff * diff).sum(dim=3)
         sigma2 = dist2.reshape(B, -1).mean(dim=1).view(B, 1, 1)
         A = torch.exp(-dist2 / sigma2) * adj
         row_sum = A.sum(dim=2, keepdim=True)
         Dg = 1.0 / (row_sum + (row_sum == 0).to(dd)).pow(0.5)
-        Le = Dg * A * Dg.transpose(1, 2)
-        # Lanczos layer (:139-247)
+        return state, Dg * A * Dg.transpose(1, 2)
+
+    def _torch_ada_lanczos(self, Le, mask, q1):
+        """The Lanczos layer (model/ada_lanczos_net.py:139-247) on the fp64 Laplacian Le ->
+        (T [B,K,K], Q [B,N,K]) in fp64, incl. the quirks of SURVEY.md F6."""
+        eps = 1.1920928955078125e-07
+        B, N = Le.shape[0], Le.shape[1]
+        K = self.num_eig_vec
+        dd = torch.float64
         m = (mask != 0).to(dd).unsqueeze(2)
         Tit = min(N, K)
         q = q1.to(dd) * m
         q = q / torch.norm(q, 2, dim=1, keepdim=True)
-        Qs, alphas, betas, valids = [torch.zeros_like(q), q], [], [torch.zeros(B, 1, 1, dtype=dd, device=L.device)], []
+        Qs, alphas, betas, valids = [torch.zeros_like(q), q], [], [torch.zeros(B, 1, 1, dtype=dd, device=Le.device)], []
         # The reference's Gram-Schmidt (:177-189) subtracts the projections on q_1 .. q_{ii-1} ONE
         # AFTER THE OTHER from the running z, twice: z <- P_{ii-1} ... P_1 z with P_j = I - q_j q_j^T
         # / (q_j^T q_j + EPS).  The product M_ii = P_{ii-1} M_{ii-1} is carried along instead of
         # replaying 2 (ii-1) vector updates per step: the same map (and the same derivative), one
         # batched N x N product per step instead of ~2000 tiny launches per forward in fp64.
-        eye = torch.eye(N, dtype=dd, device=L.device).unsqueeze(0)
+        eye = torch.eye(N, dtype=dd, device=Le.device).unsqueeze(0)
         M = None
         for ii in range(1, Tit + 1):
             z = torch.bmm(Le, Qs[ii])
@@ -1162,23 +1173,27 @@ class AdaLanczosNet(_LanczosNetBase):
         beta = torch.cat(betas[1:-1], dim=1).squeeze(2) if Tit > 1 else alpha[:, :0]
         valid = torch.cat(valids, dim=1).squeeze(2)
         idx = torch.minimum(valid.sum(dim=1), m.squeeze(2).sum(dim=1)).long()
-        valid = valid * (torch.arange(Tit, device=L.device)[None, :] < idx[:, None]).to(dd)
+        valid = valid * (torch.arange(Tit, device=Le.device)[None, :] < idx[:, None]).to(dd)
         alpha = alpha * valid
         beta = beta * valid[:, :-1]
         T = torch.diag_embed(alpha) + torch.diag_embed(beta, offset=1) + torch.diag_embed(beta, offset=-1)
         Q = torch.cat(Qs[1:-1], dim=2) * valid.unsqueeze(1)
-        Q = Q * (torch.arange(N, device=L.device)[None, :] < idx[:, None]).to(dd).unsqueeze(2)
+        Q = Q * (torch.arange(N, device=Le.device)[None, :] < idx[:, None]).to(dd).unsqueeze(2)
         if Tit < K:
             T = torch.nn.functional.pad(T, (0, K - Tit, 0, K - Tit))
             Q = torch.nn.functional.pad(Q, (0, K - Tit))
-        # T powers (:262-270)
+        return T, Q
+
+    def _torch_ada_powers(self, T):
+        """T powers (model/ada_lanczos_net.py:262-270) of the fp64 T -> cat(T^p, dim=2).view(B, -1)
+        float32 (fp64 products like lnz_ada_t_powers)."""
+        B = T.shape[0]
         T_list, TT = [], T
         for ii in range(1, self.max_long_diffusion_dist + 1):
             if ii in self.long_diffusion_dist:
                 T_list.append(TT)
             TT = torch.bmm(TT, T)
-        tcat = torch.cat(T_list, dim=2).view(B, -1).float()   # fp64 products like lnz_ada_t_powers
-        return state, tcat, Q.float()
+        return torch.cat(T_list, dim=2).view(B, -1).float()
 
     def _torch_ada_filters(self, tcat):
         """model/ada_lanczos_net.py:271-278: the symmetrised dense filters [B, K, K, S] of every
@@ -1225,14 +1240,14 @@ class AdaLanczosNet(_LanczosNetBase):
 class _AdaLanczosNetFusedFunction(torch.autograd.Function):
     """AdaLanczosNet training through the HIP kernels.
 
-    forward: the Lanczos layer has to be differentiated and its backward is autograd through the
-    fp64 restatement `_torch_ada_spectrum`, so in training that restatement IS the forward of the
-    learned Laplacian / Lanczos layer / T powers (graph kept for the backward; the HIP kernels of
-    these three stages work from the fp32 Laplacian like the reference's fp32 run, and a basis that
-    differs by the Lanczos recurrence's amplification of that rounding — 2.5e-5 on the test batch —
-    would put the same 1e-5 between the filter gradients and the reference's float64 ones); filter
-    MLPs (hidden activations kept where the fp32 chain produces them) and the fused conv kernel
-    storing every layer's activations run on its (T powers, Q).
+    forward: the learned Laplacian and the T powers as fp64 torch graphs (kept for the backward), the
+    Lanczos layer between them by lnz_ada_lanczos_layer_f64 ON THE FP64 LAPLACIAN with the state
+    its backward needs (the inference kernels of these stages work from the fp32 Laplacian like
+    the reference's fp32 run, and a basis that differs by the Lanczos recurrence's amplification
+    of that rounding — 2.5e-5 on the test batch — would put the same 1e-5 between the filter
+    gradients and the reference's float64 ones); filter MLPs (hidden activations kept where the
+    fp32 chain produces them) and the fused conv kernel storing every layer's activations run on
+    its (T powers, Q).
     backward:
       * readout head, node-state gradients, conv weights / biases: `_fused_conv_backward` — the same
         launches as LanczosNet, the kernels running their dense-filter eigen-space variant;
@@ -1242,8 +1257,10 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         as batched library GEMMs on [B, K, .] blocks;
       * filter MLPs (model/ada_lanczos_net.py:271-278): plain GEMMs on the stored activations (the
         reference's unfolded weights), symmetrisation 0.5 (DD + DD^T) transposed onto dDD;
-      * learned Laplacian + Lanczos layer + T powers (:101-270): autograd through the graph the
-        forward kept, fed (dX_0, dT-powers, dQ)."""
+      * T powers: autograd through the forward's graph -> dT; Lanczos layer (:139-247):
+        lnz_ada_lanczos_layer_f64_backward, the reverse sweep of the recurrence as one launch
+        (dT, dQ) -> dLe; learned Laplacian + embedding: autograd through the forward's graph,
+        fed (dX_0, dLe)."""
 
     @staticmethod
     def forward(ctx, module, node_feat, L, mask, q1, *params):
@@ -1253,9 +1270,18 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         K = m.num_eig_vec
         Lf = L if L.dtype == torch.float32 else L.float()
         mask_u8 = mask.to(torch.uint8).contiguous()
+        # learned Laplacian and T powers: fp64 torch graphs (kept for the backward); the Lanczos
+        # layer between them: lnz_ada_lanczos_layer_f64 on the fp64 Laplacian, its state kept for
+        # lnz_ada_lanczos_layer_f64_backward
         with torch.enable_grad():
-            spectrum = m._torch_ada_spectrum(node_feat, L, mask, q1)
-        tcat, Q = spectrum[1].detach(), spectrum[2].detach().contiguous()
+            state, Le = m._torch_ada_laplacian(node_feat, L)
+        Le_d = Le.detach().contiguous()
+        T64, Q64, lws = ops.ada_lanczos_layer_f64(Le_d, mask, q1, K)
+        T64.requires_grad_(True)
+        with torch.enable_grad():
+            tc = m._torch_ada_powers(T64)
+        tcat, Q = tc.detach(), Q64.float().contiguous()
+        spectrum = (state, Le, T64, tc, Le_d, lws)
         keep = []
         DDp = m._ada_dense_filters(plan, tcat, keep=keep)
         Lp = ops.pack_laplacian(Lf)
@@ -1355,11 +1381,14 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         if dbg:
             m._dbg = dict(dDDp=dDDp, dQ=dQ, dtcat=dtcat, dx0=dx0[:, :N, :din0].clone(), Q=Q, DDp=DDp,
                           tcat=tcat, act=act, dy=dy)
-        # ---- learned Laplacian, Lanczos layer, T powers: autograd through the forward's graph
-        st, tc, Qr = ctx.spectrum
+        # ---- T powers (autograd through the forward's fp64 graph) -> Lanczos layer (the HIP reverse
+        #      sweep) -> learned Laplacian + embedding (autograd through the forward's graph)
+        st, Le, T64, tc, Le_d, lws = ctx.spectrum
         ctx.spectrum = None
-        ge, = torch.autograd.grad([st, tc, Qr], [m.embedding.weight],
-                                  [dx0[:, :N, :din0].contiguous(), dtcat, dQ])
+        dT, = torch.autograd.grad([tc], [T64], [dtcat])
+        dLe = ops.ada_lanczos_layer_f64_backward(Le_d, lws, dT, dQ.double())
+        ge, = torch.autograd.grad([st, Le], [m.embedding.weight],
+                                  [dx0[:, :N, :din0].contiguous(), dLe])
         grads[id(m.embedding.weight)] = ge
         mark('spectrum')
         if dbg:

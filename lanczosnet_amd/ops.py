@@ -890,6 +890,41 @@ def ada_lanczos_layer(A, mask, q1, K):
   return T, Q
 
 
+def ada_lanczos_layer_f64(Le, mask, q1, K):
+  """lnz_ada_lanczos_layer_f64: the Lanczos layer on an fp64 Laplacian Le [B,N,N]; returns
+  (T [B,K,K], Q [B,N,K], ws) in fp64 — ws is the state ada_lanczos_layer_f64_backward needs."""
+  _need_cuda(Le, mask, q1)
+  assert Le.dtype == torch.float64 and Le.is_contiguous() and Le.dim() == 3
+  B, N = Le.shape[0], Le.shape[1]
+  mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
+  q = _f32c(q1).reshape(B, N)
+  lib = _lib.load()
+  T = torch.empty((B, K, K), dtype=torch.float64, device=Le.device)
+  Q = torch.empty((B, N, K), dtype=torch.float64, device=Le.device)
+  ws = torch.empty((int(lib.lnz_ada_lanczos_f64_workspace_doubles(B)),), dtype=torch.float64,
+                   device=Le.device)
+  with torch.cuda.device(Le.device):
+    _lib.check(lib.lnz_ada_lanczos_layer_f64(_ptr(Le), _ptr(mask_u8), _ptr(q), B, N, K, _ptr(T), _ptr(Q),
+                                             _ptr(ws), _stream()))
+  return T, Q, ws
+
+
+def ada_lanczos_layer_f64_backward(Le, ws, dT, dQ):
+  """dLoss/dLe [B,N,N] fp64 from dLoss/dT [B,K,K], dLoss/dQ [B,N,K] (fp64) and the forward's state."""
+  _need_cuda(Le, ws, dT, dQ)
+  B, N = Le.shape[0], Le.shape[1]
+  K = dT.shape[1]
+  dT = dT.to(torch.float64).contiguous()
+  dQ = dQ.to(torch.float64).contiguous()
+  assert tuple(dT.shape) == (B, K, K) and tuple(dQ.shape) == (B, N, K)
+  dLe = torch.empty_like(Le)
+  lib = _lib.load()
+  with torch.cuda.device(Le.device):
+    _lib.check(lib.lnz_ada_lanczos_layer_f64_backward(_ptr(Le), B, N, K, _ptr(ws), _ptr(dT), _ptr(dQ),
+                                                      _ptr(dLe), _stream()))
+  return dLe
+
+
 def ada_t_powers(T, dist):
   """T [B,K,K] -> Tcat [B, K, S*K] = cat([T^p for p in dist], dim=2) (:262-270)."""
   _need_cuda(T)
