@@ -441,6 +441,21 @@ int lnz_split_f16x3(const float* X, int M, int K, int ldx, const float* bias, fl
  * same shapes) the reverse sweep of the recurrence -> dA [B,N,N] = dLoss/dA.  Replaces torch
  * autograd through model/ada_lanczos_net.py:139-247 (the reference differentiates its own loop of
  * small ATen ops).  mask may be NULL (all nodes real); masks / flags are constants of the gradient. */
+/* The stages either side of it for training, fp64 as well.  Learned Laplacian (:101-137) from the
+ * embedded node states X [B,N,D] fp32 and the adjacency mask L0 != 0 (strided [B,N,N] view):
+ * Le [B,N,N] fp64 + `state` (lnz_ada_laplacian_f64_state_doubles(B, N) doubles: A, dist2, D^-1/2,
+ * sigma2); backward: dLe -> dX [B,N,D] fp64.  T powers (:262-270) of the fp64 T: Tcat [B,K,S K] fp32
+ * as lnz_ada_t_powers + every power P [B,pmax,K,K] fp64; backward: dTcat (fp32) -> dT [B,K,K] fp64. */
+int64_t lnz_ada_laplacian_f64_state_doubles(int B, int N);
+int lnz_ada_graph_laplacian_f64(const float* X, int D, const float* L0, int64_t stride_b,
+                                int64_t stride_r, int64_t stride_c, int B, int N, double* Le,
+                                double* state, lnz_stream_t stream);
+int lnz_ada_graph_laplacian_f64_backward(const float* X, int D, int B, int N, const double* state,
+                                         const double* dLe, double* dX, lnz_stream_t stream);
+int lnz_ada_t_powers_f64(const double* T, int B, int K, const int32_t* dist_host, int S, float* Tcat,
+                         double* P, lnz_stream_t stream);
+int lnz_ada_t_powers_f64_backward(const double* T, int B, int K, const int32_t* dist_host, int S,
+                                  const float* dTcat, const double* P, double* dT, lnz_stream_t stream);
 int64_t lnz_ada_lanczos_f64_workspace_doubles(int B);
 int lnz_ada_lanczos_layer_f64(const double* A, const uint8_t* mask, const float* q1, int B, int N,
                               int K, double* T, double* Q, double* ws, lnz_stream_t stream);

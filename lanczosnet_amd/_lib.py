@@ -100,6 +100,11 @@ SIGNATURES = {
     'lnz_f16x3_linear': (C.c_int, [_P, _P, _I, _P, _P, _I, _P, C.c_float, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     'lnz_f16x3_linear_splits': (C.c_int, [_I, _I, _I]),
     'lnz_ada_lanczos_f64_workspace_doubles': (C.c_int64, [_I]),
+    'lnz_ada_laplacian_f64_state_doubles': (C.c_int64, [_I, _I]),
+    'lnz_ada_graph_laplacian_f64': (C.c_int, [_P, _I, _P, C.c_int64, C.c_int64, C.c_int64, _I, _I, _P, _P, _P]),
+    'lnz_ada_graph_laplacian_f64_backward': (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    'lnz_ada_t_powers_f64': (C.c_int, [_P, _I, _I, _P, _I, _P, _P, _P]),
+    'lnz_ada_t_powers_f64_backward': (C.c_int, [_P, _I, _I, _P, _I, _P, _P, _P, _P]),
     'lnz_ada_lanczos_layer_f64': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'lnz_ada_lanczos_layer_f64_backward': (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_f32_linear': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),

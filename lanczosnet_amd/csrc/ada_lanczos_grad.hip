@@ -281,7 +281,312 @@ __global__ __launch_bounds__(64) void ada_lanczos_f64_backward_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// R4 for training: the learned Laplacian (model/ada_lanczos_net.py:101-137) in fp64 and its
+// backward.  One workgroup per molecule.
+//   dist2_ij = |x_j - x_i|^2 ; sigma2 = mean over ALL N^2 pairs ; A = exp(-dist2 / sigma2) adj ;
+//   rs_i = sum_j A_ij ; g_i = (rs_i + [rs_i == 0])^-1/2 ; Le_ij = g_i A_ij g_j
+// backward, G = dLoss/dLe:
+//   dg_i = sum_j (G_ij A_ij + G_ji A_ji) g_j ; drs_i = -1/2 dg_i g_i^3 ; dA_ij = G_ij g_i g_j + drs_i
+//   ddist2_ij = -dA_ij A_ij / sigma2 + dsigma2 / N^2 ,  dsigma2 = sum_ij dA_ij A_ij dist2_ij / sigma2^2
+//   W = ddist2 + ddist2^T ;  dX = 2 (diag(W 1) - W) X
+// saved by the forward: A, dist2 [N,N], g [N], sigma2 (fp64).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ada_laplacian_f64_forward_kernel(
+    const float* __restrict__ X, int D, const float* __restrict__ L0, int64_t sb, int64_t sr,
+    int64_t sc, int N, double* __restrict__ Le, double* __restrict__ sv) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* xs = dsm;               // [N][D]
+  double* d2 = xs + N * D;        // [N][N] -> A
+  double* g = d2 + N * N;         // [N]
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < N * D; i += 256) xs[i] = (double)X[(int64_t)b * N * D + i];
+  __syncthreads();
+  double* sA = sv + (int64_t)b * (2 * N * N + N + 1);
+  double* sD2 = sA + N * N;
+  double* sG = sD2 + N * N;
+  double part = 0.0;
+  for (int p = tid; p < N * N; p += 256) {
+    const int i = p / N, j = p - i * N;
+    double s = 0.0;
+    for (int f = 0; f < D; ++f) {
+      const double df = xs[j * D + f] - xs[i * D + f];
+      s = fma(df, df, s);
+    }
+    d2[p] = s;
+    sD2[p] = s;
+    part += s;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  const double sigma2 = red[0] / (double)(N * N);
+  const float* Lb = L0 + (int64_t)b * sb;
+  for (int p = tid; p < N * N; p += 256) {
+    const int i = p / N, j = p - i * N;
+    const double adj = Lb[i * sr + j * sc] != 0.0f ? 1.0 : 0.0;
+    const double a = exp(-d2[p] / sigma2) * adj;
+    d2[p] = a;
+    sA[p] = a;
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    double rs = 0.0;
+    for (int j = 0; j < N; ++j) rs += d2[i * N + j];
+    const double gi = 1.0 / sqrt(rs + (rs == 0.0 ? 1.0 : 0.0));
+    g[i] = gi;
+    sG[i] = gi;
+  }
+  if (tid == 0) sG[N] = sigma2;
+  __syncthreads();
+  double* out = Le + (int64_t)b * N * N;
+  for (int p = tid; p < N * N; p += 256) {
+    const int i = p / N, j = p - i * N;
+    out[p] = (g[i] * d2[p]) * g[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void ada_laplacian_f64_backward_kernel(
+    const float* __restrict__ X, int D, int N, const double* __restrict__ sv,
+    const double* __restrict__ G, double* __restrict__ dX) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* xs = dsm;               // [N][D]
+  double* A = xs + N * D;         // [N][N]
+  double* dd = A + N * N;         // [N][N]: dA, then ddist2, then W
+  double* g = dd + N * N;         // [N]
+  double* aux = g + N;            // [N]: drs, then row sums of W
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double* sA = sv + (int64_t)b * (2 * N * N + N + 1);
+  const double* sD2 = sA + N * N;
+  const double* sG = sD2 + N * N;
+  const double* Gb = G + (int64_t)b * N * N;
+  for (int i = tid; i < N * D; i += 256) xs[i] = (double)X[(int64_t)b * N * D + i];
+  for (int p = tid; p < N * N; p += 256) A[p] = sA[p];
+  for (int i = tid; i < N; i += 256) g[i] = sG[i];
+  const double sigma2 = sG[N];
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    double dg = 0.0;
+    for (int j = 0; j < N; ++j) dg += (Gb[i * N + j] * A[i * N + j] + Gb[j * N + i] * A[j * N + i]) * g[j];
+    aux[i] = -0.5 * dg * g[i] * g[i] * g[i];
+  }
+  __syncthreads();
+  double part = 0.0;
+  for (int p = tid; p < N * N; p += 256) {
+    const int i = p / N, j = p - i * N;
+    const double dA = Gb[p] * g[i] * g[j] + aux[i];
+    dd[p] = dA;
+    part += dA * A[p] * sD2[p];
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  const double dsig = red[0] / (sigma2 * sigma2) / (double)(N * N);
+  for (int p = tid; p < N * N; p += 256) dd[p] = -dd[p] * A[p] / sigma2 + dsig;
+  __syncthreads();
+  // W = dd + dd^T (in A: no longer needed), its row sums
+  for (int p = tid; p < N * N; p += 256) {
+    const int i = p / N, j = p - i * N;
+    A[p] = dd[p] + dd[j * N + i];
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += 256) {
+    double r = 0.0;
+    for (int j = 0; j < N; ++j) r += A[i * N + j];
+    aux[i] = r;
+  }
+  __syncthreads();
+  double* out = dX + (int64_t)b * N * D;
+  for (int e = tid; e < N * D; e += 256) {
+    const int k = e / D, f = e - k * D;
+    double acc = xs[e] * aux[k];
+    for (int i = 0; i < N; ++i) acc -= A[k * N + i] * xs[i * D + f];
+    out[e] = 2.0 * acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// T powers (model/ada_lanczos_net.py:262-270) of an fp64 T, keeping every power for the backward:
+//   P_1 = T, P_i = P_{i-1} T ; Tcat[b][r][s K + c] = (float) P_{p_s}[r][c]
+// backward: R_i = dLoss/dP_i; for i = pmax .. 2: R_{i-1} += R_i T^T, dT += P_{i-1}^T R_i; dT += R_1.
+// ---------------------------------------------------------------------------------------------
+struct PowArr64 {
+  int32_t v[16];
+};
+
+__global__ __launch_bounds__(256) void ada_t_powers_f64_forward_kernel(
+    const double* __restrict__ T, int K, PowArr64 dist, int S, int pmax, float* __restrict__ Tcat,
+    double* __restrict__ P) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* Ts = dsm;
+  double* TT = Ts + K * K;
+  double* TN = TT + K * K;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < K * K; i += 256) {
+    const double v = T[(int64_t)b * K * K + i];
+    Ts[i] = v;
+    TT[i] = v;
+  }
+  __syncthreads();
+  float* out = Tcat + (int64_t)b * K * S * K;
+  double* Pb = P + (int64_t)b * pmax * K * K;
+  for (int ii = 1; ii <= pmax; ++ii) {
+    for (int i = tid; i < K * K; i += 256) Pb[(int64_t)(ii - 1) * K * K + i] = TT[i];
+    for (int s = 0; s < S; ++s) {
+      if (dist.v[s] == ii) {
+        for (int i = tid; i < K * K; i += 256) {
+          const int r = i / K, c = i - r * K;
+          out[(int64_t)r * S * K + s * K + c] = (float)TT[i];
+        }
+      }
+    }
+    if (ii == pmax) break;
+    for (int i = tid; i < K * K; i += 256) {
+      const int r = i / K, c = i - r * K;
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) acc = fma(TT[r * K + k], Ts[k * K + c], acc);
+      TN[i] = acc;
+    }
+    __syncthreads();
+    double* t = TT;
+    TT = TN;
+    TN = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void ada_t_powers_f64_backward_kernel(
+    const double* __restrict__ T, int K, PowArr64 dist, int S, int pmax,
+    const float* __restrict__ dTcat, const double* __restrict__ P, double* __restrict__ dT) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  double* Ts = dsm;             // T
+  double* R = Ts + K * K;       // R_i
+  double* RN = R + K * K;       // R_{i-1}
+  double* Pm = RN + K * K;      // P_{i-1}
+  double* acc = Pm + K * K;     // dT
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* gin = dTcat + (int64_t)b * K * S * K;
+  const double* Pb = P + (int64_t)b * pmax * K * K;
+  for (int i = tid; i < K * K; i += 256) {
+    Ts[i] = T[(int64_t)b * K * K + i];
+    R[i] = 0.0;
+    acc[i] = 0.0;
+  }
+  __syncthreads();
+  for (int ii = pmax; ii >= 1; --ii) {
+    for (int s = 0; s < S; ++s) {
+      if (dist.v[s] == ii) {
+        for (int i = tid; i < K * K; i += 256) {
+          const int r = i / K, c = i - r * K;
+          R[i] += (double)gin[(int64_t)r * S * K + s * K + c];
+        }
+      }
+    }
+    if (ii == 1) break;
+    for (int i = tid; i < K * K; i += 256) Pm[i] = Pb[(int64_t)(ii - 2) * K * K + i];
+    __syncthreads();
+    for (int i = tid; i < K * K; i += 256) {
+      const int r = i / K, c = i - r * K;
+      double a = 0.0, d = 0.0;
+      for (int k = 0; k < K; ++k) {
+        a = fma(R[r * K + k], Ts[c * K + k], a);     // (R_i T^T)[r][c]
+        d = fma(Pm[k * K + r], R[k * K + c], d);     // (P_{i-1}^T R_i)[r][c]
+      }
+      RN[i] = a;
+      acc[i] += d;
+    }
+    __syncthreads();
+    double* t = R;
+    R = RN;
+    RN = t;
+  }
+  __syncthreads();
+  for (int i = tid; i < K * K; i += 256) dT[(int64_t)b * K * K + i] = acc[i] + R[i];
+}
+
 }  // namespace
+
+static int pow_args(const int32_t* dist_host, int S, PowArr64* d) {
+  int pmax = 0;
+  for (int i = 0; i < 16; ++i) {
+    d->v[i] = i < S ? dist_host[i] : -1;
+    if (i < S && dist_host[i] > pmax) pmax = dist_host[i];
+  }
+  return pmax;
+}
+
+extern "C" int64_t lnz_ada_laplacian_f64_state_doubles(int B, int N) {
+  return (int64_t)(B > 0 ? B : 0) * (2 * (int64_t)N * N + N + 1);
+}
+
+extern "C" int lnz_ada_graph_laplacian_f64(const float* X, int D, const float* L0, int64_t stride_b,
+                                           int64_t stride_r, int64_t stride_c, int B, int N,
+                                           double* Le, double* state, lnz_stream_t stream) {
+  LNZ_REQUIRE(X && L0 && Le && state && B > 0 && N > 0 && D > 0, LNZ_EINVAL,
+              "lnz_ada_graph_laplacian_f64: bad arguments (B=%d N=%d D=%d)", B, N, D);
+  const size_t lds = ((size_t)N * D + (size_t)N * N + N) * sizeof(double);
+  LNZ_REQUIRE(lds <= 96 * 1024, LNZ_ENOTSUP, "lnz_ada_graph_laplacian_f64: N=%d, D=%d too large", N, D);
+  (void)hipFuncSetAttribute((const void*)ada_laplacian_f64_forward_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ada_laplacian_f64_forward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, X, D,
+                     L0, stride_b, stride_r, stride_c, N, Le, state);
+  return lnz::check_launch("lnz_ada_graph_laplacian_f64");
+}
+
+extern "C" int lnz_ada_graph_laplacian_f64_backward(const float* X, int D, int B, int N,
+                                                    const double* state, const double* dLe, double* dX,
+                                                    lnz_stream_t stream) {
+  LNZ_REQUIRE(X && state && dLe && dX && B > 0 && N > 0 && D > 0, LNZ_EINVAL,
+              "lnz_ada_graph_laplacian_f64_backward: bad arguments (B=%d N=%d D=%d)", B, N, D);
+  const size_t lds = ((size_t)N * D + 2 * (size_t)N * N + 2 * N) * sizeof(double);
+  LNZ_REQUIRE(lds <= 96 * 1024, LNZ_ENOTSUP, "lnz_ada_graph_laplacian_f64_backward: N=%d, D=%d too large",
+              N, D);
+  (void)hipFuncSetAttribute((const void*)ada_laplacian_f64_backward_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ada_laplacian_f64_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, X, D,
+                     N, state, dLe, dX);
+  return lnz::check_launch("lnz_ada_graph_laplacian_f64_backward");
+}
+
+extern "C" int lnz_ada_t_powers_f64(const double* T, int B, int K, const int32_t* dist_host, int S,
+                                    float* Tcat, double* P, lnz_stream_t stream) {
+  LNZ_REQUIRE(T && dist_host && Tcat && P && B > 0 && K > 0 && S > 0, LNZ_EINVAL,
+              "lnz_ada_t_powers_f64: bad arguments");
+  LNZ_REQUIRE(S <= 16 && K <= 64, LNZ_ENOTSUP, "lnz_ada_t_powers_f64: S=%d K=%d out of range", S, K);
+  PowArr64 d;
+  const int pmax = pow_args(dist_host, S, &d);
+  LNZ_REQUIRE(pmax >= 1 && pmax <= 4096, LNZ_EINVAL, "lnz_ada_t_powers_f64: bad exponents");
+  const size_t lds = (size_t)3 * K * K * sizeof(double);
+  (void)hipFuncSetAttribute((const void*)ada_t_powers_f64_forward_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ada_t_powers_f64_forward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, K, d,
+                     S, pmax, Tcat, P);
+  return lnz::check_launch("lnz_ada_t_powers_f64");
+}
+
+extern "C" int lnz_ada_t_powers_f64_backward(const double* T, int B, int K, const int32_t* dist_host,
+                                             int S, const float* dTcat, const double* P, double* dT,
+                                             lnz_stream_t stream) {
+  LNZ_REQUIRE(T && dist_host && dTcat && P && dT && B > 0 && K > 0 && S > 0, LNZ_EINVAL,
+              "lnz_ada_t_powers_f64_backward: bad arguments");
+  LNZ_REQUIRE(S <= 16 && K <= 64, LNZ_ENOTSUP, "lnz_ada_t_powers_f64_backward: S=%d K=%d out of range", S, K);
+  PowArr64 d;
+  const int pmax = pow_args(dist_host, S, &d);
+  LNZ_REQUIRE(pmax >= 1 && pmax <= 4096, LNZ_EINVAL, "lnz_ada_t_powers_f64_backward: bad exponents");
+  const size_t lds = (size_t)5 * K * K * sizeof(double);
+  (void)hipFuncSetAttribute((const void*)ada_t_powers_f64_backward_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(ada_t_powers_f64_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, K, d,
+                     S, pmax, dTcat, P, dT);
+  return lnz::check_launch("lnz_ada_t_powers_f64_backward");
+}
 
 extern "C" int64_t lnz_ada_lanczos_f64_workspace_doubles(int B) {
   return (int64_t)(B > 0 ? B : 0) * WS_TOTAL;

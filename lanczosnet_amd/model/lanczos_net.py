@@ -1240,9 +1240,9 @@ class AdaLanczosNet(_LanczosNetBase):
 class _AdaLanczosNetFusedFunction(torch.autograd.Function):
     """AdaLanczosNet training through the HIP kernels.
 
-    forward: the learned Laplacian and the T powers as fp64 torch graphs (kept for the backward), the
-    Lanczos layer between them by lnz_ada_lanczos_layer_f64 ON THE FP64 LAPLACIAN with the state
-    its backward needs (the inference kernels of these stages work from the fp32 Laplacian like
+    forward: learned Laplacian, Lanczos layer and T powers by their fp64 training kernels
+    (lnz_ada_graph_laplacian_f64, lnz_ada_lanczos_layer_f64, lnz_ada_t_powers_f64: each keeps the
+    state its backward needs; the inference kernels of these stages work from the fp32 Laplacian like
     the reference's fp32 run, and a basis that differs by the Lanczos recurrence's amplification
     of that rounding — 2.5e-5 on the test batch — would put the same 1e-5 between the filter
     gradients and the reference's float64 ones); filter MLPs (hidden activations kept where the
@@ -1257,10 +1257,10 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         as batched library GEMMs on [B, K, .] blocks;
       * filter MLPs (model/ada_lanczos_net.py:271-278): plain GEMMs on the stored activations (the
         reference's unfolded weights), symmetrisation 0.5 (DD + DD^T) transposed onto dDD;
-      * T powers: autograd through the forward's graph -> dT; Lanczos layer (:139-247):
+      * T powers (lnz_ada_t_powers_f64_backward) -> dT; Lanczos layer (:139-247):
         lnz_ada_lanczos_layer_f64_backward, the reverse sweep of the recurrence as one launch
-        (dT, dQ) -> dLe; learned Laplacian + embedding: autograd through the forward's graph,
-        fed (dX_0, dLe)."""
+        (dT, dQ) -> dLe; learned Laplacian (lnz_ada_graph_laplacian_f64_backward) -> dX, added to
+        the conv stack's dX_0; embedding rows by a one-hot GEMM."""
 
     @staticmethod
     def forward(ctx, module, node_feat, L, mask, q1, *params):
@@ -1270,18 +1270,14 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         K = m.num_eig_vec
         Lf = L if L.dtype == torch.float32 else L.float()
         mask_u8 = mask.to(torch.uint8).contiguous()
-        # learned Laplacian and T powers: fp64 torch graphs (kept for the backward); the Lanczos
-        # layer between them: lnz_ada_lanczos_layer_f64 on the fp64 Laplacian, its state kept for
-        # lnz_ada_lanczos_layer_f64_backward
-        with torch.enable_grad():
-            state, Le = m._torch_ada_laplacian(node_feat, L)
-        Le_d = Le.detach().contiguous()
-        T64, Q64, lws = ops.ada_lanczos_layer_f64(Le_d, mask, q1, K)
-        T64.requires_grad_(True)
-        with torch.enable_grad():
-            tc = m._torch_ada_powers(T64)
-        tcat, Q = tc.detach(), Q64.float().contiguous()
-        spectrum = (state, Le, T64, tc, Le_d, lws)
+        # learned Laplacian -> Lanczos layer -> T powers, all fp64 (csrc/ada_lanczos_grad.hip), each
+        # keeping the state its backward kernel needs
+        state = m.embedding(node_feat)
+        Le, lap_saved = ops.ada_graph_laplacian_f64(state, Lf[:, :, :, 0])
+        T64, Q64, lws = ops.ada_lanczos_layer_f64(Le, mask, q1, K)
+        tcat3, pow_saved = ops.ada_t_powers_f64(T64, m.long_diffusion_dist)
+        tcat, Q = tcat3.view(B, -1), Q64.float().contiguous()
+        spectrum = (lap_saved, Le, lws, pow_saved)
         keep = []
         DDp = m._ada_dense_filters(plan, tcat, keep=keep)
         Lp = ops.pack_laplacian(Lf)
@@ -1381,15 +1377,15 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         if dbg:
             m._dbg = dict(dDDp=dDDp, dQ=dQ, dtcat=dtcat, dx0=dx0[:, :N, :din0].clone(), Q=Q, DDp=DDp,
                           tcat=tcat, act=act, dy=dy)
-        # ---- T powers (autograd through the forward's fp64 graph) -> Lanczos layer (the HIP reverse
-        #      sweep) -> learned Laplacian + embedding (autograd through the forward's graph)
-        st, Le, T64, tc, Le_d, lws = ctx.spectrum
+        # ---- T powers -> Lanczos layer (the reverse sweep of the recurrence) -> learned Laplacian:
+        #      three fp64 launches; then the embedding rows (one-hot^T dX as a GEMM, like LanczosNet)
+        lap_saved, Le, lws, pow_saved = ctx.spectrum
         ctx.spectrum = None
-        dT, = torch.autograd.grad([tc], [T64], [dtcat])
-        dLe = ops.ada_lanczos_layer_f64_backward(Le_d, lws, dT, dQ.double())
-        ge, = torch.autograd.grad([st, Le], [m.embedding.weight],
-                                  [dx0[:, :N, :din0].contiguous(), dLe])
-        grads[id(m.embedding.weight)] = ge
+        dT = ops.ada_t_powers_f64_backward(pow_saved, dtcat)
+        dLe = ops.ada_lanczos_layer_f64_backward(Le, lws, dT, dQ.double())
+        dstate = dx0[:, :N, :din0] + ops.ada_graph_laplacian_f64_backward(lap_saved, dLe).float()
+        onehot = torch.nn.functional.one_hot(node_feat.reshape(-1), m.num_atom).to(torch.float32)
+        grads[id(m.embedding.weight)] = onehot.t() @ dstate.reshape(-1, din0)
         mark('spectrum')
         if dbg:
             m._dbg['marks'] = marks

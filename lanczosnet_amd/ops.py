@@ -925,6 +925,70 @@ def ada_lanczos_layer_f64_backward(Le, ws, dT, dQ):
   return dLe
 
 
+def ada_graph_laplacian_f64(state, L0):
+  """lnz_ada_graph_laplacian_f64: learned Laplacian in fp64 from the embedded node states
+  [B,N,D] fp32 and the adjacency mask L0 != 0 ([B,N,N] view, any strides).  Returns (Le [B,N,N]
+  fp64, saved state for ada_graph_laplacian_f64_backward)."""
+  _need_cuda(state, L0)
+  X = _f32c(state)
+  B, N, D = X.shape
+  assert L0.dtype == torch.float32 and tuple(L0.shape) == (B, N, N)
+  lib = _lib.load()
+  Le = torch.empty((B, N, N), dtype=torch.float64, device=X.device)
+  sv = torch.empty((int(lib.lnz_ada_laplacian_f64_state_doubles(B, N)),), dtype=torch.float64,
+                   device=X.device)
+  with torch.cuda.device(X.device):
+    _lib.check(lib.lnz_ada_graph_laplacian_f64(_ptr(X), D, _ptr(L0), L0.stride(0), L0.stride(1),
+                                               L0.stride(2), B, N, _ptr(Le), _ptr(sv), _stream()))
+  return Le, (X, sv)
+
+
+def ada_graph_laplacian_f64_backward(saved, dLe):
+  """dLoss/dstate [B,N,D] fp64 from dLoss/dLe [B,N,N] fp64."""
+  X, sv = saved
+  _need_cuda(X, sv, dLe)
+  B, N, D = X.shape
+  dLe = dLe.to(torch.float64).contiguous()
+  dX = torch.empty((B, N, D), dtype=torch.float64, device=X.device)
+  lib = _lib.load()
+  with torch.cuda.device(X.device):
+    _lib.check(lib.lnz_ada_graph_laplacian_f64_backward(_ptr(X), D, B, N, _ptr(sv), _ptr(dLe), _ptr(dX),
+                                                        _stream()))
+  return dX
+
+
+def ada_t_powers_f64(T, dist):
+  """lnz_ada_t_powers_f64: T [B,K,K] fp64 -> (Tcat [B, K, S*K] fp32, saved powers)."""
+  _need_cuda(T)
+  assert T.dtype == torch.float64 and T.is_contiguous()
+  B, K, _ = T.shape
+  S = len(dist)
+  pmax = max(int(x) for x in dist)
+  out = torch.empty((B, K, S * K), dtype=torch.float32, device=T.device)
+  P = torch.empty((B, pmax, K, K), dtype=torch.float64, device=T.device)
+  darr = (C.c_int32 * S)(*[int(x) for x in dist])
+  lib = _lib.load()
+  with torch.cuda.device(T.device):
+    _lib.check(lib.lnz_ada_t_powers_f64(_ptr(T), B, K, darr, S, _ptr(out), _ptr(P), _stream()))
+  return out, (T, P, tuple(int(x) for x in dist))
+
+
+def ada_t_powers_f64_backward(saved, dTcat):
+  """dLoss/dT [B,K,K] fp64 from dLoss/dTcat [B, K, S*K] (or [B, K*S*K]) fp32."""
+  T, P, dist = saved
+  _need_cuda(T, P, dTcat)
+  B, K, _ = T.shape
+  S = len(dist)
+  g = _f32c(dTcat).reshape(B, K, S * K)
+  dT = torch.empty_like(T)
+  darr = (C.c_int32 * S)(*dist)
+  lib = _lib.load()
+  with torch.cuda.device(T.device):
+    _lib.check(lib.lnz_ada_t_powers_f64_backward(_ptr(T), B, K, darr, S, _ptr(g), _ptr(P), _ptr(dT),
+                                                 _stream()))
+  return dT
+
+
 def ada_t_powers(T, dist):
   """T [B,K,K] -> Tcat [B, K, S*K] = cat([T^p for p in dist], dim=2) (:262-270)."""
   _need_cuda(T)

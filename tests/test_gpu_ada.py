@@ -657,3 +657,59 @@ def test_ada_lanczos_layer_f64_forward_and_backward_match_torch_autograd(B, nmin
   err = float((got - want).abs().max()) / scale
   print('Lanczos layer backward: B=%d N=%d max dev %.2e of the largest entry' % (B, N, err))
   assert err < 1e-9
+
+
+@pytest.mark.parametrize('B,nmin,nmax', [(48, 8, 26), (3, 3, 6)])
+def test_ada_laplacian_and_t_powers_f64_match_torch_autograd(B, nmin, nmax):
+  """The other two fp64 stages of the training step — learned Laplacian
+  (lnz_ada_graph_laplacian_f64 / _backward) and T powers (lnz_ada_t_powers_f64 / _backward) —
+  against the torch restatements `_torch_ada_laplacian`, `_torch_ada_powers` and autograd through
+  them (random upstream gradients): forward 1e-12 / fp32 rounding of the output, gradients 1e-10."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import AdaLanczosNet
+  from lanczosnet_amd.synthetic import draw_batch
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3],
+             long_diffusion_dist=[5, 7, 10, 20, 30], hidden_dim=[128, 128], num_layer=2)
+  torch.manual_seed(4)
+  net = AdaLanczosNet(make_model_config(cfg, name='AdaLanczosNet')).to(DEV)
+  b = draw_batch(B, seed=B, n_min=nmin, n_max=nmax)
+  L = ops.laplacian_l4(_t(b['adjs']), _t(b['n_nodes']))
+  nf = _t(b['node_feat'])
+  # ---- learned Laplacian
+  emb = net.embedding.weight.detach().clone().requires_grad_(True)
+  with torch.no_grad():
+    net.embedding.weight.copy_(emb)
+  state_t, Le_t = net._torch_ada_laplacian(nf, L)
+  Le_h, saved = ops.ada_graph_laplacian_f64(state_t.detach(), L[:, :, :, 0])
+  assert (Le_h - Le_t).abs().max() < 1e-12
+  gL = torch.randn_like(Le_t)
+  want, = torch.autograd.grad([Le_t], [state_t], [gL])
+  got = ops.ada_graph_laplacian_f64_backward(saved, gL)
+  e1 = float((got - want.double()).abs().max() / want.abs().max())
+  # (autograd returns the gradient in the state's fp32: compare at its rounding)
+  assert e1 < 5e-7, e1
+  # ... and exactly, against an fp64 state
+  st64 = state_t.detach().double().requires_grad_(True)
+  adj = (L[:, :, :, 0] != 0).double()
+  diff = st64.unsqueeze(1) - st64.unsqueeze(2)
+  dist2 = (diff * diff).sum(dim=3)
+  sigma2 = dist2.reshape(B, -1).mean(dim=1).view(B, 1, 1)
+  A = torch.exp(-dist2 / sigma2) * adj
+  rs = A.sum(dim=2, keepdim=True)
+  Dg = 1.0 / (rs + (rs == 0).double()).pow(0.5)
+  want64, = torch.autograd.grad([Dg * A * Dg.transpose(1, 2)], [st64], [gL])
+  e1b = float((got - want64).abs().max() / want64.abs().max())
+  assert e1b < 1e-10, e1b
+  # ---- T powers
+  T = torch.randn(B, 20, 20, dtype=torch.float64, device=DEV)
+  T = ((T + T.transpose(1, 2)) * 0.08).contiguous().requires_grad_(True)
+  tc_t = net._torch_ada_powers(T)
+  tc_h, savedp = ops.ada_t_powers_f64(T.detach(), net.long_diffusion_dist)
+  assert (tc_h.view(B, -1) - tc_t).abs().max() <= 1e-6 * float(tc_t.abs().max())
+  gT = torch.randn_like(tc_t)
+  wantT, = torch.autograd.grad([tc_t], [T], [gT])
+  gotT = ops.ada_t_powers_f64_backward(savedp, gT)
+  e2 = float((gotT - wantT).abs().max() / wantT.abs().max())
+  print('fp64 stages: Laplacian backward %.2e (vs fp64 autograd %.2e), T powers backward %.2e' % (e1, e1b, e2))
+  assert e2 < 1e-10, e2
