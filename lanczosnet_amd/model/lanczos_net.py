@@ -928,6 +928,7 @@ class AdaLanczosNet(_LanczosNetBase):
         eigen-space kernel (not LNZ_DENSE_FILTER_NODE_SPACE=1) and the reference's 4-Linear filter
         MLPs."""
         return (self._fused_supported() and self.hidden_dim[0] == 128 and self.backward_impl == 'hip'
+                and self.num_eig_vec <= 32 and len(self.long_diffusion_dist) <= 16
                 and ops.pairing_supported({'filter_kind': 1}) and
                 all(len(seq) == 7 and all(isinstance(seq[i], nn.Linear) for i in (0, 2, 4, 6))
                     for seq in self.spectral_filter))
