@@ -1330,26 +1330,37 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
                                                   ctx.rtot_ready)
         mark('conv_stack')
 
-        # ---- dense filters and Lanczos basis
+        # ---- dense filters and Lanczos basis.  Layers of one input width go through the batched
+        #      GEMMs TOGETHER (layers 1 .. L-1 share d = dh: 18 launches instead of 56)
         Qt = Q.transpose(1, 2)
-        DDk = DDp.permute(0, 1, 3, 2, 4).reshape(Lnum, B, K, S * K)     # [l][b][k][(s, j)]
         dDDp = torch.empty_like(DDp)
         dQ = torch.zeros_like(Q)
-        for la in range(Lnum):
-            d = din0 if la == 0 else dh
-            X = x0[:, :N, :din0] if la == 0 else act[la - 1][:, :N]
-            dYl = dy[la][:, :N]
-            Wl = m._mix_weight(la).detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]  # [o,s,i]
-            Yq = torch.bmm(Qt, X)                                               # [B,K,d]
-            Cq = torch.bmm(Qt, dYl)                                             # [B,K,dh]
-            Bq = (Yq.reshape(B * K, d) @ Wl.permute(2, 1, 0).reshape(d, S * dh)).view(B, K, S, dh)
-            CW = (Cq.reshape(B * K, dh) @ Wl.reshape(dh, S * d)).view(B, K, S, d)
+
+        def filters_basis(layers, X, dYl, d):
+            # X [G,B,N,d], dYl [G,B,N,dh] for the G conv layers `layers`
+            G = len(layers)
+            Wl = torch.stack([m._mix_weight(la).detach().view(dh, n_chan, d)[:, n_short:n_short + S, :]
+                              for la in layers])                                  # [G, o, s, i]
+            DDk = torch.stack([DDp[la] for la in layers]).permute(0, 1, 3, 2, 4).reshape(G * B, K, S * K)
+            Qg = Qt.unsqueeze(0).expand(G, B, K, N).reshape(G * B, K, N)
+            Yq = torch.bmm(Qg, X.reshape(G * B, N, d))                            # [GB,K,d]
+            Cq = torch.bmm(Qg, dYl.reshape(G * B, N, dh))                         # [GB,K,dh]
+            Bq = torch.bmm(Yq.view(G, B * K, d), Wl.permute(0, 3, 2, 1).reshape(G, d, S * dh))
+            CW = torch.bmm(Cq.view(G, B * K, dh), Wl.reshape(G, dh, S * d))
             # dDD[b,s,k,j] = sum_o Cq[b,k,o] Bq[b,j,s,o]
-            Bs = Bq.permute(0, 2, 1, 3).reshape(B, S * K, dh)                   # rows (s, j)
-            dDDp[la] = torch.bmm(Cq, Bs.transpose(1, 2)).view(B, K, S, K).permute(0, 2, 1, 3)
-            A = torch.bmm(DDk[la], Bs)                                          # [B,K,dh]
-            E = torch.bmm(DDk[la], CW.permute(0, 2, 1, 3).reshape(B, S * K, d)) # [B,K,d]
-            dQ += torch.bmm(dYl, A.transpose(1, 2)) + torch.bmm(X, E.transpose(1, 2))
+            Bs = Bq.view(G * B, K, S, dh).permute(0, 2, 1, 3).reshape(G * B, S * K, dh)   # rows (s, j)
+            dd = torch.bmm(Cq, Bs.transpose(1, 2)).view(G, B, K, S, K).permute(0, 1, 3, 2, 4)
+            for g, la in enumerate(layers):
+                dDDp[la] = dd[g]
+            A = torch.bmm(DDk, Bs)                                                # [GB,K,dh]
+            E = torch.bmm(DDk, CW.view(G * B, K, S, d).permute(0, 2, 1, 3).reshape(G * B, S * K, d))
+            t = torch.bmm(dYl.reshape(G * B, N, dh), A.transpose(1, 2)) + \
+                torch.bmm(X.reshape(G * B, N, d), E.transpose(1, 2))
+            return t.view(G, B, N, K).sum(dim=0)
+
+        dQ += filters_basis([0], x0[:, :N, :din0].unsqueeze(0), dy[0][:, :N].unsqueeze(0), din0)
+        if Lnum > 1:
+            dQ += filters_basis(list(range(1, Lnum)), act[:Lnum - 1, :, :N], dy[1:, :, :N], dh)
 
         mark('filters_basis')
         # ---- filter MLPs: DD = 0.5 (raw + raw^T) with raw = MLP(tcat).view(B, K, K, S)
