@@ -1035,6 +1035,15 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_forward_kernel(const lnz
 // channel's GEMM1 runs on Y with the FORWARD weight pack and its result is multiplied with P and
 // reduced over the wave's 32 output columns (lane shuffles) and over the NWV waves (LDS, fixed
 // order: deterministic).  No gains, Laplacians or activations other than X_l / dY_l are read.
+// sum over the 16 lanes of a DPP row, in every lane of the row (quad swaps, then the two mirrors)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
 template <int NWV, int MT>
 __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT],
                                                float (*Xs)[2][32][PITCH], float (*Vm)[32][VPITCH],
@@ -1119,9 +1128,15 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[la]);
     const float4* __restrict__ wp =
         Wl + ((int64_t)wave * (C * Q) + (int64_t)a.n_short * Q) * 64 + lane;
-    float4 ring[4];
+    // weight stream of the layer's S long channels (contiguous in the pack) through a register ring:
+    // 8 slots / distance 7 where a channel has a multiple of 8 k-steps (every layer of the QM8
+    // model), like the forward's GEMM1 — with the 4-slot ring (distance 3: 3 x 4 MFMAs of cover per
+    // tile) the loop ran at the L2 latency: 0.73 ms for the launch against 0.13 ms of MFMA time
+    float4 ring[8];
+    const bool deep = (Q & 7) == 0;
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) ring[sl] = wp[sl * 64];
+    for (int sl = 0; sl < 7; ++sl)
+      if (sl < 3 || deep) ring[sl] = wp[sl * 64];
     lds_cptr yrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) yrow[m] = (lds_cptr)&Xs[0][m][j][4 * hh];
@@ -1135,57 +1150,63 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
         xq[m] = yrow[m];
         acur[m] = lds_f4(xq[m]);
       }
+      auto steps = [&](auto depth) {
+        constexpr int RD = decltype(depth)::value;
 #pragma unroll 1
-      for (int q0 = 0; q0 < Q; q0 += 4) {
+        for (int q0 = 0; q0 < Q; q0 += RD) {
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-          ring[(u4 + 3) & 3] = wp[(u4 + 3) * 64];
-          float4 anext[MT];
+          for (int u4 = 0; u4 < RD; ++u4) {
+            ring[(u4 + RD - 1) & (RD - 1)] = wp[(u4 + RD - 1) * 64];
+            float4 anext[MT];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) anext[m] = lds_f4(xq[m] + 8 * (u4 + 1));
-          const float4 bv = ring[u4];
+            for (int m = 0; m < MT; ++m) anext[m] = lds_f4(xq[m] + 8 * (u4 + 1));
+            const float4 bv = ring[u4];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].x, bv.x, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].y, bv.y, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].z, bv.z, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
+            for (int m = 0; m < MT; ++m) Z[m] = lnz::mfma32(acur[m].w, bv.w, Z[m]);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acur[m] = anext[m];
-          // one load between pairs of MFMAs (see forward_half's GEMM1)
-          if (MT == 2) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int m = 0; m < MT; ++m) acur[m] = anext[m];
+            // one load between pairs of MFMAs (see forward_half's GEMM1)
+            if (MT == 2) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            } else {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
           }
-        }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) xq[m] += 32;
-        wp += 4 * 64;
-      }
-      // partial[rho] over the 32 lanes of a half-wave; the dY buffer (free since the projection)
-      // collects [wave][s][rho] per tile
+          for (int m = 0; m < MT; ++m) xq[m] += 8 * RD;
+          wp += RD * 64;
+        }
+      };
+      if (deep) steps(std::integral_constant<int, 8>{});
+      else steps(std::integral_constant<int, 4>{});
+      // partial[rho] over the 16 lanes of a DPP row (four row-local DPP adds — the __shfl_xor
+      // butterfly over 32 lanes compiled to five ds_bpermute_b32 per value, 276 in the kernel, and
+      // made the LDS crossbar the launch's bottleneck); the dY buffer (free since the projection)
+      // collects [wave][lane row within the half][s][rho] per tile
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         float* red = &Xs[1][m][0][0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = Pb[m][r] * Z[m][r];
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-          if (j == 0) red[(wave * S + s) * 32 + lnz::cd_row(r, hh)] = v;
+          const float v = row16_sum(Pb[m][r] * Z[m][r]);
+          if ((lane & 15) == 0)
+            red[((wave * 2 + ((lane >> 4) & 1)) * S + s) * 32 + lnz::cd_row(r, hh)] = v;
         }
       }
     }
@@ -1202,7 +1223,7 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
       if (mol >= 0 && k < K) {
         const float* red = &Xs[1][m][0][0];
         float v = 0.0f;
-        for (int w = 0; w < NWV; ++w) v += red[(w * S + s) * 32 + rho];
+        for (int w = 0; w < 2 * NWV; ++w) v += red[(w * S + s) * 32 + rho];
         a.dgains[(((int64_t)la * B + mol) * K + k) * S + s] = v;
       }
     }
@@ -1389,8 +1410,8 @@ extern "C" int lnz_lanczosnet_gain_grad(const lnz_forward_args* args, lnz_stream
               LNZ_EINVAL, "%s: null tensor pointer (mask, V, Wp, dy, x0, act, dgains)", who);
   LNZ_REQUIRE(!a.plan || (a.n_wg && a.plan_wg_cap > 0), LNZ_EINVAL,
               "%s: plan without n_wg / plan_wg_cap", who);
-  // [wave][s][32] partial sums of a tile live in its 32 x PITCH dY buffer
-  LNZ_REQUIRE(4 * a.n_long * 32 <= 32 * PITCH, LNZ_ENOTSUP, "%s: too many long channels", who);
+  // [wave][lane row][s][32] partial sums of a tile live in its 32 x PITCH dY buffer
+  LNZ_REQUIRE(8 * a.n_long * 32 <= 32 * PITCH, LNZ_ENOTSUP, "%s: too many long channels", who);
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;
   hipLaunchKernelGGL(lanczosnet_gain_grad_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   return lnz::check_launch(who);
