@@ -1044,7 +1044,10 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int NWV, int MT>
+// DEEP: the weight-ring depth as a template constant (1: 8 slots — every layer's channels have a
+// multiple of 8 k-steps —, 0: 4 slots): with both ring loops in one kernel their rings get
+// different registers and the join behind every channel drains the prefetch (see forward_half).
+template <int NWV, int MT, int DEEP>
 __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT],
                                                float (*Xs)[2][32][PITCH], float (*Vm)[32][VPITCH],
                                                const int htid, const int wave) {
@@ -1072,24 +1075,41 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
     {
       const float* xsrc = la == 0 ? a.x0 : a.act + (int64_t)(la - 1) * B * 32 * dhid;
       const int d4 = din >> 2, e4 = dhid >> 2;
-      for (int idx = htid; idx < MT * 32 * (d4 + e4); idx += 64 * NWV) {
-        const int m = idx / (32 * (d4 + e4));
-        const int rem = idx - m * 32 * (d4 + e4);
-        const int row = rem / (d4 + e4), c = rem - row * (d4 + e4);
-        const TileDesc t = pick(td, m);
-        const bool first = row < t.split;
-        const int mol = first ? t.ta : t.tb;
-        const int lrow = first ? row : row - t.split;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < d4) {
-          if (mol >= 0) v = reinterpret_cast<const float4*>(xsrc + ((int64_t)mol * 32 + lrow) * din)[c];
-          *reinterpret_cast<float4*>(&Xs[0][m][row][4 * c]) = v;
-        } else {
-          if (mol >= 0)
-            v = reinterpret_cast<const float4*>(
-                a.dy + (((int64_t)la * B + mol) * 32 + lrow) * dhid)[c - d4];
-          *reinterpret_cast<float4*>(&Xs[1][m][row][4 * (c - d4)]) = v;
+      const int total = MT * 32 * (d4 + e4);
+      // four loads in flight per thread: with one load -> one LDS store per trip every trip waited
+      // out a global round trip (8-16 trips per layer)
+      constexpr int UN = 4;
+      for (int base = htid; base < total; base += 64 * NWV * UN) {
+        float4 v[UN];
+        float* dst[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int idx = base + u * 64 * NWV;
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[u] = nullptr;
+          if (idx < total) {
+            const int m = idx / (32 * (d4 + e4));
+            const int rem = idx - m * 32 * (d4 + e4);
+            const int row = rem / (d4 + e4), c = rem - row * (d4 + e4);
+            const TileDesc t = pick(td, m);
+            const bool first = row < t.split;
+            const int mol = first ? t.ta : t.tb;
+            const int lrow = first ? row : row - t.split;
+            if (c < d4) {
+              if (mol >= 0)
+                v[u] = reinterpret_cast<const float4*>(xsrc + ((int64_t)mol * 32 + lrow) * din)[c];
+              dst[u] = &Xs[0][m][row][4 * c];
+            } else {
+              if (mol >= 0)
+                v[u] = reinterpret_cast<const float4*>(
+                    a.dy + (((int64_t)la * B + mol) * 32 + lrow) * dhid)[c - d4];
+              dst[u] = &Xs[1][m][row][4 * (c - d4)];
+            }
+          }
         }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          if (dst[u]) *reinterpret_cast<float4*>(dst[u]) = v[u];
       }
     }
     __syncthreads();
@@ -1132,11 +1152,9 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
     // 8 slots / distance 7 where a channel has a multiple of 8 k-steps (every layer of the QM8
     // model), like the forward's GEMM1 — with the 4-slot ring (distance 3: 3 x 4 MFMAs of cover per
     // tile) the loop ran at the L2 latency: 0.73 ms for the launch against 0.13 ms of MFMA time
-    float4 ring[8];
-    const bool deep = (Q & 7) == 0;
+    float4 ring[DEEP ? 8 : 4];
 #pragma unroll
-    for (int sl = 0; sl < 7; ++sl)
-      if (sl < 3 || deep) ring[sl] = wp[sl * 64];
+    for (int sl = 0; sl < (DEEP ? 7 : 3); ++sl) ring[sl] = wp[sl * 64];
     lds_cptr yrow[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) yrow[m] = (lds_cptr)&Xs[0][m][j][4 * hh];
@@ -1193,8 +1211,7 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
           wp += RD * 64;
         }
       };
-      if (deep) steps(std::integral_constant<int, 8>{});
-      else steps(std::integral_constant<int, 4>{});
+      steps(std::integral_constant<int, DEEP ? 8 : 4>{});
       // partial[rho] over the 16 lanes of a DPP row (four row-local DPP adds — the __shfl_xor
       // butterfly over 32 lanes compiled to five ds_bpermute_b32 per value, 276 in the kernel, and
       // made the LDS crossbar the launch's bottleneck); the dY buffer (free since the projection)
@@ -1231,7 +1248,7 @@ __device__ __forceinline__ void gain_grad_half(KArgs& a, const TileDesc (&td)[MT
   }
 }
 
-template <int NWV>
+template <int NWV, int DEEP>
 __global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) float Xs[2][2][MOLS][32][PITCH];  // [half][buffer][tile]
@@ -1250,10 +1267,10 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const l
     nt += td[m].ta >= 0 ? 1 : 0;
   }
   if (nt == 2) {
-    gain_grad_half<NWV, 2>(a, td, Xs[half], Vm[half], htid, wave);
+    gain_grad_half<NWV, 2, DEEP>(a, td, Xs[half], Vm[half], htid, wave);
   } else if (nt == 1) {
     const TileDesc t1[1] = {td[0]};
-    gain_grad_half<NWV, 1>(a, t1, Xs[half], Vm[half], htid, wave);
+    gain_grad_half<NWV, 1, DEEP>(a, t1, Xs[half], Vm[half], htid, wave);
   } else {
     for (int l = 0; l < 5 * a.num_layer; ++l) __syncthreads();  // five barriers per layer
   }
@@ -1413,7 +1430,10 @@ extern "C" int lnz_lanczosnet_gain_grad(const lnz_forward_args* args, lnz_stream
   // [wave][lane row][s][32] partial sums of a tile live in its 32 x PITCH dY buffer
   LNZ_REQUIRE(8 * a.n_long * 32 <= 32 * PITCH, LNZ_ENOTSUP, "%s: too many long channels", who);
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;
-  hipLaunchKernelGGL(lanczosnet_gain_grad_kernel<4>, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  if (a.din0 % 64 == 0)
+    hipLaunchKernelGGL((lanczosnet_gain_grad_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((lanczosnet_gain_grad_kernel<4, 0>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   return lnz::check_launch(who);
 }
 
