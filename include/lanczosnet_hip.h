@@ -22,7 +22,10 @@
 extern "C" {
 #endif
 
-#define LNZ_ABI_VERSION 2
+/* 3: + lnz_f32_linear, lnz_laplacian, the fp64 training kernels of the AdaLanczosNet spectrum
+ *    (lnz_ada_graph_laplacian_f64, lnz_ada_lanczos_layer_f64, lnz_ada_t_powers_f64 and their
+ *    _backward);  2: + lnz_lanczos_ritz_ws / _workspace_bytes, lnz_f16x3_*. */
+#define LNZ_ABI_VERSION 3
 #define LNZ_OK 0
 #define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
 #define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */
