@@ -63,6 +63,9 @@ SIGNATURES = {
     'lnz_lanczos_ritz_large_sym': (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_large_nk': (C.c_int64, [_I]),
     'lnz_large_pack_operators': (C.c_int, [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'lnz_large_pack_operators_fold': (C.c_int, [_P, _L, _L, _L, _L, _P, _I, _I, _I, _I, _I,
+                                                C.POINTER(C.c_int32), _I, C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_int32), _P, _P, _P, _P]),
     'lnz_large_gemm1': (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
     'lnz_large_spectral': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lnz_large_conv': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -136,24 +136,72 @@ __device__ inline int frag_slot(int row32, int j) {  // 16 B slot of (row in gro
   return (((row32 >> 4) * 2 + (j >> 2)) * 64 + (j & 3) * 16 + (row32 & 15));
 }
 
+// Channel folding (config 5 / the graph configuration have num_edge_type = 1, reference
+// dataset/graph_data.py:225-262: the bond-type channel IS the simple-graph channel, and
+// sum_c L_c X W_c^T = L (X (sum_c W_c)^T) over a class of equal operators): the caller names the
+// Cd DISTINCT source channels to pack (`src`) and, per source channel c, the packed slot it is
+// claimed to equal (`rep`); the kernel has every channel of its 32 B x C piece of the row in hand
+// anyway and verifies each claim, and for every two packed channels reports whether they differ
+// anywhere: bit 8 c + c' (c' < c) of *neq is set iff channel c differs from channel c' somewhere
+// among the compared pairs.  A claim that fails makes the caller repack unfolded; a pair of
+// packed channels that never differed is folded from the next batch on.
+struct LargeChanMap {
+  signed char nsrc;      // Cd
+  signed char src[8];    // packed slot d  -> source channel
+  signed char rep[8];    // source channel -> packed slot of its class (src[rep[c]] == c: packed itself)
+  signed char check[8];  // source channel -> compare against the channels packed before it
+};
+
 template <int P>
 __global__ __launch_bounds__(256) void large_pack_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch,
-    const float* __restrict__ V, int B, int N, int nkb, int C, int K, u16* __restrict__ Lb,
-    u16* __restrict__ Vb) {
+    const float* __restrict__ V, int B, int N, int nkb, int C, int K, LargeChanMap cm,
+    unsigned long long* __restrict__ neq, u16* __restrict__ Lb, u16* __restrict__ Vb) {
   const int rg = blockIdx.x, b = blockIdx.y, RT = gridDim.x;
   const int row32 = threadIdx.x >> 3, j = threadIdx.x & 7;
   const int r = 32 * rg + row32;
   const bool rv = r < N;
   const float* Lr = L + (int64_t)b * sb + (int64_t)(rv ? r : 0) * sr;
-  const int64_t plane_l = (int64_t)B * C * RT * nkb * 2048;
+  const int Cd = cm.nsrc;
+  const int64_t plane_l = (int64_t)B * Cd * RT * nkb * 2048;
   const int slot = frag_slot(row32, j);
-  const bool fast = sch == 1 && sc == C && C == 2 && (((uintptr_t)Lr) & 15) == 0;
+  // channels-last pair of channels (the collate layout with one edge type): one 64 B run per thread
+  const bool fast2 = sch == 1 && sc == 2 && C == 2 && (((uintptr_t)Lr) & 15) == 0;
+  // rows contiguous per channel (channel-major tensors, expanded single-channel views)
+  const bool fast1 = sc == 1 && (((uintptr_t)Lr) & 15) == 0 && ((sch & 3) == 0);
+  unsigned long long differ = 0;
+  auto emit = [&](const float* x, int d, int kb) {
+    bf16x8 out[P];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      u16 p[P];
+      split_pieces<P>(x[u] * ElemTraits<P>::kAScale, p);
+#pragma unroll
+      for (int i = 0; i < P; ++i) out[i][u] = __builtin_bit_cast(__bf16, p[i]);
+    }
+    const int64_t o = ((((int64_t)b * Cd + d) * RT + rg) * nkb + kb) * 2048 + (int64_t)slot * 8;
+#pragma unroll
+    for (int i = 0; i < P; ++i) *reinterpret_cast<bf16x8*>(Lb + i * plane_l + o) = out[i];
+  };
+  auto fetch = [&](float* x, int c, int k0) {  // channel c, k0 .. k0 + 7 of this thread's row
+    if (fast1 && rv && k0 + 8 <= N) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(Lr + (int64_t)c * sch + k0);
+      const f32x4 a0 = src[0], a1 = src[1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { x[u] = a0[u]; x[4 + u] = a1[u]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u;
+        x[u] = (rv && k < N) ? Lr[(int64_t)k * sc + (int64_t)c * sch] : 0.0f;
+      }
+    }
+  };
   for (int kb = 0; kb < nkb; ++kb) {
     const int k0 = 64 * kb + 8 * j;
-    for (int c0 = 0; c0 < C; c0 += 2) {
+    if (fast2) {
       float x[2][8];
-      if (fast && rv && k0 + 8 <= N) {
+      if (rv && k0 + 8 <= N) {
         const f32x4* src = reinterpret_cast<const f32x4*>(Lr + (int64_t)k0 * 2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -165,28 +213,49 @@ __global__ __launch_bounds__(256) void large_pack_kernel(
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u, c = c0 + cc;
-            x[cc][u] = (rv && k < N && c < C) ? Lr[(int64_t)k * sc + (int64_t)c * sch] : 0.0f;
+            const int k = k0 + u;
+            x[cc][u] = (rv && k < N) ? Lr[(int64_t)k * 2 + cc] : 0.0f;
           }
       }
+      emit(x[0], 0, kb);
+      if (Cd == 2) emit(x[1], 1, kb);
+      if (cm.check[1]) {
+        bool ne = false;
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int c = c0 + cc;
-        if (c < C) {
-          bf16x8 out[P];
+        for (int u = 0; u < 8; ++u) ne |= x[0][u] != x[1][u];
+        differ |= ne ? (1ull << 8) : 0ull;
+      }
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const bool own = cm.src[cm.rep[c]] == c;  // packed itself
+        if (!own && !cm.check[c]) continue;        // equal by construction (zero channel stride)
+        float x[8];
+        fetch(x, c, k0);
+        if (own) emit(x, cm.rep[c], kb);
+        if (cm.check[c]) {
+          // a folded channel against its representative; a packed one against all packed before it
+          for (int d = 0; d < Cd; ++d) {
+            const int c2 = cm.src[d];
+            if (c2 >= c || (!own && d != cm.rep[c])) continue;
+            float y[8];
+            fetch(y, c2, k0);
+            bool ne = false;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            u16 p[P];
-            split_pieces<P>(x[cc][u] * ElemTraits<P>::kAScale, p);
-#pragma unroll
-            for (int i = 0; i < P; ++i) out[i][u] = __builtin_bit_cast(__bf16, p[i]);
+            for (int u = 0; u < 8; ++u) ne |= x[u] != y[u];
+            differ |= ne ? (1ull << (8 * c + c2)) : 0ull;
           }
-          const int64_t o = ((((int64_t)b * C + c) * RT + rg) * nkb + kb) * 2048 + (int64_t)slot * 8;
-#pragma unroll
-          for (int i = 0; i < P; ++i) *reinterpret_cast<bf16x8*>(Lb + i * plane_l + o) = out[i];
         }
       }
     }
+  }
+  if (neq) {
+    // wave-level OR (the bit pattern is the same for nearly all lanes: at most 28 rounds of ballot)
+    for (int c = 1; c < C; ++c)
+      for (int c2 = 0; c2 < c; ++c2) {
+        const unsigned long long bit = 1ull << (8 * c + c2);
+        if (__builtin_amdgcn_ballot_w64((differ & bit) != 0) != 0 && (threadIdx.x & 63) == 0)
+          atomicOr(neq, bit);
+      }
   }
   // the Ritz vectors: one chunk per row group
   {
@@ -716,26 +785,68 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
 
 extern "C" int64_t lnz_large_nk(int N) { return ((int64_t)N + KB - 1) / KB * KB; }
 
-extern "C" int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_t stride_r,
-                                        int64_t stride_c, int64_t stride_ch, const float* V, int B,
-                                        int N, int C, int K, int planes, uint16_t* Lb,
-                                        uint16_t* Vb, lnz_stream_t stream) {
+extern "C" int lnz_large_pack_operators_fold(const float* L, int64_t stride_b, int64_t stride_r,
+                                             int64_t stride_c, int64_t stride_ch, const float* V,
+                                             int B, int N, int C, int K, int planes,
+                                             const int32_t* chan_src, int n_src,
+                                             const int32_t* chan_rep, const int32_t* chan_check,
+                                             unsigned long long* neq, uint16_t* Lb, uint16_t* Vb,
+                                             lnz_stream_t stream) {
   LNZ_REQUIRE(L && V && Lb && Vb && B > 0 && N > 0 && C > 0 && K > 0, LNZ_EINVAL,
               "lnz_large_pack_operators: bad arguments (B=%d N=%d C=%d K=%d)", B, N, C, K);
   LNZ_REQUIRE(K <= 64, LNZ_ENOTSUP, "lnz_large_pack_operators: K=%d > 64", K);
   LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_pack_operators: planes must be 1, 2 or 3");
+  LNZ_REQUIRE(C <= 8, LNZ_ENOTSUP, "lnz_large_pack_operators: C=%d > 8 channels", C);
+  LargeChanMap cm = {};
+  if (!chan_src) n_src = C;  // identity: every channel packed
+  const bool mapped = chan_src != nullptr;
+  LNZ_REQUIRE(!mapped || (chan_rep && n_src >= 1 && n_src <= C), LNZ_EINVAL,
+              "lnz_large_pack_operators_fold: channel map needs chan_rep and 1 <= n_src <= C "
+              "(C=%d n_src=%d)", C, n_src);
+  if (mapped) {
+    cm.nsrc = (signed char)n_src;
+    for (int d = 0; d < n_src; ++d) {
+      LNZ_REQUIRE(chan_src[d] >= 0 && chan_src[d] < C && (d == 0 || chan_src[d] > chan_src[d - 1]),
+                  LNZ_EINVAL, "lnz_large_pack_operators_fold: chan_src must be ascending channels");
+      cm.src[d] = (signed char)chan_src[d];
+    }
+    for (int c = 0; c < C; ++c) {
+      LNZ_REQUIRE(chan_rep[c] >= 0 && chan_rep[c] < n_src && chan_src[chan_rep[c]] <= c, LNZ_EINVAL,
+                  "lnz_large_pack_operators_fold: chan_rep[%d] must name a packed slot of an "
+                  "earlier (or the same) channel", c);
+      cm.rep[c] = (signed char)chan_rep[c];
+      cm.check[c] = (signed char)((neq && (!chan_check || chan_check[c])) ? 1 : 0);
+    }
+    for (int d = 0; d < n_src; ++d)
+      LNZ_REQUIRE(chan_rep[chan_src[d]] == d, LNZ_EINVAL,
+                  "lnz_large_pack_operators_fold: a packed channel must represent itself");
+  } else {
+    cm.nsrc = (signed char)C;
+    for (int c = 0; c < C; ++c) {
+      cm.src[c] = cm.rep[c] = (signed char)c;
+      cm.check[c] = (signed char)(neq ? 1 : 0);
+    }
+  }
   const int nkb = (int)(lnz_large_nk(N) / KB);
   dim3 grid((N + 31) / 32, B);
   if (planes == 1)
     hipLaunchKernelGGL(large_pack_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
-                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
+                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, cm, neq, Lb, Vb);
   else if (planes == 2)
     hipLaunchKernelGGL(large_pack_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
-                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
+                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, cm, neq, Lb, Vb);
   else
     hipLaunchKernelGGL(large_pack_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, L, stride_b,
-                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, Lb, Vb);
+                       stride_r, stride_c, stride_ch, V, B, N, nkb, C, K, cm, neq, Lb, Vb);
   return lnz::check_launch("lnz_large_pack_operators");
+}
+
+extern "C" int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_t stride_r,
+                                        int64_t stride_c, int64_t stride_ch, const float* V, int B,
+                                        int N, int C, int K, int planes, uint16_t* Lb,
+                                        uint16_t* Vb, lnz_stream_t stream) {
+  return lnz_large_pack_operators_fold(L, stride_b, stride_r, stride_c, stride_ch, V, B, N, C, K,
+                                       planes, nullptr, 0, nullptr, nullptr, nullptr, Lb, Vb, stream);
 }
 
 extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wf, int B, int N,

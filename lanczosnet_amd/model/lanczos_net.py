@@ -379,7 +379,10 @@ class _LanczosNetBase(nn.Module):
         return (y * m).sum(dim=1) / m.sum(dim=1)
 
     @torch.no_grad()
-    def _plan_large(self, planes=None):
+    def _plan_large(self, planes=None, classes=None):
+        """classes: the channel fold of `_large_fold_classes` (tuple: channel -> representative
+        channel); the node-space weight blocks of a class are summed (sum_c L_c X W_c^T =
+        L (X (sum_c W_c)^T) for equal operators) and only the representatives are kept."""
         sig = self._param_signature()
         cache = getattr(self, '_plan_large_cache', None)
         if cache is None or cache['sig'] != sig:
@@ -389,11 +392,16 @@ class _LanczosNetBase(nn.Module):
                     [[(seq[i].weight, seq[i].bias) for i in (0, 2, 4, 6)]
                      for seq in self.spectral_filter], self.num_scale_long)
             cache = self._plan_large_cache = dict(sig=sig, mlp_pack=buf, conv={})
-        if planes is not None and planes not in cache['conv']:
+        key = planes if classes is None else (planes, tuple(classes))
+        if planes is not None and key not in cache['conv']:
             # per layer: the node-space (edge-type) column blocks of the mix weight as bf16 pieces
             # in MFMA fragment order (the Wf of lnz_large_gemm1) and the long-scale blocks
             # as their pack_rows_k8 image, fp32 (lnz_large_spectral)
             S, E1 = self.num_scale_long, self.num_edgetype + 1
+            if classes is None:
+                classes = tuple(range(E1))
+            assert len(classes) == E1
+            reps = sorted(set(classes))
             layers = []
             for t in range(self.num_layer):
                 W = self._mix_weight(t).detach().float()
@@ -401,12 +409,16 @@ class _LanczosNetBase(nn.Module):
                 d_in = W.shape[1] // (S + E1)
                 dinp = (d_in + 15) // 16 * 16
                 Wc = torch.nn.functional.pad(W.view(dout, S + E1, d_in), (0, dinp - d_in))
+                Wn = Wc[:, S:]
+                if len(reps) < E1:
+                    Wn = torch.stack([sum(Wn[:, c] for c in range(E1) if classes[c] == r)
+                                      for r in reps], dim=1)
                 Wb = ops.large_weight_fragments(ops.split_bf16_planes(
-                    Wc[:, S:].permute(1, 0, 2).reshape(E1 * dout, dinp), planes))
+                    Wn.permute(1, 0, 2).reshape(len(reps) * dout, dinp), planes))
                 Wt = ops.pack_rows_k8(Wc[:, :S].reshape(dout, S * dinp).contiguous()) if S else None
                 layers.append(dict(Wb=Wb, Wt=Wt, bias=self.filter[t].bias.detach().float().contiguous(),
                                    din=d_in))
-            cache['conv'][planes] = layers
+            cache['conv'][key] = layers
         return cache
 
     def _large_hip_supported(self, K):
@@ -415,30 +427,135 @@ class _LanczosNetBase(nn.Module):
         return (set(self.hidden_dim[:self.num_layer]) == {128} and self.input_dim <= 128
                 and self.num_scale_short == 0 and K <= 64)
 
+    # -- channel folding of the large-graph path ------------------------------------------------
+    # With one edge type (config/graph_lanczos_net.yaml:14) the collated L carries the SAME operator
+    # twice: channel 0 = L4 of the simple graph, channel 1 = L4 of the only bond type (reference
+    # dataset/graph_data.py:225-262).  The conv is HBM bound on the operator stream, so streaming the
+    # duplicate is half of its bytes for nothing.  Equality is a property of the DATA, and the check
+    # is free where every entry of every channel is in registers anyway — the pack kernel:
+    #   * a zero channel stride (an expanded view) proves equality without looking;
+    #   * otherwise the pack kernel compares the packed channels pairwise while it converts them
+    #     and reports "differs somewhere" bits; the bits come back through pinned memory and are
+    #     read at the NEXT call (never a host sync): channels that were equal in the last batch are
+    #     folded in this one — the claim is then verified by the same compare, and the only wait is
+    #     for the pack launch itself while the layer launches behind it keep the GPU busy; a
+    #     failed claim repacks unfolded (and drops the guess).
+    # `large_fold = False` (or LANCZOSNET_LARGE_FOLD=0) packs every channel, no comparison.
+    large_fold = os.environ.get('LANCZOSNET_LARGE_FOLD', '1') != '0'
+
+    def _large_fold_classes(self, L):
+        """-> (classes, proven): classes[c] = representative channel of channel c under the
+        current claim; proven[c] = True when channel c needs no verification (its own
+        representative, or structurally equal through a zero channel stride)."""
+        Cn = L.shape[3]
+        ident = tuple(range(Cn))
+        if not self.large_fold or Cn == 1 or Cn > 8:
+            return ident, (True,) * Cn
+        if L.stride(3) == 0:
+            return (0,) * Cn, (True,) * Cn
+        st = self.__dict__.setdefault('_large_fold_state', {}).get(Cn)
+        if st is None:
+            return ident, (True,) * Cn
+        if st.get('pending') is not None:
+            ev, host, cls = st.pop('pending')
+            st['pending'] = None
+            ev.synchronize()   # the previous call's pack: long finished
+            st['guess'] = self._classes_from_bits(int(host.item()), cls)
+        guess = st.get('guess', ident)
+        return guess, tuple(guess[c] == c for c in range(Cn))
+
+    @staticmethod
+    def _classes_from_bits(bits, packed_classes):
+        """Refine the classes a pack ran with by its comparison bits: packed channels (the
+        representatives) that never differed from an earlier packed channel join its class."""
+        Cn = len(packed_classes)
+        reps = sorted(set(packed_classes))
+        new_rep = {}
+        for r in reps:
+            new_rep[r] = r
+            for r2 in reps:
+                if r2 >= r:
+                    break
+                if new_rep[r2] == r2 and not (bits >> (8 * r + r2)) & 1:
+                    new_rep[r] = r2
+                    break
+        return tuple(new_rep[packed_classes[c]] for c in range(Cn))
+
+    def _large_pack(self, Lf, Vf, planes):
+        """Pack the operators under the current fold claim.  -> (Lb, Vb, classes, verify) where
+        verify() (or None) must be called before the result is released: it waits for the pack
+        launch and returns False when a folded channel turned out to differ."""
+        Cn = Lf.shape[3]
+        classes, proven = self._large_fold_classes(Lf)
+        capturing = torch.cuda.is_current_stream_capturing()
+        compare = self.large_fold and 1 < Cn <= 8 and not capturing and Lf.stride(3) != 0
+        if capturing and not all(proven):
+            classes, proven = tuple(range(Cn)), (True,) * Cn
+        reps = sorted(set(classes))
+        if not compare and len(reps) == Cn:
+            Lb, Vb = ops.large_pack_operators(Lf, Vf, planes)
+            return Lb, Vb, classes, None
+        slot = {r: i for i, r in enumerate(reps)}
+        neq = torch.zeros((1,), dtype=torch.int64, device=Lf.device) if compare else None
+        Lb, Vb = ops.large_pack_operators(
+            Lf, Vf, planes, chan_src=reps, chan_rep=[slot[classes[c]] for c in range(Cn)],
+            chan_check=[0 if (classes[c] != c and proven[c]) else 1 for c in range(Cn)], neq=neq)
+        if not compare:
+            return Lb, Vb, classes, None
+        st = self.__dict__.setdefault('_large_fold_state', {}).setdefault(Cn, {})
+        host = st.get('host')
+        if host is None:
+            host = st['host'] = torch.zeros((1,), dtype=torch.int64).pin_memory()
+        host.copy_(neq, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        claimed = [c for c in range(Cn) if classes[c] != c and not proven[c]]
+        if not claimed:
+            st['pending'] = (ev, host, classes)   # read at the next call
+            return Lb, Vb, classes, None
+        st['pending'] = None
+
+        def verify():
+            ev.synchronize()
+            bits = int(host.item())
+            ok = not any((bits >> (8 * c + classes[c])) & 1 for c in claimed)
+            if ok:
+                st['guess'] = self._classes_from_bits(bits, classes)
+            else:
+                st['guess'] = tuple(range(Cn))
+            return ok
+        return Lb, Vb, classes, verify
+
     @torch.no_grad()
     def _large_graph_forward_hip(self, node_feat, L, D, V, mask, planes=3):
         """Graphs beyond the 32-node MFMA tile on the hand-written streaming kernels
         (csrc/conv_large.hip; BASELINE config 5: N = 2048, K = 64, batch 256): the operators are
-        packed once (channel-major bf16 planes), every layer is gemm1 + eigen-space spectral block
-        + streamed conv.  planes = 3: fp32-grade split products (default, the 1e-5 parity mode);
-        planes = 1: plain bf16 operands / fp32 accumulate (`gemm_mode = 'bf16'`, config 5's mode)."""
+        packed once (channel-major bf16 planes, equal channels once — see `_large_pack`), every
+        layer is gemm1 + eigen-space spectral block + streamed conv.  planes = 3: fp32-grade split
+        products (default, the 1e-5 parity mode); planes = 1: plain bf16 operands / fp32
+        accumulate (`gemm_mode = 'bf16'`, config 5's mode)."""
         S = self.num_scale_long
-        plan = self._plan_large(planes)
         Lf = L if L.dtype == torch.float32 else L.float()
         Vf = V.float().contiguous()
         G = None
         if S > 0:
-            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
-        Lb, Vb = ops.large_pack_operators(Lf, Vf, planes)
-        work = ops.large_work_buffers(Lb)
-        state = node_feat.float().contiguous() if self.general else \
-            self.embedding(node_feat).float().contiguous()
-        bufs = [None, None]
-        for t, lay in enumerate(plan['conv'][planes]):
-            state = ops.large_conv_layer(state, lay['din'], Lb, Vb, Vf, lay['Wb'], lay['Wt'],
-                                         G[t] if G is not None else None, lay['bias'], work,
-                                         relu=True, out=bufs[t & 1])
-            bufs[t & 1] = state
+            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer,
+                                   self._plan_large()['mlp_pack'])
+        for attempt in range(2):
+            Lb, Vb, classes, verify = self._large_pack(Lf, Vf, planes)
+            plan = self._plan_large(planes, classes)
+            work = ops.large_work_buffers(Lb)
+            state = node_feat.float().contiguous() if self.general else \
+                self.embedding(node_feat).float().contiguous()
+            bufs = [None, None]
+            for t, lay in enumerate(plan['conv'][(planes, tuple(classes))]):
+                state = ops.large_conv_layer(state, lay['din'], Lb, Vb, Vf, lay['Wb'], lay['Wt'],
+                                             G[t] if G is not None else None, lay['bias'], work,
+                                             relu=True, out=bufs[t & 1])
+                bufs[t & 1] = state
+            if verify is None or verify():
+                break
+            # a folded channel differed in this batch: the guess is dropped, pack every channel
         y = self.filter[-1](state) * self.att_func(state)
         m = (mask != 0).float().unsqueeze(2)
         return (y * m).sum(dim=1) / m.sum(dim=1)

@@ -219,12 +219,16 @@ def large_weight_fragments(Wb):
   return x.permute(0, 1, 2, 4, 5, 3, 6).contiguous()  # p, c, mt, ks, h, l31, u
 
 
-def large_pack_operators(L, V, planes=1):
-  """lnz_large_pack_operators: L [B,N,N,C] fp32 (any strides), V [B,N,K] -> Lb [planes,B,C,RT,
-  Nk/64,4,64,8] and Vb [planes,B,RT,4,64,8] (bf16 pieces; planes = 2: fp16 pieces of 1024 x the
+def large_pack_operators(L, V, planes=1, chan_src=None, chan_rep=None, chan_check=None, neq=None):
+  """lnz_large_pack_operators[_fold]: L [B,N,N,C] fp32 (any strides), V [B,N,K] -> Lb [planes,B,Cd,
+  RT,Nk/64,4,64,8] and Vb [planes,B,RT,4,64,8] (bf16 pieces; planes = 2: fp16 pieces of 1024 x the
   entries) in fragment-tile order (RT = ceil(N/32), Nk = N rounded up to 64; see
-  include/lanczosnet_hip.h).  Lb.dims = (N, Nk)."""
-  _need_cuda(L, V)
+  include/lanczosnet_hip.h).  Lb.dims = (N, Nk).
+  Channel folding: chan_src = the Cd distinct source channels that are packed (ascending; default
+  all C), chan_rep[c] = packed slot channel c is claimed to equal, neq = a zeroed uint64 (int64
+  tensor of one element) that receives the pairwise "differs somewhere" bits 8 c + c' of the
+  compared channels (chan_check[c] = 0 exempts channel c), see the header."""
+  _need_cuda(L, V, neq)
   assert L.dim() == 4 and L.dtype == torch.float32 and V.dim() == 3
   V = _f32c(V)
   B, N, _, Cn = L.shape
@@ -233,13 +237,19 @@ def large_pack_operators(L, V, planes=1):
   Nk = lib.lnz_large_nk(N)
   RT = (N + 31) // 32
   dt = large_plane_dtype(planes)
-  Lb = torch.empty((planes, B, Cn, RT, Nk // 64, 4, 64, 8), dtype=dt, device=L.device)
+  Cd = Cn if chan_src is None else len(chan_src)
+  Lb = torch.empty((planes, B, Cd, RT, Nk // 64, 4, 64, 8), dtype=dt, device=L.device)
   Vb = torch.empty((planes, B, RT, 4, 64, 8), dtype=dt, device=L.device)
   Lb.dims = (N, Nk)
   sb, sr, sc, sch = L.stride()
+  i32 = lambda xs: (C.c_int32 * len(xs))(*[int(x) for x in xs]) if xs is not None else None  # noqa: E731
+  if neq is not None:
+    assert neq.dtype == torch.int64 and neq.numel() == 1
   with torch.cuda.device(L.device):
-    _lib.check(lib.lnz_large_pack_operators(_ptr(L), sb, sr, sc, sch, _ptr(V), B, N, Cn, K, planes,
-                                            _ptr(Lb), _ptr(Vb), _stream()))
+    _lib.check(lib.lnz_large_pack_operators_fold(
+        _ptr(L), sb, sr, sc, sch, _ptr(V), B, N, Cn, K, planes, i32(chan_src), Cd,
+        i32(chan_rep if chan_src is not None else None), i32(chan_check), _ptr(neq), _ptr(Lb),
+        _ptr(Vb), _stream()))
   return Lb, Vb
 
 

@@ -223,6 +223,117 @@ def test_large_conv_stages_match_numpy(planes, B, N, C, K, din, S):
   assert np.abs(out - ref).max() <= (2e-5 if planes == 1 else 5e-6) * np.abs(ref).max()
 
 
+@pytest.mark.parametrize('planes', [1, 3])
+@pytest.mark.parametrize('layout', ['channels_last', 'channel_major', 'pair'])
+def test_pack_fold_compares_channels_and_packs_the_distinct_ones(planes, layout):
+  """lnz_large_pack_operators_fold: the packed image of the distinct channels is the unfolded
+  image of those channels bit for bit; the comparison bits name exactly the channel pairs that
+  differ somewhere — also when the only difference is ONE entry in the last ragged row; a zero
+  channel stride (expanded view) needs no comparison."""
+  from lanczosnet_amd import ops
+  B, N, K = 2, 203, 40
+  rs = np.random.RandomState(3)
+  a = (rs.randn(B, N, N) * (rs.rand(B, N, N) < 0.1)).astype(np.float32)
+  b_ = (rs.randn(B, N, N) * (rs.rand(B, N, N) < 0.1)).astype(np.float32)
+  V = torch.from_numpy((rs.randn(B, N, K) / np.sqrt(N)).astype(np.float32)).to(DEV)
+  if layout == 'pair':                      # the collate layout of one edge type: [B,N,N,2]
+    chans, same = [a, a], {(1, 0)}
+  else:
+    chans, same = [a, b_, a], {(2, 0)}
+  Cn = len(chans)
+  L = torch.from_numpy(np.stack(chans, axis=3)).to(DEV)
+  if layout == 'channel_major':
+    L = L.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)   # rows contiguous per channel
+    assert L.stride(2) == 1
+  bit = lambda c, c2: 1 << (8 * c + c2)  # noqa: E731
+  full, _ = ops.large_pack_operators(L, V, planes)
+  neq = torch.zeros((1,), dtype=torch.int64, device=DEV)
+  full2, _ = ops.large_pack_operators(L, V, planes, neq=neq)
+  assert torch.equal(full.view(torch.int16), full2.view(torch.int16))
+  want = sum(bit(c, c2) for c in range(Cn) for c2 in range(c) if (c, c2) not in same)
+  assert int(neq.item()) == want
+  # folded: channel (c) claimed equal to channel 0
+  (cf, _), = same
+  src = [c for c in range(Cn) if c != cf]
+  rep = [src.index(c) if c != cf else 0 for c in range(Cn)]
+  neq.zero_()
+  fold, Vb = ops.large_pack_operators(L, V, planes, chan_src=src, chan_rep=rep, neq=neq)
+  assert fold.shape[2] == Cn - 1 and fold.dims == full.dims
+  assert torch.equal(fold.view(torch.int16), full[:, :, src].contiguous().view(torch.int16))
+  assert int(neq.item()) & bit(cf, 0) == 0
+  # one differing entry in the last row -> the claim fails
+  L2 = L.clone() if layout != 'channel_major' else \
+      L.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+  L2[B - 1, N - 1, N - 2, cf] += 0.5
+  neq.zero_()
+  ops.large_pack_operators(L2, V, planes, chan_src=src, chan_rep=rep, neq=neq)
+  assert int(neq.item()) & bit(cf, 0)
+  # an expanded view: equal by construction, nothing to compare (check = 0), same image
+  Le = L[:, :, :, :1].expand(B, N, N, 2)
+  assert Le.stride(3) == 0
+  neq.zero_()
+  ex, _ = ops.large_pack_operators(Le, V, planes, chan_src=[0], chan_rep=[0, 0], chan_check=[1, 0],
+                                   neq=neq)
+  assert int(neq.item()) == 0
+  assert torch.equal(ex.view(torch.int16), full[:, :, :1].contiguous().view(torch.int16))
+
+
+def test_large_forward_folds_equal_channels_and_survives_a_wrong_guess():
+  """The module's fold protocol (model/lanczos_net.py `_large_pack`): batch 1 packs both channels
+  and learns they are equal, batch 2 streams ONE operator with the summed weight blocks (same
+  scores to fp32 rounding), a batch whose channels differ fails the in-kernel verification and
+  is recomputed unfolded — equal to a module that never folds; an expanded view folds at once."""
+  from lanczosnet_amd import ops
+  B, N, K = 3, 256, 32
+  cfg, P, net, X, L, mask = _general_setup(B, N, K, 3, 7, 8.0 / N)
+  _, _, plain, _, _, _ = _general_setup(B, N, K, 3, 7, 8.0 / N)
+  plain.large_fold = False
+  Ld = torch.from_numpy(L).to(DEV)
+  Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(mask).to(DEV)
+  D, V = ops.lanczos_ritz_large(Ld[:, :, :, 0].contiguous(), K, K)
+  seen = []
+  # (the eigen-space projection adds its row chunks with fp32 atomics: runs agree to rounding)
+  close = lambda x, y: bool((x - y).abs().max() <= 2e-6 * y.abs().max())  # noqa: E731
+  orig = ops.large_pack_operators
+
+  def spy(*a, **kw):
+    out = orig(*a, **kw)
+    seen.append(out[0].shape[2])
+    return out
+  ops.large_pack_operators = spy
+  try:
+    with torch.no_grad():
+      ref = plain(Xd, Ld, D, V, mask=md)
+      assert seen == [2]
+      s1 = net(Xd, Ld, D, V, mask=md)            # learns
+      s2 = net(Xd, Ld, D, V, mask=md)            # folds
+      assert seen[1:] == [2, 1]
+      assert close(s1, ref)
+      assert close(s2, ref)
+      L2 = Ld.clone()
+      L2[:, :, :, 1] *= 0.5
+      ref2 = plain(Xd, L2, D, V, mask=md)
+      del seen[:]
+      s3 = net(Xd, L2, D, V, mask=md)            # folded guess fails -> repacked unfolded
+      assert seen[1:] == [1, 2]
+      assert close(s3, ref2)
+      s4 = net(Xd, L2, D, V, mask=md)            # guess dropped: unfolded, no verification wait
+      assert seen[3:] == [2] and close(s4, ref2)
+      s5 = net(Xd, Ld, D, V, mask=md)            # equal again: learns again ...
+      s6 = net(Xd, Ld, D, V, mask=md)            # ... and folds
+      assert seen[4:] == [2, 1] and close(s5, ref) and close(s6, s2)
+      del seen[:]
+      s7 = net(Xd, Ld[:, :, :, :1].expand(B, N, N, 2), D, V, mask=md)   # zero channel stride
+      assert seen == [1] and close(s7, s2)
+      net.gemm_mode = 'bf16'                     # config 5's mode folds the same way
+      plain.gemm_mode = 'bf16'
+      sb = net(Xd, Ld, D, V, mask=md)
+      rb = plain(Xd, Ld, D, V, mask=md)
+      assert seen[1:] == [1, 2] and (sb - rb).abs().max() <= 2e-2 * rb.abs().max()
+  finally:
+    ops.large_pack_operators = orig
+
+
 def _general_setup(B, N, K, num_layer, seed, p_edge):
   from lanczosnet_amd.model import LanczosNetGeneral
   from lanczosnet_amd.utils.arg_helper import make_model_config

@@ -190,3 +190,18 @@ def test_collate_preprocessed_matches_reference_collate():
   np.testing.assert_allclose(out['L'].numpy(), g['L'], atol=1e-7)
   np.testing.assert_allclose(out['D'].numpy(), g['D'], atol=1e-6)
   assert out['V'].shape == g['V'].shape
+
+
+def test_fold_classes_from_comparison_bits():
+  """model/lanczos_net.py `_classes_from_bits`: packed channels that never differed from an earlier
+  packed channel join its class; folded channels follow their representative."""
+  from lanczosnet_amd.model.lanczos_net import LanczosNet
+  f = LanczosNet._classes_from_bits
+  bit = lambda c, c2: 1 << (8 * c + c2)  # noqa: E731
+  assert f(0, (0, 1)) == (0, 0)
+  assert f(bit(1, 0), (0, 1)) == (0, 1)
+  assert f(bit(1, 0) | bit(2, 1), (0, 1, 2)) == (0, 1, 0)          # 2 == 0, 1 differs from both
+  assert f(bit(1, 0) | bit(2, 0), (0, 1, 2)) == (0, 1, 1)
+  assert f(bit(2, 0), (0, 0, 2)) == (0, 0, 2)                       # already folded 1 stays with 0
+  assert f(0, (0, 0, 2)) == (0, 0, 0)
+  assert f(bit(1, 0) | bit(2, 0) | bit(2, 1) | bit(3, 0) | bit(3, 2), (0, 1, 2, 3)) == (0, 1, 2, 1)
