@@ -468,6 +468,62 @@ def test_ada_lanczos_net_end_to_end_parity_protocol(filter_gemm):
   assert (e_our[rest] <= 3 * e_ref[rest] + 1e-5).all()
 
 
+_CFG4 = {}
+
+
+def _cfg4_setup():
+  """tests/golden/ada_cfg4.npz: the reference's own yaml model at full depth (7 conv layers, seven
+  4096-wide filter MLPs = 350 M parameters), built once for the four filter-GEMM modes."""
+  if not _CFG4:
+    from lanczosnet_amd.synthetic import draw_batch
+    g = load_golden('ada_cfg4.npz')
+    cfg = ast.literal_eval(str(g['cfg_json']))
+    nb = int(g['nb'])
+    b = draw_batch(int(g['batch']), seed=int(g['batch_seed']))
+    np.testing.assert_array_equal(b['n_nodes'][:nb], g['n_nodes'])
+    N = b['node_mask'].shape[1]
+    L = np.zeros((nb, N, N, 7), np.float32)
+    for i in range(nb):
+      n = int(b['n_nodes'][i])
+      L[i, :n, :n] = oracle.laplacian_multi_l4(b['adjs'][i, :n, :n])
+    P = oracle.make_ada_params(cfg, int(g['param_seed']))
+    _CFG4.update(g=g, cfg=cfg, net=_ada_model(cfg, P), nf=b['node_feat'][:nb], L=L,
+                 mask=b['node_mask'][:nb])
+  return _CFG4
+
+
+@pytest.mark.parametrize('filter_gemm', ['fp32', 'fp32_hip', 'f16x3', 'f16x3_lib'])
+def test_ada_config4_full_depth_matches_the_reference(filter_gemm):
+  """BASELINE configs[3] at its full depth against the UNMODIFIED reference: the 7-layer
+  AdaLanczosNet of config/qm8_ada_lanczos_net.yaml (reference model/ada_lanczos_net.py:289-368) on
+  the first 128 molecules of the bench batch, same start vectors; scores under the protocol of
+  `_protocol` (classification by the reference's raw betas and by the reference's own distance
+  from the same class run in float64 — both stored by tests/golden/make_golden_ada_cfg4.py)."""
+  c = _cfg4_setup()
+  g, net = c['g'], c['net']
+  assert net.num_layer == 7 and len(net.spectral_filter) == 7
+  net.filter_gemm_mode = filter_gemm
+  with _fixed_randn(g['q1']), torch.no_grad():
+    score = net(_t(c['nf']), _t(c['L']), mask=_t(c['mask'])).cpu().numpy()
+  s64 = g['score64']
+  scale = np.abs(s64).max()
+  e_ref = np.abs(g['score'] - s64).max(axis=1) / scale
+  e_our = np.abs(score - g['score']).max(axis=1) / scale
+  e_exact = np.abs(score - s64).max(axis=1) / scale
+  sep = _separation(g['betas_raw'])
+  strict = (sep >= 10) & (e_ref <= 2e-6)
+  rest = (sep >= 10) & ~strict
+  near = sep < 10
+  print('cfg4 [%s]: strict %d molecules, worst vs reference %.2e (vs float64 %.2e) | rest %d, worst '
+        '%.2e (reference noise there %.2e) | near threshold %d, worst %.2e (reference noise %.2e)' %
+        (filter_gemm, strict.sum(), e_our[strict].max(), e_exact[strict].max(), rest.sum(),
+         e_our[rest].max() if rest.any() else 0, e_ref[rest].max() if rest.any() else 0,
+         near.sum(), e_our[near].max(), e_ref[near].max()))
+  assert strict.sum() >= 80
+  assert e_our[strict].max() < 1e-5
+  assert (e_our[rest] <= 3 * e_ref[rest] + 1e-5).all()
+
+
 def test_ada_module_surface():
   from lanczosnet_amd.model import AdaLanczosNet
   from lanczosnet_amd.utils.arg_helper import make_model_config
