@@ -76,9 +76,9 @@ def cpu_baseline(cfg, params, batch_size, reps):
   K = cfg['num_eig_vec']
   # a top-K cut through a degenerate |lambda| cluster (n > K) keeps an arbitrary vector of the
   # cluster: basis dependent in the reference itself (LAPACK's choice), excluded from the parity
-  # figure as SURVEY.md 8(c) prescribes — and counted.  Gap threshold 1e-7 = the rounding of the
-  # fp32 Laplacian the device path is handed (dataset/qm8.py:262 casts L to fp32; the reference's
-  # offline eigh sees the fp64 one): a cluster tighter than that cannot be ordered from fp32 L.
+  # figure as SURVEY.md 8(c) prescribes — and counted.  The rule (oracle.degenerate_cut, gap
+  # oracle.CUT_GAP = 1e-7 = the rounding of the fp32 Laplacian the device path is handed) is the
+  # one every parity test uses.
   ambiguous = np.zeros(B, bool)
   t_start = time.perf_counter()
   for _ in range(reps):
@@ -92,8 +92,7 @@ def cpu_baseline(cfg, params, batch_size, reps):
                                             graph_laplacian_type='L4')
       Dl.append(e)
       Vl.append(V)
-      if nb > K:
-        ambiguous[b] = abs(abs(e[K - 1]) - abs(e[K])) < 1e-7
+      ambiguous[b] = oracle.degenerate_cut(e, K)
     D, V = oracle.collate_eigs(Dl, Vl, N, cfg['num_eig_vec'])
     score = oracle.lanczos_net_forward_torch(params, cfg, batch['node_feat'], L, D, V,
                                              batch['node_mask'])
@@ -684,8 +683,14 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+  per_rank_ms = None
   if dist:
+    # every rank's own clock (a SCALE run explains itself: which rank was the slow one), then the
+    # maximum over the ranks is the job's time
     tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    parts = [torch.zeros_like(tt) for _ in range(world)]
+    dist.all_gather(parts, tt)
+    per_rank_ms = [round(1e3 * float(p_.item()) / args.steps, 4) for p_ in parts]
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
@@ -872,7 +877,10 @@ def main():
           'backend': dist.get_backend(), 'world': world,
           'collective': 'all_gather_into_tensor of the [%d,%d] f32 shard scores, every step, async '
                         '(AsyncScoreGather)' % (B, cfg['output_dim']),
-          'gathered_equals_local': gather_ok}
+          'gathered_equals_local': gather_ok,
+          'ms_per_step_per_rank': per_rank_ms,
+          'note': 'ms_per_step (top level) = max over the ranks; every rank times its own %d steps '
+                  'between the two barriers' % args.steps}
     if split is not None:
       out['config']['split_precision_mode'] = split
     if pipe is not None:
@@ -933,7 +941,7 @@ def main():
                          'bar': 1e-5,
                          'excluded': int(ambiguous.sum()),
                          'excluded_why': 'n > K and the top-K cut splits a degenerate |lambda| '
-                                         'cluster (gap < 1e-7, the fp32 rounding of L): the reference keeps a LAPACK-chosen '
+                                         'cluster (oracle.degenerate_cut: gap < 1e-7, the fp32 rounding of L): the reference keeps a LAPACK-chosen '
                                          'vector of the cluster (SURVEY.md 8c)',
                          'excluded_max_rel_dev': float(dev_mol[ambiguous].max()) if ambiguous.any()
                          else None}

@@ -70,7 +70,8 @@ int lnz_laplacian(const float* adjs, const int32_t* n_nodes, int B, int N, int E
  *            with config/graph_lanczos_net.yaml: n in [20,100]): one 512-thread workgroup per
  *            graph, A staged once into LDS, the fp64 basis in LDS up to N = 111 and in a workspace
  *            above (lnz_lanczos_ritz_workspace_bytes; without one lnz_lanczos_ritz takes a
- *            stream-ordered allocation for the launch); eigenvalues by Sturm-count section search
+ *            stream-ordered allocation for the launch — LNZ_ENOTSUP while the stream is being
+ *            captured: use lnz_lanczos_ritz_ws there); eigenvalues by Sturm-count section search
  *            (one per thread), the K selected eigenvectors by twisted factorisation, V = Q S;
  *            the QL sweep, run barrier-free on per-wave copies of T, as the fallback (info += 256);
  * then stable ordering by descending |lambda| (ties: ascending lambda), cut / zero-pad to K.

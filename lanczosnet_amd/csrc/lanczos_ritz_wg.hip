@@ -685,7 +685,15 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
     const int64_t need = (int64_t)B * N * (N | 1) * (int64_t)sizeof(double);
     void* owned = nullptr;
     if (!workspace) {
-      // no caller workspace: a stream-ordered allocation that lives for this launch only
+      // no caller workspace: a stream-ordered allocation that lives for this launch only — not
+      // while the stream is being captured into a graph (an allocation made at capture time
+      // would be freed before the first replay): there the caller owns the workspace
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(s, &cap);
+      LNZ_REQUIRE(cap == hipStreamCaptureStatusNone, LNZ_ENOTSUP,
+                  "lnz_lanczos_ritz: N=%d keeps its Krylov basis in a %lld-byte workspace; under "
+                  "stream capture pass one (lnz_lanczos_ritz_ws, lnz_lanczos_ritz_workspace_bytes)",
+                  N, (long long)need);
       hipError_t e = hipMallocAsync(&owned, (size_t)need, s);
       LNZ_REQUIRE(e == hipSuccess, LNZ_ELAUNCH, "lnz_lanczos_ritz: workspace of %lld B: %s",
                   (long long)need, hipGetErrorString(e));

@@ -999,6 +999,16 @@ class AdaLanczosNet(_LanczosNetBase):
             raise NotImplementedError('HIP Lanczos layer is built with re-orthogonalisation on '
                                       '(the reference never turns it off, SURVEY.md F7)')
         self.input_dim = self.num_atom  # model/ada_lanczos_net.py:40
+        # The reference collects T^ii in ASCENDING ii whatever the order of the list
+        # (model/ada_lanczos_net.py:262-270), and a repeated entry gives it fewer T blocks than its
+        # first Linear has input columns (a shape error there).  Same here: the list is put in
+        # ascending order once; a duplicate is refused.
+        ld = [d for d in self.long_diffusion_dist]
+        if len(set(ld)) != len(ld):
+            raise ValueError('AdaLanczosNet: duplicate entries in long_diffusion_dist %r' % (ld,))
+        if any(not isinstance(d, int) for d in ld):
+            raise NotImplementedError("AdaLanczosNet: 'inf' diffusion distance is not built")
+        self.long_diffusion_dist = sorted(ld)
 
     def forward(self, node_feat, L, label=None, mask=None):
         if mask is None:
@@ -1038,6 +1048,13 @@ class AdaLanczosNet(_LanczosNetBase):
         q = self._static_q1
         if q is not None and tuple(q.shape) == (B, N, 1) and q.device == device:
             return q
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # a CPU draw + host-to-device copy inside a HIP-graph capture would bake ONE start
+            # vector into every replay (or abort the capture): the step object must provide it
+            raise RuntimeError(
+                'AdaLanczosNet: forward under stream capture needs the static start-vector buffer '
+                '[%d, %d, 1] on %s (lanczosnet_amd.train.GraphedTrainStep sets `_static_q1`); got %s'
+                % (B, N, device, None if q is None else (tuple(q.shape), str(q.device))))
         return torch.randn(B, N, 1).to(device)
 
     def _fused_backward_supported(self):
@@ -1395,7 +1412,6 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         T64, Q64, lws = ops.ada_lanczos_layer_f64(Le, mask, q1, K)
         tcat3, pow_saved = ops.ada_t_powers_f64(T64, m.long_diffusion_dist)
         tcat, Q = tcat3.view(B, -1), Q64.float().contiguous()
-        spectrum = (lap_saved, Le, lws, pow_saved)
         keep = []
         DDp = m._ada_dense_filters(plan, tcat, keep=keep)
         Lp = ops.pack_laplacian(Lf)
@@ -1415,8 +1431,12 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask_u8, tiling=tiles,
                                        act_out=act)
         ctx.module, ctx.cap, ctx.rtot, ctx.rtot_ready = m, tiles[1], rtot, ev
-        ctx.n_keep, ctx.spectrum = len(keep), spectrum
+        # the fp64 spectrum state rides with the saved tensors (version counters, saved-tensor hooks,
+        # torch's own "backward a second time" error); only the distance tuple stays on ctx
+        (lap_x, lap_sv), (pow_T, pow_P, pow_dist) = lap_saved, pow_saved
+        ctx.n_keep, ctx.pow_dist = len(keep), pow_dist
         ctx.save_for_backward(node_feat, L, mask, q1, mask_u8, Lp, Q, DDp, act, tiles[0], n_mol, tcat,
+                              lap_x, lap_sv, Le, lws, pow_T, pow_P,
                               *[h for hs in keep for h in hs])
         return score
 
@@ -1424,7 +1444,8 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
     def backward(ctx, grad_score):
         m = ctx.module
         node_feat, L, mask, q1, mask_u8, Lp, Q, DDp, act, tile_buf, n_mol, tcat = ctx.saved_tensors[:12]
-        hs = ctx.saved_tensors[12:]
+        lap_x, lap_sv, Le, lws, pow_T, pow_P = ctx.saved_tensors[12:18]
+        hs = ctx.saved_tensors[18:]
         tiles = (tile_buf, ctx.cap)
         plan = m._plan_backward()
         B, N, K = Q.shape
@@ -1508,8 +1529,7 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
                           tcat=tcat, act=act, dy=dy)
         # ---- T powers -> Lanczos layer (the reverse sweep of the recurrence) -> learned Laplacian:
         #      three fp64 launches; then the embedding rows (one-hot^T dX as a GEMM, like LanczosNet)
-        lap_saved, Le, lws, pow_saved = ctx.spectrum
-        ctx.spectrum = None
+        lap_saved, pow_saved = (lap_x, lap_sv), (pow_T, pow_P, ctx.pow_dist)
         dT = ops.ada_t_powers_f64_backward(pow_saved, dtcat)
         dLe = ops.ada_lanczos_layer_f64_backward(Le, lws, dT, dQ.double())
         dstate = dx0[:, :N, :din0] + ops.ada_graph_laplacian_f64_backward(lap_saved, dLe).float()

@@ -37,8 +37,18 @@ class _ExtNamespace(object):
         return op(*args)
       except RuntimeError as e:
         msg = str(e)
-        if 'lanczosnet_hip error %d:' % _lib.LNZ_ENOTSUP in msg:
-          raise _lib.NotSupported(_lib.LNZ_ENOTSUP, msg.split('lanczosnet_hip error', 1)[1]) from None
+        # 'lanczosnet_hip error <code>: <message>' -> the ctypes binding's exception types, so that
+        # callers catching LnzError / NotSupported behave the same under both bindings
+        if 'lanczosnet_hip error ' in msg:
+          tail = msg.split('lanczosnet_hip error ', 1)[1]
+          try:
+            code = int(tail.split(':', 1)[0])
+          except ValueError:
+            raise e from None
+          text = tail.split(':', 1)[1].strip() if ':' in tail else tail
+          if code == _lib.LNZ_ENOTSUP:
+            raise _lib.NotSupported(code, text) from None
+          raise _lib.LnzError(code, text) from None
         raise
     return call
 

@@ -61,7 +61,14 @@ class GraphedTrainStep(object):
     and step counter); captured inside the graph, that initialisation would be replayed, resetting
     the state at every step."""
 
-    def __init__(self, model, optimizer, warmup=2):
+    def __init__(self, model, optimizer, warmup=2, scheduler=None):
+        if scheduler is not None:
+            # (accepted for callers written against the first version of this class, which stepped
+            # it once per batch: the reference steps its scheduler once per EPOCH — see above)
+            import warnings
+            warnings.warn('GraphedTrainStep(scheduler=...) is ignored: step the LR scheduler in the '
+                          'epoch loop like runner/qm8_runner.py:190 does', DeprecationWarning,
+                          stacklevel=2)
         for group in optimizer.param_groups:
             # optimizers with host-side step counters (Adam & co.) expose the flag; plain SGD has
             # no such state and captures as it is
@@ -72,6 +79,9 @@ class GraphedTrainStep(object):
             raise ValueError('GraphedTrainStep: warmup must be >= 1 (the optimizer state is created '
                              'by the first eager step; capturing it would reset it on every replay)')
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
+        # the module behind a DataParallel / DDP wrapper owns the plans and the start-vector buffer
+        self._core = model.module if hasattr(model, 'module') and \
+            isinstance(getattr(model, 'module'), torch.nn.Module) else model
         self._graphs = {}
         self._seen = {}
         self._q1 = {}
@@ -98,8 +108,8 @@ class GraphedTrainStep(object):
         graph = torch.cuda.CUDAGraph()
         # gradients must be allocated inside the graph's pool: drop the eager ones first
         self.optimizer.zero_grad(set_to_none=True)
-        if hasattr(self.model, 'invalidate_plan'):
-            self.model.invalidate_plan()
+        if hasattr(self._core, 'invalidate_plan'):
+            self._core.invalidate_plan()
         kw = {'pool': self._pool} if self._pool is not None else {}
         with torch.cuda.graph(graph, stream=self._stream, **kw):
             loss = self._eager_body(*static)
@@ -123,14 +133,14 @@ class GraphedTrainStep(object):
         (model/ada_lanczos_net.py:161).  A HIP graph cannot: the draw happens HERE, once per step
         like the reference's (same generator, same shape, same order), and is copied into the static
         device buffer the captured forward reads."""
-        if not hasattr(self.model, '_draw_q1'):
+        if not hasattr(self._core, '_draw_q1'):
             return
         B, N = int(node_feat.shape[0]), int(node_feat.shape[1])
         buf = self._q1.get((B, N))
         if buf is None:
             buf = self._q1[(B, N)] = torch.empty((B, N, 1), device=node_feat.device)
         buf.copy_(torch.randn(B, N, 1))   # (pageable source: the host side of the copy is synchronous)
-        self.model._static_q1 = buf
+        self._core._static_q1 = buf
 
     def __call__(self, node_feat, L, D, V, label, mask):
         inputs = (node_feat, L, D, V, label, mask)
@@ -159,7 +169,7 @@ class GraphedTrainStep(object):
     def _after_step(self):
         # the packed-parameter plans are keyed on tensor versions, which a replay does not bump:
         # whoever runs the module eagerly next (validation, another shape's warm-up) must re-pack
-        if hasattr(self.model, 'invalidate_plan'):
-            self.model.invalidate_plan()
-        if hasattr(self.model, '_draw_q1'):
-            self.model._static_q1 = None   # eager forwards draw their own start vectors again
+        if hasattr(self._core, 'invalidate_plan'):
+            self._core.invalidate_plan()
+        if hasattr(self._core, '_draw_q1'):
+            self._core._static_q1 = None   # eager forwards draw their own start vectors again

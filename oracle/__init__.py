@@ -14,7 +14,8 @@ together with the generating script `tests/golden/make_golden.py`
 (see tests/test_oracle_golden.py).
 """
 from .laplacian import laplacian_l4, laplacian_multi_l4, get_laplacian  # noqa: F401
-from .eigs import graph_laplacian_eigs, collate_eigs, spectral_projector  # noqa: F401
+from .eigs import (graph_laplacian_eigs, collate_eigs, spectral_projector,  # noqa: F401
+                   degenerate_cut, CUT_GAP)
 from .lanczos_net import (lanczos_net_forward, spectral_gains, make_lanczosnet_params,  # noqa: F401
                           lanczosnet_dims, DEFAULT_QM8_CFG)
 from .ada_lanczos import (ada_lanczos_layer, ada_graph_laplacian, ada_t_powers,  # noqa: F401

@@ -24,6 +24,22 @@ def graph_laplacian_eigs(adj, k=100, graph_laplacian_type='L4'):
   return eigs[idx[:k]], V[:, idx[:k]], L
 
 
+# A top-K cut (n > K) through a cluster of equal |lambda| keeps an arbitrary vector of the cluster:
+# basis dependent in the reference itself (LAPACK's choice), so such molecules are excluded from
+# every (D, V) / score comparison and counted.  ONE rule for bench.py and the tests:
+# the gap below which two eigenvalues of the fp32 Laplacian the device path is handed
+# (dataset/qm8.py:262 casts L to fp32) cannot be ordered — 1e-7, its rounding.  (On the QM8-sized
+# synthetic batches the gaps are bimodal: exact symmetries at 1e-16, everything else >= 2e-4.)
+CUT_GAP = 1.0e-7
+
+
+def degenerate_cut(eigs_sorted, K, gap=CUT_GAP):
+  """eigs_sorted: one molecule's eigenvalues in the reference order (descending |lambda|).  True
+  when the cut behind slot K - 1 separates two eigenvalues whose moduli differ by less than gap."""
+  e = np.abs(np.asarray(eigs_sorted, dtype=np.float64))
+  return bool(e.shape[0] > K and abs(e[K - 1] - e[K]) < gap)
+
+
 def collate_eigs(D_list, V_list, N, K):
   """dataset/qm8.py:264-291: pad V rows to N, cut / zero-pad eigen slots to K, cast fp32.
 

@@ -61,10 +61,8 @@ def check_ritz(D, V, Dref, Vref, n_nodes, Dfull, K, powers=(1, 5, 30), tol_d=1e-
   checked = 0
   for b in range(D.shape[0]):
     n = int(n_nodes[b])
-    if n > K:
-      full = np.abs(Dfull[b][:n])
-      if abs(full[K - 1] - full[K]) < 1e-9:
-        continue
+    if oracle.degenerate_cut(Dfull[b][:n], K):
+      continue
     checked += 1
     wd = max(wd, float(np.abs(D[b] - Dref[b]).max()))
     assert np.abs(D[b] - Dref[b]).max() < tol_d, (b, n, np.abs(D[b] - Dref[b]).max())

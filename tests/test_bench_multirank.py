@@ -38,3 +38,8 @@ def test_bench_two_ranks_one_json_line():
   # whole-job aggregate: 2 shards of 1024 molecules per step over the max-over-ranks step time
   assert abs(d['value'] - 2048 / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
   assert d['roofline']['tiles_per_launch'] > 0 and 'cpu_baseline' not in d
+  # the line explains itself: world size, backend and every rank's own step time
+  ex = d['config']['exchange']
+  assert ex['world'] == 2 and ex['gathered_equals_local'] is True
+  assert len(ex['ms_per_step_per_rank']) == 2
+  assert abs(max(ex['ms_per_step_per_rank']) - d['ms_per_step']) <= 1e-3 * d['ms_per_step'] + 1e-3

@@ -205,3 +205,22 @@ def test_fold_classes_from_comparison_bits():
   assert f(bit(2, 0), (0, 0, 2)) == (0, 0, 2)                       # already folded 1 stays with 0
   assert f(0, (0, 0, 2)) == (0, 0, 0)
   assert f(bit(1, 0) | bit(2, 0) | bit(2, 1) | bit(3, 0) | bit(3, 2), (0, 1, 2, 3)) == (0, 1, 2, 1)
+
+
+def test_ada_long_diffusion_dist_is_put_in_the_reference_order():
+  """The reference walks the powers in ascending order whatever the list says
+  (model/ada_lanczos_net.py:262-270): an unsorted list is sorted once, a duplicate refused."""
+  import pytest
+  import oracle
+  from lanczosnet_amd.model import AdaLanczosNet
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+
+  class Small(AdaLanczosNet):
+    _spectral_hidden = 8
+  cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1], long_diffusion_dist=[7, 5, 30],
+             hidden_dim=[128], num_layer=1)
+  net = Small(make_model_config(cfg, name='AdaLanczosNet'))
+  assert net.long_diffusion_dist == [5, 7, 30]
+  cfg['long_diffusion_dist'] = [5, 7, 5]
+  with pytest.raises(ValueError):
+    Small(make_model_config(cfg, name='AdaLanczosNet'))
