@@ -31,15 +31,25 @@ namespace {
 #ifndef LNZ_F32LIN_MI
 #define LNZ_F32LIN_MI 16
 #endif
-constexpr int BM = 128, BN = 128, BK = 32;
+// 1: the two wave groups of a workgroup run half a slice apart (see the kernel's PP branch)
+#ifndef LNZ_F32LIN_PP
+#define LNZ_F32LIN_PP 0
+#endif
+#ifndef LNZ_F32LIN_BK
+#define LNZ_F32LIN_BK 32
+#endif
+constexpr int BM = 128, BN = 128, BK = LNZ_F32LIN_BK;   // BK = 32 or 64 floats per slice
 constexpr int RB = BK * 4;                  // bytes per LDS row
 constexpr int RPP = 1024 / RB;              // rows per 1 KB copy piece (one global_load_lds)
 constexpr int PPO = 128 / RPP;              // pieces per operand slice
 constexpr int kSlice = 128 * RB;            // one operand slice: 128 rows x BK floats
 constexpr int kStage = 2 * kSlice;          // x, w
 constexpr size_t kLds = 2 * (size_t)kStage; // two stages
-// chunk c of row r sits in slot c ^ swz(r): 128-byte rows share a 256-byte bank row in pairs
-__device__ __forceinline__ int swz(const int r) { return (r >> 1) & 7; }
+// chunk c of row r sits in slot c ^ swz(r): 128-byte rows (BK = 32) share a 256-byte bank row in
+// pairs; a 256-byte row (BK = 64) is a bank row of its own and its 16 chunks are rotated by the
+// row number (the 16-lane service groups of ds_read_b128 hold rows {0-3, 12-15} at chunk c and rows
+// {4-11} at chunk c + 1: the two slot sets are complementary for every c)
+__device__ __forceinline__ int swz(const int r) { return BK == 32 ? (r >> 1) & 7 : r & 15; }
 
 // global -> LDS copies of one K slice: pieces q0 .. q0 + NQ - 1 (8 rows x 128 B each) of one
 // operand; rows beyond the operand's extent re-read its last row (never stored)
@@ -96,8 +106,29 @@ struct Mfma<16> {
   static __device__ __forceinline__ int row(int r, int kq) { return 4 * kq + r; }
 };
 
+// workgroup barrier that waits for this wave's LDS reads only (its global_load_lds copies stay in
+// flight across it) / for everything.  Inline assembly: __syncthreads() carries a release fence,
+// which hipcc lowers to vmcnt(0) as well; "memory" keeps the compiler's loads, stores and copies on
+// their side of it (register-only instructions are fenced by the sched_barrier around the calls).
+__device__ __forceinline__ void barrier_lgkm() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void barrier_all() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // WN = wavefronts along N: 4 = eight waves of 64 x 32 (two per SIMD), 2 = four waves of 64 x 64
-template <int WN, int MI>
+// PP = 1 (WN = 4): PING-PONG — the workgroup's waves 0..3 (group A, rows 0..63) and 4..7 (group B,
+//   rows 64..127) sit pairwise on the four SIMDs; B runs HALF A SLICE behind A, with a workgroup
+//   barrier every half slice.  When all eight waves meet at one barrier per slice (PP = 0), both
+//   waves of every SIMD stand still together and the matrix pipe idles for the barrier's round
+//   trip; half a slice apart, the wave that waits is covered by its partner, which is in the
+//   middle of a register-resident run of MFMAs and takes the whole pipe.
+template <int WN, int MI, int PP>
 __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
     const float* __restrict__ X, const int ldx, const float* __restrict__ W, const int ldw,
     const float* __restrict__ bias, const int relu, const int M, const int N, const int K,
@@ -210,9 +241,90 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // fragment read
     }
   };
-  for (int kt = 0; kt < T; kt += 2) {
-    slice(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 < T) slice(kt + 1, std::integral_constant<int, 1>{});
+  if constexpr (PP == 0) {
+    for (int kt = 0; kt < T; kt += 2) {
+      slice(kt, std::integral_constant<int, 0>{});
+      if (kt + 1 < T) slice(kt + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    // Barrier G(i), i = 0, 1, 2, ...: one every half slice.  A multiplies slice kt between G(2kt)
+    // and G(2kt + 2), B between G(2kt + 1) and G(2kt + 3).  Both read the fragments of slice
+    // kt + 1 (into the other register set) in the FIRST half of their slice kt: A in (2kt, 2kt + 1),
+    // B in (2kt + 1, 2kt + 2) — so stage (kt + 1) % 2 is read during (2kt, 2kt + 2), has to be
+    // complete at G(2kt) and is free again from G(2kt + 2).  Slice s is therefore copied in
+    // (2s - 4, 2s - 2), by every wave its usual share: A issues it behind G(2s - 4) = the start of
+    // its slice s - 2, B behind the same barrier = the middle of its slice s - 3, and each waits
+    // for its copies (vmcnt(0)) in front of G(2s - 2).  A wave's LDS reads are complete
+    // (lgkmcnt(0)) in front of every barrier.
+    static_assert(PP == 0 || (WN == 4 && NG % 2 == 0), "ping-pong: eight waves, even group count");
+    constexpr int H = NG / 2;
+    auto mfma_groups = [&](auto bufc, auto q0c) {
+      constexpr int buf = decltype(bufc)::value, q0 = decltype(q0c)::value;
+#pragma unroll
+      for (int q = q0; q < q0 + H; ++q) {
+#define LNZ_STEP(E)                                                               \
+  _Pragma("unroll") for (int a = 0; a < RT; ++a)                                  \
+  _Pragma("unroll") for (int b = 0; b < CT; ++b)                                  \
+      acc[a][b] = MM::run(af[buf][q][a].E, bf[buf][q][b].E, acc[a][b]);
+        LNZ_STEP(x)
+        LNZ_STEP(y)
+        LNZ_STEP(z)
+        LNZ_STEP(w)
+#undef LNZ_STEP
+      }
+    };
+    auto order_copies = [&]() {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // global_load_lds
+      }
+    };
+    auto order_reads = [&]() {
+#pragma unroll
+      for (int i = 0; i < NG * (RT + CT); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MI == 16 ? 2 : 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // fragment read
+      }
+    };
+    const int grp = __builtin_amdgcn_readfirstlane(wr);
+    if (grp == 0) {
+      auto slice_a = [&](const int kt, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        barrier_all();                                                        // G(2 kt)
+        stage_pieces<PW>(src, ld, rows_left, clamp_k(kt + 2), smem + buf * kStage + op * kSlice, lane, pq0);
+        load_frags(smem + (buf ^ 1) * kStage, std::integral_constant<int, buf ^ 1>{});
+        mfma_groups(bufc, std::integral_constant<int, 0>{});
+        order_copies();
+        order_reads();
+        barrier_lgkm();                                                       // G(2 kt + 1)
+        mfma_groups(bufc, std::integral_constant<int, H>{});
+      };
+      for (int kt = 0; kt < T; kt += 2) {
+        slice_a(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < T) slice_a(kt + 1, std::integral_constant<int, 1>{});
+      }
+      barrier_lgkm();                                                         // G(2 T)
+    } else {
+      barrier_lgkm();                                                         // G(0)
+      stage_pieces<PW>(src, ld, rows_left, clamp_k(2), smem + op * kSlice, lane, pq0);
+      auto slice_b = [&](const int kt, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        barrier_lgkm();                                                       // G(2 kt + 1)
+        load_frags(smem + (buf ^ 1) * kStage, std::integral_constant<int, buf ^ 1>{});
+        mfma_groups(bufc, std::integral_constant<int, 0>{});
+        order_reads();
+        barrier_all();                                                        // G(2 kt + 2)
+        stage_pieces<PW>(src, ld, rows_left, clamp_k(kt + 3), smem + (buf ^ 1) * kStage + op * kSlice,
+                         lane, pq0);
+        mfma_groups(bufc, std::integral_constant<int, H>{});
+        order_copies();
+      };
+      for (int kt = 0; kt < T; kt += 2) {
+        slice_b(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < T) slice_b(kt + 1, std::integral_constant<int, 1>{});
+      }
+    }
   }
 
   // ---- epilogue: register r of lane (j, kq) holds C[MM::row(r, kq)][j] of its MI x MI tile
@@ -294,7 +406,7 @@ extern "C" int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, 
   }
   hipStream_t s = (hipStream_t)stream;
   const int nsplit = partials ? lnz_f32_linear_splits(M, N, K) : 1;
-  auto kfn = f32_linear_kernel<LNZ_F32LIN_WN, LNZ_F32LIN_MI>;
+  auto kfn = f32_linear_kernel<LNZ_F32LIN_WN, LNZ_F32LIN_MI, (LNZ_F32LIN_WN == 4 ? LNZ_F32LIN_PP : 0)>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
   hipLaunchKernelGGL(kfn, dim3(grid, nsplit), dim3(128 * LNZ_F32LIN_WN), kLds, s, x, ldx, w, ldw, bias,
                      relu, M, N, K, tiles_n, bh, out, ldo, partials);

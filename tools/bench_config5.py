@@ -69,26 +69,34 @@ for name, planes in modes:
 if ref is not None:
   res['bf16_vs_split3_rel'] = float((s1 - ref).abs().max() / ref.abs().max())
   res['f16x2_vs_split3_rel'] = float((s2 - ref).abs().max() / ref.abs().max())
-# per-stage breakdown of the bf16 mode
-with torch.no_grad():
-  plan = net._plan_large(1)
-  G = ops.spectral_gains(D, net.long_diffusion_dist, net.num_layer, plan['mlp_pack'])
-  e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-  e[0].record()
-  Lb, Vb = ops.large_pack_operators(L, V, 1)
-  e[1].record()
-  work = ops.large_work_buffers(Lb)
-  state = X.contiguous()
-  e[1].record()
-  for t, lay in enumerate(plan['conv'][1]):
-    state = ops.large_conv_layer(state, lay['din'], Lb, Vb, V, lay['Wb'], lay['Wt'], G[t], lay['bias'], work)
-  e[2].record()
-  torch.cuda.synchronize()
-Nk = Lb.dims[1]
-layer_bytes = B * (2 * N * Nk * 2 + N * 64 * 2 + 2 * 128 * Nk * 2 + N * 128 * 4 * 2)
-res['bf16_stages'] = {'pack_ms': round(e[0].elapsed_time(e[1]), 3),
-                      'pack_GBps': round(B * (N * N * 2 * 4 + 2 * N * Nk * 2) / e[0].elapsed_time(e[1]) / 1e6, 1),
-                      'layers_ms': round(e[1].elapsed_time(e[2]), 3),
-                      'layer_stream_GBps': round(7 * layer_bytes / e[1].elapsed_time(e[2]) / 1e6, 1)}
+# per-stage breakdown of the bf16 mode: as the module runs it in the steady state (equal channels
+# folded: one operator packed and streamed, weight blocks summed) and with every channel packed
+def stages(classes):
+  src = sorted(set(classes))
+  rep = [src.index(c) for c in classes]
+  with torch.no_grad():
+    plan = net._plan_large(1, classes)
+    G = ops.spectral_gains(D, net.long_diffusion_dist, net.num_layer, plan['mlp_pack'])
+    neq = torch.zeros((1,), dtype=torch.int64, device='cuda')
+    ops.large_pack_operators(L, V, 1, chan_src=src, chan_rep=rep, neq=neq)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    Lb, Vb = ops.large_pack_operators(L, V, 1, chan_src=src, chan_rep=rep, neq=neq)
+    e[1].record()
+    work = ops.large_work_buffers(Lb)
+    state = X.contiguous()
+    e[1].record()
+    for t, lay in enumerate(plan['conv'][(1, tuple(classes))]):
+      state = ops.large_conv_layer(state, lay['din'], Lb, Vb, V, lay['Wb'], lay['Wt'], G[t], lay['bias'], work)
+    e[2].record()
+    torch.cuda.synchronize()
+  Nk, Cd = Lb.dims[1], Lb.shape[2]
+  layer_bytes = B * (Cd * N * Nk * 2 + N * 64 * 2 + Cd * 128 * Nk * 2 + N * 128 * 4 * 2)
+  return {'operators_streamed': Cd, 'pack_ms': round(e[0].elapsed_time(e[1]), 3),
+          'pack_GBps': round(B * (N * N * 2 * 4 + Cd * N * Nk * 2) / e[0].elapsed_time(e[1]) / 1e6, 1),
+          'layers_ms': round(e[1].elapsed_time(e[2]), 3),
+          'layer_stream_GBps': round(7 * layer_bytes / e[1].elapsed_time(e[2]) / 1e6, 1)}
+res['bf16_stages_folded'] = stages((0, 0))
+res['bf16_stages_every_channel'] = stages((0, 1))
 print(json.dumps({'workload': 'LanczosNetGeneral N=%d K=%d batch=%d' % (N, K, B),
                   'lanczos': 'lnz_lanczos_ritz_large' + ('_sym' if SYM else ''), **res}))
