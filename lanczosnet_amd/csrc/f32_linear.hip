@@ -51,25 +51,40 @@ constexpr size_t kLds = 2 * (size_t)kStage; // two stages
 // {4-11} at chunk c + 1: the two slot sets are complementary for every c)
 __device__ __forceinline__ int swz(const int r) { return BK == 32 ? (r >> 1) & 7 : r & 15; }
 
-// global -> LDS copies of one K slice: pieces q0 .. q0 + NQ - 1 (8 rows x 128 B each) of one
-// operand; rows beyond the operand's extent re-read its last row (never stored)
+// global -> LDS copies of one K slice: NQ pieces (RPP rows x RB bytes = 1 KB each) of one operand,
+// as buffer_load_dwordx4 ... lds: the descriptor (operand tile base, wave uniform) sits in SGPRs,
+// the per-lane byte offset of a piece (row * ld + chunk, k-independent) in ONE VGPR computed once
+// per launch, the slice's k offset in an SGPR and the LDS destination in M0 by scalar arithmetic —
+// nothing of a copy is computed on the VALU inside the main loop.  (First version:
+// global_load_lds with 64-bit per-lane addresses: two v_lshl_add_u64, a v_add3 and a
+// v_readfirstlane -> s_mov m0 in front of every copy; with the copies removed the 4096 x 4096
+// Linear ran 8 % faster — the ablation is in DESIGN.md.)
+struct PieceOffsets {
+  int v[8];
+};
 template <int NQ>
-__device__ __forceinline__ void stage_pieces(const float* __restrict__ src, const int ld,
-                                             const int rows_left, const int k0,
-                                             unsigned char* lds_op, const int lane, const int q0) {
+__device__ __forceinline__ PieceOffsets piece_offsets(const int ld, const int rows_left, const int lane,
+                                                      const int q0) {
   constexpr int CPR = BK / 4;                         // 16-B chunks per row
   const int rsub = lane / CPR, slot = lane % CPR;
+  PieceOffsets o;
 #pragma unroll
   for (int qq = 0; qq < NQ; ++qq) {
-    const int q = q0 + qq;
-    const int r = RPP * q + rsub;                     // row of the 128-row slice
+    const int r = RPP * (q0 + qq) + rsub;             // row of the 128-row slice
     const int chunk = slot ^ swz(r);                  // which 16-B chunk of the row lands in `slot`
-    const int rr = r < rows_left ? r : rows_left - 1;
-    const float* g = src + (int64_t)rr * ld + k0 + 4 * chunk;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)g,
-        (__attribute__((address_space(3))) void*)(lds_op + q * 1024), 16, 0, 0);
+    const int rr = r < rows_left ? r : rows_left - 1; // rows beyond the operand re-read its last row
+    o.v[qq] = (rr * ld + 4 * chunk) * 4;
   }
+  return o;
+}
+template <int NQ>
+__device__ __forceinline__ void stage_pieces(const __amdgpu_buffer_rsrc_t rsrc, const PieceOffsets& po,
+                                             const int k0, unsigned char* lds_op, const int q0) {
+#pragma unroll
+  for (int qq = 0; qq < NQ; ++qq)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        rsrc, (__attribute__((address_space(3))) void*)(lds_op + (q0 + qq) * 1024), 16, po.v[qq],
+        k0 * 4, 0, 0);
 }
 
 // (a native vector type, not HIP's float4: that struct's union members give its loads the
@@ -142,7 +157,8 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
   constexpr int KQ = 64 / MI;         // lane groups along k: a fragment group spans 4 KQ k-values
   constexpr int NG = BK / (4 * KQ);   // fragment groups per slice
   constexpr int PW = 2 * PPO / NW;    // copy pieces per wave and slice
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
   // XCD-aware tile order (f16x3_linear.hip): an XCD's workgroups take a bh x bw block of tiles
   int tm, tn;
@@ -165,6 +181,10 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
   const float* src = op == 0 ? X + (int64_t)m0 * ldx : W + (int64_t)n0 * ldw;
   const int ld = op == 0 ? ldx : ldw;
   const int rows_left = op == 0 ? M - m0 : N - n0;
+  // (the host checks that a 128-row operand tile spans < 2^31 bytes: 32-bit offsets)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+  const PieceOffsets po = piece_offsets<PW>(ld, rows_left, lane, pq0);
 
   typename MM::acc_t acc[RT][CT];
 #pragma unroll
@@ -186,6 +206,12 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
   // neither the LDS latency nor the copies' landing is ever waited for inside the MFMA stream
   // (first version: fragments read one 8-k block ahead, barrier -> read -> wait -> MFMA at every
   // slice: 0.282 ms at 1024 x 4096 x 4096).
+#ifdef LNZ_F32LIN_STAMP
+  // diagnostic build: cycles this wave spent waiting for its copies / at the slice barrier, and in
+  // the whole main loop; written to `part` (which the caller then has to provide)
+  long long st_vm = 0, st_bar = 0;
+  const long long st_t0 = __builtin_readcyclecounter();
+#endif
   f32x4 af[2][NG][RT], bf[2][NG][CT];
   auto load_frags = [&](const unsigned char* stage, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
@@ -198,8 +224,8 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
     }
   };
   auto clamp_k = [&](const int kt) { return (kt0 + (kt < T ? kt : T - 1)) * BK; };
-  stage_pieces<PW>(src, ld, rows_left, clamp_k(0), smem + op * kSlice, lane, pq0);
-  stage_pieces<PW>(src, ld, rows_left, clamp_k(1), smem + kStage + op * kSlice, lane, pq0);
+  stage_pieces<PW>(rsrc, po, clamp_k(0), smem + op * kSlice, pq0);
+  stage_pieces<PW>(rsrc, po, clamp_k(1), smem + kStage + op * kSlice, pq0);
   lnz::wait_vmcnt0();
   __syncthreads();
   load_frags(smem, std::integral_constant<int, 0>{});
@@ -211,18 +237,33 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
     // EXPLICITLY: the compiler does not see that the fragment reads depend on them (without the
     // explicit wait one of the two unrolled barriers came out with lgkmcnt(0) only — intermittent
     // wrong tiles at K >= 4064)
-    lnz::wait_vmcnt0();
-    __syncthreads();
-#ifndef LNZ_F32LIN_NOCOPY
-    stage_pieces<PW>(src, ld, rows_left, clamp_k(kt + 2), smem + buf * kStage + op * kSlice, lane, pq0);
+#ifdef LNZ_F32LIN_STAMP
+    const long long ts0 = __builtin_readcyclecounter();
 #endif
+    lnz::wait_vmcnt0();
+#ifdef LNZ_F32LIN_STAMP
+    const long long ts1 = __builtin_readcyclecounter();
+#endif
+#ifndef LNZ_F32LIN_NOBAR    // (timing ablation: racy)
+    __syncthreads();
+#endif
+#ifdef LNZ_F32LIN_STAMP
+    const long long ts2 = __builtin_readcyclecounter();
+    st_vm += ts1 - ts0;
+    st_bar += ts2 - ts1;
+#endif
+#ifndef LNZ_F32LIN_NOCOPY
+    stage_pieces<PW>(rsrc, po, clamp_k(kt + 2), smem + buf * kStage + op * kSlice, pq0);
+#endif
+#ifndef LNZ_F32LIN_NOREAD   // (timing ablation: wrong results)
     load_frags(smem + (buf ^ 1) * kStage, std::integral_constant<int, buf ^ 1>{});
+#endif
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
 #define LNZ_STEP(E)                                                               \
   _Pragma("unroll") for (int a = 0; a < RT; ++a)                                  \
   _Pragma("unroll") for (int b = 0; b < CT; ++b)                                  \
-      acc[a][b] = MM::run(af[buf][q][a].E, bf[buf][q][b].E, acc[a][b]);
+      acc[a][b] = MM::run(bf[buf][q][b].E, af[buf][q][a].E, acc[a][b]);
       LNZ_STEP(x)
       LNZ_STEP(y)
       LNZ_STEP(z)
@@ -265,7 +306,7 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
 #define LNZ_STEP(E)                                                               \
   _Pragma("unroll") for (int a = 0; a < RT; ++a)                                  \
   _Pragma("unroll") for (int b = 0; b < CT; ++b)                                  \
-      acc[a][b] = MM::run(af[buf][q][a].E, bf[buf][q][b].E, acc[a][b]);
+      acc[a][b] = MM::run(bf[buf][q][b].E, af[buf][q][a].E, acc[a][b]);
         LNZ_STEP(x)
         LNZ_STEP(y)
         LNZ_STEP(z)
@@ -287,36 +328,40 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // fragment read
       }
     };
+#ifdef LNZ_F32LIN_STAMP
+#define LNZ_BAR(fn) { const long long b0_ = __builtin_readcyclecounter(); fn(); st_bar += (long long)__builtin_readcyclecounter() - b0_; }
+#else
+#define LNZ_BAR(fn) fn();
+#endif
     const int grp = __builtin_amdgcn_readfirstlane(wr);
     if (grp == 0) {
       auto slice_a = [&](const int kt, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        barrier_all();                                                        // G(2 kt)
-        stage_pieces<PW>(src, ld, rows_left, clamp_k(kt + 2), smem + buf * kStage + op * kSlice, lane, pq0);
+        LNZ_BAR(barrier_all)                                                        // G(2 kt)
+        stage_pieces<PW>(rsrc, po, clamp_k(kt + 2), smem + buf * kStage + op * kSlice, pq0);
         load_frags(smem + (buf ^ 1) * kStage, std::integral_constant<int, buf ^ 1>{});
         mfma_groups(bufc, std::integral_constant<int, 0>{});
         order_copies();
         order_reads();
-        barrier_lgkm();                                                       // G(2 kt + 1)
+        LNZ_BAR(barrier_lgkm)                                                       // G(2 kt + 1)
         mfma_groups(bufc, std::integral_constant<int, H>{});
       };
       for (int kt = 0; kt < T; kt += 2) {
         slice_a(kt, std::integral_constant<int, 0>{});
         if (kt + 1 < T) slice_a(kt + 1, std::integral_constant<int, 1>{});
       }
-      barrier_lgkm();                                                         // G(2 T)
+      LNZ_BAR(barrier_lgkm)                                                         // G(2 T)
     } else {
-      barrier_lgkm();                                                         // G(0)
-      stage_pieces<PW>(src, ld, rows_left, clamp_k(2), smem + op * kSlice, lane, pq0);
+      LNZ_BAR(barrier_lgkm)                                                         // G(0)
+      stage_pieces<PW>(rsrc, po, clamp_k(2), smem + op * kSlice, pq0);
       auto slice_b = [&](const int kt, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        barrier_lgkm();                                                       // G(2 kt + 1)
+        LNZ_BAR(barrier_lgkm)                                                       // G(2 kt + 1)
         load_frags(smem + (buf ^ 1) * kStage, std::integral_constant<int, buf ^ 1>{});
         mfma_groups(bufc, std::integral_constant<int, 0>{});
         order_reads();
-        barrier_all();                                                        // G(2 kt + 2)
-        stage_pieces<PW>(src, ld, rows_left, clamp_k(kt + 3), smem + (buf ^ 1) * kStage + op * kSlice,
-                         lane, pq0);
+        LNZ_BAR(barrier_all)                                                        // G(2 kt + 2)
+        stage_pieces<PW>(rsrc, po, clamp_k(kt + 3), smem + (buf ^ 1) * kStage + op * kSlice, pq0);
         mfma_groups(bufc, std::integral_constant<int, H>{});
         order_copies();
       };
@@ -327,24 +372,53 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
     }
   }
 
-  // ---- epilogue: register r of lane (j, kq) holds C[MM::row(r, kq)][j] of its MI x MI tile
+#ifdef LNZ_F32LIN_STAMP
+  if (part && lane == 0 && nsplit == 1) {
+    long long* d = reinterpret_cast<long long*>(part) + ((int64_t)blockIdx.x * NW + wave) * 4;
+    d[0] = st_vm; d[1] = st_bar; d[2] = (long long)__builtin_readcyclecounter() - st_t0; d[3] = T;
+  }
+#endif
+  // ---- epilogue.  The MFMAs ran TRANSPOSED (A operand = the W fragment, B operand = the x
+  // fragment: D[n][m] = sum_k W[n][k] x[m][k], the same k-ordered fma chain per output element, so
+  // the same bits): register r of lane (j, kq) holds out[m = j][n = MM::row(r, kq)] of its tile, and
+  // four consecutive registers are four consecutive n of one output row — one 16-byte store per
+  // lane where the row-per-register layout needed four 4-byte stores (the store tail of all 256
+  // workgroups ending together is issue bound).
   const int j = lane % MI, kq = lane / MI;
+  float* const dst_base = nsplit > 1 ? part + (int64_t)blockIdx.y * M * N : out;
+  const int ldd = nsplit > 1 ? N : ldo;
+  const bool vec = (ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(dst_base) & 15) == 0;
 #pragma unroll
   for (int b = 0; b < CT; ++b) {
-    const int col = n0 + wc * (MI * CT) + MI * b + j;
-    const float bv = (bias && col < N) ? bias[col] : 0.0f;
 #pragma unroll
-    for (int a = 0; a < RT; ++a) {
+    for (int rg = 0; rg < MM::NR / 4; ++rg) {
+      const int nb = n0 + wc * (MI * CT) + MI * b + MM::row(4 * rg, kq);   // n of register 4 rg
+      float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (bias && nsplit == 1) {
 #pragma unroll
-      for (int r = 0; r < MM::NR; ++r) {
-        const int row = m0 + wr * 64 + MI * a + MM::row(r, kq);
-        if (row >= M || col >= N) continue;
-        if (nsplit > 1) {
-          part[((int64_t)blockIdx.y * M + row) * N + col] = acc[a][b][r];
+        for (int u = 0; u < 4; ++u) bv[u] = nb + u < N ? bias[nb + u] : 0.0f;
+      }
+#pragma unroll
+      for (int a = 0; a < RT; ++a) {
+        const int m = m0 + wr * 64 + MI * a + j;
+        if (m >= M || nb >= N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float x = acc[a][b][4 * rg + u];
+          if (nsplit == 1) {
+            x += bv[u];
+            if (relu) x = fmaxf(x, 0.0f);
+          }
+          v[u] = x;
+        }
+        float* dst = dst_base + (int64_t)m * ldd + nb;
+        if (vec && nb + 3 < N) {
+          *reinterpret_cast<f32x4*>(dst) = v;
         } else {
-          float v = acc[a][b][r] + bv;
-          if (relu) v = fmaxf(v, 0.0f);
-          out[(int64_t)row * ldo + col] = v;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (nb + u < N) dst[u] = v[u];
         }
       }
     }
@@ -393,6 +467,9 @@ extern "C" int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, 
               LNZ_ENOTSUP,
               "lnz_f32_linear: K=%d must be a multiple of %d and the operand rows 16-byte aligned",
               K, BK);
+  LNZ_REQUIRE(ldx < (1 << 22) && ldw < (1 << 22), LNZ_ENOTSUP,
+              "lnz_f32_linear: row strides %d / %d: a 128-row operand tile must span < 2^31 bytes",
+              ldx, ldw);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int grid = tiles_m * tiles_n;
   // block height of an XCD's share of the tiles (0: plain row-major order)
@@ -405,7 +482,11 @@ extern "C" int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, 
         bh = h;
   }
   hipStream_t s = (hipStream_t)stream;
+#ifdef LNZ_F32LIN_STAMP
+  const int nsplit = 1;   // diagnostic build: `partials` receives the stamps
+#else
   const int nsplit = partials ? lnz_f32_linear_splits(M, N, K) : 1;
+#endif
   auto kfn = f32_linear_kernel<LNZ_F32LIN_WN, LNZ_F32LIN_MI, (LNZ_F32LIN_WN == 4 ? LNZ_F32LIN_PP : 0)>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
   hipLaunchKernelGGL(kfn, dim3(grid, nsplit), dim3(128 * LNZ_F32LIN_WN), kLds, s, x, ldx, w, ldw, bias,
