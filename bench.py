@@ -407,8 +407,9 @@ def large_graph_leg(dev, A, D, V, reps=3):
 def ada_leg(dev, L, node_feat, mask_u8, reps=5):
   """BASELINE configs[3]: AdaLanczosNet forward (config/qm8_ada_lanczos_net.yaml architecture:
   short [1,2,3], long [5,7,10,20,30], K=20, 7 x 128) on the bench batch.  Per-stage HIP-event
-  times; the filter MLPs (2000-4096-4096-4096-2000 per layer, M = batch) are library GEMMs and
-  are priced against the fp32 MFMA peak."""
+  times; the filter MLPs (2000-4096-4096-4096-2000 per layer, M = batch) run on the hand-written
+  exact-fp32 Linear (lnz_f32_linear; the default since r04) and are priced against the fp32 MFMA
+  peak; the vendor-library mode is timed beside it."""
   from lanczosnet_amd.model import AdaLanczosNet
   cfg = dict(QM8_CFG, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30])
   torch.manual_seed(1234)
@@ -443,13 +444,15 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
         tot.append(ev[0].elapsed_time(ev[6]))
   acc /= reps
   ms = float(np.mean(tot))
-  # opt-in split-precision filter GEMMs (net.filter_gemm_mode = 'f16x3'): same stages, same inputs
+  # the other filter-GEMM modes on the same stages and inputs: the opt-in split-precision chain
+  # (net.filter_gemm_mode = 'f16x3') and the vendor library (hipBLASLt with its bias + ReLU
+  # epilogue, 'fp32': the default until r04, now the comparison)
+  default_mode = net.filter_gemm_mode
   split = None
-  with torch.no_grad():
-    score32 = score
-    DD32 = DDp
-    net.filter_gemm_mode = 'f16x3'
-    t16, f16 = [], []
+
+  def run_mode(mode):
+    net.filter_gemm_mode = mode
+    tt, ff = [], []
     for it in range(reps + 2):
       ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
       ev[0].record()
@@ -464,9 +467,21 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
       ev[3].record()
       torch.cuda.synchronize()
       if it >= 2:
-        t16.append(ev[0].elapsed_time(ev[3]))
-        f16.append(ev[1].elapsed_time(ev[2]))
-    net.filter_gemm_mode = 'fp32'
+        tt.append(ev[0].elapsed_time(ev[3]))
+        ff.append(ev[1].elapsed_time(ev[2]))
+    net.filter_gemm_mode = default_mode
+    return tt, ff, DDp, score
+  with torch.no_grad():
+    score32 = score
+    DD32 = DDp
+    tl, fl, DDl, scorel = run_mode('fp32')
+    library = {'mode': "filter_gemm_mode='fp32': the filter MLPs' Linears in hipBLASLt "
+                       '(torch._addmm_activation: bias + ReLU in the GEMM epilogue)',
+               'ms_per_step': round(float(np.mean(tl)), 4), 'filter_mlp_ms': round(float(np.mean(fl)), 4),
+               'filters_bit_identical_to_default': bool(torch.equal(DDl, DD32)),
+               'max_rel_dev_scores_vs_default': float((scorel - score32).abs().max() / score32.abs().max())}
+    del DDl, scorel
+    t16, f16, DDp, score = run_mode('f16x3')
     split = {'mode': "filter_gemm_mode='f16x3': each operand of the filter MLPs' Linears as two fp16 "
                      'pieces, x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 by the hand-written '
                      'lnz_f16x3_linear chain (csrc/f16x3_linear.hip: v_mfma_f32_32x32x16_f16, the four '
@@ -562,7 +577,11 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
                       '[5,7,10,20,30], 7 x 128, fp32, 351 M parameters' % B,
           'ms_per_step': round(ms, 4), 'value': round(B / ms * 1e3, 1), 'unit': 'molecules/s',
           'stage_ms': {k: round(float(v), 4) for k, v in zip(names, acc)},
-          'filter_mlp_gemm': {'library': 'hipBLASLt via torch.nn.functional.linear', 'flops': mlp_flops,
+          'filter_gemm_mode': default_mode,
+          'filter_mlp_gemm': {'kernel': 'lnz_f32_linear (csrc/f32_linear.hip: v_mfma_f32_16x16x4_f32, exact fp32, '
+                                        'bias + ReLU in the epilogue, stream-K for the last Linear) — no vendor '
+                                        'GEMM in the step' if default_mode == 'fp32_hip' else
+                                        'hipBLASLt via torch.nn.functional.linear', 'flops': mlp_flops,
                               'achieved': round(mlp_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                               'unit': 'TFLOP/s', 'frac': round(mlp_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                               'flops_reference_shapes': mlp_flops_reference,
@@ -573,7 +592,8 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
                                       'the input gather and the 7 output scatters'},
           'conv_kernel': 'lanczosnet_forward_kernel<4,10,2,0,0>: dense K x K filters in eigen space '
                          '(Q [sum_s DD_s (Q^T X W_s^T)]), pair tiles',
-          'split_precision_mode': split, 'train_step': train, 'parity': parity, 'finite': finite}
+          'library_filter_gemm_mode': library, 'split_precision_mode': split, 'train_step': train,
+          'parity': parity, 'finite': finite}
 
 
 def main():

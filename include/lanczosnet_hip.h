@@ -22,10 +22,12 @@
 extern "C" {
 #endif
 
-/* 3: + lnz_f32_linear, lnz_laplacian, the fp64 training kernels of the AdaLanczosNet spectrum
+/* 4: + lnz_large_pack_operators_fold, lnz_f32_linear_workspace_floats (stream-K inside
+ *    lnz_f32_linear: the partials argument changed its size and gained a zero-on-entry tail);
+ * 3: + lnz_f32_linear, lnz_laplacian, the fp64 training kernels of the AdaLanczosNet spectrum
  *    (lnz_ada_graph_laplacian_f64, lnz_ada_lanczos_layer_f64, lnz_ada_t_powers_f64 and their
  *    _backward);  2: + lnz_lanczos_ritz_ws / _workspace_bytes, lnz_f16x3_*. */
-#define LNZ_ABI_VERSION 3
+#define LNZ_ABI_VERSION 4
 #define LNZ_OK 0
 #define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
 #define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */
@@ -512,13 +514,22 @@ int lnz_f16x3_linear_splits(int M, int N, int K);
  * torch.nn.functional.linear + relu of model/ada_lanczos_net.py:271-272 = nn.Sequential of
  * nn.Linear / nn.ReLU): one launch per Linear,
  *   out = [relu]( X W^T + bias ),   X [M, K] (leading dimension ldx), W [N, K] (ldw), out [M, ldo],
- * fp32 operands on v_mfma_f32_32x32x2_f32, fp32 accumulation, bias + ReLU in the epilogue.
+ * fp32 accumulation, bias + ReLU in the epilogue;
  * K %% 32 == 0, ldx / ldw multiples of 4 and the base pointers 16-byte aligned (LNZ_ENOTSUP
  * otherwise); any M, N (partial tiles re-read the last row, never store).  bias may be NULL.
- * Split-K as for lnz_f16x3_linear: `partials` = lnz_f32_linear_splits(M, N, K) * M * N floats. */
+ * fp32 operands on v_mfma_f32_16x16x4_f32 (a k-ordered fma chain per output element: the result
+ * is bit-identical to hipBLASLt's fp32 GEMM on these shapes), operand slices copied global -> LDS
+ * by buffer_load ... lds.  Outputs with too few 128 x 128 tiles to fill the chip (the last Linear,
+ * N = 1056: 72 tiles) run STREAM-K inside the one launch: (tile, k-slice) units dealt evenly over
+ * lnz_f32_linear_splits(M, N, K) workgroups, partial tiles added by the tile's owner in a fixed
+ * order (bit-reproducible).  For those shapes `partials` = lnz_f32_linear_workspace_floats(M, N, K)
+ * floats, 16-byte aligned, whose LAST tiles-many words (the tile counters) must be ZERO on entry;
+ * they are zero again on return, so one zero-initialised workspace serves every later call on
+ * the same stream.  partials = NULL (or _splits == 1): one workgroup per tile. */
 int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, const float* bias, int relu,
                    int M, int N, int K, float* out, int ldo, float* partials, lnz_stream_t stream);
 int lnz_f32_linear_splits(int M, int N, int K);
+int64_t lnz_f32_linear_workspace_floats(int M, int N, int K);
 
 
 /* ---- next row (SURVEY.md 8f rank 1 + 3): device-side collate from a packed molecule shard ----

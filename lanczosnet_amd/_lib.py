@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LANCZOSNET_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblanczosnet_hip.so')
 
 LNZ_OK, LNZ_EINVAL, LNZ_ELAUNCH, LNZ_ENOTSUP = 0, -1, -2, -3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class LnzError(RuntimeError):
@@ -112,6 +112,7 @@ SIGNATURES = {
     'lnz_ada_lanczos_layer_f64_backward': (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_f32_linear': (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
     'lnz_f32_linear_splits': (C.c_int, [_I, _I, _I]),
+    'lnz_f32_linear_workspace_floats': (C.c_int64, [_I, _I, _I]),
     'lnz_unsorted_segment_sum_forward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'lnz_unsorted_segment_sum_backward': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
 }

@@ -975,14 +975,16 @@ class AdaLanczosNet(_LanczosNetBase):
     config (:35-38)."""
     filter_kind = 1
     _spectral_hidden = 4096
-    # 'fp32': the filter MLPs' GEMMs in fp32 (hipBLASLt);  'fp32_hip': the same exact-fp32 arithmetic
-    # on the hand-written lnz_f32_linear (csrc/f32_linear.hip: bias + ReLU fused; 8 % slower than the
-    # library's 4096 x 4096 kernel, DESIGN.md §4.6 — kept selectable);  'f16x3' (opt-in): each operand split
+    # 'fp32_hip' (default since r04): the filter MLPs on the hand-written exact-fp32 Linear
+    # lnz_f32_linear (csrc/f32_linear.hip: v_mfma_f32_16x16x4_f32, bias + ReLU fused, copies as
+    # buffer_load ... lds, stream-K for the last Linear) — filters bit-identical to the library's,
+    # the MLP chain as fast (DESIGN.md §4.6), no vendor GEMM in the step;  'fp32': the same GEMMs in
+    # hipBLASLt (kept for A/B runs);  'f16x3' (opt-in): each operand split
     # into two fp16 pieces and hi w_hi + hi w_lo + lo w_hi accumulated in fp32 by the hand-written
     # lnz_f16x3_linear chain (csrc/f16x3_linear.hip; needs |activations| < 6.5e4; parity-tested at
     # the same 1e-5 bar);  'f16x3_lib': the r02 form of the same arithmetic — ONE library fp16 GEMM
     # of three times the depth per Linear, fed by lnz_split_f16x3 (kept for A/B runs)
-    filter_gemm_mode = os.environ.get('LANCZOSNET_ADA_FILTER_GEMM', 'fp32')
+    filter_gemm_mode = os.environ.get('LANCZOSNET_ADA_FILTER_GEMM', 'fp32_hip')
     # False: evaluate the filter MLPs on the full 2000 inputs / outputs (A/B runs and tests)
     fold_filter_mlp = True
 

@@ -1154,12 +1154,31 @@ def f32_linear(x, w, bias=None, relu=False, out=None):
   assert out.dtype == torch.float32 and out.stride(1) == 1 and tuple(out.shape) == (M, N)
   b = None if bias is None else _f32c(bias)
   lib = _lib.load()
-  ns = lib.lnz_f32_linear_splits(M, N, K)
-  part = torch.empty((ns, M, N), dtype=torch.float32, device=x.device) if ns > 1 else None
+  part = _f32_linear_workspace(lib, M, N, K, x.device)
   with torch.cuda.device(x.device):
     _lib.check(lib.lnz_f32_linear(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(b), int(relu), M, N,
                                   K, _ptr(out), out.stride(0), _ptr(part), _stream()))
   return out
+
+
+_F32_LINEAR_WS = {}
+
+
+def _f32_linear_workspace(lib, M, N, K, device):
+  """Stream-K workspace of lnz_f32_linear (None for shapes that run one workgroup per tile): the
+  partial tiles + the tile counters, which have to be zero on entry and are zero again on return —
+  so ONE zero-initialised buffer per (device, stream, size) serves every call (no fill launch per
+  Linear).  Kernels on one stream run in order; another stream gets its own buffer."""
+  need = int(lib.lnz_f32_linear_workspace_floats(M, N, K))
+  if need == 0:
+    return None
+  key = (device.index, torch.cuda.current_stream(device).cuda_stream, need)
+  ws = _F32_LINEAR_WS.get(key)
+  if ws is None:
+    if len(_F32_LINEAR_WS) > 64:
+      _F32_LINEAR_WS.clear()
+    ws = _F32_LINEAR_WS[key] = torch.zeros((need,), dtype=torch.float32, device=device)
+  return ws
 
 
 # ----------------------------------------------------------------------------------------- R12
