@@ -151,8 +151,7 @@ def lanczos_large_leg(dev, B=256, N=2048, M=64, reps=3):
     adj = adj + adj.t() + eye
     d = adj.sum(1).rsqrt()
     A[b] = d[:, None] * adj * d[None, :]
-  from lanczosnet_amd import _lib
-  ws = torch.empty((_lib.load().lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8,
+  ws = torch.empty((ops._abi().lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8,
                    device=dev)
   ops.lanczos_ritz_large(A, M, M, workspace=ws)
   torch.cuda.synchronize()

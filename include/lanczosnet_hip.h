@@ -153,20 +153,20 @@ int lnz_large_pack_operators(const float* L, int64_t stride_b, int64_t stride_r,
 /* The same with CHANNEL FOLDING.  With one edge type (config/graph_lanczos_net.yaml:14) the
  * bond-type channel of the collated L is the simple-graph channel again (dataset/graph_data.py:
  * 225-262), and sum_c L_c X W_c^T = L (X (sum_c W_c)^T) over a class of equal operators: only the
- * n_src DISTINCT channels chan_src[0..n_src) (ascending) are packed, Lb [planes][B][n_src]...;
+ * n_src DISTINCT channels chan_src_host[0..n_src) (ascending) are packed, Lb [planes][B][n_src]...;
  * lnz_large_gemm1 / lnz_large_conv then run with C = n_src and the caller sums the mix-weight
- * blocks of a class.  chan_rep[c] (c < C) = packed slot whose source channel c is CLAIMED to equal
- * (chan_src[chan_rep[c]] == c: packed itself).  With neq != NULL (one device uint64, zeroed by the
+ * blocks of a class.  chan_rep_host[c] (c < C) = packed slot whose source channel c is CLAIMED to equal
+ * (chan_src_host[chan_rep_host[c]] == c: packed itself).  With neq != NULL (one device uint64, zeroed by the
  * caller) the kernel — which has all C values of every entry in hand anyway — verifies: bit
  * 8 c + c' is set when channel c differs from channel c' somewhere, compared for every folded
  * channel against its representative and for every packed channel against the channels packed
- * before it (chan_check[c] == 0 exempts channel c, e.g. a zero channel stride; NULL = all).  A
+ * before it (chan_check_host[c] == 0 exempts channel c, e.g. a zero channel stride; NULL = all).  A
  * failed claim means the caller must repack; packed channels that never differed may be folded in
- * the next batch.  chan_src == NULL: identity (C <= 8). */
+ * the next batch.  chan_src_host == NULL: identity (C <= 8). */
 int lnz_large_pack_operators_fold(const float* L, int64_t stride_b, int64_t stride_r,
                                   int64_t stride_c, int64_t stride_ch, const float* V, int B, int N,
-                                  int C, int K, int planes, const int32_t* chan_src, int n_src,
-                                  const int32_t* chan_rep, const int32_t* chan_check,
+                                  int C, int K, int planes, const int32_t* chan_src_host, int n_src,
+                                  const int32_t* chan_rep_host, const int32_t* chan_check_host,
                                   unsigned long long* neq, uint16_t* Lb, uint16_t* Vb,
                                   lnz_stream_t stream);
 int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t* Wf, int B, int N, int C,

@@ -1,6 +1,8 @@
 """The torch extension (`lanczosnet_amd/csrc/torch_ext.cpp` -> `liblanczosnet_torch.so`, in-tree):
-the forward step's ops registered with the dispatcher as `torch.ops.lanczosnet.*` on top of the C
-ABI library.  `build()` compiles it (host code only: g++ against torch's headers, linked to
+every kernel of the C ABI registered with the dispatcher as `torch.ops.lanczosnet.*` — the
+high-level ops of the forward step, `fused_launch` for the argument-block launches and one
+`raw_<name>` op per remaining entry point (`csrc/torch_ext_abi.inc`, generated from the header by
+`tools/gen_torch_ext.py`).  `build()` compiles it (host code only: g++ against torch's headers, linked to
 liblanczosnet_hip.so through $ORIGIN); `load()` registers it, loudly failing when it is not built —
 there is no fallback for the ops that go through it."""
 import os
@@ -16,10 +18,11 @@ def build(force=False):
   import torch
   from torch.utils import cpp_extension as ce
   src = os.path.join(CSRC, 'torch_ext.cpp')
+  inc = os.path.join(CSRC, 'torch_ext_abi.inc')   # generated: tools/gen_torch_ext.py
   hdr = os.path.join(os.path.dirname(_HERE), 'include', 'lanczosnet_hip.h')
   lib = os.path.join(CSRC, 'liblanczosnet_hip.so')
   if not force and os.path.exists(EXT_PATH) and \
-      os.path.getmtime(EXT_PATH) >= max(os.path.getmtime(p) for p in (src, hdr, lib)):
+      os.path.getmtime(EXT_PATH) >= max(os.path.getmtime(p) for p in (src, inc, hdr, lib)):
     return EXT_PATH
   tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
   inc = ce.include_paths('cuda') if ce.include_paths.__code__.co_argcount else ce.include_paths()

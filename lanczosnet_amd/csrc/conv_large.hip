@@ -788,8 +788,8 @@ extern "C" int64_t lnz_large_nk(int N) { return ((int64_t)N + KB - 1) / KB * KB;
 extern "C" int lnz_large_pack_operators_fold(const float* L, int64_t stride_b, int64_t stride_r,
                                              int64_t stride_c, int64_t stride_ch, const float* V,
                                              int B, int N, int C, int K, int planes,
-                                             const int32_t* chan_src, int n_src,
-                                             const int32_t* chan_rep, const int32_t* chan_check,
+                                             const int32_t* chan_src_host, int n_src,
+                                             const int32_t* chan_rep_host, const int32_t* chan_check_host,
                                              unsigned long long* neq, uint16_t* Lb, uint16_t* Vb,
                                              lnz_stream_t stream) {
   LNZ_REQUIRE(L && V && Lb && Vb && B > 0 && N > 0 && C > 0 && K > 0, LNZ_EINVAL,
@@ -798,27 +798,27 @@ extern "C" int lnz_large_pack_operators_fold(const float* L, int64_t stride_b, i
   LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_pack_operators: planes must be 1, 2 or 3");
   LNZ_REQUIRE(C <= 8, LNZ_ENOTSUP, "lnz_large_pack_operators: C=%d > 8 channels", C);
   LargeChanMap cm = {};
-  if (!chan_src) n_src = C;  // identity: every channel packed
-  const bool mapped = chan_src != nullptr;
-  LNZ_REQUIRE(!mapped || (chan_rep && n_src >= 1 && n_src <= C), LNZ_EINVAL,
-              "lnz_large_pack_operators_fold: channel map needs chan_rep and 1 <= n_src <= C "
+  if (!chan_src_host) n_src = C;  // identity: every channel packed
+  const bool mapped = chan_src_host != nullptr;
+  LNZ_REQUIRE(!mapped || (chan_rep_host && n_src >= 1 && n_src <= C), LNZ_EINVAL,
+              "lnz_large_pack_operators_fold: channel map needs chan_rep_host and 1 <= n_src <= C "
               "(C=%d n_src=%d)", C, n_src);
   if (mapped) {
     cm.nsrc = (signed char)n_src;
     for (int d = 0; d < n_src; ++d) {
-      LNZ_REQUIRE(chan_src[d] >= 0 && chan_src[d] < C && (d == 0 || chan_src[d] > chan_src[d - 1]),
-                  LNZ_EINVAL, "lnz_large_pack_operators_fold: chan_src must be ascending channels");
-      cm.src[d] = (signed char)chan_src[d];
+      LNZ_REQUIRE(chan_src_host[d] >= 0 && chan_src_host[d] < C && (d == 0 || chan_src_host[d] > chan_src_host[d - 1]),
+                  LNZ_EINVAL, "lnz_large_pack_operators_fold: chan_src_host must be ascending channels");
+      cm.src[d] = (signed char)chan_src_host[d];
     }
     for (int c = 0; c < C; ++c) {
-      LNZ_REQUIRE(chan_rep[c] >= 0 && chan_rep[c] < n_src && chan_src[chan_rep[c]] <= c, LNZ_EINVAL,
-                  "lnz_large_pack_operators_fold: chan_rep[%d] must name a packed slot of an "
+      LNZ_REQUIRE(chan_rep_host[c] >= 0 && chan_rep_host[c] < n_src && chan_src_host[chan_rep_host[c]] <= c, LNZ_EINVAL,
+                  "lnz_large_pack_operators_fold: chan_rep_host[%d] must name a packed slot of an "
                   "earlier (or the same) channel", c);
-      cm.rep[c] = (signed char)chan_rep[c];
-      cm.check[c] = (signed char)((neq && (!chan_check || chan_check[c])) ? 1 : 0);
+      cm.rep[c] = (signed char)chan_rep_host[c];
+      cm.check[c] = (signed char)((neq && (!chan_check_host || chan_check_host[c])) ? 1 : 0);
     }
     for (int d = 0; d < n_src; ++d)
-      LNZ_REQUIRE(chan_rep[chan_src[d]] == d, LNZ_EINVAL,
+      LNZ_REQUIRE(chan_rep_host[chan_src_host[d]] == d, LNZ_EINVAL,
                   "lnz_large_pack_operators_fold: a packed channel must represent itself");
   } else {
     cm.nsrc = (signed char)C;

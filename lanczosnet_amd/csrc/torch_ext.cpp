@@ -39,6 +39,117 @@ void need(const Tensor& t, at::ScalarType dt, const char* name, bool contiguous 
 
 const void* optr(const c10::optional<Tensor>& t) { return t.has_value() ? t->data_ptr() : nullptr; }
 
+// ---- helpers of the generated raw ops (torch_ext_abi.inc): device pointer of an optional tensor
+// (None -> NULL) after checking device and element type
+void* raw_ptr(const c10::optional<Tensor>& t, at::ScalarType dt, const char* name) {
+  if (!t.has_value()) return nullptr;
+  TORCH_CHECK(t->is_cuda(), "lanczosnet: ", name, " must be a HIP (cuda) tensor; there is no CPU path");
+  // (uint8 buffers double as bool masks; int32 as uint32 words)
+  TORCH_CHECK(t->scalar_type() == dt || (dt == at::kByte && t->scalar_type() == at::kBool),
+              "lanczosnet: ", name, " must be ", dt, ", got ", t->scalar_type());
+  return t->data_ptr();
+}
+void* raw_2byte(const c10::optional<Tensor>& t, const char* name) {   // bf16 / fp16 / int16 planes
+  if (!t.has_value()) return nullptr;
+  TORCH_CHECK(t->is_cuda(), "lanczosnet: ", name, " must be a HIP (cuda) tensor; there is no CPU path");
+  TORCH_CHECK(t->element_size() == 2, "lanczosnet: ", name, " must have 2-byte elements, got ",
+              t->scalar_type());
+  return t->data_ptr();
+}
+void* raw_any(const c10::optional<Tensor>& t, const char* name) {     // void* workspaces
+  if (!t.has_value()) return nullptr;
+  TORCH_CHECK(t->is_cuda(), "lanczosnet: ", name, " must be a HIP (cuda) tensor; there is no CPU path");
+  return t->data_ptr();
+}
+const Tensor* first_defined(std::initializer_list<const Tensor*> ts) {
+  for (const Tensor* t : ts)
+    if (t && t->defined()) return t;
+  return nullptr;
+}
+
+#include "torch_ext_abi.inc"
+
+// ---- the four launches that take an argument block (lnz_forward_args): forward (which = 0),
+// input_grad (1), messages (2), gain_grad (3).  `in` holds the read-only device operands in the
+// order of kIn below (None = NULL), `dims` the scalar fields in the order of kDim; the buffers a
+// launch writes are separate, alias-annotated arguments.
+enum { kNodeFeat, kNodeFeatF, kEmbedding, kMask, kLp, kV, kG, kWp, kBias, kWpHead, kBiasHead, kWp16,
+       kWp16Head, kLp16, kPlan, kNwg, kAct, kX0, kIdent, kRowOff, kNumIn };
+enum { dB, dN, dK, dNumLayer, dDin0, dDhid, dDout, dNLong, dNEdge, dNumAtom, dFilterKind, dGemmMode,
+       dPlanCap, dBwdDin0, dMsgLayer, kNumDim };
+void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at::IntArrayRef dims,
+                  at::IntArrayRef w_off, at::IntArrayRef b_off, at::IntArrayRef w16_off,
+                  at::IntArrayRef short_dist, const c10::optional<Tensor>& score,
+                  const c10::optional<Tensor>& state_out, const c10::optional<Tensor>& act_out,
+                  const c10::optional<Tensor>& dy, const c10::optional<Tensor>& dx0,
+                  const c10::optional<Tensor>& msg, const c10::optional<Tensor>& dgains) {
+  TORCH_CHECK((int)in.size() == kNumIn && (int)dims.size() == kNumDim && which >= 0 && which <= 3,
+              "lanczosnet::fused_launch: ", (int)kNumIn, " operands and ", (int)kNumDim, " dims expected");
+  TORCH_CHECK(w_off.size() <= 16 && b_off.size() <= 16 && w16_off.size() <= 16 && short_dist.size() <= 8);
+  auto opt = [&](int i) -> c10::optional<Tensor> { return in.get(i); };
+  const c10::optional<Tensor> v = opt(kV);
+  TORCH_CHECK(v.has_value() && v->dim() == 3, "lanczosnet::fused_launch: V [B,N,K] is required");
+  lnz_forward_args a = {};
+  a.B = dims[dB], a.N = dims[dN], a.K = dims[dK], a.num_layer = dims[dNumLayer];
+  a.din0 = dims[dDin0], a.dhid = dims[dDhid], a.dout = dims[dDout];
+  a.n_short = short_dist.size(), a.n_long = dims[dNLong], a.n_edge = dims[dNEdge];
+  a.num_atom = dims[dNumAtom], a.filter_kind = dims[dFilterKind], a.gemm_mode = dims[dGemmMode];
+  a.plan_wg_cap = dims[dPlanCap], a.bwd_din0 = dims[dBwdDin0], a.msg_layer = dims[dMsgLayer];
+  TORCH_CHECK(v->size(0) == a.B && v->size(1) == a.N && v->size(2) == a.K && v->is_contiguous(),
+              "lanczosnet::fused_launch: V does not match (B, N, K)");
+  for (size_t i = 0; i < short_dist.size(); ++i) a.short_dist[i] = (int32_t)short_dist[i];
+  for (size_t i = 0; i < w_off.size(); ++i) a.w_off[i] = w_off[i];
+  for (size_t i = 0; i < b_off.size(); ++i) a.b_off[i] = b_off[i];
+  for (size_t i = 0; i < w16_off.size(); ++i) a.w16_off[i] = w16_off[i];
+  a.node_feat = (const int64_t*)raw_ptr(opt(kNodeFeat), at::kLong, "node_feat");
+  a.node_feat_f = (const float*)raw_ptr(opt(kNodeFeatF), at::kFloat, "node_feat_f");
+  a.embedding = (const float*)raw_ptr(opt(kEmbedding), at::kFloat, "embedding");
+  a.mask = (const uint8_t*)raw_ptr(opt(kMask), at::kByte, "mask");
+  a.Lp = (const float*)raw_ptr(opt(kLp), at::kFloat, "Lp");
+  a.V = (const float*)raw_ptr(v, at::kFloat, "V");
+  a.G = (const float*)raw_ptr(opt(kG), at::kFloat, "G");
+  a.Wp = (const float*)raw_ptr(opt(kWp), at::kFloat, "Wp");
+  a.bias = (const float*)raw_ptr(opt(kBias), at::kFloat, "bias");
+  a.Wp_head = (const float*)raw_ptr(opt(kWpHead), at::kFloat, "Wp_head");
+  a.bias_head = (const float*)raw_ptr(opt(kBiasHead), at::kFloat, "bias_head");
+  a.Wp16 = raw_any(opt(kWp16), "Wp16");
+  a.Wp16_head = raw_any(opt(kWp16Head), "Wp16_head");
+  a.Lp16 = raw_any(opt(kLp16), "Lp16");
+  a.plan = (const int32_t*)raw_ptr(opt(kPlan), at::kInt, "plan");
+  a.n_wg = (const int32_t*)raw_ptr(opt(kNwg), at::kInt, "n_wg");
+  a.act = (const float*)raw_ptr(opt(kAct), at::kFloat, "act");
+  a.x0 = (const float*)raw_ptr(opt(kX0), at::kFloat, "x0");
+  a.ident = (const uint32_t*)raw_ptr(opt(kIdent), at::kInt, "ident");
+  a.row_off = (const int64_t*)raw_ptr(opt(kRowOff), at::kLong, "row_off");
+  // shapes of the operands whose extents the kernels take on trust
+  if (a.mask) TORCH_CHECK(opt(kMask)->numel() == (int64_t)a.B * a.N, "lanczosnet::fused_launch: mask is not [B,N]");
+  if (a.node_feat) TORCH_CHECK(opt(kNodeFeat)->numel() == (int64_t)a.B * a.N, "lanczosnet::fused_launch: node_feat is not [B,N]");
+  if (a.node_feat_f)
+    TORCH_CHECK(opt(kNodeFeatF)->numel() == (int64_t)a.B * a.N * a.din0, "lanczosnet::fused_launch: node_feat is not [B,N,din0]");
+  if (a.G)
+    TORCH_CHECK(opt(kG)->numel() == (int64_t)a.num_layer * a.B * a.n_long * a.K * (a.filter_kind == 1 ? a.K : 1) ||
+                    opt(kG)->numel() == (int64_t)a.num_layer * a.B * a.n_long * a.K,
+                "lanczosnet::fused_launch: G does not match (num_layer, B, n_long, K[, K])");
+  if (a.plan) TORCH_CHECK(opt(kPlan)->numel() >= 12 * (int64_t)a.plan_wg_cap, "lanczosnet::fused_launch: plan shorter than 12 * cap");
+  a.score = (float*)raw_ptr(score, at::kFloat, "score");
+  a.state_out = (float*)raw_ptr(state_out, at::kFloat, "state_out");
+  a.act_out = (float*)raw_ptr(act_out, at::kFloat, "act_out");
+  a.dy = (float*)raw_ptr(dy, at::kFloat, "dy");
+  a.dx0 = (float*)raw_ptr(dx0, at::kFloat, "dx0");
+  a.msg = (float*)raw_ptr(msg, at::kFloat, "msg");
+  a.dgains = (float*)raw_ptr(dgains, at::kFloat, "dgains");
+  const c10::DeviceGuard guard(v->device());
+  int rc;
+  switch (which) {
+    case 0: rc = lnz_lanczosnet_forward(&a, cur_stream()); break;
+    case 1: rc = lnz_lanczosnet_input_grad(&a, cur_stream()); break;
+    case 2: rc = lnz_lanczosnet_messages(&a, cur_stream()); break;
+    default: rc = lnz_lanczosnet_gain_grad(&a, cur_stream()); break;
+  }
+  check(rc, which == 0 ? "lanczosnet_forward" : which == 1 ? "lanczosnet_input_grad"
+                                             : which == 2 ? "lanczosnet_messages" : "lanczosnet_gain_grad");
+}
+
 // ---- R1 ------------------------------------------------------------------------------------
 Tensor laplacian_l4(const Tensor& adjs, const Tensor& n_nodes) {
   need(adjs, at::kFloat, "adjs");
@@ -157,6 +268,16 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
   need(bias_head, at::kFloat, "bias_head");
   TORCH_CHECK(V.dim() == 3 && (int64_t)w_off.size() >= dims[0] && (int64_t)b_off.size() >= dims[0] &&
               dims[0] <= 16 && short_dist.size() <= 8);
+  TORCH_CHECK(mask.numel() == V.size(0) * V.size(1), "lanczosnet::forward: mask is not [B,N]");
+  TORCH_CHECK(node_feat.size(0) == V.size(0) && node_feat.size(1) == V.size(1),
+              "lanczosnet::forward: node_feat leading dims do not match V's");
+  if (G.has_value())
+    TORCH_CHECK(G->dim() >= 4 && G->size(0) == dims[0] && G->size(1) == V.size(0) && G->size(2) == dims[4] &&
+                    G->size(3) == V.size(2) && (G->dim() == 4 || (G->dim() == 5 && G->size(4) == V.size(2))),
+                "lanczosnet::forward: G must be [num_layer, B, n_long, K] or [..., K, K]");
+  if (plan.has_value())
+    TORCH_CHECK(plan->numel() >= 12 * plan_cap + 1, "lanczosnet::forward: plan shorter than 12 * cap + 1");
+  TORCH_CHECK(bias.numel() >= b_off[dims[0] - 1] + dims[2], "lanczosnet::forward: bias shorter than b_off + dhid");
   const c10::DeviceGuard guard(V.device());
   lnz_forward_args a = {};
   a.B = V.size(0), a.N = V.size(1), a.K = V.size(2);
@@ -221,7 +342,9 @@ Tensor segment_sum_forward(const Tensor& data, const Tensor& segment_ids, int64_
 Tensor segment_sum_backward(const Tensor& grad_out, const Tensor& segment_ids, int64_t dim1) {
   need(grad_out, at::kFloat, "grad_out");
   need(segment_ids, at::kLong, "segment_ids");
-  TORCH_CHECK(grad_out.dim() == 3 && segment_ids.dim() == 2);
+  TORCH_CHECK(grad_out.dim() == 3 && segment_ids.dim() == 2 && segment_ids.size(0) == grad_out.size(0) &&
+                  segment_ids.size(1) == dim1,
+              "lanczosnet::unsorted_segment_sum_backward: segment_ids must be [B, dim1] for grad_out [B, S, D]");
   const c10::DeviceGuard guard(grad_out.device());
   Tensor gd = at::zeros({grad_out.size(0), dim1, grad_out.size(2)}, grad_out.options());
   check(lnz_unsorted_segment_sum_backward(grad_out.data_ptr<float>(), segment_ids.data_ptr<int64_t>(),
@@ -246,6 +369,10 @@ TORCH_LIBRARY(lanczosnet, m) {
         "Tensor bias_head, Tensor? plan, int plan_cap, int[] dims, int[] short_dist) -> Tensor");
   m.def("unsorted_segment_sum_forward(Tensor data, Tensor segment_ids, int num_segments) -> Tensor");
   m.def("unsorted_segment_sum_backward(Tensor grad_out, Tensor segment_ids, int dim1) -> Tensor");
+  m.def("fused_launch(int which, Tensor?[] operands, int[] dims, int[] w_off, int[] b_off, int[] w16_off, "
+        "int[] short_dist, Tensor(a!)? score, Tensor(b!)? state_out, Tensor(c!)? act_out, Tensor(d!)? dy, "
+        "Tensor(e!)? dx0, Tensor(f!)? msg, Tensor(g!)? dgains) -> ()");
+  LNZ_RAW_DEFS(m)
 }
 
 TORCH_LIBRARY_IMPL(lanczosnet, CUDA, m) {  // the CUDA dispatch key is HIP on a ROCm build
@@ -256,4 +383,11 @@ TORCH_LIBRARY_IMPL(lanczosnet, CUDA, m) {  // the CUDA dispatch key is HIP on a 
   m.impl("forward", forward);
   m.impl("unsorted_segment_sum_forward", segment_sum_forward);
   m.impl("unsorted_segment_sum_backward", segment_sum_backward);
+  m.impl("fused_launch", fused_launch);
+  LNZ_RAW_IMPLS_DEVICE(m)
+}
+
+// host-side size queries of the C ABI (no tensor arguments)
+TORCH_LIBRARY_IMPL(lanczosnet, CompositeExplicitAutograd, m) {
+  LNZ_RAW_IMPLS_HOST(m)
 }

@@ -8,52 +8,62 @@ Reference interfaces replaced (paths relative to the reference repo):
   lanczosnet_forward  model/lanczos_net.py:114-117,154-194
   unsorted_segment_sum operators/functions/unsorted_segment_sum.py:8-44
 """
-import ctypes as C
-
 import torch
 
 import os
 
 from . import _lib, _torch_ext
 
-# The forward step's ops (laplacian_l4, lanczos_ritz, prepare_batch, spectral_gains, the exact-fp32
-# lanczosnet_forward, unsorted_segment_sum_*) go through the torch extension
-# (torch.ops.lanczosnet.*: ATen checks, device guard, current stream, caching-allocator outputs, no
-# ctypes marshalling).  LNZ_OPS_BINDING=ctypes keeps them on the raw C ABI (A/B diagnostics; also
-# what a host without torch, like examples/ritz_pairs.c, uses).  Everything else — packing,
-# training launches, the large-graph and Ada ops — calls the C ABI through ctypes.
-_USE_EXT = os.environ.get('LNZ_OPS_BINDING', 'torch') != 'ctypes'
+# Every kernel is reached through the torch extension (csrc/torch_ext.cpp -> torch.ops.lanczosnet.*:
+# ATen dtype / device checks, device guard, the CURRENT HIP stream of the calling thread, no Python-
+# side pointer marshalling): the high-level ops that allocate their outputs (laplacian_l4,
+# lanczos_ritz, prepare_batch, spectral_gains, forward, unsorted_segment_sum_*), `fused_launch` for
+# the four launches that take an argument block, and one `raw_<name>` op per remaining C entry point
+# (generated from include/lanczosnet_hip.h by tools/gen_torch_ext.py).  The raw C ABI itself is what
+# a host without torch binds (examples/ritz_pairs.c; lanczosnet_amd/_lib.py for the ABI tests).
+
+
+def _map_error(e):
+  """'lanczosnet_hip error <code>: <message>' -> the binding's exception types."""
+  msg = str(e)
+  if 'lanczosnet_hip error ' not in msg:
+    return e
+  tail = msg.split('lanczosnet_hip error ', 1)[1]
+  try:
+    code = int(tail.split(':', 1)[0])
+  except ValueError:
+    return e
+  text = tail.split(':', 1)[1].strip() if ':' in tail else tail
+  text = text.split('\nException raised from', 1)[0].strip()
+  if code == _lib.LNZ_ENOTSUP:
+    return _lib.NotSupported(code, text)
+  return _lib.LnzError(code, text)
 
 
 class _ExtNamespace(object):
-  """torch.ops.lanczosnet with the C ABI's error codes mapped back to the binding's exception
-  types (the extension raises RuntimeError('... lanczosnet_hip error <code>: <message>'))."""
+  """torch.ops.lanczosnet (optionally with a name prefix) with the C ABI's error codes mapped back
+  to LnzError / NotSupported."""
+
+  def __init__(self, prefix=''):
+    self._prefix = prefix
 
   def __getattr__(self, name):
-    op = getattr(torch.ops.lanczosnet, name)
+    op = getattr(torch.ops.lanczosnet, self._prefix + name)
 
     def call(*args):
       try:
         return op(*args)
       except RuntimeError as e:
-        msg = str(e)
-        # 'lanczosnet_hip error <code>: <message>' -> the ctypes binding's exception types, so that
-        # callers catching LnzError / NotSupported behave the same under both bindings
-        if 'lanczosnet_hip error ' in msg:
-          tail = msg.split('lanczosnet_hip error ', 1)[1]
-          try:
-            code = int(tail.split(':', 1)[0])
-          except ValueError:
-            raise e from None
-          text = tail.split(':', 1)[1].strip() if ':' in tail else tail
-          if code == _lib.LNZ_ENOTSUP:
-            raise _lib.NotSupported(code, text) from None
-          raise _lib.LnzError(code, text) from None
-        raise
+        m = _map_error(e)
+        if m is e:
+          raise
+        raise m from None
+    self.__dict__[name] = call   # resolved once
     return call
 
 
 _EXT_NS = _ExtNamespace()
+_RAW_NS = _ExtNamespace('raw_')
 
 
 def _ext():
@@ -61,8 +71,11 @@ def _ext():
   return _EXT_NS
 
 
-def _stream():
-  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _abi():
+  """The C entry points as dispatcher ops: _abi().<name>(...) = lnz_<name>(..., current stream);
+  tensors go in as tensors (None = NULL), host int arrays as lists."""
+  _torch_ext.load()
+  return _RAW_NS
 
 
 def _need_cuda(*tensors):
@@ -73,10 +86,6 @@ def _need_cuda(*tensors):
       raise RuntimeError(
           'lanczosnet_amd: this path runs only on an AMD GPU (HIP); got a %s tensor. '
           'There is no CPU fallback.' % (getattr(t, 'device', type(t)),))
-
-
-def _ptr(t):
-  return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
 def _f32c(t):
@@ -91,13 +100,7 @@ def laplacian_l4(adjs, n_nodes):
   n_nodes = n_nodes.to(torch.int32).contiguous()
   B, N, N2, E = adjs.shape
   assert N == N2 and n_nodes.shape == (B,)
-  if _USE_EXT:
-    return _ext().laplacian_l4(adjs, n_nodes)
-  L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=adjs.device)
-  lib = _lib.load()
-  with torch.cuda.device(adjs.device):
-    _lib.check(lib.lnz_laplacian_l4(_ptr(adjs), _ptr(n_nodes), B, N, E, _ptr(L), _stream()))
-  return L
+  return _ext().laplacian_l4(adjs, n_nodes)
 
 
 def laplacian(adjs, n_nodes, kind='L4', alpha=0.5):
@@ -113,10 +116,9 @@ def laplacian(adjs, n_nodes, kind='L4', alpha=0.5):
   B, N, N2, E = adjs.shape
   assert N == N2 and n_nodes.shape == (B,)
   L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=adjs.device)
-  lib = _lib.load()
   with torch.cuda.device(adjs.device):
-    _lib.check(lib.lnz_laplacian(_ptr(adjs), _ptr(n_nodes), B, N, E, kinds.index(kind) + 1,
-                                 float(alpha), _ptr(L), _stream()))
+    _abi().laplacian(adjs, n_nodes, B, N, E, kinds.index(kind) + 1,
+                                 float(alpha), L)
   return L
 
 
@@ -137,25 +139,24 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   assert kernel in ('auto', 'workgroup', 'workgroup_ws', 'workgroup_ql')
   B, N, _ = A.shape
   n_nodes = n_nodes.to(torch.int32).contiguous()
-  if _USE_EXT and kernel == 'auto':
+  if kernel == 'auto':
     D, V, info = _ext().lanczos_ritz(A, n_nodes, K)
     return (D, V, info) if return_info else (D, V)
   D = torch.empty((B, K), dtype=torch.float32, device=A.device)
   V = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
   info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
   sb, sr, sc = A.stride()
-  lib = _lib.load()
   with torch.cuda.device(A.device):
     if kernel == 'auto' and N <= 32:
-      _lib.check(lib.lnz_lanczos_ritz(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D),
-                                      _ptr(V), _ptr(info), _stream()))
+      _abi().lanczos_ritz(A, sb, sr, sc, n_nodes, B, N, K, D,
+                                      V, info)
     else:
       # the workspace (if any) comes from torch's caching allocator, not from a hipMallocAsync
       flags = {'workgroup_ws': 1, 'workgroup_ql': 2}.get(kernel, 0)
-      need = B * N * (N | 1) * 8 if flags & 1 else lib.lnz_lanczos_ritz_workspace_bytes(B, N)
+      need = B * N * (N | 1) * 8 if flags & 1 else _abi().lanczos_ritz_workspace_bytes(B, N)
       ws = torch.empty((need,), dtype=torch.uint8, device=A.device) if need else None
-      _lib.check(lib.lnz_lanczos_ritz_ws(_ptr(A), sb, sr, sc, _ptr(n_nodes), B, N, K, _ptr(D),
-                                         _ptr(V), _ptr(info), _ptr(ws), need, flags, _stream()))
+      _abi().lanczos_ritz_ws(A, sb, sr, sc, n_nodes, B, N, K, D,
+                                         V, info, ws, need, flags)
   return (D, V, info) if return_info else (D, V)
 
 
@@ -168,9 +169,8 @@ def tridiag_eigh(diag, offdiag):
   B, M = d.shape
   R = torch.empty((B, M), dtype=torch.float64, device=d.device)
   Bm = torch.empty((B, M, M), dtype=torch.float64, device=d.device)
-  lib = _lib.load()
   with torch.cuda.device(d.device):
-    _lib.check(lib.lnz_tridiag_eigh(_ptr(d), _ptr(e), B, M, _ptr(R), _ptr(Bm), _stream()))
+    _abi().tridiag_eigh(d, e, B, M, R, Bm)
   return R, Bm
 
 
@@ -182,17 +182,15 @@ def lanczos_ritz_large(A, M, K, workspace=None, return_info=False, symmetric=Fal
   _need_cuda(A, workspace)
   assert A.dim() == 3 and A.dtype == torch.float32 and A.stride(2) == 1
   B, N, _ = A.shape
-  lib = _lib.load()
-  need = lib.lnz_lanczos_ritz_large_workspace_bytes(B, N)
+  need = _abi().lanczos_ritz_large_workspace_bytes(B, N)
   if workspace is None or workspace.numel() * workspace.element_size() < need:
     workspace = torch.empty((need,), dtype=torch.uint8, device=A.device)
   D = torch.empty((B, K), dtype=torch.float32, device=A.device)
   V = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
   info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
   with torch.cuda.device(A.device):
-    fn = lib.lnz_lanczos_ritz_large_sym if symmetric else lib.lnz_lanczos_ritz_large
-    _lib.check(fn(_ptr(A), A.stride(0), A.stride(1), B, N, M, K, _ptr(workspace), _ptr(D),
-                  _ptr(V), _ptr(info), _stream()))
+    fn = _abi().lanczos_ritz_large_sym if symmetric else _abi().lanczos_ritz_large
+    fn(A, A.stride(0), A.stride(1), B, N, M, K, workspace, D, V, info)
   return (D, V, info) if return_info else (D, V)
 
 
@@ -243,8 +241,7 @@ def large_pack_operators(L, V, planes=1, chan_src=None, chan_rep=None, chan_chec
   V = _f32c(V)
   B, N, _, Cn = L.shape
   K = V.shape[2]
-  lib = _lib.load()
-  Nk = lib.lnz_large_nk(N)
+  Nk = _abi().large_nk(N)
   RT = (N + 31) // 32
   dt = large_plane_dtype(planes)
   Cd = Cn if chan_src is None else len(chan_src)
@@ -252,14 +249,14 @@ def large_pack_operators(L, V, planes=1, chan_src=None, chan_rep=None, chan_chec
   Vb = torch.empty((planes, B, RT, 4, 64, 8), dtype=dt, device=L.device)
   Lb.dims = (N, Nk)
   sb, sr, sc, sch = L.stride()
-  i32 = lambda xs: (C.c_int32 * len(xs))(*[int(x) for x in xs]) if xs is not None else None  # noqa: E731
+  i32 = lambda xs: [int(x) for x in xs] if xs is not None else None  # noqa: E731
   if neq is not None:
     assert neq.dtype == torch.int64 and neq.numel() == 1
   with torch.cuda.device(L.device):
-    _lib.check(lib.lnz_large_pack_operators_fold(
-        _ptr(L), sb, sr, sc, sch, _ptr(V), B, N, Cn, K, planes, i32(chan_src), Cd,
-        i32(chan_rep if chan_src is not None else None), i32(chan_check), _ptr(neq), _ptr(Lb),
-        _ptr(Vb), _stream()))
+    _abi().large_pack_operators_fold(
+        L, sb, sr, sc, sch, V, B, N, Cn, K, planes, i32(chan_src), Cd,
+        i32(chan_rep if chan_src is not None else None), i32(chan_check), neq, Lb,
+        Vb)
   return Lb, Vb
 
 
@@ -269,10 +266,8 @@ def large_gemm1(X, din, Lb, Wf, Zt):
   planes, B, Cn = Lb.shape[:3]
   N, _ = Lb.dims
   assert X.dtype == torch.float32 and X.is_contiguous() and X.shape[0] == B and X.shape[1] == N
-  lib = _lib.load()
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_large_gemm1(_ptr(X), X.shape[2], din, _ptr(Wf), B, N, Cn, planes, _ptr(Zt),
-                                   _stream()))
+    _abi().large_gemm1(X, X.shape[2], din, Wf, B, N, Cn, planes, Zt)
 
 
 def large_spectral(X, din, Lb, V, G, Wt, Ybuf, Tt):
@@ -283,10 +278,9 @@ def large_spectral(X, din, Lb, V, G, Wt, Ybuf, Tt):
   K, S = V.shape[2], G.shape[1]
   assert V.dtype == torch.float32 and V.is_contiguous()
   assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
-  lib = _lib.load()
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_large_spectral(_ptr(X), X.shape[2], din, _ptr(V), _ptr(G), _ptr(Wt), B, N, K,
-                                      S, planes, _ptr(Ybuf), _ptr(Tt), _stream()))
+    _abi().large_spectral(X, X.shape[2], din, V, G, Wt, B, N, K,
+                                      S, planes, Ybuf, Tt)
 
 
 def large_conv(Lb, Vb, Zt, Tt, bias, relu=True, out=None):
@@ -296,10 +290,9 @@ def large_conv(Lb, Vb, Zt, Tt, bias, relu=True, out=None):
   N, _ = Lb.dims
   if out is None:
     out = torch.empty((B, N, 128), dtype=torch.float32, device=Lb.device)
-  lib = _lib.load()
   with torch.cuda.device(Lb.device):
-    _lib.check(lib.lnz_large_conv(_ptr(Lb), _ptr(Vb), _ptr(Zt), _ptr(Tt), _ptr(bias), B, N, Cn,
-                                  planes, int(bool(relu)), _ptr(out), _stream()))
+    _abi().large_conv(Lb, Vb, Zt, Tt, bias, B, N, Cn,
+                                  planes, int(bool(relu)), out)
   return out
 
 
@@ -345,11 +338,10 @@ def pack_rows_k8(W):
   _need_cuda(W)
   W = _f32c(W)
   rows, cols = W.shape
-  lib = _lib.load()
-  out = torch.empty((lib.lnz_packed_rows_k8_size(rows, cols),), dtype=torch.float32,
+  out = torch.empty((_abi().packed_rows_k8_size(rows, cols),), dtype=torch.float32,
                     device=W.device)
   with torch.cuda.device(W.device):
-    _lib.check(lib.lnz_pack_rows_k8(_ptr(W), rows, cols, cols, _ptr(out), _stream()))
+    _abi().pack_rows_k8(W, rows, cols, cols, out)
   return out
 
 
@@ -358,11 +350,10 @@ def pack_rows_f16x2(W):
   _need_cuda(W)
   W = _f32c(W)
   rows, cols = W.shape
-  lib = _lib.load()
-  out = torch.empty((lib.lnz_packed_rows_f16x2_bytes(rows, cols),), dtype=torch.uint8,
+  out = torch.empty((_abi().packed_rows_f16x2_bytes(rows, cols),), dtype=torch.uint8,
                     device=W.device)
   with torch.cuda.device(W.device):
-    _lib.check(lib.lnz_pack_rows_f16x2(_ptr(W), rows, cols, cols, _ptr(out), _stream()))
+    _abi().pack_rows_f16x2(W, rows, cols, cols, out)
   return out
 
 
@@ -371,9 +362,8 @@ def pack_bias_rows(bias):
   bias = _f32c(bias)
   rows = bias.shape[0]
   out = torch.empty((((rows + 31) // 32) * 1024,), dtype=torch.float32, device=bias.device)
-  lib = _lib.load()
   with torch.cuda.device(bias.device):
-    _lib.check(lib.lnz_pack_bias_rows(_ptr(bias), rows, _ptr(out), _stream()))
+    _abi().pack_bias_rows(bias, rows, out)
   return out
 
 
@@ -386,10 +376,9 @@ def pack_laplacian(L):
   # identity-channel bits ride along with the pack (read by lanczosnet_forward)
   Lp.ident = torch.empty((B,), dtype=torch.int32, device=L.device)
   sb, sr, sc, sch = L.stride()
-  lib = _lib.load()
   with torch.cuda.device(L.device):
-    _lib.check(lib.lnz_pack_laplacian_ident(_ptr(L), sb, sr, sc, sch, B, N, Cn, _ptr(Lp),
-                                            _ptr(Lp.ident), _stream()))
+    _abi().pack_laplacian_ident(L, sb, sr, sc, sch, B, N, Cn, Lp,
+                                            Lp.ident)
   return Lp
 
 
@@ -400,10 +389,8 @@ def pack_laplacian_f16x2(L):
   B, N, _, Cn = L.shape
   out = torch.empty((B * Cn * 4096,), dtype=torch.uint8, device=L.device)
   sb, sr, sc, sch = L.stride()
-  lib = _lib.load()
   with torch.cuda.device(L.device):
-    _lib.check(lib.lnz_pack_laplacian_f16x2(_ptr(L), sb, sr, sc, sch, B, N, Cn, _ptr(out),
-                                            _stream()))
+    _abi().pack_laplacian_f16x2(L, sb, sr, sc, sch, B, N, Cn, out)
   return out
 
 
@@ -424,20 +411,19 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
     tiles, rows = plan_batch(mask_u8, pairing_supported(plan), K, n_cu)
     return pack_laplacian_for(plan, Lf), tiles, rows
   _need_cuda(Lf, mask_u8)
-  lib = _lib.load()
   B, N, _, Cn = Lf.shape
   n_cu = n_cu or _n_cu(Lf.device)
-  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  cap = _abi().plan_wg_cap(B, n_cu)
   Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=Lf.device)
   Lp.ident = torch.empty((B,), dtype=torch.int32, device=Lf.device)
   buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=Lf.device)
   n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
   sb, sr, sc, sch = Lf.stride()
   with torch.cuda.device(Lf.device):
-    _lib.check(lib.lnz_pack_laplacian_plan(
-        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), n_cu,
-        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
-        _ptr(Lp.ident), _stream()))
+    _abi().pack_laplacian_plan(
+        Lf, sb, sr, sc, sch, B, N, Cn, Lp, mask_u8, n_cu,
+        int(pairing_supported(plan)), buf, n_wg, K, rows, n_rows,
+        Lp.ident)
   return Lp, (buf, cap), (rows, n_rows)
 
 
@@ -457,31 +443,13 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
     return Lp, tiles, rows, D, V
   _need_cuda(Lf, mask_u8, n_nodes)
   n_cu = n_cu or _n_cu(Lf.device)
-  if _USE_EXT:
-    nn = n_nodes if n_nodes.dtype == torch.int32 and n_nodes.is_contiguous() else \
-        n_nodes.to(torch.int32).contiguous()
-    Lp, ident, buf, D, V = _ext().prepare_batch(Lf, mask_u8, nn, K, n_cu,
-                                                bool(pairing_supported(plan)))
-    Lp.ident = ident
-    cap = (buf.numel() - 2 - B * K) // 12
-    return Lp, (buf, cap), (buf[12 * cap + 2:], buf[12 * cap + 1:12 * cap + 2]), D, V
-  lib = _lib.load()
-  cap = lib.lnz_plan_wg_cap(B, n_cu)
-  dev = Lf.device
-  Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=dev)
-  Lp.ident = torch.empty((B,), dtype=torch.int32, device=dev)
-  buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=dev)
-  n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
-  D = torch.empty((B, K), dtype=torch.float32, device=dev)
-  V = torch.empty((B, N, K), dtype=torch.float32, device=dev)
-  nn = n_nodes.to(torch.int32).contiguous()
-  sb, sr, sc, sch = Lf.stride()
-  with torch.cuda.device(dev):
-    _lib.check(lib.lnz_prepare_batch(
-        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
-        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
-        _ptr(D), _ptr(V), C.c_void_p(0), _ptr(Lp.ident), _stream()))
-  return Lp, (buf, cap), (rows, n_rows), D, V
+  nn = n_nodes if n_nodes.dtype == torch.int32 and n_nodes.is_contiguous() else \
+      n_nodes.to(torch.int32).contiguous()
+  Lp, ident, buf, D, V = _ext().prepare_batch(Lf, mask_u8, nn, K, n_cu,
+                                              bool(pairing_supported(plan)))
+  Lp.ident = ident
+  cap = (buf.numel() - 2 - B * K) // 12
+  return Lp, (buf, cap), (buf[12 * cap + 2:], buf[12 * cap + 1:12 * cap + 2]), D, V
 
 
 def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=None):
@@ -493,9 +461,8 @@ def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=Non
   B, N, _, Cn = Lf.shape
   _need_cuda(Lf, mask_u8, n_nodes, prev[0])
   assert plan.get('Wp16') is None and N <= 32 and N * N * Cn * 4 <= 20480
-  lib = _lib.load()
   n_cu = n_cu or _n_cu(Lf.device)
-  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  cap = _abi().plan_wg_cap(B, n_cu)
   dev = Lf.device
   Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=dev)
   Lp.ident = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -510,21 +477,20 @@ def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=Non
   S = len(dist)
   Gbuf = torch.empty((num_layer * Bp * S * K + 16,), dtype=torch.float32, device=dev)
   G = Gbuf[:num_layer * Bp * S * K].view(num_layer, Bp, S, K)
-  darr = (C.c_int32 * S)(*[int(x) for x in dist])
+  darr = [int(x) for x in dist]
   sb, sr, sc, sch = Lf.stride()
   with torch.cuda.device(dev):
-    _lib.check(lib.lnz_prepare_batch_prev_gains(
-        _ptr(Lf), sb, sr, sc, sch, B, N, Cn, _ptr(Lp), _ptr(mask_u8), _ptr(nn), n_cu,
-        int(pairing_supported(plan)), _ptr(buf), _ptr(n_wg), K, _ptr(rows), _ptr(n_rows),
-        _ptr(D), _ptr(V), _ptr(Lp.ident), _ptr(D_prev), Bp, _ptr(rows_prev), _ptr(n_rows_prev),
-        darr, S, num_layer, _ptr(mlp_pack), _ptr(G), _stream()))
+    _abi().prepare_batch_prev_gains(
+        Lf, sb, sr, sc, sch, B, N, Cn, Lp, mask_u8, nn, n_cu,
+        int(pairing_supported(plan)), buf, n_wg, K, rows, n_rows,
+        D, V, Lp.ident, D_prev, Bp, rows_prev, n_rows_prev,
+        darr, S, num_layer, mlp_pack, G)
   return Lp, (buf, cap), (rows, n_rows), D, V, G
 
 
 def pack_spectral_mlp(linears, S, out=None):
   """linears: 4 (weight, bias) pairs of one `spectral_filter[l]` Sequential -> packed buffer."""
-  lib = _lib.load()
-  size = lib.lnz_spectral_mlp_pack_size(S)
+  size = _abi().spectral_mlp_pack_size(S)
   ws = []
   for (w, b) in linears:
     _need_cuda(w, b)
@@ -532,15 +498,14 @@ def pack_spectral_mlp(linears, S, out=None):
   if out is None:
     out = torch.empty((size,), dtype=torch.float32, device=ws[0].device)
   with torch.cuda.device(ws[0].device):
-    _lib.check(lib.lnz_pack_spectral_mlp(*[_ptr(t) for t in ws], S, _ptr(out), _stream()))
+    _abi().pack_spectral_mlp(*[t for t in ws], S, out)
   return out
 
 
 def pack_spectral_mlp_layers(layers, S):
   """layers: per conv layer, the 4 (weight, bias) pairs of its `spectral_filter[l]` -> one
   [num_layer, pack_size] buffer, packed by ONE launch (lnz_pack_spectral_mlp_layers)."""
-  lib = _lib.load()
-  size = lib.lnz_spectral_mlp_pack_size(S)
+  size = _abi().spectral_mlp_pack_size(S)
   keep, ptrs = [], []
   for lins in layers:
     assert len(lins) == 4
@@ -548,10 +513,9 @@ def pack_spectral_mlp_layers(layers, S):
       _need_cuda(w, b)
       keep += [_f32c(w), _f32c(b)]
   dev = keep[0].device
-  arr = (C.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
   out = torch.empty((len(layers), size), dtype=torch.float32, device=dev)
   with torch.cuda.device(dev):
-    _lib.check(lib.lnz_pack_spectral_mlp_layers(arr, len(layers), S, _ptr(out), _stream()))
+    _abi().pack_spectral_mlp_layers(keep, len(layers), S, out)
   return out
 
 
@@ -567,28 +531,14 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True)
   B, K = D.shape
   S = len(dist)
   use_rows = rows is not None and mlp_pack is not None
-  if _USE_EXT:
-    return _ext().spectral_gains(D, [int(x) for x in dist], num_layer, mlp_pack,
-                                 rows[0] if use_rows else None, rows[1] if use_rows else None,
-                                 bool(zero_fill))
-  # + 64 B of slack: the split-precision forward reads gains as whole dwordx4 groups
-  alloc = torch.zeros if (use_rows and zero_fill) else torch.empty
-  Gbuf = alloc((num_layer * B * S * K + 16,), dtype=torch.float32, device=D.device)
-  G = Gbuf[:num_layer * B * S * K].view(num_layer, B, S, K)
-  darr = (C.c_int32 * S)(*[int(x) for x in dist])
-  lib = _lib.load()
-  with torch.cuda.device(D.device):
-    _lib.check(lib.lnz_spectral_gains_rows(
-        _ptr(D), B, K, darr, S, num_layer, 0 if mlp_pack is not None else 1, _ptr(mlp_pack),
-        _ptr(rows[0]) if use_rows else C.c_void_p(0), _ptr(rows[1]) if use_rows else C.c_void_p(0),
-        _ptr(G), _stream()))
-  return G
+  return _ext().spectral_gains(D, [int(x) for x in dist], num_layer, mlp_pack,
+                               rows[0] if use_rows else None, rows[1] if use_rows else None,
+                               bool(zero_fill))
 
 
 def collate_qm8(shard, ids, N, E, P):
   """lnz_collate_qm8: device arrays of a packed shard (dataset/packed.py) + molecule ids [B] ->
   padded batch dict (node_feat, node_mask, label, L [B,N,N,E+1], n_nodes)."""
-  lib = _lib.load()
   _need_cuda(shard['mol_off'], shard['edge_off'], shard['atoms'], shard['edges'], shard['labels'],
              ids)
   assert ids.dtype == torch.int64 and ids.is_contiguous()
@@ -600,10 +550,10 @@ def collate_qm8(shard, ids, N, E, P):
   label = torch.empty((B, P), dtype=torch.float32, device=dev)
   L = torch.empty((B, N, N, E + 1), dtype=torch.float32, device=dev)
   n_nodes = torch.empty((B,), dtype=torch.int32, device=dev)
-  _lib.check(lib.lnz_collate_qm8(_ptr(shard['mol_off']), _ptr(shard['edge_off']),
-                                 _ptr(shard['atoms']), _ptr(shard['edges']), _ptr(shard['labels']),
-                                 _ptr(ids), n_mol, B, N, E, P, _ptr(node_feat), _ptr(mask),
-                                 _ptr(label), _ptr(L), _ptr(n_nodes), _stream()))
+  _abi().collate_qm8(shard['mol_off'], shard['edge_off'],
+                                 shard['atoms'], shard['edges'], shard['labels'],
+                                 ids, n_mol, B, N, E, P, node_feat, mask,
+                                 label, L, n_nodes)
   return dict(node_feat=node_feat, node_mask=mask, label=label, L=L, n_nodes=n_nodes)
 
 
@@ -621,14 +571,13 @@ def plan_batch(mask_u8, allow_pairs, K, n_cu=None):
   """lnz_plan_batch: the tile plan of plan_tiles() plus the list of eigen slots that carry a Ritz
   pair.  Returns ((buf, cap), (gain_rows, n_gain_rows)); pass the first to lanczosnet_forward
   (tiling=) and the second to spectral_gains (rows=)."""
-  lib = _lib.load()
   B, N = mask_u8.shape
   n_cu = n_cu or _n_cu(mask_u8.device)
-  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  cap = _abi().plan_wg_cap(B, n_cu)
   buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=mask_u8.device)
   n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
-  _lib.check(lib.lnz_plan_batch(_ptr(mask_u8), B, N, n_cu, int(bool(allow_pairs)), _ptr(buf),
-                                _ptr(n_wg), K, _ptr(rows), _ptr(n_rows), _stream()))
+  _abi().plan_batch(mask_u8, B, N, n_cu, int(bool(allow_pairs)), buf,
+                                n_wg, K, rows, n_rows)
   return (buf, cap), (rows, n_rows)
 
 
@@ -636,13 +585,12 @@ def plan_tiles(mask_u8, allow_pairs, n_cu=None):
   """lnz_plan_tiles: small molecules share a 32-row tile; tiles are dealt evenly over one workgroup
   per CU.  Returns (buf, cap): int32 tensor [12*cap + 1] = cap workgroup entries of 4 slots x
   (molecule A, molecule B | -1, split row), followed by the number of workgroups in use."""
-  lib = _lib.load()
   B, N = mask_u8.shape
   n_cu = n_cu or _n_cu(mask_u8.device)
-  cap = lib.lnz_plan_wg_cap(B, n_cu)
+  cap = _abi().plan_wg_cap(B, n_cu)
   buf = torch.empty((12 * cap + 1,), dtype=torch.int32, device=mask_u8.device)
-  _lib.check(lib.lnz_plan_tiles(_ptr(mask_u8), B, N, n_cu, int(bool(allow_pairs)), _ptr(buf),
-                                C.c_void_p(buf.data_ptr() + 48 * cap), _stream()))
+  _abi().plan_tiles(mask_u8, B, N, n_cu, int(bool(allow_pairs)), buf,
+                                buf[12 * cap:])
   return buf, cap
 
 
@@ -668,55 +616,44 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   channel goes through its Laplacian fragments)."""
   _need_cuda(node_feat, Lp, V, G, mask)
   B, N, K = V.shape
-  if _USE_EXT and Lp.dtype == torch.float32 and plan.get('Wp16') is None and act_out is None \
-      and not return_state:
+  if Lp.dtype == torch.float32 and plan.get('Wp16') is None and act_out is None and not return_state:
     return _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident)
-  a = _lib.ForwardArgs()
-  a.B, a.N, a.K = B, N, K
-  a.num_layer = plan['num_layer']
-  a.din0, a.dhid, a.dout = plan['din0'], plan['dhid'], plan['dout']
-  a.n_short, a.n_long, a.n_edge = len(plan['short']), plan['n_long'], plan['n_edge']
-  for i, p in enumerate(plan['short']):
-    a.short_dist[i] = int(p)
+  ops_, dims = _fused_operands(plan, V)
+  emb = None
   if node_feat.dtype in (torch.int64,):
-    nf = node_feat.contiguous()
-    a.node_feat, a.node_feat_f = nf.data_ptr(), None
-    a.embedding = plan['embedding'].data_ptr()
-    a.num_atom = plan['embedding'].shape[0]
+    ops_[_IN['node_feat']] = node_feat.contiguous()
+    emb = ops_[_IN['embedding']] = plan['embedding']
+    dims[_DIM['num_atom']] = emb.shape[0]
   else:
     nf = node_feat.to(torch.float32)
     if nf.shape[-1] != plan['din0']:  # zero-pad feature columns to the kernel's 32-column groups
       assert nf.shape[-1] == plan['din0_raw']
       nf = torch.nn.functional.pad(nf, (0, plan['din0'] - nf.shape[-1]))
-    nf = nf.contiguous()
-    a.node_feat, a.node_feat_f, a.embedding, a.num_atom = None, nf.data_ptr(), None, 0
+    ops_[_IN['node_feat_f']] = nf.contiguous()
   mask_u8 = mask.to(torch.uint8).contiguous()
-  Vc = _f32c(V)
-  a.mask, a.V = mask_u8.data_ptr(), Vc.data_ptr()
+  ops_[_IN['mask']] = mask_u8
   if Lp.dtype == torch.uint8:   # split-precision fragments (pack_laplacian_f16x2)
-    a.Lp, a.Lp16 = None, Lp.data_ptr()
+    ops_[_IN['Lp16']] = Lp
   else:
-    a.Lp, a.Lp16 = Lp.data_ptr(), None
+    ops_[_IN['Lp']] = Lp
     ident = getattr(Lp, 'ident', None)  # identity-channel bits written by the pack kernels
     if ident is not None and use_ident:
-      a.ident = ident.data_ptr()
-  a.filter_kind = int(plan.get('filter_kind', 0))
+      ops_[_IN['ident']] = ident
+  fk = int(plan.get('filter_kind', 0))
   if G is not None:
-    want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if a.filter_kind == 1 else ())
+    want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if fk == 1 else ())
     assert tuple(G.shape) == want and G.is_contiguous() and G.dtype == torch.float32, \
         (tuple(G.shape), want)
-  a.G = G.data_ptr() if G is not None else None
-  a.Wp, a.bias = plan['Wp'].data_ptr(), plan['bias'].data_ptr()
-  for i in range(plan['num_layer']):
-    a.w_off[i] = plan['w_off'][i]
-    a.b_off[i] = plan['b_off'][i]
-  a.Wp_head, a.bias_head = plan['Wp_head'].data_ptr(), plan['bias_head'].data_ptr()
-  a.gemm_mode = 1 if plan.get('Wp16') is not None else 0
-  assert (a.gemm_mode == 1) == (Lp.dtype == torch.uint8), 'Lp pack does not match gemm_mode'
-  if a.gemm_mode == 1:
-    a.Wp16, a.Wp16_head = plan['Wp16'].data_ptr(), plan['Wp16_head'].data_ptr()
-    for i in range(plan['num_layer']):
-      a.w16_off[i] = plan['w16_off'][i]
+  ops_[_IN['G']] = G
+  ops_[_IN['Wp']], ops_[_IN['bias']] = plan['Wp'], plan['bias']
+  ops_[_IN['Wp_head']], ops_[_IN['bias_head']] = plan['Wp_head'], plan['bias_head']
+  gemm_mode = 1 if plan.get('Wp16') is not None else 0
+  dims[_DIM['gemm_mode']] = gemm_mode
+  assert (gemm_mode == 1) == (Lp.dtype == torch.uint8), 'Lp pack does not match gemm_mode'
+  w16_off = []
+  if gemm_mode == 1:
+    ops_[_IN['Wp16']], ops_[_IN['Wp16_head']] = plan['Wp16'], plan['Wp16_head']
+    w16_off = [int(x) for x in plan['w16_off'][:plan['num_layer']]]
   # Tile plan: small molecules share a 32-row tile and the tiles are dealt, balanced by cost, over
   # one workgroup per CU (the launch is a single round: it lasts as long as its busiest CU).
   if isinstance(tiling, tuple):
@@ -725,23 +662,47 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     assert tiling in ('auto', 'single')
     tiles, cap = plan_tiles(mask_u8, allow_pairs=(tiling == 'auto' and pairing_supported(plan)))
   if tiling != 'none':
-    a.plan = tiles.data_ptr()
-    a.n_wg = tiles.data_ptr() + 48 * cap
-    a.plan_wg_cap = cap
+    _set_plan(ops_, dims, tiles, cap)
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
-  a.score = score.data_ptr()
   if act_out is not None:
     assert tuple(act_out.shape) == (plan['num_layer'], B, 32, plan['dhid']) and \
         act_out.is_contiguous() and act_out.dtype == torch.float32
-    a.act_out = act_out.data_ptr()
   state = None
   if return_state:
     state = torch.zeros((B, 32, plan['dhid']), dtype=torch.float32, device=V.device)
-    a.state_out = state.data_ptr()
-  lib = _lib.load()
-  with torch.cuda.device(V.device):
-    _lib.check(lib.lnz_lanczosnet_forward(C.byref(a), _stream()))
+  nl = plan['num_layer']
+  _ext().fused_launch(0, ops_, dims, [int(x) for x in plan['w_off'][:nl]],
+                      [int(x) for x in plan['b_off'][:nl]], w16_off, [int(p) for p in plan['short']],
+                      score, state, act_out, None, None, None, None)
   return (score, state) if return_state else score
+
+
+# operand / scalar slots of torch.ops.lanczosnet.fused_launch (csrc/torch_ext.cpp: kIn / kDim)
+_IN = {k: i for i, k in enumerate(
+    ['node_feat', 'node_feat_f', 'embedding', 'mask', 'Lp', 'V', 'G', 'Wp', 'bias', 'Wp_head',
+     'bias_head', 'Wp16', 'Wp16_head', 'Lp16', 'plan', 'n_wg', 'act', 'x0', 'ident', 'row_off'])}
+_DIM = {k: i for i, k in enumerate(
+    ['B', 'N', 'K', 'num_layer', 'din0', 'dhid', 'dout', 'n_long', 'n_edge', 'num_atom', 'filter_kind',
+     'gemm_mode', 'plan_cap', 'bwd_din0', 'msg_layer'])}
+
+
+def _fused_operands(plan, V):
+  """Operand list and scalar fields common to the four argument-block launches."""
+  B, N, K = V.shape
+  ops_ = [None] * len(_IN)
+  ops_[_IN['V']] = _f32c(V)
+  dims = [0] * len(_DIM)
+  for k, v in (('B', B), ('N', N), ('K', K), ('num_layer', plan['num_layer']), ('din0', plan['din0']),
+               ('dhid', plan['dhid']), ('dout', plan['dout']), ('n_long', plan['n_long']),
+               ('n_edge', plan['n_edge']), ('filter_kind', int(plan.get('filter_kind', 0)))):
+    dims[_DIM[k]] = int(v)
+  return ops_, dims
+
+
+def _set_plan(ops_, dims, tiles, cap):
+  ops_[_IN['plan']] = tiles
+  ops_[_IN['n_wg']] = tiles[12 * cap:]
+  dims[_DIM['plan_cap']] = int(cap)
 
 
 def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
@@ -783,21 +744,12 @@ def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
 
 
 def _training_args(plan, Lp, V, G, mask_u8, tiling):
-  """Common part of the two training launches: sizes, operators, gains, tile plan."""
-  B, N, K = V.shape
-  a = _lib.ForwardArgs()
-  a.B, a.N, a.K = B, N, K
-  a.num_layer = plan['num_layer']
-  a.dhid, a.dout = plan['dhid'], plan['dout']
-  a.n_short, a.n_long, a.n_edge = len(plan['short']), plan['n_long'], plan['n_edge']
-  for i, p in enumerate(plan['short']):
-    a.short_dist[i] = int(p)
-  a.mask, a.V, a.Lp = mask_u8.data_ptr(), V.data_ptr(), Lp.data_ptr()
-  a.G = G.data_ptr() if G is not None else None
-  a.filter_kind, a.gemm_mode = int(plan.get('filter_kind', 0)), 0
+  """Common part of the training launches: sizes, operators, gains, tile plan."""
+  ops_, dims = _fused_operands(plan, V)
+  ops_[_IN['mask']], ops_[_IN['Lp']], ops_[_IN['G']] = mask_u8, Lp, G
   tiles, cap = tiling
-  a.plan, a.n_wg, a.plan_wg_cap = tiles.data_ptr(), tiles.data_ptr() + 48 * cap, cap
-  return a
+  _set_plan(ops_, dims, tiles, cap)
+  return ops_, dims
 
 
 def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling):
@@ -805,20 +757,16 @@ def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling):
   fills dy[0..num_layer-2] and dx0 [B,32,din0].  plan['Wp_t'] / plan['wt_off']: transposed packs in
   kernel-layer order (LanczosNet._plan_backward).  All buffers zero-initialised by the caller."""
   _need_cuda(Lp, V, G, mask_u8, act, dy, dx0)
-  a = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  ops_, dims = _training_args(plan, Lp, V, G, mask_u8, tiling)
   B = V.shape[0]
   L, dh = plan['num_layer'], plan['dhid']
   assert tuple(dy.shape) == (L, B, 32, dh) and dy.is_contiguous() and dy.dtype == torch.float32
   assert tuple(act.shape) == (L, B, 32, dh) and act.is_contiguous() and act.dtype == torch.float32
   assert tuple(dx0.shape) == (B, 32, plan['din0']) and dx0.is_contiguous()
-  a.din0, a.bwd_din0 = dh, plan['din0']
-  a.Wp = plan['Wp_t'].data_ptr()
-  for i in range(L):
-    a.w_off[i] = plan['wt_off'][i]
-  a.act, a.dy, a.dx0 = act.data_ptr(), dy.data_ptr(), dx0.data_ptr()
-  lib = _lib.load()
-  with torch.cuda.device(V.device):
-    _lib.check(lib.lnz_lanczosnet_input_grad(C.byref(a), _stream()))
+  dims[_DIM['din0']], dims[_DIM['bwd_din0']] = dh, plan['din0']
+  ops_[_IN['Wp']], ops_[_IN['act']] = plan['Wp_t'], act
+  _ext().fused_launch(1, ops_, dims, [int(x) for x in plan['wt_off'][:L]], [], [],
+                      [int(p) for p in plan['short']], None, None, None, dy, dx0, None, None)
 
 
 def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, row_off=None):
@@ -827,21 +775,20 @@ def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, ro
   int64 (exclusive scan of the node counts) msg is compact, [sum(n), C*d], real nodes only, and
   needs no initialisation."""
   _need_cuda(Lp, V, G, mask_u8, act, x0, msg)
-  a = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  ops_, dims = _training_args(plan, Lp, V, G, mask_u8, tiling)
   B = V.shape[0]
   d = plan['din0'] if layer == 0 else plan['dhid']
-  Cn = a.n_short + a.n_long + a.n_edge
+  Cn = len(plan['short']) + plan['n_long'] + plan['n_edge']
   assert msg.shape[1] == Cn * d and msg.is_contiguous() and msg.dtype == torch.float32
   assert row_off is not None or msg.shape[0] == B * 32
   assert tuple(x0.shape) == (B, 32, plan['din0']) and x0.is_contiguous()
-  a.din0 = plan['din0']
-  a.act, a.x0, a.msg, a.msg_layer = act.data_ptr(), x0.data_ptr(), msg.data_ptr(), layer
+  dims[_DIM['msg_layer']] = int(layer)
+  ops_[_IN['act']], ops_[_IN['x0']] = act, x0
   if row_off is not None:
     assert row_off.dtype == torch.int64 and row_off.is_contiguous() and row_off.numel() == B
-    a.row_off = row_off.data_ptr()
-  lib = _lib.load()
-  with torch.cuda.device(V.device):
-    _lib.check(lib.lnz_lanczosnet_messages(C.byref(a), _stream()))
+    ops_[_IN['row_off']] = row_off
+  _ext().fused_launch(2, ops_, dims, [], [], [], [int(p) for p in plan['short']], None, None, None,
+                      None, None, msg, None)
 
 
 def lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiling):
@@ -850,23 +797,18 @@ def lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiling):
   sum_o (V^T dY_l)[k][o] ((V^T X_l) W_{l,s}^T)[k][o], evaluated per node tile in eigen space.
   Uses the FORWARD weight packs of `plan`."""
   _need_cuda(V, mask_u8, act, x0, dy)
-  a = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  ops_, dims = _training_args(plan, Lp, V, G, mask_u8, tiling)
   B, _, K = V.shape
   L, dh, S = plan['num_layer'], plan['dhid'], plan['n_long']
   assert tuple(dy.shape) == (L, B, 32, dh) and dy.is_contiguous() and dy.dtype == torch.float32
   assert tuple(act.shape) == (L, B, 32, dh) and act.is_contiguous() and act.dtype == torch.float32
   assert tuple(x0.shape) == (B, 32, plan['din0']) and x0.is_contiguous()
-  a.din0 = plan['din0']
-  a.Wp = plan['Wp'].data_ptr()
-  for i in range(L):
-    a.w_off[i] = plan['w_off'][i]
+  ops_[_IN['Wp']], ops_[_IN['act']], ops_[_IN['x0']] = plan['Wp'], act, x0
   # zero-initialised: eigen slots beyond a molecule's row block (k >= split of a shared tile) are
   # dead (k >= n) and are not written
   dG = torch.zeros((L, B, K, S), dtype=torch.float32, device=V.device)
-  a.act, a.x0, a.dy, a.dgains = act.data_ptr(), x0.data_ptr(), dy.data_ptr(), dG.data_ptr()
-  lib = _lib.load()
-  with torch.cuda.device(V.device):
-    _lib.check(lib.lnz_lanczosnet_gain_grad(C.byref(a), _stream()))
+  _ext().fused_launch(3, ops_, dims, [int(x) for x in plan['w_off'][:L]], [], [],
+                      [int(p) for p in plan['short']], None, None, None, dy, None, None, dG)
   return dG
 
 
@@ -880,16 +822,15 @@ def ada_graph_laplacian(node_feat, embedding, L0):
   assert L0.dtype == torch.float32
   Le = torch.empty((B, N, N), dtype=torch.float32, device=L0.device)
   sb, sr, sc = L0.stride()
-  lib = _lib.load()
   if node_feat.dtype == torch.int64:
     emb = _f32c(embedding)
     nf = node_feat.contiguous()
-    args = (_ptr(nf), _ptr(emb), emb.shape[0], C.c_void_p(0), emb.shape[1])
+    args = (nf, emb, emb.shape[0], None, emb.shape[1])
   else:
     nf = _f32c(node_feat)
-    args = (C.c_void_p(0), C.c_void_p(0), 0, _ptr(nf), nf.shape[2])
+    args = (None, None, 0, nf, nf.shape[2])
   with torch.cuda.device(L0.device):
-    _lib.check(lib.lnz_ada_graph_laplacian(*args, _ptr(L0), sb, sr, sc, B, N, _ptr(Le), _stream()))
+    _abi().ada_graph_laplacian(*args, L0, sb, sr, sc, B, N, Le)
   return Le
 
 
@@ -903,10 +844,8 @@ def ada_lanczos_layer(A, mask, q1, K):
   m = mask.to(torch.uint8).contiguous() if mask is not None else None
   T = torch.empty((B, K, K), dtype=torch.float32, device=A.device)
   Q = torch.empty((B, N, K), dtype=torch.float32, device=A.device)
-  lib = _lib.load()
   with torch.cuda.device(A.device):
-    _lib.check(lib.lnz_ada_lanczos_layer(_ptr(A), _ptr(m), _ptr(q1), B, N, K, _ptr(T), _ptr(Q),
-                                         _stream()))
+    _abi().ada_lanczos_layer(A, m, q1, B, N, K, T, Q)
   return T, Q
 
 
@@ -918,14 +857,13 @@ def ada_lanczos_layer_f64(Le, mask, q1, K):
   B, N = Le.shape[0], Le.shape[1]
   mask_u8 = None if mask is None else mask.to(torch.uint8).contiguous()
   q = _f32c(q1).reshape(B, N)
-  lib = _lib.load()
   T = torch.empty((B, K, K), dtype=torch.float64, device=Le.device)
   Q = torch.empty((B, N, K), dtype=torch.float64, device=Le.device)
-  ws = torch.empty((int(lib.lnz_ada_lanczos_f64_workspace_doubles(B)),), dtype=torch.float64,
+  ws = torch.empty((int(_abi().ada_lanczos_f64_workspace_doubles(B)),), dtype=torch.float64,
                    device=Le.device)
   with torch.cuda.device(Le.device):
-    _lib.check(lib.lnz_ada_lanczos_layer_f64(_ptr(Le), _ptr(mask_u8), _ptr(q), B, N, K, _ptr(T), _ptr(Q),
-                                             _ptr(ws), _stream()))
+    _abi().ada_lanczos_layer_f64(Le, mask_u8, q, B, N, K, T, Q,
+                                             ws)
   return T, Q, ws
 
 
@@ -938,10 +876,9 @@ def ada_lanczos_layer_f64_backward(Le, ws, dT, dQ):
   dQ = dQ.to(torch.float64).contiguous()
   assert tuple(dT.shape) == (B, K, K) and tuple(dQ.shape) == (B, N, K)
   dLe = torch.empty_like(Le)
-  lib = _lib.load()
   with torch.cuda.device(Le.device):
-    _lib.check(lib.lnz_ada_lanczos_layer_f64_backward(_ptr(Le), B, N, K, _ptr(ws), _ptr(dT), _ptr(dQ),
-                                                      _ptr(dLe), _stream()))
+    _abi().ada_lanczos_layer_f64_backward(Le, B, N, K, ws, dT, dQ,
+                                                      dLe)
   return dLe
 
 
@@ -953,13 +890,12 @@ def ada_graph_laplacian_f64(state, L0):
   X = _f32c(state)
   B, N, D = X.shape
   assert L0.dtype == torch.float32 and tuple(L0.shape) == (B, N, N)
-  lib = _lib.load()
   Le = torch.empty((B, N, N), dtype=torch.float64, device=X.device)
-  sv = torch.empty((int(lib.lnz_ada_laplacian_f64_state_doubles(B, N)),), dtype=torch.float64,
+  sv = torch.empty((int(_abi().ada_laplacian_f64_state_doubles(B, N)),), dtype=torch.float64,
                    device=X.device)
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_ada_graph_laplacian_f64(_ptr(X), D, _ptr(L0), L0.stride(0), L0.stride(1),
-                                               L0.stride(2), B, N, _ptr(Le), _ptr(sv), _stream()))
+    _abi().ada_graph_laplacian_f64(X, D, L0, L0.stride(0), L0.stride(1),
+                                               L0.stride(2), B, N, Le, sv)
   return Le, (X, sv)
 
 
@@ -970,10 +906,8 @@ def ada_graph_laplacian_f64_backward(saved, dLe):
   B, N, D = X.shape
   dLe = dLe.to(torch.float64).contiguous()
   dX = torch.empty((B, N, D), dtype=torch.float64, device=X.device)
-  lib = _lib.load()
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_ada_graph_laplacian_f64_backward(_ptr(X), D, B, N, _ptr(sv), _ptr(dLe), _ptr(dX),
-                                                        _stream()))
+    _abi().ada_graph_laplacian_f64_backward(X, D, B, N, sv, dLe, dX)
   return dX
 
 
@@ -986,10 +920,9 @@ def ada_t_powers_f64(T, dist):
   pmax = max(int(x) for x in dist)
   out = torch.empty((B, K, S * K), dtype=torch.float32, device=T.device)
   P = torch.empty((B, pmax, K, K), dtype=torch.float64, device=T.device)
-  darr = (C.c_int32 * S)(*[int(x) for x in dist])
-  lib = _lib.load()
+  darr = [int(x) for x in dist]
   with torch.cuda.device(T.device):
-    _lib.check(lib.lnz_ada_t_powers_f64(_ptr(T), B, K, darr, S, _ptr(out), _ptr(P), _stream()))
+    _abi().ada_t_powers_f64(T, B, K, darr, S, out, P)
   return out, (T, P, tuple(int(x) for x in dist))
 
 
@@ -1001,11 +934,9 @@ def ada_t_powers_f64_backward(saved, dTcat):
   S = len(dist)
   g = _f32c(dTcat).reshape(B, K, S * K)
   dT = torch.empty_like(T)
-  darr = (C.c_int32 * S)(*dist)
-  lib = _lib.load()
+  darr = [int(x) for x in dist]
   with torch.cuda.device(T.device):
-    _lib.check(lib.lnz_ada_t_powers_f64_backward(_ptr(T), B, K, darr, S, _ptr(g), _ptr(P), _ptr(dT),
-                                                 _stream()))
+    _abi().ada_t_powers_f64_backward(T, B, K, darr, S, g, P, dT)
   return dT
 
 
@@ -1016,10 +947,9 @@ def ada_t_powers(T, dist):
   B, K, _ = T.shape
   S = len(dist)
   out = torch.empty((B, K, S * K), dtype=torch.float32, device=T.device)
-  darr = (C.c_int32 * S)(*[int(x) for x in dist])
-  lib = _lib.load()
+  darr = [int(x) for x in dist]
   with torch.cuda.device(T.device):
-    _lib.check(lib.lnz_ada_t_powers(_ptr(T), B, K, darr, S, _ptr(out), _stream()))
+    _abi().ada_t_powers(T, B, K, darr, S, out)
   return out
 
 
@@ -1030,9 +960,8 @@ def ada_symmetrize_filters(DD, K, S, out=None):
   B = DD.shape[0]
   if out is None:
     out = torch.empty((B, S, K, K), dtype=torch.float32, device=DD.device)
-  lib = _lib.load()
   with torch.cuda.device(DD.device):
-    _lib.check(lib.lnz_ada_symmetrize_filters(_ptr(DD), B, K, S, _ptr(out), _stream()))
+    _abi().ada_symmetrize_filters(DD, B, K, S, out)
   return out
 
 
@@ -1046,10 +975,9 @@ def split_f16x3(X, bias=None, alpha=1.0, relu=False, Kp=None, out=None):
   if out is None:
     out = torch.empty((M, 3 * Kp), dtype=torch.float16, device=X.device)
   b = None if bias is None else _f32c(bias)
-  lib = _lib.load()
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_split_f16x3(_ptr(X), M, K, X.stride(0), _ptr(b), float(alpha), int(relu), Kp,
-                                   _ptr(out), _stream()))
+    _abi().split_f16x3(X, M, K, X.stride(0), b, float(alpha), int(relu), Kp,
+                                   out)
   return out
 
 
@@ -1095,10 +1023,9 @@ def f16x3_split(X, Kp=None, scale=1.0, out=None):
   Kp = Kp or (K + 63) // 64 * 64
   if out is None:
     out = torch.empty((2, Mp, Kp), dtype=torch.float16, device=X.device)
-  lib = _lib.load()
   with torch.cuda.device(X.device):
-    _lib.check(lib.lnz_f16x3_split(_ptr(X), M, K, X.stride(0), float(scale), Mp, Kp, _ptr(out[0]),
-                                   _ptr(out[1]), _stream()))
+    _abi().f16x3_split(X, M, K, X.stride(0), float(scale), Mp, Kp, out[0],
+                                   out[1])
   return out
 
 
@@ -1115,22 +1042,21 @@ def f16x3_linear(xp, wp, bias, M, N, alpha=1.0 / F16X3_WEIGHT_SCALE, relu=True, 
     out_planes = torch.zeros((2, xp.shape[1], (N + 63) // 64 * 64), dtype=torch.float16,
                              device=xp.device)
   b = None if bias is None else _f32c(bias)
-  lib = _lib.load()
-  ns = lib.lnz_f16x3_linear_splits(M, N, K)   # split-K scratch for shapes with few output tiles
+  ns = _abi().f16x3_linear_splits(M, N, K)   # split-K scratch for shapes with few output tiles
   part = torch.empty((ns, M, N), dtype=torch.float32, device=xp.device) if ns > 1 else None
   with torch.cuda.device(xp.device):
     if out_f32 is not None:
       assert out_f32.dtype == torch.float32 and out_f32.stride(1) == 1 and out_f32.shape[1] >= N
-      _lib.check(lib.lnz_f16x3_linear(_ptr(xp[0]), _ptr(xp[1]), xp.stride(1), _ptr(wp[0]), _ptr(wp[1]),
-                                      wp.stride(1), _ptr(b), float(alpha), int(relu), M, N, K,
-                                      C.c_void_p(0), C.c_void_p(0), _ptr(out_f32), out_f32.stride(0),
-                                      _ptr(part), _stream()))
+      _abi().f16x3_linear(xp[0], xp[1], xp.stride(1), wp[0], wp[1],
+                                      wp.stride(1), b, float(alpha), int(relu), M, N, K,
+                                      None, None, out_f32, out_f32.stride(0),
+                                      part)
       return out_f32
     assert out_planes.dtype == torch.float16 and out_planes.shape[2] >= N
-    _lib.check(lib.lnz_f16x3_linear(_ptr(xp[0]), _ptr(xp[1]), xp.stride(1), _ptr(wp[0]), _ptr(wp[1]),
-                                    wp.stride(1), _ptr(b), float(alpha), int(relu), M, N, K,
-                                    _ptr(out_planes[0]), _ptr(out_planes[1]), C.c_void_p(0),
-                                    out_planes.stride(1), _ptr(part), _stream()))
+    _abi().f16x3_linear(xp[0], xp[1], xp.stride(1), wp[0], wp[1],
+                                    wp.stride(1), b, float(alpha), int(relu), M, N, K,
+                                    out_planes[0], out_planes[1], None,
+                                    out_planes.stride(1), part)
   return out_planes
 
 
@@ -1153,23 +1079,22 @@ def f32_linear(x, w, bias=None, relu=False, out=None):
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
   assert out.dtype == torch.float32 and out.stride(1) == 1 and tuple(out.shape) == (M, N)
   b = None if bias is None else _f32c(bias)
-  lib = _lib.load()
-  part = _f32_linear_workspace(lib, M, N, K, x.device)
+  part = _f32_linear_workspace(M, N, K, x.device)
   with torch.cuda.device(x.device):
-    _lib.check(lib.lnz_f32_linear(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(b), int(relu), M, N,
-                                  K, _ptr(out), out.stride(0), _ptr(part), _stream()))
+    _abi().f32_linear(x, x.stride(0), w, w.stride(0), b, int(relu), M, N,
+                                  K, out, out.stride(0), part)
   return out
 
 
 _F32_LINEAR_WS = {}
 
 
-def _f32_linear_workspace(lib, M, N, K, device):
+def _f32_linear_workspace(M, N, K, device):
   """Stream-K workspace of lnz_f32_linear (None for shapes that run one workgroup per tile): the
   partial tiles + the tile counters, which have to be zero on entry and are zero again on return —
   so ONE zero-initialised buffer per (device, stream, size) serves every call (no fill launch per
   Linear).  Kernels on one stream run in order; another stream gets its own buffer."""
-  need = int(lib.lnz_f32_linear_workspace_floats(M, N, K))
+  need = int(_abi().f32_linear_workspace_floats(M, N, K))
   if need == 0:
     return None
   key = (device.index, torch.cuda.current_stream(device).cuda_stream, need)
@@ -1187,14 +1112,7 @@ def unsorted_segment_sum_forward(data, segment_ids, num_segments):
   data = _f32c(data)
   ids = segment_ids.to(torch.int64).contiguous()
   B, D1, D2 = data.shape
-  if _USE_EXT:
-    return _ext().unsorted_segment_sum_forward(data, ids, num_segments)
-  out = torch.zeros((B, num_segments, D2), dtype=torch.float32, device=data.device)
-  lib = _lib.load()
-  with torch.cuda.device(data.device):
-    _lib.check(lib.lnz_unsorted_segment_sum_forward(_ptr(data), _ptr(ids), B, D1, D2,
-                                                    num_segments, _ptr(out), _stream()))
-  return out
+  return _ext().unsorted_segment_sum_forward(data, ids, num_segments)
 
 
 def unsorted_segment_sum_backward(grad_out, segment_ids, dim1):
@@ -1202,11 +1120,4 @@ def unsorted_segment_sum_backward(grad_out, segment_ids, dim1):
   g = _f32c(grad_out)
   ids = segment_ids.to(torch.int64).contiguous()
   B, S, D2 = g.shape
-  if _USE_EXT:
-    return _ext().unsorted_segment_sum_backward(g, ids, dim1)
-  out = torch.empty((B, dim1, D2), dtype=torch.float32, device=g.device)
-  lib = _lib.load()
-  with torch.cuda.device(g.device):
-    _lib.check(lib.lnz_unsorted_segment_sum_backward(_ptr(g), _ptr(ids), B, dim1, D2, S,
-                                                     _ptr(out), _stream()))
-  return out
+  return _ext().unsorted_segment_sum_backward(g, ids, dim1)

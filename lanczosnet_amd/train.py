@@ -3,7 +3,7 @@
 `QM8Runner.train` (runner/qm8_runner.py:189-250) runs, per batch,
 `optimizer.zero_grad(); _, loss = model(...); loss.backward(); optimizer.step()`.  On the HIP
 module that is ~6 ms of GPU work at B = 1024 issued through ~400 Python-level operations (kernel
-launches through ctypes, small torch ops of the backward, the optimizer's foreach kernels): the
+launches through the dispatcher, small torch ops of the backward, the optimizer's foreach kernels): the
 eager step is bound by the host.  `GraphedTrainStep` captures exactly that
 sequence — the fused forward (activations stored), the HIP input-gradient / message /
 gain-gradient kernels, the library GEMMs, the parameter re-packing and the optimizer update —

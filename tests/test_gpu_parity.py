@@ -34,7 +34,7 @@ def _model(cfg, params, general=False):
 def test_library_loaded_in_tree():
   from lanczosnet_amd import _lib
   lib = _lib.load()
-  assert lib.lnz_abi_version() == _lib.ABI_VERSION == 3
+  assert lib.lnz_abi_version() == _lib.ABI_VERSION == 4
   assert _lib.LIB_PATH.endswith('lanczosnet_amd/csrc/liblanczosnet_hip.so')
 
 
@@ -1009,11 +1009,17 @@ def test_gain_grad_kernel_matches_the_eigen_space_formula(B, pairs):
   assert (dG[:, dead] == 0).all()
 
 
-def test_torch_extension_ops_equal_the_ctypes_binding_bitwise():
-  """The same C ABI behind two bindings: torch.ops.lanczosnet.* (csrc/torch_ext.cpp, the default of
-  lanczosnet_amd.ops) and raw ctypes — identical launches, so identical bits, for every op of the
-  forward step; and a non-default stream is honoured (the extension takes ATen's current stream)."""
-  from lanczosnet_amd import ops
+def test_torch_extension_ops_equal_the_raw_c_abi_bitwise():
+  """The same C ABI behind two bindings: torch.ops.lanczosnet.* (csrc/torch_ext.cpp — what
+  lanczosnet_amd.ops calls for EVERY kernel) and raw ctypes calls of the library
+  (lanczosnet_amd/_lib.py, the binding a host without torch would write) — identical launches, so
+  identical bits, for one op of every family: preprocessing, Ritz pairs, packing, the fused forward
+  through its argument block, the exact-fp32 Linear (incl. its stream-K workspace), the Ada
+  Lanczos layer, the large-graph pack; and a non-default stream is honoured (the extension takes
+  ATen's current stream)."""
+  import ctypes as C
+  from lanczosnet_amd import ops, _lib
+  lib = _lib.load()
   cfg = dict(oracle.DEFAULT_QM8_CFG)
   P = oracle.make_lanczosnet_params(cfg, 77)
   net = _model(cfg, P)
@@ -1022,6 +1028,9 @@ def test_torch_extension_ops_equal_the_ctypes_binding_bitwise():
   n = _t(b['n_nodes'])
   adjs, nf, mk = _t(b['adjs']), _t(b['node_feat']), _t(b['node_mask'])
   K = cfg['num_eig_vec']
+  rs = np.random.RandomState(5)
+  xl, wl = _t(rs.randn(300, 4096).astype(np.float32)), _t((rs.randn(1056, 4096) / 64).astype(np.float32))
+  q1 = _t(rs.randn(96, adjs.shape[1]).astype(np.float32))
 
   def run():
     L = ops.laplacian_l4(adjs, n)
@@ -1030,13 +1039,17 @@ def test_torch_extension_ops_equal_the_ctypes_binding_bitwise():
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
                            rows=rows, zero_fill=True)
     score = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+    score2, state = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles, return_state=True)
     seg = ops.unsorted_segment_sum_forward(V, (nf % 5), 5)
+    lin = ops.f32_linear(xl, wl, None, relu=True)
+    Ta, Qa = ops.ada_lanczos_layer(L[:, :, :, 0].contiguous(), mk, q1[:, :, None], K)
+    Wk = ops.pack_rows_k8(wl[:128, :1920])
     buf, cap = tiles
     n_rows = int(rows[1].item())
     # (the plan buffer's tail beyond the n_rows live gain rows is never written)
     return dict(L=L, D0=D0, V0=V0, info=info, Lp=Lp, ident=Lp.ident, plan=buf[:12 * cap + 2].clone(),
-                rows=rows[0][:n_rows].clone(), D=D, V=V, G=G, score=score, seg=seg)
-  assert ops._USE_EXT
+                rows=rows[0][:n_rows].clone(), D=D, V=V, G=G, score=score, score2=score2, state=state,
+                seg=seg, lin=lin, Ta=Ta, Qa=Qa, Wk=Wk)
   with torch.no_grad():
     a = run()
     side = torch.cuda.Stream()
@@ -1044,11 +1057,54 @@ def test_torch_extension_ops_equal_the_ctypes_binding_bitwise():
     with torch.cuda.stream(side):
       c = run()
     torch.cuda.current_stream().wait_stream(side)
-    ops._USE_EXT = False
-    try:
-      r = run()
-    finally:
-      ops._USE_EXT = True
   for k in a:
-    assert torch.equal(a[k], r[k]), k
     assert torch.equal(a[k], c[k]), k
+  # the raw C ABI through ctypes, on torch's current stream
+  st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+  p_ = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
+  B, N, _, E = adjs.shape
+  L = torch.empty((B, N, N, E + 1), device=DEV)
+  _lib.check(lib.lnz_laplacian_l4(p_(adjs), p_(n), B, N, E, p_(L), st))
+  assert torch.equal(L, a['L'])
+  D0, V0 = torch.empty((B, K), device=DEV), torch.empty((B, N, K), device=DEV)
+  info = torch.empty((B,), dtype=torch.int32, device=DEV)
+  A = L[:, :, :, 0]
+  _lib.check(lib.lnz_lanczos_ritz(p_(A), A.stride(0), A.stride(1), A.stride(2), p_(n), B, N, K, p_(D0),
+                                  p_(V0), p_(info), st))
+  assert torch.equal(D0, a['D0']) and torch.equal(V0, a['V0']) and torch.equal(info, a['info'])
+  M, Kl = xl.shape
+  Nl = wl.shape[0]
+  need = lib.lnz_f32_linear_workspace_floats(M, Nl, Kl)
+  assert need > 0 and lib.lnz_f32_linear_splits(M, Nl, Kl) > 1    # this shape runs stream-K
+  ws = torch.zeros((need,), device=DEV)
+  lin = torch.empty((M, Nl), device=DEV)
+  for _ in range(2):   # the workspace's counters are zero again after a launch
+    _lib.check(lib.lnz_f32_linear(p_(xl), Kl, p_(wl), Kl, None, 1, M, Nl, Kl, p_(lin), Nl, p_(ws), st))
+    assert torch.equal(lin, a['lin'])
+  Ac = A.contiguous()
+  Ta, Qa = torch.empty((B, K, K), device=DEV), torch.empty((B, N, K), device=DEV)
+  _lib.check(lib.lnz_ada_lanczos_layer(p_(Ac), p_(mk), p_(q1), B, N, K, p_(Ta), p_(Qa), st))
+  assert torch.equal(Ta, a['Ta']) and torch.equal(Qa, a['Qa'])
+  src = wl[:128, :1920]
+  Wk = torch.empty((lib.lnz_packed_rows_k8_size(128, 1920),), device=DEV)
+  _lib.check(lib.lnz_pack_rows_k8(p_(src), 128, 1920, src.stride(0), p_(Wk), st))
+  assert torch.equal(Wk, a['Wk'].reshape(-1))
+  # the argument-block launch: the struct filled by hand against torch.ops.lanczosnet.fused_launch
+  fa = _lib.ForwardArgs()
+  fa.B, fa.N, fa.K, fa.num_layer = B, N, K, plan['num_layer']
+  fa.din0, fa.dhid, fa.dout = plan['din0'], plan['dhid'], plan['dout']
+  fa.n_short, fa.n_long, fa.n_edge = 0, plan['n_long'], plan['n_edge']
+  fa.node_feat, fa.embedding, fa.num_atom = nf.data_ptr(), plan['embedding'].data_ptr(), plan['embedding'].shape[0]
+  fa.mask, fa.Lp, fa.V, fa.G = mk.data_ptr(), a['Lp'].data_ptr(), a['V'].data_ptr(), a['G'].data_ptr()
+  fa.ident = a['ident'].data_ptr()
+  fa.Wp, fa.bias = plan['Wp'].data_ptr(), plan['bias'].data_ptr()
+  for i in range(plan['num_layer']):
+    fa.w_off[i], fa.b_off[i] = plan['w_off'][i], plan['b_off'][i]
+  fa.Wp_head, fa.bias_head = plan['Wp_head'].data_ptr(), plan['bias_head'].data_ptr()
+  tiles = ops.plan_tiles(mk, allow_pairs=True)
+  fa.plan, fa.n_wg, fa.plan_wg_cap = tiles[0].data_ptr(), tiles[0].data_ptr() + 48 * tiles[1], tiles[1]
+  score = torch.empty((B, plan['dout']), device=DEV)
+  state = torch.zeros((B, 32, plan['dhid']), device=DEV)
+  fa.score, fa.state_out = score.data_ptr(), state.data_ptr()
+  _lib.check(lib.lnz_lanczosnet_forward(C.byref(fa), st))
+  assert torch.equal(score, a['score']) and torch.equal(score, a['score2']) and torch.equal(state, a['state'])

@@ -224,3 +224,33 @@ def test_ada_long_diffusion_dist_is_put_in_the_reference_order():
   cfg['long_diffusion_dist'] = [5, 7, 5]
   with pytest.raises(ValueError):
     Small(make_model_config(cfg, name='AdaLanczosNet'))
+
+
+def test_torch_extension_registers_every_entry_point_and_is_the_only_binding_of_the_product():
+  """csrc/torch_ext_abi.inc is current with the header (tools/gen_torch_ext.py --check); every
+  entry point the header declares is reachable as a dispatcher op (raw_<name>, or fused_launch for
+  the four argument-block launches); host-side size queries answer without a GPU; and no module of
+  the product path marshals through ctypes any more — only lanczosnet_amd/_lib.py (the raw-ABI
+  binding kept for these tests) does."""
+  import subprocess
+  import sys
+  import torch
+  from lanczosnet_amd import _torch_ext
+  assert subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_torch_ext.py'), '--check']).returncode == 0
+  _torch_ext.load()
+  struct_launches = {'lnz_lanczosnet_forward', 'lnz_lanczosnet_input_grad', 'lnz_lanczosnet_messages',
+                     'lnz_lanczosnet_gain_grad'}
+  for sym in _header_symbols():
+    if sym in ('lnz_abi_version', 'lnz_last_error') or sym in struct_launches:
+      continue
+    assert hasattr(torch.ops.lanczosnet, 'raw_' + sym[4:]), sym
+  assert hasattr(torch.ops.lanczosnet, 'fused_launch')
+  assert torch.ops.lanczosnet.raw_large_nk(100) == 128
+  assert torch.ops.lanczosnet.raw_lanczos_ritz_workspace_bytes(3, 192) == 3 * 192 * 193 * 8
+  assert torch.ops.lanczosnet.raw_f32_linear_splits(1024, 4096, 4096) == 1
+  assert torch.ops.lanczosnet.raw_f32_linear_splits(1024, 1056, 4096) == 256
+  pkg = os.path.join(ROOT, 'lanczosnet_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith('.py') and f != '_lib.py':
+        assert 'ctypes' not in open(os.path.join(dirpath, f)).read(), os.path.join(dirpath, f)

@@ -35,7 +35,7 @@ for b in range(B):
 X = torch.randn((B, N, 10), generator=g, device='cuda')
 mask = torch.ones((B, N), dtype=torch.uint8, device='cuda')
 A0 = L[:, :, :, 0].contiguous()
-ws = torch.empty((ops._lib.load().lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
+ws = torch.empty((ops._abi().lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 res = {}
 modes = [('hip_bf16', 1), ('hip_split3', 3), ('hip_f16x2', 2)] + ([('library_fp32', None)] if args.library else [])

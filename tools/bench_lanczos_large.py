@@ -26,8 +26,7 @@ for b in range(B):  # G(n, p = 0.01) + self loops, symmetric GCN normalisation (
   adj = adj + adj.t() + torch.eye(N, device='cuda')
   d = adj.sum(1).rsqrt()
   A[b] = d[:, None] * adj * d[None, :]
-lib = _lib.load()
-ws = torch.empty((lib.lnz_lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
+ws = torch.empty((ops._abi().lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ops.lanczos_ritz_large(A, M, M, workspace=ws, symmetric=args.sym)
 torch.cuda.synchronize()

@@ -1,13 +1,12 @@
 import os, sys, torch, json
 sys.path.insert(0, os.getcwd())
-from lanczosnet_amd import ops, _lib
+from lanczosnet_amd import ops
 import ctypes as C
 B,N,K,S=256,2048,64,8
 X=torch.randn(B,N,128,device='cuda'); V=torch.randn(B,N,K,device='cuda'); G=torch.randn(B,S,K,device='cuda')
 Wt=ops.pack_rows_k8(torch.randn(128,S*128,device='cuda')); Y=torch.zeros(B,64,128,device='cuda'); Tt=torch.zeros(1,B,128,64,dtype=torch.bfloat16,device='cuda')
-lib=_lib.load()
 def run():
-  _lib.check(lib.lnz_large_spectral(ops._ptr(X),128,128,ops._ptr(V),ops._ptr(G),ops._ptr(Wt),B,N,K,S,1,ops._ptr(Y),ops._ptr(Tt),ops._stream()))
+  ops._abi().large_spectral(X,128,128,V,G,Wt,B,N,K,S,1,Y,Tt)
 run(); torch.cuda.synchronize()
 e=[torch.cuda.Event(enable_timing=True) for _ in range(2)]
 e[0].record()

@@ -18,8 +18,7 @@ for b in range(B):
   adj = adj + adj.t() + torch.eye(N, device='cuda')
   d = adj.sum(1).rsqrt()
   A0[b] = d[:, None] * adj * d[None, :]
-lib = _lib.load()
-need = lib.lnz_lanczos_ritz_large_workspace_bytes(B, N)
+need = ops._abi().lanczos_ritz_large_workspace_bytes(B, N)
 As = [A0] + [A0.clone() for _ in range(args.copies - 1)]
 Ws = [torch.empty((need,), dtype=torch.uint8, device='cuda') for _ in range(2)]
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

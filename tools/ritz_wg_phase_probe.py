@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where the workgroup-per-graph Ritz kernel spends its cycles (needs tools/libprobe_ritz_wg.so =
 the library with lanczos_ritz_wg.hip built -DLNZ_PROFILE_PHASES):
-    LANCZOSNET_HIP_LIB=tools/libprobe_ritz_wg.so LNZ_OPS_BINDING=ctypes python tools/ritz_wg_phase_probe.py"""
+    LANCZOSNET_HIP_LIB=tools/libprobe_ritz_wg.so python tools/ritz_wg_phase_probe.py"""
 import sys
 import numpy as np
 import torch
