@@ -352,6 +352,19 @@ typedef struct lnz_forward_args {
   float* dgains;              /* gain_grad: [num_layer,B,K,n_long] dLoss/dG, ZERO-INITIALISED by the
                                  caller (slots beyond a molecule's row block in a shared tile are
                                  dead, k >= n, and are not written)                                */
+  /* ---- input_grad, optional (ABI 4): what the weight / bias gradients need, produced where the
+   * values are in registers anyway instead of by separate gather and reduction launches */
+  float* dy_compact;          /* [num_layer][dy_compact_rows][dhid]: slots 0 .. num_layer-2 receive
+                                 dLoss/dY_l in the COMPACT row numbering of `row_off` (real nodes
+                                 only: row_off[molecule] + node) — the row order of the compact
+                                 message matrix, so dW_l = dy_compact[l]^T msg_l needs no gather.
+                                 Needs row_off.  Slot num_layer-1 (the incoming gradient) is the
+                                 caller's.                                                          */
+  int64_t dy_compact_rows;    /* rows per slot of dy_compact                                         */
+  float* dbias_part;          /* [2 * plan_wg_cap][num_layer][dhid], ZERO-INITIALISED: entry (2 g + h,
+                                 l) = column sums of dLoss/dY_l over the node tiles of half h of
+                                 workgroup g, for l = 0 .. num_layer-2; their sum over the first
+                                 index (any fixed order) is the bias gradient of conv layer l      */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
 /* Backward of the conv stack w.r.t. its node-state inputs, in the forward's own structure:

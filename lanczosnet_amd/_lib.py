@@ -44,6 +44,7 @@ class ForwardArgs(C.Structure):
       ('Wp16_head', C.c_void_p), ('Lp16', C.c_void_p), ('plan', C.c_void_p), ('n_wg', C.c_void_p), ('plan_wg_cap', C.c_int),
       ('act_out', C.c_void_p), ('act', C.c_void_p), ('dy', C.c_void_p), ('dx0', C.c_void_p),
       ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p), ('dgains', C.c_void_p),
+      ('dy_compact', C.c_void_p), ('dy_compact_rows', C.c_int64), ('dbias_part', C.c_void_p),
   ]
 
 

@@ -906,6 +906,42 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
           for (int r = 0; r < 16; ++r) Xs[cur][m][lnz::cd_row(r, hh)][col] = Y[r];
         }
       }
+      if (MODE == 1 && la > 0 && (a.dy_compact || a.dbias_part)) {
+        // What the weight / bias gradients of conv layer la - 1 need, as a second pass over the
+        // values this lane just wrote to LDS (the accumulators are dead by now: no registers
+        // taken from the loop above): dY_{la-1} in the COMPACT row numbering of the message
+        // matrix (real nodes only), and this half's column sums (rows of padded nodes and of
+        // unowned tile rows are zero here) — one writer per (workgroup half, layer, column).
+        float colsum = 0.0f;
+#pragma unroll 1
+        for (int m = 0; m < MT; ++m) {
+          const TileDesc t = pick(td, m);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bool first = 8 * g < t.split;
+            const int mol = first ? t.ta : t.tb;
+            const int lrow0 = 8 * g + 4 * hh - (first ? 0 : t.split);
+            const int nmol = first ? pick(nA, m) : pick(nB, m);
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = Xs[nxt][m][8 * g + 4 * hh + u][col];
+            colsum += (v[0] + v[1]) + (v[2] + v[3]);
+            if (a.dy_compact && mol >= 0) {
+              float* dc = a.dy_compact +
+                          ((int64_t)(la - 1) * a.dy_compact_rows + a.row_off[mol] + lrow0) * dhid + col;
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (lrow0 + u < nmol) dc[u * dhid] = v[u];
+            }
+          }
+        }
+        if (a.dbias_part) {
+          colsum += __shfl_xor(colsum, 32, 64);
+          const int half = threadIdx.x / (64 * NWV);
+          if (hh == 0)
+            a.dbias_part[(((int64_t)blockIdx.x * 2 + half) * a.num_layer + (la - 1)) * dhid + col] = colsum;
+        }
+      }
     }
     __syncthreads();
     cur = nxt;
@@ -1340,6 +1376,8 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
       LNZ_REQUIRE(a.Wp && a.dy && a.dx0 && a.din0 == a.dhid && a.bwd_din0 > 0 &&
                       a.bwd_din0 % 32 == 0 && a.bwd_din0 <= a.dhid,
                   LNZ_EINVAL, "%s: need Wp (transposed packs), dy, dx0, din0 == dhid, bwd_din0", who);
+      LNZ_REQUIRE(!a.dy_compact || (a.row_off && a.dy_compact_rows > 0), LNZ_EINVAL,
+                  "%s: dy_compact needs row_off and dy_compact_rows", who);
     } else {
       LNZ_REQUIRE(a.msg && a.msg_layer >= 0 && a.msg_layer < a.num_layer &&
                       (a.msg_layer > 0 || a.x0),

@@ -724,7 +724,8 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
           for (int ord = P - 1; ord >= 0; --ord)
 #pragma unroll
             for (int i = 0; i <= ord; ++i)
-              acc[rt][nt] = mfma_16x16x32<P>(A[gs % DEPTH][i][rt][ks], bf[ord - i], acc[rt][nt]);
+              // (operands swapped: D[feature][node] — see the epilogue)
+              acc[rt][nt] = mfma_16x16x32<P>(bf[ord - i], A[gs % DEPTH][i][rt][ks], acc[rt][nt]);
       }
     if constexpr (BDIST == 1) load_b(std::integral_constant<int, (gs + 1) % 2>{});
     store_b(g + 1, std::integral_constant<int, (gs + 1) % 2>{});
@@ -762,22 +763,29 @@ __global__ __launch_bounds__(64 * NW) void large_conv_kernel(
       if (g + 2 < total) block(g + 2, std::integral_constant<int, 2>{});
     }
   }
-  // epilogue: C/D layout of 16x16: col = lane & 15, row = 4 * (lane >> 4) + reg
+  // epilogue.  The MFMAs ran with the operands SWAPPED (first = the B image's feature rows, second
+  // = the operator's node rows; both fragment layouts are "lane = 16 kq + index, 8 consecutive k",
+  // and the products are the same numbers in the same k order): D[feature][node], so the C/D
+  // layout col = lane & 15, row = 4 * (lane >> 4) + reg puts FOUR CONSECUTIVE FEATURES of one node
+  // into a lane's four registers — one 16-byte store per tile instead of four 4-byte ones.  With
+  // the row-per-register layout the 64 dword stores per lane were a ~20 us store tail per
+  // workgroup (issue bound), a third of a one-channel tile's time.
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) {
-    const int col = 16 * nt + l15;
-    const float bv = bias[col];
+    const int col = 16 * nt + 4 * kq;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt)
+    for (int rt = 0; rt < NRT; ++rt) {
+      const int row = r0 + 16 * rt + l15;
+      if (row < N) {
+        f32x4 v = acc[rt][nt] * ElemTraits<P>::kAInv + bv;   // (2^-10: fp16 mode's A scale)
+        if (relu) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + 16 * rt + 4 * kq + r;
-        if (row < N) {
-          float v = acc[rt][nt][r] * ElemTraits<P>::kAInv + bv;   // (2^-10: fp16 mode's A scale)
-          if (relu) v = v > 0.0f ? v : 0.0f;
-          Xout[((int64_t)b * N + row) * DH + col] = v;
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
         }
+        *reinterpret_cast<f32x4*>(Xout + ((int64_t)b * N + row) * DH + col) = v;
       }
+    }
   }
 }
 

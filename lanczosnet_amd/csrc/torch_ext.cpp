@@ -76,13 +76,14 @@ const Tensor* first_defined(std::initializer_list<const Tensor*> ts) {
 enum { kNodeFeat, kNodeFeatF, kEmbedding, kMask, kLp, kV, kG, kWp, kBias, kWpHead, kBiasHead, kWp16,
        kWp16Head, kLp16, kPlan, kNwg, kAct, kX0, kIdent, kRowOff, kNumIn };
 enum { dB, dN, dK, dNumLayer, dDin0, dDhid, dDout, dNLong, dNEdge, dNumAtom, dFilterKind, dGemmMode,
-       dPlanCap, dBwdDin0, dMsgLayer, kNumDim };
+       dPlanCap, dBwdDin0, dMsgLayer, dDyCompactRows, kNumDim };
 void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at::IntArrayRef dims,
                   at::IntArrayRef w_off, at::IntArrayRef b_off, at::IntArrayRef w16_off,
                   at::IntArrayRef short_dist, const c10::optional<Tensor>& score,
                   const c10::optional<Tensor>& state_out, const c10::optional<Tensor>& act_out,
                   const c10::optional<Tensor>& dy, const c10::optional<Tensor>& dx0,
-                  const c10::optional<Tensor>& msg, const c10::optional<Tensor>& dgains) {
+                  const c10::optional<Tensor>& msg, const c10::optional<Tensor>& dgains,
+                  const c10::optional<Tensor>& dy_compact, const c10::optional<Tensor>& dbias_part) {
   TORCH_CHECK((int)in.size() == kNumIn && (int)dims.size() == kNumDim && which >= 0 && which <= 3,
               "lanczosnet::fused_launch: ", (int)kNumIn, " operands and ", (int)kNumDim, " dims expected");
   TORCH_CHECK(w_off.size() <= 16 && b_off.size() <= 16 && w16_off.size() <= 16 && short_dist.size() <= 8);
@@ -138,6 +139,15 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
   a.dx0 = (float*)raw_ptr(dx0, at::kFloat, "dx0");
   a.msg = (float*)raw_ptr(msg, at::kFloat, "msg");
   a.dgains = (float*)raw_ptr(dgains, at::kFloat, "dgains");
+  a.dy_compact = (float*)raw_ptr(dy_compact, at::kFloat, "dy_compact");
+  a.dy_compact_rows = dims[dDyCompactRows];
+  a.dbias_part = (float*)raw_ptr(dbias_part, at::kFloat, "dbias_part");
+  if (a.dy_compact)
+    TORCH_CHECK(dy_compact->numel() >= (int64_t)a.num_layer * a.dy_compact_rows * a.dhid && a.row_off,
+                "lanczosnet::fused_launch: dy_compact needs [num_layer, rows, dhid] and row_off");
+  if (a.dbias_part)
+    TORCH_CHECK(dbias_part->numel() >= 2 * (int64_t)(a.plan ? a.plan_wg_cap : (a.B + 3) / 4) * a.num_layer * a.dhid,
+                "lanczosnet::fused_launch: dbias_part shorter than [2 * workgroups, num_layer, dhid]");
   const c10::DeviceGuard guard(v->device());
   int rc;
   switch (which) {
@@ -371,7 +381,7 @@ TORCH_LIBRARY(lanczosnet, m) {
   m.def("unsorted_segment_sum_backward(Tensor grad_out, Tensor segment_ids, int dim1) -> Tensor");
   m.def("fused_launch(int which, Tensor?[] operands, int[] dims, int[] w_off, int[] b_off, int[] w16_off, "
         "int[] short_dist, Tensor(a!)? score, Tensor(b!)? state_out, Tensor(c!)? act_out, Tensor(d!)? dy, "
-        "Tensor(e!)? dx0, Tensor(f!)? msg, Tensor(g!)? dgains) -> ()");
+        "Tensor(e!)? dx0, Tensor(f!)? msg, Tensor(g!)? dgains, Tensor(h!)? dy_compact, Tensor(i!)? dbias_part) -> ()");
   LNZ_RAW_DEFS(m)
 }
 

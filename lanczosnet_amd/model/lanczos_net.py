@@ -704,6 +704,28 @@ def _linear_relu(x, w, b):
     return torch.relu_(torch.nn.functional.linear(x, w, b))
 
 
+class _BatchedLinear(torch.autograd.Function):
+    """y[l] = x[l] W[l]^T + b[l] for the stacked spectral-filter MLPs of all conv layers
+    (x [L, R, i], W [L, o, i], b [L, o]).  torch's own backward of the broadcast bias is a
+    reduction over the [L, R, o] block (88 us per Linear at R = 20 k, three of them per step);
+    here the bias gradient is one thin batched GEMM, ones^T g."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.baddbmm(b.unsqueeze(1), x, W.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.bmm(g, W) if ctx.needs_input_grad[0] else None
+        dW = torch.bmm(g.transpose(1, 2), x)
+        ones = g.new_ones((g.shape[0], 1, g.shape[1]))
+        db = torch.bmm(ones, g).squeeze(1)
+        return dx, dW, db
+
+
 def _tn_split_k(a, b, splits=4):
     """a^T b for tall operands a [R, m], b [R, n] (the conv weight gradient: m = 128, n = 1920,
     R = every node row of the batch).  One library GEMM tiles the small m x n output into ~60
@@ -750,8 +772,25 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     dy[Lnum - 1][:, :N] = hg[0] * (XL > 0).float()
     dx0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
 
-    # ---- node-state gradients of the conv stack
-    ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles)
+    # ---- compact row numbering (real nodes only: half of the padded rows are empty) — the row
+    #      order of the message matrix; node extent (last real node + 1) is what the kernels size
+    #      a molecule by
+    row_end = torch.cumsum(n_mol, 0)
+    row_off = (row_end - n_mol).contiguous()                                 # int64 [B]
+    if static_rows:
+        R_tot = B * N   # graph capture: no host round trip; rows past the real count are masked
+    else:
+        rtot_ready.synchronize()   # recorded before the forward kernel: long complete
+        R_tot = int(rtot[0])
+    # ---- node-state gradients of the conv stack.  The kernel also leaves what the weight / bias
+    #      gradients need: dY_l in the compact numbering (no gather per layer) and per-workgroup
+    #      column sums of dY_l (no reduction over the [L, B * 32, dh] block)
+    # (graph capture: rows past the real count are never written — zeros, they meet zero messages)
+    dyc = (torch.zeros if static_rows else torch.empty)((Lnum, R_tot, dh), dtype=torch.float32,
+                                                        device=dev)
+    dbp = torch.zeros((2 * tiles[1], Lnum, dh), dtype=torch.float32, device=dev)
+    ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles, row_off=row_off,
+                              dy_compact=dyc, dbias_part=dbp)
 
     # ---- X_0
     x0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
@@ -761,16 +800,12 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
         x0[:, :N, :din0] = m.embedding.weight.detach()[node_feat]
 
     # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l, over
-    #      the REAL node rows only (half of the padded rows are empty): compact row numbering
-    # node extent (last real node + 1) — what the kernels size a molecule by
-    row_end = torch.cumsum(n_mol, 0)
-    row_off = (row_end - n_mol).contiguous()                                 # int64 [B]
+    #      the REAL node rows only
     valid = None
+    r = torch.arange(R_tot, device=dev)
     if static_rows:
-        # graph capture: no host round trip.  R_tot = B * N rows; rows past the real count are
-        # never written by the message kernel (zero-filled here) and their dY rows are masked.
-        R_tot = B * N
-        r = torch.arange(R_tot, device=dev)
+        # rows past the real count are never written by the kernels: zero-filled here, and the
+        # incoming gradient's rows are masked
         valid = (r < row_end[-1]).to(torch.float32).unsqueeze(1)
         mol_of_r = torch.searchsorted(row_end, r, right=True).clamp_(max=B - 1)
         real = mol_of_r * 32 + (r - row_off[mol_of_r]).clamp_(min=0, max=31)
@@ -778,28 +813,27 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
         msg_buf0 = msg_buf if din0p == dh else \
             torch.zeros((R_tot * n_chan * din0p,), dtype=torch.float32, device=dev)
     else:
-        rtot_ready.synchronize()   # recorded before the forward kernel: long complete
-        R_tot = int(rtot[0])
         # compact row r -> padded row (molecule * 32 + node), without a data-dependent shape
-        r = torch.arange(R_tot, device=dev)
         mol_of_r = torch.searchsorted(row_end, r, right=True)
         real = mol_of_r * 32 + (r - row_off[mol_of_r])
         msg_buf = msg_buf0 = torch.empty((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
+    # the incoming gradient (slot L - 1) is the one layer the kernel does not write compactly
+    last = dy[Lnum - 1].view(B * 32, dh).index_select(0, real)
+    dyc[Lnum - 1] = last if valid is None else last * valid
     for la in range(Lnum):
         d = din0p if la == 0 else dh
         msg = (msg_buf0 if la == 0 else msg_buf)[:R_tot * n_chan * d].view(R_tot, n_chan * d)
         ops.lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, la, msg, tiles,
                                 row_off=row_off)
-        dyl = dy[la].view(B * 32, dh).index_select(0, real)
-        if valid is not None:
-            dyl = dyl * valid
-        dW = _tn_split_k(dyl, msg)
+        dW = _tn_split_k(dyc[la], msg)
         if la == 0 and din0p != din0:
             dW = dW.view(dh, n_chan, din0p)[:, :, :din0].reshape(dh, n_chan * din0)
         grads[id(m.filter[la].weight)] = m._to_reference_channel_order(dW)
-    # bias gradients: column sums of dY_l — rows of padded nodes are zero in `dy`, so one
-    # reduction over the padded layout serves all layers (7 strided reductions were 0.5 ms)
-    db_all = dy.view(Lnum, B * 32, dh).sum(dim=1)
+    # bias gradients: the kernel's per-workgroup column sums added in a fixed order (one small
+    # reduction over [2 * workgroups, L, dh] instead of one over the [L, B * 32, dh] block);
+    # the last layer's from the incoming gradient
+    db_all = dbp.sum(dim=0)
+    db_all[Lnum - 1] = dy[Lnum - 1].view(B * 32, dh).sum(dim=0)
     for la in range(Lnum):
         grads[id(m.filter[la].bias)] = db_all[la]
     return grads, dy, dx0, x0
@@ -901,7 +935,7 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
                 for li, i in enumerate(lin_idx):
                     Wst = torch.stack([m.spectral_filter[t][i].weight for t in range(Lnum)])
                     bst = torch.stack([m.spectral_filter[t][i].bias for t in range(Lnum)])
-                    h = torch.baddbmm(bst.unsqueeze(1), h, Wst.transpose(1, 2))
+                    h = _BatchedLinear.apply(h, Wst, bst)
                     if li + 1 < len(lin_idx):
                         h = torch.relu(h)
                 mlp_params = [m.spectral_filter[t][i].weight for i in lin_idx for t in range(Lnum)] + \

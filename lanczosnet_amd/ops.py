@@ -673,7 +673,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   nl = plan['num_layer']
   _ext().fused_launch(0, ops_, dims, [int(x) for x in plan['w_off'][:nl]],
                       [int(x) for x in plan['b_off'][:nl]], w16_off, [int(p) for p in plan['short']],
-                      score, state, act_out, None, None, None, None)
+                      score, state, act_out, None, None, None, None, None, None)
   return (score, state) if return_state else score
 
 
@@ -683,7 +683,7 @@ _IN = {k: i for i, k in enumerate(
      'bias_head', 'Wp16', 'Wp16_head', 'Lp16', 'plan', 'n_wg', 'act', 'x0', 'ident', 'row_off'])}
 _DIM = {k: i for i, k in enumerate(
     ['B', 'N', 'K', 'num_layer', 'din0', 'dhid', 'dout', 'n_long', 'n_edge', 'num_atom', 'filter_kind',
-     'gemm_mode', 'plan_cap', 'bwd_din0', 'msg_layer'])}
+     'gemm_mode', 'plan_cap', 'bwd_din0', 'msg_layer', 'dy_compact_rows'])}
 
 
 def _fused_operands(plan, V):
@@ -752,12 +752,25 @@ def _training_args(plan, Lp, V, G, mask_u8, tiling):
   return ops_, dims
 
 
-def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling):
+def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling, row_off=None,
+                          dy_compact=None, dbias_part=None):
   """lnz_lanczosnet_input_grad: dy[num_layer-1] holds dLoss/dY of the last conv layer on entry;
   fills dy[0..num_layer-2] and dx0 [B,32,din0].  plan['Wp_t'] / plan['wt_off']: transposed packs in
-  kernel-layer order (LanczosNet._plan_backward).  All buffers zero-initialised by the caller."""
-  _need_cuda(Lp, V, G, mask_u8, act, dy, dx0)
+  kernel-layer order (LanczosNet._plan_backward).  All buffers zero-initialised by the caller.
+  Optional: dy_compact [num_layer, R, dhid] with row_off [B] int64 — slots 0 .. num_layer-2 receive
+  the same gradients in the compact row numbering of the message matrix; dbias_part [2 * cap,
+  num_layer, dhid] (zero-initialised) — per workgroup half the column sums of dY_l, l <= num_layer-2."""
+  _need_cuda(Lp, V, G, mask_u8, act, dy, dx0, row_off, dy_compact, dbias_part)
   ops_, dims = _training_args(plan, Lp, V, G, mask_u8, tiling)
+  if dy_compact is not None:
+    assert row_off is not None and row_off.dtype == torch.int64 and row_off.is_contiguous()
+    assert dy_compact.dim() == 3 and dy_compact.is_contiguous() and dy_compact.dtype == torch.float32 \
+        and dy_compact.shape[0] == plan['num_layer'] and dy_compact.shape[2] == plan['dhid']
+    ops_[_IN['row_off']] = row_off
+    dims[_DIM['dy_compact_rows']] = int(dy_compact.shape[1])
+  if dbias_part is not None:
+    assert tuple(dbias_part.shape) == (2 * tiling[1], plan['num_layer'], plan['dhid']) and \
+        dbias_part.is_contiguous() and dbias_part.dtype == torch.float32
   B = V.shape[0]
   L, dh = plan['num_layer'], plan['dhid']
   assert tuple(dy.shape) == (L, B, 32, dh) and dy.is_contiguous() and dy.dtype == torch.float32
@@ -766,7 +779,7 @@ def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling):
   dims[_DIM['din0']], dims[_DIM['bwd_din0']] = dh, plan['din0']
   ops_[_IN['Wp']], ops_[_IN['act']] = plan['Wp_t'], act
   _ext().fused_launch(1, ops_, dims, [int(x) for x in plan['wt_off'][:L]], [], [],
-                      [int(p) for p in plan['short']], None, None, None, dy, dx0, None, None)
+                      [int(p) for p in plan['short']], None, None, None, dy, dx0, None, None, dy_compact, dbias_part)
 
 
 def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, row_off=None):
@@ -788,7 +801,7 @@ def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, ro
     assert row_off.dtype == torch.int64 and row_off.is_contiguous() and row_off.numel() == B
     ops_[_IN['row_off']] = row_off
   _ext().fused_launch(2, ops_, dims, [], [], [], [int(p) for p in plan['short']], None, None, None,
-                      None, None, msg, None)
+                      None, None, msg, None, None, None)
 
 
 def lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiling):
@@ -808,7 +821,7 @@ def lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiling):
   # dead (k >= n) and are not written
   dG = torch.zeros((L, B, K, S), dtype=torch.float32, device=V.device)
   _ext().fused_launch(3, ops_, dims, [int(x) for x in plan['w_off'][:L]], [], [],
-                      [int(p) for p in plan['short']], None, None, None, dy, None, None, dG)
+                      [int(p) for p in plan['short']], None, None, None, dy, None, None, dG, None, None)
   return dG
 
 

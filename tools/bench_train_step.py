@@ -13,7 +13,7 @@ cfg = dict(oracle.DEFAULT_QM8_CFG)
 net = LanczosNet(make_model_config(cfg)).train()
 net.load_state_dict({k: torch.from_numpy(v) for k, v in oracle.make_lanczosnet_params(cfg, 1).items()})
 net = net.cuda()
-opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=os.environ.get('ADAM_FUSED', '0') == '1')
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=os.environ.get('ADAM_FUSED', '1') == '1')
 b = draw_batch(B, seed=0)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 n = t(b['n_nodes']); nf, mask, label = t(b['node_feat']), t(b['node_mask']), t(b['label'])

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c8
+mkdir -p gpurun_out/c11
 export TMPDIR=/tmp
-(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -40) > gpurun_out/c8/pytest.log 2>&1
-(timeout 600 python bench.py --cpu-reps 1 2>&1 | tail -2) > gpurun_out/c8/bench.log 2>&1
-tail -30 gpurun_out/c8/pytest.log; tail -c 1500 gpurun_out/c8/bench.log
+(timeout 900 python -m pytest tests -m gpu -q -x -k "train or grad or backward" 2>&1 | tail -4) > gpurun_out/c11/pytest.log 2>&1
+(timeout 300 python tools/bench_train_step.py 2>&1 | tail -1) > gpurun_out/c11/train.log 2>&1
+tail -3 gpurun_out/c11/pytest.log; cat gpurun_out/c11/train.log

@@ -1,5 +1,5 @@
 """One mode of the training step per process, for `rocprofv3 --kernel-trace --stats`:
-  python tools/train_step_profile.py eager|graph [steps]
+  python tools/train_step_profile.py eager|eager_fused|graph [steps]     (eager_fused: torch.optim.Adam(fused=True))
 prints wall ms per step; the kernel stats of the run give the summed kernel time per step."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +23,8 @@ t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 n = t(b['n_nodes']); nf, mask, label = t(b['node_feat']), t(b['node_mask']), t(b['label'])
 L = ops.laplacian_l4(t(b['adjs']), n)
 D, V = ops.lanczos_ritz(L[..., 0], n, 20)
-opt = make_adam(net.parameters(), lr=1e-4)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True) if mode == 'eager_fused' else \
+    make_adam(net.parameters(), lr=1e-4)
 if mode == 'graph':
   gs = GraphedTrainStep(net, opt, warmup=2)
   step = lambda: gs(nf, L, D, V, label, mask)
