@@ -72,9 +72,7 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
   double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
   unsigned na = 0u, nb = 0u;  // sign of the previous p (p_{-1} = 1 > 0)
   ca = cb = 0;
-  for (int i = s; i <= t; ++i) {
-    const double di = d[i];
-    const double ep = i > s ? e2[i - 1] : 0.0;
+  auto row = [&](const double di, const double ep) {
     const double pa = fma(di - xa, a1, -(ep * a2));
     const double pb = fma(di - xb, b1, -(ep * b2));
     const unsigned sa = (unsigned)__double2hiint(pa) >> 31, sb = (unsigned)__double2hiint(pb) >> 31;
@@ -82,13 +80,29 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
     cb += (int)(sb ^ nb);
     na = sa, nb = sb;
     a2 = a1, a1 = pa, b2 = b1, b1 = pb;
-    if (((i - s) & 7) == 7) {  // keep |p| inside the exponent range
-      const double fa = fabs(a1), fb = fabs(b1);
-      const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
-      const double kb = fb < 1e-100 ? 1e100 : (fb > 1e100 ? 1e-100 : 1.0);
-      a1 *= ka, a2 *= ka, b1 *= kb, b2 *= kb;
+  };
+  auto rescale = [&]() {  // keep |p| inside the exponent range
+    const double fa = fabs(a1), fb = fabs(b1);
+    const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
+    const double kb = fb < 1e-100 ? 1e100 : (fb > 1e100 ? 1e-100 : 1.0);
+    a1 *= ka, a2 *= ka, b1 *= kb, b2 *= kb;
+  };
+  // Rows in groups of eight whose (d, e^2) are all fetched from LDS BEFORE the dependent chain
+  // runs: read in program order, every row waited ~120 cycles for its two LDS words in front of
+  // ~60 cycles of fp64 chain (the section search was 0.93 M of a 100-node graph's 2.5 M cycles).
+  int i = s;
+  for (; i + 7 <= t; i += 8) {
+    double dv[8], ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      dv[u] = d[i + u];
+      ev[u] = (i + u) > s ? e2[i + u - 1] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) row(dv[u], ev[u]);
+    rescale();
   }
+  for (; i <= t; ++i) row(d[i], i > s ? e2[i - 1] : 0.0);
 }
 
 template <bool QG>
@@ -180,7 +194,23 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           const double* qi = Qt + (size_t)di * LD;
           double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
           int c = dc0;
-          for (; c + 3 < dc1; c += 4) {   // four independent chains: the LDS latency overlaps
+          // eight elements per round, all sixteen LDS words requested before the first FMA (read
+          // pair by pair, every FMA waited a full LDS round trip: the step's parts are a barrier
+          // plus a few such round trips around a few dozen FMAs); four independent chains
+          for (; c + 7 < dc1; c += 8) {
+            double qv[8], zv_[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qv[u] = qi[c + u], zv_[u] = sm.zb[c + u];
+            p0 = fma(qv[0], zv_[0], p0);
+            p1 = fma(qv[1], zv_[1], p1);
+            p2 = fma(qv[2], zv_[2], p2);
+            p3 = fma(qv[3], zv_[3], p3);
+            p0 = fma(qv[4], zv_[4], p0);
+            p1 = fma(qv[5], zv_[5], p1);
+            p2 = fma(qv[6], zv_[6], p2);
+            p3 = fma(qv[7], zv_[7], p3);
+          }
+          for (; c + 3 < dc1; c += 4) {
             p0 = fma(qi[c], sm.zb[c], p0);
             p1 = fma(qi[c + 1], sm.zb[c + 1], p1);
             p2 = fma(qi[c + 2], sm.zb[c + 2], p2);
@@ -202,6 +232,19 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         if (seg_n < nsu) {
           double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
           int i = ui0;
+          for (; i + 7 < ui1; i += 8) {   // (eight rows per round, loads first: see the dot products)
+            double qv[8], cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qv[u] = Qt[(size_t)(i + u) * LD + row_n], cv[u] = sm.cb[i + u];
+            p0 = fma(qv[0], cv[0], p0);
+            p1 = fma(qv[1], cv[1], p1);
+            p2 = fma(qv[2], cv[2], p2);
+            p3 = fma(qv[3], cv[3], p3);
+            p0 = fma(qv[4], cv[4], p0);
+            p1 = fma(qv[5], cv[5], p1);
+            p2 = fma(qv[6], cv[6], p2);
+            p3 = fma(qv[7], cv[7], p3);
+          }
           for (; i + 3 < ui1; i += 4) {
             p0 = fma(Qt[(size_t)i * LD + row_n], sm.cb[i], p0);
             p1 = fma(Qt[(size_t)(i + 1) * LD + row_n], sm.cb[i + 1], p1);
@@ -243,6 +286,28 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           const float* ar = As + row_n * LA;
           double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, s0 = 0.0, s1 = 0.0;
           int c = sc0;
+          for (; c + 7 < sc1; c += 8) {   // (eight columns per round, loads first)
+            float av[8];
+            double zz[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) av[q] = ar[c + q], zz[q] = sm.zb[c + q];
+            u0 = fma((double)av[0], zz[0], u0);
+            u1 = fma((double)av[1], zz[1], u1);
+            u2 = fma((double)av[2], zz[2], u2);
+            u3 = fma((double)av[3], zz[3], u3);
+            s0 = fma(zz[0], zz[0], s0);
+            s1 = fma(zz[1], zz[1], s1);
+            s0 = fma(zz[2], zz[2], s0);
+            s1 = fma(zz[3], zz[3], s1);
+            u0 = fma((double)av[4], zz[4], u0);
+            u1 = fma((double)av[5], zz[5], u1);
+            u2 = fma((double)av[6], zz[6], u2);
+            u3 = fma((double)av[7], zz[7], u3);
+            s0 = fma(zz[4], zz[4], s0);
+            s1 = fma(zz[5], zz[5], s1);
+            s0 = fma(zz[6], zz[6], s0);
+            s1 = fma(zz[7], zz[7], s1);
+          }
           for (; c + 3 < sc1; c += 4) {
             const double z0 = sm.zb[c], z1 = sm.zb[c + 1], z2 = sm.zb[c + 2], z3 = sm.zb[c + 3];
             u0 = fma((double)ar[c], z0, u0);
@@ -349,32 +414,60 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       double gmax = 0.0;
       for (int i = 0; i < n; ++i) gmax = fmax(gmax, sm.zb[i]);
       const double gsc = gmax > 0.0 ? gmax : 1.0;
-      int bs = tid, bt = tid;
+      // P threads per eigenvalue (P = kNT / n, at most 8): a pass probes 2 P points that cut the
+      // bracket into 2 P + 1 parts — the threads of a group exchange their Sturm counts through
+      // LDS and all take the same new bracket — so a 100-node graph needs 15 passes (x 11) where
+      // one thread per eigenvalue needed 33 (x 3), and every thread of the workgroup works.
+      int P = kNT / n;
+      P = P > 8 ? 8 : P;
+      const int ev = tid / P, sub = tid - ev * P;       // eigenvalue index, probe pair of this thread
+      const bool mine = ev < n;
+      int bs = mine ? ev : 0, bt = bs;
       double lam = 0.0;
-      if (tid < n) {
+      double lo = -gsc * 1.0000001, hi = gsc * 1.0000001;
+      int jloc = 0;
+      if (mine) {
         while (bs > 0 && Te[bs - 1] != 0.0) --bs;
         while (bt < n - 1 && Te[bt] != 0.0) ++bt;
-        const int jloc = tid - bs;
-        double lo = -gsc * 1.0000001, hi = gsc * 1.0000001;
-        for (int it = 0; it < 48; ++it) {
-          const double w = (hi - lo) * (1.0 / 3.0);
-          const double xa = lo + w, xb = lo + 2.0 * w;
+        jloc = ev - bs;
+      }
+      // [n][2 P] Sturm counts (n P <= kNT: fits sm.part); the uniform-exit vote below is the
+      // barrier between a pass's reads and the next pass's writes
+      int* cnt = reinterpret_cast<int*>(sm.part);
+      const int np = 2 * P;
+      bool done = !mine;
+      for (int it = 0; it < 48; ++it) {
+        const double w = (hi - lo) / (double)(np + 1);
+        int* cb_ = cnt;
+        if (!done) {
+          const double xa = lo + (double)(2 * sub + 1) * w, xb = lo + (double)(2 * sub + 2) * w;
           int ca, cb;
           sturm2(Td, Te2, bs, bt, xa, xb, ca, cb);
-          if (ca > jloc) hi = xa;
-          else if (cb > jloc) lo = xa, hi = xb;
-          else lo = xb;
-          // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|
-          if ((hi - lo) <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc)) break;
+          cb_[ev * np + 2 * sub] = ca;
+          cb_[ev * np + 2 * sub + 1] = cb;
         }
-        lam = 0.5 * (lo + hi);
+        __syncthreads();
+        if (!done) {
+          // first probe with more than jloc eigenvalues below it: the eigenvalue lies in the part
+          // in front of it (behind the last probe when there is none)
+          int pidx = np;
+          for (int q = np - 1; q >= 0; --q)
+            if (cb_[ev * np + q] > jloc) pidx = q;
+          const double nlo = lo + (double)pidx * w, nhi = pidx == np ? hi : lo + (double)(pidx + 1) * w;
+          lo = nlo, hi = nhi;
+          // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|
+          done = (hi - lo) <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
+        }
+        if (!__syncthreads_or(done ? 0 : 1)) break;
       }
+      lam = 0.5 * (lo + hi);
+      const bool writer = mine && sub == 0;
       __syncthreads();  // zb (Gershgorin rows) is dead: reuse for the eigenvalues
-      if (tid < n) sm.zb[tid] = lam;
+      if (writer) sm.zb[ev] = lam;
       __syncthreads();
-      const bool cluster = tid < n && tid > bs && (lam - sm.zb[tid - 1]) <= 1e-8 * gsc;
+      const bool cluster = writer && ev > bs && (lam - sm.zb[ev - 1]) <= 1e-8 * gsc;
       solved = !__syncthreads_or(cluster ? 1 : 0);
-      if (solved && tid < n) sm.dd[tid] = lam;   // (T itself stays in Td / Te / Te2)
+      if (solved && writer) sm.dd[ev] = lam;   // (T itself stays in Td / Te / Te2)
       __syncthreads();
     }
 

@@ -73,7 +73,11 @@ def test_graphed_train_step_follows_the_eager_trajectory(optim):
     bt = batches[0]
     se = net_e(bt[0], bt[1], bt[2], bt[3], mask=bt[5])
     sg = net_g(bt[0], bt[1], bt[2], bt[3], mask=bt[5])
-  assert (se - sg).abs().max().item() <= (1e-5 if optim == 'sgd' else 1e-2) * se.abs().max().item()
+  # (Adam: the eager backward runs the spectral-filter MLPs on the live eigen rows only, the
+  # captured one — no host knowledge of their number — on all B K rows with the dead ones masked:
+  # the same sums in a different order, and Adam turns rounding noise on near-zero gradients into
+  # +-lr moves, see above)
+  assert (se - sg).abs().max().item() <= (1e-5 if optim == 'sgd' else 5e-2) * se.abs().max().item()
 
 
 def test_graphed_step_needs_a_capturable_optimizer():

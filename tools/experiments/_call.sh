@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c11
+mkdir -p gpurun_out/c13
 export TMPDIR=/tmp
-(timeout 900 python -m pytest tests -m gpu -q -x -k "train or grad or backward" 2>&1 | tail -4) > gpurun_out/c11/pytest.log 2>&1
-(timeout 300 python tools/bench_train_step.py 2>&1 | tail -1) > gpurun_out/c11/train.log 2>&1
-tail -3 gpurun_out/c11/pytest.log; cat gpurun_out/c11/train.log
+(timeout 600 python -m pytest tests/test_gpu_train_graph.py -m gpu -q -x -s 2>&1 | tail -40) > gpurun_out/c13/pytest.log 2>&1
+cat gpurun_out/c13/pytest.log
