@@ -28,7 +28,10 @@ namespace {
 
 constexpr double kBreakdownTol = 1e-8;  // see lanczos_ritz.hip
 constexpr double kEps = 2.220446049250313e-16;
-constexpr int kNT = 512;     // threads per workgroup (the reductions of a Lanczos step are split over all of them)
+#ifndef LNZ_RITZ_WG_THREADS
+#define LNZ_RITZ_WG_THREADS 512
+#endif
+constexpr int kNT = LNZ_RITZ_WG_THREADS;   // threads per workgroup (the reductions of a Lanczos step are split over all of them)
 constexpr int kWaves = kNT / 64;
 constexpr int kNMax = 192;   // largest graph one workgroup owns
 // LDS a workgroup may ask for: the CU has 160 KB; a request of 163,712 B was refused by the runtime
@@ -41,7 +44,8 @@ struct WgFixed {  // fixed part of the LDS block
   double part[kNT];    // (segment, output) partial sums
   double dd[kNMax];    // T diagonal / eigenvalues
   double ee[kNMax];    // T off-diagonal
-  double pn[8];        // partial squared norms
+  double pn[32];       // partial squared norms (one per reduction segment)
+  double pc[kWaves];   // per-wave sums of squared Gram-Schmidt coefficients
   int perm[kNMax];
   float sgn[kNMax];
 };
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         __syncthreads();
         if (ds < nsd) {
           const double* qi = Qt + (size_t)di * LD;
-          double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+          double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, q0 = 0.0, q1 = 0.0;
           int c = dc0;
           // eight elements per round, all sixteen LDS words requested before the first FMA (read
           // pair by pair, every FMA waited a full LDS round trip: the step's parts are a barrier
@@ -209,26 +213,52 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
             p1 = fma(qv[5], zv_[5], p1);
             p2 = fma(qv[6], zv_[6], p2);
             p3 = fma(qv[7], zv_[7], p3);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) q0 = fma(zv_[u], zv_[u], q0), q1 = fma(zv_[u + 1], zv_[u + 1], q1);
           }
-          for (; c + 3 < dc1; c += 4) {
-            p0 = fma(qi[c], sm.zb[c], p0);
-            p1 = fma(qi[c + 1], sm.zb[c + 1], p1);
-            p2 = fma(qi[c + 2], sm.zb[c + 2], p2);
-            p3 = fma(qi[c + 3], sm.zb[c + 3], p3);
+          for (; c < dc1; ++c) {
+            const double zc_ = sm.zb[c];
+            p0 = fma(qi[c], zc_, p0);
+            q0 = fma(zc_, zc_, q0);
           }
-          for (; c < dc1; ++c) p0 = fma(qi[c], sm.zb[c], p0);
           sm.part[ds * cnt + di] = (p0 + p1) + (p2 + p3);
+          if (di == 0 && pass == 0) sm.pn[ds] = q0 + q1;   // |x|^2 over this segment (second-pass test)
         }
         __syncthreads();
         LNZ_LACC(tl_dot)
-        if (tid < cnt) {
-          double c = sm.part[tid];
-          for (int s = 1; s < nsd; ++s) c += sm.part[s * cnt + tid];
-          sm.cb[tid] = c;
+        {
+          double c = 0.0;
+          if (tid < cnt) {
+            c = sm.part[tid];
+            for (int s = 1; s < nsd; ++s) c += sm.part[s * cnt + tid];
+            sm.cb[tid] = c;
+          }
+          if (pass == 0) {   // sum of the squared coefficients, per wave (fixed order)
+            double c2 = c * c;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c2 += __shfl_xor(c2, off, 64);
+            if (lane == 0) sm.pc[wave] = c2;
+          }
         }
         __syncthreads();
         LNZ_LACC(tl_red)
         coef += sm.cb[jidx];
+        // The second pass only where the first one cancelled: with an orthonormal basis
+        // |x'|^2 = |x|^2 - sum c_i^2, and one classical Gram-Schmidt pass leaves components of
+        // order eps |x| along the basis, i.e. eps |x| / |x'| relative to the new vector.  A Lanczos
+        // vector A q_j always loses most of its length to q_j and q_{j-1} (alpha, beta), so the
+        // textbook threshold 1 / sqrt(2) would never skip; the second pass (four of the ten
+        // barrier phases of a step) runs when |x'| < 0.1 |x| — orthogonality 10 eps per step
+        // otherwise, nine orders of magnitude inside what (D, V) are compared at.  The breakdown
+        // / restart path (|x'| tiny) always takes it.  Every thread sees the same numbers: the
+        // decision is workgroup uniform.
+        bool again = true;
+        if (pass == 0) {
+          double xx = sm.pn[0], cc2 = sm.pc[0];
+          for (int s = 1; s < nsd; ++s) xx += sm.pn[s];
+          for (int wv = 1; wv < kWaves; ++wv) cc2 += sm.pc[wv];
+          again = !(cc2 <= 0.99 * xx);
+        }
         if (seg_n < nsu) {
           double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
           int i = ui0;
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           }
         }
         LNZ_LACC(tl_upd)
+        if (!again) break;
       }
       return coef;
     };
