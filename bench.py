@@ -868,7 +868,8 @@ def main():
     # padded rows and the GEMM2 of identity bond-type channels — counted instruction by
     # instruction from the plan (lanczosnet_amd/utils/flop_model.py; agrees with rocprofv3's
     # SQ_INSTS_VALU_MFMA_MOPS_F32 of this kernel, tests/test_flop_model.py)
-    from lanczosnet_amd.utils.flop_model import tiles_from_plan, forward_mfma_issued
+    from lanczosnet_amd.utils.flop_model import (tiles_from_plan, forward_mfma_issued,
+                                                 forward16_mfma_issued, forward16_selected)
     with torch.no_grad():
       Lp_m, (buf, cap), _, _, _ = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
     torch.cuda.synchronize()
@@ -876,7 +877,12 @@ def main():
     extents = np.where(mk.any(axis=1), mk.shape[1] - np.argmax(mk[:, ::-1] != 0, axis=1), 0)
     tile_list = tiles_from_plan(buf[:12 * cap].cpu().numpy(), extents,
                                 Lp_m.ident.cpu().numpy() if hasattr(Lp_m, 'ident') else None, K)
-    fm = forward_mfma_issued(tile_list, cfg)
+    # which of the two exact-fp32 forward kernels took the launches (csrc/conv_forward.hip launch_conv)
+    f16 = args.gemm == 'fp32' and forward16_selected(cfg)
+    fm = forward16_mfma_issued(tile_list, cfg) if f16 else forward_mfma_issued(tile_list, cfg)
+    roof_kernel = 'lanczosnet_forward16_kernel' if f16 else 'lanczosnet_forward_kernel<4,10,0,0>'
+    roof_insn = ('2048 flop x the v_mfma_f32_16x16x4_f32' if f16 else
+                 '4096 flop x the v_mfma_f32_32x32x2_f32')
     n_tiles = fm['tiles']
     flops_exec = fm['flops_issued']
     achieved = flops_exec / fwd_s / 1e12
@@ -887,7 +893,7 @@ def main():
     # process, so `traffic` cites the committed counter run of the SAME command and workload
     # (tools/pmc_forward_profile.py -> profiles/), never a number measured in this run
     traffic, traffic_source = None, None
-    for name in ('r03_forward_pmc.json', 'pmc_forward_hbm_bytes.json'):
+    for name in (('r04_forward16_pmc.json',) if f16 else ('r03_forward_pmc.json', 'pmc_forward_hbm_bytes.json')):
       prof = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(prof) and B == 1024:
         try:
@@ -912,7 +918,7 @@ def main():
                    % world, 'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()}},
         # frac = flops the kernel ISSUES / launch time / peak: the long-scale
         # channels run in eigen space, 9.5 % fewer flops than the reference's association
-        'roofline': {'kernel': 'lanczosnet_forward_kernel<4,10,0,0>', 'bound': 'mfma',
+        'roofline': {'kernel': roof_kernel, 'bound': 'mfma',
                      'achieved': round(achieved, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                      'traffic': traffic, 'traffic_source': traffic_source,
@@ -925,7 +931,7 @@ def main():
                      'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4),
                      'reference_association_tflops': round(FWD_FLOP_PER_MOL * n_tiles / fwd_s / 1e12, 2),
                      'note': 'achieved = frac * peak = flops_per_launch_executed / avg_launch_ms. '
-                             'flops_per_launch_executed = 4096 flop x the v_mfma_f32_32x32x2_f32 '
+                             'flops_per_launch_executed = %s '
                              'instructions the kernel issues for THIS batch\'s tile plan (k-groups of '
                              'padded rows / empty eigen slots and identity bond-type channels are '
                              'skipped; utils/flop_model.py, checked against the PMC counter '
@@ -936,7 +942,7 @@ def main():
                              'reference_association_tflops prices the tiles at SURVEY 8(d)\'s %d flop '
                              '(filter build + L_s Z per long channel, which the kernel replaces by one '
                              'projection and one lift per layer)'
-                             % (n_tiles, B, n_tiles, FWD_FLOP_PER_MOL)},
+                             % (roof_insn, n_tiles, B, n_tiles, FWD_FLOP_PER_MOL)},
     }
     if dist:
       out['config']['exchange'] = {

@@ -33,6 +33,7 @@
 // HBM bytes per molecule: Lp 28,672 + V 2,560 + G 4,480 + ids 256 + mask 32 in, 64 out; the
 // 7.4 MB of packed weights are shared by all workgroups and stay L2 / Infinity-Cache resident.
 #include "common.hpp"
+#include "conv_tiles.hpp"
 #include <type_traits>
 
 namespace {
@@ -62,16 +63,6 @@ __device__ inline f32x16 frag_from4(const float4 (&v)[4]) {
   }
   return f;
 }
-
-// The argument block is read where the dispatch packet put it — the kernarg segment (constant
-// address space, scalar loads, dynamic indexing of its arrays) — instead of a private copy.
-typedef const __attribute__((address_space(4))) lnz_forward_args KArgs;
-
-struct TileDesc {
-  int ta;     // molecule in rows [0, split)  (the only one of a single tile)
-  int tb;     // molecule in rows [split, 32) or -1
-  int split;  // multiple of 8; 32 for a single tile
-};
 
 // One HALF of a workgroup: NWV wavefronts (wave w owns output-feature tile w) running the whole
 // network for MT node tiles, so every packed-weight fragment a wave loads feeds MT x 4 MFMAs (the
@@ -105,57 +96,6 @@ __device__ __forceinline__ int pick(const int (&v)[MT], int m) {
 // row rho >= split is slot k = rho - split of molecule B (a molecule has <= min(n, K) live slots and
 // n <= its row extent), so V^T and V are block-diagonal exactly like the Laplacians and the
 // summation order of a molecule's terms never depends on its tile partner.
-// Slot `slot` of the tile plan (or, without a plan, molecule `slot` as a single tile).
-__device__ __forceinline__ TileDesc load_tile_desc(KArgs& a, int slot) {
-  TileDesc t;
-  if (a.plan) {
-    t.ta = a.plan[3 * slot + 0];
-    t.tb = a.plan[3 * slot + 1];
-    t.split = a.plan[3 * slot + 2];
-  } else {
-    t.ta = slot < a.B ? slot : -1;
-    t.tb = -1;
-    t.split = 32;
-  }
-  t.ta = __builtin_amdgcn_readfirstlane(t.ta);
-  t.tb = __builtin_amdgcn_readfirstlane(t.tb);
-  t.split = __builtin_amdgcn_readfirstlane(t.split);
-  return t;
-}
-
-// Node extents (last real node + 1) of the one or two molecules of a tile, wave uniform.
-__device__ __forceinline__ void tile_extents(KArgs& a, const TileDesc& t, int lane, int& nA, int& nB) {
-  const bool pr = t.tb >= 0;
-  int la = 0, lb = 0;
-  for (int i = lane; i < a.N; i += 64) {
-    la = a.mask[(int64_t)t.ta * a.N + i] ? i + 1 : la;
-    if (pr) lb = a.mask[(int64_t)t.tb * a.N + i] ? i + 1 : lb;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    la = max(la, __shfl_xor(la, off, 64));
-    lb = max(lb, __shfl_xor(lb, off, 64));
-  }
-  nA = __builtin_amdgcn_readfirstlane(la);
-  nB = __builtin_amdgcn_readfirstlane(lb);
-}
-
-// 8-row groups of the tile that hold real nodes (bit g: rows 8g..8g+7): A from row 0, B from `split`.
-__device__ __forceinline__ int row_group_mask(int nA, int nB, int split) {
-  return ((1 << ((nA + 7) >> 3)) - 1) | (((1 << ((nB + 7) >> 3)) - 1) << (split >> 3));
-}
-
-// Ritz tile [node row][slot row] of one node tile, block diagonal: element (jj, rho) belongs to
-// the molecule owning BOTH rows, V[mol][local node][local slot] (zero elsewhere / beyond N, K).
-__device__ __forceinline__ float ritz_tile_elem(KArgs& a, const TileDesc& t, int jj, int rho) {
-  const bool first = jj < t.split, sfirst = rho < t.split;
-  const int row = first ? jj : jj - t.split;
-  const int k = sfirst ? rho : rho - t.split;
-  const int mol = first ? t.ta : t.tb;
-  const bool ok = sfirst == first && k < a.K && row < a.N && mol >= 0;
-  return ok ? a.V[((int64_t)mol * a.N + row) * a.K + k] : 0.0f;
-}
-
 // MODE 0 = forward; MODE 3 = forward that also stores every layer's activations (training);
 // MODE 1 = input-gradient pass (lnz_lanczosnet_input_grad): the same two chained GEMMs run on dY
 //          with per-channel transposed weights, kernel layer t = conv layer num_layer-1-t, the
@@ -1316,6 +1256,8 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const l
 
 namespace lnz {
 int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_forward_f16.hip
+bool forward16_eligible(const lnz_forward_args& a);                   // conv_forward16.hip
+int launch_forward16(const lnz_forward_args& a, hipStream_t s);
 }
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
@@ -1327,6 +1269,17 @@ static bool dense_filters_in_node_space() {
   static const bool v = [] {
     const char* e = getenv("LNZ_DENSE_FILTER_NODE_SPACE");
     return e && atoi(e) != 0;
+  }();
+  return v;
+}
+
+// The inference forward runs on 16 x 16 MFMA tiles with all eight waves on all of a workgroup's
+// node tiles (conv_forward16.hip) where that kernel is built; LNZ_FORWARD16=0 keeps the 32 x 32
+// kernel of this file for A/B runs (lanczosnet_amd/utils/flop_model.py reads the same variable).
+static bool forward16_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("LNZ_FORWARD16");
+    return !e || atoi(e) != 0;
   }();
   return v;
 }
@@ -1367,6 +1320,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
+    if (forward16_enabled() && lnz::forward16_eligible(a)) return lnz::launch_forward16(a, s);
   } else {
     LNZ_REQUIRE(a.gemm_mode == 0 && (a.filter_kind == 0 || dense_es) && a.dhid == 128, LNZ_ENOTSUP,
                 "%s: built for gemm_mode 0, hidden width 128, diagonal gains or dense filters in "

@@ -17,10 +17,25 @@ inside din0) and the head (one wave per tile, dhid / 2 instructions).  g2mask / 
 `row_group_mask` (conv_forward.hip:139): molecule A fills groups from row 0, molecule B from the
 split row.  One instruction = 2 * 32 * 32 * 2 = 4096 flop = 8 counts of the PMC counter (512 flop
 per count).
+
+`lanczosnet_forward16_kernel` (csrc/conv_forward16.hip: the same algebra on
+`v_mfma_f32_16x16x4_f32`, 2048 flop = 4 counter units; eight waves of 16 output columns on every tile
+of the workgroup) issues per tile, wave and layer
+
+    GEMM1      (n_long + n_edge) * d_in / 2                  (8 instructions per 16-k step)
+    lift-back  8 * popcount(slot subtiles)                   16-row subtiles that hold Ritz pairs
+    GEMM2      (n_edge - n_ident) * 8 * popcount(row subtiles)
+    projection 8 * popcount(row subtiles)                    (not the last layer)
+
+plus the first layer's projection (waves whose 16 columns lie inside din0) and the head (one wave per
+tile, dhid / 2 instructions of the 32x32x2 kind).  It takes the launches `forward16_selected` says.
 """
+import os
+
 import numpy as np
 
 FLOP_PER_MFMA = 2 * 32 * 32 * 2          # v_mfma_f32_32x32x2_f32
+FLOP_PER_MFMA16 = 2 * 16 * 16 * 4        # v_mfma_f32_16x16x4_f32
 FLOP_PER_MOPS_COUNT = 512                # SQ_INSTS_VALU_MFMA_MOPS_F32 unit
 
 
@@ -28,6 +43,26 @@ def _row_groups(n_a, n_b, split):
   ga = (n_a + 7) >> 3
   gb = ((n_b + 7) >> 3) if n_b > 0 else 0
   return ga + gb if split < 32 else ga   # B's groups start at split / 8: disjoint from A's
+
+
+def _subtiles16(n_a, n_b, split):
+  """16-row subtiles of a tile that hold a row of A (from row 0) or B (from the split row):
+  conv_forward16.hip live16."""
+  mask = (1 << ((n_a + 7) >> 3)) - 1
+  if split < 32 and n_b > 0:
+    mask |= ((1 << ((n_b + 7) >> 3)) - 1) << (split >> 3)
+  return (1 if mask & 3 else 0) + (1 if mask & 12 else 0)
+
+
+def forward16_selected(cfg):
+  """Mirror of lnz::forward16_eligible + the LNZ_FORWARD16 switch (csrc/conv_forward.hip): does the
+  exact-fp32 inference forward of this LanczosNet model run on the 16 x 16-tile kernel?"""
+  if os.environ.get('LNZ_FORWARD16', '1') in ('0',):
+    return False
+  hid = cfg['hidden_dim']
+  return (len(cfg['short_diffusion_dist']) == 0 and all(h == 128 for h in hid) and
+          cfg['input_dim'] % 64 == 0 and cfg['input_dim'] <= 128 and
+          len(cfg['long_diffusion_dist']) <= 12)
 
 
 def tiles_from_plan(plan_entries, extents, ident=None, K=20):
@@ -47,9 +82,10 @@ def tiles_from_plan(plan_entries, extents, ident=None, K=20):
       idb = int(ident[ta]) & 0xffffffff
       if tb >= 0:
         idb &= int(ident[tb]) & 0xffffffff
-    out.append(dict(nA=n_a, nB=n_b, split=int(split) if tb >= 0 else 32, ident=idb,
-                    pg=_row_groups(n_a, n_b, int(split) if tb >= 0 else 32),
-                    ps=_row_groups(min(n_a, K), min(n_b, K), int(split) if tb >= 0 else 32)))
+    sp = int(split) if tb >= 0 else 32
+    out.append(dict(nA=n_a, nB=n_b, split=sp, ident=idb,
+                    pg=_row_groups(n_a, n_b, sp), ps=_row_groups(min(n_a, K), min(n_b, K), sp),
+                    pg16=_subtiles16(n_a, n_b, sp), ps16=_subtiles16(min(n_a, K), min(n_b, K), sp)))
   return out
 
 
@@ -87,4 +123,43 @@ def forward_mfma_issued(tiles, cfg, nwv=4):
   return dict(tiles=len(tiles), mfma_issued=int(issued), mfma_unskipped=int(full),
               flops_issued=int(issued) * FLOP_PER_MFMA, flops_unskipped=int(full) * FLOP_PER_MFMA,
               mops_counts=int(issued) * (FLOP_PER_MFMA // FLOP_PER_MOPS_COUNT),
+              useful_row_frac=rows_real / (32.0 * max(1, len(tiles))))
+
+
+def forward16_mfma_issued(tiles, cfg):
+  """The same record as forward_mfma_issued for lanczosnet_forward16_kernel.  `mfma_issued` counts
+  v_mfma_f32_16x16x4_f32 instructions (2048 flop) plus the head's 32x32x2 instructions counted
+  double (4096 flop): flops_issued = 2048 * mfma_issued."""
+  n_long = len(cfg['long_diffusion_dist'])
+  n_edge = cfg['num_bond_type'] + 1
+  C = n_long + n_edge
+  din0, dhid, nl = cfg['input_dim'], cfg['hidden_dim'][0], cfg['num_layer']
+  assert len(cfg['short_diffusion_dist']) == 0 and dhid == 128
+
+  def per_tile(pg, ps, n_ident):
+    tot = 0
+    for l in range(nl):
+      d_in = din0 if l == 0 else dhid
+      per_wave = C * (d_in // 2) + (8 * ps if n_long else 0) + (n_edge - n_ident) * 8 * pg
+      if n_long and l + 1 < nl:
+        per_wave += 8 * pg
+      tot += 8 * per_wave
+    if n_long:
+      tot += (din0 // 16) * 8 * pg                   # first layer's projection
+    tot += 2 * (dhid // 2)                           # head: one wave per tile, 32x32x2
+    return tot
+
+  issued = 0
+  rows_real = 0
+  emask = (1 << n_edge) - 1
+  K = cfg['num_eig_vec']
+  for t in tiles:
+    pg16 = t['pg16'] if 'pg16' in t else _subtiles16(t['nA'], t['nB'], t['split'])
+    ps16 = t['ps16'] if 'ps16' in t else _subtiles16(min(t['nA'], K), min(t['nB'], K), t['split'])
+    issued += per_tile(pg16, ps16, bin(t['ident'] & emask).count('1'))
+    rows_real += t['nA'] + t['nB']
+  full = per_tile(2, 2, 0) * len(tiles)
+  return dict(tiles=len(tiles), mfma_issued=int(issued), mfma_unskipped=int(full),
+              flops_issued=int(issued) * FLOP_PER_MFMA16, flops_unskipped=int(full) * FLOP_PER_MFMA16,
+              mops_counts=int(issued) * (FLOP_PER_MFMA16 // FLOP_PER_MOPS_COUNT),
               useful_row_frac=rows_real / (32.0 * max(1, len(tiles))))

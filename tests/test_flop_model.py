@@ -8,7 +8,8 @@ import os
 
 import numpy as np
 
-from lanczosnet_amd.utils.flop_model import forward_mfma_issued, tiles_from_plan
+from lanczosnet_amd.utils.flop_model import (forward16_mfma_issued, forward16_selected,
+                                             forward_mfma_issued, tiles_from_plan)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 QM8_CFG = dict(num_atom=70, num_bond_type=6, short_diffusion_dist=[],
@@ -30,6 +31,34 @@ def test_issued_mfma_model_agrees_with_the_pmc_counter():
   # the skipped k-groups and identity channels are real: the unskipped count is what r02 priced
   assert fm['mfma_unskipped'] > fm['mfma_issued']
   assert 0.5 < fm['useful_row_frac'] < 1.0
+
+
+def test_issued_mfma_model_of_the_16x16_tile_kernel_agrees_with_the_pmc_counter():
+  """lanczosnet_forward16_kernel (the default inference forward of the QM8 model, round 4):
+  profiles/r04_forward16_pmc.json / r04_forward16_tile_plan.npz, same tool and command."""
+  pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_forward16_pmc.json')))
+  assert pmc['kernel'].startswith('lanczosnet_forward16_kernel')
+  plan = np.load(os.path.join(ROOT, 'profiles', 'r04_forward16_tile_plan.npz'))
+  tiles = [dict(nA=int(a), nB=int(b), split=int(s), ident=int(i))
+           for a, b, s, i in zip(plan['nA'], plan['nB'], plan['split'], plan['ident'])]
+  fm = forward16_mfma_issued(tiles, QM8_CFG)
+  measured = pmc['SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch']
+  assert abs(fm['mops_counts'] - measured) <= 0.002 * measured, (fm['mops_counts'], measured)
+  assert fm['mfma_unskipped'] > fm['mfma_issued']
+  # the recorded subtile counts are the ones the model derives from the extents
+  rec = forward16_mfma_issued([dict(t, pg16=int(g), ps16=int(p))
+                               for t, g, p in zip(tiles, plan['pg16'], plan['ps16'])], QM8_CFG)
+  assert rec['mfma_issued'] == fm['mfma_issued']
+
+
+def test_forward16_selection_mirrors_the_launcher(monkeypatch):
+  monkeypatch.delenv('LNZ_FORWARD16', raising=False)
+  assert forward16_selected(QM8_CFG)
+  assert not forward16_selected(dict(QM8_CFG, short_diffusion_dist=[1, 2]))
+  assert not forward16_selected(dict(QM8_CFG, input_dim=32))
+  assert not forward16_selected(dict(QM8_CFG, hidden_dim=[64] * 7))
+  monkeypatch.setenv('LNZ_FORWARD16', '0')
+  assert not forward16_selected(QM8_CFG)
 
 
 def test_tile_masks_follow_row_group_mask():
