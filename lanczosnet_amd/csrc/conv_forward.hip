@@ -1256,8 +1256,8 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const l
 
 namespace lnz {
 int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_forward_f16.hip
-bool forward16_eligible(const lnz_forward_args& a);                   // conv_forward16.hip
-int launch_forward16(const lnz_forward_args& a, hipStream_t s);
+bool forward16_eligible(const lnz_forward_args& a, int mode);         // conv_forward16.hip
+int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s);
 }
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
@@ -1320,7 +1320,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
-    if (forward16_enabled() && lnz::forward16_eligible(a)) return lnz::launch_forward16(a, s);
+    if (forward16_enabled() && lnz::forward16_eligible(a, 0)) return lnz::launch_forward16(a, 0, s);
   } else {
     LNZ_REQUIRE(a.gemm_mode == 0 && (a.filter_kind == 0 || dense_es) && a.dhid == 128, LNZ_ENOTSUP,
                 "%s: built for gemm_mode 0, hidden width 128, diagonal gains or dense filters in "
@@ -1332,6 +1332,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                   LNZ_EINVAL, "%s: need Wp (transposed packs), dy, dx0, din0 == dhid, bwd_din0", who);
       LNZ_REQUIRE(!a.dy_compact || (a.row_off && a.dy_compact_rows > 0), LNZ_EINVAL,
                   "%s: dy_compact needs row_off and dy_compact_rows", who);
+      if (forward16_enabled() && lnz::forward16_eligible(a, 1)) return lnz::launch_forward16(a, 1, s);
     } else {
       LNZ_REQUIRE(a.msg && a.msg_layer >= 0 && a.msg_layer < a.num_layer &&
                       (a.msg_layer > 0 || a.x0),

@@ -80,9 +80,15 @@ __device__ __forceinline__ int live16(int nA, int nB, int split) {
   return ((g & 3) ? 1 : 0) | ((g & 12) ? 2 : 0);
 }
 
-template <int NT, int P>
+// MODE 0 = forward (a.act_out: every layer's activations are stored as well — the training forward);
+// MODE 1 = input-gradient pass (lnz_lanczosnet_input_grad): the same chained GEMMs run on dY with the
+//          per-channel transposed weight packs, kernel iteration l = conv layer num_layer - 1 - l,
+//          the epilogue masks with the stored activation instead of bias + ReLU and writes dY_{la-1}
+//          (last iteration: dX_0, bwd_din0 columns — the waves beyond them only keep the barriers).
+template <int NT, int P, int MODE>
 __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], float* lds,
                                           const int tid, const int wave) {
+  constexpr bool FWD = MODE == 0;
 #ifdef LNZ_F16_PHASES
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_all = clock64(), _t0 = t_all;
 #define LNZ_PH(i) { const long long _t1 = clock64(); ph[i] += _t1 - _t0; _t0 = _t1; }
@@ -111,7 +117,11 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
       const int mol = first ? t.ta : t.tb;
       const int lrow = first ? row : row - t.split;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lrow < N && mol >= 0) {
+      if (!FWD) {  // the incoming gradient dY of the last conv layer
+        if (mol >= 0)
+          v = reinterpret_cast<const float4*>(
+              a.dy + (((int64_t)(a.num_layer - 1) * B + mol) * 32 + lrow) * 128)[c4];
+      } else if (lrow < N && mol >= 0) {
         if (a.node_feat) {
           int64_t id = a.node_feat[(int64_t)mol * N + lrow];
           id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
@@ -131,8 +141,8 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
     tile_extents(a, td[m], lane, nA[m], nB[m]);
     rl[m] = live16(nA[m], nB[m], td[m].split);
     sl[m] = live16(nA[m] < K ? nA[m] : K, nB[m] < K ? nB[m] : K, td[m].split);
-    unsigned v = a.ident ? a.ident[td[m].ta] : 0u;
-    if (a.ident && td[m].tb >= 0) v &= a.ident[td[m].tb];
+    unsigned v = (FWD && a.ident) ? a.ident[td[m].ta] : 0u;
+    if (FWD && a.ident && td[m].tb >= 0) v &= a.ident[td[m].tb];
     idm[m] = __builtin_amdgcn_readfirstlane((int)v);
   }
 
@@ -185,8 +195,8 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
     }
   };
   if (nl > 0) {
-    load_gains(0);
-    store_gains(0);
+    load_gains(FWD ? 0 : a.num_layer - 1);
+    store_gains(FWD ? 0 : a.num_layer - 1);
   }
 
   // ---- per-lane addressing of the packed Laplacian: for (tile m, row subtile I) this lane's row
@@ -221,25 +231,33 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
   const lds_cptr xlane = (lds_cptr)(Xs + j * P + 4 * kq);  // this lane's A row of tile 0, subtile 0
   int cur = 0;
   for (int l = 0; l < a.num_layer; ++l) {
+    const int la = FWD ? l : a.num_layer - 1 - l;  // conv layer of this iteration
+    const int lg = FWD ? l + 1 : la - 1;            // layer whose gains are staged under it
+    const bool more = l + 1 < a.num_layer;
     const int din = l == 0 ? a.din0 : 128;
     const int Q = din >> 3, Q16 = din >> 4;
     const int Gtot = C * Q;
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
-    const float* gsl = Gs + (l & 1) * NT * nl * 32;
+    const float* gsl = Gs + (la & 1) * NT * nl * 32;
     const int nxt = cur ^ 1;
+    // width this iteration produces: waves beyond it only keep the barriers
+    const int wout = FWD ? 128 : (la == 0 ? a.bwd_din0 : 128);
+    const bool active = FWD || 16 * wave < wout;
 
     // weight stream of this wave: contiguous over the layer's channels, 128 float4 per 16-k step,
     // 4-slot register ring (prefetch distance 3 steps = 24 NT MFMAs)
     const float4* __restrict__ wp = Wl + (int64_t)rt * Gtot * 64 + wlane;
     float4 ring[4];
+    if (active) {
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+      for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+    }
     // (behind the ring prime: vector loads return in order, the first steps must not wait for G)
-    if (nl > 0 && l + 1 < a.num_layer) load_gains(l + 1);
+    if (nl > 0 && more) load_gains(lg);
 
     f32x4 out[NT][2];
     {
-      const float bv = (a.bias + a.b_off[l])[16 * wave + j];
+      const float bv = FWD ? (a.bias + a.b_off[l])[16 * wave + j] : 0.0f;
 #pragma unroll
       for (int m = 0; m < NT; ++m) out[m][0] = out[m][1] = splat4(bv);
     }
@@ -351,7 +369,7 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
     };
 
     // ---------------- eigen-space block: out += V [ sum_s diag(g_s) (Y W_s^T) ] ----------------
-    if (nl > 0) {
+    if (nl > 0 && active) {
       const lds_cptr y0 = xlane + nxt * NT * TILE;
       load_first(y0);
       // each channel's GEMM1 runs unscaled and its C/D rows (= eigen slots) are scaled into T
@@ -396,7 +414,7 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
 
     LNZ_PH(3)  // lift
     // ---------------- node-space block: out += M_e (X W_e^T) per edge type ----------------
-    {
+    if (active) {
       const lds_cptr x0 = xlane + cur * NT * TILE;
       load_first(x0);
       f32x4 mop[NT][2][2];
@@ -442,22 +460,55 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
       }
     }
 
-    // ---------------- epilogue: X' = relu(out) where Y was, Y' = V^T X' where X was ----------
-    if (nl > 0 && l + 1 < a.num_layer) store_gains(l + 1);  // (buffer last read in layer l - 1)
+    // ---------------- epilogue: X' where Y was, Y' = V^T X' where X was ----------
+    //   forward: X' = relu(out) (+ the activation store training asks for)
+    //   MODE 1:  dY_{la-1} = out * [X_la > 0] -> LDS and dy[la-1]; the last iteration writes dX_0
+    if (nl > 0 && more) store_gains(lg);  // (buffer last read two iterations ago)
     if (nl > 0) __syncthreads();  // every wave is through with X and Y
-    {
+    if (active) {
       const int col = 16 * wave + j;
 #pragma unroll
       for (int m = 0; m < NT; ++m) {
+        // (the tile's ids pass through an empty asm: row addresses are recomputed per layer instead
+        // of being hoisted out of the layer loop, where they would hold registers across the GEMMs)
+        int t_sp = td[m].split, t_a = td[m].ta, t_b = td[m].tb;
+        asm volatile("" : "+s"(t_sp), "+s"(t_a), "+s"(t_b));
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < 2; ++I) {
+          // rows 16 I + 4 kq + r of the tile: one owner (the split row is a multiple of 8)
+          const int row0 = 16 * I + 4 * kq;
+          const bool first = row0 < t_sp;
+          const int mol = first ? t_a : t_b;
+          const int64_t rowbase = (int64_t)(mol >= 0 ? mol : 0) * 32 + (row0 - (first ? 0 : t_sp));
+          f32x4 v = out[m][I];
+          if (FWD) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = fmaxf(out[m][I][r], 0.0f);
-            out[m][I][r] = v;
-            Xs[nxt * NT * TILE + m * TILE + (16 * I + 4 * kq + r) * P + col] = v;
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            if (a.act_out && mol >= 0) {
+              float* p = a.act_out + ((int64_t)l * B * 32 + rowbase) * 128 + col;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) p[r * 128] = v[r];
+            }
+          } else if (la > 0) {
+            const int64_t at = ((int64_t)(la - 1) * B * 32 + rowbase) * 128 + col;
+            const float* xa = a.act + at;
+            float* dyp = a.dy + at;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = (mol >= 0 && xa[r * 128] > 0.0f) ? v[r] : 0.0f;
+              if (mol >= 0) dyp[r * 128] = v[r];
+            }
+          } else if (mol >= 0) {
+            float* p = a.dx0 + rowbase * a.bwd_din0 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r * a.bwd_din0] = v[r];
           }
-        if (nl > 0 && l + 1 < a.num_layer) {
+          out[m][I] = v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Xs[nxt * NT * TILE + m * TILE + (row0 + r) * P + col] = v[r];
+        }
+        if (nl > 0 && more) {
           f32x4 Y[2] = {splat4(0.f), splat4(0.f)};
 #pragma unroll
           for (int J = 0; J < 2; ++J) {
@@ -476,6 +527,41 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
               Xs[cur * NT * TILE + m * TILE + (16 * I + 4 * kq + r) * P + col] = Y[I][r];
         }
       }
+      if (MODE == 1 && la > 0 && (a.dy_compact || a.dbias_part)) {
+        // What the weight / bias gradients of conv layer la - 1 need: dY_{la-1} in the COMPACT row
+        // numbering of the message matrix (real nodes only) and this workgroup's column sums (rows
+        // of padded nodes and of unowned tile rows are zero) — one writer per (workgroup, layer,
+        // column): entry 2 * blockIdx.x of dbias_part, its odd neighbour stays zero.
+        float colsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          int t_sp = td[m].split, t_a = td[m].ta, t_b = td[m].tb;
+          asm volatile("" : "+s"(t_sp), "+s"(t_a), "+s"(t_b));
+#pragma unroll
+          for (int I = 0; I < 2; ++I) {
+            const int row0 = 16 * I + 4 * kq;
+            const bool first = row0 < t_sp;
+            const int mol = first ? t_a : t_b;
+            const int lrow0 = row0 - (first ? 0 : t_sp);
+            const int nmol = first ? nA[m] : nB[m];
+            const f32x4 v = out[m][I];
+            colsum += (v[0] + v[1]) + (v[2] + v[3]);
+            if (a.dy_compact && mol >= 0) {
+              float* dc = a.dy_compact +
+                          ((int64_t)(la - 1) * a.dy_compact_rows + a.row_off[mol] + lrow0) * 128 + col;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (lrow0 + r < nmol) dc[r * 128] = v[r];
+            }
+          }
+        }
+        if (a.dbias_part) {
+          colsum += __shfl_xor(colsum, 16, 64);
+          colsum += __shfl_xor(colsum, 32, 64);
+          if (kq == 0)
+            a.dbias_part[(((int64_t)blockIdx.x * 2) * a.num_layer + (la - 1)) * 128 + col] = colsum;
+        }
+      }
     }
     __syncthreads();
     cur = nxt;
@@ -489,6 +575,8 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
     d[9] = (float)NT;
   }
 #endif
+
+  if (!FWD) return;
 
   // ---- optional debug/test output of the final node state (rows of the tile each molecule owns)
   if (a.state_out) {
@@ -561,6 +649,7 @@ constexpr int lds_floats(int NT, int P, int nl) {
 // One workgroup = 8 waves on the 1..4 node tiles of its plan entry.  Three tiles or fewer: row
 // pitch 136 (conflict-free A fragments); four tiles only fit in 160 KB at pitch 132 (one of the
 // instruction's four lane groups then takes a 2-way conflict).
+template <int MODE>
 __global__ __launch_bounds__(512) void lanczosnet_forward16_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) float lds16[];
@@ -584,16 +673,16 @@ __global__ __launch_bounds__(512) void lanczosnet_forward16_kernel(const lnz_for
   constexpr int ONLY = LNZ_F16_ONLY_NT;
   if (nt == 3 && (ONLY == 0 || ONLY == 3)) {
     const TileDesc t3[3] = {s0, c1, c2};
-    forward16<3, 136>(a, t3, lds16, tid, wave);
+    forward16<3, 136, MODE>(a, t3, lds16, tid, wave);
   } else if (nt == 2 && (ONLY == 0 || ONLY == 2)) {
     const TileDesc t2[2] = {s0, c1};
-    forward16<2, 136>(a, t2, lds16, tid, wave);
+    forward16<2, 136, MODE>(a, t2, lds16, tid, wave);
   } else if (nt == 4 && (ONLY == 0 || ONLY == 4)) {
     const TileDesc t4[4] = {s0, s1, s2, s3};
-    forward16<4, 132>(a, t4, lds16, tid, wave);
+    forward16<4, 132, MODE>(a, t4, lds16, tid, wave);
   } else if (nt == 1 && (ONLY == 0 || ONLY == 1)) {
     const TileDesc t1[1] = {s0};
-    forward16<1, 136>(a, t1, lds16, tid, wave);
+    forward16<1, 136, MODE>(a, t1, lds16, tid, wave);
   }
 }
 
@@ -601,11 +690,13 @@ __global__ __launch_bounds__(512) void lanczosnet_forward16_kernel(const lnz_for
 
 namespace lnz {
 
-// The inference forward on 16 x 16 tiles where it is built (see the file comment); returns
-// LNZ_ENOTSUP without touching the error text when the launch belongs to conv_forward.hip.
-bool forward16_eligible(const lnz_forward_args& a) {
-  if (a.gemm_mode != 0 || a.filter_kind != 0 || a.act_out) return false;
+// The forward (mode 0, with or without the activation store) and the input-gradient pass (mode 1)
+// on 16 x 16 tiles where they are built (see the file comment).
+bool forward16_eligible(const lnz_forward_args& a, int mode) {
+  if (mode != 0 && mode != 1) return false;
+  if (a.gemm_mode != 0 || a.filter_kind != 0) return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128 || a.n_short != 0) return false;
+  if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
   if (a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12) return false;
   // 32-bit byte offsets into the packed Laplacian and the gains (raw buffer loads)
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
@@ -613,18 +704,22 @@ bool forward16_eligible(const lnz_forward_args& a) {
   return (size_t)lds_floats(4, 132, a.n_long) * sizeof(float) <= 160 * 1024;
 }
 
-int launch_forward16(const lnz_forward_args& a, hipStream_t s) {
+int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s) {
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;
   const int f3 = lds_floats(3, 136, a.n_long), f4 = lds_floats(4, 132, a.n_long);
   const size_t bytes = (size_t)(f3 > f4 ? f3 : f4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lanczosnet_forward16_kernel,
+    (void)hipFuncSetAttribute((const void*)lanczosnet_forward16_kernel<0>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lanczosnet_forward16_kernel<1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(lanczosnet_forward16_kernel, dim3(grid), dim3(512), bytes, s, a);
-  return check_launch("lnz_lanczosnet_forward (16x16 tiles)");
+  if (mode == 0) hipLaunchKernelGGL(lanczosnet_forward16_kernel<0>, dim3(grid), dim3(512), bytes, s, a);
+  else hipLaunchKernelGGL(lanczosnet_forward16_kernel<1>, dim3(grid), dim3(512), bytes, s, a);
+  return check_launch(mode == 0 ? "lnz_lanczosnet_forward (16x16 tiles)"
+                                : "lnz_lanczosnet_input_grad (16x16 tiles)");
 }
 
 }  // namespace lnz
