@@ -589,8 +589,11 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
                                         'folded into the first / last weights)' % (n_in, n_out),
                               'note': 'achieved prices the flops executed; stage time includes '
                                       'the input gather and the 7 output scatters'},
-          'conv_kernel': 'lanczosnet_forward_kernel<4,10,2,0,0>: dense K x K filters in eigen space '
-                         '(Q [sum_s DD_s (Q^T X W_s^T)]), pair tiles',
+          'conv_kernel': ('lanczosnet_forward16_kernel<0,2,true> (16 x 16 MFMA tiles, eight waves on every '
+                          'node tile of a workgroup; input width zero-padded 70 -> 128)'
+                          if os.environ.get('LNZ_FORWARD16', '1') != '0' else
+                          'lanczosnet_forward_kernel<4,10,2,0,0> (32 x 32 tiles)') +
+                         ': dense K x K filters in eigen space (Q [sum_s DD_s (Q^T X W_s^T)]), pair tiles',
           'library_filter_gemm_mode': library, 'split_precision_mode': split, 'train_step': train,
           'parity': parity, 'finite': finite}
 

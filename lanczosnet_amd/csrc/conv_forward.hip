@@ -1276,12 +1276,9 @@ static bool dense_filters_in_node_space() {
 // The inference forward runs on 16 x 16 MFMA tiles with all eight waves on all of a workgroup's
 // node tiles (conv_forward16.hip) where that kernel is built; LNZ_FORWARD16=0 keeps the 32 x 32
 // kernel of this file for A/B runs (lanczosnet_amd/utils/flop_model.py reads the same variable).
-static bool forward16_enabled() {
-  static const bool v = [] {
-    const char* e = getenv("LNZ_FORWARD16");
-    return !e || atoi(e) != 0;
-  }();
-  return v;
+static bool forward16_enabled() {  // (read per launch: tests and A/B runs switch it in-process)
+  const char* e = getenv("LNZ_FORWARD16");
+  return !e || atoi(e) != 0;
 }
 
 static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const char* who) {
@@ -1320,7 +1317,12 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
-    if (forward16_enabled() && lnz::forward16_eligible(a, 0)) return lnz::launch_forward16(a, 0, s);
+    if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 0))
+      return lnz::launch_forward16(a, 0, s);
+    if (getenv("LNZ_FORWARD16_VERBOSE"))
+      fprintf(stderr, "lnz forward on 32x32 tiles: fk %d dense_es %d gemm %d dhid %d din0 %d short %d long %d "
+              "edge %d K %d B %d L %d\n", a.filter_kind, (int)dense_es, a.gemm_mode, a.dhid, a.din0,
+              a.n_short, a.n_long, a.n_edge, a.K, a.B, a.num_layer);
   } else {
     LNZ_REQUIRE(a.gemm_mode == 0 && (a.filter_kind == 0 || dense_es) && a.dhid == 128, LNZ_ENOTSUP,
                 "%s: built for gemm_mode 0, hidden width 128, diagonal gains or dense filters in "
@@ -1332,7 +1334,8 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                   LNZ_EINVAL, "%s: need Wp (transposed packs), dy, dx0, din0 == dhid, bwd_din0", who);
       LNZ_REQUIRE(!a.dy_compact || (a.row_off && a.dy_compact_rows > 0), LNZ_EINVAL,
                   "%s: dy_compact needs row_off and dy_compact_rows", who);
-      if (forward16_enabled() && lnz::forward16_eligible(a, 1)) return lnz::launch_forward16(a, 1, s);
+      if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 1))
+        return lnz::launch_forward16(a, 1, s);
     } else {
       LNZ_REQUIRE(a.msg && a.msg_layer >= 0 && a.msg_layer < a.num_layer &&
                       (a.msg_layer > 0 || a.x0),

@@ -85,10 +85,21 @@ __device__ __forceinline__ int live16(int nA, int nB, int split) {
 //          per-channel transposed weight packs, kernel iteration l = conv layer num_layer - 1 - l,
 //          the epilogue masks with the stored activation instead of bias + ReLU and writes dY_{la-1}
 //          (last iteration: dX_0, bwd_din0 columns — the waves beyond them only keep the barriers).
-template <int NT, int P, int MODE>
+// FK  0 = diagonal spectral gains on Ritz vectors (LanczosNet): G [L][B][n_long][K], staged in LDS,
+//          a long channel's C/D rows (= eigen slots) are scaled into T on the VALU;
+//     2 = dense K x K filters on the Lanczos basis (AdaLanczosNet, model/ada_lanczos_net.py:280-281):
+//          G [L][B][n_long][K][K]; T += DD_s Z_s is one more MFMA chain with the filter's fragments
+//          as A operand (block diagonal per tile like the Laplacians), fetched under the channel's
+//          own GEMM1.
+// Short-diffusion channels c < n_short (powers p_c of the first Laplacian, model/lanczos_net.py:
+// 172-174) run in node space: Z <- L_0^(p-1) Z in registers, then GEMM2 with L_0.
+// SHORT: the model has short-diffusion channels (a template constant: their block would otherwise
+// set the register allocation of the kernels that never run it).
+template <int NT, int P, int MODE, int FK, bool SHORT>
 __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], float* lds,
-                                          const int tid, const int wave) {
+                                          const int tid, const int wave, const int part_slot = 0) {
   constexpr bool FWD = MODE == 0;
+  constexpr bool DIAG = FK == 0;
 #ifdef LNZ_F16_PHASES
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_all = clock64(), _t0 = t_all;
 #define LNZ_PH(i) { const long long _t1 = clock64(); ph[i] += _t1 - _t0; _t0 = _t1; }
@@ -98,8 +109,8 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
   const int lane = tid & 63;
   const int j = lane & 15, kq = lane >> 4;
   const int N = a.N, K = a.K, B = a.B;
-  const int nl = a.n_long, ne = a.n_edge;
-  const int C = nl + ne;
+  const int ns = SHORT ? a.n_short : 0, nl = a.n_long, ne = a.n_edge;
+  const int C = ns + nl + ne;
   constexpr int TILE = 32 * P;  // floats per tile buffer
   float* Xs = lds;                               // [2][NT][32][P]
   float* Vm = lds + 2 * NT * TILE;               // [NT][32][VP]   [node row][slot row]
@@ -162,13 +173,13 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
   // for a weight-ring slot never drains younger loads
   constexpr unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.G), 0, nl > 0 ? a.num_layer * B * nl * K * 4 : 0, 0x00020000);
+      const_cast<float*>(a.G), 0, nl > 0 ? a.num_layer * B * nl * K * (DIAG ? 1 : K) * 4 : 0, 0x00020000);
   unsigned goff[GREG];  // byte offset of this thread's element(s) in layer 0
 #pragma unroll
   for (int u = 0; u < GREG; ++u) {
     const int idx = tid + 512 * u;
     goff[u] = OOB;
-    if (idx < NT * nl * 32) {
+    if (DIAG && idx < NT * nl * 32) {
       const int m = idx / (nl * 32);
       const int rem = idx - m * nl * 32;
       const int sc = rem >> 5, rho = rem & 31;
@@ -194,7 +205,7 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
       if (idx < NT * nl * 32) dst[idx] = greg[u];
     }
   };
-  if (nl > 0) {
+  if (DIAG && nl > 0) {
     load_gains(FWD ? 0 : a.num_layer - 1);
     store_gains(FWD ? 0 : a.num_layer - 1);
   }
@@ -222,6 +233,29 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
         const bool ok = mol >= 0 && (rowA ? g < g0 : g >= g0);
         const int gl = rowA ? g : g - g0;
         loff[m][I][J] = ok ? (unsigned)((mol * ne * 256 + gl * 64 + 32 * (kq & 1) + jl) * 16) : OOB;
+      }
+    }
+  }
+  // FK = 2: fragment (I, J) of a dense filter, DDtile[16 I + j][16 J + 4 kq + 0..3]: slot row 16 I + j
+  // is slot kr of molecule A (rows below the split) or B, its columns molecule-local; zero off the
+  // diagonal blocks and beyond K (K % 4 == 0: a float4 never straddles K)
+  unsigned doff[DIAG ? 1 : NT][2][2];
+  if (!DIAG) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+#pragma unroll
+      for (int I = 0; I < 2; ++I) {
+        const int rho = 16 * I + j;
+        const bool rowA = rho < td[m].split;
+        const int mol = rowA ? td[m].ta : td[m].tb;
+        const int kr = rowA ? rho : rho - td[m].split;
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+          const int c0 = 16 * J + 4 * kq;
+          const int k0 = c0 - (rowA ? 0 : td[m].split);
+          const bool ok = mol >= 0 && kr < K && (rowA ? c0 < td[m].split : c0 >= td[m].split) && k0 < K;
+          doff[DIAG ? 0 : m][I][J] = ok ? (unsigned)((((mol * nl) * K + kr) * K + k0) * 4) : OOB;
+        }
       }
     }
   }
@@ -253,7 +287,7 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
       for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
     }
     // (behind the ring prime: vector loads return in order, the first steps must not wait for G)
-    if (nl > 0 && more) load_gains(lg);
+    if (DIAG && nl > 0 && more) load_gains(lg);
 
     f32x4 out[NT][2];
     {
@@ -368,29 +402,105 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
       steps4(Zc, xb, x0, std::true_type{});
     };
 
-    // ---------------- eigen-space block: out += V [ sum_s diag(g_s) (Y W_s^T) ] ----------------
+    // Laplacian fragments of one edge type for every (tile, I, J): they land under the last four
+    // steps of the channel's own GEMM1 (identity channels of a tile: offsets beyond the buffer, no
+    // memory traffic).  The same registers hold a dense filter's fragments in the long block.
+    f32x4 mop[NT][2][2];
+    auto fetch = [&](int e, bool use_ident) {
+#pragma unroll
+      for (int m = 0; m < NT; ++m) {
+        const unsigned skip = (use_ident && ((idm[m] >> e) & 1)) ? OOB : 0u;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+          for (int J = 0; J < 2; ++J)
+            mop[m][I][J] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[m][I][J] | skip, e * 4096, 0));
+      }
+    };
+    // acc[m][I] += M[I][J] Zp[m][J] over the live node subtiles J (GEMM2 / one power of L_0)
+    auto apply_m = [&](f32x4 (&acc)[NT][2], const f32x4 (&Zp)[NT][2], int m) {
+#pragma unroll
+      for (int J = 0; J < 2; ++J) {
+        if ((rl[m] >> J) & 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+              acc[m][I] = mfma16(mop[m][I][J][r], Zp[m][J][r], acc[m][I]);
+        }
+      }
+    };
+
+    // ---------------- short-diffusion channels: out += L_0^p (X W_c^T) ----------------
+    if (SHORT && active) {
+      const lds_cptr x0 = xlane + cur * NT * TILE;
+      load_first(x0);
+      for (int c = 0; c < ns; ++c) {
+        gemm1(Z, x0, [&] { fetch(0, false); });
+        const int p = a.short_dist[c];
+        for (int rep = 1; rep < p; ++rep) {
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {  // tile by tile: one pair of temporaries
+            f32x4 Zn[NT][2];
+            Zn[m][0] = Zn[m][1] = splat4(0.f);
+            apply_m(Zn, Z, m);
+            Z[m][0] = Zn[m][0];
+            Z[m][1] = Zn[m][1];
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < NT; ++m) apply_m(out, Z, m);
+      }
+    }
+
+    // ---------------- eigen-space block: out += V [ sum_s F_s (Y W_s^T) ] ----------------
+    //   F_s = diag(g_s) (FK 0) or the dense filter DD_s (FK 2)
     if (nl > 0 && active) {
       const lds_cptr y0 = xlane + nxt * NT * TILE;
       load_first(y0);
-      // each channel's GEMM1 runs unscaled and its C/D rows (= eigen slots) are scaled into T
       f32x4 T[NT][2];
 #pragma unroll
       for (int m = 0; m < NT; ++m) T[m][0] = T[m][1] = splat4(0.f);
-      auto scale_into_t = [&](const f32x4 (&Zp)[NT][2], int s) {
-#pragma unroll
-        for (int m = 0; m < NT; ++m)
-#pragma unroll
-          for (int I = 0; I < 2; ++I) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(gsl + (m * nl + s) * 32 + 16 * I + 4 * kq);
-            T[m][I] += gv * Zp[m][I];
-          }
-      };
-      // (deferring the scaling into the NEXT channel's GEMM1, with two accumulator sets, so that
-      // it does not wait for the channel's last MFMAs to retire: measured, no gain — the matrix
-      // pipe is shared with the SIMD's other wave, which fills the gap)
+      // (deferring a channel's contribution to T into the NEXT channel's GEMM1, with two
+      // accumulator sets, so that it does not wait for the channel's last MFMAs to retire:
+      // measured, no gain — the matrix pipe is shared with the SIMD's other wave, which fills the gap)
       for (int s = 0; s < nl; ++s) {
-        gemm1(Z, y0, [] {});
-        scale_into_t(Z, s);
+        if constexpr (DIAG) {
+          gemm1(Z, y0, [] {});
+#pragma unroll
+          for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int I = 0; I < 2; ++I) {
+              const f32x4 gv = *reinterpret_cast<const f32x4*>(gsl + (m * nl + s) * 32 + 16 * I + 4 * kq);
+              T[m][I] += gv * Z[m][I];
+            }
+        } else {
+          gemm1(Z, y0, [&] {
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+              for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+                  mop[m][I][J] = __builtin_bit_cast(
+                      f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                 g_rsrc, doff[DIAG ? 0 : m][I][J], (la * B * nl + s) * K * K * 4, 0));
+          });
+#pragma unroll
+          for (int m = 0; m < NT; ++m) {
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+              if ((sl[m] >> J) & 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                  for (int I = 0; I < 2; ++I)
+                    T[m][I] = mfma16(mop[m][I][J][r], Z[m][J][r], T[m][I]);
+              }
+            }
+          }
+        }
       }
       LNZ_PH(1)
       // lift back: out[I] += V[rows of I][slots of J] T[J]
@@ -417,45 +527,18 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
     if (active) {
       const lds_cptr x0 = xlane + cur * NT * TILE;
       load_first(x0);
-      f32x4 mop[NT][2][2];
-      // the channel's Laplacian fragments land under the last four steps of its own GEMM1
-      // (identity channels of a tile: offsets beyond the buffer, no memory traffic)
-      auto fetch = [&](int e) {
-#pragma unroll
-        for (int m = 0; m < NT; ++m) {
-          const unsigned skip = ((idm[m] >> e) & 1) ? OOB : 0u;
-#pragma unroll
-          for (int I = 0; I < 2; ++I)
-#pragma unroll
-            for (int J = 0; J < 2; ++J)
-              mop[m][I][J] = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[m][I][J] | skip, e * 4096, 0));
-        }
-      };
-      auto gemm2 = [&](const f32x4 (&Zp)[NT][2], int e) {
+      for (int e = 0; e < ne; ++e) {
+        gemm1(Z, x0, [&] { fetch(e, true); });
+        LNZ_PH(4)
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           if ((idm[m] >> e) & 1) {  // identity on the tile's molecules: out += Z
-            out[m][0] += Zp[m][0];
-            out[m][1] += Zp[m][1];
-            continue;
-          }
-#pragma unroll
-          for (int J = 0; J < 2; ++J) {
-            if ((rl[m] >> J) & 1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int I = 0; I < 2; ++I)
-                  out[m][I] = mfma16(mop[m][I][J][r], Zp[m][J][r], out[m][I]);
-            }
+            out[m][0] += Z[m][0];
+            out[m][1] += Z[m][1];
+          } else {
+            apply_m(out, Z, m);
           }
         }
-      };
-      for (int e = 0; e < ne; ++e) {
-        gemm1(Z, x0, [&] { fetch(e); });
-        LNZ_PH(4)
-        gemm2(Z, e);
         LNZ_PH(5)
       }
     }
@@ -463,7 +546,7 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
     // ---------------- epilogue: X' where Y was, Y' = V^T X' where X was ----------
     //   forward: X' = relu(out) (+ the activation store training asks for)
     //   MODE 1:  dY_{la-1} = out * [X_la > 0] -> LDS and dy[la-1]; the last iteration writes dX_0
-    if (nl > 0 && more) store_gains(lg);  // (buffer last read two iterations ago)
+    if (DIAG && nl > 0 && more) store_gains(lg);  // (buffer last read two iterations ago)
     if (nl > 0) __syncthreads();  // every wave is through with X and Y
     if (active) {
       const int col = 16 * wave + j;
@@ -531,7 +614,8 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
         // What the weight / bias gradients of conv layer la - 1 need: dY_{la-1} in the COMPACT row
         // numbering of the message matrix (real nodes only) and this workgroup's column sums (rows
         // of padded nodes and of unowned tile rows are zero) — one writer per (workgroup, layer,
-        // column): entry 2 * blockIdx.x of dbias_part, its odd neighbour stays zero.
+        // column): entry 2 * blockIdx.x + part_slot of dbias_part (the odd entry only where a
+        // workgroup runs its four tiles as two passes; it stays zero otherwise).
         float colsum = 0.0f;
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
@@ -559,7 +643,7 @@ __device__ __forceinline__ void forward16(KArgs& a, const TileDesc (&td)[NT], fl
           colsum += __shfl_xor(colsum, 16, 64);
           colsum += __shfl_xor(colsum, 32, 64);
           if (kq == 0)
-            a.dbias_part[(((int64_t)blockIdx.x * 2) * a.num_layer + (la - 1)) * 128 + col] = colsum;
+            a.dbias_part[(((int64_t)blockIdx.x * 2 + part_slot) * a.num_layer + (la - 1)) * 128 + col] = colsum;
         }
       }
     }
@@ -649,7 +733,7 @@ constexpr int lds_floats(int NT, int P, int nl) {
 // One workgroup = 8 waves on the 1..4 node tiles of its plan entry.  Three tiles or fewer: row
 // pitch 136 (conflict-free A fragments); four tiles only fit in 160 KB at pitch 132 (one of the
 // instruction's four lane groups then takes a 2-way conflict).
-template <int MODE>
+template <int MODE, int FK, bool SHORT>
 __global__ __launch_bounds__(512) void lanczosnet_forward16_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) float lds16[];
@@ -673,16 +757,25 @@ __global__ __launch_bounds__(512) void lanczosnet_forward16_kernel(const lnz_for
   constexpr int ONLY = LNZ_F16_ONLY_NT;
   if (nt == 3 && (ONLY == 0 || ONLY == 3)) {
     const TileDesc t3[3] = {s0, c1, c2};
-    forward16<3, 136, MODE>(a, t3, lds16, tid, wave);
+    forward16<3, 136, MODE, FK, SHORT>(a, t3, lds16, tid, wave);
   } else if (nt == 2 && (ONLY == 0 || ONLY == 2)) {
     const TileDesc t2[2] = {s0, c1};
-    forward16<2, 136, MODE>(a, t2, lds16, tid, wave);
+    forward16<2, 136, MODE, FK, SHORT>(a, t2, lds16, tid, wave);
   } else if (nt == 4 && (ONLY == 0 || ONLY == 4)) {
-    const TileDesc t4[4] = {s0, s1, s2, s3};
-    forward16<4, 132, MODE>(a, t4, lds16, tid, wave);
+    if constexpr (FK == 0) {
+      const TileDesc t4[4] = {s0, s1, s2, s3};
+      forward16<4, 132, MODE, FK, SHORT>(a, t4, lds16, tid, wave);
+    } else {
+      // dense filters: four tiles next to the filter fragments do not fit in 256 registers —
+      // two passes of two tiles (batches beyond three tiles per CU only)
+      const TileDesc ta[2] = {s0, s1}, tb[2] = {s2, s3};
+      forward16<2, 136, MODE, FK, SHORT>(a, ta, lds16, tid, wave, 0);
+      __syncthreads();
+      forward16<2, 136, MODE, FK, SHORT>(a, tb, lds16, tid, wave, 1);
+    }
   } else if (nt == 1 && (ONLY == 0 || ONLY == 1)) {
     const TileDesc t1[1] = {s0};
-    forward16<1, 136, MODE>(a, t1, lds16, tid, wave);
+    forward16<1, 136, MODE, FK, SHORT>(a, t1, lds16, tid, wave);
   }
 }
 
@@ -691,16 +784,19 @@ __global__ __launch_bounds__(512) void lanczosnet_forward16_kernel(const lnz_for
 namespace lnz {
 
 // The forward (mode 0, with or without the activation store) and the input-gradient pass (mode 1)
-// on 16 x 16 tiles where they are built (see the file comment).
+// on 16 x 16 tiles where they are built (see the file comment): diagonal gains (filter_kind 0) and
+// dense filters in eigen space (filter_kind 1).
 bool forward16_eligible(const lnz_forward_args& a, int mode) {
   if (mode != 0 && mode != 1) return false;
-  if (a.gemm_mode != 0 || a.filter_kind != 0) return false;
-  if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128 || a.n_short != 0) return false;
+  if (a.gemm_mode != 0 || (a.filter_kind != 0 && a.filter_kind != 1)) return false;
+  if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
   if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
-  if (a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12) return false;
-  // 32-bit byte offsets into the packed Laplacian and the gains (raw buffer loads)
+  if (a.n_short + a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12) return false;
+  if (a.filter_kind == 1 && a.K % 4 != 0) return false;
+  // 32-bit byte offsets into the packed Laplacian and the gains / filters (raw buffer loads)
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
-  if ((int64_t)a.num_layer * a.B * a.n_long * a.K * 4 >= (1ll << 31)) return false;
+  const int64_t per_slot = a.filter_kind == 1 ? (int64_t)a.K * a.K : a.K;
+  if ((int64_t)a.num_layer * a.B * a.n_long * per_slot * 4 >= (1ll << 31)) return false;
   return (size_t)lds_floats(4, 132, a.n_long) * sizeof(float) <= 160 * 1024;
 }
 
@@ -708,16 +804,21 @@ int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s) {
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;
   const int f3 = lds_floats(3, 136, a.n_long), f4 = lds_floats(4, 132, a.n_long);
   const size_t bytes = (size_t)(f3 > f4 ? f3 : f4) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lanczosnet_forward16_kernel<0>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)lanczosnet_forward16_kernel<1>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  const void* fns[8] = {
+      (const void*)lanczosnet_forward16_kernel<0, 0, false>, (const void*)lanczosnet_forward16_kernel<1, 0, false>,
+      (const void*)lanczosnet_forward16_kernel<0, 2, false>, (const void*)lanczosnet_forward16_kernel<1, 2, false>,
+      (const void*)lanczosnet_forward16_kernel<0, 0, true>,  (const void*)lanczosnet_forward16_kernel<1, 0, true>,
+      (const void*)lanczosnet_forward16_kernel<0, 2, true>,  (const void*)lanczosnet_forward16_kernel<1, 2, true>};
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
+  const void* fn = fns[which];
+  if (!attr_set[which]) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[which] = true;
   }
-  if (mode == 0) hipLaunchKernelGGL(lanczosnet_forward16_kernel<0>, dim3(grid), dim3(512), bytes, s, a);
-  else hipLaunchKernelGGL(lanczosnet_forward16_kernel<1>, dim3(grid), dim3(512), bytes, s, a);
+  lnz_forward_args args = a;
+  void* params[] = {&args};
+  (void)hipLaunchKernel(fn, dim3(grid), dim3(512), params, bytes, s);
   return check_launch(mode == 0 ? "lnz_lanczosnet_forward (16x16 tiles)"
                                 : "lnz_lanczosnet_input_grad (16x16 tiles)");
 }

@@ -222,10 +222,13 @@ class _LanczosNetBase(nn.Module):
         dev = self.filter[0].weight.device
         dhid = self.hidden_dim[0]
         packs, biases, w_off, b_off, woff, boff = [], [], [], [], 0, 0
-        # the kernel consumes the input width in 32-column groups: zero-pad layer-0 weight
-        # columns (per message channel) and the embedding / feature columns to match
+        # the kernels consume the input width in 32-column groups — 64-column groups for width-128
+        # models, whose launches run on 16 x 16 tiles (csrc/conv_forward16.hip: four 16-k steps per
+        # ring rotation): zero-pad layer-0 weight columns (per message channel) and the embedding /
+        # feature columns to match
         din0 = self.input_dim
-        din0p = (din0 + 31) // 32 * 32
+        group = 64 if dhid == 128 else 32
+        din0p = (din0 + group - 1) // group * group
         n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
         # layer 0 has its own width; the other layers share a shape and are packed by one launch
         # (rows of the stacked matrix are whole 32-row tiles of each layer, so the pack of the

@@ -378,11 +378,17 @@ def test_ada_dense_filter_conv_matches_oracle_given_TQ():
   np.testing.assert_array_equal(unplanned, score)
 
 
+@pytest.mark.parametrize('tiles16', ['1', '0'])
 @pytest.mark.parametrize('n_cu', [1, 3])
-def test_ada_dense_filters_on_pair_tiles(n_cu):
-  """The eigen-space dense-filter kernel on PAIR tiles (8|24 and 16|16 rows, block-diagonal DD
-  fragments): a plan for few CUs makes the planner pair small molecules; every molecule's scores are
-  bit-identical to the one-molecule-per-tile plan and match the fp64 oracle fed the same (T, Q)."""
+def test_ada_dense_filters_on_pair_tiles(n_cu, tiles16, monkeypatch):
+  """The eigen-space dense-filter kernels on PAIR tiles (8|24 and 16|16 rows, block-diagonal DD
+  fragments): a plan for few CUs makes the planner pair small molecules; every molecule's scores
+  match the one-molecule-per-tile plan and the fp64 oracle fed the same (T, Q).  On the 32 x 32-tile
+  kernel (LNZ_FORWARD16=0) pairing is bit-invariant: an 8-row shift keeps the two node rows of an
+  MFMA k-step together.  The 16 x 16-tile kernel contracts four node rows per instruction, so a
+  molecule that starts at row 8 of a tile is summed in a different association: equal to the
+  parity tolerance."""
+  monkeypatch.setenv('LNZ_FORWARD16', tiles16)
   from lanczosnet_amd import ops
   from lanczosnet_amd.synthetic import draw_batch
   cfg = dict(oracle.DEFAULT_QM8_CFG, short_diffusion_dist=[1, 2, 3], long_diffusion_dist=[5, 7, 10, 20, 30],
@@ -412,7 +418,10 @@ def test_ada_dense_filters_on_pair_tiles(n_cu):
     assert n_pairs >= 8, n_pairs
     paired = ops.lanczosnet_forward(plan, _t(b['node_feat']), Lp, Q, DDp, mk, tiling=tiles).cpu().numpy()
     single = ops.lanczosnet_forward(plan, _t(b['node_feat']), Lp, Q, DDp, mk, tiling='single').cpu().numpy()
-  np.testing.assert_array_equal(paired, single)
+  if tiles16 == '0':
+    np.testing.assert_array_equal(paired, single)
+  else:
+    assert np.abs(paired - single).max() <= 2e-6 * np.abs(single).max()
   ref, _ = oracle.ada_lanczos_net_forward(P, cfg, b['node_feat'], L, b['node_mask'], None,
                                           dtype=np.float64, TQ=(T.cpu().numpy(), Q.cpu().numpy()))
   per = np.abs(paired - ref).max(axis=1) / np.abs(ref).max(axis=1)
