@@ -27,7 +27,7 @@ extern "C" {
  * 3: + lnz_f32_linear, lnz_laplacian, the fp64 training kernels of the AdaLanczosNet spectrum
  *    (lnz_ada_graph_laplacian_f64, lnz_ada_lanczos_layer_f64, lnz_ada_t_powers_f64 and their
  *    _backward);  2: + lnz_lanczos_ritz_ws / _workspace_bytes, lnz_f16x3_*. */
-#define LNZ_ABI_VERSION 4
+#define LNZ_ABI_VERSION 5
 #define LNZ_OK 0
 #define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
 #define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */
@@ -35,6 +35,11 @@ extern "C" {
 
 #define LNZ_TILE 32       /* node tile: one v_mfma_f32_32x32x2_f32 tile per molecule */
 #define LNZ_MAX_CHANNELS 32
+/* strip plan (lnz_plan_strips): subtiles of 16 node rows per strip, int32 words per strip entry,
+ * largest batch the planner takes */
+#define LNZ_STRIP_SUB 6
+#define LNZ_STRIP_INTS 80
+#define LNZ_STRIP_MAX_B 2048
 
 typedef void* lnz_stream_t;
 
@@ -365,6 +370,12 @@ typedef struct lnz_forward_args {
                                  l) = column sums of dLoss/dY_l over the node tiles of half h of
                                  workgroup g, for l = 0 .. num_layer-2; their sum over the first
                                  index (any fixed order) is the bias gradient of conv layer l      */
+  /* ---- forward, optional (ABI 5): strip plan of lnz_plan_strips.  With it the exact-fp32
+   * inference forward of a diagonal-gain model without short-diffusion channels runs on strips of
+   * 16-row subtiles (conv_strip.hip) instead of 32-row tiles; every other launch ignores it. */
+  const int32_t* strips;      /* [strip_cap][LNZ_STRIP_INTS] int32                                   */
+  const int32_t* n_strips;    /* device scalar: strips in use                                        */
+  int strip_cap;              /* lnz_strip_cap(B): entries in `strips` (= grid size)                 */
 } lnz_forward_args;
 int lnz_lanczosnet_forward(const lnz_forward_args* args, lnz_stream_t stream);
 /* Backward of the conv stack w.r.t. its node-state inputs, in the forward's own structure:
@@ -401,7 +412,23 @@ int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
  * which then skips the MLP for the zero-padded eigen columns (~18 % of the rows for QM8 sizes). */
 int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs, int32_t* plan,
                    int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
-                   lnz_stream_t stream);
+                   int32_t* strips, int32_t* n_strips, lnz_stream_t stream);
+/* Strip plan for lnz_forward_args.strips (the 16 x 16-tile inference forward, conv_strip.hip): a
+ * workgroup runs a strip of up to LNZ_STRIP_SUB subtiles of 16 node rows; a molecule takes
+ * ceil(n / 4) * 4 consecutive rows at a 4-aligned start and spans at most two subtiles, so the
+ * strip's operators are block diagonal on the subtile diagonal and its neighbours.  Packing: first
+ * fit decreasing by size class, stable in batch order (a pure function of the mask); the strip
+ * height is the smallest for which the batch fits R strips per compute unit, R = the rounds it
+ * needs at full height (one round for B = 1024 QM8 molecules on 256 units).  Against the 32-row
+ * tiles of lnz_plan_tiles a QM8-sized batch needs 21 % fewer rows.
+ * strips: [lnz_strip_cap(B) * LNZ_STRIP_INTS] int32 — words 0, 1 of an entry = molecules and
+ * subtiles of the strip, words 2 + 3 i + {0,1,2} = (molecule, first row, node extent) of its i-th
+ * molecule; n_strips [1] int32 (device): strips in use.  B <= LNZ_STRIP_MAX_B, N <= 32.
+ * The strips / n_strips arguments of lnz_plan_batch, lnz_prepare_batch[_prev_gains] and
+ * lnz_pack_laplacian_plan (may be NULL) make the same plan inside those launches. */
+int lnz_strip_cap(int B);
+int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips,
+                    int32_t* n_strips, lnz_stream_t stream);
 /* The whole batch preparation in ONE launch: lnz_plan_batch (workgroup 0), lnz_lanczos_ritz on
  * channel 0 of L (workgroups 1..B, dispatched first: they are the long, latency-bound pole) and
  * lnz_pack_laplacian (workgroups B+1..2B) — the two byte movers run in the shadow of the Lanczos
@@ -411,7 +438,8 @@ int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r, int64_
                       int64_t stride_ch, int B, int N, int C, float* Lp, const uint8_t* mask,
                       const int32_t* n_nodes, int n_cu, int allow_pairs, int32_t* plan,
                       int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
-                      float* V, int32_t* info, uint32_t* ident, lnz_stream_t stream);
+                      float* V, int32_t* info, uint32_t* ident, int32_t* strips, int32_t* n_strips,
+                      lnz_stream_t stream);
 /* Software pipeline over a STREAM of batches: lnz_prepare_batch of batch k+1 and the spectral
  * gains (kind 0, live rows) of batch k in one launch.  The two are independent — no flags — and
  * complementary: the Lanczos / eigensolve wavefronts are latency bound (one per SIMD, matrix pipes
@@ -424,7 +452,7 @@ int lnz_prepare_batch_prev_gains(
     int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
     float* V, uint32_t* ident, const float* D_prev, int B_prev, const int32_t* rows_prev,
     const int32_t* n_rows_prev, const int32_t* dist_host, int S, int num_layer,
-    const float* mlp_pack, float* G_prev, lnz_stream_t stream);
+    const float* mlp_pack, float* G_prev, int32_t* strips, int32_t* n_strips, lnz_stream_t stream);
 /* lnz_pack_laplacian + lnz_plan_batch in ONE launch (workgroup B plans while 0..B-1 pack): the two
  * byte movers in front of the Lanczos kernel are independent, and the planner is a single
  * latency-bound workgroup.  Arguments as in the two functions; gain_rows may be NULL. */
@@ -432,7 +460,8 @@ int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t stride_r, 
                             int64_t stride_ch, int B, int N, int C, float* Lp,
                             const uint8_t* mask, int n_cu, int allow_pairs, int32_t* plan,
                             int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows,
-                            uint32_t* ident, lnz_stream_t stream);
+                            uint32_t* ident, int32_t* strips, int32_t* n_strips,
+                            lnz_stream_t stream);
 /* sizeof(lnz_forward_args) as compiled into the library — lets a foreign-language binding verify
  * its struct layout before the first call. */
 int64_t lnz_forward_args_size(void);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LANCZOSNET_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblanczosnet_hip.so')
 
 LNZ_OK, LNZ_EINVAL, LNZ_ELAUNCH, LNZ_ENOTSUP = 0, -1, -2, -3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LnzError(RuntimeError):
@@ -45,6 +45,7 @@ class ForwardArgs(C.Structure):
       ('act_out', C.c_void_p), ('act', C.c_void_p), ('dy', C.c_void_p), ('dx0', C.c_void_p),
       ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p), ('dgains', C.c_void_p),
       ('dy_compact', C.c_void_p), ('dy_compact_rows', C.c_int64), ('dbias_part', C.c_void_p),
+      ('strips', C.c_void_p), ('n_strips', C.c_void_p), ('strip_cap', C.c_int),
   ]
 
 
@@ -78,11 +79,13 @@ SIGNATURES = {
     'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_collate_qm8': (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     'lnz_plan_wg_cap': (C.c_int, [_I, _I]),
-    'lnz_pack_laplacian_plan': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    'lnz_pack_laplacian_plan': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'lnz_pack_laplacian_ident': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P]),
-    'lnz_prepare_batch_prev_gains': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P, _P]),
-    'lnz_prepare_batch': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
-    'lnz_plan_batch': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    'lnz_prepare_batch_prev_gains': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, C.POINTER(C.c_int32), _I, _I, _P, _P, _P, _P, _P]),
+    'lnz_prepare_batch': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'lnz_plan_batch': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
+    'lnz_plan_strips': (C.c_int, [_P, _I, _I, _I, _P, _P, _P]),
+    'lnz_strip_cap': (C.c_int, [_I]),
     'lnz_plan_tiles': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     'lnz_pack_laplacian_f16x2': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),

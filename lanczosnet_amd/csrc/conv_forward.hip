@@ -1258,6 +1258,8 @@ namespace lnz {
 int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_forward_f16.hip
 bool forward16_eligible(const lnz_forward_args& a, int mode);         // conv_forward16.hip
 int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s);
+bool strip_forward_eligible(const lnz_forward_args& a);               // conv_strip.hip
+int launch_strip_forward(const lnz_forward_args& a, hipStream_t s);
 }
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
@@ -1278,6 +1280,13 @@ static bool dense_filters_in_node_space() {
 // kernel of this file for A/B runs (lanczosnet_amd/utils/flop_model.py reads the same variable).
 static bool forward16_enabled() {  // (read per launch: tests and A/B runs switch it in-process)
   const char* e = getenv("LNZ_FORWARD16");
+  return !e || atoi(e) != 0;
+}
+
+// LNZ_STRIPS=0: inference launches that carry a strip plan run on the 32-row tile plan all the
+// same (A/B runs; lanczosnet_amd/utils/flop_model.py reads the same variable).
+static bool strips_enabled() {
+  const char* e = getenv("LNZ_STRIPS");
   return !e || atoi(e) != 0;
 }
 
@@ -1317,6 +1326,8 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
+    if (forward16_enabled() && strips_enabled() && lnz::strip_forward_eligible(a))
+      return lnz::launch_strip_forward(a, s);
     if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 0))
       return lnz::launch_forward16(a, 0, s);
     if (getenv("LNZ_FORWARD16_VERBOSE"))

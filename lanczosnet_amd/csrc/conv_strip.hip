@@ -1,0 +1,530 @@
+// R7 + R9 + R10, inference: the LanczosNet forward on STRIPS of 16-row subtiles.
+//
+// conv_forward16.hip runs 32-row node tiles (one molecule, or an 8 | 24 / 16 | 16 pair): the QM8
+// bench batch rides in 744 tiles = 23.8 k rows for 17.3 k atoms, three tiles (96 rows) on the
+// busiest compute unit.  Here a workgroup runs one strip of the plan of lnz_plan_strips — up to
+// LNZ_STRIP_SUB subtiles of 16 rows in which every molecule takes ceil(n / 4) * 4 consecutive rows
+// at a 4-aligned start and spans at most two subtiles: 18.8 k rows, five subtiles (80 rows) per
+// compute unit.  GEMM1 (X W_c^T, 87 % of the matrix work) is row-proportional; the block-diagonal
+// products (GEMM2 with the Laplacians, projection on / lift from the Ritz vectors) visit the
+// subtile blocks (I, J), |I - J| <= 1, that some molecule touches.
+//
+// Everything else is conv_forward16.hip's scheme (same packs, same fragment indexing, see its file
+// comment): wave w owns output columns [16 w, 16 w + 16) of every subtile; a 16-k step of GEMM1 is
+// one weight float4 per lane (4-slot register ring), S A fragments (ds_read_b128, pitch 136) and
+// 4 S MFMAs v_mfma_f32_16x16x4_f32; long channels in eigen space (Y = V^T X, rows scaled by the
+// gains, one lift per layer), edge channels with the GEMM1 result chained into GEMM2 as B operand,
+// the next layer's Y from the epilogue's C/D registers; all vector loads of the layer loop are
+// issued unconditionally (raw buffer loads, out-of-range offset = 0.0) so that every s_waitcnt
+// vmcnt is exact.  Laplacian fragment of block (I, J) for lane (j, kq): M[16 I + j][16 J + 4 kq +
+// 0..3] — both the row and the 4-column group belong to one molecule each (4-row granularity), the
+// fragment is real when they are the same molecule, and sits in that molecule's pack at its local
+// (row, column group).
+#include "common.hpp"
+#include "conv_tiles.hpp"
+#include <type_traits>
+
+namespace {
+
+constexpr int P = 136;     // row pitch of the node-state buffers (floats)
+constexpr int VBP = 20;    // row pitch of a 16 x 16 Ritz block (floats: 16-byte rows)
+constexpr int HP = 33;     // row pitch of the gated head outputs
+constexpr int MAXMOL = 24; // molecules per strip (96 rows / 4)
+typedef const __attribute__((address_space(3))) float* lds_cptr;
+typedef const __attribute__((address_space(3))) f32x4* lds_c4ptr;
+
+__device__ __forceinline__ f32x4 lds4(lds_cptr p) { return *(lds_c4ptr)p; }
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+
+// LDS floats of a strip of S subtiles with nl long channels
+constexpr int strip_lds_floats(int S, int nl) {
+  return 2 * S * 16 * P + S * 3 * 16 * VBP + 2 * nl * S * 16 + 3 * S * 16 + 3 * MAXMOL + 8;
+}
+
+template <int S>
+__device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restrict__ ent, float* lds,
+                                              const int tid, const int wave) {
+  constexpr int R = 16 * S;
+  const int lane = tid & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int N = a.N, K = a.K, B = a.B;
+  const int nl = a.n_long, ne = a.n_edge;
+  const int C = nl + ne;
+  float* Xs = lds;                                   // [2][R][P]
+  float* Vb = Xs + 2 * R * P;                        // [S node subtile][3 = slot subtile - node subtile + 1][16 node][VBP]
+  float* Gs = Vb + S * 3 * 16 * VBP;                 // [2][nl][R]
+  int* rowinfo = reinterpret_cast<int*>(Gs + 2 * nl * R);  // [R] molecule of the strip owning the row, or -1
+  int* rowok = rowinfo + R;                          // [R] the row is a real (masked-in) node
+  int* idI = rowok + R;                              // [S] identity-channel bits common to a subtile's molecules (+ pad to R)
+  int* mstart = idI + R;                             // [MAXMOL] first row, node extent, molecule
+  int* mext = mstart + MAXMOL;
+  int* mid = mext + MAXMOL;
+  const int nm = ent[0];
+
+  // ---- the strip's molecules and the row map
+  if (tid < MAXMOL) {
+    const bool in = tid < nm;
+    mid[tid] = in ? ent[2 + 3 * tid] : -1;
+    mstart[tid] = in ? ent[3 + 3 * tid] : 0;
+    mext[tid] = in ? ent[4 + 3 * tid] : 0;
+  }
+  if (tid < S) idI[tid] = a.ident ? -1 : 0;
+  __syncthreads();
+  if (tid < R) {
+    int own = -1;
+    for (int i = 0; i < nm; ++i) {
+      const int n = mext[i];
+      const int rows = n <= 4 ? 4 : (n + 3) & ~3;
+      if (tid >= mstart[i] && tid < mstart[i] + rows) own = i;
+    }
+    rowinfo[tid] = own;
+    int ok = 0;
+    if (own >= 0) {
+      const int lrow = tid - mstart[own];
+      ok = (lrow < N && a.mask[(int64_t)mid[own] * N + lrow] != 0) ? 1 : 0;
+      if (a.ident) atomicAnd(&idI[tid >> 4], (int)a.ident[mid[own]]);
+    }
+    rowok[tid] = ok;
+  }
+  __syncthreads();
+
+  // ---- embedding gather / float features (model/lanczos_net.py:154, lanczos_net_general.py:156)
+  {
+    const int d4 = a.din0 >> 2;
+    for (int idx = tid; idx < R * d4; idx += 512) {
+      const int row = idx / d4, c4 = idx - row * d4;
+      const int own = rowinfo[row];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (own >= 0) {
+        const int mol = mid[own], lrow = row - mstart[own];
+        if (lrow < N) {
+          if (a.node_feat) {
+            int64_t id = a.node_feat[(int64_t)mol * N + lrow];
+            id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
+            v = reinterpret_cast<const float4*>(a.embedding + id * a.din0)[c4];
+          } else {
+            v = reinterpret_cast<const float4*>(a.node_feat_f + ((int64_t)mol * N + lrow) * a.din0)[c4];
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&Xs[row * P + 4 * c4]) = v;
+    }
+  }
+  // ---- Ritz blocks: Vb[Jn][d][nu][ro] = V[molecule][node][slot] when node row 16 Jn + nu and
+  //      slot row 16 (Jn + d - 1) + ro belong to the same molecule (slot k of a molecule rides on
+  //      its k-th row), zero elsewhere
+  for (int idx = tid; idx < S * 3 * 256; idx += 512) {
+    const int Jn = idx / 768, rem = idx - Jn * 768;
+    const int d = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
+    const int nrow = 16 * Jn + nu, srow = 16 * (Jn + d - 1) + ro;
+    float v = 0.0f;
+    if (srow >= 0 && srow < R) {
+      const int own = rowinfo[nrow];
+      if (own >= 0 && rowinfo[srow] == own) {
+        const int lnode = nrow - mstart[own], k = srow - mstart[own];
+        if (lnode < N && k < K) v = a.V[((int64_t)mid[own] * N + lnode) * K + k];
+      }
+    }
+    Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = v;
+  }
+  // ---- spectral gains by slot row: Gs[l & 1][s][rho]; loads of layer l + 1 are issued at the
+  //      start of layer l and go to LDS in front of the layer's last barrier
+  constexpr int GREG = 3;  // nl * R <= 512 * GREG  (nl <= 12, R <= 96: 1152)
+  constexpr unsigned OOB = 0x80000000u;
+  float greg[GREG];
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.G), 0, nl > 0 ? a.num_layer * B * nl * K * 4 : 0, 0x00020000);
+  unsigned goff[GREG];
+#pragma unroll
+  for (int u = 0; u < GREG; ++u) {
+    const int idx = tid + 512 * u;
+    goff[u] = OOB;
+    if (idx < nl * R) {
+      const int sc = idx / R, rho = idx - sc * R;
+      const int own = rowinfo[rho];
+      if (own >= 0) {
+        const int k = rho - mstart[own];
+        if (k < K && k < mext[own]) goff[u] = (unsigned)(((mid[own] * nl + sc) * K + k) * 4);
+      }
+    }
+  }
+  auto load_gains = [&](int l) {
+#pragma unroll
+    for (int u = 0; u < GREG; ++u)
+      greg[u] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, goff[u], l * B * nl * K * 4, 0));
+  };
+  auto store_gains = [&](int l) {
+    float* dst = Gs + (l & 1) * nl * R;
+#pragma unroll
+    for (int u = 0; u < GREG; ++u) {
+      const int idx = tid + 512 * u;
+      if (idx < nl * R) dst[idx] = greg[u];
+    }
+  };
+  if (nl > 0) {
+    load_gains(0);
+    store_gains(0);
+  }
+
+  // ---- per-lane addressing of the packed Laplacian and the block masks
+  const int rt = wave >> 1;
+  const int wlane = 64 * (kq >> 1) + 32 * (kq & 1) + 16 * (wave & 1) + j;  // float4 within a 16-k step
+  unsigned loff[S][3];  // byte offset of fragment (I, J = I + d - 1) of edge type 0, or OOB
+  int blk[S];           // bit d: some molecule has rows in subtile I and in subtile I + d - 1
+  const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.Lp), 0, B * ne * 4096, 0x00020000);
+  int idm[S];
+#pragma unroll
+  for (int I = 0; I < S; ++I) {
+    const int row = 16 * I + j;
+    const int own = rowinfo[row];
+    const int st = own >= 0 ? mstart[own] : 0;
+    const int mol = own >= 0 ? mid[own] : 0;
+    int bits = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int J = I + d - 1;
+      bool ok = false;
+      unsigned off = OOB;
+      if (J >= 0 && J < S) {
+        const int cg = 16 * J + 4 * kq;
+        ok = own >= 0 && rowinfo[cg] == own;
+        const int c = cg - st;
+        if (ok) off = (unsigned)((mol * ne * 256 + (c >> 3) * 64 + ((c >> 2) & 1) * 32 + (row - st)) * 16);
+      }
+      loff[I][d] = off;
+      bits |= (__ballot(ok) != 0ull) ? (1 << d) : 0;
+    }
+    blk[I] = __builtin_amdgcn_readfirstlane(bits);
+    idm[I] = __builtin_amdgcn_readfirstlane(idI[I]);
+  }
+  __syncthreads();
+
+  const lds_cptr xlane = (lds_cptr)(Xs + j * P + 4 * kq);  // this lane's A row of subtile 0
+  int cur = 0;
+  for (int l = 0; l < a.num_layer; ++l) {
+    const bool more = l + 1 < a.num_layer;
+    const int din = l == 0 ? a.din0 : 128;
+    const int Q = din >> 3, Q16 = din >> 4;
+    const int Gtot = C * Q;
+    const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
+    const float* gsl = Gs + (l & 1) * nl * R;
+    const int nxt = cur ^ 1;
+
+    // weight stream of this wave: contiguous over the layer's channels, 128 float4 per 16-k step,
+    // 4-slot register ring (prefetch distance 3 steps = 12 S MFMAs)
+    const float4* __restrict__ wp = Wl + (int64_t)rt * Gtot * 64 + wlane;
+    float4 ring[4];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+    // (behind the ring prime: vector loads return in order, the first steps must not wait for G)
+    if (nl > 0 && more) load_gains(l + 1);
+
+    f32x4 out[S];
+    {
+      const float bv = (a.bias + a.b_off[l])[16 * wave + j];
+#pragma unroll
+      for (int I = 0; I < S; ++I) out[I] = splat4(bv);
+    }
+
+    // ---------------- first layer: Y = V^T X from LDS into the other buffer ----------------
+    if (nl > 0 && l == 0) {
+      if (16 * wave < din) {
+#pragma unroll
+        for (int I = 0; I < S; ++I) {  // slot subtile
+          f32x4 Y = splat4(0.f);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int J = I + d - 1;   // node subtile
+            if (J < 0 || J >= S) continue;
+            if ((blk[I] >> d) & 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int nu = 4 * kq + r;
+                Y = mfma16(Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j],
+                           Xs[cur * R * P + (16 * J + nu) * P + 16 * wave + j], Y);
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Xs[nxt * R * P + (16 * I + 4 * kq + r) * P + 16 * wave + j] = Y[r];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---------------- GEMM1 of one channel: Z[I] = A rows (X or Y) x W_c^T ----------------
+    f32x4 Z[S], acur[S];
+    auto load_first = [&](lds_cptr x0) {
+#pragma unroll
+      for (int I = 0; I < S; ++I) acur[I] = lds4(x0 + 16 * I * P);
+    };
+    // four steps; `wrap`: the A prefetch of the last one fetches k = 0 again — the first fragments
+    // of the NEXT channel (channels of a block read the same rows)
+    auto steps4 = [&](lds_cptr xb, lds_cptr x0, auto wrap) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ring[(u + 3) & 3] = wp[(u + 3) * 128];
+        f32x4 anext[S];
+        const lds_cptr xn = (decltype(wrap)::value && u == 3) ? x0 : xb + 16 * (u + 1);
+#pragma unroll
+        for (int I = 0; I < S; ++I) anext[I] = lds4(xn + 16 * I * P);
+        const float4 bv = ring[u];
+#pragma unroll
+        for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][0], bv.x, Z[I]);
+#pragma unroll
+        for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][1], bv.y, Z[I]);
+#pragma unroll
+        for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][2], bv.z, Z[I]);
+#pragma unroll
+        for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][3], bv.w, Z[I]);
+#pragma unroll
+        for (int I = 0; I < S; ++I) acur[I] = anext[I];
+        // issue order: one LDS read behind every fourth MFMA, the ring load in the last gap
+#pragma unroll
+        for (int g = 0; g < S; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (g == S - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+      wp += 4 * 128;
+    };
+    int chan = 0;  // channels done in this layer
+    auto gemm1 = [&](lds_cptr x0, auto&& before_last) {
+      // the two waves of a SIMD (w, w + 4) take turns at the head of the matrix pipe
+      if (((chan ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      ++chan;
+#pragma unroll
+      for (int I = 0; I < S; ++I) Z[I] = splat4(0.f);
+      lds_cptr xb = x0;
+#pragma unroll 1
+      for (int q0 = 4; q0 < Q16; q0 += 4) {
+        steps4(xb, x0, std::false_type{});
+        xb += 64;
+      }
+      before_last();
+      steps4(xb, x0, std::true_type{});
+    };
+
+    // ---------------- eigen-space block: out += V [ sum_s diag(g_s) (Y W_s^T) ] ----------------
+    if (nl > 0) {
+      const lds_cptr y0 = xlane + nxt * R * P;
+      load_first(y0);
+      f32x4 T[S];
+#pragma unroll
+      for (int I = 0; I < S; ++I) T[I] = splat4(0.f);
+      for (int s = 0; s < nl; ++s) {
+        gemm1(y0, [] {});
+#pragma unroll
+        for (int I = 0; I < S; ++I) {
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(gsl + s * R + 16 * I + 4 * kq);
+          T[I] += gv * Z[I];
+        }
+      }
+      // lift back: out[I] (node rows) += V[I][J] T[J] over the slot subtiles J the block mask names
+#pragma unroll
+      for (int I = 0; I < S; ++I) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int J = I + d - 1;
+          if (J < 0 || J >= S) continue;
+          if ((blk[I] >> d) & 1) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Vb[((I * 3 + d) * 16 + j) * VBP + 4 * kq]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[I] = mfma16(v[r], T[J][r], out[I]);
+          }
+        }
+      }
+    }
+
+    // ---------------- node-space block: out += M_e (X W_e^T) per edge type ----------------
+    {
+      const lds_cptr x0 = xlane + cur * R * P;
+      load_first(x0);
+      for (int e = 0; e < ne; ++e) {
+        // the channel's Laplacian fragments land under the last four steps of its own GEMM1
+        // (identity channels of a subtile: offsets beyond the buffer, no memory traffic)
+        f32x4 mop[S][3];
+        gemm1(x0, [&] {
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            const unsigned skip = ((idm[I] >> e) & 1) ? OOB : 0u;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              if (I + d - 1 < 0 || I + d - 1 >= S) continue;
+              mop[I][d] = __builtin_bit_cast(
+                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[I][d] | skip, e * 4096, 0));
+            }
+          }
+        });
+#pragma unroll
+        for (int I = 0; I < S; ++I) {
+          if ((idm[I] >> e) & 1) {  // identity on every molecule of the subtile: out += Z
+            out[I] += Z[I];
+            continue;
+          }
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int J = I + d - 1;
+            if (J < 0 || J >= S) continue;
+            if ((blk[I] >> d) & 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) out[I] = mfma16(mop[I][d][r], Z[J][r], out[I]);
+            }
+          }
+        }
+      }
+    }
+
+    // ---------------- epilogue: X' = relu(out) where Y was, Y' = V^T X' where X was ----------
+    if (nl > 0 && more) store_gains(l + 1);  // (buffer last read in layer l - 1)
+    if (nl > 0) __syncthreads();  // every wave is through with X and Y
+    {
+      const int col = 16 * wave + j;
+#pragma unroll
+      for (int I = 0; I < S; ++I) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaxf(out[I][r], 0.0f);
+          out[I][r] = v;
+          Xs[nxt * R * P + (16 * I + 4 * kq + r) * P + col] = v;
+        }
+      }
+      if (nl > 0 && more) {
+#pragma unroll
+        for (int I = 0; I < S; ++I) {  // slot subtile
+          f32x4 Y = splat4(0.f);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int J = I + d - 1;   // node subtile
+            if (J < 0 || J >= S) continue;
+            if ((blk[I] >> d) & 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                Y = mfma16(Vb[((J * 3 + (2 - d)) * 16 + 4 * kq + r) * VBP + j], out[J][r], Y);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Xs[cur * R * P + (16 * I + 4 * kq + r) * P + col] = Y[r];
+        }
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+  }
+  __builtin_amdgcn_s_setprio(0);
+
+  // ---- optional debug/test output of the final node state
+  if (a.state_out) {
+    for (int idx = tid; idx < R * 128; idx += 512) {
+      const int row = idx >> 7, col = idx & 127;
+      const int own = rowinfo[row];
+      if (own >= 0)
+        a.state_out[((int64_t)mid[own] * 32 + (row - mstart[own])) * 128 + col] = Xs[cur * R * P + row * P + col];
+    }
+  }
+
+  // ---- head (model/lanczos_net.py:185-194): wave w = subtile w; one 32-column tile = [W_o ; w_a ;
+  //      0] as two 16-column MFMA tiles; the gate logit is column dout of the same row.  The gated
+  //      rows go to LDS (the free node-state buffer) and every (molecule, output) is summed over
+  //      the molecule's rows in a fixed order.
+  float* Hs = Xs + (cur ^ 1) * R * P;  // [R][HP]
+  const int Pd = a.dout;
+  if (wave < S) {
+    const int I = wave;
+    f32x4 acc[2] = {splat4(a.bias_head[j]), splat4(a.bias_head[16 + j])};
+    const float4* __restrict__ wh = reinterpret_cast<const float4*>(a.Wp_head) + 64 * (kq >> 1) + 32 * (kq & 1) + j;
+    const lds_cptr xr = xlane + cur * R * P + 16 * I * P;
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 av = lds4(xr + 16 * q);
+      const float4 b0 = wh[q * 128], b1 = wh[q * 128 + 16];
+      acc[0] = mfma16(av[0], b0.x, acc[0]);
+      acc[1] = mfma16(av[0], b1.x, acc[1]);
+      acc[0] = mfma16(av[1], b0.y, acc[0]);
+      acc[1] = mfma16(av[1], b1.y, acc[1]);
+      acc[0] = mfma16(av[2], b0.z, acc[0]);
+      acc[1] = mfma16(av[2], b1.z, acc[1]);
+      acc[0] = mfma16(av[3], b0.w, acc[0]);
+      acc[1] = mfma16(av[3], b1.w, acc[1]);
+    }
+    const int glane = (lane & 48) | (Pd & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float logit = __shfl(Pd < 16 ? acc[0][r] : acc[1][r], glane, 64);
+      const float gate = 1.0f / (1.0f + __expf(-logit));
+      const int row = 16 * I + 4 * kq + r;
+      const bool ok = rowok[row] != 0;
+      Hs[row * HP + j] = ok ? gate * acc[0][r] : 0.0f;
+      Hs[row * HP + 16 + j] = ok ? gate * acc[1][r] : 0.0f;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < nm * Pd; t += 512) {
+    const int i = t / Pd, c = t - i * Pd;
+    const int st = mstart[i], n = mext[i];
+    float sum = 0.0f, cnt = 0.0f;
+    for (int r = 0; r < n; ++r) {
+      sum += Hs[(st + r) * HP + c];
+      cnt += rowok[st + r] ? 1.0f : 0.0f;
+    }
+    a.score[(int64_t)mid[i] * Pd + c] = sum / cnt;
+  }
+}
+
+// One workgroup = 8 waves on one strip of the plan.
+__global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward_args) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  extern __shared__ __attribute__((aligned(16))) float lds_strip[];
+  if ((int)blockIdx.x >= *a.n_strips) return;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int32_t* ent = a.strips + (int64_t)blockIdx.x * LNZ_STRIP_INTS;
+  const int sub = __builtin_amdgcn_readfirstlane(ent[1]);
+  switch (sub) {
+    case 1: strip_forward<1>(a, ent, lds_strip, tid, wave); break;
+    case 2: strip_forward<2>(a, ent, lds_strip, tid, wave); break;
+    case 3: strip_forward<3>(a, ent, lds_strip, tid, wave); break;
+    case 4: strip_forward<4>(a, ent, lds_strip, tid, wave); break;
+    case 5: strip_forward<5>(a, ent, lds_strip, tid, wave); break;
+    case 6: strip_forward<6>(a, ent, lds_strip, tid, wave); break;
+    default: break;
+  }
+}
+
+}  // namespace
+
+namespace lnz {
+
+// The inference forward of a diagonal-gain model without short-diffusion channels, on strips.
+bool strip_forward_eligible(const lnz_forward_args& a) {
+  if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
+  if (a.gemm_mode != 0 || a.filter_kind != 0 || a.act_out || a.n_short != 0) return false;
+  if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
+  if (a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12 || a.dout > 31) return false;
+  if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
+  if ((int64_t)a.num_layer * a.B * a.n_long * a.K * 4 >= (1ll << 31)) return false;
+  return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float) <= 160 * 1024;
+}
+
+int launch_strip_forward(const lnz_forward_args& a, hipStream_t s) {
+  const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)lanczosnet_strip_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lanczosnet_strip_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
+  return check_launch("lnz_lanczosnet_forward (strips)");
+}
+
+}  // namespace lnz

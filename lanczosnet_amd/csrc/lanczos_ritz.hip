@@ -700,12 +700,17 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
-    int32_t* __restrict__ info, uint32_t* __restrict__ ident) {
+    int32_t* __restrict__ info, uint32_t* __restrict__ ident, int32_t* __restrict__ strips,
+    int32_t* __restrict__ n_strips) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
   const int blk = blockIdx.x;
   if (blk == 0) {
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    if (strips) {  // (this kernel is launched with a staging tile > kPrepLds >= kStripScratch)
+      __syncthreads();
+      plan_strips_body(mask, B, N, n_cu, strips, n_strips, reinterpret_cast<unsigned char*>(tile));
+    }
   } else if (blk <= B) {
     if (threadIdx.x >= 64) return;
     // channel 0 of L is the simple-graph Laplacian the Ritz pairs belong to (dataset/qm8.py:262)
@@ -717,6 +722,7 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
 
 constexpr int kPrepLds = 20480;  // static LDS of the fused preparation launch (>= sizeof(Ritz32Smem))
 static_assert(sizeof(Ritz32Smem) <= kPrepLds, "Ritz scratch must fit the shared block");
+static_assert(kStripScratch <= kPrepLds, "the strip planner works in the same block");
 
 // The same launch with ONE static LDS block per workgroup, used according to its role (Ritz
 // scratch or pack staging tile), for staging tiles up to kPrepLds (QM8: 26 x 26 x 7 floats =
@@ -729,11 +735,16 @@ __global__ __launch_bounds__(256) void prepare_batch_union_kernel(
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
-    int32_t* __restrict__ info, uint32_t* __restrict__ ident) {
+    int32_t* __restrict__ info, uint32_t* __restrict__ ident, int32_t* __restrict__ strips,
+    int32_t* __restrict__ n_strips) {
   __shared__ __attribute__((aligned(16))) unsigned char ubuf[kPrepLds];
   const int blk = blockIdx.x;
   if (blk == 0) {
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    if (strips) {
+      __syncthreads();
+      plan_strips_body(mask, B, N, n_cu, strips, n_strips, ubuf);
+    }
   } else if (blk <= B) {
     if (threadIdx.x >= 64) return;
     lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x,
@@ -763,7 +774,8 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
     lnz_gains::DistArr dist, int S, int num_layer,
     const float* __restrict__ mlp_pack, float* __restrict__ G, uint32_t* __restrict__ ident,
     int n_cons, const float* __restrict__ Dg, const int32_t* __restrict__ rows_g,
-    const int32_t* __restrict__ n_rows_g, int Bg) {
+    const int32_t* __restrict__ n_rows_g, int Bg, int32_t* __restrict__ strips,
+    int32_t* __restrict__ n_strips) {
   // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
   // tile): with a separate dynamic tile every workgroup carried 32 KB and the four resident Ritz
   // workgroups of a CU left room for ONE more — the pack workgroups trickled through and the
@@ -774,6 +786,10 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
   const int blk = blockIdx.x;
   if (blk == 0) {
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    if (strips) {
+      __syncthreads();
+      plan_strips_body(mask, B, N, n_cu, strips, n_strips, ubuf);
+    }
   } else if (blk <= B) {
     if (threadIdx.x >= 64) return;
     // the Lanczos / eigensolve chain is the critical path of the launch: it wins every issue
@@ -807,7 +823,8 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
                                  float* Lp, const uint8_t* mask, const int32_t* n_nodes, int n_cu,
                                  int allow_pairs, int32_t* plan, int32_t* n_wg, int K,
                                  int32_t* gain_rows, int32_t* n_gain_rows, float* D, float* V,
-                                 int32_t* info, uint32_t* ident, lnz_stream_t stream) {
+                                 int32_t* info, uint32_t* ident, int32_t* strips,
+                                 int32_t* n_strips, lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && D && V && B > 0 && C > 0 &&
                   C <= LNZ_MAX_CHANNELS && n_cu > 0 && K > 0,
               LNZ_EINVAL, "lnz_prepare_batch: bad arguments (B=%d C=%d K=%d)", B, C, K);
@@ -816,16 +833,18 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
   size_t lds = (size_t)N * N * C * sizeof(float);
   LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
+  LNZ_REQUIRE(!strips || (n_strips && B <= LNZ_STRIP_MAX_B), LNZ_EINVAL,
+              "lnz_prepare_batch: strips need n_strips and B <= %d", LNZ_STRIP_MAX_B);
   if (lds <= (size_t)kPrepLds)
     hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(2 * B + 1), dim3(256), 0,
                        (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                        (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
-                       K, gain_rows, n_gain_rows, n_nodes, D, V, info, ident);
+                       K, gain_rows, n_gain_rows, n_nodes, D, V, info, ident, strips, n_strips);
   else
     hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(256), lds, (hipStream_t)stream,
                        L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
                        allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
-                       n_nodes, D, V, info, ident);
+                       n_nodes, D, V, info, ident, strips, n_strips);
   return lnz::check_launch("lnz_prepare_batch");
 }
 
@@ -835,7 +854,8 @@ extern "C" int lnz_prepare_batch_prev_gains(
     int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows, int32_t* n_gain_rows, float* D,
     float* V, uint32_t* ident, const float* D_prev, int B_prev, const int32_t* rows_prev,
     const int32_t* n_rows_prev, const int32_t* dist_host, int S, int num_layer,
-    const float* mlp_pack, float* G_prev, lnz_stream_t stream) {
+    const float* mlp_pack, float* G_prev, int32_t* strips, int32_t* n_strips,
+    lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && gain_rows && n_gain_rows && D && V &&
                   D_prev && rows_prev && n_rows_prev && dist_host && mlp_pack && G_prev && B > 0 &&
                   B_prev > 0 && C > 0 && C <= LNZ_MAX_CHANNELS && n_cu > 0 && K > 0 && num_layer > 0,
@@ -857,7 +877,8 @@ extern "C" int lnz_prepare_batch_prev_gains(
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, dist, S, num_layer, mlp_pack, G_prev,
-                     ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev);
+                     ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev,
+                     (strips && n_strips && B <= LNZ_STRIP_MAX_B) ? strips : nullptr, n_strips);
   return lnz::check_launch("lnz_prepare_batch_prev_gains");
 }
 

@@ -218,8 +218,16 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
                                                           int wg_cap, int32_t* __restrict__ plan,
                                                           int32_t* __restrict__ n_wg, int K,
                                                           int32_t* __restrict__ gain_rows,
-                                                          int32_t* __restrict__ n_gain_rows) {
-  plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+                                                          int32_t* __restrict__ n_gain_rows,
+                                                          int32_t* __restrict__ strips,
+                                                          int32_t* __restrict__ n_strips) {
+  __shared__ __attribute__((aligned(16))) unsigned char strip_scratch[kStripScratch];
+  if (plan)
+    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+  if (strips) {
+    __syncthreads();
+    plan_strips_body(mask, B, N, n_cu, strips, n_strips, strip_scratch);
+  }
 }
 
 // Both byte movers that precede the Lanczos kernel in ONE launch: workgroup 0 plans the batch,
@@ -230,10 +238,15 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(
     float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
     int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
-    uint32_t* __restrict__ ident) {
+    uint32_t* __restrict__ ident, int32_t* __restrict__ strips, int32_t* __restrict__ n_strips) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ __attribute__((aligned(16))) unsigned char strip_scratch[kStripScratch];
   if (blockIdx.x == 0) {  // dispatched first: the planner's latency chain starts immediately
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    if (strips) {
+      __syncthreads();
+      plan_strips_body(mask, B, N, n_cu, strips, n_strips, strip_scratch);
+    }
   } else {
     pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, (int)blockIdx.x - 1, ident);
   }
@@ -243,8 +256,8 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
                                        int64_t stride_c, int64_t stride_ch, int B, int N, int C,
                                        float* Lp, const uint8_t* mask, int n_cu, int allow_pairs,
                                        int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
-                                       int32_t* n_gain_rows, uint32_t* ident,
-                                       lnz_stream_t stream) {
+                                       int32_t* n_gain_rows, uint32_t* ident, int32_t* strips,
+                                       int32_t* n_strips, lnz_stream_t stream) {
   LNZ_REQUIRE(L && Lp && mask && plan && n_wg && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS &&
                   n_cu > 0,
               LNZ_EINVAL, "lnz_pack_laplacian_plan: bad arguments (B=%d C=%d n_cu=%d)", B, C, n_cu);
@@ -253,12 +266,14 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
   LNZ_REQUIRE(!gain_rows || (n_gain_rows && K > 0), LNZ_EINVAL,
               "lnz_pack_laplacian_plan: gain_rows needs n_gain_rows and K > 0");
   size_t lds = (size_t)N * N * C * sizeof(float);
-  LNZ_REQUIRE(lds <= 48 * 1024, LNZ_ENOTSUP,
-              "lnz_pack_laplacian_plan: N*N*C*4 = %zu B exceeds the 48 KiB staging tile", lds);
+  LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
+              "lnz_pack_laplacian_plan: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
+  LNZ_REQUIRE(!strips || (n_strips && B <= LNZ_STRIP_MAX_B), LNZ_EINVAL,
+              "lnz_pack_laplacian_plan: strips need n_strips and B <= %d", LNZ_STRIP_MAX_B);
   hipLaunchKernelGGL(pack_plan_kernel, dim3(B + 1), dim3(1024), lds, (hipStream_t)stream, L,
                      stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
-                     ident);
+                     ident, strips, n_strips);
   return lnz::check_launch("lnz_pack_laplacian_plan");
 }
 
@@ -269,18 +284,36 @@ extern "C" int lnz_plan_wg_cap(int B, int n_cu) {
 
 extern "C" int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
                               int32_t* plan, int32_t* n_wg, int K, int32_t* gain_rows,
-                              int32_t* n_gain_rows, lnz_stream_t stream) {
+                              int32_t* n_gain_rows, int32_t* strips, int32_t* n_strips,
+                              lnz_stream_t stream) {
   LNZ_REQUIRE(mask && plan && n_wg && B > 0 && N > 0 && N <= LNZ_TILE && n_cu > 0, LNZ_EINVAL,
               "lnz_plan_batch: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
   LNZ_REQUIRE(!gain_rows || (n_gain_rows && K > 0), LNZ_EINVAL,
               "lnz_plan_batch: gain_rows needs n_gain_rows and K > 0");
+  LNZ_REQUIRE(!strips || (n_strips && B <= LNZ_STRIP_MAX_B), LNZ_EINVAL,
+              "lnz_plan_batch: strips need n_strips and B <= %d", LNZ_STRIP_MAX_B);
   hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
                      n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows,
-                     n_gain_rows);
+                     n_gain_rows, strips, n_strips);
   return lnz::check_launch("lnz_plan_batch");
+}
+
+extern "C" int lnz_strip_cap(int B) { return B <= 0 ? 0 : (B < kStripBins ? B : kStripBins); }
+
+extern "C" int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips,
+                               int32_t* n_strips, lnz_stream_t stream) {
+  LNZ_REQUIRE(mask && strips && n_strips && B > 0 && N > 0 && n_cu > 0, LNZ_EINVAL,
+              "lnz_plan_strips: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
+  LNZ_REQUIRE(N <= LNZ_TILE && B <= LNZ_STRIP_MAX_B, LNZ_ENOTSUP,
+              "lnz_plan_strips: built for N <= %d, B <= %d (N=%d B=%d)", LNZ_TILE, LNZ_STRIP_MAX_B, N, B);
+  hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
+                     n_cu, 0, 0, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
+                     (int32_t*)nullptr, strips, n_strips);
+  return lnz::check_launch("lnz_plan_strips");
 }
 
 extern "C" int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
                               int32_t* plan, int32_t* n_wg, lnz_stream_t stream) {
-  return lnz_plan_batch(mask, B, N, n_cu, allow_pairs, plan, n_wg, 0, nullptr, nullptr, stream);
+  return lnz_plan_batch(mask, B, N, n_cu, allow_pairs, plan, n_wg, 0, nullptr, nullptr, nullptr,
+                        nullptr, stream);
 }

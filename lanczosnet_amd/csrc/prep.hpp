@@ -200,3 +200,181 @@ __device__ __forceinline__ void plan_tiles_body(const uint8_t* __restrict__ mask
   }
 }
 
+
+
+// ---- strip plan: molecules packed at 4-row granularity into strips of 16-row subtiles -----------
+// The 16 x 16-tile forward (conv_strip.hip) runs one workgroup on a STRIP of up to LNZ_STRIP_SUB
+// subtiles (96 node rows).  A molecule takes ceil(n / 4) * 4 consecutive rows at a 4-aligned start
+// and never spans more than two subtiles, so every operator of the strip is block diagonal with
+// blocks on the subtile diagonal and its two neighbours.  Against the 32-row tiles of
+// plan_tiles_body (rows of 8 | 24, 16 | 16 pairs or singles) the bench batch needs 18.8 k rows
+// instead of 23.8 k — five subtiles per CU instead of six.
+//
+// Packing: first fit decreasing by size class (rows / 4 = 8 .. 1), a whole class at a time — the
+// items of a class are identical, so a bin's capacity for the class is a count, the bins' counts
+// are prefix-summed and item r of the class (stable rank: batch order) lands in the bin whose
+// range holds r.  Deterministic: the plan is a pure function of the mask.  The strip height is the
+// smallest number of subtiles (2 .. LNZ_STRIP_SUB) for which the batch fits R strips per CU, R =
+// the rounds it needs at full height (one for the bench batch).
+// strips[s * LNZ_STRIP_INTS + {0, 1}] = molecules, subtiles of strip s; + 2 + 3 i + {0, 1, 2} =
+// (molecule, first row, node extent) of its i-th molecule, rows ascending.
+// scratch: >= kStripScratch bytes of LDS; B <= LNZ_STRIP_MAX_B.
+constexpr int kStripBins = 1024;
+constexpr int kStripScratch = 7 * LNZ_STRIP_MAX_B + 5 * kStripBins + 64;
+
+__device__ __forceinline__ int strip_place(int fill, int rows) {  // first row of the next molecule
+  return ((fill & 15) + rows <= 32) ? fill : ((fill + 15) & ~15);
+}
+
+__device__ __forceinline__ void plan_strips_body(const uint8_t* __restrict__ mask, int B, int N,
+                                                 int n_cu, int32_t* __restrict__ strips,
+                                                 int32_t* __restrict__ n_strips,
+                                                 unsigned char* scratch) {
+  const int NT = blockDim.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+  uint8_t* ext = scratch;                                        // [B] node extent
+  uint8_t* poff = ext + LNZ_STRIP_MAX_B;                         // [B] first row in its strip
+  uint8_t* pslot = poff + LNZ_STRIP_MAX_B;                       // [B] position in its strip
+  uint16_t* rnk = reinterpret_cast<uint16_t*>(pslot + LNZ_STRIP_MAX_B);  // [B] rank in its class
+  uint16_t* pbin = rnk + LNZ_STRIP_MAX_B;                        // [B] strip
+  uint16_t* pre = pbin + LNZ_STRIP_MAX_B;                        // [bins] exclusive capacity sums
+  uint8_t* fill = reinterpret_cast<uint8_t*>(pre + kStripBins);  // [bins] rows in use
+  uint8_t* nmol = fill + kStripBins;                             // [bins] molecules
+  uint8_t* capk = nmol + kStripBins;                             // [bins] capacity for the class
+  __shared__ int ccnt[9], cbase[9], wcnt[16][9], s_total, s_used, s_chunk[17];
+  if (tid < 9) ccnt[tid] = 0, cbase[tid] = 0;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  // ---- extents, size classes, stable ranks within a class
+  for (int c0 = 0; c0 < B; c0 += NT) {
+    const int b = c0 + tid;
+    int cl = 0;
+    if (b < B) {
+      int n = 0;
+      for (int i = 0; i < N; ++i) n = mask[(int64_t)b * N + i] ? i + 1 : n;
+      ext[b] = (uint8_t)n;
+      cl = n <= 4 ? 1 : (n + 3) >> 2;
+    }
+    int lr = 0;
+    for (int v = 1; v <= 8; ++v) {
+      const unsigned long long mk = __ballot(cl == v);
+      if (cl == v) lr = __popcll(mk & ((1ull << ln) - 1ull));
+      if (ln == 0) wcnt[wv][v] = __popcll(mk);
+    }
+    __syncthreads();
+    if (b < B) {
+      int r = cbase[cl] + lr;
+      for (int w = 0; w < wv; ++w) r += wcnt[w][cl];
+      rnk[b] = (uint16_t)r;
+    }
+    __syncthreads();
+    if (tid >= 1 && tid <= 8) {
+      int add = 0;
+      for (int w = 0; w < NT / 64; ++w) add += wcnt[w][tid];
+      cbase[tid] += add;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    int t = 0;
+    for (int v = 1; v <= 8; ++v) ccnt[v] = cbase[v], t += 4 * v * cbase[v];
+    s_total = t;
+  }
+  __syncthreads();
+  // rounds of n_cu strips the batch needs at full height; the strips are then made just high
+  // enough for that many rounds, so that every compute unit carries the same number of subtiles
+  const int total16 = (s_total + 15) >> 4;
+  const int rounds = (total16 + LNZ_STRIP_SUB * n_cu - 1) / (LNZ_STRIP_SUB * n_cu);
+  const int target = rounds * n_cu < kStripBins ? rounds * n_cu : kStripBins;
+  int cap = (total16 + target - 1) / target;
+  cap = cap < 2 ? 2 : (cap > LNZ_STRIP_SUB ? LNZ_STRIP_SUB : cap);
+  for (;; ++cap) {
+    for (int i = tid; i < kStripBins; i += NT) fill[i] = 0, nmol[i] = 0;
+    __syncthreads();
+    for (int v = 8; v >= 1; --v) {
+      const int cnt = ccnt[v], rows = 4 * v;
+      if (cnt == 0) continue;  // (uniform)
+      // capacity of every bin for this class
+      for (int i = tid; i < kStripBins; i += NT) {
+        int f = fill[i], k = 0;
+        for (;;) {
+          const int off = strip_place(f, rows);
+          if (off + rows > 16 * cap) break;
+          f = off + rows;
+          ++k;
+        }
+        capk[i] = (uint8_t)k;
+      }
+      __syncthreads();
+      // exclusive prefix sums over the bins: chunks of 64 bins per thread group, then the chunks
+      if (tid < kStripBins / 64) {
+        int sum = 0;
+        for (int i = 0; i < 64; ++i) sum += capk[tid * 64 + i];
+        s_chunk[tid + 1] = sum;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        s_chunk[0] = 0;
+        for (int i = 1; i <= kStripBins / 64; ++i) s_chunk[i] += s_chunk[i - 1];
+      }
+      __syncthreads();
+      if (tid < kStripBins / 64) {
+        int run = s_chunk[tid];
+        for (int i = 0; i < 64; ++i) {
+          pre[tid * 64 + i] = (uint16_t)(run > 65535 ? 65535 : run);
+          run += capk[tid * 64 + i];
+        }
+      }
+      __syncthreads();
+      // the class's molecules: strip by rank, row by replaying the strip's placements
+      for (int b = tid; b < B; b += NT) {
+        const int n = ext[b];
+        if ((n <= 4 ? 1 : (n + 3) >> 2) != v) continue;
+        const int r = rnk[b];
+        int lo = 0, hi = kStripBins - 1;  // last bin with pre <= r
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (pre[mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        const int k = r - pre[lo];
+        int f = fill[lo], off = 0;
+        for (int i = 0; i <= k; ++i) {
+          off = strip_place(f, rows);
+          f = off + rows;
+        }
+        pbin[b] = (uint16_t)lo;
+        poff[b] = (uint8_t)off;
+        pslot[b] = (uint8_t)(nmol[lo] + k);
+      }
+      __syncthreads();
+      for (int i = tid; i < kStripBins; i += NT) {
+        int take = cnt - (int)pre[i];
+        take = take < 0 ? 0 : (take > capk[i] ? capk[i] : take);
+        int f = fill[i];
+        for (int k = 0; k < take; ++k) f = strip_place(f, rows) + rows;
+        fill[i] = (uint8_t)f;
+        nmol[i] = (uint8_t)(nmol[i] + take);
+      }
+      __syncthreads();
+    }
+    // strips in use form a prefix of the bins (first fit)
+    if (tid == 0) s_used = 0;
+    __syncthreads();
+    for (int i = tid; i < kStripBins; i += NT)
+      if (nmol[i] > 0) atomicMax(&s_used, i + 1);
+    __syncthreads();
+    if (s_used <= target || cap >= LNZ_STRIP_SUB) break;
+    __syncthreads();
+  }
+  const int used = s_used;
+  for (int i = tid; i < used; i += NT) {
+    strips[i * LNZ_STRIP_INTS + 0] = nmol[i];
+    strips[i * LNZ_STRIP_INTS + 1] = (fill[i] + 15) >> 4;
+  }
+  for (int b = tid; b < B; b += NT) {
+    int32_t* e = strips + (int64_t)pbin[b] * LNZ_STRIP_INTS + 2 + 3 * pslot[b];
+    e[0] = b;
+    e[1] = poff[b];
+    e[2] = ext[b];
+  }
+  if (tid == 0) *n_strips = used;
+}

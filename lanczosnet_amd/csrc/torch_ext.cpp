@@ -74,9 +74,9 @@ const Tensor* first_defined(std::initializer_list<const Tensor*> ts) {
 // order of kIn below (None = NULL), `dims` the scalar fields in the order of kDim; the buffers a
 // launch writes are separate, alias-annotated arguments.
 enum { kNodeFeat, kNodeFeatF, kEmbedding, kMask, kLp, kV, kG, kWp, kBias, kWpHead, kBiasHead, kWp16,
-       kWp16Head, kLp16, kPlan, kNwg, kAct, kX0, kIdent, kRowOff, kNumIn };
+       kWp16Head, kLp16, kPlan, kNwg, kAct, kX0, kIdent, kRowOff, kStrips, kNStrips, kNumIn };
 enum { dB, dN, dK, dNumLayer, dDin0, dDhid, dDout, dNLong, dNEdge, dNumAtom, dFilterKind, dGemmMode,
-       dPlanCap, dBwdDin0, dMsgLayer, dDyCompactRows, kNumDim };
+       dPlanCap, dBwdDin0, dMsgLayer, dDyCompactRows, dStripCap, kNumDim };
 void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at::IntArrayRef dims,
                   at::IntArrayRef w_off, at::IntArrayRef b_off, at::IntArrayRef w16_off,
                   at::IntArrayRef short_dist, const c10::optional<Tensor>& score,
@@ -122,6 +122,13 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
   a.x0 = (const float*)raw_ptr(opt(kX0), at::kFloat, "x0");
   a.ident = (const uint32_t*)raw_ptr(opt(kIdent), at::kInt, "ident");
   a.row_off = (const int64_t*)raw_ptr(opt(kRowOff), at::kLong, "row_off");
+  a.strips = (const int32_t*)raw_ptr(opt(kStrips), at::kInt, "strips");
+  a.n_strips = (const int32_t*)raw_ptr(opt(kNStrips), at::kInt, "n_strips");
+  a.strip_cap = dims[dStripCap];
+  if (a.strips)
+    TORCH_CHECK(a.n_strips && a.strip_cap > 0 &&
+                    opt(kStrips)->numel() >= (int64_t)a.strip_cap * LNZ_STRIP_INTS,
+                "lanczosnet::fused_launch: strips shorter than strip_cap entries, or n_strips missing");
   // shapes of the operands whose extents the kernels take on trust
   if (a.mask) TORCH_CHECK(opt(kMask)->numel() == (int64_t)a.B * a.N, "lanczosnet::fused_launch: mask is not [B,N]");
   if (a.node_feat) TORCH_CHECK(opt(kNodeFeat)->numel() == (int64_t)a.B * a.N, "lanczosnet::fused_launch: node_feat is not [B,N]");
@@ -201,8 +208,8 @@ std::tuple<Tensor, Tensor, Tensor> lanczos_ritz(const Tensor& A, const Tensor& n
 }
 
 // ---- batch preparation: pack + plan + Ritz pairs in one launch ------------------------------
-// returns (Lp [B,C,4,64,4], ident [B], plan [12 cap + 2 + B K] = tile plan | n_wg | n_rows | rows,
-//          D [B,K], V [B,N,K])
+// returns (Lp [B,C,4,64,4], ident [B], plan [12 cap + 2 + B K (+ scap LNZ_STRIP_INTS + 1)] = tile plan
+//          | n_wg | n_rows | rows (| strip plan | n_strips, for B <= LNZ_STRIP_MAX_B), D [B,K], V [B,N,K])
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> prepare_batch(const Tensor& L, const Tensor& mask,
                                                                  const Tensor& n_nodes, int64_t K,
                                                                  int64_t n_cu, bool allow_pairs) {
@@ -217,7 +224,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> prepare_batch(const Tensor& L
   auto iopt = n_nodes.options();
   Tensor Lp = at::empty({B, C, 4, 64, 4}, L.options());
   Tensor ident = at::empty({B}, iopt);
-  Tensor plan = at::empty({12 * (int64_t)cap + 2 + (int64_t)B * K}, iopt);
+  const int scap = B <= LNZ_STRIP_MAX_B ? lnz_strip_cap(B) : 0;
+  const int64_t soff = 12 * (int64_t)cap + 2 + (int64_t)B * K;
+  Tensor plan = at::empty({soff + (scap ? (int64_t)scap * LNZ_STRIP_INTS + 1 : 0)}, iopt);
   Tensor D = at::empty({B, K}, L.options());
   Tensor V = at::empty({B, N, K}, L.options());
   int32_t* pb = plan.data_ptr<int32_t>();
@@ -226,7 +235,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> prepare_batch(const Tensor& L
                           n_nodes.data_ptr<int32_t>(), (int)n_cu, allow_pairs ? 1 : 0, pb,
                           pb + 12 * cap, (int)K, pb + 12 * cap + 2, pb + 12 * cap + 1,
                           D.data_ptr<float>(), V.data_ptr<float>(), nullptr,
-                          (uint32_t*)ident.data_ptr<int32_t>(), cur_stream()),
+                          (uint32_t*)ident.data_ptr<int32_t>(), scap ? pb + soff : nullptr,
+                          scap ? pb + soff + (int64_t)scap * LNZ_STRIP_INTS : nullptr, cur_stream()),
         "prepare_batch");
   return {Lp, ident, plan, D, V};
 }
@@ -266,7 +276,7 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
                const Tensor& mask, const Tensor& Wp, const Tensor& bias, at::IntArrayRef w_off,
                at::IntArrayRef b_off, const Tensor& Wp_head, const Tensor& bias_head,
                const c10::optional<Tensor>& plan, int64_t plan_cap, at::IntArrayRef dims,
-               at::IntArrayRef short_dist) {
+               at::IntArrayRef short_dist, const c10::optional<Tensor>& strips, int64_t strip_cap) {
   TORCH_CHECK(dims.size() == 7, "lanczosnet::forward: dims = [num_layer, din0, dhid, dout, n_long, "
                                 "n_edge, filter_kind]");
   need(Lp, at::kFloat, "Lp");
@@ -328,6 +338,14 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
     a.n_wg = plan->data_ptr<int32_t>() + 12 * plan_cap;
     a.plan_wg_cap = (int)plan_cap;
   }
+  if (strips.has_value()) {  // [strip_cap * LNZ_STRIP_INTS + 1]: the strip plan, then n_strips
+    need(*strips, at::kInt, "strips");
+    TORCH_CHECK(strip_cap > 0 && strips->numel() >= strip_cap * LNZ_STRIP_INTS + 1,
+                "lanczosnet::forward: strips shorter than strip_cap entries + 1");
+    a.strips = strips->data_ptr<int32_t>();
+    a.n_strips = strips->data_ptr<int32_t>() + strip_cap * LNZ_STRIP_INTS;
+    a.strip_cap = (int)strip_cap;
+  }
   Tensor score = at::empty({a.B, a.dout}, V.options());
   a.score = score.data_ptr<float>();
   check(lnz_lanczosnet_forward(&a, cur_stream()), "forward");
@@ -376,7 +394,8 @@ TORCH_LIBRARY(lanczosnet, m) {
         "Tensor? n_rows, bool zero_fill) -> Tensor");
   m.def("forward(Tensor node_feat, Tensor? embedding, Tensor Lp, Tensor? ident, Tensor V, Tensor? G, "
         "Tensor mask, Tensor Wp, Tensor bias, int[] w_off, int[] b_off, Tensor Wp_head, "
-        "Tensor bias_head, Tensor? plan, int plan_cap, int[] dims, int[] short_dist) -> Tensor");
+        "Tensor bias_head, Tensor? plan, int plan_cap, int[] dims, int[] short_dist, Tensor? strips, "
+        "int strip_cap) -> Tensor");
   m.def("unsorted_segment_sum_forward(Tensor data, Tensor segment_ids, int num_segments) -> Tensor");
   m.def("unsorted_segment_sum_backward(Tensor grad_out, Tensor segment_ids, int dim1) -> Tensor");
   m.def("fused_launch(int which, Tensor?[] operands, int[] dims, int[] w_off, int[] b_off, int[] w16_off, "

@@ -418,12 +418,17 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
   Lp.ident = torch.empty((B,), dtype=torch.int32, device=Lf.device)
   buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=Lf.device)
   n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
+  strips, ns = None, None
+  if strip_plan_wanted(B, N):
+    strips, scap = _strip_buf(B, Lf.device)
+    ns = strips[scap * STRIP_INTS:]
+    buf.strips = strips
   sb, sr, sc, sch = Lf.stride()
   with torch.cuda.device(Lf.device):
     _abi().pack_laplacian_plan(
         Lf, sb, sr, sc, sch, B, N, Cn, Lp, mask_u8, n_cu,
         int(pairing_supported(plan)), buf, n_wg, K, rows, n_rows,
-        Lp.ident)
+        Lp.ident, strips, ns)
   return Lp, (buf, cap), (rows, n_rows)
 
 
@@ -448,8 +453,11 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
   Lp, ident, buf, D, V = _ext().prepare_batch(Lf, mask_u8, nn, K, n_cu,
                                               bool(pairing_supported(plan)))
   Lp.ident = ident
-  cap = (buf.numel() - 2 - B * K) // 12
-  return Lp, (buf, cap), (buf[12 * cap + 2:], buf[12 * cap + 1:12 * cap + 2]), D, V
+  cap = _abi().plan_wg_cap(B, n_cu)
+  soff = 12 * cap + 2 + B * K
+  if buf.numel() > soff:  # the strip plan rides behind the live-slot list
+    buf.strips = buf[soff:]
+  return Lp, (buf, cap), (buf[12 * cap + 2:soff], buf[12 * cap + 1:12 * cap + 2]), D, V
 
 
 def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=None):
@@ -478,13 +486,18 @@ def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=Non
   Gbuf = torch.empty((num_layer * Bp * S * K + 16,), dtype=torch.float32, device=dev)
   G = Gbuf[:num_layer * Bp * S * K].view(num_layer, Bp, S, K)
   darr = [int(x) for x in dist]
+  strips, ns = None, None
+  if strip_plan_wanted(B, N):
+    strips, scap = _strip_buf(B, dev)
+    ns = strips[scap * STRIP_INTS:]
+    buf.strips = strips
   sb, sr, sc, sch = Lf.stride()
   with torch.cuda.device(dev):
     _abi().prepare_batch_prev_gains(
         Lf, sb, sr, sc, sch, B, N, Cn, Lp, mask_u8, nn, n_cu,
         int(pairing_supported(plan)), buf, n_wg, K, rows, n_rows,
         D, V, Lp.ident, D_prev, Bp, rows_prev, n_rows_prev,
-        darr, S, num_layer, mlp_pack, G)
+        darr, S, num_layer, mlp_pack, G, strips, ns)
   return Lp, (buf, cap), (rows, n_rows), D, V, G
 
 
@@ -576,8 +589,13 @@ def plan_batch(mask_u8, allow_pairs, K, n_cu=None):
   cap = _abi().plan_wg_cap(B, n_cu)
   buf = torch.empty((12 * cap + 2 + B * K,), dtype=torch.int32, device=mask_u8.device)
   n_wg, n_rows, rows = buf[12 * cap:12 * cap + 1], buf[12 * cap + 1:12 * cap + 2], buf[12 * cap + 2:]
+  strips, ns = None, None
+  if strip_plan_wanted(B, N):
+    strips, scap = _strip_buf(B, mask_u8.device)
+    ns = strips[scap * STRIP_INTS:]
+    buf.strips = strips
   _abi().plan_batch(mask_u8, B, N, n_cu, int(bool(allow_pairs)), buf,
-                                n_wg, K, rows, n_rows)
+                                n_wg, K, rows, n_rows, strips, ns)
   return (buf, cap), (rows, n_rows)
 
 
@@ -589,6 +607,14 @@ def plan_tiles(mask_u8, allow_pairs, n_cu=None):
   n_cu = n_cu or _n_cu(mask_u8.device)
   cap = _abi().plan_wg_cap(B, n_cu)
   buf = torch.empty((12 * cap + 1,), dtype=torch.int32, device=mask_u8.device)
+  if allow_pairs and strip_plan_wanted(B, N):
+    # (a plan that may share tiles also carries the strip plan; 'single' plans keep one molecule
+    # per tile for the kernels and tests that ask for exactly that)
+    strips, scap = _strip_buf(B, mask_u8.device)
+    buf.strips = strips
+    _abi().plan_batch(mask_u8, B, N, n_cu, 1, buf, buf[12 * cap:], 0, None, None, strips,
+                      strips[scap * STRIP_INTS:])
+    return buf, cap
   _abi().plan_tiles(mask_u8, B, N, n_cu, int(bool(allow_pairs)), buf,
                                 buf[12 * cap:])
   return buf, cap
@@ -680,10 +706,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
 # operand / scalar slots of torch.ops.lanczosnet.fused_launch (csrc/torch_ext.cpp: kIn / kDim)
 _IN = {k: i for i, k in enumerate(
     ['node_feat', 'node_feat_f', 'embedding', 'mask', 'Lp', 'V', 'G', 'Wp', 'bias', 'Wp_head',
-     'bias_head', 'Wp16', 'Wp16_head', 'Lp16', 'plan', 'n_wg', 'act', 'x0', 'ident', 'row_off'])}
+     'bias_head', 'Wp16', 'Wp16_head', 'Lp16', 'plan', 'n_wg', 'act', 'x0', 'ident', 'row_off',
+     'strips', 'n_strips'])}
 _DIM = {k: i for i, k in enumerate(
     ['B', 'N', 'K', 'num_layer', 'din0', 'dhid', 'dout', 'n_long', 'n_edge', 'num_atom', 'filter_kind',
-     'gemm_mode', 'plan_cap', 'bwd_din0', 'msg_layer', 'dy_compact_rows'])}
+     'gemm_mode', 'plan_cap', 'bwd_din0', 'msg_layer', 'dy_compact_rows', 'strip_cap'])}
 
 
 def _fused_operands(plan, V):
@@ -703,6 +730,37 @@ def _set_plan(ops_, dims, tiles, cap):
   ops_[_IN['plan']] = tiles
   ops_[_IN['n_wg']] = tiles[12 * cap:]
   dims[_DIM['plan_cap']] = int(cap)
+  strips = getattr(tiles, 'strips', None)  # strip plan made with the tile plan (_attach_strips)
+  if strips is not None:
+    scap = (strips.numel() - 1) // STRIP_INTS
+    ops_[_IN['strips']], ops_[_IN['n_strips']] = strips, strips[scap * STRIP_INTS:]
+    dims[_DIM['strip_cap']] = scap
+
+
+STRIP_INTS, STRIP_MAX_B = 80, 2048   # LNZ_STRIP_INTS, LNZ_STRIP_MAX_B
+
+
+def strip_plan_wanted(B, N):
+  """The strip plan (lnz_plan_strips) is made next to the tile plan for every batch it takes."""
+  return B <= STRIP_MAX_B and N <= 32
+
+
+def _strip_buf(B, device):
+  scap = _abi().strip_cap(B)
+  return torch.empty((scap * STRIP_INTS + 1,), dtype=torch.int32, device=device), scap
+
+
+def plan_strips(mask_u8, n_cu=None):
+  """lnz_plan_strips: molecules packed at 4-row granularity into strips of 16-row subtiles, one
+  workgroup of the 16 x 16-tile inference forward each.  Returns the int32 tensor
+  [scap * 80 + 1] = scap entries (molecules, subtiles, then (molecule, first row, extent) triples)
+  followed by the number of strips in use."""
+  B, N = mask_u8.shape
+  n_cu = n_cu or _n_cu(mask_u8.device)
+  buf, scap = _strip_buf(B, mask_u8.device)
+  with torch.cuda.device(mask_u8.device):
+    _abi().plan_strips(mask_u8, B, N, n_cu, buf, buf[scap * STRIP_INTS:])
+  return buf
 
 
 def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
@@ -739,8 +797,11 @@ def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
         [int(p) for p in plan['short']])
   w_off, b_off, dims, short = consts
   ident = getattr(Lp, 'ident', None) if use_ident else None
+  strips = getattr(tiles, 'strips', None)
+  scap = (strips.numel() - 1) // STRIP_INTS if strips is not None else 0
   return _ext().forward(nf, emb, Lp, ident, _f32c(V), G, mask_u8, plan['Wp'], plan['bias'], w_off,
-                        b_off, plan['Wp_head'], plan['bias_head'], tiles, cap, dims, short)
+                        b_off, plan['Wp_head'], plan['bias_head'], tiles, cap, dims, short,
+                        strips, scap)
 
 
 def _training_args(plan, Lp, V, G, mask_u8, tiling):

@@ -34,7 +34,7 @@ def _model(cfg, params, general=False):
 def test_library_loaded_in_tree():
   from lanczosnet_amd import _lib
   lib = _lib.load()
-  assert lib.lnz_abi_version() == _lib.ABI_VERSION == 4
+  assert lib.lnz_abi_version() == _lib.ABI_VERSION == 5
   assert _lib.LIB_PATH.endswith('lanczosnet_amd/csrc/liblanczosnet_hip.so')
 
 
@@ -1103,6 +1103,9 @@ def test_torch_extension_ops_equal_the_raw_c_abi_bitwise():
   fa.Wp_head, fa.bias_head = plan['Wp_head'].data_ptr(), plan['bias_head'].data_ptr()
   tiles = ops.plan_tiles(mk, allow_pairs=True)
   fa.plan, fa.n_wg, fa.plan_wg_cap = tiles[0].data_ptr(), tiles[0].data_ptr() + 48 * tiles[1], tiles[1]
+  strips = tiles[0].strips      # the strip plan made with the tile plan (ops.plan_tiles)
+  scap = (strips.numel() - 1) // 80
+  fa.strips, fa.n_strips, fa.strip_cap = strips.data_ptr(), strips.data_ptr() + 4 * 80 * scap, scap
   score = torch.empty((B, plan['dout']), device=DEV)
   state = torch.zeros((B, 32, plan['dhid']), device=DEV)
   fa.score, fa.state_out = score.data_ptr(), state.data_ptr()

@@ -1,0 +1,152 @@
+"""The strip plan (lnz_plan_strips: molecules at 4-row granularity in strips of 16-row subtiles) and
+the inference forward that runs on it (csrc/conv_strip.hip).  The plan is checked against a Python
+restatement of the packing rule and against its invariants; the forward against the 32-row-tile
+kernels on the same batch and (through the parity tests of test_gpu_parity.py, whose default launches
+carry a strip plan) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+INTS, SUB = 80, 6
+
+
+def _place(fill, rows):
+  return fill if (fill % 16) + rows <= 32 else (fill + 15) // 16 * 16
+
+
+def plan_strips_mirror(ext, n_cu, bins=1024):
+  """First fit decreasing by size class (rows / 4), a class at a time, stable in batch order; strip
+  height = the smallest number of subtiles (2..6) for which the strips in use fit the rounds of
+  n_cu strips the batch needs at full height."""
+  rows4 = np.where(ext <= 4, 4, (ext + 3) // 4 * 4)
+  total16 = (int(rows4.sum()) + 15) // 16
+  rounds = (total16 + SUB * n_cu - 1) // (SUB * n_cu)
+  target = min(rounds * n_cu, bins)
+  cap = min(max((total16 + target - 1) // target, 2), SUB)
+  while True:
+    fill = np.zeros(bins, int)
+    mols = [[] for _ in range(bins)]
+    for rows in range(32, 0, -4):
+      items = [b for b in range(len(ext)) if rows4[b] == rows]
+      k = 0
+      for bi in range(bins):
+        while k < len(items):
+          off = _place(fill[bi], rows)
+          if off + rows > 16 * cap:
+            break
+          mols[bi].append((items[k], off, int(ext[items[k]])))
+          fill[bi] = off + rows
+          k += 1
+        if k == len(items):
+          break
+      assert k == len(items)
+    used = max(i + 1 for i in range(bins) if mols[i])
+    if used <= target or cap >= SUB:
+      return [(mols[i], (fill[i] + 15) // 16) for i in range(used)]
+    cap += 1
+
+
+def _check_plan(buf, ext, n_cu):
+  scap = (buf.numel() - 1) // INTS
+  p = buf.cpu().numpy()
+  used = int(p[scap * INTS])
+  seen = np.zeros(len(ext), int)
+  plan = []
+  for s in range(used):
+    e = p[s * INTS:(s + 1) * INTS]
+    nm, sub = int(e[0]), int(e[1])
+    assert 1 <= nm <= 24 and 1 <= sub <= SUB
+    taken = np.zeros(16 * sub, int)
+    mols = []
+    for i in range(nm):
+      b, st, n = (int(x) for x in e[2 + 3 * i:5 + 3 * i])
+      rows = 4 if n <= 4 else (n + 3) // 4 * 4
+      assert n == ext[b] and st % 4 == 0 and st + rows <= 16 * sub
+      assert st // 16 + 1 >= (st + rows - 1) // 16, 'a molecule spans at most two subtiles'
+      taken[st:st + rows] += 1
+      seen[b] += 1
+      mols.append((b, st, n))
+    assert taken.max() == 1
+    assert [m[1] for m in mols] == sorted(m[1] for m in mols), 'rows ascending'
+    plan.append((mols, sub))
+  assert (seen == 1).all()
+  return plan
+
+
+@pytest.mark.parametrize('B,nmin,nmax,n_cu', [(1024, 8, 26, 256), (1024, 1, 32, 256), (2048, 3, 26, 256),
+                                              (5, 1, 9, 256), (300, 20, 32, 64), (777, 1, 6, 3)])
+def test_strip_plan_invariants_and_packing_rule(B, nmin, nmax, n_cu):
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(B + nmax)
+  ext = rs.randint(nmin, nmax + 1, size=B)
+  N = 32 if nmax > 26 else 26
+  mask = np.zeros((B, N), np.uint8)
+  for b in range(B):
+    mask[b, :ext[b]] = 1
+    if ext[b] > 2 and b % 7 == 0:
+      mask[b, ext[b] // 2] = 0          # a hole: the extent is the LAST real node + 1
+  mk = torch.from_numpy(mask).to(DEV)
+  buf = ops.plan_strips(mk, n_cu=n_cu)
+  plan = _check_plan(buf, ext, n_cu)
+  want = plan_strips_mirror(ext, n_cu)
+  assert len(plan) == len(want)
+  for (got_m, got_s), (want_m, want_s) in zip(plan, want):
+    assert got_s == want_s and got_m == want_m
+  assert _check_plan(ops.plan_strips(mk, n_cu=n_cu), ext, n_cu) == plan   # (unused words are not written)
+  # the same plan out of the fused launches' planner workgroup
+  (tiles, cap), _ = ops.plan_batch(mk, True, 20, n_cu=n_cu)
+  assert _check_plan(tiles.strips, ext, n_cu) == plan
+
+
+def test_bench_batch_fits_five_subtiles_per_compute_unit():
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  for seed in (0, 1):
+    b = draw_batch(1024, seed=seed)
+    buf = ops.plan_strips(torch.from_numpy(b['node_mask'].astype(np.uint8)).to(DEV), n_cu=256)
+    plan = _check_plan(buf, b['n_nodes'], 256)
+    assert len(plan) <= 256 and max(s for _, s in plan) == 5
+
+
+@pytest.mark.parametrize('B,n_cu', [(1024, 256), (96, 7), (33, 256)])
+def test_strip_forward_matches_the_tile_kernels_and_the_oracle(B, n_cu, monkeypatch):
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNet
+  from lanczosnet_amd.synthetic import draw_batch
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  P = oracle.make_lanczosnet_params(cfg, 3)
+  net = LanczosNet(make_model_config(cfg)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  net = net.to(DEV)
+  b = draw_batch(B, seed=11, n_min=2, n_max=26)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+  plan = net._plan()
+  Lp = ops.pack_laplacian_for(plan, L)
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  nf, mk = t(b['node_feat']), t(b['node_mask'].astype(np.uint8))
+  tiles = ops.plan_tiles(mk, True, n_cu=n_cu)
+  assert getattr(tiles[0], 'strips', None) is not None
+  with torch.no_grad():
+    s_strip, st_strip = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles, return_state=True)
+    s_fast = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+    monkeypatch.setenv('LNZ_STRIPS', '0')
+    s_tile, st_tile = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles, return_state=True)
+  assert torch.equal(s_strip, s_fast)
+  scale = s_tile.abs().max().item()
+  assert (s_strip - s_tile).abs().max().item() <= 2e-6 * scale
+  # final node states of the real nodes
+  real = torch.arange(32, device=DEV)[None, :] < n[:, None]
+  d = (st_strip - st_tile).abs().amax(dim=2)
+  assert d[real].max().item() <= 2e-6 * st_tile.abs().max().item()
+  ref = oracle.lanczos_net_forward(P, cfg, b['node_feat'], L.cpu().numpy(), D.cpu().numpy(),
+                                   V.cpu().numpy(), b['node_mask'], dtype=np.float64)
+  got = s_strip.cpu().numpy()
+  assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
