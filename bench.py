@@ -129,7 +129,15 @@ def forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, sizes, r
       torch.cuda.synchronize()
       ms = e[0].elapsed_time(e[1]) / reps
       tf = FWD_FLOP_EXECUTED * n_tiles / (ms * 1e-3) / 1e12
-      out.append({'batch': B0 * r, 'tiles': n_tiles, 'workgroups': n_wg, 'forward_ms': round(ms, 4),
+      kern = 'tiles'
+      from lanczosnet_amd.utils.flop_model import strips_selected, strips_from_plan, strip_mfma_issued
+      if getattr(buf, 'strips', None) is not None and strips_selected(cfg, B0 * r, Lr.shape[1]):
+        # this size runs on the strip plan: flops from the instructions that plan issues
+        fm = strip_mfma_issued(strips_from_plan(buf.strips.cpu().numpy(),
+                                                Lp.ident.cpu().numpy() if hasattr(Lp, 'ident') else None), cfg)
+        tf = fm['flops_issued'] / (ms * 1e-3) / 1e12
+        kern, n_tiles, n_wg = 'strips (%d subtiles)' % fm['subtiles'], fm['tiles'], fm['tiles']
+      out.append({'batch': B0 * r, 'plan': kern, 'tiles': n_tiles, 'workgroups': n_wg, 'forward_ms': round(ms, 4),
                   'executed_tflops': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                   'molecules_per_s_forward_only': round(B0 * r / ms * 1e3, 1)})
       del Lr, Lp, V, G
@@ -872,7 +880,8 @@ def main():
     # instruction from the plan (lanczosnet_amd/utils/flop_model.py; agrees with rocprofv3's
     # SQ_INSTS_VALU_MFMA_MOPS_F32 of this kernel, tests/test_flop_model.py)
     from lanczosnet_amd.utils.flop_model import (tiles_from_plan, forward_mfma_issued,
-                                                 forward16_mfma_issued, forward16_selected)
+                                                 forward16_mfma_issued, forward16_selected,
+                                                 strips_selected, strips_from_plan, strip_mfma_issued)
     with torch.no_grad():
       Lp_m, (buf, cap), _, _, _ = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
     torch.cuda.synchronize()
@@ -880,23 +889,35 @@ def main():
     extents = np.where(mk.any(axis=1), mk.shape[1] - np.argmax(mk[:, ::-1] != 0, axis=1), 0)
     tile_list = tiles_from_plan(buf[:12 * cap].cpu().numpy(), extents,
                                 Lp_m.ident.cpu().numpy() if hasattr(Lp_m, 'ident') else None, K)
-    # which of the two exact-fp32 forward kernels took the launches (csrc/conv_forward.hip launch_conv)
+    # which of the exact-fp32 forward kernels took the launches (csrc/conv_forward.hip launch_conv)
     f16 = args.gemm == 'fp32' and forward16_selected(cfg)
-    fm = forward16_mfma_issued(tile_list, cfg) if f16 else forward_mfma_issued(tile_list, cfg)
-    roof_kernel = 'lanczosnet_forward16_kernel' if f16 else 'lanczosnet_forward_kernel<4,10,0,0>'
+    strip = f16 and getattr(buf, 'strips', None) is not None and strips_selected(cfg, B, L.shape[1])
+    if strip:
+      ident_np = Lp_m.ident.cpu().numpy() if hasattr(Lp_m, 'ident') else None
+      tile_list = strips_from_plan(buf.strips.cpu().numpy(), ident_np)
+      fm = strip_mfma_issued(tile_list, cfg)
+    else:
+      fm = forward16_mfma_issued(tile_list, cfg) if f16 else forward_mfma_issued(tile_list, cfg)
+    roof_kernel = ('lanczosnet_strip_kernel' if strip else 'lanczosnet_forward16_kernel' if f16
+                   else 'lanczosnet_forward_kernel<4,10,0,0>')
     roof_insn = ('2048 flop x the v_mfma_f32_16x16x4_f32' if f16 else
                  '4096 flop x the v_mfma_f32_32x32x2_f32')
     n_tiles = fm['tiles']
     flops_exec = fm['flops_issued']
     achieved = flops_exec / fwd_s / 1e12
     if os.environ.get('LNZ_BENCH_DUMP_PLAN'):
-      np.savez_compressed(os.environ['LNZ_BENCH_DUMP_PLAN'],
-                          **{k_: np.array([t_[k_] for t_ in tile_list]) for k_ in tile_list[0]})
+      if strip:
+        np.savez_compressed(os.environ['LNZ_BENCH_DUMP_PLAN'], strips=buf.strips.cpu().numpy(),
+                            ident=ident_np if ident_np is not None else np.zeros(0, np.int32))
+      else:
+        np.savez_compressed(os.environ['LNZ_BENCH_DUMP_PLAN'],
+                            **{k_: np.array([t_[k_] for t_ in tile_list]) for k_ in tile_list[0]})
     # HBM bytes per launch of the roofline kernel: PMC counters cannot be read from inside this
     # process, so `traffic` cites the committed counter run of the SAME command and workload
     # (tools/pmc_forward_profile.py -> profiles/), never a number measured in this run
     traffic, traffic_source = None, None
-    for name in (('r04_forward16_pmc.json',) if f16 else ('r03_forward_pmc.json', 'pmc_forward_hbm_bytes.json')):
+    for name in (('r04_strip_pmc.json',) if strip else ('r04_forward16_pmc.json',) if f16 else
+                 ('r03_forward_pmc.json', 'pmc_forward_hbm_bytes.json')):
       prof = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(prof) and B == 1024:
         try:
@@ -932,20 +953,36 @@ def main():
                      'useful_row_frac': round(fm['useful_row_frac'], 4),
                      'useful_frac': round(achieved / PEAK_FP32_MFMA_TFLOPS * fm['useful_row_frac'], 4),
                      'avg_launch_ms': round(stage_ms['lanczosnet_forward'], 4),
-                     'reference_association_tflops': round(FWD_FLOP_PER_MOL * n_tiles / fwd_s / 1e12, 2),
-                     'note': 'achieved = frac * peak = flops_per_launch_executed / avg_launch_ms. '
-                             'flops_per_launch_executed = %s '
-                             'instructions the kernel issues for THIS batch\'s tile plan (k-groups of '
-                             'padded rows / empty eigen slots and identity bond-type channels are '
-                             'skipped; utils/flop_model.py, checked against the PMC counter '
-                             'SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/); without the skips the same '
-                             '%d tiles would issue flops_per_launch_without_skips. useful_row_frac = '
-                             'real node rows / tile rows (%d molecules ride in %d 32-row tiles, '
-                             'lnz_plan_tiles); useful_frac = frac x useful_row_frac. '
-                             'reference_association_tflops prices the tiles at SURVEY 8(d)\'s %d flop '
-                             '(filter build + L_s Z per long channel, which the kernel replaces by one '
-                             'projection and one lift per layer)'
-                             % (roof_insn, n_tiles, B, n_tiles, FWD_FLOP_PER_MOL)},
+                     'reference_association_tflops': round(
+                         FWD_FLOP_PER_MOL * (fm['subtiles'] / 2.0 if strip else n_tiles) / fwd_s / 1e12, 2),
+                     'note': ('achieved = frac * peak = flops_per_launch_executed / avg_launch_ms. '
+                              'flops_per_launch_executed = %s instructions the kernel issues for THIS '
+                              'batch\'s strip plan (lnz_plan_strips: %d molecules at 4-row granularity '
+                              'in %d strips = %d subtiles of 16 rows, at most %d per strip; the block '
+                              'products visit the subtile pairs some molecule touches, identity '
+                              'bond-type channels are skipped; utils/flop_model.py, checked against '
+                              'the PMC counter SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/); '
+                              'flops_per_launch_without_skips = every neighbouring subtile pair, no '
+                              'identity channel. useful_row_frac = real node rows / strip rows; '
+                              'useful_frac = frac x useful_row_frac. reference_association_tflops '
+                              'prices every 32 rows at SURVEY 8(d)\'s %d flop (filter build + L_s Z per '
+                              'long channel, which the kernel replaces by one projection and one lift '
+                              'per layer)' % (roof_insn, B, n_tiles, fm['subtiles'],
+                                              fm['max_subtiles_per_strip'], FWD_FLOP_PER_MOL))
+                             if strip else
+                             ('achieved = frac * peak = flops_per_launch_executed / avg_launch_ms. '
+                              'flops_per_launch_executed = %s '
+                              'instructions the kernel issues for THIS batch\'s tile plan (k-groups of '
+                              'padded rows / empty eigen slots and identity bond-type channels are '
+                              'skipped; utils/flop_model.py, checked against the PMC counter '
+                              'SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/); without the skips the same '
+                              '%d tiles would issue flops_per_launch_without_skips. useful_row_frac = '
+                              'real node rows / tile rows (%d molecules ride in %d 32-row tiles, '
+                              'lnz_plan_tiles); useful_frac = frac x useful_row_frac. '
+                              'reference_association_tflops prices the tiles at SURVEY 8(d)\'s %d flop '
+                              '(filter build + L_s Z per long channel, which the kernel replaces by one '
+                              'projection and one lift per layer)'
+                              % (roof_insn, n_tiles, B, n_tiles, FWD_FLOP_PER_MOL))},
     }
     if dist:
       out['config']['exchange'] = {

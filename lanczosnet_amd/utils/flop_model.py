@@ -29,6 +29,18 @@ of the workgroup) issues per tile, wave and layer
 
 plus the first layer's projection (waves whose 16 columns lie inside din0) and the head (one wave per
 tile, dhid / 2 instructions of the 32x32x2 kind).  It takes the launches `forward16_selected` says.
+
+`lanczosnet_strip_kernel` (csrc/conv_strip.hip: the inference forward on the strip plan of
+lnz_plan_strips — S subtiles of 16 rows per workgroup, molecules at 4-row granularity) issues per
+strip, wave and layer
+
+    GEMM1      (n_long + n_edge) * d_in / 16 * 4 * S
+    lift-back  4 * blocks                                    blocks = subtile pairs (I, J), |I - J| <= 1,
+    GEMM2      4 * sum_e blocks of subtiles not identity     that some molecule touches
+    projection 4 * blocks                                    (not the last layer)
+
+plus the first layer's projection (din0 / 16 waves) and the head (S waves, 64 instructions), all of
+the 16x16x4 kind.  It takes the launches `strips_selected` says.
 """
 import os
 
@@ -163,3 +175,79 @@ def forward16_mfma_issued(tiles, cfg):
               flops_issued=int(issued) * FLOP_PER_MFMA16, flops_unskipped=int(full) * FLOP_PER_MFMA16,
               mops_counts=int(issued) * (FLOP_PER_MFMA16 // FLOP_PER_MOPS_COUNT),
               useful_row_frac=rows_real / (32.0 * max(1, len(tiles))))
+
+
+STRIP_INTS = 80   # LNZ_STRIP_INTS
+
+
+def strips_selected(cfg, B, N):
+  """Mirror of lnz::strip_forward_eligible + the LNZ_STRIPS switch for launches that carry a strip
+  plan (every batch with B <= 2048, N <= 32: ops.strip_plan_wanted)."""
+  if os.environ.get('LNZ_STRIPS', '1') == '0' or not forward16_selected(cfg):
+    return False
+  return B <= 2048 and N <= 32
+
+
+def strips_from_plan(strips, ident=None):
+  """strips: the int32 array written by lnz_plan_strips ([cap * 80 + 1], last word = strips in use);
+  ident [B] = identity-channel bits of the edge channels or None.  Returns one dict per strip:
+  subtiles, blocks (number of subtile pairs some molecule touches), per-subtile block counts and
+  identity bits, real rows."""
+  p = np.asarray(strips)
+  cap = (p.size - 1) // STRIP_INTS
+  out = []
+  for s in range(int(p[cap * STRIP_INTS])):
+    e = p[s * STRIP_INTS:(s + 1) * STRIP_INTS]
+    nm, sub = int(e[0]), int(e[1])
+    owner = -np.ones(16 * sub, int)
+    idb = [0xffffffff if ident is not None else 0] * sub
+    rows_real = 0
+    for i in range(nm):
+      b, st, n = (int(x) for x in e[2 + 3 * i:5 + 3 * i])
+      rows = 4 if n <= 4 else (n + 3) // 4 * 4
+      owner[st:st + rows] = i
+      rows_real += n
+      if ident is not None:
+        for I in range(st // 16, (st + rows - 1) // 16 + 1):
+          idb[I] &= int(ident[b]) & 0xffffffff
+    blk = []
+    for I in range(sub):
+      mine = set(owner[16 * I:16 * I + 16]) - {-1}
+      blk.append(sum(1 for J in (I - 1, I, I + 1)
+                     if 0 <= J < sub and mine & (set(owner[16 * J:16 * J + 16]) - {-1})))
+    out.append(dict(sub=sub, blk=blk, ident=idb, rows_real=rows_real, mols=nm))
+  return out
+
+
+def strip_mfma_issued(strips, cfg):
+  """The record of forward_mfma_issued for lanczosnet_strip_kernel; `mfma_issued` counts
+  v_mfma_f32_16x16x4_f32 instructions (2048 flop)."""
+  n_long = len(cfg['long_diffusion_dist'])
+  n_edge = cfg['num_bond_type'] + 1
+  C = n_long + n_edge
+  din0, dhid, nl = cfg['input_dim'], cfg['hidden_dim'][0], cfg['num_layer']
+  din0 = (din0 + 63) // 64 * 64
+  emask = (1 << n_edge) - 1
+  issued = full = rows_real = rows_tile = 0
+  for t in strips:
+    S, blocks = t['sub'], sum(t['blk'])
+    g2 = sum(b * (n_edge - bin(i & emask).count('1')) for b, i in zip(t['blk'], t['ident']))
+    g2_full = n_edge * (3 * S - 2)
+    for l in range(nl):
+      d_in = din0 if l == 0 else dhid
+      proj = 1 if (n_long and l + 1 < nl) else 0
+      issued += 8 * (C * (d_in // 16) * 4 * S + 4 * blocks * ((1 if n_long else 0) + proj) + 4 * g2)
+      full += 8 * (C * (d_in // 16) * 4 * S + 4 * (3 * S - 2) * ((1 if n_long else 0) + proj) + 4 * g2_full)
+    if n_long:
+      issued += (din0 // 16) * 4 * blocks
+      full += (din0 // 16) * 4 * (3 * S - 2)
+    issued += S * 64
+    full += S * 64
+    rows_real += t['rows_real']
+    rows_tile += 16 * S
+  return dict(tiles=len(strips), mfma_issued=int(issued), mfma_unskipped=int(full),
+              flops_issued=int(issued) * FLOP_PER_MFMA16, flops_unskipped=int(full) * FLOP_PER_MFMA16,
+              mops_counts=int(issued) * (FLOP_PER_MFMA16 // FLOP_PER_MOPS_COUNT),
+              useful_row_frac=rows_real / float(max(1, rows_tile)),
+              subtiles=int(sum(t['sub'] for t in strips)),
+              max_subtiles_per_strip=int(max(t['sub'] for t in strips)))

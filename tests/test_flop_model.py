@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 from lanczosnet_amd.utils.flop_model import (forward16_mfma_issued, forward16_selected,
-                                             forward_mfma_issued, tiles_from_plan)
+                                             forward_mfma_issued, strip_mfma_issued, strips_from_plan,
+                                             strips_selected, tiles_from_plan)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 QM8_CFG = dict(num_atom=70, num_bond_type=6, short_diffusion_dist=[],
@@ -49,6 +50,34 @@ def test_issued_mfma_model_of_the_16x16_tile_kernel_agrees_with_the_pmc_counter(
   rec = forward16_mfma_issued([dict(t, pg16=int(g), ps16=int(p))
                                for t, g, p in zip(tiles, plan['pg16'], plan['ps16'])], QM8_CFG)
   assert rec['mfma_issued'] == fm['mfma_issued']
+
+
+def test_issued_mfma_model_of_the_strip_kernel_agrees_with_the_pmc_counter():
+  """lanczosnet_strip_kernel (the default inference forward of the bench batch since the strip
+  plan): profiles/r04_strip_pmc.json / r04_strip_plan.npz (the int32 strip plan and the identity
+  bits of the timed batch), same tool and command."""
+  pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r04_strip_pmc.json')))
+  assert pmc['kernel'].startswith('lanczosnet_strip_kernel')
+  rec = np.load(os.path.join(ROOT, 'profiles', 'r04_strip_plan.npz'))
+  strips = strips_from_plan(rec['strips'], rec['ident'])
+  fm = strip_mfma_issued(strips, QM8_CFG)
+  measured = pmc['SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch']
+  assert abs(fm['mops_counts'] - measured) <= 0.002 * measured, (fm['mops_counts'], measured)
+  assert fm['mfma_unskipped'] > fm['mfma_issued']
+  # 1024 QM8-sized molecules: at most five subtiles on a compute unit, one strip per unit
+  assert fm['max_subtiles_per_strip'] == 5 and fm['tiles'] <= 256
+  assert sum(t['mols'] for t in strips) == 1024
+  assert 0.85 < fm['useful_row_frac'] < 1.0
+
+
+def test_strip_selection_mirrors_the_launcher(monkeypatch):
+  monkeypatch.delenv('LNZ_FORWARD16', raising=False)
+  monkeypatch.delenv('LNZ_STRIPS', raising=False)
+  assert strips_selected(QM8_CFG, 1024, 26) and strips_selected(QM8_CFG, 2048, 32)
+  assert not strips_selected(QM8_CFG, 4096, 26) and not strips_selected(QM8_CFG, 64, 48)
+  assert not strips_selected(dict(QM8_CFG, short_diffusion_dist=[1]), 1024, 26)
+  monkeypatch.setenv('LNZ_STRIPS', '0')
+  assert not strips_selected(QM8_CFG, 1024, 26)
 
 
 def test_forward16_selection_mirrors_the_launcher(monkeypatch):

@@ -60,7 +60,7 @@ def main():
   os.makedirs(outdir, exist_ok=True)
   res = {c: run_pass(c, outdir, extra) for c in
          ('SQ_INSTS_VALU_MFMA_MOPS_F32', 'FETCH_SIZE', 'WRITE_SIZE')}
-  fwd = [k for k in res['SQ_INSTS_VALU_MFMA_MOPS_F32'] if k.startswith('lanczosnet_forward')]
+  fwd = [k for k in res['SQ_INSTS_VALU_MFMA_MOPS_F32'] if k.startswith('lanczosnet_forward') or k.startswith('lanczosnet_strip')]
   fwd = max(fwd, key=lambda k: res['SQ_INSTS_VALU_MFMA_MOPS_F32'][k]['launches'])
   mops = res['SQ_INSTS_VALU_MFMA_MOPS_F32'][fwd]
   fetch, write = res['FETCH_SIZE'][fwd], res['WRITE_SIZE'][fwd]
