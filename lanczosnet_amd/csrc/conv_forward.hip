@@ -1258,8 +1258,8 @@ namespace lnz {
 int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_forward_f16.hip
 bool forward16_eligible(const lnz_forward_args& a, int mode);         // conv_forward16.hip
 int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s);
-bool strip_forward_eligible(const lnz_forward_args& a);               // conv_strip.hip
-int launch_strip_forward(const lnz_forward_args& a, hipStream_t s);
+bool strip_forward_eligible(const lnz_forward_args& a, int mode);     // conv_strip.hip
+int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s);
 }
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
@@ -1326,8 +1326,9 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
-    if (forward16_enabled() && strips_enabled() && lnz::strip_forward_eligible(a))
-      return lnz::launch_strip_forward(a, s);
+    if (forward16_enabled() && strips_enabled() && (a.filter_kind == 0 || dense_es) &&
+        lnz::strip_forward_eligible(a, 0))
+      return lnz::launch_strip_forward(a, 0, s);
     if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 0))
       return lnz::launch_forward16(a, 0, s);
     if (getenv("LNZ_FORWARD16_VERBOSE"))
@@ -1345,6 +1346,9 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                   LNZ_EINVAL, "%s: need Wp (transposed packs), dy, dx0, din0 == dhid, bwd_din0", who);
       LNZ_REQUIRE(!a.dy_compact || (a.row_off && a.dy_compact_rows > 0), LNZ_EINVAL,
                   "%s: dy_compact needs row_off and dy_compact_rows", who);
+      if (forward16_enabled() && strips_enabled() && (a.filter_kind == 0 || dense_es) &&
+          lnz::strip_forward_eligible(a, 1))
+        return lnz::launch_strip_forward(a, 1, s);
       if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 1))
         return lnz::launch_forward16(a, 1, s);
     } else {

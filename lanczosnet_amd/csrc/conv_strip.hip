@@ -44,15 +44,20 @@ constexpr int strip_lds_floats(int S, int nl) {
   return 2 * S * 16 * P + S * 3 * 16 * VBP + 2 * nl * S * 16 + 3 * S * 16 + 3 * MAXMOL + 8;
 }
 
-template <int S>
+// MODE 0 = forward (a.act_out: the training forward's activation store); MODE 1 = the
+// input-gradient pass; FK 0 = diagonal gains, 2 = dense K x K filters; SHORT = short-diffusion
+// channels — all as in conv_forward16.hip.
+template <int S, int MODE, int FK, bool SHORT>
 __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restrict__ ent, float* lds,
                                               const int tid, const int wave) {
   constexpr int R = 16 * S;
+  constexpr bool FWD = MODE == 0;
+  constexpr bool DIAG = FK == 0;
   const int lane = tid & 63;
   const int j = lane & 15, kq = lane >> 4;
   const int N = a.N, K = a.K, B = a.B;
-  const int nl = a.n_long, ne = a.n_edge;
-  const int C = nl + ne;
+  const int ns = SHORT ? a.n_short : 0, nl = a.n_long, ne = a.n_edge;
+  const int C = ns + nl + ne;
   float* Xs = lds;                                   // [2][R][P]
   float* Vb = Xs + 2 * R * P;                        // [S node subtile][3 = slot subtile - node subtile + 1][16 node][VBP]
   float* Gs = Vb + S * 3 * 16 * VBP;                 // [2][nl][R]
@@ -71,7 +76,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     mstart[tid] = in ? ent[3 + 3 * tid] : 0;
     mext[tid] = in ? ent[4 + 3 * tid] : 0;
   }
-  if (tid < S) idI[tid] = a.ident ? -1 : 0;
+  if (tid < S) idI[tid] = (FWD && a.ident) ? -1 : 0;
   __syncthreads();
   if (tid < R) {
     int own = -1;
@@ -85,7 +90,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     if (own >= 0) {
       const int lrow = tid - mstart[own];
       ok = (lrow < N && a.mask[(int64_t)mid[own] * N + lrow] != 0) ? 1 : 0;
-      if (a.ident) atomicAnd(&idI[tid >> 4], (int)a.ident[mid[own]]);
+      if (FWD && a.ident) atomicAnd(&idI[tid >> 4], (int)a.ident[mid[own]]);
     }
     rowok[tid] = ok;
   }
@@ -98,7 +103,10 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       const int row = idx / d4, c4 = idx - row * d4;
       const int own = rowinfo[row];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (own >= 0) {
+      if (own >= 0 && !FWD) {  // the incoming gradient dY of the last conv layer
+        v = reinterpret_cast<const float4*>(
+            a.dy + (((int64_t)(a.num_layer - 1) * B + mid[own]) * 32 + (row - mstart[own])) * 128)[c4];
+      } else if (own >= 0) {
         const int mol = mid[own], lrow = row - mstart[own];
         if (lrow < N) {
           if (a.node_feat) {
@@ -136,13 +144,13 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   constexpr unsigned OOB = 0x80000000u;
   float greg[GREG];
   const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.G), 0, nl > 0 ? a.num_layer * B * nl * K * 4 : 0, 0x00020000);
+      const_cast<float*>(a.G), 0, nl > 0 ? a.num_layer * B * nl * K * (DIAG ? 1 : K) * 4 : 0, 0x00020000);
   unsigned goff[GREG];
 #pragma unroll
   for (int u = 0; u < GREG; ++u) {
     const int idx = tid + 512 * u;
     goff[u] = OOB;
-    if (idx < nl * R) {
+    if (DIAG && idx < nl * R) {
       const int sc = idx / R, rho = idx - sc * R;
       const int own = rowinfo[rho];
       if (own >= 0) {
@@ -165,15 +173,17 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       if (idx < nl * R) dst[idx] = greg[u];
     }
   };
-  if (nl > 0) {
-    load_gains(0);
-    store_gains(0);
+  if (DIAG && nl > 0) {
+    load_gains(FWD ? 0 : a.num_layer - 1);
+    store_gains(FWD ? 0 : a.num_layer - 1);
   }
 
   // ---- per-lane addressing of the packed Laplacian and the block masks
   const int rt = wave >> 1;
   const int wlane = 64 * (kq >> 1) + 32 * (kq & 1) + 16 * (wave & 1) + j;  // float4 within a 16-k step
   unsigned loff[S][3];  // byte offset of fragment (I, J = I + d - 1) of edge type 0, or OOB
+  unsigned doff[DIAG ? 1 : S][3];  // FK 2: fragment (I, J) of a dense filter: slot row 16 I + j is
+                                   // slot kr of its molecule, the 4-column group molecule-local
   int blk[S];           // bit d: some molecule has rows in subtile I and in subtile I + d - 1
   const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.Lp), 0, B * ne * 4096, 0x00020000);
@@ -195,6 +205,11 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         ok = own >= 0 && rowinfo[cg] == own;
         const int c = cg - st;
         if (ok) off = (unsigned)((mol * ne * 256 + (c >> 3) * 64 + ((c >> 2) & 1) * 32 + (row - st)) * 16);
+        if (!DIAG)
+          doff[DIAG ? 0 : I][d] = (ok && row - st < K && c < K)
+                                      ? (unsigned)((((mol * nl) * K + (row - st)) * K + c) * 4) : OOB;
+      } else if (!DIAG) {
+        doff[DIAG ? 0 : I][d] = OOB;
       }
       loff[I][d] = off;
       bits |= (__ballot(ok) != 0ull) ? (1 << d) : 0;
@@ -208,25 +223,32 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   int cur = 0;
   for (int l = 0; l < a.num_layer; ++l) {
     const bool more = l + 1 < a.num_layer;
+    const int la = FWD ? l : a.num_layer - 1 - l;  // conv layer of this iteration
+    const int lg = FWD ? l + 1 : la - 1;            // layer whose gains are staged under it
     const int din = l == 0 ? a.din0 : 128;
     const int Q = din >> 3, Q16 = din >> 4;
     const int Gtot = C * Q;
     const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[l]);
-    const float* gsl = Gs + (l & 1) * nl * R;
+    const float* gsl = Gs + (la & 1) * nl * R;
     const int nxt = cur ^ 1;
+    // width this iteration produces: waves beyond it only keep the barriers
+    const int wout = FWD ? 128 : (la == 0 ? a.bwd_din0 : 128);
+    const bool active = FWD || 16 * wave < wout;
 
     // weight stream of this wave: contiguous over the layer's channels, 128 float4 per 16-k step,
     // 4-slot register ring (prefetch distance 3 steps = 12 S MFMAs)
     const float4* __restrict__ wp = Wl + (int64_t)rt * Gtot * 64 + wlane;
     float4 ring[4];
+    if (active) {
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+      for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+    }
     // (behind the ring prime: vector loads return in order, the first steps must not wait for G)
-    if (nl > 0 && more) load_gains(l + 1);
+    if (DIAG && nl > 0 && more) load_gains(lg);
 
     f32x4 out[S];
     {
-      const float bv = (a.bias + a.b_off[l])[16 * wave + j];
+      const float bv = FWD ? (a.bias + a.b_off[l])[16 * wave + j] : 0.0f;
 #pragma unroll
       for (int I = 0; I < S; ++I) out[I] = splat4(bv);
     }
@@ -314,19 +336,87 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       steps4(xb, x0, std::true_type{});
     };
 
-    // ---------------- eigen-space block: out += V [ sum_s diag(g_s) (Y W_s^T) ] ----------------
-    if (nl > 0) {
+    // Laplacian fragments of one edge type for every block (I, J): they land under the last four
+    // steps of the channel's own GEMM1 (identity channels of a subtile: offsets beyond the buffer,
+    // no memory traffic).  The same registers hold a dense filter's fragments in the long block.
+    f32x4 mop[S][3];
+    auto fetch = [&](int e, bool use_ident) {
+#pragma unroll
+      for (int I = 0; I < S; ++I) {
+        const unsigned skip = (use_ident && ((idm[I] >> e) & 1)) ? OOB : 0u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (I + d - 1 < 0 || I + d - 1 >= S) continue;
+          mop[I][d] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[I][d] | skip, e * 4096, 0));
+        }
+      }
+    };
+    // acc[I] += M[I][J] Zp[J] over the blocks of subtile I
+    auto apply_m = [&](f32x4 (&acc)[S], const f32x4 (&Zp)[S], int I) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int J = I + d - 1;
+        if (J < 0 || J >= S) continue;
+        if ((blk[I] >> d) & 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[I] = mfma16(mop[I][d][r], Zp[J][r], acc[I]);
+        }
+      }
+    };
+
+    // ---------------- short-diffusion channels: out += L_0^p (X W_c^T) ----------------
+    if (SHORT && active) {
+      const lds_cptr x0 = xlane + cur * R * P;
+      load_first(x0);
+      for (int c = 0; c < ns; ++c) {
+        gemm1(x0, [&] { fetch(0, false); });
+        const int p = a.short_dist[c];
+        for (int rep = 1; rep < p; ++rep) {
+          f32x4 Zn[S];
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            Zn[I] = splat4(0.f);
+            apply_m(Zn, Z, I);
+          }
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = Zn[I];
+        }
+#pragma unroll
+        for (int I = 0; I < S; ++I) apply_m(out, Z, I);
+      }
+    }
+
+    // ---------------- eigen-space block: out += V [ sum_s F_s (Y W_s^T) ] ----------------
+    //   F_s = diag(g_s) (FK 0) or the dense filter DD_s (FK 2)
+    if (nl > 0 && active) {
       const lds_cptr y0 = xlane + nxt * R * P;
       load_first(y0);
       f32x4 T[S];
 #pragma unroll
       for (int I = 0; I < S; ++I) T[I] = splat4(0.f);
       for (int s = 0; s < nl; ++s) {
-        gemm1(y0, [] {});
+        if constexpr (DIAG) {
+          gemm1(y0, [] {});
 #pragma unroll
-        for (int I = 0; I < S; ++I) {
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(gsl + s * R + 16 * I + 4 * kq);
-          T[I] += gv * Z[I];
+          for (int I = 0; I < S; ++I) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gsl + s * R + 16 * I + 4 * kq);
+            T[I] += gv * Z[I];
+          }
+        } else {
+          gemm1(y0, [&] {
+#pragma unroll
+            for (int I = 0; I < S; ++I)
+#pragma unroll
+              for (int d = 0; d < 3; ++d) {
+                if (I + d - 1 < 0 || I + d - 1 >= S) continue;
+                mop[I][d] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                               g_rsrc, doff[DIAG ? 0 : I][d], (la * B * nl + s) * K * K * 4, 0));
+              }
+          });
+#pragma unroll
+          for (int I = 0; I < S; ++I) apply_m(T, Z, I);
         }
       }
       // lift back: out[I] (node rows) += V[I][J] T[J] over the slot subtiles J the block mask names
@@ -346,57 +436,62 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     }
 
     // ---------------- node-space block: out += M_e (X W_e^T) per edge type ----------------
-    {
+    if (active) {
       const lds_cptr x0 = xlane + cur * R * P;
       load_first(x0);
       for (int e = 0; e < ne; ++e) {
-        // the channel's Laplacian fragments land under the last four steps of its own GEMM1
-        // (identity channels of a subtile: offsets beyond the buffer, no memory traffic)
-        f32x4 mop[S][3];
-        gemm1(x0, [&] {
-#pragma unroll
-          for (int I = 0; I < S; ++I) {
-            const unsigned skip = ((idm[I] >> e) & 1) ? OOB : 0u;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              if (I + d - 1 < 0 || I + d - 1 >= S) continue;
-              mop[I][d] = __builtin_bit_cast(
-                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[I][d] | skip, e * 4096, 0));
-            }
-          }
-        });
+        gemm1(x0, [&] { fetch(e, true); });
 #pragma unroll
         for (int I = 0; I < S; ++I) {
-          if ((idm[I] >> e) & 1) {  // identity on every molecule of the subtile: out += Z
-            out[I] += Z[I];
-            continue;
-          }
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int J = I + d - 1;
-            if (J < 0 || J >= S) continue;
-            if ((blk[I] >> d) & 1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) out[I] = mfma16(mop[I][d][r], Z[J][r], out[I]);
-            }
-          }
+          if ((idm[I] >> e) & 1) out[I] += Z[I];  // identity on every molecule of the subtile
+          else apply_m(out, Z, I);
         }
       }
     }
 
-    // ---------------- epilogue: X' = relu(out) where Y was, Y' = V^T X' where X was ----------
-    if (nl > 0 && more) store_gains(l + 1);  // (buffer last read in layer l - 1)
+    // ---------------- epilogue: X' where Y was, Y' = V^T X' where X was ----------
+    //   forward: X' = relu(out) (+ the activation store training asks for)
+    //   MODE 1:  dY_{la-1} = out * [X_la > 0] -> LDS and dy[la-1]; the last iteration writes dX_0
+    if (DIAG && nl > 0 && more) store_gains(lg);  // (buffer last read two iterations ago)
     if (nl > 0) __syncthreads();  // every wave is through with X and Y
-    {
+    if (active) {
       const int col = 16 * wave + j;
 #pragma unroll
       for (int I = 0; I < S; ++I) {
+        // rows 16 I + 4 kq + r: one owner (molecules start on multiples of 4).  The row map is
+        // re-read per layer: addresses kept across the layer loop would hold registers under the GEMMs
+        const int row0 = 16 * I + 4 * kq;
+        int own = rowinfo[row0];
+        asm volatile("" : "+v"(own));
+        const int mol = own >= 0 ? mid[own] : 0;
+        const int lrow0 = own >= 0 ? row0 - mstart[own] : 0;
+        const int64_t rowbase = (int64_t)mol * 32 + lrow0;
+        f32x4 v = out[I];
+        if (FWD) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = fmaxf(out[I][r], 0.0f);
-          out[I][r] = v;
-          Xs[nxt * R * P + (16 * I + 4 * kq + r) * P + col] = v;
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+          if (a.act_out && own >= 0) {
+            float* p = a.act_out + ((int64_t)l * B * 32 + rowbase) * 128 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r * 128] = v[r];
+          }
+        } else if (la > 0) {
+          const int64_t at = ((int64_t)(la - 1) * B * 32 + rowbase) * 128 + col;
+          const float* xa = a.act + at;
+          float* dyp = a.dy + at;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = (own >= 0 && xa[r * 128] > 0.0f) ? v[r] : 0.0f;
+            if (own >= 0) dyp[r * 128] = v[r];
+          }
+        } else if (own >= 0) {
+          float* p = a.dx0 + rowbase * a.bwd_din0 + col;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r * a.bwd_din0] = v[r];
         }
+        out[I] = v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[nxt * R * P + (row0 + r) * P + col] = v[r];
       }
       if (nl > 0 && more) {
 #pragma unroll
@@ -416,11 +511,41 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
           for (int r = 0; r < 4; ++r) Xs[cur * R * P + (16 * I + 4 * kq + r) * P + col] = Y[r];
         }
       }
+      if (MODE == 1 && la > 0 && (a.dy_compact || a.dbias_part)) {
+        // What the weight / bias gradients of conv layer la - 1 need: dY_{la-1} in the COMPACT row
+        // numbering of the message matrix (real nodes only) and this strip's column sums (rows of
+        // padded nodes and unowned rows are zero) — one writer per (strip, layer, column): entry
+        // blockIdx.x of dbias_part (zero-initialised, summed over all entries by the consumer).
+        float colsum = 0.0f;
+#pragma unroll
+        for (int I = 0; I < S; ++I) {
+          const int row0 = 16 * I + 4 * kq;
+          int own = rowinfo[row0];
+          asm volatile("" : "+v"(own));
+          const f32x4 v = out[I];
+          colsum += (v[0] + v[1]) + (v[2] + v[3]);
+          if (a.dy_compact && own >= 0) {
+            const int lrow0 = row0 - mstart[own], nmol = mext[own];
+            float* dc = a.dy_compact +
+                        ((int64_t)(la - 1) * a.dy_compact_rows + a.row_off[mid[own]] + lrow0) * 128 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (lrow0 + r < nmol) dc[r * 128] = v[r];
+          }
+        }
+        if (a.dbias_part && (int)blockIdx.x < 2 * a.plan_wg_cap) {
+          colsum += __shfl_xor(colsum, 16, 64);
+          colsum += __shfl_xor(colsum, 32, 64);
+          if (kq == 0)
+            a.dbias_part[((int64_t)blockIdx.x * a.num_layer + (la - 1)) * 128 + col] = colsum;
+        }
+      }
     }
     __syncthreads();
     cur = nxt;
   }
   __builtin_amdgcn_s_setprio(0);
+  if (!FWD) return;
 
   // ---- optional debug/test output of the final node state
   if (a.state_out) {
@@ -481,6 +606,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
 }
 
 // One workgroup = 8 waves on one strip of the plan.
+template <int MODE, int FK, bool SHORT>
 __global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) float lds_strip[];
@@ -490,12 +616,12 @@ __global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward
   const int32_t* ent = a.strips + (int64_t)blockIdx.x * LNZ_STRIP_INTS;
   const int sub = __builtin_amdgcn_readfirstlane(ent[1]);
   switch (sub) {
-    case 1: strip_forward<1>(a, ent, lds_strip, tid, wave); break;
-    case 2: strip_forward<2>(a, ent, lds_strip, tid, wave); break;
-    case 3: strip_forward<3>(a, ent, lds_strip, tid, wave); break;
-    case 4: strip_forward<4>(a, ent, lds_strip, tid, wave); break;
-    case 5: strip_forward<5>(a, ent, lds_strip, tid, wave); break;
-    case 6: strip_forward<6>(a, ent, lds_strip, tid, wave); break;
+    case 1: strip_forward<1, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 2: strip_forward<2, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 3: strip_forward<3, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 4: strip_forward<4, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 5: strip_forward<5, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 6: strip_forward<6, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
     default: break;
   }
 }
@@ -504,27 +630,40 @@ __global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward
 
 namespace lnz {
 
-// The inference forward of a diagonal-gain model without short-diffusion channels, on strips.
-bool strip_forward_eligible(const lnz_forward_args& a) {
+// The forward (mode 0, with or without the activation store) and the input-gradient pass (mode 1)
+// of a width-128 model on strips: diagonal gains or dense filters in eigen space.
+bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
+  if (mode != 0 && mode != 1) return false;
   if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
-  if (a.gemm_mode != 0 || a.filter_kind != 0 || a.act_out || a.n_short != 0) return false;
+  if (a.gemm_mode != 0 || (a.filter_kind != 0 && a.filter_kind != 1)) return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
-  if (a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12 || a.dout > 31) return false;
+  if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
+  if (a.n_short + a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12 || a.dout > 31) return false;
+  if (a.filter_kind == 1 && a.K % 4 != 0) return false;
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
-  if ((int64_t)a.num_layer * a.B * a.n_long * a.K * 4 >= (1ll << 31)) return false;
+  const int64_t per_slot = a.filter_kind == 1 ? (int64_t)a.K * a.K : a.K;
+  if ((int64_t)a.num_layer * a.B * a.n_long * per_slot * 4 >= (1ll << 31)) return false;
   return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float) <= 160 * 1024;
 }
 
-int launch_strip_forward(const lnz_forward_args& a, hipStream_t s) {
+int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
   const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lanczosnet_strip_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+  const void* fns[8] = {
+      (const void*)lanczosnet_strip_kernel<0, 0, false>, (const void*)lanczosnet_strip_kernel<1, 0, false>,
+      (const void*)lanczosnet_strip_kernel<0, 2, false>, (const void*)lanczosnet_strip_kernel<1, 2, false>,
+      (const void*)lanczosnet_strip_kernel<0, 0, true>,  (const void*)lanczosnet_strip_kernel<1, 0, true>,
+      (const void*)lanczosnet_strip_kernel<0, 2, true>,  (const void*)lanczosnet_strip_kernel<1, 2, true>};
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
+  const void* fn = fns[which];
+  if (!attr_set[which]) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[which] = true;
   }
-  hipLaunchKernelGGL(lanczosnet_strip_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
-  return check_launch("lnz_lanczosnet_forward (strips)");
+  lnz_forward_args args = a;
+  void* params[] = {&args};
+  (void)hipLaunchKernel(fn, dim3(a.strip_cap), dim3(512), params, bytes, s);
+  return check_launch(mode == 0 ? "lnz_lanczosnet_forward (strips)" : "lnz_lanczosnet_input_grad (strips)");
 }
 
 }  // namespace lnz

@@ -366,16 +366,17 @@ def test_ada_dense_filter_conv_matches_oracle_given_TQ():
     Lp = ops.pack_laplacian(_t(c['L'][:nb]))
     score = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(Q), DDp,
                                    _t(c['node_mask'][:nb])).cpu().numpy()
-    # the eigen-space dense-filter kernel takes pair tiles; one molecule per tile is the same sum
-    # per molecule in the same order: bit-identical
+    # the default launch runs on the strip plan (molecules at 4-row granularity); 'single' and
+    # 'none' carry no strip plan and run one molecule per 32-row tile — the same sums in another
+    # association: equal to the parity tolerance, and to each other bit for bit
     assert ops.pairing_supported(plan)
     single = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(Q), DDp,
                                     _t(c['node_mask'][:nb]), tiling='single').cpu().numpy()
     unplanned = ops.lanczosnet_forward(plan, _t(c['node_feat'][:nb]), Lp, _t(Q), DDp,
                                        _t(c['node_mask'][:nb]), tiling='none').cpu().numpy()
   assert rel_err(score, ref) < 1e-5
-  np.testing.assert_array_equal(single, score)
-  np.testing.assert_array_equal(unplanned, score)
+  assert np.abs(single - score).max() <= 2e-6 * np.abs(score).max()
+  np.testing.assert_array_equal(unplanned, single)
 
 
 @pytest.mark.parametrize('tiles16', ['1', '0'])
