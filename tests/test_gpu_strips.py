@@ -112,8 +112,9 @@ def test_bench_batch_fits_five_subtiles_per_compute_unit():
     assert len(plan) <= 256 and max(s for _, s in plan) == 5
 
 
-@pytest.mark.parametrize('B,n_cu', [(1024, 256), (96, 7), (33, 256)])
-def test_strip_forward_matches_the_tile_kernels_and_the_oracle(B, n_cu, monkeypatch):
+@pytest.mark.parametrize('B,n_cu,nmin,nmax', [(1024, 256, 2, 26), (96, 7, 2, 26), (33, 256, 2, 26),
+                                              (64, 256, 1, 32), (1, 256, 5, 5), (700, 16, 27, 32)])
+def test_strip_forward_matches_the_tile_kernels_and_the_oracle(B, n_cu, nmin, nmax, monkeypatch):
   from lanczosnet_amd import ops
   from lanczosnet_amd.model import LanczosNet
   from lanczosnet_amd.synthetic import draw_batch
@@ -123,7 +124,7 @@ def test_strip_forward_matches_the_tile_kernels_and_the_oracle(B, n_cu, monkeypa
   net = LanczosNet(make_model_config(cfg)).eval()
   net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
   net = net.to(DEV)
-  b = draw_batch(B, seed=11, n_min=2, n_max=26)
+  b = draw_batch(B, seed=11, n_min=nmin, n_max=nmax)
   t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
   n = t(b['n_nodes'])
   L = ops.laplacian_l4(t(b['adjs']), n)
