@@ -36,7 +36,7 @@ extern "C" {
 #define LNZ_TILE 32       /* node tile: one v_mfma_f32_32x32x2_f32 tile per molecule */
 #define LNZ_MAX_CHANNELS 32
 /* strip plan (lnz_plan_strips): subtiles of 16 node rows per strip, int32 words per strip entry,
- * largest batch the planner takes */
+ * molecules the planner packs together (larger batches: chunk by chunk) */
 #define LNZ_STRIP_SUB 6
 #define LNZ_STRIP_INTS 80
 #define LNZ_STRIP_MAX_B 2048
@@ -423,7 +423,8 @@ int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
  * tiles of lnz_plan_tiles a QM8-sized batch needs 21 % fewer rows.
  * strips: [lnz_strip_cap(B) * LNZ_STRIP_INTS] int32 — words 0, 1 of an entry = molecules and
  * subtiles of the strip, words 2 + 3 i + {0,1,2} = (molecule, first row, node extent) of its i-th
- * molecule; n_strips [1] int32 (device): strips in use.  B <= LNZ_STRIP_MAX_B, N <= 32.
+ * molecule; n_strips [1] int32 (device): strips in use.  N <= 32; batches beyond
+ * LNZ_STRIP_MAX_B molecules are planned in chunks of that many (consecutive strip ranges).
  * The strips / n_strips arguments of lnz_plan_batch, lnz_prepare_batch[_prev_gains] and
  * lnz_pack_laplacian_plan (may be NULL) make the same plan inside those launches. */
 int lnz_strip_cap(int B);

@@ -833,8 +833,7 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
   size_t lds = (size_t)N * N * C * sizeof(float);
   LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
-  LNZ_REQUIRE(!strips || (n_strips && B <= LNZ_STRIP_MAX_B), LNZ_EINVAL,
-              "lnz_prepare_batch: strips need n_strips and B <= %d", LNZ_STRIP_MAX_B);
+  LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_prepare_batch: strips need n_strips");
   if (lds <= (size_t)kPrepLds)
     hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(2 * B + 1), dim3(256), 0,
                        (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
@@ -878,7 +877,7 @@ extern "C" int lnz_prepare_batch_prev_gains(
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, dist, S, num_layer, mlp_pack, G_prev,
                      ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev,
-                     (strips && n_strips && B <= LNZ_STRIP_MAX_B) ? strips : nullptr, n_strips);
+                     (strips && n_strips) ? strips : nullptr, n_strips);
   return lnz::check_launch("lnz_prepare_batch_prev_gains");
 }
 

@@ -268,8 +268,7 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
   size_t lds = (size_t)N * N * C * sizeof(float);
   LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_pack_laplacian_plan: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
-  LNZ_REQUIRE(!strips || (n_strips && B <= LNZ_STRIP_MAX_B), LNZ_EINVAL,
-              "lnz_pack_laplacian_plan: strips need n_strips and B <= %d", LNZ_STRIP_MAX_B);
+  LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_pack_laplacian_plan: strips need n_strips");
   hipLaunchKernelGGL(pack_plan_kernel, dim3(B + 1), dim3(1024), lds, (hipStream_t)stream, L,
                      stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
@@ -290,22 +289,24 @@ extern "C" int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int a
               "lnz_plan_batch: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
   LNZ_REQUIRE(!gain_rows || (n_gain_rows && K > 0), LNZ_EINVAL,
               "lnz_plan_batch: gain_rows needs n_gain_rows and K > 0");
-  LNZ_REQUIRE(!strips || (n_strips && B <= LNZ_STRIP_MAX_B), LNZ_EINVAL,
-              "lnz_plan_batch: strips need n_strips and B <= %d", LNZ_STRIP_MAX_B);
+  LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_plan_batch: strips need n_strips");
   hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
                      n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows,
                      n_gain_rows, strips, n_strips);
   return lnz::check_launch("lnz_plan_batch");
 }
 
-extern "C" int lnz_strip_cap(int B) { return B <= 0 ? 0 : (B < kStripBins ? B : kStripBins); }
+extern "C" int lnz_strip_cap(int B) {  // every chunk of LNZ_STRIP_MAX_B molecules: <= kStripBins strips
+  if (B <= 0) return 0;
+  const int full = B / LNZ_STRIP_MAX_B, rest = B - full * LNZ_STRIP_MAX_B;
+  return full * kStripBins + (rest < kStripBins ? rest : kStripBins);
+}
 
 extern "C" int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips,
                                int32_t* n_strips, lnz_stream_t stream) {
   LNZ_REQUIRE(mask && strips && n_strips && B > 0 && N > 0 && n_cu > 0, LNZ_EINVAL,
               "lnz_plan_strips: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
-  LNZ_REQUIRE(N <= LNZ_TILE && B <= LNZ_STRIP_MAX_B, LNZ_ENOTSUP,
-              "lnz_plan_strips: built for N <= %d, B <= %d (N=%d B=%d)", LNZ_TILE, LNZ_STRIP_MAX_B, N, B);
+  LNZ_REQUIRE(N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_plan_strips: built for N <= %d (N=%d)", LNZ_TILE, N);
   hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
                      n_cu, 0, 0, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
                      (int32_t*)nullptr, strips, n_strips);

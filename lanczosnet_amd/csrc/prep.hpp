@@ -226,9 +226,10 @@ __device__ __forceinline__ int strip_place(int fill, int rows) {  // first row o
   return ((fill & 15) + rows <= 32) ? fill : ((fill + 15) & ~15);
 }
 
-__device__ __forceinline__ void plan_strips_body(const uint8_t* __restrict__ mask, int B, int N,
-                                                 int n_cu, int32_t* __restrict__ strips,
-                                                 int32_t* __restrict__ n_strips,
+// One chunk of up to LNZ_STRIP_MAX_B molecules (mask rows of the chunk, molecule ids offset by
+// mol0); returns the number of strips written at `strips`.
+__device__ __forceinline__ int plan_strips_chunk(const uint8_t* __restrict__ mask, int B, int N,
+                                                 int n_cu, int mol0, int32_t* __restrict__ strips,
                                                  unsigned char* scratch) {
   const int NT = blockDim.x, tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
   uint8_t* ext = scratch;                                        // [B] node extent
@@ -372,9 +373,26 @@ __device__ __forceinline__ void plan_strips_body(const uint8_t* __restrict__ mas
   }
   for (int b = tid; b < B; b += NT) {
     int32_t* e = strips + (int64_t)pbin[b] * LNZ_STRIP_INTS + 2 + 3 * pslot[b];
-    e[0] = b;
+    e[0] = mol0 + b;
     e[1] = poff[b];
     e[2] = ext[b];
   }
-  if (tid == 0) *n_strips = used;
+  __syncthreads();  // (the scratch block is reused by the next chunk)
+  return used;
+}
+
+// Batches beyond LNZ_STRIP_MAX_B molecules are planned chunk by chunk (the planner's working set
+// lives in one workgroup's LDS); every chunk's strips are as high as ITS rows need for a whole
+// number of rounds over the CUs, which for full chunks of QM8-sized molecules is the same height.
+__device__ __forceinline__ void plan_strips_body(const uint8_t* __restrict__ mask, int B, int N,
+                                                 int n_cu, int32_t* __restrict__ strips,
+                                                 int32_t* __restrict__ n_strips,
+                                                 unsigned char* scratch) {
+  int total = 0;
+  for (int c0 = 0; c0 < B; c0 += LNZ_STRIP_MAX_B) {
+    const int nb = B - c0 < LNZ_STRIP_MAX_B ? B - c0 : LNZ_STRIP_MAX_B;
+    total += plan_strips_chunk(mask + (int64_t)c0 * N, nb, N, n_cu, c0,
+                               strips + (int64_t)total * LNZ_STRIP_INTS, scratch);
+  }
+  if (threadIdx.x == 0) *n_strips = total;
 }

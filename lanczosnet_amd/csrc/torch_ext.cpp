@@ -224,7 +224,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> prepare_batch(const Tensor& L
   auto iopt = n_nodes.options();
   Tensor Lp = at::empty({B, C, 4, 64, 4}, L.options());
   Tensor ident = at::empty({B}, iopt);
-  const int scap = B <= LNZ_STRIP_MAX_B ? lnz_strip_cap(B) : 0;
+  const int scap = lnz_strip_cap(B);
   const int64_t soff = 12 * (int64_t)cap + 2 + (int64_t)B * K;
   Tensor plan = at::empty({soff + (scap ? (int64_t)scap * LNZ_STRIP_INTS + 1 : 0)}, iopt);
   Tensor D = at::empty({B, K}, L.options());

@@ -737,12 +737,12 @@ def _set_plan(ops_, dims, tiles, cap):
     dims[_DIM['strip_cap']] = scap
 
 
-STRIP_INTS, STRIP_MAX_B = 80, 2048   # LNZ_STRIP_INTS, LNZ_STRIP_MAX_B
+STRIP_INTS = 80   # LNZ_STRIP_INTS
 
 
 def strip_plan_wanted(B, N):
   """The strip plan (lnz_plan_strips) is made next to the tile plan for every batch it takes."""
-  return B <= STRIP_MAX_B and N <= 32
+  return N <= 32
 
 
 def _strip_buf(B, device):

@@ -182,10 +182,10 @@ STRIP_INTS = 80   # LNZ_STRIP_INTS
 
 def strips_selected(cfg, B, N):
   """Mirror of lnz::strip_forward_eligible + the LNZ_STRIPS switch for launches that carry a strip
-  plan (every batch with B <= 2048, N <= 32: ops.strip_plan_wanted)."""
+  plan (every batch with N <= 32: ops.strip_plan_wanted)."""
   if os.environ.get('LNZ_STRIPS', '1') == '0' or not forward16_selected(cfg):
     return False
-  return B <= 2048 and N <= 32
+  return N <= 32
 
 
 def strips_from_plan(strips, ident=None):

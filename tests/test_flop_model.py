@@ -74,7 +74,7 @@ def test_strip_selection_mirrors_the_launcher(monkeypatch):
   monkeypatch.delenv('LNZ_FORWARD16', raising=False)
   monkeypatch.delenv('LNZ_STRIPS', raising=False)
   assert strips_selected(QM8_CFG, 1024, 26) and strips_selected(QM8_CFG, 2048, 32)
-  assert not strips_selected(QM8_CFG, 4096, 26) and not strips_selected(QM8_CFG, 64, 48)
+  assert strips_selected(QM8_CFG, 16384, 26) and not strips_selected(QM8_CFG, 64, 48)
   assert not strips_selected(dict(QM8_CFG, short_diffusion_dist=[1]), 1024, 26)
   monkeypatch.setenv('LNZ_STRIPS', '0')
   assert not strips_selected(QM8_CFG, 1024, 26)

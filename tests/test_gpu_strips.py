@@ -18,7 +18,16 @@ def _place(fill, rows):
   return fill if (fill % 16) + rows <= 32 else (fill + 15) // 16 * 16
 
 
-def plan_strips_mirror(ext, n_cu, bins=1024):
+def plan_strips_mirror(ext, n_cu, chunk=2048):
+  """Batches beyond 2048 molecules: chunk by chunk, consecutive strip ranges."""
+  out = []
+  for c0 in range(0, len(ext), chunk):
+    for mols, sub in _plan_chunk_mirror(ext[c0:c0 + chunk], n_cu):
+      out.append(([(b + c0, st, n) for b, st, n in mols], sub))
+  return out
+
+
+def _plan_chunk_mirror(ext, n_cu, bins=1024):
   """First fit decreasing by size class (rows / 4), a class at a time, stable in batch order; strip
   height = the smallest number of subtiles (2..6) for which the strips in use fit the rounds of
   n_cu strips the batch needs at full height."""
@@ -78,6 +87,7 @@ def _check_plan(buf, ext, n_cu):
 
 
 @pytest.mark.parametrize('B,nmin,nmax,n_cu', [(1024, 8, 26, 256), (1024, 1, 32, 256), (2048, 3, 26, 256),
+                                              (5000, 8, 26, 256),
                                               (5, 1, 9, 256), (300, 20, 32, 64), (777, 1, 6, 3)])
 def test_strip_plan_invariants_and_packing_rule(B, nmin, nmax, n_cu):
   from lanczosnet_amd import ops
@@ -112,7 +122,7 @@ def test_bench_batch_fits_five_subtiles_per_compute_unit():
     assert len(plan) <= 256 and max(s for _, s in plan) == 5
 
 
-@pytest.mark.parametrize('B,n_cu,nmin,nmax', [(1024, 256, 2, 26), (96, 7, 2, 26), (33, 256, 2, 26),
+@pytest.mark.parametrize('B,n_cu,nmin,nmax', [(1024, 256, 2, 26), (96, 7, 2, 26), (33, 256, 2, 26), (4100, 256, 8, 26),
                                               (64, 256, 1, 32), (1, 256, 5, 5), (700, 16, 27, 32)])
 def test_strip_forward_matches_the_tile_kernels_and_the_oracle(B, n_cu, nmin, nmax, monkeypatch):
   from lanczosnet_amd import ops
