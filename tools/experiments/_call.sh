@@ -1,4 +1,13 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_strips.py -m gpu -x -q 2>&1 | tail -8
-for B in 4096 16384; do for v in 0 1; do PROBE_B=$B LNZ_STRIPS=$v timeout 300 python tools/experiments/forward_ab.py 2>&1 | tail -1 | sed "s/^/B=$B strips=$v /"; done; done
+bash tools/profile_round.sh r04b > /dev/null 2>&1
+ls gpurun_out/prof_r04b | head -20
+cd $GRAFT_REPO_ROOT
+timeout 900 python bench.py > gpurun_out/prof_r04b/final_bench.json 2> gpurun_out/prof_r04b/final_bench.err
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/prof_r04b/final_bench.json').read().strip().splitlines()[-1])
+r=d['roofline']
+print(d['value'], d['ms_per_step'], r['kernel'], r['frac'], r['avg_launch_ms'], d['config']['stage_ms'], d.get('parity_rel_err'))
+print({k:(v.get('ms_per_step') if isinstance(v,dict) else None) for k,v in d['config'].items() if isinstance(v,dict)})
+PY
