@@ -44,6 +44,7 @@ constexpr int strip_lds_floats(int S, int nl) {
   return 2 * S * 16 * P + S * 3 * 16 * VBP + 2 * nl * S * 16 + 3 * S * 16 + 3 * MAXMOL + 8;
 }
 
+
 // MODE 0 = forward (a.act_out: the training forward's activation store); MODE 1 = the
 // input-gradient pass; FK 0 = diagonal gains, 2 = dense K x K filters; SHORT = short-diffusion
 // channels — all as in conv_forward16.hip.
@@ -53,6 +54,12 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   constexpr int R = 16 * S;
   constexpr bool FWD = MODE == 0;
   constexpr bool DIAG = FK == 0;
+#ifdef LNZ_STRIP_PHASES  // per-wave clock64 stamps of the phases (tools/phase_probe16.py)
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_all = clock64(), _t0 = t_all;
+#define LNZ_PH(i) { const long long _t1 = clock64(); ph[i] += _t1 - _t0; _t0 = _t1; }
+#else
+#define LNZ_PH(i)
+#endif
   const int lane = tid & 63;
   const int j = lane & 15, kq = lane >> 4;
   const int N = a.N, K = a.K, B = a.B;
@@ -219,6 +226,8 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   }
   __syncthreads();
 
+  int chan_total = 0;
+  LNZ_PH(0)  // prologue
   const lds_cptr xlane = (lds_cptr)(Xs + j * P + 4 * kq);  // this lane's A row of subtile 0
   int cur = 0;
   for (int l = 0; l < a.num_layer; ++l) {
@@ -280,6 +289,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       __syncthreads();
     }
 
+    LNZ_PH(1)  // layer head: ring prime, gains loads, first-layer projection
     // ---------------- GEMM1 of one channel: Z[I] = A rows (X or Y) x W_c^T ----------------
     f32x4 Z[S], acur[S];
     auto load_first = [&](lds_cptr x0) {
@@ -318,12 +328,14 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       }
       wp += 4 * 128;
     };
-    int chan = 0;  // channels done in this layer
     auto gemm1 = [&](lds_cptr x0, auto&& before_last) {
-      // the two waves of a SIMD (w, w + 4) take turns at the head of the matrix pipe
-      if (((chan ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+      // the two waves of a SIMD (w, w + 4) take turns at the head of the matrix pipe.  (A feedback
+      // version — each wave publishes the channels it has started in LDS and the one behind its
+      // partner raises its priority — evens the two out, 548 | 596 k cycles in the long block
+      // instead of 506 | 625, and is 1.3 % SLOWER over the launch.)
+      if (((chan_total ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
-      ++chan;
+      ++chan_total;
 #pragma unroll
       for (int I = 0; I < S; ++I) Z[I] = splat4(0.f);
       lds_cptr xb = x0;
@@ -419,6 +431,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
           for (int I = 0; I < S; ++I) apply_m(T, Z, I);
         }
       }
+      LNZ_PH(2)  // long block
       // lift back: out[I] (node rows) += V[I][J] T[J] over the slot subtiles J the block mask names
 #pragma unroll
       for (int I = 0; I < S; ++I) {
@@ -435,17 +448,20 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       }
     }
 
+    LNZ_PH(3)  // lift
     // ---------------- node-space block: out += M_e (X W_e^T) per edge type ----------------
     if (active) {
       const lds_cptr x0 = xlane + cur * R * P;
       load_first(x0);
       for (int e = 0; e < ne; ++e) {
         gemm1(x0, [&] { fetch(e, true); });
+        LNZ_PH(4)  // edge GEMM1
 #pragma unroll
         for (int I = 0; I < S; ++I) {
           if ((idm[I] >> e) & 1) out[I] += Z[I];  // identity on every molecule of the subtile
           else apply_m(out, Z, I);
         }
+        LNZ_PH(5)  // GEMM2
       }
     }
 
@@ -543,6 +559,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     }
     __syncthreads();
     cur = nxt;
+    LNZ_PH(6)  // epilogue
   }
   __builtin_amdgcn_s_setprio(0);
   if (!FWD) return;
@@ -603,6 +620,15 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     }
     a.score[(int64_t)mid[i] * Pd + c] = sum / cnt;
   }
+#ifdef LNZ_STRIP_PHASES
+  LNZ_PH(7)  // head
+  if (a.state_out && lane == 0 && blockIdx.x < 8) {
+    float* d = a.state_out + ((int64_t)B * 32 * 128) + (blockIdx.x * 8 + wave) * 16;
+    for (int i = 0; i < 8; ++i) d[i] = (float)ph[i];
+    d[8] = (float)(clock64() - t_all);
+    d[9] = (float)S;
+  }
+#endif
 }
 
 // One workgroup = 8 waves on one strip of the plan.

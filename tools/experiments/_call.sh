@@ -1,13 +1,8 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-bash tools/profile_round.sh r04b > /dev/null 2>&1
-ls gpurun_out/prof_r04b | head -20
-cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py > gpurun_out/prof_r04b/final_bench.json 2> gpurun_out/prof_r04b/final_bench.err
-python - <<PY
-import json
-d=json.loads(open('gpurun_out/prof_r04b/final_bench.json').read().strip().splitlines()[-1])
-r=d['roofline']
-print(d['value'], d['ms_per_step'], r['kernel'], r['frac'], r['avg_launch_ms'], d['config']['stage_ms'], d.get('parity_rel_err'))
-print({k:(v.get('ms_per_step') if isinstance(v,dict) else None) for k,v in d['config'].items() if isinstance(v,dict)})
-PY
+V=tools/experiments/_variants
+timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1
+LANCZOSNET_HIP_LIB=$V/liblnz_conv_strip_prio1.so timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1
+timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1
+LANCZOSNET_HIP_LIB=$V/liblnz_conv_strip_prio1.so timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1
+PROBE_NAMES="prologue layer-head long-block lift edge-gemm1 gemm2 epilogue head total subtiles" LANCZOSNET_HIP_LIB=$V/liblnz_conv_strip_phases.so timeout 300 python tools/phase_probe16.py 2>&1 | tail -4

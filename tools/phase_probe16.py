@@ -31,7 +31,7 @@ for _ in range(3):
   ops.lanczosnet_forward(plan, t(b['node_feat']), Lp, V, G, t(b['node_mask']), return_state=True)
 torch.cuda.synchronize(); torch.zeros = orig
 rec = big.buf[B * 32 * 128:B * 32 * 128 + 1024].cpu().numpy().reshape(8, 8, 16)
-names = 'layer-head gemm1-long gain-scale lift gemm1-edge gemm2 epilogue prologue total tiles'.split()
+names = (os.environ.get('PROBE_NAMES') or 'layer-head gemm1-long gain-scale lift gemm1-edge gemm2 epilogue prologue total tiles').split()
 print('B=%d  [block, wave] kcycles: %s' % (B, ' '.join(names)))
 for blk in range(2):
   for w in (0, 3, 7):
