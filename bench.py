@@ -903,7 +903,10 @@ def main():
     roof_insn = ('2048 flop x the v_mfma_f32_16x16x4_f32' if f16 else
                  '4096 flop x the v_mfma_f32_32x32x2_f32')
     n_tiles = fm['tiles']
-    flops_exec = fm['flops_issued']
+    # strips: the block products are branch free — the kernel also multiplies the neighbouring
+    # subtile pairs no molecule touches and the identity channels' zero fragments (6 % of its
+    # instructions); `achieved` prices only the instructions of GEMM1 and of touched blocks
+    flops_exec = fm['mfma_in_touched_blocks'] * 2048 if strip else fm['flops_issued']
     achieved = flops_exec / fwd_s / 1e12
     if os.environ.get('LNZ_BENCH_DUMP_PLAN'):
       if strip:
@@ -948,6 +951,7 @@ def main():
                      'traffic': traffic, 'traffic_source': traffic_source,
                      'flops_per_launch_executed': flops_exec,
                      'mfma_instructions_per_launch': fm['mfma_issued'],
+                     'flops_per_launch_issued': fm['flops_issued'],
                      'flops_per_launch_without_skips': fm['flops_unskipped'],
                      'tiles_per_launch': n_tiles,
                      'useful_row_frac': round(fm['useful_row_frac'], 4),
@@ -959,11 +963,11 @@ def main():
                               'flops_per_launch_executed = %s instructions the kernel issues for THIS '
                               'batch\'s strip plan (lnz_plan_strips: %d molecules at 4-row granularity '
                               'in %d strips = %d subtiles of 16 rows, at most %d per strip; the block '
-                              'products visit the subtile pairs some molecule touches, identity '
-                              'bond-type channels are skipped; utils/flop_model.py, checked against '
-                              'the PMC counter SQ_INSTS_VALU_MFMA_MOPS_F32 in profiles/); '
-                              'flops_per_launch_without_skips = every neighbouring subtile pair, no '
-                              'identity channel. useful_row_frac = real node rows / strip rows; '
+                              'products of subtile pairs no molecule touches and of identity bond-type '
+                              'channels are NOT counted, although the branch-free kernel issues them '
+                              'on zero fragments: flops_per_launch_issued = mfma_instructions_per_launch '
+                              'x 2048 is what the PMC counter SQ_INSTS_VALU_MFMA_MOPS_F32 shows; '
+                              'utils/flop_model.py, profiles/). useful_row_frac = real node rows / strip rows; '
                               'useful_frac = frac x useful_row_frac. reference_association_tflops '
                               'prices every 32 rows at SURVEY 8(d)\'s %d flop (filter build + L_s Z per '
                               'long channel, which the kernel replaces by one projection and one lift '

@@ -191,7 +191,6 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   unsigned loff[S][3];  // byte offset of fragment (I, J = I + d - 1) of edge type 0, or OOB
   unsigned doff[DIAG ? 1 : S][3];  // FK 2: fragment (I, J) of a dense filter: slot row 16 I + j is
                                    // slot kr of its molecule, the 4-column group molecule-local
-  int blk[S];           // bit d: some molecule has rows in subtile I and in subtile I + d - 1
   const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.Lp), 0, B * ne * 4096, 0x00020000);
   int idm[S];
@@ -201,7 +200,6 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     const int own = rowinfo[row];
     const int st = own >= 0 ? mstart[own] : 0;
     const int mol = own >= 0 ? mid[own] : 0;
-    int bits = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const int J = I + d - 1;
@@ -219,9 +217,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         doff[DIAG ? 0 : I][d] = OOB;
       }
       loff[I][d] = off;
-      bits |= (__ballot(ok) != 0ull) ? (1 << d) : 0;
     }
-    blk[I] = __builtin_amdgcn_readfirstlane(bits);
     idm[I] = __builtin_amdgcn_readfirstlane(idI[I]);
   }
   __syncthreads();
@@ -265,26 +261,26 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     // ---------------- first layer: Y = V^T X from LDS into the other buffer ----------------
     if (nl > 0 && l == 0) {
       if (16 * wave < din) {
+        f32x4 Y[S];
 #pragma unroll
-        for (int I = 0; I < S; ++I) {  // slot subtile
-          f32x4 Y = splat4(0.f);
+        for (int I = 0; I < S; ++I) Y[I] = splat4(0.f);
 #pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int J = I + d - 1;   // node subtile
-            if (J < 0 || J >= S) continue;
-            if ((blk[I] >> d) & 1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int nu = 4 * kq + r;
-                Y = mfma16(Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j],
-                           Xs[cur * R * P + (16 * J + nu) * P + 16 * wave + j], Y);
-              }
-            }
-          }
+        for (int d = 0; d < 3; ++d)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            Xs[nxt * R * P + (16 * I + 4 * kq + r) * P + 16 * wave + j] = Y[r];
-        }
+#pragma unroll
+            for (int I = 0; I < S; ++I) {  // slot subtile I, node subtile J
+              const int J = I + d - 1;
+              if (J < 0 || J >= S) continue;
+              const int nu = 4 * kq + r;
+              Y[I] = mfma16(Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j],
+                            Xs[cur * R * P + (16 * J + nu) * P + 16 * wave + j], Y[I]);
+            }
+#pragma unroll
+        for (int I = 0; I < S; ++I)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Xs[nxt * R * P + (16 * I + 4 * kq + r) * P + 16 * wave + j] = Y[I][r];
       }
       __syncthreads();
     }
@@ -364,17 +360,22 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         }
       }
     };
-    // acc[I] += M[I][J] Zp[J] over the blocks of subtile I
-    auto apply_m = [&](f32x4 (&acc)[S], const f32x4 (&Zp)[S], int I) {
+    // acc[I] += M[I][J] Zp[J] over every neighbouring block (I, J): branch free — a block no
+    // molecule touches has all-zero fragments (offsets beyond the buffer) — and ordered so that
+    // consecutive MFMAs go to different accumulators.  (With the blocks masked by a wave-uniform
+    // bit each, 8 % fewer MFMAs were issued in chains of four dependent ones behind a branch:
+    // the block phases ran at 2 - 5 x their matrix time.)
+    auto apply_all = [&](f32x4 (&acc)[S], const f32x4 (&Zp)[S]) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const int J = I + d - 1;
-        if (J < 0 || J >= S) continue;
-        if ((blk[I] >> d) & 1) {
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[I] = mfma16(mop[I][d][r], Zp[J][r], acc[I]);
-        }
-      }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            const int J = I + d - 1;
+            if (J < 0 || J >= S) continue;
+            acc[I] = mfma16(mop[I][d][r], Zp[J][r], acc[I]);
+          }
     };
 
     // ---------------- short-diffusion channels: out += L_0^p (X W_c^T) ----------------
@@ -387,15 +388,12 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         for (int rep = 1; rep < p; ++rep) {
           f32x4 Zn[S];
 #pragma unroll
-          for (int I = 0; I < S; ++I) {
-            Zn[I] = splat4(0.f);
-            apply_m(Zn, Z, I);
-          }
+          for (int I = 0; I < S; ++I) Zn[I] = splat4(0.f);
+          apply_all(Zn, Z);
 #pragma unroll
           for (int I = 0; I < S; ++I) Z[I] = Zn[I];
         }
-#pragma unroll
-        for (int I = 0; I < S; ++I) apply_m(out, Z, I);
+        apply_all(out, Z);
       }
     }
 
@@ -427,25 +425,29 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
                                g_rsrc, doff[DIAG ? 0 : I][d], (la * B * nl + s) * K * K * 4, 0));
               }
           });
-#pragma unroll
-          for (int I = 0; I < S; ++I) apply_m(T, Z, I);
+          apply_all(T, Z);
         }
       }
       LNZ_PH(2)  // long block
       // lift back: out[I] (node rows) += V[I][J] T[J] over the slot subtiles J the block mask names
+      f32x4 vl[S][3];
 #pragma unroll
-      for (int I = 0; I < S; ++I) {
+      for (int I = 0; I < S; ++I)
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          const int J = I + d - 1;
-          if (J < 0 || J >= S) continue;
-          if ((blk[I] >> d) & 1) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&Vb[((I * 3 + d) * 16 + j) * VBP + 4 * kq]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[I] = mfma16(v[r], T[J][r], out[I]);
-          }
+          if (I + d - 1 < 0 || I + d - 1 >= S) continue;
+          vl[I][d] = *reinterpret_cast<const f32x4*>(&Vb[((I * 3 + d) * 16 + j) * VBP + 4 * kq]);
         }
-      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            const int J = I + d - 1;
+            if (J < 0 || J >= S) continue;
+            out[I] = mfma16(vl[I][d][r], T[J][r], out[I]);
+          }
     }
 
     LNZ_PH(3)  // lift
@@ -456,11 +458,10 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       for (int e = 0; e < ne; ++e) {
         gemm1(x0, [&] { fetch(e, true); });
         LNZ_PH(4)  // edge GEMM1
+        apply_all(out, Z);  // (identity subtiles: zero fragments)
 #pragma unroll
-        for (int I = 0; I < S; ++I) {
+        for (int I = 0; I < S; ++I)
           if ((idm[I] >> e) & 1) out[I] += Z[I];  // identity on every molecule of the subtile
-          else apply_m(out, Z, I);
-        }
         LNZ_PH(5)  // GEMM2
       }
     }
@@ -510,22 +511,23 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         for (int r = 0; r < 4; ++r) Xs[nxt * R * P + (row0 + r) * P + col] = v[r];
       }
       if (nl > 0 && more) {
+        f32x4 Y[S];
 #pragma unroll
-        for (int I = 0; I < S; ++I) {  // slot subtile
-          f32x4 Y = splat4(0.f);
+        for (int I = 0; I < S; ++I) Y[I] = splat4(0.f);
 #pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const int J = I + d - 1;   // node subtile
-            if (J < 0 || J >= S) continue;
-            if ((blk[I] >> d) & 1) {
+        for (int d = 0; d < 3; ++d)
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                Y = mfma16(Vb[((J * 3 + (2 - d)) * 16 + 4 * kq + r) * VBP + j], out[J][r], Y);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int I = 0; I < S; ++I) {  // slot subtile I, node subtile J
+              const int J = I + d - 1;
+              if (J < 0 || J >= S) continue;
+              Y[I] = mfma16(Vb[((J * 3 + (2 - d)) * 16 + 4 * kq + r) * VBP + j], out[J][r], Y[I]);
             }
-          }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Xs[cur * R * P + (16 * I + 4 * kq + r) * P + col] = Y[r];
-        }
+        for (int I = 0; I < S; ++I)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Xs[cur * R * P + (16 * I + 4 * kq + r) * P + col] = Y[I][r];
       }
       if (MODE == 1 && la > 0 && (a.dy_compact || a.dbias_part)) {
         // What the weight / bias gradients of conv layer la - 1 need: dY_{la-1} in the COMPACT row

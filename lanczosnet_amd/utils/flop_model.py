@@ -35,9 +35,10 @@ lnz_plan_strips — S subtiles of 16 rows per workgroup, molecules at 4-row gran
 strip, wave and layer
 
     GEMM1      (n_long + n_edge) * d_in / 16 * 4 * S
-    lift-back  4 * blocks                                    blocks = subtile pairs (I, J), |I - J| <= 1,
-    GEMM2      4 * sum_e blocks of subtiles not identity     that some molecule touches
-    projection 4 * blocks                                    (not the last layer)
+    lift-back  4 * blocks                                    blocks = 3 S - 2: every subtile pair (I, J),
+    GEMM2      4 * n_edge * blocks                           |I - J| <= 1 (branch free: a pair no molecule
+    projection 4 * blocks      (not the last layer)          touches, or an identity channel's, has zero
+                                                             fragments and is multiplied all the same)
 
 plus the first layer's projection (din0 / 16 waves) and the head (S waves, 64 instructions), all of
 the 16x16x4 kind.  It takes the launches `strips_selected` says.
@@ -229,25 +230,28 @@ def strip_mfma_issued(strips, cfg):
   din0 = (din0 + 63) // 64 * 64
   emask = (1 << n_edge) - 1
   issued = full = rows_real = rows_tile = 0
+  useful = 0   # the instructions of blocks some molecule touches, identity channels left out
   for t in strips:
-    S, blocks = t['sub'], sum(t['blk'])
-    g2 = sum(b * (n_edge - bin(i & emask).count('1')) for b, i in zip(t['blk'], t['ident']))
-    g2_full = n_edge * (3 * S - 2)
+    S, touched = t['sub'], sum(t['blk'])
+    blocks = 3 * S - 2
+    g2_useful = sum(b * (n_edge - bin(i & emask).count('1')) for b, i in zip(t['blk'], t['ident']))
     for l in range(nl):
       d_in = din0 if l == 0 else dhid
       proj = 1 if (n_long and l + 1 < nl) else 0
-      issued += 8 * (C * (d_in // 16) * 4 * S + 4 * blocks * ((1 if n_long else 0) + proj) + 4 * g2)
-      full += 8 * (C * (d_in // 16) * 4 * S + 4 * (3 * S - 2) * ((1 if n_long else 0) + proj) + 4 * g2_full)
+      issued += 8 * (C * (d_in // 16) * 4 * S + 4 * blocks * ((1 if n_long else 0) + proj) + 4 * n_edge * blocks)
+      useful += 8 * (C * (d_in // 16) * 4 * S + 4 * touched * ((1 if n_long else 0) + proj) + 4 * g2_useful)
     if n_long:
       issued += (din0 // 16) * 4 * blocks
-      full += (din0 // 16) * 4 * (3 * S - 2)
+      useful += (din0 // 16) * 4 * touched
     issued += S * 64
-    full += S * 64
+    useful += S * 64
+    full = issued
     rows_real += t['rows_real']
     rows_tile += 16 * S
   return dict(tiles=len(strips), mfma_issued=int(issued), mfma_unskipped=int(full),
               flops_issued=int(issued) * FLOP_PER_MFMA16, flops_unskipped=int(full) * FLOP_PER_MFMA16,
               mops_counts=int(issued) * (FLOP_PER_MFMA16 // FLOP_PER_MOPS_COUNT),
               useful_row_frac=rows_real / float(max(1, rows_tile)),
+              mfma_in_touched_blocks=int(useful),
               subtiles=int(sum(t['sub'] for t in strips)),
               max_subtiles_per_strip=int(max(t['sub'] for t in strips)))

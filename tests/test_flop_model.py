@@ -63,7 +63,10 @@ def test_issued_mfma_model_of_the_strip_kernel_agrees_with_the_pmc_counter():
   fm = strip_mfma_issued(strips, QM8_CFG)
   measured = pmc['SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch']
   assert abs(fm['mops_counts'] - measured) <= 0.002 * measured, (fm['mops_counts'], measured)
-  assert fm['mfma_unskipped'] > fm['mfma_issued']
+  # branch-free block products: every neighbouring subtile pair is multiplied; 94 % of the
+  # instructions sit in GEMM1 or in blocks some molecule touches (what bench.py prices)
+  assert fm['mfma_unskipped'] == fm['mfma_issued']
+  assert 0.9 * fm['mfma_issued'] < fm['mfma_in_touched_blocks'] <= fm['mfma_issued']
   # 1024 QM8-sized molecules: at most five subtiles on a compute unit, one strip per unit
   assert fm['max_subtiles_per_strip'] == 5 and fm['tiles'] <= 256
   assert sum(t['mols'] for t in strips) == 1024
