@@ -1260,6 +1260,8 @@ bool forward16_eligible(const lnz_forward_args& a, int mode);         // conv_fo
 int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s);
 bool strip_forward_eligible(const lnz_forward_args& a, int mode);     // conv_strip.hip
 int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s);
+bool strip_gain_grad_eligible(const lnz_forward_args& a);
+int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s);
 }
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
@@ -1440,6 +1442,8 @@ extern "C" int lnz_lanczosnet_gain_grad(const lnz_forward_args* args, lnz_stream
               "%s: plan without n_wg / plan_wg_cap", who);
   // [wave][lane row][s][32] partial sums of a tile live in its 32 x PITCH dY buffer
   LNZ_REQUIRE(8 * a.n_long * 32 <= 32 * PITCH, LNZ_ENOTSUP, "%s: too many long channels", who);
+  if (forward16_enabled() && strips_enabled() && lnz::strip_gain_grad_eligible(a))
+    return lnz::launch_strip_gain_grad(a, (hipStream_t)stream);
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;
   if (a.din0 % 64 == 0)
     hipLaunchKernelGGL((lanczosnet_gain_grad_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);

@@ -633,6 +633,227 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
 #endif
 }
 
+// -----------------------------------------------------------------------------------------
+// Gradient of the loss w.r.t. the spectral gains on strips (training; conv_forward.hip's
+// gain_grad_half on the tile plan):
+//   dG[l][b][k][s] = sum_o P[k][o] Q_s[k][o],   P = V^T dY_l,   Q_s = (V^T X_l) W_s^T
+// Every conv layer in turn: X_l and dY_l are staged in the two node-state buffers, projected (Y to
+// LDS over X_l, P kept in C/D registers), then each long channel's GEMM1 runs on Y with the FORWARD
+// weight pack and its result is multiplied with P and reduced over the wave's 16 columns (DPP row
+// sums) and over the eight waves (LDS, fixed order: deterministic).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+  return v;
+}
+
+template <int S>
+__device__ __forceinline__ void strip_gain_grad(KArgs& a, const int32_t* __restrict__ ent, float* lds,
+                                                const int tid, const int wave) {
+  constexpr int R = 16 * S;
+  const int lane = tid & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int N = a.N, K = a.K, B = a.B;
+  const int nl = a.n_long;
+  const int C = a.n_short + a.n_long + a.n_edge;
+  float* Xs = lds;                                   // [2][R][P]: X_l / Y, dY_l / wave partials
+  float* Vb = Xs + 2 * R * P;
+  int* rowinfo = reinterpret_cast<int*>(Vb + S * 3 * 16 * VBP);
+  int* mstart = rowinfo + R;
+  int* mext = mstart + MAXMOL;
+  int* mid = mext + MAXMOL;
+  const int nm = ent[0];
+  if (tid < MAXMOL) {
+    const bool in = tid < nm;
+    mid[tid] = in ? ent[2 + 3 * tid] : -1;
+    mstart[tid] = in ? ent[3 + 3 * tid] : 0;
+    mext[tid] = in ? ent[4 + 3 * tid] : 0;
+  }
+  __syncthreads();
+  if (tid < R) {
+    int own = -1;
+    for (int i = 0; i < nm; ++i) {
+      const int n = mext[i];
+      const int rows = n <= 4 ? 4 : (n + 3) & ~3;
+      if (tid >= mstart[i] && tid < mstart[i] + rows) own = i;
+    }
+    rowinfo[tid] = own;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < S * 3 * 256; idx += 512) {
+    const int Jn = idx / 768, rem = idx - Jn * 768;
+    const int d = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
+    const int nrow = 16 * Jn + nu, srow = 16 * (Jn + d - 1) + ro;
+    float v = 0.0f;
+    if (srow >= 0 && srow < R) {
+      const int own = rowinfo[nrow];
+      if (own >= 0 && rowinfo[srow] == own) {
+        const int lnode = nrow - mstart[own], k = srow - mstart[own];
+        if (lnode < N && k < K) v = a.V[((int64_t)mid[own] * N + lnode) * K + k];
+      }
+    }
+    Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = v;
+  }
+  const int rt = wave >> 1;
+  const int wlane = 64 * (kq >> 1) + 32 * (kq & 1) + 16 * (wave & 1) + j;
+  const lds_cptr ylane = (lds_cptr)(Xs + j * P + 4 * kq);
+
+  for (int la = 0; la < a.num_layer; ++la) {
+    const int din = la == 0 ? a.din0 : 128;
+    const int Q = din >> 3, Q16 = din >> 4;
+    // ---- stage X_la (buffer 0) and dY_la (buffer 1): rows of the strip's molecules, zero elsewhere
+    {
+      const float* xsrc = la == 0 ? a.x0 : a.act + (int64_t)(la - 1) * B * 32 * 128;
+      const int d4 = din >> 2, e4 = 32;
+      const int total = R * (d4 + e4);
+      constexpr int UN = 4;  // loads in flight per thread
+      for (int base = tid; base < total; base += 512 * UN) {
+        float4 v[UN];
+        int dst[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int idx = base + u * 512;
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[u] = -1;
+          if (idx < total) {
+            const int row = idx / (d4 + e4), c = idx - row * (d4 + e4);
+            const int own = rowinfo[row];
+            const int64_t mrow = own >= 0 ? (int64_t)mid[own] * 32 + (row - mstart[own]) : 0;
+            if (c < d4) {
+              if (own >= 0) v[u] = reinterpret_cast<const float4*>(xsrc + mrow * din)[c];
+              dst[u] = row * P + 4 * c;
+            } else {
+              if (own >= 0)
+                v[u] = reinterpret_cast<const float4*>(a.dy + ((int64_t)la * B * 32 + mrow) * 128)[c - d4];
+              dst[u] = R * P + row * P + 4 * (c - d4);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+          if (dst[u] >= 0) *reinterpret_cast<float4*>(&Xs[dst[u]]) = v[u];
+      }
+    }
+    __syncthreads();
+    // ---- projections: Pb = V^T dY (registers), Y = V^T X (registers, then LDS over X)
+    f32x4 Pb[S], Yb[S];
+#pragma unroll
+    for (int I = 0; I < S; ++I) Pb[I] = Yb[I] = splat4(0.f);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int I = 0; I < S; ++I) {  // slot subtile I, node subtile J
+          const int J = I + d - 1;
+          if (J < 0 || J >= S) continue;
+          const int nu = 4 * kq + r;
+          const float vt = Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j];
+          Pb[I] = mfma16(vt, Xs[R * P + (16 * J + nu) * P + 16 * wave + j], Pb[I]);
+          if (16 * wave < din) Yb[I] = mfma16(vt, Xs[(16 * J + nu) * P + 16 * wave + j], Yb[I]);
+        }
+    __syncthreads();  // every wave has read X and dY
+    if (16 * wave < din) {
+#pragma unroll
+      for (int I = 0; I < S; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(16 * I + 4 * kq + r) * P + 16 * wave + j] = Yb[I][r];
+    }
+    __syncthreads();
+    // ---- long channels: Q_s = Y W_s^T, row-wise <P, Q_s> over this wave's 16 columns
+    const float4* __restrict__ Wl = reinterpret_cast<const float4*>(a.Wp + a.w_off[la]);
+    const float4* __restrict__ wp = Wl + ((int64_t)rt * (C * Q) + (int64_t)a.n_short * Q) * 64 + wlane;
+    float4 ring[4];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+    float* red = Xs + R * P;  // [8 waves][nl][R] partial sums (the dY buffer is free now)
+    f32x4 acur[S];
+#pragma unroll
+    for (int I = 0; I < S; ++I) acur[I] = lds4(ylane + 16 * I * P);
+    for (int s = 0; s < nl; ++s) {
+      f32x4 Z[S];
+#pragma unroll
+      for (int I = 0; I < S; ++I) Z[I] = splat4(0.f);
+      lds_cptr xb = ylane;
+#pragma unroll 1
+      for (int q0 = 0; q0 < Q16; q0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ring[(u + 3) & 3] = wp[(u + 3) * 128];
+          f32x4 anext[S];
+          // (the read one step past the channel's last wraps to k = 0: the next channel's first)
+          const lds_cptr xn = (q0 + u + 1 == Q16) ? ylane : xb + 16 * (u + 1);
+#pragma unroll
+          for (int I = 0; I < S; ++I) anext[I] = lds4(xn + 16 * I * P);
+          const float4 bv = ring[u];
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][0], bv.x, Z[I]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][1], bv.y, Z[I]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][2], bv.z, Z[I]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma16(acur[I][3], bv.w, Z[I]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) acur[I] = anext[I];
+#pragma unroll
+          for (int g = 0; g < S; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g == S - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        }
+        wp += 4 * 128;
+        xb += 64;
+      }
+#pragma unroll
+      for (int I = 0; I < S; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = row16_sum(Pb[I][r] * Z[I][r]);
+          if (j == 0) red[(wave * nl + s) * R + 16 * I + 4 * kq + r] = v;
+        }
+    }
+    __syncthreads();
+    // ---- sum over the waves (fixed order) and store dG[la][mol][k][s]
+    for (int idx = tid; idx < nl * R; idx += 512) {
+      const int s = idx / R, rho = idx - s * R;
+      const int own = rowinfo[rho];
+      if (own >= 0) {
+        const int k = rho - mstart[own];
+        if (k < K) {
+          float v = 0.0f;
+          for (int w = 0; w < 8; ++w) v += red[(w * nl + s) * R + rho];
+          a.dgains[(((int64_t)la * B + mid[own]) * K + k) * nl + s] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(512) void lanczosnet_strip_gain_grad_kernel(const lnz_forward_args) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  extern __shared__ __attribute__((aligned(16))) float lds_strip[];
+  if ((int)blockIdx.x >= *a.n_strips) return;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int32_t* ent = a.strips + (int64_t)blockIdx.x * LNZ_STRIP_INTS;
+  const int sub = __builtin_amdgcn_readfirstlane(ent[1]);
+  switch (sub) {
+    case 1: strip_gain_grad<1>(a, ent, lds_strip, tid, wave); break;
+    case 2: strip_gain_grad<2>(a, ent, lds_strip, tid, wave); break;
+    case 3: strip_gain_grad<3>(a, ent, lds_strip, tid, wave); break;
+    case 4: strip_gain_grad<4>(a, ent, lds_strip, tid, wave); break;
+    case 5: strip_gain_grad<5>(a, ent, lds_strip, tid, wave); break;
+    case 6: strip_gain_grad<6>(a, ent, lds_strip, tid, wave); break;
+    default: break;
+  }
+}
+
 // One workgroup = 8 waves on one strip of the plan.
 template <int MODE, int FK, bool SHORT>
 __global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward_args) {
@@ -672,6 +893,26 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   const int64_t per_slot = a.filter_kind == 1 ? (int64_t)a.K * a.K : a.K;
   if ((int64_t)a.num_layer * a.B * a.n_long * per_slot * 4 >= (1ll << 31)) return false;
   return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float) <= 160 * 1024;
+}
+
+// lnz_lanczosnet_gain_grad on strips (the arguments have passed that entry point's checks)
+bool strip_gain_grad_eligible(const lnz_forward_args& a) {
+  if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
+  if (a.din0 % 64 != 0 || a.n_long < 1 || a.n_long > 12) return false;
+  // the eight waves' partial sums of a strip fit in its dY buffer
+  return 8 * a.n_long <= P;
+}
+
+int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s) {
+  const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)lanczosnet_strip_gain_grad_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lanczosnet_strip_gain_grad_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
+  return check_launch("lnz_lanczosnet_gain_grad (strips)");
 }
 
 int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
