@@ -1,4 +1,5 @@
-// R7 + R9 + R10, inference: the LanczosNet forward on STRIPS of 16-row subtiles.
+// R7 + R9 + R10 on STRIPS of 16-row subtiles: the forward (inference and training), the
+// input-gradient pass and the gain-gradient pass of the width-128 models.
 //
 // conv_forward16.hip runs 32-row node tiles (one molecule, or an 8 | 24 / 16 | 16 pair): the QM8
 // bench batch rides in 744 tiles = 23.8 k rows for 17.3 k atoms, three tiles (96 rows) on the
@@ -8,6 +9,9 @@
 // compute unit.  GEMM1 (X W_c^T, 87 % of the matrix work) is row-proportional; the block-diagonal
 // products (GEMM2 with the Laplacians, projection on / lift from the Ritz vectors) visit the
 // subtile blocks (I, J), |I - J| <= 1, that some molecule touches.
+//
+// The block products are branch free: every neighbouring pair is multiplied (a pair no molecule
+// touches has all-zero fragments), ordered so that consecutive MFMAs go to different accumulators.
 //
 // Everything else is conv_forward16.hip's scheme (same packs, same fragment indexing, see its file
 // comment): wave w owns output columns [16 w, 16 w + 16) of every subtile; a 16-k step of GEMM1 is
