@@ -224,8 +224,9 @@ __device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem&
 }
 
 __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, const double ereg,
-                                            const int n, const int r, const int h) {
+                                            const int n, const int r, const int h, long long* ts = nullptr) {
   constexpr int LD = Ritz32Smem::LD;
+  if (ts) ts[0] = clock64();
   // ---- d, e -> LDS (broadcast reads); negligible couplings split the matrix
   const double dn = __shfl_down(dreg, 1, 64);
   const bool live = r < n - 1 && fabs(ereg) > kEps * (fabs(dreg) + fabs(dn));
@@ -312,6 +313,7 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     bool bail2 = false;
     lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail2, &blo, &bhi, false);
   }
+  if (ts) ts[1] = clock64();
   // ---- 3. eigenvector of the block: twisted factorisation of T - lam
   double z[32];
   {
@@ -417,6 +419,7 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     }
   }
 
+  if (ts) ts[2] = clock64();
   // ---- 4. V = Q S: column k, node rows 16h .. 16h+15
   double acc[16];
 #pragma unroll
@@ -437,6 +440,7 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     if (h == 0) sm.dd[r] = lam;
   }
   __syncthreads();
+  if (ts) ts[3] = clock64();
   return true;
 }
 
@@ -468,6 +472,7 @@ __device__ __forceinline__ void lanczos_ritz32_body(
   __syncthreads();
 #ifdef LNZ_PROFILE_PHASES
   long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
+  long long tsx[4] = {0, 0, 0, 0};
 #endif
 
   int nrestart = 0;
@@ -531,7 +536,11 @@ __device__ __forceinline__ void lanczos_ritz32_body(
 #endif
 
 #ifndef LNZ_RITZ32_QL
+#ifdef LNZ_PROFILE_PHASES
+    const bool solved = tridiag_eig_parallel(sm, dreg, ereg, n, r, h, tsx);
+#else
     const bool solved = tridiag_eig_parallel(sm, dreg, ereg, n, r, h);
+#endif
 #else
     const bool solved = false;
 #endif
@@ -676,6 +685,9 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     D[(int64_t)b * K + 1] = (float)(tp2 - tp1);
     D[(int64_t)b * K + 2] = (float)(tp3 - tp2);
     D[(int64_t)b * K + 3] = (float)n;
+    D[(int64_t)b * K + 4] = (float)(tsx[1] - tsx[0]);
+    D[(int64_t)b * K + 5] = (float)(tsx[2] - tsx[1]);
+    D[(int64_t)b * K + 6] = (float)(tsx[3] - tsx[2]);
   }
 #endif
 }

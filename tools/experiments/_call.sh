@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+LANCZOSNET_HIP_LIB=tools/experiments/_variants/liblnz_lanczos_ritz_phases.so timeout 300 python tools/ritz_phase_probe.py 2>&1 | tail -22

@@ -1,4 +1,6 @@
-"""Diagnostic: clock64 phase times of lanczos_ritz_kernel (needs tools/libprobe_ritz.so)."""
+"""Diagnostic: clock64 phase times of the one-wavefront Ritz kernel per molecule size (needs the
+library built with -DLNZ_PROFILE_PHASES: tools/experiments/build_variant.sh lanczos_ritz.hip
+phases:"-DLNZ_PROFILE_PHASES", then LANCZOSNET_HIP_LIB=tools/experiments/_variants/liblnz_lanczos_ritz_phases.so)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,8 +13,8 @@ for _ in range(3):
   D, V, info = ops.lanczos_ritz(L[..., 0], n, 20, return_info=True)
 torch.cuda.synchronize()
 D = D.cpu().numpy(); info = info.cpu().numpy()
-print('n   count  lanczos   ql   out (kcycles, mean)   restarts(mean)')
+print('n   count  lanczos   eig   out | eigenvalue  vector  V=QS (kcycles, mean)   restarts(mean)')
 for nn in sorted(set(D[:, 3].astype(int))):
   m = D[:, 3].astype(int) == nn
-  print('%2d %5d %8.1f %8.1f %6.1f   %.2f' % (nn, m.sum(), D[m, 0].mean() / 1e3, D[m, 1].mean() / 1e3, D[m, 2].mean() / 1e3, info[m].mean()))
+  print('%2d %5d %8.1f %8.1f %6.1f | %8.1f %8.1f %8.1f   %.2f' % (nn, m.sum(), D[m, 0].mean() / 1e3, D[m, 1].mean() / 1e3, D[m, 2].mean() / 1e3, D[m, 4].mean() / 1e3, D[m, 5].mean() / 1e3, D[m, 6].mean() / 1e3, info[m].mean()))
 print('max total kcycles', (D[:, 0] + D[:, 1] + D[:, 2]).max() / 1e3)
