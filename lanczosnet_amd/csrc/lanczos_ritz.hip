@@ -86,6 +86,11 @@ __device__ inline double dot16(const double (&a)[16], const double (&b)[16]) {
 
 // x <- (I - Q Q^T)^2 x over all stored basis rows (rows not yet written are zero); returns the
 // accumulated coefficient on basis vector j.  r = lane & 31, h = lane >> 5.
+// The second pass runs only where the first one removed more than 99 % of the vector's squared
+// length (sum of the squared coefficients against its squared norm, both from the 16-element
+// blocks the pass has in registers anyway; every lane computes the same two numbers, so the
+// decision is wave uniform): what is left then has lost two digits to cancellation and is
+// re-orthogonalised ("twice is enough").  LNZ_RITZ32_CGS2_ALWAYS restores the unconditional form.
 __device__ inline double cgs2_32(Ritz32Smem& sm, double& x, int j, int r, int h) {
   constexpr int LD = Ritz32Smem::LD;
   double qrow[16], qcol[16], v[16];
@@ -103,11 +108,20 @@ __device__ inline double cgs2_32(Ritz32Smem& sm, double& x, int j, int r, int h)
       for (int t = 0; t < 16; ++t) qcol[t] = sm.Qt[(16 * h + t) * LD + r];  // element r of vectors
     }
     double c = xhalf_sum(dot16(qrow, v));  // <q_r, x>
+#ifndef LNZ_RITZ32_CGS2_ALWAYS
+    const double xx = pass == 0 ? xhalf_sum(dot16(v, v)) : 0.0;  // |x|^2
+#endif
     cbuf[r] = c;
     coef += readlane_f64(c, j);
     __syncthreads();
     load16(cbuf + 16 * h, v);
     x -= xhalf_sum(dot16(qcol, v));
+#ifndef LNZ_RITZ32_CGS2_ALWAYS
+    if (pass == 0) {
+      const double cc2 = xhalf_sum(dot16(v, v));  // sum of the squared coefficients
+      if (cc2 <= 0.99 * xx) break;
+    }
+#endif
   }
   return coef;
 }

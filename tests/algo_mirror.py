@@ -12,11 +12,16 @@ EPS = 2.220446049250313e-16
 
 
 def _cgs2(Qt, w, j):
+  """Classical Gram-Schmidt against the stored basis; the second pass only where the first one
+  removed more than 99 % of the vector's squared length (csrc/lanczos_ritz.hip cgs2_32)."""
   coef = 0.0
-  for _ in range(2):
+  for p in range(2):
+    xx = float(w @ w)
     c = Qt[:j + 1] @ w
     w = w - Qt[:j + 1].T @ c
     coef += c[j]
+    if p == 0 and float(c @ c) <= 0.99 * xx:
+      break
   return w, coef
 
 
