@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-LANCZOSNET_HIP_LIB=tools/experiments/_variants/liblnz_lanczos_ritz_always.so timeout 600 python tools/experiments/ritz_quality.py 24 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_runner_dropin.py tests/test_graph_runner_dropin.py -m gpu -q 2>&1 | tail -2
