@@ -1,4 +1,6 @@
-# scratch: the command file of the last gpurun call (tools/experiments/README.md)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
+V=tools/experiments/_variants
+timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1
+for v in s1 s2 s3; do LANCZOSNET_HIP_LIB=$V/liblnz_conv_strip_$v.so timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1; done
+timeout 200 python tools/experiments/forward_ab.py 2>&1 | tail -1
