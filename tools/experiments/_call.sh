@@ -1,13 +1,8 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/f2
-for v in 1 0; do
-rm -rf /tmp/rp_busy$v
-(cd /tmp && LNZ_STRIPS=$v LNZ_FORWARD16=1 timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/rp_busy$v -- python $GRAFT_REPO_ROOT/tools/experiments/forward_ab.py > /dev/null 2>&1)
-python tools/pmc_summary.py $(dirname $(find /tmp/rp_busy$v -name '*counter_collection.csv' | head -1)) 2>&1 | grep -i "lanczosnet\|spectral\|prepare" > gpurun_out/f2/busy_$v.txt
-cat gpurun_out/f2/busy_$v.txt
-done
-rm -rf /tmp/rp_busy2
-(cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/rp_busy2 -- python $GRAFT_REPO_ROOT/bench.py --no-secondary --no-cpu-baseline > /dev/null 2>&1)
-python tools/pmc_summary.py $(dirname $(find /tmp/rp_busy2 -name '*counter_collection.csv' | head -1)) 2>&1 | grep -i "lanczosnet\|spectral\|prepare" > gpurun_out/f2/busy_bench.txt
-cat gpurun_out/f2/busy_bench.txt
+V=tools/experiments/_variants
+for lib in "" $V/liblnz_conv_forward_f16_vform.so; do LANCZOSNET_HIP_LIB=$lib timeout 300 python bench.py --gemm f16x3 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f16x3 fwd [$lib]', d['ms_per_step'], d['config']['stage_ms'], d.get('parity_rel_err'))"; done
+for lib in "" $V/liblnz_conv_large_vform.so; do LANCZOSNET_HIP_LIB=$lib timeout 300 python tools/bench_config5.py --reps 2 2>&1 | tail -1 | cut -c1-400; done
+for lib in "" $V/liblnz_f16x3_linear_vform.so; do LANCZOSNET_HIP_LIB=$lib timeout 300 python tools/bench_f16x3_linear.py 2>&1 | tail -2 | cut -c1-300; done
