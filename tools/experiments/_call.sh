@@ -1,7 +1,13 @@
+# scratch: the command file of the last gpurun call
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-V=tools/experiments/_variants
-for t in 2 1; do
-LNZ_GAINS_TILES=$t timeout 200 python tools/bench_gains.py 200 2>&1 | tail -1 | sed "s/^/tiles=$t base /"
-LNZ_GAINS_TILES=$t LANCZOSNET_HIP_LIB=$V/liblnz_spectral_gains_il.so timeout 200 python tools/bench_gains.py 200 2>&1 | tail -1 | sed "s/^/tiles=$t interleave /"
-done
+mkdir -p gpurun_out/f3
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/f3/pytest.log 2>&1; tail -3 gpurun_out/f3/pytest.log | cut -c1-200
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python bench.py > gpurun_out/f3/bench.json 2> gpurun_out/f3/bench.err
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/f3/bench.json').read().strip().splitlines()[-1])
+r=d['roofline']
+print(d['value'], d['ms_per_step'], r['kernel'], r['frac'], r['avg_launch_ms'], d['config']['stage_ms'], d.get('parity_rel_err'), d['cpu_baseline']['value'])
+PY
