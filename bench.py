@@ -135,7 +135,7 @@ def forward_batch_sweep(net, plan, L, node_feat, mask_u8, n_nodes, cfg, sizes, r
         # this size runs on the strip plan: flops from the instructions that plan issues
         fm = strip_mfma_issued(strips_from_plan(buf.strips.cpu().numpy(),
                                                 Lp.ident.cpu().numpy() if hasattr(Lp, 'ident') else None), cfg)
-        tf = fm['flops_issued'] / (ms * 1e-3) / 1e12
+        tf = fm['mfma_in_touched_blocks'] * 2048 / (ms * 1e-3) / 1e12   # (priced like `roofline`)
         kern, n_tiles, n_wg = 'strips (%d subtiles)' % fm['subtiles'], fm['tiles'], fm['tiles']
       out.append({'batch': B0 * r, 'plan': kern, 'tiles': n_tiles, 'workgroups': n_wg, 'forward_ms': round(ms, 4),
                   'executed_tflops': round(tf, 2), 'frac': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
