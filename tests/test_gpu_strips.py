@@ -11,52 +11,7 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-INTS, SUB = 80, 6
-
-
-def _place(fill, rows):
-  return fill if (fill % 16) + rows <= 32 else (fill + 15) // 16 * 16
-
-
-def plan_strips_mirror(ext, n_cu, chunk=2048):
-  """Batches beyond 2048 molecules: chunk by chunk, consecutive strip ranges."""
-  out = []
-  for c0 in range(0, len(ext), chunk):
-    for mols, sub in _plan_chunk_mirror(ext[c0:c0 + chunk], n_cu):
-      out.append(([(b + c0, st, n) for b, st, n in mols], sub))
-  return out
-
-
-def _plan_chunk_mirror(ext, n_cu, bins=1024):
-  """First fit decreasing by size class (rows / 4), a class at a time, stable in batch order; strip
-  height = the smallest number of subtiles (2..6) for which the strips in use fit the rounds of
-  n_cu strips the batch needs at full height."""
-  rows4 = np.where(ext <= 4, 4, (ext + 3) // 4 * 4)
-  total16 = (int(rows4.sum()) + 15) // 16
-  rounds = (total16 + SUB * n_cu - 1) // (SUB * n_cu)
-  target = min(rounds * n_cu, bins)
-  cap = min(max((total16 + target - 1) // target, 2), SUB)
-  while True:
-    fill = np.zeros(bins, int)
-    mols = [[] for _ in range(bins)]
-    for rows in range(32, 0, -4):
-      items = [b for b in range(len(ext)) if rows4[b] == rows]
-      k = 0
-      for bi in range(bins):
-        while k < len(items):
-          off = _place(fill[bi], rows)
-          if off + rows > 16 * cap:
-            break
-          mols[bi].append((items[k], off, int(ext[items[k]])))
-          fill[bi] = off + rows
-          k += 1
-        if k == len(items):
-          break
-      assert k == len(items)
-    used = max(i + 1 for i in range(bins) if mols[i])
-    if used <= target or cap >= SUB:
-      return [(mols[i], (fill[i] + 15) // 16) for i in range(used)]
-    cap += 1
+from strip_mirror import INTS, SUB, plan_strips_mirror  # noqa: E402
 
 
 def _check_plan(buf, ext, n_cu):
