@@ -213,7 +213,7 @@ __device__ __forceinline__ void forward_half(KArgs& a, const TileDesc (&td)[MT],
 #pragma unroll
       for (int t = 0; t < (FK == 1 ? KHT : 1); ++t) {
         int k = lnz::cd_row(t, hh);
-        vreg[m][t] = (k < K && j < N) ? a.V[((int64_t)td[m].ta * N + j) * K + k] : 0.0f;
+        vreg[m][t] = (k < K && j < N) ? finite_or_zero(a.V[((int64_t)td[m].ta * N + j) * K + k]) : 0.0f;
       }
     }
   }

@@ -144,7 +144,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       const int own = rowinfo[nrow];
       if (own >= 0 && rowinfo[srow] == own) {
         const int lnode = nrow - mstart[own], k = srow - mstart[own];
-        if (lnode < N && k < K) v = a.V[((int64_t)mid[own] * N + lnode) * K + k];
+        if (lnode < N && k < K) v = finite_or_zero(a.V[((int64_t)mid[own] * N + lnode) * K + k]);
       }
     }
     Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = v;
@@ -695,7 +695,7 @@ __device__ __forceinline__ void strip_gain_grad(KArgs& a, const int32_t* __restr
       const int own = rowinfo[nrow];
       if (own >= 0 && rowinfo[srow] == own) {
         const int lnode = nrow - mstart[own], k = srow - mstart[own];
-        if (lnode < N && k < K) v = a.V[((int64_t)mid[own] * N + lnode) * K + k];
+        if (lnode < N && k < K) v = finite_or_zero(a.V[((int64_t)mid[own] * N + lnode) * K + k]);
       }
     }
     Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = v;

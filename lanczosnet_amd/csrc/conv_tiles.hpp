@@ -55,6 +55,14 @@ __device__ __forceinline__ int row_group_mask(int nA, int nB, int split) {
   return ((1 << ((nA + 7) >> 3)) - 1) | (((1 << ((nB + 7) >> 3)) - 1) << (split >> 3));
 }
 
+// Molecules that share a tile or a strip meet in the matrix instructions (0 x NaN = NaN): a
+// non-finite Ritz entry (a degenerate molecule of AdaLanczosNet's in-model Lanczos layer, whose
+// learned Laplacian is 0 / 0 when every node carries the same embedding) is staged as 0, so that
+// it stays with its own molecule, as it does in the reference's batched products.
+__device__ __forceinline__ float finite_or_zero(float v) {
+  return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u ? 0.0f : v;
+}
+
 // Ritz tile [node row][slot row] of one node tile, block diagonal: element (jj, rho) belongs to
 // the molecule owning BOTH rows, V[mol][local node][local slot] (zero elsewhere / beyond N, K).
 __device__ __forceinline__ float ritz_tile_elem(KArgs& a, const TileDesc& t, int jj, int rho) {
@@ -63,7 +71,7 @@ __device__ __forceinline__ float ritz_tile_elem(KArgs& a, const TileDesc& t, int
   const int k = sfirst ? rho : rho - t.split;
   const int mol = first ? t.ta : t.tb;
   const bool ok = sfirst == first && k < a.K && row < a.N && mol >= 0;
-  return ok ? a.V[((int64_t)mol * a.N + row) * a.K + k] : 0.0f;
+  return ok ? finite_or_zero(a.V[((int64_t)mol * a.N + row) * a.K + k]) : 0.0f;
 }
 
 }  // namespace

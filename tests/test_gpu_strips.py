@@ -116,3 +116,49 @@ def test_strip_forward_matches_the_tile_kernels_and_the_oracle(B, n_cu, nmin, nm
                                    V.cpu().numpy(), b['node_mask'], dtype=np.float64)
   got = s_strip.cpu().numpy()
   assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('strips', ['1', '0'])
+def test_a_non_finite_ritz_block_stays_with_its_molecule(strips, monkeypatch):
+  """Molecules that share a strip (or a pair tile) meet in the matrix instructions, where
+  0 x NaN = NaN: the kernels stage a non-finite Ritz entry as 0 (csrc/conv_tiles.hpp,
+  finite_or_zero), so that a degenerate molecule — AdaLanczosNet's learned Laplacian is 0 / 0 for a
+  one-node molecule whose padding carries the same embedding (model/ada_lanczos_net.py:126-129) —
+  cannot change the scores of its neighbours, as it cannot in the reference's batched products."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNet
+  from lanczosnet_amd.synthetic import draw_batch
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  P = oracle.make_lanczosnet_params(cfg, 3)
+  net = LanczosNet(make_model_config(cfg)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  net = net.to(DEV)
+  B = 93
+  b = draw_batch(B, seed=5, n_min=1, n_max=12)  # N = 12: pair tiles as well as strips
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+  plan = net._plan()
+  Lp = ops.pack_laplacian_for(plan, L)
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  nf, mk = t(b['node_feat']), t(b['node_mask'].astype(np.uint8))
+  tiles = ops.plan_tiles(mk, True)
+  monkeypatch.setenv('LNZ_STRIPS', strips)
+  bad = [7, 40, 78]
+  V_nan, V_zero = V.clone(), V.clone()
+  V_nan[bad[0]] = float('nan')
+  V_nan[bad[1]] = float('inf')
+  V_nan[bad[2], 0, 0] = float('-inf')
+  V_zero[bad[0]] = 0
+  V_zero[bad[1]] = 0
+  V_zero[bad[2], 0, 0] = 0
+  with torch.no_grad():
+    s_nan = ops.lanczosnet_forward(plan, nf, Lp, V_nan, G, mk, tiling=tiles)
+    s_zero = ops.lanczosnet_forward(plan, nf, Lp, V_zero, G, mk, tiling=tiles)
+    s_ref = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+  assert torch.equal(s_nan, s_zero)
+  others = torch.ones(B, dtype=torch.bool, device=DEV)
+  others[bad] = False
+  assert torch.equal(s_nan[others], s_ref[others])
