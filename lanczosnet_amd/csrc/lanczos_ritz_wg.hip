@@ -34,6 +34,9 @@ constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNT = LNZ_RITZ_WG_THREADS;   // threads per workgroup (the reductions of a Lanczos step are split over all of them)
 constexpr int kWaves = kNT / 64;
 constexpr int kNMax = 192;   // largest graph one workgroup owns
+#ifndef LNZ_RITZ_ONE_WAVE_MAX
+#define LNZ_RITZ_ONE_WAVE_MAX 64   // graphs up to this size run their Lanczos phase on one wavefront
+#endif
 // LDS a workgroup may ask for: the CU has 160 KB; a request of 163,712 B was refused by the runtime
 // (HSA_STATUS_ERROR_INVALID_ALLOCATION) where 163,020 B had launched — keep 2 KB clear
 constexpr int kLdsMax = 160 * 1024 - 2048;
@@ -50,15 +53,29 @@ struct WgFixed {  // fixed part of the LDS block
   float sgn[kNMax];
 };
 
-__host__ __device__ inline size_t wg_a_bytes(int N) {
+// Floats per row of the staged A.  Eight-wave Lanczos phase: odd ("thread i reads row i" is conflict
+// free for single words).  One-wave phase (basis in LDS, n <= 64): the lanes read their rows four
+// columns at a time — a multiple of four that is not one of eight (sixteen lanes' ds_read_b128 then
+// cover every bank once).
+__host__ __device__ inline int wg_a_pitch4(int N) {
+  const int p = (N + 3) & ~3;
+  return (p & 7) ? p : p + 4;
+}
+
+__host__ __device__ inline size_t wg_a_bytes(int N, bool qg) {
   size_t a = (size_t)N * (size_t)(N | 1) * sizeof(float);
+  if (!qg) {
+    const size_t a1 = (size_t)(N < LNZ_RITZ_ONE_WAVE_MAX ? N : LNZ_RITZ_ONE_WAVE_MAX) * wg_a_pitch4(N) * sizeof(float);
+    a = a < a1 ? a1 : a;
+  }
   const size_t ql = (size_t)kWaves * 2 * (size_t)N * sizeof(double);  // QL's per-wave (d, e) copies
   a = a < ql ? ql : a;
   return (a + 15) & ~(size_t)15;
 }
 
 inline size_t wg_lds_bytes(int N, bool qg) {
-  return sizeof(WgFixed) + (qg ? 0 : (size_t)N * (size_t)(N | 1) * sizeof(double)) + wg_a_bytes(N);
+  // (+ 8: A starts on a 16-byte boundary behind an odd number of basis doubles)
+  return sizeof(WgFixed) + (qg ? 0 : (size_t)N * (size_t)(N | 1) * sizeof(double) + 8) + wg_a_bytes(N, qg);
 }
 
 __device__ __forceinline__ double rcp_nr(double x) {  // 1/x: hardware seed + one Newton step
@@ -109,16 +126,302 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
   for (; i <= t; ++i) row(d[i], i > s ? e2[i - 1] : 0.0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The Lanczos phase on ONE wavefront (basis in LDS, n <= 64).  A step of the eight-wave form below
+// is a chain of ~7-10 workgroup barriers, each in front of one or two LDS round trips around a few
+// dozen FMAs: ~1.3 k cycles per phase whatever the work.  Here lane l owns row l
+// of the residual, basis vector l in the Gram-Schmidt dot products, and nothing in a step waits
+// for another wave: the only cross-lane traffic is the broadcast of a
+// vector through LDS (same wave: in order, no barrier) and three wave reductions by DPP.  The
+// other seven waves wait at the barrier behind the phase.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, bit-identical in every lane (symmetric pairings inside a row of 16, the
+// four row sums added in a fixed order)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  const double s0 = readlane_f64(v, 0), s1 = readlane_f64(v, 16);
+  const double s2 = readlane_f64(v, 32), s3 = readlane_f64(v, 48);
+  return (s0 + s1) + (s2 + s3);
+}
+
+// LDS traffic between the lanes of one wave: in order in hardware; this keeps the compiler from
+// moving a load over the store it depends on
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) double* lds_cd;
+typedef const __attribute__((address_space(3))) d2_t* lds_cd2;
+typedef const __attribute__((address_space(3))) f4_t* lds_cf4;
+
+// The three inner products of a step, each a walk over LDS in chunks of eight with TWO chunks in
+// flight: the loads of chunk i + 1 are issued before the FMAs of chunk i — one wave has nobody to
+// hide an LDS round trip behind.  Four (two) independent accumulators, combined in a fixed order.
+// Not inlined: inlined six times into the step the three pipelines took 256 registers + 178 spills.
+
+// sum_r q[r] z[r], r < n: q = this lane's own words (stride 1), z = a broadcast vector (16-byte
+// aligned)
+__device__ __noinline__ double walk_own(lds_cd q, lds_cd z, const int n_) {
+  const int n = __builtin_amdgcn_readfirstlane(n_);   // (arguments arrive in vector registers)
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+  struct Ch { d2_t z[4]; double a[8]; };
+  auto ld = [&](Ch& ch, const int r) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ch.z[u] = *(lds_cd2)(z + r + 2 * u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ch.a[u] = q[r + u];
+  };
+  auto fm = [&](const Ch& ch) {
+    p0 = fma(ch.a[0], ch.z[0][0], p0), p1 = fma(ch.a[1], ch.z[0][1], p1);
+    p2 = fma(ch.a[2], ch.z[1][0], p2), p3 = fma(ch.a[3], ch.z[1][1], p3);
+    p0 = fma(ch.a[4], ch.z[2][0], p0), p1 = fma(ch.a[5], ch.z[2][1], p1);
+    p2 = fma(ch.a[6], ch.z[3][0], p2), p3 = fma(ch.a[7], ch.z[3][1], p3);
+  };
+  const int nc = n >> 3;
+  Ch A8, B8;
+  if (nc > 0) {
+    // (the loop body is branch free: behind a conditional load the wait counters fall back to
+    // "everything", which would wait for the chunk that was just requested)
+    ld(A8, 0);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 < nc; i += 2) {
+      ld(B8, 8 * (i + 1));
+      fm(A8);
+      ld(A8, 8 * (i + 2));
+      fm(B8);
+    }
+    if (i + 1 < nc) {
+      ld(B8, 8 * (i + 1));
+      fm(A8);
+      fm(B8);
+    } else {
+      fm(A8);
+    }
+  }
+  for (int r = 8 * nc; r < n; ++r) p0 = fma(q[r], z[r], p0);
+  return (p0 + p1) + (p2 + p3);
+}
+
+// sum_k q[k * ld] c[k], k < cnt: q = this lane's row of every basis vector, c = a broadcast vector
+__device__ __noinline__ double walk_strided(lds_cd q, const int ld_v, lds_cd c, const int cnt_) {
+  const int ld_ = __builtin_amdgcn_readfirstlane(ld_v), cnt = __builtin_amdgcn_readfirstlane(cnt_);
+  double p0 = 0.0, p1 = 0.0;
+  struct Ch { d2_t z[4]; double a[8]; };
+  auto ld = [&](Ch& ch, const int k) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ch.z[u] = *(lds_cd2)(c + k + 2 * u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ch.a[u] = q[(k + u) * ld_];
+  };
+  auto fm = [&](const Ch& ch) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p0 = fma(ch.a[2 * u], ch.z[u][0], p0), p1 = fma(ch.a[2 * u + 1], ch.z[u][1], p1);
+  };
+  const int nc = cnt >> 3;
+  Ch A8, B8;
+  if (nc > 0) {
+    // (the loop body is branch free: behind a conditional load the wait counters fall back to
+    // "everything", which would wait for the chunk that was just requested)
+    ld(A8, 0);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 < nc; i += 2) {
+      ld(B8, 8 * (i + 1));
+      fm(A8);
+      ld(A8, 8 * (i + 2));
+      fm(B8);
+    }
+    if (i + 1 < nc) {
+      ld(B8, 8 * (i + 1));
+      fm(A8);
+      fm(B8);
+    } else {
+      fm(A8);
+    }
+  }
+  for (int k = 8 * nc; k < cnt; ++k) p0 = fma(q[k * ld_], c[k], p0);
+  return p0 + p1;
+}
+
+// sum_c a[c] z[c], c < n4 (a multiple of four): a = this lane's fp32 row of A (16-byte aligned)
+__device__ __noinline__ double walk_arow(const __attribute__((address_space(3))) float* a, lds_cd z,
+                                         const int n4_) {
+  const int n4 = __builtin_amdgcn_readfirstlane(n4_);
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+  struct Ch { d2_t z[4]; f4_t xa, xb; };
+  auto ld = [&](Ch& ch, const int c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ch.z[u] = *(lds_cd2)(z + c + 2 * u);
+    ch.xa = *(lds_cf4)(a + c), ch.xb = *(lds_cf4)(a + c + 4);
+  };
+  auto fm = [&](const Ch& ch) {
+    p0 = fma((double)ch.xa[0], ch.z[0][0], p0), p1 = fma((double)ch.xa[1], ch.z[0][1], p1);
+    p2 = fma((double)ch.xa[2], ch.z[1][0], p2), p3 = fma((double)ch.xa[3], ch.z[1][1], p3);
+    p0 = fma((double)ch.xb[0], ch.z[2][0], p0), p1 = fma((double)ch.xb[1], ch.z[2][1], p1);
+    p2 = fma((double)ch.xb[2], ch.z[3][0], p2), p3 = fma((double)ch.xb[3], ch.z[3][1], p3);
+  };
+  const int nc = n4 >> 3;
+  Ch A8, B8;
+  if (nc > 0) {
+    // (the loop body is branch free: behind a conditional load the wait counters fall back to
+    // "everything", which would wait for the chunk that was just requested)
+    ld(A8, 0);
+    int i = 0;
+#pragma unroll 1
+    for (; i + 2 < nc; i += 2) {
+      ld(B8, 8 * (i + 1));
+      fm(A8);
+      ld(A8, 8 * (i + 2));
+      fm(B8);
+    }
+    if (i + 1 < nc) {
+      ld(B8, 8 * (i + 1));
+      fm(A8);
+      fm(B8);
+    } else {
+      fm(A8);
+    }
+  }
+  if (n4 & 4) {   // one group of four left
+    const int c = 8 * nc;
+    const d2_t za = *(lds_cd2)(z + c), zc = *(lds_cd2)(z + c + 2);
+    const f4_t xa = *(lds_cf4)(a + c);
+    p0 = fma((double)xa[0], za[0], p0), p1 = fma((double)xa[1], za[1], p1);
+    p2 = fma((double)xa[2], zc[0], p2), p3 = fma((double)xa[3], zc[1], p3);
+  }
+  return (p0 + p1) + (p2 + p3);
+}
+
+// n <= 64: lane l owns row l of the residual and basis vector l of the Gram-Schmidt dot products.
+// (Two rows per lane — n up to 128 — were measured as well: 3 % slower than the eight-wave form at
+// n = 68, 13 % at n = 100; one row per lane is 20 % faster at n = 64.)
+static_assert(LNZ_RITZ_ONE_WAVE_MAX <= 64, "one row of the residual per lane");
+__device__ __forceinline__ int lanczos_one_wave(WgFixed& sm, double* __restrict__ Qt,
+                                                const float* __restrict__ As, const int n,
+                                                const int LD, const int LA, const int lane) {
+  const bool vr = lane < n;
+  const int n4 = (n + 3) & ~3;
+  int nrestart = 0;
+  const lds_cd zb = (lds_cd)sm.zb, cb = (lds_cd)sm.cb, Ql = (lds_cd)Qt;
+
+  // x <- (I - Q Q^T) x once or twice over basis vectors 0..cnt-1 (x: this lane's row); returns the
+  // accumulated coefficient on vector jidx.  The second pass runs where the first removed more
+  // than 99 % of the squared length (the rule of the eight-wave form).
+  auto cgs2 = [&](double& x, const int cnt, const int jidx) -> double {
+    double coef = 0.0;
+    const bool vk = lane < cnt;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (vr) sm.zb[lane] = x;
+      wave_sync();
+      // ---- c_k = <q_k, x>: lane k walks its own vector, x is a broadcast read
+      // (lanes beyond cnt walk rows that were never written: masked)
+      double c = walk_own(Ql + lane * LD, zb, n);
+      c = vk ? c : 0.0;
+      if (vk) sm.cb[lane] = c;
+      bool again = true;
+      if (pass == 0) {
+        const double xx = wave_sum_f64(x * x);    // (rows beyond n hold 0)
+        const double cc2 = wave_sum_f64(c * c);
+        again = !(cc2 <= 0.99 * xx);
+      }
+      wave_sync();
+      coef += sm.cb[jidx];
+      // ---- x -= sum_k c_k q_k: lanes along the rows of every vector, c a broadcast read
+      const double d = walk_strided(Ql + lane, LD, cb, cnt);
+      if (vr) x -= d;
+      wave_sync();   // cb and zb are rewritten by the next pass / the caller
+      if (!again) break;
+    }
+    return coef;
+  };
+
+  // deterministic, strictly positive, non-symmetric start vector (as lanczos_ritz.hip)
+  double w = 0.0;
+  if (vr) {
+    const unsigned hsh = (unsigned)(lane + 1) * 2654435761u;
+    w = 1.0 + (double)((hsh >> 8) & 0xffff) * (1.0 / 65536.0);
+  }
+  if (lane < 4 && n + lane < n4) sm.zb[n + lane] = 0.0;   // A w reads the vector four columns at a time
+  const __attribute__((address_space(3))) float* Al = (const __attribute__((address_space(3))) float*)As;
+  bool fresh = true;  // w is a start / restart vector: its norm is not a coupling beta
+  for (int j = 0; j < n; ++j) {
+    double beta, u;
+    for (;;) {
+      // ---- beta = |w| and u = A w from one broadcast of w
+      if (vr) sm.zb[lane] = w;
+      wave_sync();
+      u = walk_arow(Al + lane * LA, zb, n4);   // (lanes beyond n walk rows that were never staged)
+      u = vr ? u : 0.0;
+      beta = sqrt(wave_sum_f64(w * w));
+      wave_sync();   // zb is rewritten below
+      if (fresh || beta > kBreakdownTol) break;
+      // breakdown: span(q_0..q_{j-1}) is A-invariant.  Restart from the unit vector with the
+      // largest residual against the basis (residual^2 >= (n-j)/n > 0; ties: the lowest row);
+      // T[j-1][j] stays 0.
+      ++nrestart;
+      double best = -1.0;
+      int cand = lane;
+      if (vr) {
+        double s = 0.0;
+        for (int i = 0; i < j; ++i) {
+          const double qv = Qt[(size_t)i * LD + lane];
+          s = fma(qv, qv, s);
+        }
+        best = 1.0 - s;
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oc = __shfl_xor(cand, off, 64);
+        if (ob > best || (ob == best && oc < cand)) best = ob, cand = oc;
+      }
+      w = (lane == cand) ? 1.0 : 0.0;
+      (void)cgs2(w, j, 0);
+      fresh = true;
+    }
+    if (!fresh && lane == 0) sm.ee[j - 1] = beta;
+    fresh = false;
+    const double binv = 1.0 / beta;
+    double x = u * binv;  // A q_j
+    if (vr) Qt[(size_t)j * LD + lane] = w * binv;
+    wave_sync();
+    const double alpha = cgs2(x, j + 1, j);
+    if (lane == 0) sm.dd[j] = alpha;
+    w = x;
+  }
+  return nrestart;
+}
+
 template <bool QG>
 __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info, double* __restrict__ ws,
-    const bool force_ql) {
+    const int mode_flags) {  // bit 0: the QL sweep; bit 1: the eight-wave Lanczos phase
+  const bool force_ql = (mode_flags & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   WgFixed& sm = *reinterpret_cast<WgFixed*>(smem_raw);
   const int LD = N | 1;  // doubles per basis row: odd -> "lane i reads row i" is conflict free
-  const int LA = N | 1;  // floats per row of A
   double* Qt;
   float* As;
   if constexpr (QG) {
@@ -126,19 +429,23 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     As = reinterpret_cast<float*>(smem_raw + sizeof(WgFixed));
   } else {
     Qt = reinterpret_cast<double*>(smem_raw + sizeof(WgFixed));
-    As = reinterpret_cast<float*>(Qt + (size_t)N * LD);
+    As = reinterpret_cast<float*>(Qt + (((size_t)N * LD + 1) & ~(size_t)1));
   }
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int n = n_nodes[b];
   n = n < 0 ? 0 : (n > N ? N : n);
+  // graphs of up to 64 nodes with the basis in LDS: the Lanczos phase on one wavefront
+  const bool one_wave = !QG && n <= LNZ_RITZ_ONE_WAVE_MAX && !(mode_flags & 2);
+  const int LA = one_wave ? wg_a_pitch4(N) : (N | 1);  // floats per row of A
   const int kk = K < n ? K : n;  // number of non-padded eigen slots
 
   // ---- stage the n x n block of A: wave per row, lanes along the row (coalesced when sc == 1)
   {
     const float* Ab = A + (int64_t)b * sb;
+    const int nc = one_wave ? (n + 3) & ~3 : n;   // (one-wave phase: rows are read four columns at a time)
     for (int r = wave; r < n; r += kWaves)
-      for (int c = lane; c < n; c += 64) As[r * LA + c] = Ab[r * sr + c * sc];
+      for (int c = lane; c < nc; c += 64) As[r * LA + c] = c < n ? Ab[r * sr + c * sc] : 0.0f;
   }
   if (tid < kNMax) {
     sm.dd[tid] = 0.0;
@@ -157,7 +464,11 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
 #define LNZ_LT0
 #define LNZ_LACC(x)
 #endif
-  if (n > 0) {
+  if (n > 0 && one_wave) {
+    if (wave == 0) nrestart = lanczos_one_wave(sm, Qt, As, n, LD, LA, lane);
+    __syncthreads();
+  }
+  if (n > 0 && !one_wave) {
     // (output row, segment) split of the length-n reductions with n outputs (A w; w -= Q c)
     const int row_n = tid % n, seg_n = tid / n;
     int nss = kNT / n;
@@ -407,6 +718,8 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       w = x;
     }
     __syncthreads();
+  }
+  if (n > 0) {
 #ifdef LNZ_PROFILE_PHASES
     tp1 = clock64();
 #endif
@@ -427,7 +740,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     double* Te = Td + N;
     double* Te2 = Te + N;
     double* zv = Te2 + N;  // [n][kk]: component i of selected vector q at zv[i * kk + q]
-    bool solved = (size_t)3 * N * sizeof(double) + (size_t)kk * n * sizeof(double) <= wg_a_bytes(N) &&
+    bool solved = (size_t)3 * N * sizeof(double) + (size_t)kk * n * sizeof(double) <= wg_a_bytes(N, QG) &&
                   !force_ql;
     if (solved) {
       if (tid < n) {
@@ -793,7 +1106,8 @@ extern "C" int64_t lnz_lanczos_ritz_workspace_bytes(int B, int N) {
 
 // Shared by lnz_lanczos_ritz (lanczos_ritz.hip) and lnz_lanczos_ritz_ws.
 // flags: bit 0 = the basis goes to the workspace even if it would fit in LDS; bit 1 = the QL sweep
-// instead of the parallel tridiagonal eigensolver (both for testing).
+// instead of the parallel tridiagonal eigensolver; bit 2 = the eight-wave Lanczos phase where the
+// one-wave form would run (basis in LDS) — all for testing.
 int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                        const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                        int32_t* info, void* workspace, int64_t workspace_bytes, int flags,
@@ -831,7 +1145,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N,
-                       K, D, V, info, (double*)workspace, (flags & 2) != 0);
+                       K, D, V, info, (double*)workspace, (flags >> 1) & 3);
     const int rc = lnz::check_launch("lnz_lanczos_ritz");
     if (owned) (void)hipFreeAsync(owned, s);
     return rc;
@@ -839,7 +1153,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
   auto kfn = lanczos_ritz_wg_kernel<false>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N, K,
-                     D, V, info, (double*)nullptr, (flags & 2) != 0);
+                     D, V, info, (double*)nullptr, (flags >> 1) & 3);
   return lnz::check_launch("lnz_lanczos_ritz");
 }
 

@@ -153,9 +153,14 @@ def test_workgroup_ritz_kernel_matches_eigh(N, p):
   assert c >= 3
   if p < 0.1:
     assert int((info % 256).sum()) > 0   # the restart branch ran
-  # the workspace variant is the same arithmetic in the same order: bit-identical results
+  # the eight-wave Lanczos phase (what runs with the basis in the workspace) with the basis in LDS
+  # and in the workspace: the same arithmetic in the same order, bit-identical results; the
+  # one-wave phase of the LDS placement sums in another order
   D2, V2 = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel='workgroup_ws')
-  assert torch.equal(D, D2) and torch.equal(V, V2)
+  Dm, Vm = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel='workgroup_mw')
+  assert torch.equal(Dm, D2) and torch.equal(Vm, V2)
+  assert (D - D2).abs().max().item() < 1e-6
+  check_ritz(D2.cpu().numpy(), V2.cpu().numpy(), Dr, Vr, ns, full, Kk, powers=(1, 5))
   # the QL sweep (the fallback of the parallel tridiagonal eigensolver), forced: same function
   Dq, Vq, iq = ops.lanczos_ritz(_t(A), _t(ns), Kk, return_info=True, kernel='workgroup_ql')
   assert (iq.cpu().numpy() >= 256).all()
@@ -253,7 +258,7 @@ def _structured_graphs():
   return gs
 
 
-@pytest.mark.parametrize('kernel', ['auto', 'workgroup_ws', 'workgroup_ql'])
+@pytest.mark.parametrize('kernel', ['auto', 'workgroup_ws', 'workgroup_ql', 'workgroup_mw'])
 def test_workgroup_ritz_kernel_on_degenerate_spectra(kernel):
   """Paths, cycles, grids, a hypercube, complete bipartite, barbell, star and disjoint Petersen
   graphs: multiplicities up to 20.  K = N so that no top-K cut splits a cluster; eigenvalues to

@@ -1,6 +1,12 @@
 # scratch: the command file of the last gpurun call
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_strips.py -q -x -k "non_finite" 2>&1 | tail -5
-timeout 600 python tools/experiments/ada_strip_one.py 32 2>&1 | grep -v "nan molecules" | tail -8
-timeout 900 python tools/experiments/ada_strip_fuzz.py 0 100 2>&1 | tail -4
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_graph.py tests/test_graph_runner_dropin.py -x -q 2>&1 | tail -3
+timeout 600 python tools/bench_ritz_wg.py 2>/dev/null > gpurun_out/ritz_wg.jsonl
+python -c "
+import sys, json
+for l in open('gpurun_out/ritz_wg.jsonl'):
+    if l.startswith('{'):
+        d = json.loads(l); print(d['case'], d['B'], d['N'], {k: v['ms'] for k, v in d.items() if isinstance(v, dict)})
+"
