@@ -35,7 +35,7 @@ constexpr int kNT = LNZ_RITZ_WG_THREADS;   // threads per workgroup (the reducti
 constexpr int kWaves = kNT / 64;
 constexpr int kNMax = 192;   // largest graph one workgroup owns
 #ifndef LNZ_RITZ_ONE_WAVE_MAX
-#define LNZ_RITZ_ONE_WAVE_MAX 64   // graphs up to this size run their Lanczos phase on one wavefront
+#define LNZ_RITZ_ONE_WAVE_MAX 128   // graphs up to this size (basis in LDS) run their Lanczos phase on one or two wavefronts
 #endif
 // LDS a workgroup may ask for: the CU has 160 KB; a request of 163,712 B was refused by the runtime
 // (HSA_STATUS_ERROR_INVALID_ALLOCATION) where 163,020 B had launched — keep 2 KB clear
@@ -311,45 +311,121 @@ __device__ __noinline__ double walk_arow(const __attribute__((address_space(3)))
   return (p0 + p1) + (p2 + p3);
 }
 
-// n <= 64: lane l owns row l of the residual and basis vector l of the Gram-Schmidt dot products.
-// (Two rows per lane — n up to 128 — were measured as well: 3 % slower than the eight-wave form at
-// n = 68, 13 % at n = 100; one row per lane is 20 % faster at n = 64.)
-static_assert(LNZ_RITZ_ONE_WAVE_MAX <= 64, "one row of the residual per lane");
-__device__ __forceinline__ int lanczos_one_wave(WgFixed& sm, double* __restrict__ Qt,
-                                                const float* __restrict__ As, const int n,
-                                                const int LD, const int LA, const int lane) {
-  const bool vr = lane < n;
+// W = 1 (n <= 64): lane l owns row l of the residual and basis vector l of the Gram-Schmidt dot
+// products; no workgroup barrier at all.
+// W = 2 (64 < n <= 128): wave v owns rows 64 v + l; a dot product's row range is split between the
+// two waves (partials through LDS, summed in a fixed order by both), each wave keeps its own copy
+// of the coefficients, and a step has four workgroup barriers (+ two for a second Gram-Schmidt
+// pass) instead of the eight-wave form's seven to ten — with a quarter of the LDS round trips.
+// The waves without a part keep the barriers company (lanczos_idle_waves).
+// (Two rows per lane on ONE wave were measured as well: 3 % slower than the eight-wave form at
+// n = 68, 13 % at n = 100.)
+struct DuoScratch {   // lives in WgFixed::part (512 doubles)
+  double pc[2][128];  // partial dot products by wave
+  double pn[2];       // partial |w|^2
+  double px[2];       // partial |x|^2
+  double best[2];     // restart: largest residual by wave
+  int cand[2];
+  int pad_[2];        // (cb1 on a 16-byte boundary: the coefficients are read in pairs)
+  double cb1[128];    // wave 1's copy of the coefficients (wave 0 uses WgFixed::cb)
+};
+static_assert(sizeof(DuoScratch) <= sizeof(double) * kNT, "DuoScratch lives in WgFixed::part");
+
+// The waves without a part arrive at every barrier of the phase and leave with its last one.  The
+// "last" mark alternates between two words by barrier parity: a wave reads word k & 1 behind
+// barrier k, the mark for barrier k is written behind barrier k - 1 — into the word nobody reads
+// then, so a wave can never see it one barrier early.
+__device__ __forceinline__ void lanczos_idle_waves(WgFixed& sm) {
+  for (int k = 0;; ++k) {
+    __syncthreads();
+    if (*reinterpret_cast<volatile int*>(&sm.perm[k & 1]) != 0) break;
+  }
+}
+
+template <int W>
+__device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Qt,
+                                             const float* __restrict__ As, const int n,
+                                             const int LD, const int LA, const int lane, const int wave,
+                                             long long* tl = nullptr) {  // tl: LNZ_PROFILE_PHASES (A w, dots, sums, update)
+#ifdef LNZ_PROFILE_PHASES
+  long long _lt = clock64();
+#define LNZ_WT(i) { const long long _l1 = clock64(); tl[i] += _l1 - _lt; _lt = _l1; }
+#else
+#define LNZ_WT(i)
+#endif
+  const int row = 64 * wave + lane;
+  const bool vr = row < n;
   const int n4 = (n + 3) & ~3;
   int nrestart = 0;
-  const lds_cd zb = (lds_cd)sm.zb, cb = (lds_cd)sm.cb, Ql = (lds_cd)Qt;
+  DuoScratch& ds = *reinterpret_cast<DuoScratch*>(sm.part);
+  const lds_cd zb = (lds_cd)sm.zb, Ql = (lds_cd)Qt;
+  double* cbw = (W == 2 && wave == 1) ? ds.cb1 : sm.cb;   // this wave's coefficients
+  const lds_cd cb = (lds_cd)cbw;
+  // this wave's part of a dot product's row range (even bounds: the broadcast vector is read in pairs)
+  const int nh = W == 1 ? n : ((n >> 1) + 7) & ~7;
+  const int h0 = (W == 2 && wave == 1) ? nh : 0, h1 = (W == 2 && wave == 0) ? nh : n;
+  int kbar = 0;   // workgroup barriers of this phase so far (W = 2; see lanczos_idle_waves)
+  auto wg_bar = [&]() {
+    __syncthreads();
+    ++kbar;
+  };
+  auto bar = [&]() {
+    if constexpr (W == 1) wave_sync();
+    else wg_bar();
+  };
+  // sum of one value per lane over the cooperating waves, identical in all of them; slot: where the
+  // partials meet (the barrier after the store is the caller's)
+  auto put_partial = [&](double (&slot)[2], const double v) {
+    const double s = wave_sum_f64(v);
+    if constexpr (W == 2) {
+      if (lane == 0) slot[wave] = s;
+    }
+    return s;
+  };
 
   // x <- (I - Q Q^T) x once or twice over basis vectors 0..cnt-1 (x: this lane's row); returns the
   // accumulated coefficient on vector jidx.  The second pass runs where the first removed more
   // than 99 % of the squared length (the rule of the eight-wave form).
   auto cgs2 = [&](double& x, const int cnt, const int jidx) -> double {
     double coef = 0.0;
-    const bool vk = lane < cnt;
+    const bool vk0 = lane < cnt, vk1 = lane + 64 < cnt;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      if (vr) sm.zb[lane] = x;
-      wave_sync();
-      // ---- c_k = <q_k, x>: lane k walks its own vector, x is a broadcast read
+      if (vr) sm.zb[row] = x;
+      bar();
+      // ---- c_k = <q_k, x>: lane k walks its own vector over this wave's rows, x is a broadcast read
       // (lanes beyond cnt walk rows that were never written: masked)
-      double c = walk_own(Ql + lane * LD, zb, n);
-      c = vk ? c : 0.0;
-      if (vk) sm.cb[lane] = c;
+      double c0 = walk_own(Ql + lane * LD + h0, zb + h0, h1 - h0), c1 = 0.0;
+      c0 = vk0 ? c0 : 0.0;
+      if (W == 2 && cnt > 64) {
+        c1 = walk_own(Ql + (lane + 64) * LD + h0, zb + h0, h1 - h0);
+        c1 = vk1 ? c1 : 0.0;
+      }
+      double xx = put_partial(ds.px, x * x);   // (rows beyond n hold 0)
+      if constexpr (W == 2) {
+        ds.pc[wave][lane] = c0;
+        ds.pc[wave][lane + 64] = c1;
+        wg_bar();
+        c0 = ds.pc[0][lane] + ds.pc[1][lane];
+        c1 = ds.pc[0][lane + 64] + ds.pc[1][lane + 64];
+        xx = ds.px[0] + ds.px[1];
+      }
+      LNZ_WT(1)
+      if (vk0) cbw[lane] = c0;
+      if (W == 2 && vk1) cbw[lane + 64] = c1;
       bool again = true;
       if (pass == 0) {
-        const double xx = wave_sum_f64(x * x);    // (rows beyond n hold 0)
-        const double cc2 = wave_sum_f64(c * c);
+        const double cc2 = wave_sum_f64(fma(c0, c0, c1 * c1));
         again = !(cc2 <= 0.99 * xx);
       }
       wave_sync();
-      coef += sm.cb[jidx];
+      coef += cbw[jidx];
+      LNZ_WT(2)
       // ---- x -= sum_k c_k q_k: lanes along the rows of every vector, c a broadcast read
-      const double d = walk_strided(Ql + lane, LD, cb, cnt);
+      const double d = walk_strided(Ql + row, LD, cb, cnt);
       if (vr) x -= d;
-      wave_sync();   // cb and zb are rewritten by the next pass / the caller
+      wave_sync();   // the coefficients are rewritten by the next pass / call (zb, pc: behind a barrier)
+      LNZ_WT(3)
       if (!again) break;
     }
     return coef;
@@ -358,33 +434,36 @@ __device__ __forceinline__ int lanczos_one_wave(WgFixed& sm, double* __restrict_
   // deterministic, strictly positive, non-symmetric start vector (as lanczos_ritz.hip)
   double w = 0.0;
   if (vr) {
-    const unsigned hsh = (unsigned)(lane + 1) * 2654435761u;
+    const unsigned hsh = (unsigned)(row + 1) * 2654435761u;
     w = 1.0 + (double)((hsh >> 8) & 0xffff) * (1.0 / 65536.0);
   }
-  if (lane < 4 && n + lane < n4) sm.zb[n + lane] = 0.0;   // A w reads the vector four columns at a time
+  if (wave == 0 && lane < 4 && n + lane < n4) sm.zb[n + lane] = 0.0;   // A w reads the vector four columns at a time
   const __attribute__((address_space(3))) float* Al = (const __attribute__((address_space(3))) float*)As;
   bool fresh = true;  // w is a start / restart vector: its norm is not a coupling beta
   for (int j = 0; j < n; ++j) {
     double beta, u;
     for (;;) {
       // ---- beta = |w| and u = A w from one broadcast of w
-      if (vr) sm.zb[lane] = w;
-      wave_sync();
-      u = walk_arow(Al + lane * LA, zb, n4);   // (lanes beyond n walk rows that were never staged)
+      if (vr) sm.zb[row] = w;
+      bar();
+      u = walk_arow(Al + row * LA, zb, n4);   // (lanes beyond n walk rows that were never staged)
       u = vr ? u : 0.0;
-      beta = sqrt(wave_sum_f64(w * w));
-      wave_sync();   // zb is rewritten below
+      double nn = put_partial(ds.pn, w * w);
+      bar();   // zb is rewritten below
+      if constexpr (W == 2) nn = ds.pn[0] + ds.pn[1];
+      beta = sqrt(nn);
+      LNZ_WT(0)
       if (fresh || beta > kBreakdownTol) break;
       // breakdown: span(q_0..q_{j-1}) is A-invariant.  Restart from the unit vector with the
       // largest residual against the basis (residual^2 >= (n-j)/n > 0; ties: the lowest row);
       // T[j-1][j] stays 0.
       ++nrestart;
       double best = -1.0;
-      int cand = lane;
+      int cand = row;
       if (vr) {
         double s = 0.0;
         for (int i = 0; i < j; ++i) {
-          const double qv = Qt[(size_t)i * LD + lane];
+          const double qv = Qt[(size_t)i * LD + row];
           s = fma(qv, qv, s);
         }
         best = 1.0 - s;
@@ -395,19 +474,30 @@ __device__ __forceinline__ int lanczos_one_wave(WgFixed& sm, double* __restrict_
         const int oc = __shfl_xor(cand, off, 64);
         if (ob > best || (ob == best && oc < cand)) best = ob, cand = oc;
       }
-      w = (lane == cand) ? 1.0 : 0.0;
+      if constexpr (W == 2) {
+        if (lane == 0) ds.best[wave] = best, ds.cand[wave] = cand;
+        wg_bar();
+        const double b1 = ds.best[1];
+        best = ds.best[0], cand = ds.cand[0];
+        if (b1 > best) best = b1, cand = ds.cand[1];   // (equal: wave 0's row is the lower one)
+      }
+      w = (row == cand) ? 1.0 : 0.0;
       (void)cgs2(w, j, 0);
       fresh = true;
     }
-    if (!fresh && lane == 0) sm.ee[j - 1] = beta;
+    if (!fresh && wave == 0 && lane == 0) sm.ee[j - 1] = beta;
     fresh = false;
     const double binv = 1.0 / beta;
     double x = u * binv;  // A q_j
-    if (vr) Qt[(size_t)j * LD + lane] = w * binv;
-    wave_sync();
+    if (vr) Qt[(size_t)j * LD + row] = w * binv;
+    // (the barrier inside cgs2 orders this store before the basis reads)
     const double alpha = cgs2(x, j + 1, j);
-    if (lane == 0) sm.dd[j] = alpha;
+    if (wave == 0 && lane == 0) sm.dd[j] = alpha;
     w = x;
+  }
+  if constexpr (W == 2) {
+    if (wave == 0 && lane == 0) sm.perm[kbar & 1] = 1;   // releases the waves that kept the barriers company
+    __syncthreads();
   }
   return nrestart;
 }
@@ -435,7 +525,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int n = n_nodes[b];
   n = n < 0 ? 0 : (n > N ? N : n);
-  // graphs of up to 64 nodes with the basis in LDS: the Lanczos phase on one wavefront
+  // basis in LDS: the Lanczos phase on one wavefront (n <= 64) or two
   const bool one_wave = !QG && n <= LNZ_RITZ_ONE_WAVE_MAX && !(mode_flags & 2);
   const int LA = one_wave ? wg_a_pitch4(N) : (N | 1);  // floats per row of A
   const int kk = K < n ? K : n;  // number of non-padded eigen slots
@@ -456,7 +546,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
   int nrestart = 0;
   bool solved_out = false;  // the parallel eigensolver ran: V = Q S is formed at the output
 #ifdef LNZ_PROFILE_PHASES
-  long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
+  long long tp0 = clock64(), tp1 = tp0, tp2 = tp0, tq0 = tp0, tq1 = tp0, tq2 = tp0, tq3 = tp0;
   long long tl_mv = 0, tl_dot = 0, tl_red = 0, tl_upd = 0;   // Lanczos step parts (thread 0's clock)
 #define LNZ_LT0 long long _lt = clock64();
 #define LNZ_LACC(x) { const long long _l1 = clock64(); x += _l1 - _lt; _lt = _l1; }
@@ -464,9 +554,24 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
 #define LNZ_LT0
 #define LNZ_LACC(x)
 #endif
+  long long* tlw = nullptr;
+#ifdef LNZ_PROFILE_PHASES
+  long long tlw_[4] = {0, 0, 0, 0};
+  tlw = tlw_;
+#endif
   if (n > 0 && one_wave) {
-    if (wave == 0) nrestart = lanczos_one_wave(sm, Qt, As, n, LD, LA, lane);
+    if (n <= 64) {
+      if (wave == 0) nrestart = lanczos_waves<1>(sm, Qt, As, n, LD, LA, lane, 0, tlw);
+    } else {
+      if (tid == 0) sm.perm[0] = sm.perm[1] = 0;
+      __syncthreads();
+      if (wave < 2) nrestart = lanczos_waves<2>(sm, Qt, As, n, LD, LA, lane, wave, tlw);
+      else lanczos_idle_waves(sm);
+    }
     __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+    tl_mv = tlw_[0], tl_dot = tlw_[1], tl_red = tlw_[2], tl_upd = tlw_[3];
+#endif
   }
   if (n > 0 && !one_wave) {
     // (output row, segment) split of the length-n reductions with n outputs (A w; w -= Q c)
@@ -956,6 +1061,9 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       sm.perm[rank] = tid;
     }
     __syncthreads();
+#ifdef LNZ_PROFILE_PHASES
+    tq0 = clock64();
+#endif
     if (solved) {
       // ---- eigenvectors of the kk selected eigenvalues: twisted factorisation of T - lambda on the
       //      eigenvalue's block (the dlar1v / MRRR vector: stationary and progressive qd transforms,
@@ -972,38 +1080,106 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         const double tiny = kEps * (gs > 0.0 ? gs : 1.0);
         auto guard = [&](double v) { return fabs(v) < tiny ? (v < 0.0 ? -tiny : tiny) : v; };
         for (int i = 0; i < n; ++i) zv[(size_t)i * kk + q] = 0.0;
+        // Rows in chunks of eight whose LDS words are all requested before the dependent chain runs
+        // (read row by row, every step of the recurrences waited for two or three LDS round trips
+        // in front of ~60 cycles of chain: 177 k of a 100-node graph's 1.5 M cycles) — the same
+        // operations in the same order.
         double Dp = 1.0;
-        for (int i = s0; i <= t0; ++i) {   // stationary transform, top down
-          const double di = Td[i] - lamq;
-          Dp = guard(i > s0 ? di - Te2[i - 1] * rcp_nr(Dp) : di);
-          zv[(size_t)i * kk + q] = Dp;
+        for (int c0 = s0; c0 <= t0; c0 += 8) {   // stationary transform, top down
+          double td[8], te[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = min(c0 + u, t0);
+            td[u] = Td[i];
+            te[u] = i > s0 ? Te2[i - 1] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = c0 + u;
+            if (i <= t0) {
+              const double di = td[u] - lamq;
+              Dp = guard(i > s0 ? di - te[u] * rcp_nr(Dp) : di);
+              zv[(size_t)i * kk + q] = Dp;
+            }
+          }
         }
         double Dn = 1.0, gbest = 1e300;
         int tw = s0;
-        for (int i = t0; i >= s0; --i) {   // progressive transform, bottom up: find the twist
-          const double di = Td[i] - lamq;
-          Dn = guard(i < t0 ? di - Te2[i] * rcp_nr(Dn) : di);
-          const double g = fabs(zv[(size_t)i * kk + q] + Dn - di);
-          if (g < gbest) gbest = g, tw = i;
+        for (int c0 = t0; c0 >= s0; c0 -= 8) {   // progressive transform, bottom up: find the twist
+          double td[8], te[8], zp[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = max(c0 - u, s0);
+            td[u] = Td[i];
+            te[u] = i < t0 ? Te2[i] : 0.0;
+            zp[u] = zv[(size_t)i * kk + q];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = c0 - u;
+            if (i >= s0) {
+              const double di = td[u] - lamq;
+              Dn = guard(i < t0 ? di - te[u] * rcp_nr(Dn) : di);
+              const double g = fabs(zp[u] + Dn - di);
+              if (g < gbest) gbest = g, tw = i;
+            }
+          }
         }
         Dn = 1.0;
-        for (int i = t0; i > tw; --i) {    // D- again, kept where D+ is no longer needed
-          const double di = Td[i] - lamq;
-          Dn = guard(i < t0 ? di - Te2[i] * rcp_nr(Dn) : di);
-          zv[(size_t)i * kk + q] = Dn;
+        for (int c0 = t0; c0 > tw; c0 -= 8) {    // D- again, kept where D+ is no longer needed
+          double td[8], te[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = max(c0 - u, s0);
+            td[u] = Td[i];
+            te[u] = i < t0 ? Te2[i] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = c0 - u;
+            if (i > tw) {
+              const double di = td[u] - lamq;
+              Dn = guard(i < t0 ? di - te[u] * rcp_nr(Dn) : di);
+              zv[(size_t)i * kk + q] = Dn;
+            }
+          }
         }
         double zc = 1.0, nn = 1.0;
         zv[(size_t)tw * kk + q] = 1.0;
-        for (int i = tw - 1; i >= s0; --i) {   // z_i = -(e_i / D+_i) z_{i+1}
-          zc = -(Te[i] * rcp_nr(zv[(size_t)i * kk + q])) * zc;
-          zv[(size_t)i * kk + q] = zc;
-          nn = fma(zc, zc, nn);
+        for (int c0 = tw - 1; c0 >= s0; c0 -= 8) {   // z_i = -(e_i / D+_i) z_{i+1}
+          double rr[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = max(c0 - u, s0);
+            rr[u] = Te[i] * rcp_nr(zv[(size_t)i * kk + q]);   // (off the chain)
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = c0 - u;
+            if (i >= s0) {
+              zc = -rr[u] * zc;
+              zv[(size_t)i * kk + q] = zc;
+              nn = fma(zc, zc, nn);
+            }
+          }
         }
         zc = 1.0;
-        for (int i = tw + 1; i <= t0; ++i) {   // z_i = -(e_{i-1} / D-_i) z_{i-1}
-          zc = -(Te[i - 1] * rcp_nr(zv[(size_t)i * kk + q])) * zc;
-          zv[(size_t)i * kk + q] = zc;
-          nn = fma(zc, zc, nn);
+        for (int c0 = tw + 1; c0 <= t0; c0 += 8) {   // z_i = -(e_{i-1} / D-_i) z_{i-1}
+          double rr[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = min(c0 + u, t0);
+            rr[u] = Te[i - 1] * rcp_nr(zv[(size_t)i * kk + q]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = c0 + u;
+            if (i <= t0) {
+              zc = -rr[u] * zc;
+              zv[(size_t)i * kk + q] = zc;
+              nn = fma(zc, zc, nn);
+            }
+          }
         }
         const double sc = rsqrt(nn);
         for (int i = s0; i <= t0; ++i) zv[(size_t)i * kk + q] *= sc;
@@ -1026,6 +1202,9 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     }
     __syncthreads();
     solved_out = solved;
+#ifdef LNZ_PROFILE_PHASES
+    tq1 = clock64();
+#endif
   }
 
   // ---- write D [K] and V [N, K] (dataset/graph_data.py:262-287: zero rows >= n, zero slots >= n)
@@ -1040,6 +1219,13 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       const int rr = idx / K, k = idx - rr * K;
       if (rr >= n || k >= kk) Vb[idx] = 0.0f;
     }
+    // (the sign of a column = the sign of its largest fp32 component, the first one on ties: an
+    // LDS maximum over keys |v| bits : 2^31 - 1 - row : sign bit, taken where the values are in
+    // registers — a scan of the column just written to global memory was 67 k of a 100-node
+    // graph's 1.5 M cycles, one L2 round trip per row)
+    unsigned long long* skey = reinterpret_cast<unsigned long long*>(sm.cb);
+    for (int k = tid; k < kk; k += kNT) skey[k] = 0ull;
+    __syncthreads();
     const int row = tid % n, seg = tid / n, nseg = kNT / n;
     if (seg < nseg) {
       for (int q = seg; q < kk; q += nseg) {
@@ -1050,21 +1236,21 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           a1 = fma(Qt[(size_t)(i + 1) * LD + row], zvp[(size_t)(i + 1) * kk + q], a1);
         }
         if (i < n) a0 = fma(Qt[(size_t)i * LD + row], zvp[(size_t)i * kk + q], a0);
-        Vb[(size_t)row * K + q] = (float)(a0 + a1);
+        const float v = (float)(a0 + a1);
+        Vb[(size_t)row * K + q] = v;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(fabsf(v)) << 32) |
+                                       ((unsigned long long)(0x7fffffffu - (unsigned)row) << 1) |
+                                       (v < 0.0f ? 1ull : 0ull);
+        atomicMax(&skey[q], key);
       }
     }
     __syncthreads();
-    if (tid < kk) {
-      float best = 0.0f, sg = 1.0f;
-      for (int r = 0; r < n; ++r) {
-        const float v = Vb[(size_t)r * K + tid], a = fabsf(v);
-        if (a > best) best = a, sg = v < 0.0f ? -1.0f : 1.0f;
-      }
-      sm.sgn[tid] = sg;
-    }
-    __syncthreads();
-    if (seg < nseg)
-      for (int q = seg; q < kk; q += nseg) Vb[(size_t)row * K + q] *= sm.sgn[q];
+#ifdef LNZ_PROFILE_PHASES
+    tq2 = tq3 = clock64();
+#endif
+    if (seg < nseg)   // (every thread re-reads what it wrote itself)
+      for (int q = seg; q < kk; q += nseg)
+        if (skey[q] & 1ull) Vb[(size_t)row * K + q] = -Vb[(size_t)row * K + q];
   } else {
     const int dq = kNT / K, dr = kNT - dq * K;
     int rr = tid / K, k = tid - rr * K;
@@ -1091,6 +1277,13 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       D[(int64_t)b * K + 5] = (float)tl_dot;
       D[(int64_t)b * K + 6] = (float)tl_red;
       D[(int64_t)b * K + 7] = (float)tl_upd;
+    }
+    if (K >= 13) {  // ordering | twisted vectors | V = Q S | sign scan | sign apply
+      D[(int64_t)b * K + 8] = (float)(tq0 - tp2);
+      D[(int64_t)b * K + 9] = (float)(tq1 - tq0);
+      D[(int64_t)b * K + 10] = (float)(tq2 - tq1);
+      D[(int64_t)b * K + 11] = (float)(tq3 - tq2);
+      D[(int64_t)b * K + 12] = (float)(tp3 - tq3);
     }
   }
 #endif
