@@ -34,12 +34,27 @@ constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNT = LNZ_RITZ_WG_THREADS;   // threads per workgroup (the reductions of a Lanczos step are split over all of them)
 constexpr int kWaves = kNT / 64;
 constexpr int kNMax = 192;   // largest graph one workgroup owns
+#ifndef LNZ_RITZ_PARTS_SMALL
+#define LNZ_RITZ_PARTS_SMALL 4   // parts per row group of the wave-level Lanczos phase, n <= 64
+#endif
+#ifndef LNZ_RITZ_PARTS_LARGE
+#define LNZ_RITZ_PARTS_LARGE 2   // ... 64 < n <= 128
+#endif
 #ifndef LNZ_RITZ_ONE_WAVE_MAX
 #define LNZ_RITZ_ONE_WAVE_MAX 128   // graphs up to this size (basis in LDS) run their Lanczos phase on one or two wavefronts
 #endif
 // LDS a workgroup may ask for: the CU has 160 KB; a request of 163,712 B was refused by the runtime
 // (HSA_STATUS_ERROR_INVALID_ALLOCATION) where 163,020 B had launched — keep 2 KB clear
 constexpr int kLdsMax = 160 * 1024 - 2048;
+
+struct LwExtra {   // wave-level Lanczos phase (lanczos_waves; basis in LDS only): what does not fit in WgFixed::part
+  double pd[256];      // partial updates [part][row]
+  double cbx[3][128];  // the coefficient copies of waves 1..3 (wave 0: WgFixed::cb)
+  double pn[2], px[2]; // partial |w|^2, |x|^2 by row group
+  double best[4];      // restart: largest residual by wave
+  int cand[4];
+};
+static_assert(sizeof(LwExtra) % 16 == 0, "the basis behind it starts on a 16-byte boundary");
 
 struct WgFixed {  // fixed part of the LDS block
   double zb[kNMax];    // broadcast of the current vector
@@ -75,7 +90,8 @@ __host__ __device__ inline size_t wg_a_bytes(int N, bool qg) {
 
 inline size_t wg_lds_bytes(int N, bool qg) {
   // (+ 8: A starts on a 16-byte boundary behind an odd number of basis doubles)
-  return sizeof(WgFixed) + (qg ? 0 : (size_t)N * (size_t)(N | 1) * sizeof(double) + 8) + wg_a_bytes(N, qg);
+  return sizeof(WgFixed) + (qg ? 0 : sizeof(LwExtra) + (size_t)N * (size_t)(N | 1) * sizeof(double) + 8) +
+         wg_a_bytes(N, qg);
 }
 
 __device__ __forceinline__ double rcp_nr(double x) {  // 1/x: hardware seed + one Newton step
@@ -311,25 +327,16 @@ __device__ __noinline__ double walk_arow(const __attribute__((address_space(3)))
   return (p0 + p1) + (p2 + p3);
 }
 
-// W = 1 (n <= 64): lane l owns row l of the residual and basis vector l of the Gram-Schmidt dot
-// products; no workgroup barrier at all.
-// W = 2 (64 < n <= 128): wave v owns rows 64 v + l; a dot product's row range is split between the
-// two waves (partials through LDS, summed in a fixed order by both), each wave keeps its own copy
-// of the coefficients, and a step has four workgroup barriers (+ two for a second Gram-Schmidt
-// pass) instead of the eight-wave form's seven to ten — with a quarter of the LDS round trips.
+// G row groups x H parts = W waves.  Wave (g, h) holds row 64 g + l of the residual (every part h
+// keeps its own identical copy) and walks part h of every inner product: a column range of A w, a
+// vector range of the update w -= Q c, and (all W waves) a row range of the Gram-Schmidt dot
+// products, whose vector l (and l + 64) is lane l's.  Partials meet in LDS and are summed in a fixed
+// order by every wave that needs them; every wave keeps its own copy of the coefficients.  A step
+// has four workgroup barriers (five with H > 1; + three for a second Gram-Schmidt pass) with one LDS
+// round trip each, against the eight-wave form's seven to ten with two or three; <1, 1> has none.
 // The waves without a part keep the barriers company (lanczos_idle_waves).
 // (Two rows per lane on ONE wave were measured as well: 3 % slower than the eight-wave form at
 // n = 68, 13 % at n = 100.)
-struct DuoScratch {   // lives in WgFixed::part (512 doubles)
-  double pc[2][128];  // partial dot products by wave
-  double pn[2];       // partial |w|^2
-  double px[2];       // partial |x|^2
-  double best[2];     // restart: largest residual by wave
-  int cand[2];
-  int pad_[2];        // (cb1 on a 16-byte boundary: the coefficients are read in pairs)
-  double cb1[128];    // wave 1's copy of the coefficients (wave 0 uses WgFixed::cb)
-};
-static_assert(sizeof(DuoScratch) <= sizeof(double) * kNT, "DuoScratch lives in WgFixed::part");
 
 // The waves without a part arrive at every barrier of the phase and leave with its last one.  The
 // "last" mark alternates between two words by barrier parity: a wave reads word k & 1 behind
@@ -342,8 +349,16 @@ __device__ __forceinline__ void lanczos_idle_waves(WgFixed& sm) {
   }
 }
 
-template <int W>
-__device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Qt,
+// part idx of `parts` of the range [0, total): bounds on multiples of eight (16-byte aligned
+// broadcast reads, whole chunks), the last part takes what is left
+__device__ __forceinline__ void part_range(const int total, const int parts, const int idx, int& lo, int& hi) {
+  const int per = ((total + parts - 1) / parts + 7) & ~7;
+  lo = idx * per < total ? idx * per : total;
+  hi = (idx + 1) * per < total ? (idx + 1) * per : total;
+}
+
+template <int G, int H>
+__device__ __forceinline__ int lanczos_waves(WgFixed& sm, LwExtra& lw, double* __restrict__ Qt,
                                              const float* __restrict__ As, const int n,
                                              const int LD, const int LA, const int lane, const int wave,
                                              long long* tl = nullptr) {  // tl: LNZ_PROFILE_PHASES (A w, dots, sums, update)
@@ -353,18 +368,21 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
 #else
 #define LNZ_WT(i)
 #endif
-  const int row = 64 * wave + lane;
+  constexpr int W = G * H, RW = 64 * G;
+  const int g = wave % G, h = wave / G;
+  const int row = 64 * g + lane;
   const bool vr = row < n;
   const int n4 = (n + 3) & ~3;
   int nrestart = 0;
-  DuoScratch& ds = *reinterpret_cast<DuoScratch*>(sm.part);
-  const lds_cd zb = (lds_cd)sm.zb, Ql = (lds_cd)Qt;
-  double* cbw = (W == 2 && wave == 1) ? ds.cb1 : sm.cb;   // this wave's coefficients
-  const lds_cd cb = (lds_cd)cbw;
-  // this wave's part of a dot product's row range (even bounds: the broadcast vector is read in pairs)
-  const int nh = W == 1 ? n : ((n >> 1) + 7) & ~7;
-  const int h0 = (W == 2 && wave == 1) ? nh : 0, h1 = (W == 2 && wave == 0) ? nh : n;
-  int kbar = 0;   // workgroup barriers of this phase so far (W = 2; see lanczos_idle_waves)
+  double* pu = sm.part;     // [H][RW] partial A w          (dead before the dot products)
+  double* pc = sm.part;     // [W][RW] partial dot products
+  double* pd = lw.pd;    // [H][RW] partial updates
+  double* cbw = wave == 0 ? sm.cb : lw.cbx[wave > 0 ? wave - 1 : 0];   // this wave's coefficients
+  const lds_cd zb = (lds_cd)sm.zb, Ql = (lds_cd)Qt, cb = (lds_cd)cbw;
+  int ac0, ac1, dr0, dr1;
+  part_range(n4, H, h, ac0, ac1);      // this wave's columns of A w
+  part_range(n, W, wave, dr0, dr1);    // this wave's rows of the dot products
+  int kbar = 0;   // workgroup barriers of this phase so far (see lanczos_idle_waves)
   auto wg_bar = [&]() {
     __syncthreads();
     ++kbar;
@@ -373,15 +391,6 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
     if constexpr (W == 1) wave_sync();
     else wg_bar();
   };
-  // sum of one value per lane over the cooperating waves, identical in all of them; slot: where the
-  // partials meet (the barrier after the store is the caller's)
-  auto put_partial = [&](double (&slot)[2], const double v) {
-    const double s = wave_sum_f64(v);
-    if constexpr (W == 2) {
-      if (lane == 0) slot[wave] = s;
-    }
-    return s;
-  };
 
   // x <- (I - Q Q^T) x once or twice over basis vectors 0..cnt-1 (x: this lane's row); returns the
   // accumulated coefficient on vector jidx.  The second pass runs where the first removed more
@@ -389,30 +398,39 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
   auto cgs2 = [&](double& x, const int cnt, const int jidx) -> double {
     double coef = 0.0;
     const bool vk0 = lane < cnt, vk1 = lane + 64 < cnt;
+    int uk0, uk1;
+    part_range(cnt, H, h, uk0, uk1);   // this wave's vectors of the update
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      if (vr) sm.zb[row] = x;
+      if (vr && h == 0) sm.zb[row] = x;
       bar();
       // ---- c_k = <q_k, x>: lane k walks its own vector over this wave's rows, x is a broadcast read
       // (lanes beyond cnt walk rows that were never written: masked)
-      double c0 = walk_own(Ql + lane * LD + h0, zb + h0, h1 - h0), c1 = 0.0;
+      double c0 = walk_own(Ql + lane * LD + dr0, zb + dr0, dr1 - dr0), c1 = 0.0;
       c0 = vk0 ? c0 : 0.0;
-      if (W == 2 && cnt > 64) {
-        c1 = walk_own(Ql + (lane + 64) * LD + h0, zb + h0, h1 - h0);
+      if (G == 2 && cnt > 64) {
+        c1 = walk_own(Ql + (lane + 64) * LD + dr0, zb + dr0, dr1 - dr0);
         c1 = vk1 ? c1 : 0.0;
       }
-      double xx = put_partial(ds.px, x * x);   // (rows beyond n hold 0)
-      if constexpr (W == 2) {
-        ds.pc[wave][lane] = c0;
-        ds.pc[wave][lane + 64] = c1;
+      double xx = wave_sum_f64(x * x);   // (rows beyond n hold 0)
+      if constexpr (W > 1) {
+        if (h == 0 && lane == 0) lw.px[g] = xx;
+        pc[wave * RW + lane] = c0;
+        if (G == 2) pc[wave * RW + 64 + lane] = c1;
         wg_bar();
-        c0 = ds.pc[0][lane] + ds.pc[1][lane];
-        c1 = ds.pc[0][lane + 64] + ds.pc[1][lane + 64];
-        xx = ds.px[0] + ds.px[1];
+        c0 = pc[lane];
+        if (G == 2) c1 = pc[64 + lane];
+#pragma unroll
+        for (int p_ = 1; p_ < W; ++p_) {
+          c0 += pc[p_ * RW + lane];
+          if (G == 2) c1 += pc[p_ * RW + 64 + lane];
+        }
+        xx = lw.px[0];
+        if (G == 2) xx += lw.px[1];
       }
       LNZ_WT(1)
       if (vk0) cbw[lane] = c0;
-      if (W == 2 && vk1) cbw[lane + 64] = c1;
+      if (G == 2 && vk1) cbw[lane + 64] = c1;
       bool again = true;
       if (pass == 0) {
         const double cc2 = wave_sum_f64(fma(c0, c0, c1 * c1));
@@ -421,10 +439,17 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
       wave_sync();
       coef += cbw[jidx];
       LNZ_WT(2)
-      // ---- x -= sum_k c_k q_k: lanes along the rows of every vector, c a broadcast read
-      const double d = walk_strided(Ql + row, LD, cb, cnt);
+      // ---- x -= sum_k c_k q_k: lanes along the rows of this wave's vectors, c a broadcast read
+      double d = walk_strided(Ql + row + uk0 * LD, LD, cb + uk0, uk1 - uk0);
+      if constexpr (H > 1) {
+        pd[h * RW + row] = d;
+        wg_bar();
+        d = pd[row];
+#pragma unroll
+        for (int p_ = 1; p_ < H; ++p_) d += pd[p_ * RW + row];
+      }
       if (vr) x -= d;
-      wave_sync();   // the coefficients are rewritten by the next pass / call (zb, pc: behind a barrier)
+      wave_sync();   // the coefficients are rewritten by the next pass / call (zb, pc, pd: behind a barrier)
       LNZ_WT(3)
       if (!again) break;
     }
@@ -444,13 +469,25 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
     double beta, u;
     for (;;) {
       // ---- beta = |w| and u = A w from one broadcast of w
-      if (vr) sm.zb[row] = w;
+      if (vr && h == 0) sm.zb[row] = w;
       bar();
-      u = walk_arow(Al + row * LA, zb, n4);   // (lanes beyond n walk rows that were never staged)
+      u = walk_arow(Al + row * LA + ac0, zb + ac0, ac1 - ac0);   // (lanes beyond n walk rows that were never staged)
       u = vr ? u : 0.0;
-      double nn = put_partial(ds.pn, w * w);
+      double nn = wave_sum_f64(w * w);
+      if constexpr (W > 1) {
+        if (H > 1) pu[h * RW + row] = u;
+        if (h == 0 && lane == 0) lw.pn[g] = nn;
+      }
       bar();   // zb is rewritten below
-      if constexpr (W == 2) nn = ds.pn[0] + ds.pn[1];
+      if constexpr (W > 1) {
+        if (H > 1) {
+          u = pu[row];
+#pragma unroll
+          for (int p_ = 1; p_ < H; ++p_) u += pu[p_ * RW + row];
+        }
+        nn = lw.pn[0];
+        if (G == 2) nn += lw.pn[1];
+      }
       beta = sqrt(nn);
       LNZ_WT(0)
       if (fresh || beta > kBreakdownTol) break;
@@ -474,12 +511,11 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
         const int oc = __shfl_xor(cand, off, 64);
         if (ob > best || (ob == best && oc < cand)) best = ob, cand = oc;
       }
-      if constexpr (W == 2) {
-        if (lane == 0) ds.best[wave] = best, ds.cand[wave] = cand;
+      if constexpr (W > 1) {
+        if (lane == 0) lw.best[wave] = best, lw.cand[wave] = cand;
         wg_bar();
-        const double b1 = ds.best[1];
-        best = ds.best[0], cand = ds.cand[0];
-        if (b1 > best) best = b1, cand = ds.cand[1];   // (equal: wave 0's row is the lower one)
+        best = lw.best[0], cand = lw.cand[0];     // (waves 0..G-1 are the row groups' part 0)
+        if (G == 2 && lw.best[1] > best) cand = lw.cand[1];   // (equal: group 0's row is the lower one)
       }
       w = (row == cand) ? 1.0 : 0.0;
       (void)cgs2(w, j, 0);
@@ -489,13 +525,13 @@ __device__ __forceinline__ int lanczos_waves(WgFixed& sm, double* __restrict__ Q
     fresh = false;
     const double binv = 1.0 / beta;
     double x = u * binv;  // A q_j
-    if (vr) Qt[(size_t)j * LD + row] = w * binv;
+    if (vr && h == 0) Qt[(size_t)j * LD + row] = w * binv;
     // (the barrier inside cgs2 orders this store before the basis reads)
     const double alpha = cgs2(x, j + 1, j);
     if (wave == 0 && lane == 0) sm.dd[j] = alpha;
     w = x;
   }
-  if constexpr (W == 2) {
+  if constexpr (W > 1) {
     if (wave == 0 && lane == 0) sm.perm[kbar & 1] = 1;   // releases the waves that kept the barriers company
     __syncthreads();
   }
@@ -507,7 +543,9 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info, double* __restrict__ ws,
-    const int mode_flags) {  // bit 0: the QL sweep; bit 1: the eight-wave Lanczos phase
+    const int mode_flags,    // bit 0: the QL sweep; bit 1: the eight-wave Lanczos phase; bits 2-3: parts
+    const int a_bytes) {     // size of the A region (>= wg_a_bytes(N, QG): the launcher adds what the
+                             // parallel eigensolver's scratch needs beyond a small graph's A)
   const bool force_ql = (mode_flags & 1) != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   WgFixed& sm = *reinterpret_cast<WgFixed*>(smem_raw);
@@ -518,7 +556,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     Qt = ws + (int64_t)blockIdx.x * N * LD;
     As = reinterpret_cast<float*>(smem_raw + sizeof(WgFixed));
   } else {
-    Qt = reinterpret_cast<double*>(smem_raw + sizeof(WgFixed));
+    Qt = reinterpret_cast<double*>(smem_raw + sizeof(WgFixed) + sizeof(LwExtra));
     As = reinterpret_cast<float*>(Qt + (((size_t)N * LD + 1) & ~(size_t)1));
   }
   const int b = blockIdx.x;
@@ -560,13 +598,25 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
   tlw = tlw_;
 #endif
   if (n > 0 && one_wave) {
-    if (n <= 64) {
-      if (wave == 0) nrestart = lanczos_waves<1>(sm, Qt, As, n, LD, LA, lane, 0, tlw);
-    } else {
+    LwExtra& lwx = *reinterpret_cast<LwExtra*>(smem_raw + sizeof(WgFixed));
+    // parts per row group: mode_flags bits 2-3 (1, 2, 4; testing), else by size
+    int parts = (mode_flags >> 2) & 3;
+    parts = parts == 0 ? (n <= 64 ? LNZ_RITZ_PARTS_SMALL : LNZ_RITZ_PARTS_LARGE) : (parts == 3 ? 4 : parts);
+    if (n > 64 && parts > 2) parts = 2;
+    const int nw = (n <= 64 ? 1 : 2) * parts;   // waves with a part
+    if (nw > 1) {
       if (tid == 0) sm.perm[0] = sm.perm[1] = 0;
       __syncthreads();
-      if (wave < 2) nrestart = lanczos_waves<2>(sm, Qt, As, n, LD, LA, lane, wave, tlw);
-      else lanczos_idle_waves(sm);
+    }
+    if (wave >= nw) {
+      if (nw > 1) lanczos_idle_waves(sm);   // (one wave alone has no barrier to keep company at)
+    } else if (n <= 64) {
+      if (parts == 1) nrestart = lanczos_waves<1, 1>(sm, lwx, Qt, As, n, LD, LA, lane, wave, tlw);
+      else if (parts == 2) nrestart = lanczos_waves<1, 2>(sm, lwx, Qt, As, n, LD, LA, lane, wave, tlw);
+      else nrestart = lanczos_waves<1, 4>(sm, lwx, Qt, As, n, LD, LA, lane, wave, tlw);
+    } else {
+      if (parts == 1) nrestart = lanczos_waves<2, 1>(sm, lwx, Qt, As, n, LD, LA, lane, wave, tlw);
+      else nrestart = lanczos_waves<2, 2>(sm, lwx, Qt, As, n, LD, LA, lane, wave, tlw);
     }
     __syncthreads();
 #ifdef LNZ_PROFILE_PHASES
@@ -845,7 +895,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     double* Te = Td + N;
     double* Te2 = Te + N;
     double* zv = Te2 + N;  // [n][kk]: component i of selected vector q at zv[i * kk + q]
-    bool solved = (size_t)3 * N * sizeof(double) + (size_t)kk * n * sizeof(double) <= wg_a_bytes(N, QG) &&
+    bool solved = (size_t)3 * N * sizeof(double) + (size_t)kk * n * sizeof(double) <= (size_t)a_bytes &&
                   !force_ql;
     if (solved) {
       if (tid < n) {
@@ -1300,7 +1350,8 @@ extern "C" int64_t lnz_lanczos_ritz_workspace_bytes(int B, int N) {
 // Shared by lnz_lanczos_ritz (lanczos_ritz.hip) and lnz_lanczos_ritz_ws.
 // flags: bit 0 = the basis goes to the workspace even if it would fit in LDS; bit 1 = the QL sweep
 // instead of the parallel tridiagonal eigensolver; bit 2 = the eight-wave Lanczos phase where the
-// one-wave form would run (basis in LDS) — all for testing.
+// wave-level form would run (basis in LDS); bits 3-4 = parts per row group of the wave-level form
+// (1: one, 2: two, 3: four; 0: by size) — all for testing.
 int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                        const int32_t* n_nodes, int B, int N, int K, float* D, float* V,
                        int32_t* info, void* workspace, int64_t workspace_bytes, int flags,
@@ -1309,7 +1360,18 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
               "lnz_lanczos_ritz: N=%d > %d: use lnz_lanczos_ritz_large / _sym (streamed kernels)",
               N, kNMax);
   const bool qg = (flags & 1) || wg_lds_bytes(N, false) > (size_t)kLdsMax;
-  const size_t lds = wg_lds_bytes(N, qg);
+  size_t lds = wg_lds_bytes(N, qg);
+  // The parallel tridiagonal eigensolver keeps 3 N + min(K, N) N doubles in the (then dead) A
+  // region; a small graph's A is smaller than that (N = 40, K = 20: 7.4 KB against 6.6 KB — the QL
+  // sweep ran instead, 0.49 ms against 0.2).  The region grows to hold it where LDS allows.
+  size_t a_bytes = wg_a_bytes(N, qg);
+  {
+    const size_t want = ((size_t)3 * N + (size_t)(K < N ? K : N) * N) * sizeof(double);
+    if (want > a_bytes && lds + (want - a_bytes) <= (size_t)kLdsMax) {
+      lds += want - a_bytes;
+      a_bytes = want;
+    }
+  }
   LNZ_REQUIRE(lds <= (size_t)kLdsMax, LNZ_ENOTSUP, "lnz_lanczos_ritz: N=%d needs %zu B of LDS", N,
               lds);
   if (qg) {
@@ -1338,7 +1400,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N,
-                       K, D, V, info, (double*)workspace, (flags >> 1) & 3);
+                       K, D, V, info, (double*)workspace, (flags >> 1) & 15, (int)a_bytes);
     const int rc = lnz::check_launch("lnz_lanczos_ritz");
     if (owned) (void)hipFreeAsync(owned, s);
     return rc;
@@ -1346,7 +1408,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
   auto kfn = lanczos_ritz_wg_kernel<false>;
   (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N, K,
-                     D, V, info, (double*)nullptr, (flags >> 1) & 3);
+                     D, V, info, (double*)nullptr, (flags >> 1) & 15, (int)a_bytes);
   return lnz::check_launch("lnz_lanczos_ritz");
 }
 

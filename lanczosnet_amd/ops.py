@@ -132,13 +132,15 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
   dataset/graph_data.py:262-287.
   kernel: 'auto' (wavefront per graph up to N = 32, workgroup per graph above), 'workgroup'
   (workgroup per graph at any N), 'workgroup_ws' (the same with the fp64 basis in a device
-  workspace instead of LDS — what 'auto' does for N > 111), 'workgroup_ql' (the workgroup kernel
+  workspace instead of LDS — what 'auto' does for N > 108), 'workgroup_ql' (the workgroup kernel
   with the QL sweep instead of its parallel tridiagonal eigensolver — its fallback, forced),
-  'workgroup_mw' (the Lanczos phase on all eight waves where the one-wave form would run — the
-  arithmetic of 'workgroup_ws' in the same order)."""
+  'workgroup_mw' (the Lanczos phase on all eight waves where the wave-level form would run — the
+  arithmetic of 'workgroup_ws' in the same order), 'workgroup_p1' / '_p2' / '_p4' (the wave-level
+  Lanczos phase with one, two, four parts per row group instead of the number chosen by size)."""
   _need_cuda(A, n_nodes)
   assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
-  assert kernel in ('auto', 'workgroup', 'workgroup_ws', 'workgroup_ql', 'workgroup_mw')
+  assert kernel in ('auto', 'workgroup', 'workgroup_ws', 'workgroup_ql', 'workgroup_mw', 'workgroup_p1',
+                    'workgroup_p2', 'workgroup_p4')
   B, N, _ = A.shape
   n_nodes = n_nodes.to(torch.int32).contiguous()
   if kernel == 'auto':
@@ -154,7 +156,8 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
                                       V, info)
     else:
       # the workspace (if any) comes from torch's caching allocator, not from a hipMallocAsync
-      flags = {'workgroup_ws': 1, 'workgroup_ql': 2, 'workgroup_mw': 4}.get(kernel, 0)
+      flags = {'workgroup_ws': 1, 'workgroup_ql': 2, 'workgroup_mw': 4, 'workgroup_p1': 8, 'workgroup_p2': 16,
+               'workgroup_p4': 24}.get(kernel, 0)
       need = B * N * (N | 1) * 8 if flags & 1 else _abi().lanczos_ritz_workspace_bytes(B, N)
       ws = torch.empty((need,), dtype=torch.uint8, device=A.device) if need else None
       _abi().lanczos_ritz_ws(A, sb, sr, sc, n_nodes, B, N, K, D,

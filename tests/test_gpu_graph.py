@@ -160,6 +160,10 @@ def test_workgroup_ritz_kernel_matches_eigh(N, p):
   Dm, Vm = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel='workgroup_mw')
   assert torch.equal(Dm, D2) and torch.equal(Vm, V2)
   assert (D - D2).abs().max().item() < 1e-6
+  for parts in ('workgroup_p1', 'workgroup_p2', 'workgroup_p4'):   # every split of the wave-level phase
+    Dp, Vp = ops.lanczos_ritz(_t(A), _t(ns), Kk, kernel=parts)
+    assert (Dp - D2).abs().max().item() < 1e-6, parts
+    check_ritz(Dp.cpu().numpy(), Vp.cpu().numpy(), Dr, Vr, ns, full, Kk, powers=(1, 5))
   check_ritz(D2.cpu().numpy(), V2.cpu().numpy(), Dr, Vr, ns, full, Kk, powers=(1, 5))
   # the QL sweep (the fallback of the parallel tridiagonal eigensolver), forced: same function
   Dq, Vq, iq = ops.lanczos_ritz(_t(A), _t(ns), Kk, return_info=True, kernel='workgroup_ql')
@@ -258,7 +262,7 @@ def _structured_graphs():
   return gs
 
 
-@pytest.mark.parametrize('kernel', ['auto', 'workgroup_ws', 'workgroup_ql', 'workgroup_mw'])
+@pytest.mark.parametrize('kernel', ['auto', 'workgroup_ws', 'workgroup_ql', 'workgroup_mw', 'workgroup_p2', 'workgroup_p4'])
 def test_workgroup_ritz_kernel_on_degenerate_spectra(kernel):
   """Paths, cycles, grids, a hypercube, complete bipartite, barbell, star and disjoint Petersen
   graphs: multiplicities up to 20.  K = N so that no top-K cut splits a cluster; eigenvalues to

@@ -48,7 +48,7 @@ def main():
     A, ns = laplacians(rs, B, N, lo, hi, 0.5)
     Ad, nd = torch.from_numpy(A).cuda(), torch.from_numpy(ns).cuda()
     row = dict(case=name, B=B, N=N)
-    kernels = ['auto'] + (['workgroup'] if N <= 64 else []) + (['workgroup_ws', 'workgroup_mw'] if N <= 111 else [])
+    kernels = ['auto'] + (['workgroup'] if N <= 64 else []) + (['workgroup_ws', 'workgroup_mw'] if N <= 108 else [])
     for kern in kernels:
       ms = time_kernel(Ad, nd, K, kern)
       bytes_ = float((4.0 * ns.astype(np.float64) ** 2).sum() + B * (4 * K + 4 * N * K))

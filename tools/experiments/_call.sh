@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_graph.py tests/test_graph_runner_dropin.py -x -q 2>&1 | tail -3
+timeout 300 python -m pytest tests/test_gpu_graph.py tests/test_graph_runner_dropin.py -x -q 2>&1 | tail -2
 LANCZOSNET_HIP_LIB=tools/experiments/_variants/liblnz_lanczos_ritz_wg_probe.so timeout 300 python tools/ritz_wg_phase_probe.py workgroup 2>&1 | grep -v amdgpu.ids | head -9
 timeout 300 python tools/bench_ritz_wg.py 2>/dev/null > gpurun_out/ritz_wg.jsonl
 python -c "

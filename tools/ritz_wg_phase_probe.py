@@ -17,10 +17,10 @@ rs = np.random.RandomState(0)
 KERNELS = sys.argv[1:] or ['workgroup']
 for N, kern in [(N, k) for N in (48, 64, 100, 128, 192) for k in KERNELS]:
   A, ns = laplacians(rs, 8, N, N, N, 0.5)
-  if N > 111 and kern != KERNELS[0]:
+  if N > 108 and kern != KERNELS[0]:
     continue
   D, V = ops.lanczos_ritz(torch.from_numpy(A).cuda(), torch.from_numpy(ns).cuda(), 20,
-                          kernel=kern if N <= 111 else 'auto')
+                          kernel=kern if N <= 108 else 'auto')
   d = D.cpu().numpy()[:, :13].mean(axis=0)
   print('N=%3d %-13s Lanczos %9.0f cycles  QL %9.0f  order+output %8.0f   (QL %.0f cycles per n^2)'
         % (N, kern, d[0], d[1], d[2], d[1] / (N * N)))
