@@ -99,6 +99,39 @@ __device__ __forceinline__ double rcp_nr(double x) {  // 1/x: hardware seed + on
   return fma(y, fma(-x, y, 1.0), y);
 }
 
+// The unreduced block [bs, bt] of T that row e belongs to, from the bit mask of the rows whose
+// coupling to the next row is zero (three 64-bit words, one ballot each) — instead of every thread
+// walking the off-diagonal through LDS one dependent read at a time (~12 k cycles at n = 100).
+__device__ __forceinline__ void block_bounds(const unsigned long long* cutw, const int e, const int n,
+                                             int& bs, int& bt) {
+  bt = n - 1;
+  bs = 0;
+  {
+    int w = e >> 6;
+    unsigned long long m = cutw[w] & (~0ull << (e & 63));
+    for (;;) {
+      if (m) {
+        bt = 64 * w + __ffsll((long long)m) - 1;
+        break;
+      }
+      if (++w >= 3) break;
+      m = cutw[w];
+    }
+  }
+  {
+    int w = e >> 6;
+    unsigned long long m = (e & 63) ? cutw[w] & (~0ull >> (64 - (e & 63))) : 0ull;
+    for (;;) {
+      if (m) {
+        bs = 64 * w + 64 - __clzll((long long)m);
+        break;
+      }
+      if (--w < 0) break;
+      m = cutw[w];
+    }
+  }
+}
+
 // Eigenvalues of rows s..t of T (an unreduced block: no coupling to its neighbours) below x — the
 // Sturm count in product form, p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}: one dependent FMA per
 // row instead of a division (LAPACK dstebz's recurrence); the count is the number of sign changes.
@@ -109,15 +142,6 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
   double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
   unsigned na = 0u, nb = 0u;  // sign of the previous p (p_{-1} = 1 > 0)
   ca = cb = 0;
-  auto row = [&](const double di, const double ep) {
-    const double pa = fma(di - xa, a1, -(ep * a2));
-    const double pb = fma(di - xb, b1, -(ep * b2));
-    const unsigned sa = (unsigned)__double2hiint(pa) >> 31, sb = (unsigned)__double2hiint(pb) >> 31;
-    ca += (int)(sa ^ na);
-    cb += (int)(sb ^ nb);
-    na = sa, nb = sb;
-    a2 = a1, a1 = pa, b2 = b1, b1 = pb;
-  };
   auto rescale = [&]() {  // keep |p| inside the exponent range
     const double fa = fabs(a1), fb = fabs(b1);
     const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
@@ -127,6 +151,9 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
   // Rows in groups of eight whose (d, e^2) are all fetched from LDS BEFORE the dependent chain
   // runs: read in program order, every row waited ~120 cycles for its two LDS words in front of
   // ~60 cycles of fp64 chain (the section search was 0.93 M of a 100-node graph's 2.5 M cycles).
+  // The search is bound by the number of vector instructions (every thread of the workgroup walks
+  // the rows): a row is a subtraction, a product, an FMA and ONE v_alignbit that shifts p's sign
+  // into a mask; the sign changes of a group are a popcount.
   int i = s;
   for (; i + 7 <= t; i += 8) {
     double dv[8], ev[8];
@@ -135,11 +162,30 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
       dv[u] = d[i + u];
       ev[u] = (i + u) > s ? e2[i + u - 1] : 0.0;
     }
+    unsigned ma = na, mb = nb;   // bit 8: the sign before the group; bits 7..0: its rows, oldest first
 #pragma unroll
-    for (int u = 0; u < 8; ++u) row(dv[u], ev[u]);
+    for (int u = 0; u < 8; ++u) {
+      const double pa = fma(dv[u] - xa, a1, -(ev[u] * a2));
+      const double pb = fma(dv[u] - xb, b1, -(ev[u] * b2));
+      ma = __builtin_amdgcn_alignbit(ma, (unsigned)__double2hiint(pa), 31);   // (ma << 1) | sign(pa)
+      mb = __builtin_amdgcn_alignbit(mb, (unsigned)__double2hiint(pb), 31);
+      a2 = a1, a1 = pa, b2 = b1, b1 = pb;
+    }
+    ca += __popc((ma ^ (ma >> 1)) & 0xffu);
+    cb += __popc((mb ^ (mb >> 1)) & 0xffu);
+    na = ma & 1u, nb = mb & 1u;
     rescale();
   }
-  for (; i <= t; ++i) row(d[i], i > s ? e2[i - 1] : 0.0);
+  for (; i <= t; ++i) {
+    const double di = d[i], ep = i > s ? e2[i - 1] : 0.0;
+    const double pa = fma(di - xa, a1, -(ep * a2));
+    const double pb = fma(di - xb, b1, -(ep * b2));
+    const unsigned sa = (unsigned)__double2hiint(pa) >> 31, sb = (unsigned)__double2hiint(pb) >> 31;
+    ca += (int)(sa ^ na);
+    cb += (int)(sb ^ nb);
+    na = sa, nb = sb;
+    a2 = a1, a1 = pa, b2 = b1, b1 = pb;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -895,16 +941,22 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     double* Te = Td + N;
     double* Te2 = Te + N;
     double* zv = Te2 + N;  // [n][kk]: component i of selected vector q at zv[i * kk + q]
+    unsigned long long* cutw = reinterpret_cast<unsigned long long*>(sm.pn);   // [3]
     bool solved = (size_t)3 * N * sizeof(double) + (size_t)kk * n * sizeof(double) <= (size_t)a_bytes &&
                   !force_ql;
     if (solved) {
+      bool live = false;
       if (tid < n) {
         const double di = sm.dd[tid], ei = tid < n - 1 ? sm.ee[tid] : 0.0;
         const double dn = tid < n - 1 ? sm.dd[tid + 1] : 0.0;
-        const bool live = tid < n - 1 && fabs(ei) > kEps * (fabs(di) + fabs(dn));
+        live = tid < n - 1 && fabs(ei) > kEps * (fabs(di) + fabs(dn));
         Td[tid] = di;
         Te[tid] = live ? ei : 0.0;
         Te2[tid] = live ? ei * ei : 0.0;
+      }
+      {  // rows whose coupling to the next one is zero (block_bounds)
+        const unsigned long long cm = __ballot(tid < n - 1 && !live);
+        if (wave < 3 && lane == 0) cutw[wave] = cm;
       }
       __syncthreads();
       // Gershgorin bound of the spectrum
@@ -926,8 +978,7 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       double lo = -gsc * 1.0000001, hi = gsc * 1.0000001;
       int jloc = 0;
       if (mine) {
-        while (bs > 0 && Te[bs - 1] != 0.0) --bs;
-        while (bt < n - 1 && Te[bt] != 0.0) ++bt;
+        block_bounds(cutw, ev, n, bs, bt);
         jloc = ev - bs;
       }
       // [n][2 P] Sturm counts (n P <= kNT: fits sm.part); the uniform-exit vote below is the
@@ -1103,10 +1154,17 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
     if (tid < n) {
       const double di = sm.dd[tid], ai = fabs(di);
       int rank = 0;
-      for (int jj = 0; jj < n; ++jj) {
-        const double dj = sm.dd[jj], aj = fabs(dj);
-        const bool before = (aj > ai) || (aj == ai && (dj < di || (dj == di && jj < tid)));
-        rank += before ? 1 : 0;
+      for (int j0 = 0; j0 < n; j0 += 8) {   // (eight values requested before they are compared)
+        double dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dv[u] = sm.dd[min(j0 + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int jj = j0 + u;
+          const double dj = dv[u], aj = fabs(dj);
+          const bool before = (aj > ai) || (aj == ai && (dj < di || (dj == di && jj < tid)));
+          rank += (jj < n && before) ? 1 : 0;
+        }
       }
       sm.perm[rank] = tid;
     }
@@ -1122,14 +1180,20 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       if (tid < kk) {
         const int q = tid, idx = sm.perm[q];
         const double lamq = sm.dd[idx];
-        int s0 = idx, t0 = idx;
-        while (s0 > 0 && Te[s0 - 1] != 0.0) --s0;
-        while (t0 < n - 1 && Te[t0] != 0.0) ++t0;
+        int s0, t0;
+        block_bounds(cutw, idx, n, s0, t0);
         double gs = 0.0;
-        for (int i = s0; i <= t0; ++i) gs = fmax(gs, fabs(Td[i]) + fabs(Te[i]));
+        for (int c0 = s0; c0 <= t0; c0 += 8) {   // (a repeated last row does not change a maximum)
+          double td[8], te[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) td[u] = Td[min(c0 + u, t0)], te[u] = Te[min(c0 + u, t0)];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) gs = fmax(gs, fabs(td[u]) + fabs(te[u]));
+        }
         const double tiny = kEps * (gs > 0.0 ? gs : 1.0);
         auto guard = [&](double v) { return fabs(v) < tiny ? (v < 0.0 ? -tiny : tiny) : v; };
-        for (int i = 0; i < n; ++i) zv[(size_t)i * kk + q] = 0.0;
+        for (int i = 0; i < s0; ++i) zv[(size_t)i * kk + q] = 0.0;   // (zero outside the block)
+        for (int i = t0 + 1; i < n; ++i) zv[(size_t)i * kk + q] = 0.0;
         // Rows in chunks of eight whose LDS words are all requested before the dependent chain runs
         // (read row by row, every step of the recurrences waited for two or three LDS round trips
         // in front of ~60 cycles of chain: 177 k of a 100-node graph's 1.5 M cycles) — the same
@@ -1232,7 +1296,14 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           }
         }
         const double sc = rsqrt(nn);
-        for (int i = s0; i <= t0; ++i) zv[(size_t)i * kk + q] *= sc;
+        for (int c0 = s0; c0 <= t0; c0 += 8) {
+          double zz[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) zz[u] = zv[(size_t)min(c0 + u, t0) * kk + q];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (c0 + u <= t0) zv[(size_t)(c0 + u) * kk + q] = zz[u] * sc;
+        }
       }
       __syncthreads();
     }
