@@ -75,7 +75,7 @@ int lnz_laplacian(const float* adjs, const int32_t* n_nodes, int B, int N, int E
  *            (info += 256);
  *   32 < N <= 192 (the reference's synthetic-graph configuration, dataset/get_graph_data.py:15-49
  *            with config/graph_lanczos_net.yaml: n in [20,100]): one 512-thread workgroup per
- *            graph, A staged once into LDS, the fp64 basis in LDS up to N = 111 and in a workspace
+ *            graph, A staged once into LDS, the fp64 basis in LDS up to N = 108 and in a workspace
  *            above (lnz_lanczos_ritz_workspace_bytes; without one lnz_lanczos_ritz takes a
  *            stream-ordered allocation for the launch — LNZ_ENOTSUP while the stream is being
  *            captured: use lnz_lanczos_ritz_ws there); eigenvalues by Sturm-count section search
@@ -96,10 +96,12 @@ int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride_r, int64_t
                      int32_t* info, lnz_stream_t stream);
 
 /* The same with an explicit workspace for the fp64 Krylov basis of graphs too large to keep it in
- * LDS next to A (N > 111): lnz_lanczos_ritz_workspace_bytes(B, N) bytes (0 when none is needed).
+ * LDS next to A (N > 108): lnz_lanczos_ritz_workspace_bytes(B, N) bytes (0 when none is needed).
  * Always takes the workgroup-per-graph kernel (any N <= 192); flags bit 0 places the basis in the
  * workspace even when it would fit in LDS, bit 1 takes the QL sweep instead of the parallel
- * tridiagonal eigensolver (both used by the tests to cover every variant at one size).
+ * tridiagonal eigensolver, bit 2 the eight-wave Lanczos phase where the wave-level one would run
+ * (basis in LDS), bits 3-4 fix the wave-level phase's parts per row group (1: one, 2: two, 3: four)
+ * — all used by the tests to cover every variant at one size.
  * The workgroup kernel's eigensolver: T split into unreduced blocks, one eigenvalue per thread by
  * section search on Sturm counts, the eigenvectors of the K SELECTED eigenvalues by the twisted
  * factorisation of T - lambda (one thread per vector), V = Q S; two eigenvalues of one block closer

@@ -1,5 +1,5 @@
 // R2 + R6 for graphs of 33..192 nodes: full-length Lanczos -> tridiagonal eigensolve -> Ritz
-// select, ONE WORKGROUP (4 wavefronts) per graph.  This is the regime of the reference's own
+// select, ONE WORKGROUP (8 wavefronts) per graph.  This is the regime of the reference's own
 // synthetic-graph configuration (config/graph_lanczos_net.yaml with dataset/get_graph_data.py:15-49:
 // n in [20, 100]; (D, V) = np.linalg.eigh + |lambda| sort, utils/data_helper.py:197-223) and of
 // SURVEY.md §8(d)'s "A fits on chip" band (N <= ~180).
@@ -8,17 +8,21 @@
 // previous vectors; restart from the unit vector of largest residual on breakdown; implicit-shift
 // QL with the rotations applied to the basis so it ends up holding V = Q B; |lambda| ordering and
 // sign convention) — what changes is where things live and who works on them:
-//   * A (fp32, n x n, row pitch N|1 floats) is staged ONCE into LDS: HBM traffic per graph stays
-//     the algorithmic 4 n^2 (A) + 4 K (D) + 4 N K (V) bytes;
+//   * A (fp32, n x n) is staged ONCE into LDS: HBM traffic per graph stays the algorithmic
+//     4 n^2 (A) + 4 K (D) + 4 N K (V) bytes;
 //   * the Krylov basis Qt[i][r] = q_i[r] (fp64, row pitch N|1 doubles) lives in LDS next to A while
-//     12 N (N|1) + 12 KB <= 158 KB, i.e. N <= 111 (every graph of the reference generator); for
-//     111 < N <= 192 A alone takes up to 148 KB and the basis moves to a caller-provided workspace
+//     12 N (N|1) + 17 KB <= 158 KB, i.e. N <= 108 (every graph of the reference generator); for
+//     108 < N <= 192 A alone takes up to 148 KB and the basis moves to a caller-provided workspace
 //     (N (N|1) 8 bytes per graph, L2 / MALL resident: it is written and re-read by the one CU that
 //     owns the graph) — template parameter QG;
-//   * every reduction of a step (A w, the j+1 Gram-Schmidt dot products, the update w -= Q c) is
-//     split over all 512 threads as (output row) x (segment of the reduction range); partials are
-//     combined through LDS in a fixed order, so alpha / beta are bit-identical in every thread and
-//     the breakdown / restart control flow stays workgroup-uniform.  No atomics, no shuffles;
+//   * basis in LDS: the Lanczos phase runs on FOUR of the eight waves (lanczos_waves: row groups x
+//     parts, one row of the residual per lane, every inner product a software-pipelined walk over
+//     LDS, four or five workgroup barriers per step) while the others keep the barriers company;
+//   * basis in the workspace (and flags bit 2): every reduction of a step (A w, the j+1
+//     Gram-Schmidt dot products, the update w -= Q c) is split over all 512 threads as (output
+//     row) x (segment of the reduction range); partials are combined through LDS in a fixed
+//     order.  In both forms alpha / beta are bit-identical in every thread and the breakdown /
+//     restart control flow stays workgroup-uniform.  No atomics in the recurrences;
 //   * QL runs barrier-free: thread r owns element r of every basis vector (the rotation of rows
 //     i, i+1 touches only its own two words), each wavefront carries a PRIVATE copy of T's diagonal
 //     and off-diagonal (in the then dead A region) and runs the scalar recurrences redundantly.
