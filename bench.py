@@ -284,7 +284,7 @@ def graph_config_leg(dev, B=64, reps=5):
           'ritz': {'kernel': 'lanczos_ritz_wg_kernel<false>', 'graphs_per_s': round(B / acc[1] * 1e3, 1),
                    'algorithmic_GBps': round(bytes_ / acc[1] / 1e6, 3),
                    'bound': 'latency (one workgroup per graph, %d of 256 CUs busy; serial Lanczos '
-                            'recurrence of n steps)' % B,
+                            'recurrence of n steps on four waves, then the section search on all eight)' % B,
                    'qL_fallbacks': int((info >= 256).sum().item()),
                    'max_abs_dD_vs_numpy_eigh_16_graphs': worst,
                    'host_numpy_eigh_ms_per_graph': round(eigh_ms, 4)},

@@ -298,3 +298,32 @@ def test_workgroup_ritz_kernel_on_degenerate_spectra(kernel):
   assert restarts.sum() > 50   # the degenerate spectra really went through the restart path
   print('structured graphs (%s): restarts %s, QL fallbacks %d of %d'
         % (kernel, restarts.tolist(), int((info.cpu().numpy() >= 256).sum()), B))
+
+
+@pytest.mark.parametrize('p', [0.4, 0.03])
+def test_wave_level_lanczos_phase_at_its_size_boundaries(p):
+  """The Lanczos phase of graphs with the basis in LDS runs on four waves (csrc/lanczos_ritz_wg.hip,
+  lanczos_waves): one row group of 64 rows in four parts up to n = 64, two row groups in two parts
+  above.  Graphs on both sides of every boundary (n = 33, 63..66, the row ranges of the parts, N)
+  in one batch, dense and sparse (isolated nodes and twin leaves: breakdowns and restarts in every
+  graph), every split against numpy.linalg.eigh and against the eight-wave form."""
+  from lanczosnet_amd import ops
+  N = 100
+  sizes = [33, 40, 47, 48, 49, 63, 64, 65, 66, 71, 72, 73, 96, 97, 99, 100]
+  rs = np.random.RandomState(7)
+  A = np.zeros((len(sizes), N, N), np.float32)
+  ns = np.array(sizes, np.int32)
+  for b, n in enumerate(sizes):
+    adj = np.triu((rs.rand(n, n) < p).astype(np.float64), 1)
+    A[b, :n, :n] = oracle.laplacian_l4(adj + adj.T)
+  Kk = 24 if p >= 0.1 else N
+  Dr, Vr, full = _eigh_ref(A, ns, N, Kk)
+  Dm, Vm, im = ops.lanczos_ritz(_t(A), _t(ns), Kk, return_info=True, kernel='workgroup_mw')
+  if p < 0.1:
+    assert int((im % 256).sum()) > 0   # the restart branch ran
+  for kern in ('auto', 'workgroup_p1', 'workgroup_p2', 'workgroup_p4'):
+    D, V, info = ops.lanczos_ritz(_t(A), _t(ns), Kk, return_info=True, kernel=kern)
+    assert torch.isfinite(D).all() and torch.isfinite(V).all()
+    check_ritz(D.cpu().numpy(), V.cpu().numpy(), Dr, Vr, ns, full, Kk, powers=(1, 5))
+    assert (D - Dm).abs().max().item() < 1e-6, kern
+    assert torch.equal(info % 256 > 0, im % 256 > 0), kern   # the same graphs broke down
