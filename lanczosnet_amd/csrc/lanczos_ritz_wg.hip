@@ -38,6 +38,9 @@ constexpr double kEps = 2.220446049250313e-16;
 constexpr int kNT = LNZ_RITZ_WG_THREADS;   // threads per workgroup (the reductions of a Lanczos step are split over all of them)
 constexpr int kWaves = kNT / 64;
 constexpr int kNMax = 192;   // largest graph one workgroup owns
+#ifndef LNZ_RITZ_EIG_THREADS
+#define LNZ_RITZ_EIG_THREADS 512   // threads of the section search: P = this / n probe pairs per eigenvalue
+#endif
 #ifndef LNZ_RITZ_PARTS_SMALL
 #define LNZ_RITZ_PARTS_SMALL 4   // parts per row group of the wave-level Lanczos phase, n <= 64
 #endif
@@ -973,8 +976,10 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
       // bracket into 2 P + 1 parts — the threads of a group exchange their Sturm counts through
       // LDS and all take the same new bracket — so a 100-node graph needs 15 passes (x 11) where
       // one thread per eigenvalue needed 33 (x 3), and every thread of the workgroup works.
-      int P = kNT / n;
-      P = P > 8 ? 8 : P;
+      // (n <= 64: the probes of 256 threads — one wave per SIMD; 512 threads' 17 x shrink per pass
+      // saves fewer passes than its second wave per SIMD costs: n = 40 / 64 -5 / -4 %, n = 100 +2 %)
+      int P = (n <= 64 ? LNZ_RITZ_EIG_THREADS / 2 : LNZ_RITZ_EIG_THREADS) / n;
+      P = P > 8 ? 8 : (P < 1 ? 1 : P);
       const int ev = tid / P, sub = tid - ev * P;       // eigenvalue index, probe pair of this thread
       const bool mine = ev < n;
       int bs = mine ? ev : 0, bt = bs;

@@ -1,8 +1,6 @@
 # scratch: the command file of the last gpurun call
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-rm -rf gpurun_out/graphleg; mkdir -p gpurun_out/graphleg
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/graphleg -o gl -- python $GRAFT_REPO_ROOT/tools/experiments/graph_leg.py 20 2>&1 | grep "laplacian_l4"
-cd $GRAFT_REPO_ROOT
-python tools/rocpd_kernel_stats.py gpurun_out/graphleg/gl_results.db gpurun_out/graphleg/stats.csv > /dev/null 2>&1
-rm -f gpurun_out/graphleg/gl_results.db
+timeout 300 python -m pytest tests/test_gpu_graph.py tests/test_graph_runner_dropin.py -x -q 2>&1 | tail -2
+RITZ_WG_KERNELS="auto" timeout 200 python tools/experiments/ritz_wg_sizes.py 2>&1 | grep -v amdgpu.ids | tr '\n' ' '; echo
+timeout 300 python tools/experiments/ritz_wg_fuzz.py 500 150 2>&1 | grep -v amdgpu.ids | tail -3
