@@ -1,6 +1,11 @@
 # scratch: the command file of the last gpurun call
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_graph.py tests/test_graph_runner_dropin.py -x -q 2>&1 | tail -2
-RITZ_WG_KERNELS="auto" timeout 200 python tools/experiments/ritz_wg_sizes.py 2>&1 | grep -v amdgpu.ids | tr '\n' ' '; echo
-timeout 300 python tools/experiments/ritz_wg_fuzz.py 500 150 2>&1 | grep -v amdgpu.ids | tail -3
+mkdir -p gpurun_out
+timeout 300 python tools/bench_ritz_wg.py 2>/dev/null > gpurun_out/ritz_wg.jsonl
+python -c "
+import sys, json
+for l in open('gpurun_out/ritz_wg.jsonl'):
+    if l.startswith('{'):
+        d = json.loads(l); print(d['case'], d['B'], d['N'], {k: v['ms'] for k, v in d.items() if isinstance(v, dict)})
+"
