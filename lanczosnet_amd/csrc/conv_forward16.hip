@@ -809,13 +809,10 @@ int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s) {
       (const void*)lanczosnet_forward16_kernel<0, 2, false>, (const void*)lanczosnet_forward16_kernel<1, 2, false>,
       (const void*)lanczosnet_forward16_kernel<0, 0, true>,  (const void*)lanczosnet_forward16_kernel<1, 0, true>,
       (const void*)lanczosnet_forward16_kernel<0, 2, true>,  (const void*)lanczosnet_forward16_kernel<1, 2, true>};
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
-  if (!attr_set[which]) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[which] = true;
-  }
+  // per launch: the attribute is per device, and a process may drive several (DataParallel)
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;
   void* params[] = {&args};
   (void)hipLaunchKernel(fn, dim3(grid), dim3(512), params, bytes, s);

@@ -891,6 +891,9 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   if (a.gemm_mode != 0 || (a.filter_kind != 0 && a.filter_kind != 1)) return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
   if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
+  // dbias_part is sized by the TILE plan ([2 * plan_wg_cap] entries) and indexed by strip here: a
+  // strip beyond it would drop its bias-gradient partial, so such a launch stays on the tile kernel
+  if (mode == 1 && a.dbias_part && (!a.plan || a.strip_cap > 2 * a.plan_wg_cap)) return false;
   if (a.n_short + a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12 || a.dout > 31) return false;
   if (a.filter_kind == 1 && a.K % 4 != 0) return false;
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
@@ -909,12 +912,9 @@ bool strip_gain_grad_eligible(const lnz_forward_args& a) {
 
 int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s) {
   const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)lanczosnet_strip_gain_grad_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and a process may drive several (DataParallel)
+  (void)hipFuncSetAttribute((const void*)lanczosnet_strip_gain_grad_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(lanczosnet_strip_gain_grad_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
   return check_launch("lnz_lanczosnet_gain_grad (strips)");
 }
@@ -926,13 +926,10 @@ int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
       (const void*)lanczosnet_strip_kernel<0, 2, false>, (const void*)lanczosnet_strip_kernel<1, 2, false>,
       (const void*)lanczosnet_strip_kernel<0, 0, true>,  (const void*)lanczosnet_strip_kernel<1, 0, true>,
       (const void*)lanczosnet_strip_kernel<0, 2, true>,  (const void*)lanczosnet_strip_kernel<1, 2, true>};
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
-  if (!attr_set[which]) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[which] = true;
-  }
+  // per launch: the attribute is per device, and a process may drive several (DataParallel)
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;
   void* params[] = {&args};
   (void)hipLaunchKernel(fn, dim3(a.strip_cap), dim3(512), params, bytes, s);

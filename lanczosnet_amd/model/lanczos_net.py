@@ -424,11 +424,12 @@ class _LanczosNetBase(nn.Module):
             cache['conv'][key] = layers
         return cache
 
-    def _large_hip_supported(self, K):
+    def _large_hip_supported(self, K, channels=1):
         """lnz_large_*: uniform hidden width 128, input width <= 128, no short-diffusion powers,
-        K <= 64."""
+        K <= 64, at most 8 operator channels (the pack kernel's channel map, csrc/conv_large.hip:
+        `LargeChanMap`; more edge types take the library path like any other unsupported shape)."""
         return (set(self.hidden_dim[:self.num_layer]) == {128} and self.input_dim <= 128
-                and self.num_scale_short == 0 and K <= 64)
+                and self.num_scale_short == 0 and K <= 64 and channels <= 8)
 
     # -- channel folding of the large-graph path ------------------------------------------------
     # With one edge type (config/graph_lanczos_net.yaml:14) the collated L carries the SAME operator
@@ -456,7 +457,7 @@ class _LanczosNetBase(nn.Module):
             return ident, (True,) * Cn
         if L.stride(3) == 0:
             return (0,) * Cn, (True,) * Cn
-        st = self.__dict__.setdefault('_large_fold_state', {}).get(Cn)
+        st = self.__dict__.setdefault('_large_fold_state', {}).get((Cn, L.device.index))
         if st is None:
             return ident, (True,) * Cn
         if st.get('pending') is not None:
@@ -505,7 +506,9 @@ class _LanczosNetBase(nn.Module):
             chan_check=[0 if (classes[c] != c and proven[c]) else 1 for c in range(Cn)], neq=neq)
         if not compare:
             return Lb, Vb, classes, None
-        st = self.__dict__.setdefault('_large_fold_state', {}).setdefault(Cn, {})
+        # keyed per device: nn.DataParallel replicas are shallow copies that share this dict, and
+        # each of them runs on a device (and thread) of its own
+        st = self.__dict__.setdefault('_large_fold_state', {}).setdefault((Cn, Lf.device.index), {})
         host = st.get('host')
         if host is None:
             host = st['host'] = torch.zeros((1,), dtype=torch.int64).pin_memory()
@@ -679,7 +682,7 @@ class _LanczosNetBase(nn.Module):
                 # the reference trains arbitrary widths / sizes: differentiate the device-side
                 # torch restatement (same association as the kernels)
                 score = self._torch_forward(node_feat, L, D, V, mask, dropout=drop)
-            elif L.shape[1] > 32 and self._large_hip_supported(V.shape[2]):
+            elif L.shape[1] > 32 and self._large_hip_supported(V.shape[2], L.shape[3]):
                 # hand-written streaming kernels; 'bf16' = config 5's bf16-operand mode
                 score = self._large_graph_forward_hip(node_feat, L, D, V, mask,
                                                       planes=1 if self.gemm_mode == 'bf16'
@@ -875,7 +878,8 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         # Under HIP-graph capture (train.GraphedTrainStep) nothing may touch the host: the backward
         # then sizes its message matrix by the padded row count B * N and masks the tail on the
         # device instead of reading the real row count.
-        ctx.static_rows = torch.cuda.is_current_stream_capturing()
+        ctx.static_rows = (torch.cuda.is_current_stream_capturing()
+                           or bool(getattr(module, 'train_static_rows', False)))
         rtot = ev = None
         if not ctx.static_rows:
             rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
@@ -1478,7 +1482,8 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
                  torch.arange(1, N + 1, device=Q.device).view(1, N)).amax(dim=1)
         # (as _LanczosNetFusedFunction: under HIP-graph capture nothing may touch the host, the
         # backward then sizes its message matrix by the padded row count)
-        ctx.static_rows = torch.cuda.is_current_stream_capturing()
+        ctx.static_rows = (torch.cuda.is_current_stream_capturing()
+                           or bool(getattr(module, 'train_static_rows', False)))
         rtot = ev = None
         if not ctx.static_rows:
             rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)

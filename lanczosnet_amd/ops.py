@@ -1179,8 +1179,8 @@ def _f32_linear_workspace(M, N, K, device):
   key = (device.index, torch.cuda.current_stream(device).cuda_stream, need)
   ws = _F32_LINEAR_WS.get(key)
   if ws is None:
-    if len(_F32_LINEAR_WS) > 64:
-      _F32_LINEAR_WS.clear()
+    # never evicted: a captured HIP graph (train.GraphedTrainStep) holds these addresses — partial
+    # tiles and tile counters — for its lifetime; one entry per (device, stream, size), a few MB each
     ws = _F32_LINEAR_WS[key] = torch.zeros((need,), dtype=torch.float32, device=device)
   return ws
 

@@ -63,12 +63,10 @@ class GraphedTrainStep(object):
 
     def __init__(self, model, optimizer, warmup=2, scheduler=None):
         if scheduler is not None:
-            # (accepted for callers written against the first version of this class, which stepped
-            # it once per batch: the reference steps its scheduler once per EPOCH — see above)
-            import warnings
-            warnings.warn('GraphedTrainStep(scheduler=...) is ignored: step the LR scheduler in the '
-                          'epoch loop like runner/qm8_runner.py:190 does', DeprecationWarning,
-                          stacklevel=2)
+            # the reference steps its scheduler once per EPOCH (see above); silently ignoring the
+            # argument would train with a learning rate that never decays
+            raise TypeError('GraphedTrainStep(scheduler=...) is not supported: step the LR scheduler '
+                            'in the epoch loop like runner/qm8_runner.py:190 does')
         for group in optimizer.param_groups:
             # optimizers with host-side step counters (Adam & co.) expose the flag; plain SGD has
             # no such state and captures as it is

@@ -162,3 +162,65 @@ def test_a_non_finite_ritz_block_stays_with_its_molecule(strips, monkeypatch):
   others = torch.ones(B, dtype=torch.bool, device=DEV)
   others[bad] = False
   assert torch.equal(s_nan[others], s_ref[others])
+
+
+def test_strip_launches_from_two_threads_on_fresh_streams():
+  """The strip forward, input-gradient and gain-gradient launches set their dynamic-LDS function
+  attribute at EVERY launch (it is per device and `nn.DataParallel` — the reference's multi-GPU
+  mechanism, runner/qm8_runner.py:62 — drives one thread per device): nothing is configured "once
+  per process".  Two threads, each on a stream of its own, run the training step of the same batch
+  concurrently, several times; every result must equal the single-threaded one bit for bit.  (The
+  two-DEVICE variant is tests/test_gpu_multidevice.py, which needs a box with two GPUs; the CPU lint
+  test_no_process_wide_mutable_state_in_the_kernels_sources keeps the guard from coming back.)"""
+  import threading
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNet
+  from lanczosnet_amd.synthetic import draw_batch
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  P = oracle.make_lanczosnet_params(cfg, 3)
+  b = draw_batch(192, seed=5)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)  # noqa: E731
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+  nf, mk, lab = t(b['node_feat']), t(b['node_mask'].astype(np.uint8)), t(b['label'])
+  torch.cuda.synchronize()
+
+  def step(net):
+    net.zero_grad(set_to_none=True)
+    score, loss = net(nf, L, D, V, label=lab, mask=mk)
+    loss.backward()
+    return [score.detach().clone()] + [p.grad.detach().clone() for p in net.parameters()]
+
+  def make():
+    net = LanczosNet(make_model_config(cfg))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    return net.to(DEV).train()
+
+  want = step(make())
+  torch.cuda.synchronize()
+  out, err = {}, []
+
+  def worker(i):
+    try:
+      net = make()
+      s = torch.cuda.Stream()
+      s.wait_stream(torch.cuda.default_stream())
+      with torch.cuda.stream(s):
+        for _ in range(4):
+          out[i] = step(net)
+      s.synchronize()
+    except Exception as e:  # noqa: BLE001
+      err.append(e)
+
+  th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+  for x in th:
+    x.start()
+  for x in th:
+    x.join()
+  assert not err, err
+  for i in range(2):
+    assert len(out[i]) == len(want)
+    for a, w in zip(out[i], want):
+      assert torch.equal(a, w)

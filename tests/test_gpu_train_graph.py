@@ -39,6 +39,11 @@ def test_graphed_train_step_follows_the_eager_trajectory(optim):
   from lanczosnet_amd.train import GraphedTrainStep, make_adam
   net_e, batches = _setup(3)
   net_g, _ = _setup(3)
+  # the eager run on the captured step's row set (padded B * N message rows, all B * K eigen rows
+  # with the dead ones masked) instead of the live rows only: the two runs then add the same terms
+  # in the same order, and Adam — which turns rounding noise on near-zero gradients into +-lr
+  # moves — has no noise to amplify
+  net_e.train_static_rows = optim == 'adam'
   lr = 1e-2 if optim == 'sgd' else 1e-3
   mk = (lambda p: torch.optim.SGD(p, lr=lr)) if optim == 'sgd' else (lambda p: make_adam(p, lr=lr))
   opt_e, opt_g = mk(net_e.parameters()), mk(net_g.parameters())
@@ -73,11 +78,7 @@ def test_graphed_train_step_follows_the_eager_trajectory(optim):
     bt = batches[0]
     se = net_e(bt[0], bt[1], bt[2], bt[3], mask=bt[5])
     sg = net_g(bt[0], bt[1], bt[2], bt[3], mask=bt[5])
-  # (Adam: the eager backward runs the spectral-filter MLPs on the live eigen rows only, the
-  # captured one — no host knowledge of their number — on all B K rows with the dead ones masked:
-  # the same sums in a different order, and Adam turns rounding noise on near-zero gradients into
-  # +-lr moves, see above)
-  assert (se - sg).abs().max().item() <= (1e-5 if optim == 'sgd' else 5e-2) * se.abs().max().item()
+  assert (se - sg).abs().max().item() <= (1e-5 if optim == 'sgd' else 1e-3) * se.abs().max().item()
 
 
 def test_graphed_step_needs_a_capturable_optimizer():

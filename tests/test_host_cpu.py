@@ -254,3 +254,28 @@ def test_torch_extension_registers_every_entry_point_and_is_the_only_binding_of_
     for f in files:
       if f.endswith('.py') and f != '_lib.py':
         assert 'ctypes' not in open(os.path.join(dirpath, f)).read(), os.path.join(dirpath, f)
+
+
+def test_no_process_wide_mutable_state_in_the_kernels_sources():
+  """no global mutable state in the extension.  A function attribute (dynamic LDS
+  above 64 KiB) is PER DEVICE, and the reference's own multi-GPU mechanism drives several devices
+  from one process in one thread each (`nn.DataParallel`, runner/qm8_runner.py:62): a
+  `static bool attr_set` guard configures the first device only and is written without
+  synchronisation.  Any non-const `static` / namespace-scope variable in csrc/ fails here; the one
+  allowed object is the thread-local error string of `lnz_last_error()`."""
+  import re
+  csrc = os.path.join(ROOT, 'lanczosnet_amd', 'csrc')
+  decl = re.compile(r'^\s*static\s+(?!const\b|constexpr\b|inline\b|__device__|__global__|__host__|'
+                    r'__forceinline__|thread_local\b)[\w:<>,\s\*&]+?\b(\w+)\s*(\[[^\]]*\])*\s*(=|;|\{)')
+  bad = []
+  for f in sorted(os.listdir(csrc)):
+    if not f.endswith(('.hip', '.hpp', '.cpp', '.inc')):
+      continue
+    for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+      code = line.split('//')[0]
+      if 'attr_set' in code or decl.match(code):
+        bad.append('%s:%d: %s' % (f, i, line.strip()))
+  assert not bad, '\n'.join(bad)
+  tl = [l for f in os.listdir(csrc) if f.endswith(('.hip', '.hpp', '.cpp'))
+        for l in open(os.path.join(csrc, f)) if 'thread_local' in l.split('//')[0]]
+  assert len(tl) == 1 and 'g_err' in tl[0], tl

@@ -73,3 +73,62 @@ def test_hip_segment_sum_equals_the_built_reference():
     gout = rs.randn(B, D1, D2).astype(np.float32)
     gd = ops.unsorted_segment_sum_backward(dev(gout), dev(ids), D1).cpu().numpy()
     np.testing.assert_array_equal(gd, _ref_backward(gout, ids))              # gather: exact
+
+
+def test_operator_classes_have_the_reference_surface_and_refuse_cpu_tensors():
+  """`operators/functions/unsorted_segment_sum.py:8-44`, `operators/modules/unsorted_segment_sum.py:7-15`:
+  same class names, call forms and attribute; no CPU path behind them."""
+  from lanczosnet_amd.operators.functions.unsorted_segment_sum import UnsortedSegmentSumFunction
+  from lanczosnet_amd.operators.modules.unsorted_segment_sum import UnsortedSegmentSum
+  m = UnsortedSegmentSum(7)
+  assert m.num_segments == 7 and not list(m.parameters())
+  assert issubclass(UnsortedSegmentSumFunction, torch.autograd.Function)
+  with pytest.raises(Exception):
+    m(torch.zeros(2, 7, 3), torch.zeros(2, 7, dtype=torch.int64))
+  with pytest.raises(ValueError):
+    UnsortedSegmentSumFunction.apply(torch.zeros(2, 7), torch.zeros(2, 7, dtype=torch.int64), 7)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_operator_function_and_module_autograd_against_the_built_reference():
+  """`UnsortedSegmentSumFunction.apply(data, segment_index, num_segments)` (the form
+  `model/mpnn.py:9,88` uses) and `UnsortedSegmentSum(num_segments)(data, segment_index)`: forward
+  and the gradient autograd returns for `data` against the built reference operator's forward /
+  backward on the same inputs (shared ids, num_segments == dim1: the in-bounds use of both), plus
+  a finite-difference check of the backward on integer-valued data (exact in fp32)."""
+  from lanczosnet_amd.operators.functions.unsorted_segment_sum import UnsortedSegmentSumFunction
+  from lanczosnet_amd.operators.modules.unsorted_segment_sum import UnsortedSegmentSum
+  rs = np.random.RandomState(4)
+  dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to('cuda:0')  # noqa: E731
+  for (B, D1, D2) in ((3, 7, 5), (4, 33, 64), (2, 100, 128), (64, 24, 256)):
+    ids = np.repeat(rs.randint(0, D1, size=(1, D1)), B, axis=0).astype(np.int64)
+    data = rs.randint(-8, 9, size=(B, D1, D2)).astype(np.float32)
+    gout = rs.randint(-4, 5, size=(B, D1, D2)).astype(np.float32)
+    x = dev(data).requires_grad_(True)
+    y = UnsortedSegmentSumFunction.apply(x, dev(ids), D1)
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), _ref_forward(data, ids))
+    y.backward(dev(gout))
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), _ref_backward(gout, ids))
+    # module form, with a loss: d/d data of sum(w * y) is the gather of w
+    x2 = dev(data).requires_grad_(True)
+    (UnsortedSegmentSum(D1)(x2, dev(ids)) * dev(gout)).sum().backward()
+    assert torch.equal(x2.grad, x.grad)
+    # finite differences on one entry per batch (integers: every sum is exact)
+    b, i, j = rs.randint(B), rs.randint(D1), rs.randint(D2)
+    bump = data.copy()
+    bump[b, i, j] += 1.0
+    d = (UnsortedSegmentSumFunction.apply(dev(bump), dev(ids), D1) - y.detach()) * dev(gout)
+    assert float(d.sum()) == float(x.grad[b, i, j])
+  # per-batch ids and num_segments != dim1 (the GPU semantics): against the oracle's restatement
+  B, D1, D2, S = 5, 40, 36, 11
+  ids = rs.randint(0, S, size=(B, D1)).astype(np.int64)
+  data = rs.randint(-8, 9, size=(B, D1, D2)).astype(np.float32)
+  gout = rs.randint(-4, 5, size=(B, S, D2)).astype(np.float32)
+  x = dev(data).requires_grad_(True)
+  y = UnsortedSegmentSumFunction.apply(x, dev(ids), S)
+  np.testing.assert_array_equal(y.detach().cpu().numpy(),
+                                oracle.unsorted_segment_sum_forward_gpu_semantics(data, ids, S))
+  y.backward(dev(gout))
+  np.testing.assert_array_equal(x.grad.cpu().numpy(),
+                                oracle.unsorted_segment_sum_backward_gpu_semantics(gout, ids, D1))
