@@ -34,17 +34,50 @@ constexpr double kEps = 2.220446049250313e-16;
 //     v_readlane, writes by lane-select), and the rotated eigenvector row is carried in a
 //     register, so the LDS eigenvector update is off the scalar sqrt/rsqrt critical path.
 // =========================================================================================
-struct Ritz32Smem {
+struct Ritz32Smem {  // a VIEW (pointers in registers) onto the wavefront's dynamic LDS block
   static constexpr int LD = 34;   // doubles per basis row: b128 row reads conflict free
-  double Qt[32 * LD];
-  double za[32];
-  double zb[32];
-  double ca[32];
-  double cb[32];
-  double dd[32];
-  int perm[32];
-  float sgn[32];
+  double* Qt;     // [NR][LD] Krylov basis (transposed), then the Ritz vectors
+  double* za;     // [32] broadcast buffers of the Lanczos steps; the eigensolver keeps d here,
+  double* zb;     // [32] ... e,
+  double* ca;     // [32] ... e^2
+  double* cb;     // [32]
+  double* dd;     // [32] eigenvalues
+  double* Dw;     // [2][NR][32] twisted factorisation: lane-private columns [row][eigen lane]
+  double2* de;    // [10 + 2 NR] eigenvalue search: row operands {d_i, e_{i-1}^2}, a pad row behind every block
+  int* perm;      // [32]
+  float* sgn;     // [32]
+  int NR;         // rows of Dw = the batch's tile size N (n <= N <= 32)
+  __device__ __forceinline__ double& dw(int hh, int i, int rr) const { return Dw[(hh * NR + i) * 32 + rr]; }
 };
+
+// bytes of the block for tile size N.  Layout: the small arrays, the basis, the factorisation
+// columns, the search rows.  The basis is zeroed (and read) over its full 32-row extent whatever N:
+// rows N..31 lie in the arrays BEHIND it, which nothing writes before the eigensolver — the block
+// is never smaller than that extent.
+__host__ __device__ constexpr size_t ritz32_lds_bytes(int N) {
+  const size_t small_arrays = 5 * 32 * 8 + 256;
+  const size_t need = (size_t)(N * Ritz32Smem::LD + 64 * N + 2 * (10 + 2 * N)) * 8;
+  const size_t zeroed = (size_t)32 * Ritz32Smem::LD * 8;
+  return small_arrays + (need > zeroed ? need : zeroed);
+}
+
+__device__ __forceinline__ Ritz32Smem ritz32_view(unsigned char* base, int N) {
+  Ritz32Smem v;
+  double* p = reinterpret_cast<double*>(base);
+  v.za = p, p += 32;
+  v.zb = p, p += 32;
+  v.ca = p, p += 32;
+  v.cb = p, p += 32;
+  v.dd = p, p += 32;
+  v.perm = reinterpret_cast<int*>(p);
+  v.sgn = reinterpret_cast<float*>(v.perm + 32);
+  p += 32;
+  v.Qt = p, p += N * Ritz32Smem::LD;
+  v.Dw = p, p += 64 * N;
+  v.de = reinterpret_cast<double2*>(p);
+  v.NR = N;
+  return v;
+}
 
 __device__ inline double xhalf_sum(double x) {
   // x(lower half lane) + x(upper half lane), identical (bitwise) in both halves
@@ -91,7 +124,7 @@ __device__ inline double dot16(const double (&a)[16], const double (&b)[16]) {
 // blocks the pass has in registers anyway; every lane computes the same two numbers, so the
 // decision is wave uniform): what is left then has lost two digits to cancellation and is
 // re-orthogonalised ("twice is enough").  LNZ_RITZ32_CGS2_ALWAYS restores the unconditional form.
-__device__ inline double cgs2_32(Ritz32Smem& sm, double& x, int j, int r, int h) {
+__device__ inline double cgs2_32(const Ritz32Smem& sm, double& x, int j, int r, int h) {
   constexpr int LD = Ritz32Smem::LD;
   double qrow[16], qcol[16], v[16];
   double coef = 0.0;
@@ -149,108 +182,226 @@ __device__ __forceinline__ double rcp_nr(double x) {
   return fma(y, fma(-x, y, 1.0), y);
 }
 
-// Eigenvalue of rank (r - s) of the lane's block (see tridiag_eig_parallel).  Kept out of line:
-// inlined, its two 32-entry register arrays stay allocated next to those of the eigenvector stage
-// and push the kernel past 256 registers.
-__device__ __attribute__((noinline)) double tridiag_eigenvalue(const Ritz32Smem& sm, const int n,
-                                                               const int r, const int h, const int s,
-                                                               const int t, const int jloc,
-                                                               const double gsc, bool* bail,
-                                                               double* blo, double* bhi,
-                                                               const bool may_bail) {
-  // may_bail: first call (start from the spectral bound, stop at pass 12 if a cluster shows);
-  // otherwise resume from the bracket the first call returned in *blo / *bhi
-  const bool act = r < n;
-    // ---- 2. eigenvalue.  Sturm count in product form — p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},
-    //      one dependent FMA per row instead of a division; the count is the number of sign
-    //      changes, collected as sign bits.  The lane's rows outside its block are replaced by a
-    //      diagonal above the spectrum (never a sign change) with no coupling, so the 32-row
-    //      recurrence is straight-line code with no predicate.  Each lane carries two probe
-    //      points, the two lane halves four: the bracket shrinks 5x per pass.
-    double dv[32], e2[32];
-    const double pad = 2.0 * gsc + 1.0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const bool in = act && i >= s && i <= t;
-      dv[i] = in ? sm.za[i] : pad;
-      e2[i] = (in && i < t) ? sm.ca[i] : 0.0;
-    }
-    double lo = may_bail ? -gsc : *blo, hi = may_bail ? gsc : *bhi;
-    bool cluster = false;
-    for (int it = may_bail ? 0 : 13; it < 30; ++it) {
-      const double w = (hi - lo) * 0.2;
-      const double xa = lo + w * (h ? 3.0 : 1.0), xb = lo + w * (h ? 4.0 : 2.0);
-      double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
-      unsigned ma = 0u, mb = 0u;  // sign bits of p_0 .. p_31, row 31 in bit 0
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        const double ep = i > 0 ? e2[i > 0 ? i - 1 : 0] : 0.0;
-        const double pa = fma(dv[i] - xa, a1, -(ep * a2));
-        const double pb = fma(dv[i] - xb, b1, -(ep * b2));
-        ma = (ma << 1) | ((unsigned)__double2hiint(pa) >> 31);
-        mb = (mb << 1) | ((unsigned)__double2hiint(pb) >> 31);
-        a2 = a1, a1 = pa, b2 = b1, b1 = pb;
-        if ((i & 7) == 7) {  // keep |p| inside the exponent range
-          const double fa = fabs(a1), fb = fabs(b1);
-          const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
-          const double kb = fb < 1e-100 ? 1e100 : (fb > 1e100 ? 1e-100 : 1.0);
-          a1 *= ka, a2 *= ka, b1 *= kb, b2 *= kb;
-        }
-      }
-      // sign changes between consecutive p (p_{-1} = 1 > 0)
-      const int ca = __popc(ma ^ (ma >> 1)), cb = __popc(mb ^ (mb >> 1));
-      const int oa = __shfl_xor(ca, 32, 64), ob = __shfl_xor(cb, 32, 64);
-      // eigenvalues of the block below lo + w, lo + 2w, lo + 3w, lo + 4w
-      const int c1 = h ? oa : ca, c2 = h ? ob : cb, c3 = h ? ca : oa, c4 = h ? cb : ob;
-      const double x1 = lo + w, x2 = lo + 2.0 * w, x3 = lo + 3.0 * w, x4 = lo + 4.0 * w;
-      if (c1 > jloc) {
-        hi = x1;
-      } else if (c2 > jloc) {
-        lo = x1, hi = x2;
-      } else if (c3 > jloc) {
-        lo = x2, hi = x3;
-      } else if (c4 > jloc) {
-        lo = x3, hi = x4;
-      } else {
-        lo = x4;
-      }
-      if (may_bail && it == 12) {
-        // Bracket width is now ~1e-8 |T|.  Two eigenvalues of ONE block still sharing a bracket:
-        // a degenerate eigenvalue whose second copy crept into the Krylov space through round-off
-        // instead of a clean breakdown — the twisted vectors of such a pair would coincide.
-        // Rare (about one molecule per thousand): give up early, the caller runs the QL sweep.
-        const double lo_n = __shfl_up(lo, 1, 64);
-        const int s_n = __shfl_up(s, 1, 64);
-        cluster = act && (r & 31) > 0 && s_n == s && lo_n == lo;
-        if (__any(cluster)) {
-          *bail = cluster;  // per lane: shares its bracket with the lane below
-          *blo = lo, *bhi = hi;
-          return 0.0;
-        }
-      }
-      // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T| — an
-      // eigenvalue at (or next to) zero would otherwise keep every lane of the wave in the loop
-      // for all 30 passes without gaining anything the fp32 outputs or the twisted vectors need
-      const bool done = !act || (hi - lo) <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
-      if (__all(done)) break;
-    }
-    return 0.5 * (lo + hi);
+// ---- 2. eigenvalue search.  Sturm count in product form — p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2},
+// one dependent FMA per row instead of a division; the count is the number of sign changes of the
+// sequence, collected as sign bits (one v_alignbit per row and probe).  ALL blocks of T are
+// searched at once: the row operands {d_i, e_{i-1}^2} sit in LDS with one pad row (diagonal above
+// the spectrum, no coupling: never a sign change) behind every block, lane r walks the rows of
+// ITS block from P(s) on and stays on its pad row once it is through — address = min(running
+// address, pad address), one integer instruction per row — so the recurrence is predicate-free
+// straight-line code over ceil(longest block / 8) * 8 rows: its cost follows the molecule's size,
+// not the 32-row tile, and restarts (more blocks) cost nothing.  The operands of the next eight
+// rows are in flight while the current eight are worked on.  The value p_len(x) of the
+// characteristic polynomial comes out of the same recurrence (renormalised every eight rows,
+// exponent tracked) and drives the probe placement.
+struct EigState {
+  double lo, hi;    // bracket of the lane's eigenvalue
+  double flo, fhi;  // p(lo), p(hi): mantissas ...
+  int elo, ehi;     // ... and binary exponents
+  int clo, chi;     // eigenvalues of the block below lo / below hi
+  bool done, sect;
+};
+
+__device__ __forceinline__ double both_halves(double x, double& upper) {
+  // -> value of the lower-half lane (returned) and of the upper-half lane, in both halves
+  unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  upper = __hiloint2double((int)rh[1], (int)rl[1]);
+  return __hiloint2double((int)rh[0], (int)rl[0]);
 }
 
-__device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, const double ereg,
+__device__ __forceinline__ int both_halves(int x, int& upper) {
+  auto rr = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  upper = (int)rr[1];
+  return (int)rr[0];
+}
+
+// value of the neighbouring lanes (lane - 1, lane + 1) by DPP wave shifts (0 at the wave's ends)
+__device__ __forceinline__ void lane_neighbours(double x, double& below, double& above) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  below = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false),   // wave_shr:1
+                           __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false));
+  above = __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false),   // wave_shl:1
+                           __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false));
+}
+
+struct SturmRows {
+  double2 v[8];
+};
+
+// the eight row operands from byte address a0 on (lane-private walk, clamped to the pad row)
+__device__ __forceinline__ void sturm_load(const Ritz32Smem& sm, const unsigned a0,
+                                           const unsigned (&lim)[8], SturmRows& rows) {
+  const char* base = reinterpret_cast<const char*>(sm.de);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const unsigned a = a0 < lim[u] ? a0 : lim[u];  // min(a0 + 16 u, pad) - 16 u
+    rows.v[u] = *reinterpret_cast<const double2*>(base + a + 16 * u);
+  }
+}
+
+struct SturmChain {
+  double p1, p2;
+  unsigned m;
+  int k;
+};
+
+__device__ __forceinline__ void sturm_rows(const SturmRows& rows, const double xa, const double xb,
+                                           SturmChain& A, SturmChain& B) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const double pa = fma(rows.v[u].x - xa, A.p1, -(rows.v[u].y * A.p2));
+    const double pb = fma(rows.v[u].x - xb, B.p1, -(rows.v[u].y * B.p2));
+    A.m = __builtin_amdgcn_alignbit(A.m, (unsigned)__double2hiint(pa), 31);
+    B.m = __builtin_amdgcn_alignbit(B.m, (unsigned)__double2hiint(pb), 31);
+    A.p2 = A.p1, A.p1 = pa, B.p2 = B.p1, B.p1 = pb;
+  }
+  // keep |p| inside the exponent range: p = mantissa * 2^k, 0.5 <= |mantissa| < 1
+  const int qa = __builtin_amdgcn_frexp_exp(A.p1), qb = __builtin_amdgcn_frexp_exp(B.p1);
+  A.p1 = __builtin_ldexp(A.p1, -qa), A.p2 = __builtin_ldexp(A.p2, -qa), A.k += qa;
+  B.p1 = __builtin_ldexp(B.p1, -qb), B.p2 = __builtin_ldexp(B.p2, -qb), B.k += qb;
+}
+
+// Sturm counts and polynomial values of the lane's block at its two probe points.  a_base: byte
+// offset of the block's first row in sm.de, lim[u] = (pad row's offset) - 16 u.
+__device__ __forceinline__ void sturm_pair(const Ritz32Smem& sm, const unsigned a_base,
+                                           const unsigned (&lim)[8], const int maxlen,
+                                           const double xa, const double xb, int& ca, int& cb,
+                                           double& fa, double& fb, int& ea, int& eb) {
+  SturmChain A = {1.0, 0.0, 0u, 0}, B = {1.0, 0.0, 0u, 0};
+  SturmRows r0, r1;
+  sturm_load(sm, a_base, lim, r0);
+  if (maxlen > 8) sturm_load(sm, a_base + 128u, lim, r1);
+  sturm_rows(r0, xa, xb, A, B);
+  if (maxlen > 8) {
+    if (maxlen > 16) sturm_load(sm, a_base + 256u, lim, r0);
+    sturm_rows(r1, xa, xb, A, B);
+    if (maxlen > 16) {
+      if (maxlen > 24) sturm_load(sm, a_base + 384u, lim, r1);
+      sturm_rows(r0, xa, xb, A, B);
+      if (maxlen > 24) sturm_rows(r1, xa, xb, A, B);
+    }
+  }
+  // sign changes between consecutive p (p_{-1} = 1 > 0)
+  ca = __popc(A.m ^ (A.m >> 1)), cb = __popc(B.m ^ (B.m >> 1));
+  fa = A.p1, fb = B.p1, ea = A.k, eb = B.k;
+}
+
+// Passes it0 .. 29 of the search.  Every lane carries two probe points, the two lane halves four.
+// Placement:
+//   pass 0    the bracket's ends and its thirds (so that every later end point carries p);
+//   section   lo + k w / 5: the bracket shrinks 5x per pass;
+//   isolated  (exactly one eigenvalue inside, p changes sign): the secant point x* of the two end
+//             values, probes at x* -+ d1 and x* -+ d2 with d1 ~ the secant's error w^2 / gap (gap:
+//             distance to the neighbouring lanes' brackets) and d2 = 16 d1: the bracket collapses
+//             quadratically — the lanes of a well separated spectrum are through after 8..11
+//             passes instead of 23..25; a pass that gains less than 4x is followed by a section pass.
+// The brackets are always updated from the COUNTS (the values only place the probes).
+// may_bail: at pass 12 (bracket width ~ 3e-9 |T|) two lanes of one block that still share a
+// bracket are reported in `bail` (a numerically multiple eigenvalue, see the caller) and the
+// search of their block stops; the caller resumes it with it0 = 13.
+__device__ __forceinline__ void eigenvalue_search(const Ritz32Smem& sm, EigState& st, const int n,
+                                                  const int r, const int h, const int s, const int t,
+                                                  const unsigned a_base, const unsigned a_pad,
+                                                  const int maxlen, const double gsc, const int it0,
+                                                  const bool may_bail, bool& bail) {
+  const bool act = r < n;
+  const int jloc = r - s;
+  const bool has_dn = act && r > s, has_up = act && r < t;
+  unsigned lim[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) lim[u] = a_pad - 16u * u;
+  bool halt = false;  // the lane's block holds a cluster: wait for the caller
+  for (int it = it0; it < 30; ++it) {
+    if (__all(st.done || halt)) break;
+    const double lo = st.lo, hi = st.hi, w = hi - lo;
+    const double tol = 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
+    // the neighbouring lanes' brackets
+    double m_dn, m_up;
+    lane_neighbours(0.5 * (lo + hi), m_dn, m_up);
+    const bool iso = it > 0 && !st.sect && st.chi - st.clo == 1 && st.flo != 0.0 &&
+                     ((__double2hiint(st.flo) ^ __double2hiint(st.fhi)) < 0);
+    // section placement (pass 0: thirds and both ends)
+    const double step = it == 0 ? w * (1.0 / 3.0) : w * 0.2;
+    double x1 = it == 0 ? lo : lo + step, x2 = x1 + step, x3 = x2 + step, x4 = it == 0 ? hi : x3 + step;
+    if (iso) {
+      int de_ = st.ehi - st.elo;
+      de_ = de_ < -1000 ? -1000 : (de_ > 1000 ? 1000 : de_);
+      // x* = lo + w p(lo) / (p(lo) - p(hi)), the values of opposite sign
+      const double fh = __builtin_ldexp(st.fhi, de_);
+      const double xs = fma(w, st.flo * rcp_nr(st.flo - fh), lo);
+      double g = gsc;
+      g = has_dn ? fmin(g, fabs(xs - m_dn)) : g;
+      g = has_up ? fmin(g, fabs(m_up - xs)) : g;
+      double d1 = 0.5 * w * w * __builtin_amdgcn_rcp(fmax(g, 1e-300));
+      d1 = fmin(d1, 0.125 * w);
+      d1 = fmax(d1, 0.45 * tol);
+      const double d2 = fmin(0.25 * w, 16.0 * d1);
+      x1 = fmin(fmax(xs - d2, lo), hi), x2 = fmin(fmax(xs - d1, lo), hi);
+      x3 = fmin(fmax(xs + d1, lo), hi), x4 = fmin(fmax(xs + d2, lo), hi);
+    }
+    int ca, cb, ea, eb;
+    double fa, fb;
+    sturm_pair(sm, a_base, lim, maxlen, h ? x3 : x1, h ? x4 : x2, ca, cb, fa, fb, ea, eb);
+    // all four probes in both halves (count and exponent travel in one word)
+    int k3, k4;
+    const int k1 = both_halves((ea << 8) | ca, k3), k2 = both_halves((eb << 8) | cb, k4);
+    double f3, f4;
+    const double f1 = both_halves(fa, f3), f2 = both_halves(fb, f4);
+    // the first probe with more than jloc eigenvalues below it closes the bracket from above
+    const bool b1 = (k1 & 255) > jloc, b2 = (k2 & 255) > jloc, b3 = (k3 & 255) > jloc, b4 = (k4 & 255) > jloc;
+    const bool upd = !st.done && !halt;
+    const bool nl = upd && !b1, nh = upd && (b1 || b2 || b3 || b4);  // a new lower / upper end
+    // lower end: the last probe in front of that one
+    const bool l4 = !b1 && !b2 && !b3 && !b4, l3 = !b1 && !b2 && !b3 && b4, l2 = !b1 && !b2 && b3;
+    const double nlo = l4 ? x4 : (l3 ? x3 : (l2 ? x2 : x1));
+    const double nflo = l4 ? f4 : (l3 ? f3 : (l2 ? f2 : f1));
+    const int nklo = l4 ? k4 : (l3 ? k3 : (l2 ? k2 : k1));
+    const double nhi = b1 ? x1 : (b2 ? x2 : (b3 ? x3 : x4));
+    const double nfhi = b1 ? f1 : (b2 ? f2 : (b3 ? f3 : f4));
+    const int nkhi = b1 ? k1 : (b2 ? k2 : (b3 ? k3 : k4));
+    st.lo = nl ? nlo : st.lo, st.flo = nl ? nflo : st.flo;
+    st.clo = nl ? (nklo & 255) : st.clo, st.elo = nl ? (nklo >> 8) : st.elo;
+    st.hi = nh ? nhi : st.hi, st.fhi = nh ? nfhi : st.fhi;
+    st.chi = nh ? (nkhi & 255) : st.chi, st.ehi = nh ? (nkhi >> 8) : st.ehi;
+    const double nw = st.hi - st.lo;
+    st.sect = nw > 0.25 * w;
+    // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|
+    st.done = st.done || nw <= 4.0 * kEps * fmax(fmax(fabs(st.lo), fabs(st.hi)), 0.125 * gsc);
+    if (may_bail && it == 12) {
+      // Two eigenvalues of ONE block still sharing a bracket: a degenerate eigenvalue whose
+      // second copy crept into the Krylov space through round-off instead of a clean breakdown
+      // — the twisted vectors of such a pair would coincide.  Rare (about two molecules per
+      // thousand): the caller assigns twist windows (or runs the QL sweep).
+      const double lo_n = __shfl_up(st.lo, 1, 64);
+      const bool cluster = has_dn && !st.done && lo_n == st.lo;
+      const unsigned cm = (unsigned)__ballot(cluster && h == 0);
+      if (cm) {
+        bail = bail || cluster;  // per lane: shares its bracket with the lane below
+        // every lane of a block with a cluster stops here (blocks are lane ranges [s, t])
+        const unsigned range = (t >= 31 ? 0xffffffffu : ((2u << t) - 1u)) & ~((1u << s) - 1u);
+        halt = act && (cm & range) != 0u;
+      }
+    }
+  }
+}
+
+__device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double dreg, const double ereg,
                                             const int n, const int r, const int h, long long* ts = nullptr) {
   constexpr int LD = Ritz32Smem::LD;
   if (ts) ts[0] = clock64();
   // ---- d, e -> LDS (broadcast reads); negligible couplings split the matrix
   const double dn = __shfl_down(dreg, 1, 64);
   const bool live = r < n - 1 && fabs(ereg) > kEps * (fabs(dreg) + fabs(dn));
-  if (h == 0) {
-    sm.za[r] = r < n ? dreg : 0.0;
-    sm.zb[r] = live ? ereg : 0.0;
-    sm.ca[r] = live ? ereg * ereg : 0.0;
-  }
-  __syncthreads();
+  const double e_live = live ? fabs(ereg) : 0.0;
+  const double e_prev = __shfl_up(e_live, 1, 64);
   const bool act = r < n;
+  // Gershgorin bound of the spectrum: one row per lane, wave maximum
+  double gmax = act ? fabs(dreg) + ((r & 31) > 0 ? e_prev : 0.0) + e_live : 0.0;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
+  const double gsc = gmax > 0.0 ? gmax : 1.0;
   // block [s, t] of this lane's index; the lane owns the (r - s)-th eigenvalue of that block.
   // Bit i of `cut` = coupling e_i (between rows i and i+1) is dead: s is one past the highest cut
   // below r, t the lowest cut at or above r (bit n-1 is always set) — bit scans, not LDS walks.
@@ -263,16 +414,37 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     t = above ? __ffs(above) - 1 : n - 1;
     t = t > n - 1 ? n - 1 : t;
   }
-  // Gershgorin bound of the spectrum: one row per lane, wave maximum
-  const double e_live = live ? fabs(ereg) : 0.0;
-  const double e_prev = __shfl_up(e_live, 1, 64);
-  double gmax = act ? fabs(dreg) + ((r & 31) > 0 ? e_prev : 0.0) + e_live : 0.0;
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, off, 64));
-  const double gsc = gmax > 0.0 ? gmax : 1.0;
+  // row i of T sits at entry P(i) = 8 + i + (blocks in front of it) of sm.de, the pad row of a
+  // block behind its last row (see eigenvalue_search)
+  const unsigned nlow = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+  auto P = [&](int i) { return 8 + i + __popc(cut & nlow & ((1u << i) - 1u)); };
+  const int last_pad = P(n - 1) + 1;
+  if (h == 0 && act) {
+    sm.za[r] = dreg;
+    sm.zb[r] = live ? ereg : 0.0;
+    sm.ca[r] = live ? ereg * ereg : 0.0;
+    const int p = P(r);
+    sm.de[p] = make_double2(dreg, (r & 31) > 0 ? e_prev * e_prev : 0.0);
+    if ((cut >> r) & 1u) sm.de[p + 1] = make_double2(2.0 * gsc + 1.0, 0.0);
+  }
+  __syncthreads();
+  const unsigned a_base = 16u * (unsigned)(act ? P(s) : last_pad);
+  const unsigned a_pad = 16u * (unsigned)(act ? P(t) + 1 : last_pad);
+  // longest block (wave uniform): the loop bound of the recurrences below
+  int maxlen = 1;
+  for (int sb = 0; sb < n;) {
+    const unsigned above = cut & ~((1u << sb) - 1u);
+    int tb = above ? __ffs(above) - 1 : n - 1;
+    tb = tb > n - 1 ? n - 1 : tb;
+    maxlen = tb - sb + 1 > maxlen ? tb - sb + 1 : maxlen;
+    sb = tb + 1;
+  }
+  EigState st;
+  st.lo = -gsc, st.hi = gsc, st.flo = st.fhi = 0.0, st.elo = st.ehi = 0, st.clo = 0, st.chi = t - s + 1;
+  st.done = !act, st.sect = true;
+  if (act && t == s) st.lo = st.hi = dreg, st.done = true;  // a 1 x 1 block: its diagonal entry
   bool bail = false;
-  double blo = 0.0, bhi = 0.0;
-  double lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail, &blo, &bhi, true);
+  eigenvalue_search(sm, st, n, r, h, s, t, a_base, a_pad, maxlen, gsc, 0, true, bail);
   // twist window: where this lane looks for the twist index (its whole block unless it is part
   // of a cluster, see below)
   int ws = s, wt = t;
@@ -303,13 +475,13 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     };
     bool ok = true;
     if (member && act) {
-      const double cut = 1e-3 * gsc, wd = 1e-5 * gsc;
-      const double xl = blo - wd, xh = bhi + wd;
+      const double cutoff = 1e-3 * gsc, wd = 1e-5 * gsc;
+      const double xl = st.lo - wd, xh = st.hi + wd;
       int g = (r - s) - count(xl, s, t);  // rank inside the widened bracket
       int a = s;
       bool found = false;
       for (int i = s; i <= t && !found; ++i) {
-        if (i == t || fabs(sm.zb[i]) <= cut) {
+        if (i == t || fabs(sm.zb[i]) <= cutoff) {
           const int inside = count(xh, a, i) - count(xl, a, i);
           if (g < inside) {
             ws = a, wt = i;
@@ -325,80 +497,104 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     }
     if (__any(!ok)) return false;
     bool bail2 = false;
-    lam = tridiag_eigenvalue(sm, n, r, h, s, t, r - s, gsc, &bail2, &blo, &bhi, false);
+    eigenvalue_search(sm, st, n, r, h, s, t, a_base, a_pad, maxlen, gsc, 13, false, bail2);
   }
+  const double lam = 0.5 * (st.lo + st.hi);
   if (ts) ts[1] = clock64();
-  // ---- 3. eigenvector of the block: twisted factorisation of T - lam
-  double z[32];
+  // ---- 3. eigenvector of the block: twisted factorisation of T - lam, both lane halves at work.
+  //      Half 0 runs the stationary transform top down, D+_{i+1} = (d_{i+1} - lam) - e_i^2 / D+_i,
+  //      half 1 the progressive one bottom up, D-_i = (d_i - lam) - e_i^2 / D-_{i+1} — the same
+  //      instruction stream on mirrored rows; both park their pivots in the lane's LDS columns
+  //      Dw[0] / Dw[1] ([row][eigen lane]: conflict free).  gamma_i = D+_i + D-_i - (d_i - lam);
+  //      twist where |gamma| is smallest; then half 0 solves upwards from the twist index, half 1
+  //      downwards, and the vector replaces D+ in Dw[0].  Loop bounds: the longest block.
+  const double tiny = kEps * gsc;
+  const int len = act ? t - s : -1;
   {
-    double Dm[32];
-    const double tiny = kEps * gsc;
-    // stationary transform, top down: D+_{i+1} = (d_{i+1} - lam) - e_i^2 / D+_i   (parked in z)
-    double Dp = 1.0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      z[i] = 0.0;
-      if (i < n) {
-        const bool in = act && i >= s && i <= t;
-        const double di = sm.za[i] - lam;
-        const double e2p = i > 0 ? sm.ca[i > 0 ? i - 1 : 0] : 0.0;
-        double dnew = (i > s) ? di - e2p * rcp_nr(Dp) : di;
-        dnew = fabs(dnew) < tiny ? (dnew < 0.0 ? -tiny : tiny) : dnew;
-        Dp = in ? dnew : Dp;
-        z[i] = in ? dnew : 0.0;
+    double Dprev = 1.0;
+    // the row operands travel one step ahead of the pivot chain
+    int i = len >= 0 ? (h ? t : s) : 0;
+    double dcur = sm.za[i], ecur = 0.0;  // (no coupling into the first row of the sweep)
+    for (int k = 0; k < maxlen; ++k) {
+      const bool in = k <= len;
+      const bool in_n = k + 1 <= len;
+      const int i_n = in_n ? (h ? t - k - 1 : s + k + 1) : 1;
+      const double dnx = sm.za[i_n], enx = sm.ca[h ? i_n : i_n - 1];
+      const double di = dcur - lam;
+      double dnew = fma(-ecur, rcp_nr(Dprev), di);
+      dnew = fabs(dnew) < tiny ? (dnew < 0.0 ? -tiny : tiny) : dnew;
+      if (in) {
+        Dprev = dnew;
+        sm.dw(h, i, r) = dnew;
       }
+      i = i_n, dcur = dnx, ecur = enx;
     }
-    // progressive transform, bottom up: D-_i = (d_i - lam) - e_i^2 / D-_{i+1};
-    // gamma_i = D+_i + D-_i - (d_i - lam); twist where |gamma| is smallest
-    double Dn = 1.0, gbest = 1e300;
-    int tw = s;
+  }
+  __syncthreads();
+  if (ts) ts[4] = clock64();
+  int tw = s;
+  {
+    double gbest = 1e300;
+    for (int k = h; k < maxlen; k += 2) {     // the halves take alternate rows
+      const int i = s + k;
+      const bool in = k <= len && i >= ws && i <= wt;
+      const int ic = in ? i : 0;
+      const double g = fabs((sm.dw(0, ic, r) + sm.dw(1, ic, r)) - (sm.za[ic] - lam));
+      // ties: the highest index (the order of a downward scan with a strict comparison)
+      if (in && (g < gbest || (g == gbest && i > tw))) gbest = g, tw = i;
+    }
+    double g_up;
+    int t_up;
+    const double g_lo = both_halves(gbest, g_up);
+    const int t_lo = both_halves(tw, t_up);
+    const bool take_up = g_up < g_lo || (g_up == g_lo && t_up > t_lo);
+    tw = take_up ? t_up : t_lo;
+    tw = act ? tw : 0;
+  }
+  __syncthreads();  // (every gamma has been read before the vectors overwrite D+)
+  if (ts) ts[5] = clock64();
+  double sc;
+  {
+    // half 0: z_i = -(e_i / D+_i) z_{i+1} upwards from the twist index; half 1:
+    // z_i = -(e_{i-1} / D-_i) z_{i-1} downwards.  The multipliers do not depend on the chain:
+    // four rows at a time, their reciprocals overlap.
+    double zprev = 1.0, nn = h ? 0.0 : 1.0;
+    if (act && h == 0) sm.dw(0, tw, r) = 1.0;
+    for (int k0 = 1; k0 < maxlen; k0 += 4) {
+      double mul[4];
+      int ix[4];
+      bool inx[4];
 #pragma unroll
-    for (int i = 31; i >= 0; --i) {
-      Dm[i] = 1.0;
-      if (i < n) {
-        const bool in = act && i >= s && i <= t;
-        const double di = sm.za[i] - lam;
-        const double e2 = sm.ca[i];
-        double dnew = (i < t) ? di - e2 * rcp_nr(Dn) : di;
-        dnew = fabs(dnew) < tiny ? (dnew < 0.0 ? -tiny : tiny) : dnew;
-        Dn = in ? dnew : Dn;
-        Dm[i] = in ? dnew : 1.0;
-        const double g = fabs(z[i] + dnew - di);
-        if (in && i >= ws && i <= wt && g < gbest) {
-          gbest = g;
-          tw = i;
+      for (int u = 0; u < 4; ++u) {
+        const int i = h ? tw + k0 + u : tw - k0 - u;
+        inx[u] = act && (h ? i <= t : i >= s);
+        ix[u] = inx[u] ? i : 1;
+        mul[u] = -(sm.zb[h ? ix[u] - 1 : ix[u]] * rcp_nr(sm.dw(h, ix[u], r)));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double znew = mul[u] * zprev;
+        if (inx[u]) {
+          sm.dw(0, ix[u], r) = znew;
+          zprev = znew;
+          nn = fma(znew, znew, nn);
         }
       }
     }
-    // z_tw = 1; upward z_i = -(e_i / D+_i) z_{i+1} (D+_i is read from z[i] before it is replaced);
-    // downward z_{i+1} = -(e_i / D-_{i+1}) z_i
-#pragma unroll
-    for (int i = 31; i >= 0; --i) {
-      if (i < n) {
-        const bool in = act && i >= s && i <= t;
-        const double up = i < 31 ? -(sm.zb[i] * rcp_nr(z[i])) * z[i < 31 ? i + 1 : 31] : 0.0;
-        z[i] = !in ? 0.0 : (i == tw ? 1.0 : (i < tw ? up : 0.0));
-      }
-    }
-#pragma unroll
-    for (int i = 1; i < 32; ++i) {
-      if (i < n) {
-        const bool in = act && i >= s && i <= t;
-        z[i] = (in && i > tw) ? -(sm.zb[i - 1] * rcp_nr(Dm[i])) * z[i - 1] : z[i];
-      }
-    }
-    double nn = 0.0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) nn = fma(z[i], z[i], nn);
-    const double sc = act ? rsqrt(nn) : 0.0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) z[i] *= sc;
+    nn = xhalf_sum(nn);
+    sc = act ? rsqrt(nn) : 0.0;
   }
+  __syncthreads();
 
   if (__any(member)) {
-    // cluster lanes: modified Gram-Schmidt in lane order.  pos = how many consecutive lower lanes
-    // belong to the same cluster; the lane at position p is orthogonalised against the (final)
-    // vectors of the p lanes below it.
+    // cluster lanes: modified Gram-Schmidt in lane order, on the LDS columns.  pos = how many
+    // consecutive lower lanes belong to the same cluster; the lane at position p is
+    // orthogonalised against the (final) vectors of the p lanes below it.
+    if (member && act) {  // normalised column, zero outside the block (both halves write the same)
+      for (int i = 0; i < n; ++i) sm.dw(0, i, r) = (i >= s && i <= t) ? sm.dw(0, i, r) * sc : 0.0;
+      sc = 1.0;
+    }
+    __syncthreads();
     int pos = 0;
     {
       bool chain = true;
@@ -413,23 +609,18 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
     }
     for (int p = 1; p <= 3; ++p) {
       if (!__any(pos >= p)) break;
-      for (int d = 1; d <= p; ++d) {
-        const bool fix = pos == p;
-        double dot = 0.0;
-#pragma unroll
-        for (int i = 0; i < 32; ++i) dot = fma(z[i], __shfl_up(z[i], d, 64), dot);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-          const double zl = __shfl_up(z[i], d, 64);
-          z[i] = fix ? fma(-dot, zl, z[i]) : z[i];
+      if (pos == p) {
+        for (int d = 1; d <= p; ++d) {
+          double dot = 0.0;
+          for (int i = 0; i < n; ++i) dot = fma(sm.dw(0, i, r), sm.dw(0, i, r - d), dot);
+          for (int i = 0; i < n; ++i) sm.dw(0, i, r) = fma(-dot, sm.dw(0, i, r - d), sm.dw(0, i, r));
         }
+        double nn = 0.0;
+        for (int i = 0; i < n; ++i) nn = fma(sm.dw(0, i, r), sm.dw(0, i, r), nn);
+        const double s2 = nn > 0.0 ? rsqrt(nn) : 1.0;
+        for (int i = 0; i < n; ++i) sm.dw(0, i, r) *= s2;
       }
-      double nn = 0.0;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) nn = fma(z[i], z[i], nn);
-      const double sc = (pos == p && nn > 0.0) ? rsqrt(nn) : 1.0;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) z[i] *= sc;
+      __syncthreads();
     }
   }
 
@@ -438,19 +629,18 @@ __device__ inline bool tridiag_eig_parallel(Ritz32Smem& sm, const double dreg, c
   double acc[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+#pragma unroll 2
+  for (int i = 0; i < n; ++i) {
+    double q[16];
+    load16(&sm.Qt[i * LD + 16 * h], q);
+    const double zi = (act && i >= s && i <= t) ? sm.dw(0, i, r) : 0.0;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    if (i < n) {
-      double q[16];
-      load16(&sm.Qt[i * LD + 16 * h], q);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] = fma(q[u], z[i], acc[u]);
-    }
+    for (int u = 0; u < 16; ++u) acc[u] = fma(q[u], zi, acc[u]);
   }
   __syncthreads();
   if (act) {
 #pragma unroll
-    for (int u = 0; u < 16; ++u) sm.Qt[r * LD + 16 * h + u] = acc[u];
+    for (int u = 0; u < 16; ++u) sm.Qt[r * LD + 16 * h + u] = acc[u] * sc;
     if (h == 0) sm.dd[r] = lam;
   }
   __syncthreads();
@@ -463,7 +653,7 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info, const int b, const int lane,
-    Ritz32Smem& sm) {
+    const Ritz32Smem& sm) {
   constexpr int LD = Ritz32Smem::LD;
   const int r = lane & 31, h = lane >> 5;
   int n = n_nodes[b];
@@ -480,13 +670,15 @@ __device__ __forceinline__ void lanczos_ritz32_body(
       arow[t] = (r < n && c < n) ? (double)Ab[c * sc] : 0.0;
     }
   }
-  // zero the basis (rows beyond the current step must read as zero)
+  // zero the basis (rows beyond the current step must read as zero) over its full 32-row extent:
+  // rows NR..31 lie in the factorisation columns behind it, which nothing writes before the
+  // eigensolver (8.7 KB < the block's size for every N >= 1)
   for (int idx = lane; idx < 32 * LD / 2; idx += 64)
     reinterpret_cast<double2*>(sm.Qt)[idx] = make_double2(0.0, 0.0);
   __syncthreads();
 #ifdef LNZ_PROFILE_PHASES
   long long tp0 = clock64(), tp1 = tp0, tp2 = tp0;
-  long long tsx[4] = {0, 0, 0, 0};
+  long long tsx[6] = {0, 0, 0, 0, 0, 0};
 #endif
 
   int nrestart = 0;
@@ -702,6 +894,8 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     D[(int64_t)b * K + 4] = (float)(tsx[1] - tsx[0]);
     D[(int64_t)b * K + 5] = (float)(tsx[2] - tsx[1]);
     D[(int64_t)b * K + 6] = (float)(tsx[3] - tsx[2]);
+    D[(int64_t)b * K + 7] = (float)(tsx[4] - tsx[1]);   // pivot sweeps
+    D[(int64_t)b * K + 8] = (float)(tsx[5] - tsx[4]);   // twist index
   }
 #endif
 }
@@ -710,17 +904,25 @@ __global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
-  lanczos_ritz32_body(A, sb, sr, sc, n_nodes, N, K, D, V, info, blockIdx.x, threadIdx.x, sm);
+  extern __shared__ __attribute__((aligned(16))) unsigned char ubuf[];
+  lanczos_ritz32_body(A, sb, sr, sc, n_nodes, N, K, D, V, info, blockIdx.x, threadIdx.x,
+                      ritz32_view(ubuf, N));
 }
 
 // Everything the fused forward needs from a collated batch besides the gains, in ONE launch of
-// 256-thread workgroups: workgroup 0 plans the batch (tile plan + live eigen slots), workgroups
-// 1..B are the Lanczos/QL wavefronts (one live wave each — the other three exit at once, and a
-// terminated wave does not take part in barriers), workgroups B+1..2B pack the Laplacian tiles.
-// The Ritz wavefronts are the long pole (latency bound, one wave per SIMD); dispatched first, they
-// leave most of the machine idle, and the two byte movers run in that shadow instead of in front.
-__global__ __launch_bounds__(256) void prepare_batch_kernel(
+// 256-thread workgroups: workgroup 0 plans the batch (tile plan + live eigen slots + strips),
+// workgroups 1..B are the Lanczos / eigensolve wavefronts (one live wave each — the other three
+// exit at once, and a terminated wave does not take part in barriers), workgroups B+1..2B pack
+// the Laplacian tiles.  The Ritz wavefronts are the long pole (latency bound, one wave per SIMD);
+// dispatched first, they leave most of the machine idle, and the two byte movers run in that
+// shadow instead of in front.
+// ONE dynamic LDS block per workgroup, used according to its role (Ritz scratch, pack staging
+// tile, planner scratch): max of the three — QM8 (N = 26, C = 7): 24.5 KB, six workgroups per
+// compute unit.  168 registers (three wave slots per SIMD): next to the four resident Ritz
+// wavefronts of a compute unit, two pack workgroups run at a time (with the 248 registers of the
+// r04 body it was one, and the B pack workgroups trickled through behind the Ritz waves).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+void prepare_batch_union_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
     float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
     int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
@@ -728,42 +930,7 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
     const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
     int32_t* __restrict__ info, uint32_t* __restrict__ ident, int32_t* __restrict__ strips,
     int32_t* __restrict__ n_strips) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  __shared__ __attribute__((aligned(16))) Ritz32Smem sm;
-  const int blk = blockIdx.x;
-  if (blk == 0) {
-    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
-    if (strips) {  // (this kernel is launched with a staging tile > kPrepLds >= kStripScratch)
-      __syncthreads();
-      plan_strips_body(mask, B, N, n_cu, strips, n_strips, reinterpret_cast<unsigned char*>(tile));
-    }
-  } else if (blk <= B) {
-    if (threadIdx.x >= 64) return;
-    // channel 0 of L is the simple-graph Laplacian the Ritz pairs belong to (dataset/qm8.py:262)
-    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x, sm);
-  } else {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blk - 1 - B, ident);
-  }
-}
-
-constexpr int kPrepLds = 20480;  // static LDS of the fused preparation launch (>= sizeof(Ritz32Smem))
-static_assert(sizeof(Ritz32Smem) <= kPrepLds, "Ritz scratch must fit the shared block");
-static_assert(kStripScratch <= kPrepLds, "the strip planner works in the same block");
-
-// The same launch with ONE static LDS block per workgroup, used according to its role (Ritz
-// scratch or pack staging tile), for staging tiles up to kPrepLds (QM8: 26 x 26 x 7 floats =
-// 18.9 KB).  With the separate dynamic tile above every workgroup carries ~29 KB: the four
-// resident Ritz workgroups of a CU (one per SIMD, the long pole) leave room for ONE more, and the
-// B pack workgroups trickle through behind them instead of running in their shadow.
-__global__ __launch_bounds__(256) void prepare_batch_union_kernel(
-    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
-    float4* __restrict__ Lp, const uint8_t* __restrict__ mask, int B, int n_cu, int allow_pairs,
-    int wg_cap, int32_t* __restrict__ plan, int32_t* __restrict__ n_wg, int K,
-    int32_t* __restrict__ gain_rows, int32_t* __restrict__ n_gain_rows,
-    const int32_t* __restrict__ n_nodes, float* __restrict__ D, float* __restrict__ V,
-    int32_t* __restrict__ info, uint32_t* __restrict__ ident, int32_t* __restrict__ strips,
-    int32_t* __restrict__ n_strips) {
-  __shared__ __attribute__((aligned(16))) unsigned char ubuf[kPrepLds];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ubuf[];
   const int blk = blockIdx.x;
   if (blk == 0) {
     plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
@@ -773,12 +940,23 @@ __global__ __launch_bounds__(256) void prepare_batch_union_kernel(
     }
   } else if (blk <= B) {
     if (threadIdx.x >= 64) return;
+    // channel 0 of L is the simple-graph Laplacian the Ritz pairs belong to (dataset/qm8.py:262)
+#ifdef LNZ_PREP_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x,
-                        *reinterpret_cast<Ritz32Smem*>(ubuf));
+                        ritz32_view(ubuf, N));
   } else {
     pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, reinterpret_cast<float*>(ubuf), blk - 1 - B,
                         ident);
   }
+}
+
+// dynamic LDS of the preparation launches: the largest of the three roles' blocks
+static size_t prep_lds_bytes(int N, int C) {
+  size_t lds = (size_t)N * N * C * sizeof(float);
+  lds = lds > ritz32_lds_bytes(N) ? lds : ritz32_lds_bytes(N);
+  return lds > (size_t)kStripScratch ? lds : (size_t)kStripScratch;
 }
 
 // Software pipeline over a stream of batches, ONE launch of 256-thread workgroups: workgroup 0
@@ -802,12 +980,12 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
     int n_cons, const float* __restrict__ Dg, const int32_t* __restrict__ rows_g,
     const int32_t* __restrict__ n_rows_g, int Bg, int32_t* __restrict__ strips,
     int32_t* __restrict__ n_strips) {
-  // One static LDS block per workgroup, used according to its role (Ritz scratch, pack staging
-  // tile): with a separate dynamic tile every workgroup carried 32 KB and the four resident Ritz
-  // workgroups of a CU left room for ONE more — the pack workgroups trickled through and the
-  // consumers started 50 us late.
-  __shared__ __attribute__((aligned(16))) unsigned char ubuf[kPrepLds];
-  Ritz32Smem& sm = *reinterpret_cast<Ritz32Smem*>(ubuf);
+  // One dynamic LDS block per workgroup, used according to its role (Ritz scratch, pack staging
+  // tile, planner scratch): with a separate tile every workgroup carried 32 KB and the four
+  // resident Ritz workgroups of a CU left room for ONE more — the pack workgroups trickled
+  // through and the consumers started 50 us late.
+  extern __shared__ __attribute__((aligned(16))) unsigned char ubuf[];
+  const Ritz32Smem sm = ritz32_view(ubuf, N);
   float* tile = reinterpret_cast<float*>(ubuf);
   const int blk = blockIdx.x;
   if (blk == 0) {
@@ -856,20 +1034,14 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
               LNZ_EINVAL, "lnz_prepare_batch: bad arguments (B=%d C=%d K=%d)", B, C, K);
   LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch: N=%d > %d", N, LNZ_TILE);
   LNZ_REQUIRE(!gain_rows || n_gain_rows, LNZ_EINVAL, "lnz_prepare_batch: gain_rows needs n_gain_rows");
-  size_t lds = (size_t)N * N * C * sizeof(float);
-  LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
-              "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
+  const size_t tile = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(tile <= 40 * 1024, LNZ_ENOTSUP,
+              "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", tile);
   LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_prepare_batch: strips need n_strips");
-  if (lds <= (size_t)kPrepLds)
-    hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(2 * B + 1), dim3(256), 0,
-                       (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
-                       (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
-                       K, gain_rows, n_gain_rows, n_nodes, D, V, info, ident, strips, n_strips);
-  else
-    hipLaunchKernelGGL(prepare_batch_kernel, dim3(2 * B + 1), dim3(256), lds, (hipStream_t)stream,
-                       L, stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
-                       allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
-                       n_nodes, D, V, info, ident, strips, n_strips);
+  hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(2 * B + 1), dim3(256), prep_lds_bytes(N, C),
+                     (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
+                     (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
+                     K, gain_rows, n_gain_rows, n_nodes, D, V, info, ident, strips, n_strips);
   return lnz::check_launch("lnz_prepare_batch");
 }
 
@@ -888,18 +1060,17 @@ extern "C" int lnz_prepare_batch_prev_gains(
   LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: N=%d > %d", N,
               LNZ_TILE);
   LNZ_REQUIRE(S >= 1 && S <= lnz_gains::SMAX, LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: S=%d", S);
-  size_t lds = (size_t)N * N * C * sizeof(float);
-  LNZ_REQUIRE(lds <= (size_t)kPrepLds, LNZ_ENOTSUP,
-              "lnz_prepare_batch_prev_gains: N*N*C*4 = %zu B exceeds the %d B staging tile", lds,
-              kPrepLds);
+  const size_t tile = (size_t)N * N * C * sizeof(float);
+  LNZ_REQUIRE(tile <= 40 * 1024, LNZ_ENOTSUP,
+              "lnz_prepare_batch_prev_gains: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", tile);
   lnz_gains::DistArr dist;
   for (int i = 0; i < lnz_gains::SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
   const int64_t tiles = ((int64_t)B_prev * K + 31) / 32;
   const int64_t n_cons = (tiles * num_layer + 3) / 4;
   const int64_t grid = 2 * (int64_t)B + 1 + n_cons;
   LNZ_REQUIRE(grid < (1ll << 31), LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: batch too large");
-  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256), 0,
-                     (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
+  hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256),
+                     prep_lds_bytes(N, C), (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, dist, S, num_layer, mlp_pack, G_prev,
                      ident, (int)n_cons, D_prev, rows_prev, n_rows_prev, B_prev,
@@ -924,8 +1095,8 @@ extern "C" int lnz_lanczos_ritz(const float* A, int64_t stride_b, int64_t stride
   if (N > 32)
     return lnz_launch_ritz_wg(A, stride_b, stride_r, stride_c, n_nodes, B, N, K, D, V, info, nullptr,
                               0, 0, s);
-  hipLaunchKernelGGL(lanczos_ritz32_kernel, dim3(B), dim3(64), 0, s, A, stride_b, stride_r,
-                     stride_c, n_nodes, N, K, D, V, info);
+  hipLaunchKernelGGL(lanczos_ritz32_kernel, dim3(B), dim3(64), ritz32_lds_bytes(N), s, A, stride_b,
+                     stride_r, stride_c, n_nodes, N, K, D, V, info);
   return lnz::check_launch("lnz_lanczos_ritz");
 }
 

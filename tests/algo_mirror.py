@@ -84,42 +84,88 @@ def _tql2(dd, ee, Qt, n):
 def _sturm_below(d, e2, a, b, x):
   """Eigenvalues of rows a..b (no outside coupling) below x — the product-form count of the kernel:
   sign changes of p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}."""
-  p1, p2, c = 1.0, 0.0, 0
+  return _sturm_poly(d, e2, a, b, x)[0]
+
+
+def _sturm_poly(d, e2, a, b, x):
+  """-> (count, mantissa, exponent): the count above and the value p_len(x) of the block's
+  characteristic polynomial from the same recurrence, renormalised every eight rows with the
+  binary exponent tracked (csrc/lanczos_ritz.hip sturm_rows)."""
+  import math
+  p1, p2, c, ex = 1.0, 0.0, 0, 0
   for i in range(a, b + 1):
     ep = e2[i - 1] if i > a else 0.0
     p = (d[i] - x) * p1 - ep * p2
-    if (p < 0) != (p1 < 0):
+    if (math.copysign(1.0, p) < 0) != (math.copysign(1.0, p1) < 0):
       c += 1
     p2, p1 = p1, p
-    if abs(p1) < 1e-100:
-      p1 *= 1e100
-      p2 *= 1e100
-  return c
+    if ((i - a) & 7) == 7 or i == b:
+      if p1 != 0.0:
+        m, k = math.frexp(p1)
+        p1, p2, ex = m, math.ldexp(p2, -k), ex + k
+  return c, p1, ex
 
 
-def _section_search(d, e2, s, t, j, gsc, may_bail):
-  """The (j)-th eigenvalue of block [s, t]: 5-section on Sturm counts.  Returns (lam, lo, hi) — or
-  (None, lo, hi) at pass 12 when may_bail (the caller then compares brackets for the cluster test)."""
-  lo, hi = -gsc, gsc
-  for it in range(30):
-    w = (hi - lo) * 0.2
-    xs = [lo + w * k for k in (1, 2, 3, 4)]
-    cs = [_sturm_below(d, e2, s, t, x) for x in xs]
-    if cs[0] > j:
-      hi = xs[0]
-    elif cs[1] > j:
-      lo, hi = xs[0], xs[1]
-    elif cs[2] > j:
-      lo, hi = xs[1], xs[2]
-    elif cs[3] > j:
-      lo, hi = xs[2], xs[3]
-    else:
-      lo = xs[3]
-    if may_bail and it == 12:
-      return None, lo, hi
-    if hi - lo <= 4.0 * EPS * max(abs(lo), abs(hi)) + 1e-300:
+def _search_block(d, e2, s, t, gsc, state=None):
+  """All eigenvalues of block [s, t], the lanes in lock step (eigenvalue_search of the kernel):
+  pass 0 probes the bracket's ends and thirds, a section pass lo + k w / 5, and once exactly one
+  eigenvalue is inside (p changes sign) the secant point x* of the end values with probes at
+  x* -+ d1, x* -+ 16 d1, d1 ~ w^2 / (2 gap to the neighbouring lanes' brackets); brackets are
+  updated from the COUNTS only.  state=None: passes 0..12, returning (None, state, bail flags)
+  when two lanes still share a bracket after pass 12 (a cluster); otherwise passes 13.. ."""
+  import math
+  L = t - s + 1
+  if state is None:
+    state = [dict(lo=-gsc, hi=gsc, clo=0, chi=L, flo=None, fhi=None, done=False, sect=True)
+             for _ in range(L)]
+    if L == 1:
+      state[0].update(lo=d[s], hi=d[s], done=True)
+    it0, may_bail = 0, True
+  else:
+    it0, may_bail = 13, False
+  tol_of = lambda lo, hi: 4.0 * EPS * max(abs(lo), abs(hi), 0.125 * gsc)  # noqa: E731
+  for it in range(it0, 30):
+    if all(st['done'] for st in state):
       break
-  return 0.5 * (lo + hi), lo, hi
+    mids = [0.5 * (st['lo'] + st['hi']) for st in state]
+    for j, st in enumerate(state):
+      if st['done']:
+        continue
+      lo, hi = st['lo'], st['hi']
+      w = hi - lo
+      iso = (it > 0 and not st['sect'] and st['chi'] - st['clo'] == 1 and st['flo'][0] != 0.0
+             and (math.copysign(1.0, st['flo'][0]) < 0) != (math.copysign(1.0, st['fhi'][0]) < 0))
+      if it == 0:
+        xs = [lo, lo + w * (1.0 / 3.0), lo + 2.0 * (w * (1.0 / 3.0)), hi]
+      elif iso:
+        (ml, el), (mh, eh) = st['flo'], st['fhi']
+        fh = math.ldexp(mh, max(-1000, min(1000, eh - el)))
+        xstar = lo + w * (ml / (ml - fh))
+        g = gsc
+        if j > 0:
+          g = min(g, abs(xstar - mids[j - 1]))
+        if j < L - 1:
+          g = min(g, abs(mids[j + 1] - xstar))
+        d1 = 0.5 * w * w / max(g, 1e-300)
+        d1 = max(min(d1, 0.125 * w), 0.45 * tol_of(lo, hi))
+        d2 = min(0.25 * w, 16.0 * d1)
+        xs = [min(max(x, lo), hi) for x in (xstar - d2, xstar - d1, xstar + d1, xstar + d2)]
+      else:
+        xs = [lo + w * 0.2 * k for k in (1, 2, 3, 4)]
+      ev = [_sturm_poly(d, e2, s, t, x) for x in xs]
+      idx = next((k for k in range(4) if ev[k][0] > j), 4)
+      if idx > 0:
+        st['lo'], st['clo'], st['flo'] = xs[idx - 1], ev[idx - 1][0], ev[idx - 1][1:]
+      if idx < 4:
+        st['hi'], st['chi'], st['fhi'] = xs[idx], ev[idx][0], ev[idx][1:]
+      nw = st['hi'] - st['lo']
+      st['sect'] = nw > 0.25 * w
+      st['done'] = nw <= tol_of(st['lo'], st['hi'])
+    if may_bail and it == 12:
+      bail = [j > 0 and not state[j]['done'] and state[j]['lo'] == state[j - 1]['lo'] for j in range(L)]
+      if any(bail):
+        return None, state, bail
+  return [0.5 * (st['lo'] + st['hi']) for st in state], state, [False] * L
 
 
 def _twisted_vector(d, e, e2, s, t, lam, ws, wt, tiny):
@@ -171,8 +217,15 @@ def _tridiag_eig_parallel(dd, ee, Qt, n):
     while t < n - 1 and e[t] != 0.0:
       t += 1
     blk.append((s, t))
-  first = [_section_search(d, e2, blk[k][0], blk[k][1], k - blk[k][0], gsc, True) for k in range(n)]
-  bail = [k > 0 and blk[k] == blk[k - 1] and first[k][1] == first[k - 1][1] for k in range(n)]
+  lam = [0.0] * n
+  states, bail = {}, [False] * n
+  for (s, t) in sorted(set(blk)):
+    res, st, bl = _search_block(d, e2, s, t, gsc)
+    states[(s, t)] = (res, st)
+    for k in range(s, t + 1):
+      bail[k] = bool(bl[k - s])
+      if res is not None:
+        lam[k] = res[k - s]
   win = list(blk)
   member = [False] * n
   if any(bail):
@@ -182,7 +235,8 @@ def _tridiag_eig_parallel(dd, ee, Qt, n):
       if not member[k]:
         continue
       s, t = blk[k]
-      xl, xh = first[k][1] - wd, first[k][2] + wd
+      stk = states[(s, t)][1][k - s]
+      xl, xh = stk['lo'] - wd, stk['hi'] + wd
       g = (k - s) - _sturm_below(d, e2, s, t, xl)
       a, found = s, False
       for i in range(s, t + 1):
@@ -198,7 +252,11 @@ def _tridiag_eig_parallel(dd, ee, Qt, n):
           a = i + 1
       if not found:
         return False
-  lam = [_section_search(d, e2, blk[k][0], blk[k][1], k - blk[k][0], gsc, False)[0] for k in range(n)]
+    for (s, t), (res, st) in states.items():
+      if res is None:
+        res, _, _ = _search_block(d, e2, s, t, gsc, state=st)
+        for k in range(s, t + 1):
+          lam[k] = res[k - s]
   tiny = EPS * gsc
   S = np.zeros((n, n))
   for k in range(n):

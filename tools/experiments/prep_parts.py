@@ -26,3 +26,14 @@ print(json.dumps({'prepare_batch': timed(lambda: ops.prepare_batch(plan, L, mk, 
                   'pack_and_plan': timed(lambda: ops.pack_and_plan(plan, L, mk, 20)),
                   'plan_strips': timed(lambda: ops.plan_strips(mk)),
                   'plan_batch': timed(lambda: ops.plan_batch(mk, True, 20))}))
+
+# the Ritz kernel and pack + plan as two launches on two streams (fork / join by events)
+s2 = torch.cuda.Stream()
+def two_streams():
+  cur = torch.cuda.current_stream()
+  s2.wait_stream(cur)
+  with torch.cuda.stream(s2):
+    ops.pack_and_plan(plan, L, mk, 20)
+  ops.lanczos_ritz(A, n, 20)
+  cur.wait_stream(s2)
+print(json.dumps({'two_streams': timed(two_streams)}))
