@@ -691,13 +691,18 @@ def main():
   ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(6)] for k in range(args.steps)}
   mask_u8 = mask.to(torch.uint8).contiguous()
 
+  # LNZ_BENCH_SPLIT_PACK=1: the Laplacian pack of a step on a second stream under its
+  # spectral-gains launch instead of inside the preparation launch (measured in r05: 0.802 against
+  # 0.787 ms per step — the gains launch slows down by what the preparation saves)
+  pack_stream = torch.cuda.Stream(device=dev) if os.environ.get('LNZ_BENCH_SPLIT_PACK', '0') == '1' else None
+
   def step(events=None, all_stages=False):
     # the timed loop brackets only the dominant kernel with HIP events (the roofline's live launch
     # duration); the per-stage breakdown comes from a separate, untimed pass (all_stages) so that
     # the event markers between the short launches do not sit in the measured region
     if events and all_stages:
       events[0].record()
-    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K)
+    Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mask_u8, n_nodes, K, pack_stream=pack_stream)
     if events and all_stages:
       events[1].record()
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],

@@ -436,7 +436,10 @@ int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips
  * channel 0 of L (workgroups 1..B, dispatched first: they are the long, latency-bound pole) and
  * lnz_pack_laplacian (workgroups B+1..2B) — the two byte movers run in the shadow of the Lanczos
  * wavefronts instead of in front of them.  L [B,N,N,C] with strides (elements); n_nodes [B] as
- * for lnz_lanczos_ritz; outputs as in the three functions.  N <= 32. */
+ * for lnz_lanczos_ritz; outputs as in the three functions.  N <= 32.
+ * Lp == NULL (then ident must be NULL too): plan + Ritz pairs only, B + 1 workgroups — the pack is
+ * then the caller's lnz_pack_laplacian_ident on a second stream, under the spectral-gains launch
+ * (matrix-pipe work that leaves the memory path idle) instead of next to the Lanczos wavefronts. */
 int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                       int64_t stride_ch, int B, int N, int C, float* Lp, const uint8_t* mask,
                       const int32_t* n_nodes, int n_cu, int allow_pairs, int32_t* plan,

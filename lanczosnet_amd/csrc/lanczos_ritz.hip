@@ -1029,16 +1029,19 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
                                  int32_t* gain_rows, int32_t* n_gain_rows, float* D, float* V,
                                  int32_t* info, uint32_t* ident, int32_t* strips,
                                  int32_t* n_strips, lnz_stream_t stream) {
-  LNZ_REQUIRE(L && Lp && mask && n_nodes && plan && n_wg && D && V && B > 0 && C > 0 &&
+  LNZ_REQUIRE(L && mask && n_nodes && plan && n_wg && D && V && B > 0 && C > 0 &&
                   C <= LNZ_MAX_CHANNELS && n_cu > 0 && K > 0,
               LNZ_EINVAL, "lnz_prepare_batch: bad arguments (B=%d C=%d K=%d)", B, C, K);
+  LNZ_REQUIRE(Lp || !ident, LNZ_EINVAL, "lnz_prepare_batch: ident needs Lp (the pack writes both)");
   LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_prepare_batch: N=%d > %d", N, LNZ_TILE);
   LNZ_REQUIRE(!gain_rows || n_gain_rows, LNZ_EINVAL, "lnz_prepare_batch: gain_rows needs n_gain_rows");
   const size_t tile = (size_t)N * N * C * sizeof(float);
   LNZ_REQUIRE(tile <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", tile);
   LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_prepare_batch: strips need n_strips");
-  hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(2 * B + 1), dim3(256), prep_lds_bytes(N, C),
+  // without Lp: plan + Ritz pairs only (no pack workgroups in the grid)
+  hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(Lp ? 2 * B + 1 : B + 1), dim3(256),
+                     Lp ? prep_lds_bytes(N, C) : prep_lds_bytes(N, 0),
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
                      K, gain_rows, n_gain_rows, n_nodes, D, V, info, ident, strips, n_strips);

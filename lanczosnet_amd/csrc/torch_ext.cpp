@@ -241,6 +241,35 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> prepare_batch(const Tensor& L
   return {Lp, ident, plan, D, V};
 }
 
+// plan + Ritz pairs without the pack (lnz_prepare_batch with Lp = NULL): the caller packs on a
+// second stream, under the spectral-gains launch
+std::tuple<Tensor, Tensor, Tensor> plan_ritz(const Tensor& L, const Tensor& mask, const Tensor& n_nodes,
+                                             int64_t K, int64_t n_cu, bool allow_pairs) {
+  need(L, at::kFloat, "L", /*contiguous=*/false);
+  need(mask, at::kByte, "mask");
+  need(n_nodes, at::kInt, "n_nodes");
+  TORCH_CHECK(L.dim() == 4 && L.size(1) == L.size(2) && mask.size(0) == L.size(0) &&
+              mask.size(1) == L.size(1));
+  const c10::DeviceGuard guard(L.device());
+  const int B = L.size(0), N = L.size(1), C = L.size(3);
+  const int cap = lnz_plan_wg_cap(B, (int)n_cu);
+  auto iopt = n_nodes.options();
+  const int scap = lnz_strip_cap(B);
+  const int64_t soff = 12 * (int64_t)cap + 2 + (int64_t)B * K;
+  Tensor plan = at::empty({soff + (scap ? (int64_t)scap * LNZ_STRIP_INTS + 1 : 0)}, iopt);
+  Tensor D = at::empty({B, K}, L.options());
+  Tensor V = at::empty({B, N, K}, L.options());
+  int32_t* pb = plan.data_ptr<int32_t>();
+  check(lnz_prepare_batch(L.data_ptr<float>(), L.stride(0), L.stride(1), L.stride(2), L.stride(3), B,
+                          N, C, nullptr, mask.data_ptr<uint8_t>(), n_nodes.data_ptr<int32_t>(),
+                          (int)n_cu, allow_pairs ? 1 : 0, pb, pb + 12 * cap, (int)K, pb + 12 * cap + 2,
+                          pb + 12 * cap + 1, D.data_ptr<float>(), V.data_ptr<float>(), nullptr, nullptr,
+                          scap ? pb + soff : nullptr,
+                          scap ? pb + soff + (int64_t)scap * LNZ_STRIP_INTS : nullptr, cur_stream()),
+        "plan_ritz");
+  return {plan, D, V};
+}
+
 // ---- R7a: spectral gains ---------------------------------------------------------------------
 Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
                       const c10::optional<Tensor>& mlp_pack, const c10::optional<Tensor>& rows,
@@ -390,6 +419,8 @@ TORCH_LIBRARY(lanczosnet, m) {
   m.def("lanczos_ritz(Tensor A, Tensor n_nodes, int K) -> (Tensor, Tensor, Tensor)");
   m.def("prepare_batch(Tensor L, Tensor mask, Tensor n_nodes, int K, int n_cu, bool allow_pairs) -> "
         "(Tensor, Tensor, Tensor, Tensor, Tensor)");
+  m.def("plan_ritz(Tensor L, Tensor mask, Tensor n_nodes, int K, int n_cu, bool allow_pairs) -> "
+        "(Tensor, Tensor, Tensor)");
   m.def("spectral_gains(Tensor D, int[] dist, int num_layer, Tensor? mlp_pack, Tensor? rows, "
         "Tensor? n_rows, bool zero_fill) -> Tensor");
   m.def("forward(Tensor node_feat, Tensor? embedding, Tensor Lp, Tensor? ident, Tensor V, Tensor? G, "
@@ -408,6 +439,7 @@ TORCH_LIBRARY_IMPL(lanczosnet, CUDA, m) {  // the CUDA dispatch key is HIP on a 
   m.impl("laplacian_l4", laplacian_l4);
   m.impl("lanczos_ritz", lanczos_ritz);
   m.impl("prepare_batch", prepare_batch);
+  m.impl("plan_ritz", plan_ritz);
   m.impl("spectral_gains", spectral_gains);
   m.impl("forward", forward);
   m.impl("unsorted_segment_sum_forward", segment_sum_forward);

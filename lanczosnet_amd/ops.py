@@ -437,9 +437,14 @@ def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
   return Lp, (buf, cap), (rows, n_rows)
 
 
-def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
+def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, pack_stream=None):
   """lnz_prepare_batch: Laplacian pack, batch plan and the Ritz pairs of L[..., 0] in one launch
-  (exact-fp32 plans, N <= 32).  Returns (Lp, tiles, rows, D, V)."""
+  (exact-fp32 plans, N <= 32).  Returns (Lp, tiles, rows, D, V).
+  pack_stream: a second stream.  The launch then carries the plan and the Ritz pairs only, and the
+  pack is enqueued on `pack_stream` BEHIND it — it runs under whatever the caller launches next
+  on the current stream (the spectral gains: matrix-pipe work, the memory path is idle) instead of
+  next to the latency-bound Lanczos wavefronts.  `Lp.ready` is the event the pack's consumer has
+  to wait for; lanczosnet_forward does (on its own stream)."""
   Lf = L if L.dtype == torch.float32 else L.float()
   B, N, _, Cn = Lf.shape
   # The single launch pays when the Ritz wavefronts are latency bound (about one per SIMD); with
@@ -455,9 +460,24 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None):
   n_cu = n_cu or _n_cu(Lf.device)
   nn = n_nodes if n_nodes.dtype == torch.int32 and n_nodes.is_contiguous() else \
       n_nodes.to(torch.int32).contiguous()
-  Lp, ident, buf, D, V = _ext().prepare_batch(Lf, mask_u8, nn, K, n_cu,
-                                              bool(pairing_supported(plan)))
-  Lp.ident = ident
+  if pack_stream is not None and not torch.cuda.is_current_stream_capturing():
+    buf, D, V = _ext().plan_ritz(Lf, mask_u8, nn, K, n_cu, bool(pairing_supported(plan)))
+    # the pack's buffers come from the CURRENT stream's pool (ordered behind the last launch that
+    # read their previous contents); the side stream starts behind the launch above
+    Lp = torch.empty((B, Cn, 4, 64, 4), dtype=torch.float32, device=Lf.device)
+    Lp.ident = torch.empty((B,), dtype=torch.int32, device=Lf.device)
+    pack_stream.wait_stream(torch.cuda.current_stream(Lf.device))
+    sb, sr, sc, sch = Lf.stride()
+    with torch.cuda.stream(pack_stream):
+      _abi().pack_laplacian_ident(Lf, sb, sr, sc, sch, B, N, Cn, Lp, Lp.ident)
+      Lp.ready = torch.cuda.Event()
+      Lp.ready.record(pack_stream)
+    for t_ in (Lp, Lp.ident, Lf):
+      t_.record_stream(pack_stream)
+  else:
+    Lp, ident, buf, D, V = _ext().prepare_batch(Lf, mask_u8, nn, K, n_cu,
+                                                bool(pairing_supported(plan)))
+    Lp.ident = ident
   cap = _abi().plan_wg_cap(B, n_cu)
   soff = 12 * cap + 2 + B * K
   if buf.numel() > soff:  # the strip plan rides behind the live-slot list
@@ -647,6 +667,9 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   channel goes through its Laplacian fragments)."""
   _need_cuda(node_feat, Lp, V, G, mask)
   B, N, K = V.shape
+  ready = getattr(Lp, 'ready', None)   # a pack on a second stream (prepare_batch(pack_stream=...))
+  if ready is not None:
+    torch.cuda.current_stream(Lp.device).wait_event(ready)
   if Lp.dtype == torch.float32 and plan.get('Wp16') is None and act_out is None and not return_state:
     return _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident)
   ops_, dims = _fused_operands(plan, V)

@@ -882,6 +882,21 @@ def test_prepare_batch_is_the_three_launches_in_one(B):
   nr = int(rows1[1].item())
   assert int(rows2[1].item()) == nr
   assert sorted(rows1[0][:nr].tolist()) == sorted(rows2[0][:nr].tolist())
+  # [r05] the pack on a second stream (plan + Ritz pairs in the launch, lnz_prepare_batch with
+  # Lp = NULL): the same bits, and the forward waits for the pack's event by itself
+  side = torch.cuda.Stream()
+  Lp3, tiles3, rows3, D3, V3 = ops.prepare_batch(plan, L, mask, n, 20, pack_stream=side)
+  assert Lp3.ready is not None
+  G = ops.spectral_gains(D3, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'], rows=rows3,
+                         zero_fill=not ops.pairing_supported(plan))
+  s3 = ops.lanczosnet_forward(plan, _t(batch['node_feat']), Lp3, V3, G, mask, tiling=tiles3)
+  G2 = ops.spectral_gains(D2, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'], rows=rows2,
+                          zero_fill=not ops.pairing_supported(plan))
+  s2 = ops.lanczosnet_forward(plan, _t(batch['node_feat']), Lp2, V2, G2, mask, tiling=tiles2)
+  torch.cuda.synchronize()
+  assert torch.equal(Lp3, Lp2) and torch.equal(Lp3.ident, Lp2.ident)
+  assert torch.equal(D3, D2) and torch.equal(V3, V2) and torch.equal(s3, s2)
+  assert torch.equal(tiles3[0][:12 * cap + 1], tiles2[0][:12 * cap + 1])
 
 
 @pytest.mark.gpu
