@@ -305,7 +305,8 @@ __device__ __forceinline__ void eigenvalue_search(const Ritz32Smem& sm, EigState
                                                   const int r, const int h, const int s, const int t,
                                                   const unsigned a_base, const unsigned a_pad,
                                                   const int maxlen, const double gsc, const int it0,
-                                                  const bool may_bail, bool& bail) {
+                                                  const bool may_bail, bool& bail,
+                                                  const bool loose = false) {
   const bool act = r < n;
   const int jloc = r - s;
   const bool has_dn = act && r > s, has_up = act && r < t;
@@ -367,8 +368,12 @@ __device__ __forceinline__ void eigenvalue_search(const Ritz32Smem& sm, EigState
     st.chi = nh ? (nkhi & 255) : st.chi, st.ehi = nh ? (nkhi >> 8) : st.ehi;
     const double nw = st.hi - st.lo;
     st.sect = nw > 0.25 * w;
-    // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|
-    st.done = st.done || nw <= 4.0 * kEps * fmax(fmax(fabs(st.lo), fabs(st.hi)), 0.125 * gsc);
+    // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|.  loose: a
+    // lane of a cluster (see the caller) — its bracket holds the eigenvalue's copies and cannot
+    // collapse below their distance; 1e-12 |T| is what its vector needs (the component along any
+    // OTHER eigenvector is |lambda - copy| / gap to that eigenvalue)
+    st.done = st.done || nw <= fmax(4.0 * kEps * fmax(fmax(fabs(st.lo), fabs(st.hi)), 0.125 * gsc),
+                                    loose ? 1e-12 * gsc : 0.0);
     if (may_bail && it == 12) {
       // Two eigenvalues of ONE block still sharing a bracket: a degenerate eigenvalue whose
       // second copy crept into the Krylov space through round-off instead of a clean breakdown
@@ -462,27 +467,35 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
     // copies, the caller runs the QL sweep.
     const int upper = __shfl_down(bail ? 1 : 0, 1, 64);  // all lanes take part in the shuffle
     member = bail || (upper != 0 && (r & 31) < 31);
-    auto count = [&](double x, int a, int b) {  // eigenvalues of rows a..b (no outside coupling) below x
-      int c = 0;
-      double q = 1.0;
+    // eigenvalues of rows a..b (no outside coupling) below xa / below xb: the two recurrences
+    // side by side (each is one chain of reciprocals: latency bound)
+    auto count2 = [&](double xa, double xb, int a, int b, int& na, int& nb) {
+      na = nb = 0;
+      double qa = 1.0, qb = 1.0;
       for (int i = a; i <= b; ++i) {
-        const double e2p = i > a ? sm.ca[i - 1] : 0.0;
-        q = (sm.za[i] - x) - e2p / q;
-        q = fabs(q) < 1e-290 ? -1e-290 : q;
-        c += q < 0.0 ? 1 : 0;
+        const double e2p = i > a ? sm.ca[i - 1] : 0.0, di = sm.za[i];
+        qa = fma(-e2p, rcp_nr(qa), di - xa);
+        qb = fma(-e2p, rcp_nr(qb), di - xb);
+        qa = fabs(qa) < 1e-290 ? -1e-290 : qa;
+        qb = fabs(qb) < 1e-290 ? -1e-290 : qb;
+        na += qa < 0.0 ? 1 : 0;
+        nb += qb < 0.0 ? 1 : 0;
       }
-      return c;
     };
     bool ok = true;
     if (member && act) {
       const double cutoff = 1e-3 * gsc, wd = 1e-5 * gsc;
       const double xl = st.lo - wd, xh = st.hi + wd;
-      int g = (r - s) - count(xl, s, t);  // rank inside the widened bracket
+      int below_l, below_h;
+      count2(xl, xh, s, t, below_l, below_h);
+      int g = (r - s) - below_l;  // rank inside the widened bracket
       int a = s;
       bool found = false;
       for (int i = s; i <= t && !found; ++i) {
         if (i == t || fabs(sm.zb[i]) <= cutoff) {
-          const int inside = count(xh, a, i) - count(xl, a, i);
+          int cl, ch;
+          count2(xl, xh, a, i, cl, ch);
+          const int inside = ch - cl;
           if (g < inside) {
             ws = a, wt = i;
             found = true;
@@ -497,7 +510,7 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
     }
     if (__any(!ok)) return false;
     bool bail2 = false;
-    eigenvalue_search(sm, st, n, r, h, s, t, a_base, a_pad, maxlen, gsc, 13, false, bail2);
+    eigenvalue_search(sm, st, n, r, h, s, t, a_base, a_pad, maxlen, gsc, 13, false, bail2, member);
   }
   const double lam = 0.5 * (st.lo + st.hi);
   if (ts) ts[1] = clock64();
@@ -691,7 +704,7 @@ __device__ __forceinline__ void lanczos_ritz32_body(
     }
     bool fresh = true;  // w is a start/restart vector: its norm is not a coupling beta
     for (int j = 0; j < n; ++j) {
-      double beta, u;
+      double beta, u, binv;
       for (;;) {
         // ---- one broadcast of w: beta = |w| and u = A w
         sm.za[r] = w;
@@ -700,7 +713,19 @@ __device__ __forceinline__ void lanczos_ritz32_body(
         load16(sm.za + 16 * h, v);
         double nn = xhalf_sum(dot16(v, v));
         u = xhalf_sum(dot16(arow, v));
-        beta = sqrt(nn);
+        {
+          // 1 / sqrt(nn) by the hardware seed + two Newton steps, beta = nn / sqrt(nn): one chain
+          // of 9 instructions instead of a square root and a division (about 25)
+          double y = __builtin_amdgcn_rsq(nn);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const double hy = 0.5 * y;
+            const double er = fma(-(nn * y), hy, 0.5);
+            y = fma(y, er, y);
+          }
+          binv = y;
+          beta = nn > 0.0 ? nn * y : 0.0;
+        }
         __syncthreads();
         if (fresh || beta > kBreakdownTol) break;
         // breakdown: span(q_0..q_{j-1}) is A-invariant -> restart from the unit vector with the
@@ -727,7 +752,6 @@ __device__ __forceinline__ void lanczos_ritz32_body(
       }
       if (!fresh && r == j - 1) ereg = beta;
       fresh = false;
-      const double binv = 1.0 / beta;
       const double q = w * binv;
       double x = u * binv;  // A q
       if (h == 0) sm.Qt[j * LD + r] = q;
@@ -851,25 +875,46 @@ __device__ __forceinline__ void lanczos_ritz32_body(
       if (lane < n) sm.perm[rank] = lane;
     }
     __syncthreads();
-    if (lane < kk) {
-      const double* v = &sm.Qt[sm.perm[lane] * LD];
+    {
+      // sign convention: the entry of largest magnitude is positive (the first one on ties).  Lane
+      // (k, h) scans nodes 16h .. 16h+15 of Ritz vector k from registers; the halves combine.
+      const bool on = r < kk;
+      double v[16];
+      load16(&sm.Qt[(on ? sm.perm[r] : 0) * LD + 16 * h], v);
       double best = 0.0;
       float sg = 1.0f;
-      for (int x = 0; x < n; ++x) {
-        double av = fabs(v[x]);
-        if (av > best) {
-          best = av;
-          sg = v[x] < 0 ? -1.0f : 1.0f;
-        }
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const double av = fabs(v[x]);
+        const bool take = av > best;
+        sg = take ? (v[x] < 0 ? -1.0f : 1.0f) : sg;
+        best = take ? av : best;
       }
-      sm.sgn[lane] = sg;
+      double best_up;
+      const double best_lo = both_halves(best, best_up);
+      int sg_up;
+      const int sg_lo = both_halves(__float_as_int(sg), sg_up);
+      if (on && h == 0) sm.sgn[r] = __int_as_float(best_up > best_lo ? sg_up : sg_lo);
     }
     __syncthreads();
   }
 
   for (int k = lane; k < K; k += 64) D[(int64_t)b * K + k] = k < kk ? (float)sm.dd[sm.perm[k]] : 0.0f;
   float* Vb = V + (int64_t)b * N * K;
-  {
+  if (K <= 64) {
+    // lane -> (node row of the pass, slot): the slot is fixed per lane, 64 / K node rows per pass
+    // (K = 20: three rows = 240 contiguous bytes per store)
+    const int rpp = 64 / K;
+    const int rr0 = lane / K, k = lane - rr0 * K;
+    const bool lane_on = rr0 < rpp, col_on = lane_on && k < kk;
+    const double* col = &sm.Qt[(col_on ? sm.perm[k] : 0) * LD];
+    const float sg = col_on ? sm.sgn[k] : 0.0f;
+#pragma unroll 4
+    for (int r0 = 0; r0 < N; r0 += rpp) {
+      const int rr = r0 + rr0;
+      if (lane_on && rr < N) Vb[rr * K + k] = (col_on && rr < n) ? sg * (float)col[rr] : 0.0f;
+    }
+  } else {
     // idx = rr * K + k walks by 64 per pass: one division up front, then carries
     const int dq = 64 / K, dr = 64 - dq * K;
     int rr = lane / K, k = lane - rr * K;
