@@ -1266,17 +1266,6 @@ int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s);
 
 extern "C" int64_t lnz_forward_args_size(void) { return (int64_t)sizeof(lnz_forward_args); }
 
-// LNZ_DENSE_FILTER_NODE_SPACE=1: the r02 dense-filter kernel (L_s = Q DD_s Q^T built per channel in
-// node space, single tiles only) instead of the eigen-space one — A/B runs.  The Python side
-// (ops.pairing_supported) reads the same variable: the node-space kernel cannot take pair tiles.
-static bool dense_filters_in_node_space() {
-  static const bool v = [] {
-    const char* e = getenv("LNZ_DENSE_FILTER_NODE_SPACE");
-    return e && atoi(e) != 0;
-  }();
-  return v;
-}
-
 // The inference forward runs on 16 x 16 MFMA tiles with all eight waves on all of a workgroup's
 // node tiles (conv_forward16.hip) where that kernel is built; LNZ_FORWARD16=0 keeps the 32 x 32
 // kernel of this file for A/B runs (lanczosnet_amd/utils/flop_model.py reads the same variable).
@@ -1316,7 +1305,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
               a.filter_kind);
   LNZ_REQUIRE(!a.plan || (a.n_wg && a.plan_wg_cap > 0), LNZ_EINVAL,
               "%s: plan without n_wg / plan_wg_cap", who);
-  const bool dense_es = a.filter_kind == 1 && !dense_filters_in_node_space();
+  const bool dense_es = a.filter_kind == 1;  // dense K x K filters run in eigen space
   if (mode == 0) {
     LNZ_REQUIRE(a.dout >= 1 && a.dout <= 31, LNZ_ENOTSUP, "%s: output width %d not in 1..31", who,
                 a.dout);
@@ -1328,11 +1317,16 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
-    if (forward16_enabled() && strips_enabled() && (a.filter_kind == 0 || dense_es) &&
-        lnz::strip_forward_eligible(a, 0))
+    // (the training forward — act_out — has no 32 x 32-tile kernel any more: the switch that
+    // selects those for A/B runs applies to inference launches only)
+    const bool tiles16 = forward16_enabled() || a.act_out;
+    if (tiles16 && strips_enabled() && lnz::strip_forward_eligible(a, 0))
       return lnz::launch_strip_forward(a, 0, s);
-    if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 0))
-      return lnz::launch_forward16(a, 0, s);
+    if (tiles16 && lnz::forward16_eligible(a, 0)) return lnz::launch_forward16(a, 0, s);
+    LNZ_REQUIRE(!a.act_out, LNZ_ENOTSUP,
+                "%s: the activation store (training forward) is built on the 16 x 16-tile kernels: "
+                "hidden width 128, input width 64 or 128, <= 12 long and <= 32 channels in all, "
+                "K %% 4 == 0 for dense filters", who);
     if (getenv("LNZ_FORWARD16_VERBOSE"))
       fprintf(stderr, "lnz forward on 32x32 tiles: fk %d dense_es %d gemm %d dhid %d din0 %d short %d long %d "
               "edge %d K %d B %d L %d\n", a.filter_kind, (int)dense_es, a.gemm_mode, a.dhid, a.din0,
@@ -1348,11 +1342,13 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                   LNZ_EINVAL, "%s: need Wp (transposed packs), dy, dx0, din0 == dhid, bwd_din0", who);
       LNZ_REQUIRE(!a.dy_compact || (a.row_off && a.dy_compact_rows > 0), LNZ_EINVAL,
                   "%s: dy_compact needs row_off and dy_compact_rows", who);
-      if (forward16_enabled() && strips_enabled() && (a.filter_kind == 0 || dense_es) &&
-          lnz::strip_forward_eligible(a, 1))
+      if (strips_enabled() && lnz::strip_forward_eligible(a, 1))
         return lnz::launch_strip_forward(a, 1, s);
-      if (forward16_enabled() && (a.filter_kind == 0 || dense_es) && lnz::forward16_eligible(a, 1))
-        return lnz::launch_forward16(a, 1, s);
+      if (lnz::forward16_eligible(a, 1)) return lnz::launch_forward16(a, 1, s);
+      // (the 32 x 32-tile instantiations of this pass — up to 79 spilled registers — went in r05)
+      LNZ_REQUIRE(false, LNZ_ENOTSUP,
+                  "%s: built on the 16 x 16-tile kernels: <= 12 long and <= 32 channels in all, "
+                  "bwd_din0 %% 16 == 0, K %% 4 == 0 for dense filters", who);
     } else {
       LNZ_REQUIRE(a.msg && a.msg_layer >= 0 && a.msg_layer < a.num_layer &&
                       (a.msg_layer > 0 || a.x0),
@@ -1380,35 +1376,19 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
   // model with an input width that is a multiple of 64 takes the 8-slot ring in the forward
   // modes; the backward modes always take the 4-slot ring.
   const bool all_deep = a.dhid == 128 && a.din0 % 64 == 0;
-  if (mode == 1) {
-    if (a.filter_kind == 0) LNZ_LAUNCH_D(4, 10, 0, 1, 0);
-    else LNZ_LAUNCH_D(4, 10, 2, 1, 0);
-  } else if (mode == 2) {
+  if (mode == 2) {
     if (a.filter_kind == 0) LNZ_LAUNCH_D(4, 10, 0, 2, 0);
     else LNZ_LAUNCH_D(4, 10, 2, 2, 0);
-  } else if (a.filter_kind != 0 && a.act_out) {
-    LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
-    LNZ_LAUNCH_D(4, 10, 2, 3, 0);
-  } else if (a.filter_kind == 0 && a.act_out) {
-    LNZ_REQUIRE(a.dhid == 128, LNZ_ENOTSUP, "%s: act_out is built for hidden width 128", who);
-    if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 3, 1);
-    else LNZ_LAUNCH(4, 10, 0, 3);
   } else if (a.filter_kind == 0) {
     if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 0, 1);
     else if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
     else LNZ_LAUNCH(2, 10, 0, 0);
-  } else if (!dense_filters_in_node_space()) {
+  } else {
     // dense K x K filters (AdaLanczosNet) in eigen space: pair tiles, DD fragments as GEMM2 operand
     // 4-slot weight ring in every layer: the DD fragments are live across the channel's GEMM1
     // next to T, Z and out — the 8-slot ring does not fit in 256 registers beside them
     if (a.dhid == 128) LNZ_LAUNCH_D(4, 10, 2, 0, 0);
     else LNZ_LAUNCH_D(2, 10, 2, 0, 0);
-  } else {
-    const bool k24 = a.K <= 24;  // cd_row order: 12 steps cover k < 24
-    if (a.dhid == 128 && k24) LNZ_LAUNCH(4, 12, 1, 0);
-    else if (a.dhid == 128) LNZ_LAUNCH(4, KHMAX, 1, 0);
-    else if (k24) LNZ_LAUNCH(2, 12, 1, 0);
-    else LNZ_LAUNCH(2, KHMAX, 1, 0);
   }
 #undef LNZ_LAUNCH_D
 #undef LNZ_LAUNCH

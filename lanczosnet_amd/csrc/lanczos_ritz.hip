@@ -977,22 +977,30 @@ void prepare_batch_union_kernel(
     int32_t* __restrict__ n_strips) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ubuf[];
   const int blk = blockIdx.x;
-  if (blk == 0) {
-    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
-    if (strips) {
-      __syncthreads();
+#ifdef LNZ_PREP_X_NOPLAN   // probes of the launch's parts (tools/experiments/prep_parts.py)
+  if (blk < 2) return;
+#endif
+#ifdef LNZ_PREP_X_EMPTYPACK
+  if (blk > B + 1) return;
+#endif
+  if (blk < 2) {
+    // The two planners — tile plan + live eigen slots (workgroup 0), strip plan (workgroup 1) —
+    // are independent serial chains of scans over the mask.  As ONE workgroup behind each other,
+    // sharing its compute unit with four Ritz wavefronts, they were the long pole of the launch
+    // (r05 probes, B = 1024: 92 us with the planner, 75 without).  Side by side and at raised issue
+    // priority they finish under the Ritz wavefronts.
+    __builtin_amdgcn_s_setprio(3);
+    if (blk == 0)
+      plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    else if (strips)
       plan_strips_body(mask, B, N, n_cu, strips, n_strips, ubuf);
-    }
-  } else if (blk <= B) {
+  } else if (blk <= B + 1) {
     if (threadIdx.x >= 64) return;
     // channel 0 of L is the simple-graph Laplacian the Ritz pairs belong to (dataset/qm8.py:262)
-#ifdef LNZ_PREP_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 1, threadIdx.x,
+    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, info, blk - 2, threadIdx.x,
                         ritz32_view(ubuf, N));
   } else {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, reinterpret_cast<float*>(ubuf), blk - 1 - B,
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, reinterpret_cast<float*>(ubuf), blk - 2 - B,
                         ident);
   }
 }
@@ -1033,22 +1041,23 @@ __global__ __launch_bounds__(256, 2) void prepare_batch_gains_kernel(
   const Ritz32Smem sm = ritz32_view(ubuf, N);
   float* tile = reinterpret_cast<float*>(ubuf);
   const int blk = blockIdx.x;
-  if (blk == 0) {
-    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
-    if (strips) {
-      __syncthreads();
+  if (blk < 2) {
+    // the two planners side by side (see prepare_batch_union_kernel)
+    __builtin_amdgcn_s_setprio(3);
+    if (blk == 0)
+      plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    else if (strips)
       plan_strips_body(mask, B, N, n_cu, strips, n_strips, ubuf);
-    }
-  } else if (blk <= B) {
+  } else if (blk <= B + 1) {
     if (threadIdx.x >= 64) return;
     // the Lanczos / eigensolve chain is the critical path of the launch: it wins every issue
     // arbitration against the gains wave that shares its SIMD
     __builtin_amdgcn_s_setprio(3);
-    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 1, threadIdx.x, sm);
+    lanczos_ritz32_body(L, sb, sr, sc, n_nodes, N, K, D, V, nullptr, blk - 2, threadIdx.x, sm);
   } else {
     // behind the Ritz workgroups: the gains workgroups, then the pack (needed by the next launch
     // only).  Alternating the two measured slower (229 vs 182 us).
-    const int p = blk - B - 1;
+    const int p = blk - B - 2;
     if (p >= n_cons) {
       pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, p - n_cons, ident);
       return;
@@ -1085,7 +1094,7 @@ extern "C" int lnz_prepare_batch(const float* L, int64_t stride_b, int64_t strid
               "lnz_prepare_batch: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", tile);
   LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_prepare_batch: strips need n_strips");
   // without Lp: plan + Ritz pairs only (no pack workgroups in the grid)
-  hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(Lp ? 2 * B + 1 : B + 1), dim3(256),
+  hipLaunchKernelGGL(prepare_batch_union_kernel, dim3(Lp ? 2 * B + 2 : B + 2), dim3(256),
                      Lp ? prep_lds_bytes(N, C) : prep_lds_bytes(N, 0),
                      (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,
                      (float4*)Lp, mask, B, n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg,
@@ -1115,7 +1124,7 @@ extern "C" int lnz_prepare_batch_prev_gains(
   for (int i = 0; i < lnz_gains::SMAX; ++i) dist.v[i] = i < S ? dist_host[i] : 0;
   const int64_t tiles = ((int64_t)B_prev * K + 31) / 32;
   const int64_t n_cons = (tiles * num_layer + 3) / 4;
-  const int64_t grid = 2 * (int64_t)B + 1 + n_cons;
+  const int64_t grid = 2 * (int64_t)B + 2 + n_cons;
   LNZ_REQUIRE(grid < (1ll << 31), LNZ_ENOTSUP, "lnz_prepare_batch_prev_gains: batch too large");
   hipLaunchKernelGGL(prepare_batch_gains_kernel, dim3((unsigned)grid), dim3(256),
                      prep_lds_bytes(N, C), (hipStream_t)stream, L, stride_b, stride_r, stride_c, stride_ch, N, C,

@@ -221,17 +221,19 @@ __global__ __launch_bounds__(1024) void plan_tiles_kernel(const uint8_t* __restr
                                                           int32_t* __restrict__ n_gain_rows,
                                                           int32_t* __restrict__ strips,
                                                           int32_t* __restrict__ n_strips) {
+  // two workgroups: the tile plan (+ live eigen slots) and the strip plan are independent chains
+  // of scans over the mask — side by side instead of behind each other
   __shared__ __attribute__((aligned(16))) unsigned char strip_scratch[kStripScratch];
-  if (plan)
-    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
-  if (strips) {
-    __syncthreads();
+  if (blockIdx.x == 0) {
+    if (plan)
+      plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+  } else if (strips) {
     plan_strips_body(mask, B, N, n_cu, strips, n_strips, strip_scratch);
   }
 }
 
-// Both byte movers that precede the Lanczos kernel in ONE launch: workgroup 0 plans the batch,
-// workgroups 1..B pack a molecule's Laplacian tile each — the single-workgroup planner (~15 us of
+// Both byte movers that precede the Lanczos kernel in ONE launch: workgroups 0 and 1 plan the batch
+// (tile plan, strip plan), workgroups 2..B+1 pack a molecule's Laplacian tile each — the single-workgroup planner (~15 us of
 // latency-bound work) runs under the packing instead of behind it.
 __global__ __launch_bounds__(1024) void pack_plan_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
@@ -241,14 +243,14 @@ __global__ __launch_bounds__(1024) void pack_plan_kernel(
     uint32_t* __restrict__ ident, int32_t* __restrict__ strips, int32_t* __restrict__ n_strips) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   __shared__ __attribute__((aligned(16))) unsigned char strip_scratch[kStripScratch];
-  if (blockIdx.x == 0) {  // dispatched first: the planner's latency chain starts immediately
-    plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
-    if (strips) {
-      __syncthreads();
+  if (blockIdx.x < 2) {  // dispatched first: the planners' latency chains start immediately
+    __builtin_amdgcn_s_setprio(3);
+    if (blockIdx.x == 0)
+      plan_tiles_body(mask, B, N, n_cu, allow_pairs, wg_cap, plan, n_wg, K, gain_rows, n_gain_rows);
+    else if (strips)
       plan_strips_body(mask, B, N, n_cu, strips, n_strips, strip_scratch);
-    }
   } else {
-    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, (int)blockIdx.x - 1, ident);
+    pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, (int)blockIdx.x - 2, ident);
   }
 }
 
@@ -269,7 +271,7 @@ extern "C" int lnz_pack_laplacian_plan(const float* L, int64_t stride_b, int64_t
   LNZ_REQUIRE(lds <= 40 * 1024, LNZ_ENOTSUP,
               "lnz_pack_laplacian_plan: N*N*C*4 = %zu B exceeds the 40 KiB staging tile", lds);
   LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_pack_laplacian_plan: strips need n_strips");
-  hipLaunchKernelGGL(pack_plan_kernel, dim3(B + 1), dim3(1024), lds, (hipStream_t)stream, L,
+  hipLaunchKernelGGL(pack_plan_kernel, dim3(B + 2), dim3(1024), lds, (hipStream_t)stream, L,
                      stride_b, stride_r, stride_c, stride_ch, N, C, (float4*)Lp, mask, B, n_cu,
                      allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows, n_gain_rows,
                      ident, strips, n_strips);
@@ -290,7 +292,7 @@ extern "C" int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int a
   LNZ_REQUIRE(!gain_rows || (n_gain_rows && K > 0), LNZ_EINVAL,
               "lnz_plan_batch: gain_rows needs n_gain_rows and K > 0");
   LNZ_REQUIRE(!strips || n_strips, LNZ_EINVAL, "lnz_plan_batch: strips need n_strips");
-  hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
+  hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
                      n_cu, allow_pairs, lnz_plan_wg_cap(B, n_cu), plan, n_wg, K, gain_rows,
                      n_gain_rows, strips, n_strips);
   return lnz::check_launch("lnz_plan_batch");
@@ -307,7 +309,7 @@ extern "C" int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int3
   LNZ_REQUIRE(mask && strips && n_strips && B > 0 && N > 0 && n_cu > 0, LNZ_EINVAL,
               "lnz_plan_strips: bad arguments (B=%d N=%d n_cu=%d)", B, N, n_cu);
   LNZ_REQUIRE(N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_plan_strips: built for N <= %d (N=%d)", LNZ_TILE, N);
-  hipLaunchKernelGGL(plan_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
+  hipLaunchKernelGGL(plan_tiles_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, mask, B, N,
                      n_cu, 0, 0, (int32_t*)nullptr, (int32_t*)nullptr, 0, (int32_t*)nullptr,
                      (int32_t*)nullptr, strips, n_strips);
   return lnz::check_launch("lnz_plan_strips");

@@ -566,11 +566,19 @@ class _LanczosNetBase(nn.Module):
         m = (mask != 0).float().unsqueeze(2)
         return (y * m).sum(dim=1) / m.sum(dim=1)
 
+    def _tiles16_channels_ok(self):
+        """Channel counts of the 16 x 16-tile kernels (csrc/conv_forward16.hip forward16_eligible),
+        the only home of the training forward and the input-gradient pass since r05: at most 12
+        long-diffusion channels, at most 32 channels in all."""
+        n_long, n_short = len(self.long_diffusion_dist), len(self.short_diffusion_dist)
+        return n_long <= 12 and n_short + n_long + self.num_edgetype + 1 <= 32
+
     def _fused_backward_supported(self):
         """The HIP backward (lnz_lanczosnet_input_grad / _messages) is built for the exact-fp32
         LanczosNet kernel with hidden width 128."""
         return (self.filter_kind == 0 and self.gemm_mode == 'fp32' and self._fused_supported()
-                and self.hidden_dim[0] == 128 and self.backward_impl == 'hip')
+                and self.hidden_dim[0] == 128 and self.backward_impl == 'hip'
+                and self._tiles16_channels_ok())
 
     @torch.no_grad()
     def _plan_backward(self):
@@ -1119,12 +1127,10 @@ class AdaLanczosNet(_LanczosNetBase):
         return torch.randn(B, N, 1).to(device)
 
     def _fused_backward_supported(self):
-        """The HIP conv-stack backward with dense filters is built for hidden width 128, the
-        eigen-space kernel (not LNZ_DENSE_FILTER_NODE_SPACE=1) and the reference's 4-Linear filter
-        MLPs."""
+        """The HIP conv-stack backward with dense filters is built for hidden width 128 on the
+        16 x 16-tile kernels (K a multiple of 4) and the reference's 4-Linear filter MLPs."""
         return (self._fused_supported() and self.hidden_dim[0] == 128 and self.backward_impl == 'hip'
-                and self.num_eig_vec <= 32 and len(self.long_diffusion_dist) <= 16
-                and ops.pairing_supported({'filter_kind': 1}) and
+                and self.num_eig_vec <= 32 and self.num_eig_vec % 4 == 0 and self._tiles16_channels_ok() and
                 all(len(seq) == 7 and all(isinstance(seq[i], nn.Linear) for i in (0, 2, 4, 6))
                     for seq in self.spectral_filter))
 

@@ -646,14 +646,9 @@ def plan_tiles(mask_u8, allow_pairs, n_cu=None):
 
 
 def pairing_supported(plan):
-  """Pair tiles exist in the exact-fp32 kernels whose spectral channels run in eigen space:
-  diagonal gains (LanczosNet) and dense K x K filters (AdaLanczosNet) — unless
-  LNZ_DENSE_FILTER_NODE_SPACE=1 selects the r02 node-space dense-filter kernel (single tiles)."""
-  if plan.get('Wp16') is not None:
-    return False
-  if int(plan.get('filter_kind', 0)) == 0:
-    return True
-  return os.environ.get('LNZ_DENSE_FILTER_NODE_SPACE', '0') in ('', '0')
+  """Pair tiles exist in the exact-fp32 kernels, whose spectral channels run in eigen space:
+  diagonal gains (LanczosNet) and dense K x K filters (AdaLanczosNet)."""
+  return plan.get('Wp16') is None
 
 
 def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tiling='auto',

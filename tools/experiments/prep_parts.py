@@ -37,3 +37,8 @@ def two_streams():
   ops.lanczos_ritz(A, n, 20)
   cur.wait_stream(s2)
 print(json.dumps({'two_streams': timed(two_streams)}))
+
+# plan + Ritz pairs without the pack workgroups (lnz_prepare_batch with Lp = NULL)
+from lanczosnet_amd import ops as _o
+nn32 = n.to(torch.int32).contiguous()
+print(json.dumps({'plan_ritz_no_pack': timed(lambda: _o._ext().plan_ritz(L, mk, nn32, 20, 256, True))}))
