@@ -524,37 +524,49 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
   const double tiny = kEps * gsc;
   const int len = act ? t - s : -1;
   {
+    // pivot chains: one reciprocal per row is the critical path (rcp, Newton step, FMA, clamp);
+    // the row operands are read one step ahead, the store sits behind the chain
     double Dprev = 1.0;
-    // the row operands travel one step ahead of the pivot chain
-    int i = len >= 0 ? (h ? t : s) : 0;
-    double dcur = sm.za[i], ecur = 0.0;  // (no coupling into the first row of the sweep)
+    const int i0 = len >= 0 ? (h ? t : s) : 0, step = h ? -1 : 1;
+    double dcur = sm.za[i0], ecur = 0.0;  // (no coupling into the first row of the sweep)
+#pragma unroll 2
     for (int k = 0; k < maxlen; ++k) {
       const bool in = k <= len;
-      const bool in_n = k + 1 <= len;
-      const int i_n = in_n ? (h ? t - k - 1 : s + k + 1) : 1;
-      const double dnx = sm.za[i_n], enx = sm.ca[h ? i_n : i_n - 1];
-      const double di = dcur - lam;
-      double dnew = fma(-ecur, rcp_nr(Dprev), di);
+      const int i = i0 + step * (in ? k : 0);
+      const int i_n = i0 + step * (k + 1 <= len ? k + 1 : 0);
+      const double dnx = sm.za[i_n], enx = sm.ca[h ? i_n : (i_n > 0 ? i_n - 1 : 0)];
+      double dnew = fma(-ecur, rcp_nr(Dprev), dcur - lam);
       dnew = fabs(dnew) < tiny ? (dnew < 0.0 ? -tiny : tiny) : dnew;
-      if (in) {
-        Dprev = dnew;
-        sm.dw(h, i, r) = dnew;
-      }
-      i = i_n, dcur = dnx, ecur = enx;
+      Dprev = in ? dnew : Dprev;
+      if (in) sm.dw(h, i, r) = dnew;
+      dcur = dnx, ecur = enx;
     }
   }
   __syncthreads();
   if (ts) ts[4] = clock64();
   int tw = s;
   {
+    // gamma over the rows of the window, the halves on alternate rows, four rows in flight
     double gbest = 1e300;
-    for (int k = h; k < maxlen; k += 2) {     // the halves take alternate rows
-      const int i = s + k;
-      const bool in = k <= len && i >= ws && i <= wt;
-      const int ic = in ? i : 0;
-      const double g = fabs((sm.dw(0, ic, r) + sm.dw(1, ic, r)) - (sm.za[ic] - lam));
-      // ties: the highest index (the order of a downward scan with a strict comparison)
-      if (in && (g < gbest || (g == gbest && i > tw))) gbest = g, tw = i;
+    for (int k0 = 0; k0 < maxlen; k0 += 8) {
+      double g[4];
+      int ii[4];
+      bool inn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 2 * u + h;
+        ii[u] = s + k;
+        inn[u] = k <= len && ii[u] >= ws && ii[u] <= wt;
+        const int ic = inn[u] ? ii[u] : 0;
+        g[u] = fabs((sm.dw(0, ic, r) + sm.dw(1, ic, r)) - (sm.za[ic] - lam));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // ties: the highest index (the order of a downward scan with a strict comparison)
+        const bool take = inn[u] && (g[u] < gbest || (g[u] == gbest && ii[u] > tw));
+        gbest = take ? g[u] : gbest;
+        tw = take ? ii[u] : tw;
+      }
     }
     double g_up;
     int t_up;
@@ -570,11 +582,12 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
   {
     // half 0: z_i = -(e_i / D+_i) z_{i+1} upwards from the twist index; half 1:
     // z_i = -(e_{i-1} / D-_i) z_{i-1} downwards.  The multipliers do not depend on the chain:
-    // four rows at a time, their reciprocals overlap.
+    // four rows at a time, loads and reciprocals issued together, branch free; the chain itself
+    // is one multiplication per row.
     double zprev = 1.0, nn = h ? 0.0 : 1.0;
     if (act && h == 0) sm.dw(0, tw, r) = 1.0;
     for (int k0 = 1; k0 < maxlen; k0 += 4) {
-      double mul[4];
+      double Dv[4], ev[4];
       int ix[4];
       bool inx[4];
 #pragma unroll
@@ -582,16 +595,19 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
         const int i = h ? tw + k0 + u : tw - k0 - u;
         inx[u] = act && (h ? i <= t : i >= s);
         ix[u] = inx[u] ? i : 1;
-        mul[u] = -(sm.zb[h ? ix[u] - 1 : ix[u]] * rcp_nr(sm.dw(h, ix[u], r)));
+        Dv[u] = sm.dw(h, ix[u], r);
+        ev[u] = sm.zb[h ? ix[u] - 1 : ix[u]];
       }
+      double mul[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mul[u] = -(ev[u] * rcp_nr(Dv[u]));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double znew = mul[u] * zprev;
-        if (inx[u]) {
-          sm.dw(0, ix[u], r) = znew;
-          zprev = znew;
-          nn = fma(znew, znew, nn);
-        }
+        zprev = inx[u] ? znew : zprev;
+        const double zz = inx[u] ? znew : 0.0;
+        nn = fma(zz, zz, nn);
+        if (inx[u]) sm.dw(0, ix[u], r) = znew;
       }
     }
     nn = xhalf_sum(nn);
@@ -625,12 +641,16 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
       if (pos == p) {
         for (int d = 1; d <= p; ++d) {
           double dot = 0.0;
+#pragma unroll 4
           for (int i = 0; i < n; ++i) dot = fma(sm.dw(0, i, r), sm.dw(0, i, r - d), dot);
+#pragma unroll 4
           for (int i = 0; i < n; ++i) sm.dw(0, i, r) = fma(-dot, sm.dw(0, i, r - d), sm.dw(0, i, r));
         }
         double nn = 0.0;
+#pragma unroll 4
         for (int i = 0; i < n; ++i) nn = fma(sm.dw(0, i, r), sm.dw(0, i, r), nn);
         const double s2 = nn > 0.0 ? rsqrt(nn) : 1.0;
+#pragma unroll 4
         for (int i = 0; i < n; ++i) sm.dw(0, i, r) *= s2;
       }
       __syncthreads();
