@@ -432,6 +432,31 @@ int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
 int lnz_strip_cap(int B);
 int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips,
                     int32_t* n_strips, lnz_stream_t stream);
+/* ---- R9 + R10 + R11 for graphs of 33..128 nodes: the reference's own graph configuration
+ * (config/graph_lanczos_net.yaml, dataset/get_graph_data.py:15-49: n in [20, 100]) — every conv
+ * layer of model/lanczos_net_general.py:157-182 (model/lanczos_net.py:157-182), the head and the
+ * gated masked mean (:185-194) in ONE launch, exact fp32 (v_mfma_f32_16x16x4_f32).  A graph is
+ * spread over four workgroups by output columns (32 each); the layer's state goes through Xwork
+ * behind a counter in `sync` the four spin on (csrc/conv_mid.hip).
+ *   X0     [B,N,din0] fp32   layer-0 state (node features / embedding rows), din0 a multiple of
+ *                            16 (zero-padded columns), <= 128
+ *   L      [B,N,N,C] fp32    by element strides; C = edge types + 1 channels, 1..2
+ *   V, G, mask               as for lnz_lanczosnet_forward: [B,N,K], [num_layer,B,S,K], [B,N]
+ *   W      fp32              per layer [128][S + C][din_l] (din_0 = din0, else 128): the mix
+ *                            weight's column blocks in the reference's order — long scales, then
+ *                            edge types (no short-diffusion channels) —, the layers behind each other
+ *   bias   [num_layer,128];  Whead [dout + 1,128], bhead [dout + 1]: head rows, then the gate row
+ *   Xwork  [lnz_midgraph_workspace_floats(B, N, num_layer)] fp32 scratch
+ *   sync   [B * num_layer] int32, ZERO on entry
+ *   score  [B,dout]
+ * N <= 128, K <= 32, S <= 16, dout <= 31, hidden width 128. */
+int64_t lnz_midgraph_workspace_floats(int B, int N, int num_layer);
+int lnz_midgraph_forward(const float* X0, const float* L, int64_t stride_b, int64_t stride_r,
+                         int64_t stride_c, int64_t stride_ch, const float* V, const float* G,
+                         const uint8_t* mask, const float* W, const float* bias, const float* Whead,
+                         const float* bhead, int B, int N, int K, int C, int S, int num_layer,
+                         int din0, int dout, float* Xwork, int32_t* sync, float* score,
+                         lnz_stream_t stream);
 /* The whole batch preparation in ONE launch: lnz_plan_batch (workgroup 0), lnz_lanczos_ritz on
  * channel 0 of L (workgroups 1..B, dispatched first: they are the long, latency-bound pole) and
  * lnz_pack_laplacian (workgroups B+1..2B) — the two byte movers run in the shadow of the Lanczos

@@ -71,6 +71,9 @@ SIGNATURES = {
     'lnz_large_gemm1': (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
     'lnz_large_spectral': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lnz_large_conv': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'lnz_midgraph_workspace_floats': (C.c_int64, [_I, _I, _I]),
+    'lnz_midgraph_forward': (C.c_int, [_P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
+                                       _I, _I, _I, _P, _P, _P, _P]),
     'lnz_packed_rows_k8_size': (C.c_int64, [_I, _I]),
     'lnz_pack_rows_k8': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_packed_rows_f16x2_bytes': (C.c_int64, [_I, _I]),

@@ -424,6 +424,58 @@ class _LanczosNetBase(nn.Module):
             cache['conv'][key] = layers
         return cache
 
+    # -- graphs of 33..128 nodes: one fused launch (csrc/conv_mid.hip) ---------------------------
+    mid_graph_kernel = os.environ.get('LANCZOSNET_MID_KERNEL', '1') != '0'
+
+    def _mid_hip_supported(self, N, K, channels):
+        """lnz_midgraph_forward: exact fp32, uniform hidden width 128, input width <= 128, no
+        short-diffusion powers, K <= 32, <= 16 long scales, <= 2 operator channels, 32 < N <= 128."""
+        return (self.mid_graph_kernel and 32 < N <= 128 and K <= 32 and channels <= 2
+                and self.gemm_mode == 'fp32' and self.filter_kind == 0
+                and set(self.hidden_dim[:self.num_layer]) == {128} and self.input_dim <= 128
+                and self.num_scale_short == 0 and self.num_scale_long <= 16 and self.output_dim <= 31
+                and self._channel_order() is None)
+
+    @torch.no_grad()
+    def _plan_mid(self):
+        """Weights of lnz_midgraph_forward: per layer the mix weight as [128][S + E + 1][dinp]
+        (input width zero-padded to a multiple of 16), biases, head + gate rows."""
+        cache = self._plan_large()
+        if 'mid' not in cache:
+            S, E1 = self.num_scale_long, self.num_edgetype + 1
+            Ws, din0p = [], None
+            for t in range(self.num_layer):
+                W = self._mix_weight(t).detach().float()
+                d_in = W.shape[1] // (S + E1)
+                dinp = (d_in + 15) // 16 * 16
+                if t == 0:
+                    din0p = dinp
+                Ws.append(torch.nn.functional.pad(W.view(W.shape[0], S + E1, d_in),
+                                                  (0, dinp - d_in)).reshape(-1))
+            cache['mid'] = dict(
+                W=torch.cat(Ws).contiguous(), din0p=din0p,
+                bias=torch.stack([self.filter[t].bias.detach().float() for t in range(self.num_layer)]).contiguous(),
+                Whead=torch.cat([self.filter[-1].weight.detach().float(),
+                                 self.att_func[0].weight.detach().float()]).contiguous(),
+                bhead=torch.cat([self.filter[-1].bias.detach().float(),
+                                 self.att_func[0].bias.detach().float()]).contiguous())
+        return cache
+
+    @torch.no_grad()
+    def _mid_graph_forward_hip(self, node_feat, L, D, V, mask):
+        plan = self._plan_mid()
+        mid = plan['mid']
+        X0 = node_feat.float() if self.general else self.embedding(node_feat).float()
+        if X0.shape[2] != mid['din0p']:
+            X0 = torch.nn.functional.pad(X0, (0, mid['din0p'] - X0.shape[2]))
+        G = None
+        if self.num_scale_long > 0:
+            G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'])
+        Lf = L if L.dtype == torch.float32 else L.float()
+        return ops.midgraph_forward(X0.contiguous(), Lf, V.float().contiguous(), G,
+                                    mask.to(torch.uint8).contiguous(), mid['W'], mid['bias'], mid['Whead'],
+                                    mid['bhead'], self.num_layer)
+
     def _large_hip_supported(self, K, channels=1):
         """lnz_large_*: uniform hidden width 128, input width <= 128, no short-diffusion powers,
         K <= 64, at most 8 operator channels (the pack kernel's channel map, csrc/conv_large.hip:
@@ -690,6 +742,9 @@ class _LanczosNetBase(nn.Module):
                 # the reference trains arbitrary widths / sizes: differentiate the device-side
                 # torch restatement (same association as the kernels)
                 score = self._torch_forward(node_feat, L, D, V, mask, dropout=drop)
+            elif self._mid_hip_supported(L.shape[1], V.shape[2], L.shape[3]):
+                # 33..128 nodes: every layer, the head and the readout in one launch
+                score = self._mid_graph_forward_hip(node_feat, L, D, V, mask)
             elif L.shape[1] > 32 and self._large_hip_supported(V.shape[2], L.shape[3]):
                 # hand-written streaming kernels; 'bf16' = config 5's bf16-operand mode
                 score = self._large_graph_forward_hip(node_feat, L, D, V, mask,

@@ -325,6 +325,29 @@ def large_conv_layer(X, din, Lb, Vb, V, Wf, Wt, G, bias, work, relu=True, out=No
   return large_conv(Lb, Vb, Zt, Tt, bias, relu=relu, out=out)
 
 
+def midgraph_forward(X0, L, V, G, mask_u8, W, bias, Whead, bhead, num_layer):
+  """lnz_midgraph_forward: every conv layer, the head and the gated masked mean of a batch of
+  graphs with 33..128 nodes in ONE launch (csrc/conv_mid.hip; config/graph_lanczos_net.yaml).
+  X0 [B,N,din0] fp32 (din0 a multiple of 16), L [B,N,N,C] (any strides), V [B,N,K], G
+  [num_layer,B,S,K] or None, W: the layers' [128][S + C][din_l] weight blocks behind each other,
+  bias [num_layer,128], Whead [dout + 1,128], bhead [dout + 1].  Returns score [B,dout]."""
+  _need_cuda(X0, L, V, G, mask_u8, W, bias, Whead, bhead)
+  B, N, din0 = X0.shape
+  K, Cn = V.shape[2], L.shape[3]
+  S = 0 if G is None else G.shape[2]
+  dout = Whead.shape[0] - 1
+  dev = X0.device
+  Xwork = torch.empty((int(_abi().midgraph_workspace_floats(B, N, num_layer)),), dtype=torch.float32, device=dev)
+  sync = torch.zeros((B * num_layer + 16,), dtype=torch.int32, device=dev)   # (+ 16: phase stamps of profiling builds)
+  midgraph_forward.last_sync = sync
+  score = torch.empty((B, dout), dtype=torch.float32, device=dev)
+  sb, sr, sc, sch = L.stride()
+  with torch.cuda.device(dev):
+    _abi().midgraph_forward(X0, L, sb, sr, sc, sch, V, G, mask_u8, W, bias, Whead, bhead, B, N, K, Cn, S,
+                            num_layer, din0, dout, Xwork, sync, score)
+  return score
+
+
 def large_work_buffers(Lb):
   """(Zt, Tt, Ybuf) work buffers for large_conv_layer: Zt [planes,B,C,128,Nk] and Tt [planes,B,128,
   64] bf16 and Ybuf [B,64,128] fp32, zero-initialised (gemm1 never writes the k padding; Tt stays
