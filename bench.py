@@ -263,6 +263,52 @@ def graph_config_leg(dev, B=64, reps=5):
       if it >= 2:
         acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
   acc /= reps
+  # the forward's one launch (lnz_midgraph_forward, csrc/conv_mid.hip) on its own, and the streamed
+  # large-graph kernels it replaced for this size class
+  fwd = {}
+  with torch.no_grad():
+    def timed(fn, n=20):
+      fn()
+      torch.cuda.synchronize()
+      e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+      e[0].record()
+      for _ in range(n):
+        fn()
+      e[1].record()
+      torch.cuda.synchronize()
+      return e[0].elapsed_time(e[1]) / n
+    if net._mid_hip_supported(N, K, L.shape[3]):
+      plan = net._plan_mid()
+      mid = plan['mid']
+      X0 = torch.nn.functional.pad(Xd, (0, mid['din0p'] - Xd.shape[2])).contiguous()
+      G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+      Vc = V.float().contiguous()
+      launch_ms = timed(lambda: ops.midgraph_forward(X0, L, Vc, G, md, mid['W'], mid['bias'],
+                                                     mid['Whead'], mid['bhead'], cfg['num_layer']))
+      # v_mfma_f32_16x16x4_f32 instructions the kernel issues (2048 flop each): per workgroup and
+      # layer, R = ceil(N / 16) node subtiles, nk = din / 16 k-blocks, S long scales on eight waves,
+      # ONE edge pass (the two channels of L are equal and folded in the kernel)
+      R, S = (N + 15) // 16, len(cfg['long_diffusion_dist'])
+      def layer_mfma(din):
+        nk = din // 16
+        y = min(8, nk) * 2 * R * 4
+        long_ = max(S, 0) * 4 * nk * 4
+        return y + long_ + R * 2 * nk * 4 + R * 2 * R * 4 + R * 2 * 8
+      mfma = 4 * B * (layer_mfma(mid['din0p']) + (cfg['num_layer'] - 1) * layer_mfma(128))
+      fl = 2048.0 * mfma
+      net.mid_graph_kernel = False
+      streamed_ms = timed(lambda: net(Xd, L, D, V, mask=md), n=10)
+      net.mid_graph_kernel = True
+      fwd = {'kernel': 'midgraph_forward_kernel<2> (csrc/conv_mid.hip): every conv layer, the head and the '
+                       'readout in ONE launch, a graph on four workgroups (32 output columns each), exact fp32 '
+                       'on v_mfma_f32_16x16x4_f32; equal operator channels folded in the kernel',
+             'launch_ms': round(launch_ms, 4),
+             'roofline': {'bound': 'mfma', 'flops_per_launch_issued': fl,
+                          'achieved': round(fl / launch_ms / 1e9, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                          'unit': 'TFLOP/s', 'frac': round(fl / launch_ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                          'note': 'issued matrix instructions x 2048 flop / launch time; about 40 % of the launch '
+                                  'is the per-layer exchange between the four workgroups of a graph (DESIGN.md 4.5c)'},
+             'streamed_large_graph_kernels_ms': round(streamed_ms, 4)}
   t0 = time.perf_counter()
   Ln = L[:16, :, :, 0].cpu().numpy().astype(np.float64)
   worst = 0.0
@@ -275,7 +321,7 @@ def graph_config_leg(dev, B=64, reps=5):
   eigh_ms = (time.perf_counter() - t0) / 16 * 1e3
   bytes_ = float((4.0 * ns.astype(np.float64) ** 2).sum() + B * (4 * K + 4 * N * K))
   return {'workload': 'config/graph_lanczos_net.yaml: B=%d graphs G(n,0.5), n~U{20..100} (N=%d), K=20, '
-                      'E+1=2, LanczosNetGeneral 10->7x128->2, fp32 (split-precision streamed conv)'
+                      'E+1=2, LanczosNetGeneral 10->7x128->2, exact fp32 (one fused launch for the forward)'
                       % (B, N),
           'stage_ms': {'laplacian_l4': round(acc[0], 4), 'lanczos_ritz(workgroup per graph)':
                        round(acc[1], 4), 'forward': round(acc[2], 4)},
@@ -288,6 +334,7 @@ def graph_config_leg(dev, B=64, reps=5):
                    'qL_fallbacks': int((info >= 256).sum().item()),
                    'max_abs_dD_vs_numpy_eigh_16_graphs': worst,
                    'host_numpy_eigh_ms_per_graph': round(eigh_ms, 4)},
+          'forward': fwd,
           'finite': bool(torch.isfinite(score).all())}
 
 
