@@ -92,6 +92,9 @@ __host__ __device__ inline size_t wg_a_bytes(int N, bool qg) {
   }
   const size_t ql = (size_t)kWaves * 2 * (size_t)N * sizeof(double);  // QL's per-wave (d, e) copies
   a = a < ql ? ql : a;
+  // the eigenvalue search: T's (d, e, e^2), the probes' polynomial values, the brackets' midpoints
+  const size_t hs = (size_t)4 * N * sizeof(double) + 2 * LNZ_RITZ_EIG_THREADS * sizeof(float);
+  a = a < hs ? hs : a;
   return (a + 15) & ~(size_t)15;
 }
 
@@ -145,15 +148,18 @@ __device__ __forceinline__ void block_bounds(const unsigned long long* cutw, con
 // Two probe points per call so that two independent chains are in flight.
 __device__ __forceinline__ void sturm2(const double* __restrict__ d, const double* __restrict__ e2,
                                        const int s, const int t, const double xa, const double xb,
-                                       int& ca, int& cb) {
+                                       int& ca, int& cb, float& fa, float& fb, int& ea, int& eb) {
+  // fa * 2^ea, fb * 2^eb: the value p_len(x) of the block's characteristic polynomial at the two
+  // probes (the recurrence is renormalised every eight rows, the exponent tracked) — it places
+  // the probes of the passes behind the isolation of the eigenvalue (see the search loop)
   double a1 = 1.0, a2 = 0.0, b1 = 1.0, b2 = 0.0;
   unsigned na = 0u, nb = 0u;  // sign of the previous p (p_{-1} = 1 > 0)
+  int ka = 0, kb = 0;
   ca = cb = 0;
-  auto rescale = [&]() {  // keep |p| inside the exponent range
-    const double fa = fabs(a1), fb = fabs(b1);
-    const double ka = fa < 1e-100 ? 1e100 : (fa > 1e100 ? 1e-100 : 1.0);
-    const double kb = fb < 1e-100 ? 1e100 : (fb > 1e100 ? 1e-100 : 1.0);
-    a1 *= ka, a2 *= ka, b1 *= kb, b2 *= kb;
+  auto rescale = [&]() {  // keep |p| inside the exponent range: p = mantissa * 2^k, 0.5 <= |mantissa| < 1
+    const int qa = __builtin_amdgcn_frexp_exp(a1), qb = __builtin_amdgcn_frexp_exp(b1);
+    a1 = __builtin_ldexp(a1, -qa), a2 = __builtin_ldexp(a2, -qa), ka += qa;
+    b1 = __builtin_ldexp(b1, -qb), b2 = __builtin_ldexp(b2, -qb), kb += qb;
   };
   // Rows in groups of eight whose (d, e^2) are all fetched from LDS BEFORE the dependent chain
   // runs: read in program order, every row waited ~120 cycles for its two LDS words in front of
@@ -193,6 +199,8 @@ __device__ __forceinline__ void sturm2(const double* __restrict__ d, const doubl
     na = sa, nb = sb;
     a2 = a1, a1 = pa, b2 = b1, b1 = pb;
   }
+  rescale();
+  fa = (float)a1, fb = (float)b1, ea = ka, eb = kb;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -990,20 +998,58 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
         block_bounds(cutw, ev, n, bs, bt);
         jloc = ev - bs;
       }
-      // [n][2 P] Sturm counts (n P <= kNT: fits sm.part); the uniform-exit vote below is the
-      // barrier between a pass's reads and the next pass's writes
+      // [n][2 P] Sturm counts + exponents (n P <= kNT: fits sm.part), the probes' mantissas and
+      // the brackets' midpoints behind T in the dead A region; the uniform-exit vote below is the
+      // barrier between a pass's reads and the next pass's writes.
+      // Placement of a group's 2 P probes (the r05 hybrid of csrc/lanczos_ritz.hip): pass 0 covers
+      // the bracket uniformly INCLUDING its ends (every later end point carries p); a section pass
+      // cuts it into 2 P + 1 parts; once exactly one eigenvalue is inside and p changes sign the
+      // probes sit in rings x* -+ d1 8^i around the secant point x* of the end values, d1 ~ the
+      // secant's error w^2 / (2 gap to the neighbouring brackets): the bracket collapses
+      // quadratically (a 100-node graph: 7..9 passes instead of 15).  Brackets follow the COUNTS.
       int* cnt = reinterpret_cast<int*>(sm.part);
+      float* fm = reinterpret_cast<float*>(Te2 + N);
+      double* mids = reinterpret_cast<double*>(fm + 2 * LNZ_RITZ_EIG_THREADS);
       const int np = 2 * P;
-      bool done = !mine;
+      bool done = !mine, sect = true;
+      float flo = 0.0f, fhi = 0.0f;
+      int elo = 0, ehi = 0, clo = 0, chi = bt - bs + 1;
+      if (mine && sub == 0) mids[ev] = 0.0;
+      __syncthreads();
       for (int it = 0; it < 48; ++it) {
-        const double w = (hi - lo) / (double)(np + 1);
-        int* cb_ = cnt;
+        const double w = hi - lo;
+        const double tol = 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
+        const bool iso = it > 0 && !sect && chi - clo == 1 && flo != 0.0f && ((flo < 0.0f) != (fhi < 0.0f));
+        double xs = 0.0, d1 = 0.0;
+        if (iso && !done) {
+          int de_ = ehi - elo;
+          de_ = de_ < -1000 ? -1000 : (de_ > 1000 ? 1000 : de_);
+          const double fl = (double)flo, fh = __builtin_ldexp((double)fhi, de_);
+          xs = fma(w, fl * rcp_nr(fl - fh), lo);
+          double g = gsc;
+          if (ev > bs) g = fmin(g, fabs(xs - mids[ev - 1]));
+          if (ev < bt) g = fmin(g, fabs(mids[ev + 1] - xs));
+          d1 = 0.5 * w * w * __builtin_amdgcn_rcp(fmax(g, 1e-300));
+          d1 = fmin(d1, 0.125 * w);
+          d1 = fmax(fmax(d1, 0.45 * tol), 4e-7 * w);   // (the probes' values travel as fp32 mantissas)
+        }
+        const double step0 = w / (double)(np - 1), step1 = w / (double)(np + 1);
+        auto probe = [&](int k) -> double {
+          if (it == 0) return k == np - 1 ? hi : lo + (double)k * step0;
+          if (!iso) return lo + (double)(k + 1) * step1;
+          const int ring = k < P ? P - 1 - k : k - P;
+          const double off = fmin(__builtin_ldexp(d1, 3 * ring), 0.25 * w);
+          const double x = k < P ? xs - off : xs + off;
+          return fmin(fmax(x, lo), hi);
+        };
         if (!done) {
-          const double xa = lo + (double)(2 * sub + 1) * w, xb = lo + (double)(2 * sub + 2) * w;
-          int ca, cb;
-          sturm2(Td, Te2, bs, bt, xa, xb, ca, cb);
-          cb_[ev * np + 2 * sub] = ca;
-          cb_[ev * np + 2 * sub + 1] = cb;
+          int ca, cb, ea, eb;
+          float fa, fb;
+          sturm2(Td, Te2, bs, bt, probe(2 * sub), probe(2 * sub + 1), ca, cb, fa, fb, ea, eb);
+          cnt[ev * np + 2 * sub] = (ea << 8) | ca;
+          cnt[ev * np + 2 * sub + 1] = (eb << 8) | cb;
+          fm[ev * np + 2 * sub] = fa;
+          fm[ev * np + 2 * sub + 1] = fb;
         }
         __syncthreads();
         if (!done) {
@@ -1011,11 +1057,22 @@ __global__ __launch_bounds__(kNT) void lanczos_ritz_wg_kernel(
           // in front of it (behind the last probe when there is none)
           int pidx = np;
           for (int q = np - 1; q >= 0; --q)
-            if (cb_[ev * np + q] > jloc) pidx = q;
-          const double nlo = lo + (double)pidx * w, nhi = pidx == np ? hi : lo + (double)(pidx + 1) * w;
-          lo = nlo, hi = nhi;
+            if ((cnt[ev * np + q] & 255) > jloc) pidx = q;
+          const double xlo = pidx > 0 ? probe(pidx - 1) : lo, xhi = pidx < np ? probe(pidx) : hi;
+          if (pidx > 0) {
+            const int kq_ = cnt[ev * np + pidx - 1];
+            clo = kq_ & 255, elo = kq_ >> 8, flo = fm[ev * np + pidx - 1];
+          }
+          if (pidx < np) {
+            const int kq_ = cnt[ev * np + pidx];
+            chi = kq_ & 255, ehi = kq_ >> 8, fhi = fm[ev * np + pidx];
+          }
+          lo = xlo, hi = xhi;
+          const double nw = hi - lo;
+          sect = nw > 0.25 * w;
           // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|
-          done = (hi - lo) <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
+          done = nw <= 4.0 * kEps * fmax(fmax(fabs(lo), fabs(hi)), 0.125 * gsc);
+          if (sub == 0) mids[ev] = 0.5 * (lo + hi);
         }
         if (!__syncthreads_or(done ? 0 : 1)) break;
       }
