@@ -69,7 +69,10 @@ def main():
       'kernel': fwd,
       'SQ_INSTS_VALU_MFMA_MOPS_F32_per_launch': mops['per_launch'],
       'mfma_flops_per_launch': mops['per_launch'] * 512.0,
-      'mfma_instructions_per_launch': mops['per_launch'] / 8.0,
+      # one counted "MOP" = 512 flop: v_mfma_f32_16x16x4_f32 (strip / 16 x 16-tile kernels) = 4,
+      # v_mfma_f32_32x32x2_f32 (the 32-row-tile kernels) = 8
+      'mfma_instruction': 'v_mfma_f32_32x32x2_f32' if fwd.startswith('lanczosnet_forward_kernel') else 'v_mfma_f32_16x16x4_f32',
+      'mfma_instructions_per_launch': mops['per_launch'] / (8.0 if fwd.startswith('lanczosnet_forward_kernel') else 4.0),
       'launches': mops['launches'],
       'avg_duration_us_under_counters': mops['avg_duration_us'],
       'FETCH_SIZE_KB': fetch['per_launch'], 'WRITE_SIZE_KB': write['per_launch'],

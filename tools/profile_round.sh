@@ -7,7 +7,7 @@
 #    lnz_f32_linear and the library GEMM on the filter-MLP shapes; FETCH_SIZE / WRITE_SIZE of the
 #    large-graph conv kernels (folded and every-channel) — separate passes per counter group
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
