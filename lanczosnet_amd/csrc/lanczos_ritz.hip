@@ -305,8 +305,7 @@ __device__ __forceinline__ void eigenvalue_search(const Ritz32Smem& sm, EigState
                                                   const int r, const int h, const int s, const int t,
                                                   const unsigned a_base, const unsigned a_pad,
                                                   const int maxlen, const double gsc, const int it0,
-                                                  const bool may_bail, bool& bail,
-                                                  const bool loose = false) {
+                                                  const bool may_bail, bool& bail) {
   const bool act = r < n;
   const int jloc = r - s;
   const bool has_dn = act && r > s, has_up = act && r < t;
@@ -368,12 +367,10 @@ __device__ __forceinline__ void eigenvalue_search(const Ritz32Smem& sm, EigState
     st.chi = nh ? (nkhi & 255) : st.chi, st.ehi = nh ? (nkhi >> 8) : st.ehi;
     const double nw = st.hi - st.lo;
     st.sect = nw > 0.25 * w;
-    // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|.  loose: a
-    // lane of a cluster (see the caller) — its bracket holds the eigenvalue's copies and cannot
-    // collapse below their distance; 1e-12 |T| is what its vector needs (the component along any
-    // OTHER eigenvector is |lambda - copy| / gap to that eigenvalue)
-    st.done = st.done || nw <= fmax(4.0 * kEps * fmax(fmax(fabs(st.lo), fabs(st.hi)), 0.125 * gsc),
-                                    loose ? 1e-12 * gsc : 0.0);
+    // LAPACK dstebz's stopping rule: relative to |lambda| but never below ulp * |T|.  (Stopping the
+    // lanes of a cluster at 1e-12 |T| was tried: 5 passes fewer, and one molecule in 30 k whose
+    // cluster vectors lost orthogonality to 3e-5.)
+    st.done = st.done || nw <= 4.0 * kEps * fmax(fmax(fabs(st.lo), fabs(st.hi)), 0.125 * gsc);
     if (may_bail && it == 12) {
       // Two eigenvalues of ONE block still sharing a bracket: a degenerate eigenvalue whose
       // second copy crept into the Krylov space through round-off instead of a clean breakdown
@@ -393,7 +390,8 @@ __device__ __forceinline__ void eigenvalue_search(const Ritz32Smem& sm, EigState
 }
 
 __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double dreg, const double ereg,
-                                            const int n, const int r, const int h, long long* ts = nullptr) {
+                                            const int n, const int r, const int h, long long* ts = nullptr,
+                                            float* dbg = nullptr) {
   constexpr int LD = Ritz32Smem::LD;
   if (ts) ts[0] = clock64();
   // ---- d, e -> LDS (broadcast reads); negligible couplings split the matrix
@@ -467,6 +465,21 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
     // copies, the caller runs the QL sweep.
     const int upper = __shfl_down(bail ? 1 : 0, 1, 64);  // all lanes take part in the shuffle
     member = bail || (upper != 0 && (r & 31) < 31);
+    // An eigenvalue of the block within 1e-7 |T| of a member belongs to the cluster as well.  The
+    // window of a member is chosen by its RANK inside the widened bracket, which counts every
+    // eigenvalue in there: a simple eigenvalue 5e-9 next to a double one (r05 fuzz: two molecules
+    // in 65 k) took a rank without taking part, one member got ITS window and the two vectors
+    // came out equal.  Three rounds reach a chain of four.
+    {
+      const double midv = 0.5 * (st.lo + st.hi);
+      for (int rep = 0; rep < 3; ++rep) {
+        const double m_dn = __shfl_up(midv, 1, 64), m_up = __shfl_down(midv, 1, 64);
+        const int mem_dn = __shfl_up(member ? 1 : 0, 1, 64), mem_up = __shfl_down(member ? 1 : 0, 1, 64);
+        const bool join = act && ((r > s && mem_dn != 0 && fabs(midv - m_dn) <= 1e-7 * gsc) ||
+                                  (r < t && mem_up != 0 && fabs(m_up - midv) <= 1e-7 * gsc));
+        member = member || join;
+      }
+    }
     // eigenvalues of rows a..b (no outside coupling) below xa / below xb: the two recurrences
     // side by side (each is one chain of reciprocals: latency bound)
     auto count2 = [&](double xa, double xb, int a, int b, int& na, int& nb) {
@@ -510,7 +523,7 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
     }
     if (__any(!ok)) return false;
     bool bail2 = false;
-    eigenvalue_search(sm, st, n, r, h, s, t, a_base, a_pad, maxlen, gsc, 13, false, bail2, member);
+    eigenvalue_search(sm, st, n, r, h, s, t, a_base, a_pad, maxlen, gsc, 13, false, bail2);
   }
   const double lam = 0.5 * (st.lo + st.hi);
   if (ts) ts[1] = clock64();
@@ -657,6 +670,17 @@ __device__ inline bool tridiag_eig_parallel(const Ritz32Smem& sm, const double d
     }
   }
 
+#ifdef LNZ_RITZ_DEBUG  // per-lane eigensolver state of molecule LNZ_RITZ_DEBUG -> dbg (16 floats per lane)
+  if (dbg && act && h == 0) {
+    float* o = dbg + 16 * r;
+    o[0] = (float)lam, o[1] = (float)((lam - (double)(float)lam) * 1e9), o[2] = (float)s, o[3] = (float)t;
+    o[4] = member ? 1.0f : 0.0f, o[5] = (float)ws, o[6] = (float)wt, o[7] = (float)tw;
+    o[8] = (float)((st.hi - st.lo) / gsc * 1e12), o[9] = (float)st.clo, o[10] = (float)st.chi, o[11] = bail ? 1.0f : 0.0f;
+    o[12] = (float)dreg, o[13] = (float)(dreg - (double)(float)dreg);
+    o[14] = (float)ereg, o[15] = (float)(ereg - (double)(float)ereg);
+    o[1] = (float)(lam - (double)(float)lam);
+  }
+#endif
   if (ts) ts[2] = clock64();
   // ---- 4. V = Q S: column k, node rows 16h .. 16h+15
   double acc[16];
@@ -786,7 +810,10 @@ __device__ __forceinline__ void lanczos_ritz32_body(
 #endif
 
 #ifndef LNZ_RITZ32_QL
-#ifdef LNZ_PROFILE_PHASES
+#ifdef LNZ_RITZ_DEBUG  // (the caller's info buffer holds B ints + 32 x 16 floats)
+    float* dbg_ = b == LNZ_RITZ_DEBUG ? reinterpret_cast<float*>(info) + gridDim.x : nullptr;
+    const bool solved = tridiag_eig_parallel(sm, dreg, ereg, n, r, h, nullptr, dbg_);
+#elif defined(LNZ_PROFILE_PHASES)
     const bool solved = tridiag_eig_parallel(sm, dreg, ereg, n, r, h, tsx);
 #else
     const bool solved = tridiag_eig_parallel(sm, dreg, ereg, n, r, h);

@@ -230,6 +230,20 @@ def _tridiag_eig_parallel(dd, ee, Qt, n):
   member = [False] * n
   if any(bail):
     member = [bail[k] or (k + 1 < n and bail[k + 1]) for k in range(n)]
+    # an eigenvalue of the block within 1e-7 |T| of a member belongs to the cluster as well
+    # (its rank inside the widened bracket counts when the windows are handed out)
+    mid = [0.0] * n
+    for (s, t), (res, st) in states.items():
+      for k in range(s, t + 1):
+        mid[k] = 0.5 * (st[k - s]['lo'] + st[k - s]['hi'])
+    for _ in range(3):
+      new = list(member)
+      for k in range(n):
+        s, t = blk[k]
+        if (k > s and member[k - 1] and abs(mid[k] - mid[k - 1]) <= 1e-7 * gsc) or \
+           (k < t and member[k + 1] and abs(mid[k + 1] - mid[k]) <= 1e-7 * gsc):
+          new[k] = True
+      member = new
     cut, wd = 1e-3 * gsc, 1e-5 * gsc
     for k in range(n):
       if not member[k]:

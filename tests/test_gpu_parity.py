@@ -956,6 +956,29 @@ def test_ritz_pairs_orthonormal_and_accurate_including_degenerate_clusters(seed)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('seed', [15, 42])
+def test_ritz_pairs_of_a_simple_eigenvalue_next_to_a_double_one(seed):
+  """r05 fuzz (tools/experiments/ritz_fuzz.py, 160 seeds x 1024 molecules): two molecules whose
+  Lanczos matrix holds an eigenvalue twice AND a third one 5e-9 |T| above it in the same
+  unreduced block (seed 15 / molecule 440: 0.5, 0.5, 0.5 + 5.5e-9).  The third takes a rank inside
+  the cluster's widened bracket, so it has to take part in the window hand-out as well — when it
+  did not, one member got its window and two Ritz vectors came out EQUAL (V^T V off by 1.0).
+  The draw is the 32-node tile (n in 1..32), not the QM8 sizes of the test above."""
+  from lanczosnet_amd import ops
+  batch = draw_batch(1024, seed=seed, n_min=1, n_max=32, N=32)
+  n = _t(batch['n_nodes'])
+  L = ops.laplacian_l4(_t(batch['adjs']), n)
+  D, V, info = ops.lanczos_ritz(L[:, :, :, 0], n, 20, return_info=True)
+  assert int((info >= 256).sum()) == 0
+  A = L[:, :, :, 0].double()
+  Vd, Dd = V.double(), D.double()
+  kk = torch.clamp(n, max=20).long()
+  eye = torch.diag_embed((torch.arange(20, device=DEV)[None, :] < kk[:, None]).double())
+  assert (Vd.transpose(1, 2) @ Vd - eye).abs().max().item() < 2e-6
+  assert (A @ Vd - Vd * Dd[:, None, :]).abs().max().item() < 2e-6
+
+
+@pytest.mark.gpu
 def test_pipelined_preparation_computes_the_previous_batch_gains():
   """lnz_prepare_batch_prev_gains: batch B's preparation and batch A's spectral gains in one launch
   equal the separate launches bit for bit (different batch sizes on purpose)."""
