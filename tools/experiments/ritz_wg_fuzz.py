@@ -1,57 +1,38 @@
-"""Fuzz of the workgroup Ritz kernel (csrc/lanczos_ritz_wg.hip) over graph sizes 20..N and edge
-densities from forests to dense: every graph against numpy.linalg.eigh — the kept eigenvalues as a
-multiset to 1e-6 (slot by slot the order of +x and -x with equal |x| is decided by the last bit, in
-LAPACK as well: ritz_wg_one.py shows such a pair), V^T V = I to 1e-5, |A V - V D| to 1e-6 — and
-against the eight-wave Lanczos phase ('workgroup_mw'); the restart branch (sparse graphs) and the
-QL fallback are counted.  Graphs whose top-K cut splits a |lambda| cluster are skipped.
-  python tools/experiments/ritz_wg_fuzz.py [first seed] [seeds]"""
-import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+"""The workgroup-per-graph Ritz kernel over random graphs of 33..160 nodes (sparse to dense, incl.
+highly symmetric ones): V^T V = I, |A V - V D|, D against numpy eigh, QL fallbacks."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
-import oracle
 from lanczosnet_amd import ops
-
-s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-ns_ = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-bad, restarts, ql = [], 0, 0
-for seed in range(s0, s0 + ns_):
-  rs = np.random.RandomState(9000 + seed)
-  N = int(rs.choice([40, 64, 65, 72, 96, 100, 108]))
-  B = 12
-  p = float(rs.choice([0.015, 0.03, 0.08, 0.2, 0.5, 0.9]))
-  sizes = rs.randint(33 if N > 40 else 20, N + 1, size=B).astype(np.int32)
-  sizes[0] = N
-  A = np.zeros((B, N, N), np.float32)
-  for b, n in enumerate(sizes):
-    adj = np.triu((rs.rand(n, n) < p).astype(np.float64), 1)
-    A[b, :n, :n] = oracle.laplacian_l4(adj + adj.T)
-  Kk = 24 if p >= 0.1 else N   # sparse graphs: degenerate clusters everywhere, nothing is cut
-  Dl, Vl, full = [], [], np.zeros((B, N))
-  for b, n in enumerate(sizes):
-    e, v = np.linalg.eigh(A[b, :n, :n].astype(np.float64))
-    idx = np.argsort(-np.abs(e), kind='mergesort')
-    Dl.append(e[idx]); Vl.append(v[:, idx]); full[b, :n] = e[idx]
-  Dr, Vr = oracle.collate_eigs(Dl, Vl, N, Kk)
-  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
-  try:
-    D, V, info = ops.lanczos_ritz(t(A), t(sizes), Kk, return_info=True)
-    Dm, Vm, im = ops.lanczos_ritz(t(A), t(sizes), Kk, return_info=True, kernel='workgroup_mw')
-    assert torch.isfinite(D).all() and torch.isfinite(V).all()
-    Dn, Vn, Dmn = D.cpu().numpy(), V.cpu().numpy(), Dm.cpu().numpy()
-    for b, n in enumerate(sizes):
-      if oracle.degenerate_cut(full[b][:n], Kk):
-        continue
-      k = min(int(n), Kk)
-      assert np.abs(np.sort(Dn[b, :k]) - np.sort(Dr[b, :k])).max() < 1e-6, ('D', b, n)
-      assert np.abs(np.sort(Dn[b, :k]) - np.sort(Dmn[b, :k])).max() < 1e-6, ('D vs mw', b, n)
-      Vb = Vn[b, :n, :k].astype(np.float64)
-      assert np.abs(Vb.T @ Vb - np.eye(k)).max() < 1e-5, ('orth', b, n)
-      assert np.abs(A[b, :n, :n].astype(np.float64) @ Vb - Vb * Dn[b, :k][None, :]).max() < 1e-6, ('res', b, n)
-      assert (Vn[b, n:] == 0).all() and (Vn[b, :, k:] == 0).all()
-    restarts += int((info % 256).sum()); ql += int((info >= 256).sum())
-  except AssertionError as e:
-    bad.append((seed, N, p, str(e)[:80]))
-print('seeds %d..%d: %d failures, %d restarts, %d QL fallbacks' % (s0, s0 + ns_ - 1, len(bad), restarts, ql))
-for b in bad:
-  print(b)
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+worst = dict(orth=0.0, resid=0.0, dD=0.0, ql=0, graphs=0)
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
+  rs = np.random.RandomState(seed)
+  B, N = 96, int(rs.choice([40, 64, 100, 128, 160]))
+  ns = rs.randint(33, N + 1, size=B); ns[0] = N
+  adj = np.zeros((B, N, N, 1), np.float32)
+  for b in range(B):
+    n = int(ns[b]); kind = b % 4
+    if kind == 3:   # a forest of equal stars / paths: highly degenerate spectrum
+      a = np.zeros((n, n), np.float32); m = rs.randint(3, 9)
+      for i in range(1, n):
+        a[(i - 1) // m * m if i % m else max(i - m, 0), i] = 1.0
+    else:
+      a = np.triu((rs.rand(n, n) < [0.03, 0.2, 0.6][kind]).astype(np.float32), 1)
+    adj[b, :n, :n, 0] = np.maximum(a, a.T)
+  n_d = t(ns.astype(np.int32)); L = ops.laplacian_l4(t(adj), n_d)
+  D, V, info = ops.lanczos_ritz(L[..., 0], n_d, 20, return_info=True)
+  A = L[..., 0].double(); Vd, Dd = V.double(), D.double()
+  eye = torch.eye(20, device='cuda', dtype=torch.float64)[None]
+  worst['orth'] = max(worst['orth'], float((Vd.transpose(1, 2) @ Vd - eye).abs().max()))
+  worst['resid'] = max(worst['resid'], float((A @ Vd - Vd * Dd[:, None, :]).abs().max()))
+  worst['ql'] += int((info >= 256).sum()); worst['graphs'] += B
+  per = (Vd.transpose(1, 2) @ Vd - eye).abs().amax(dim=(1, 2)).cpu().numpy()
+  bad = np.nonzero(per > 1e-5)[0]
+  if len(bad):
+    print('seed', seed, 'N', N, 'bad graphs', len(bad), 'kinds', sorted(set(int(x) % 4 for x in bad)), 'n of first', int(ns[bad[0]]), 'info', int(info[bad[0]]), 'err', per[bad[0]], file=sys.stderr)
+  for bb in range(0, B, 7):
+    nb = int(ns[bb]); lam = torch.linalg.eigvalsh(A[bb, :nb, :nb].cpu())
+    want = lam[torch.argsort(-lam.abs(), stable=True)][:20]
+    worst['dD'] = max(worst['dD'], float((torch.sort(Dd[bb].cpu()).values - torch.sort(want).values).abs().max()))
+print(json.dumps(worst))
