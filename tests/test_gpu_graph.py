@@ -327,3 +327,36 @@ def test_wave_level_lanczos_phase_at_its_size_boundaries(p):
     check_ritz(D.cpu().numpy(), V.cpu().numpy(), Dr, Vr, ns, full, Kk, powers=(1, 5))
     assert (D - Dm).abs().max().item() < 1e-6, kern
     assert torch.equal(info % 256 > 0, im % 256 > 0), kern   # the same graphs broke down
+
+
+@pytest.mark.parametrize('N', [128, 160, 192])
+def test_workgroup_ritz_kernel_on_forests_of_equal_stars(N):
+  """Massively degenerate spectra beyond 128 nodes (r05 fuzz, tools/experiments/ritz_wg_forest.py):
+  caterpillars of equal stars with 112..192 nodes.  Their Ritz values converge within a few steps,
+  and the eight-wave Lanczos form — which re-orthogonalised a second time only where the first pass
+  had removed more than 99 % of the vector's squared length — lost orthogonality geometrically:
+  half of the graphs of 150+ nodes came back with a non-orthonormal V (r04 and r05 alike).  Beyond
+  128 nodes the second pass now runs whenever the first removed more than half ("twice is enough")."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(N)
+  B = 48
+  ns = rs.randint(N - 16, N + 1, size=B)
+  adj = np.zeros((B, N, N, 1), np.float32)
+  for b in range(B):
+    n, m = int(ns[b]), rs.randint(3, 9)
+    a = np.zeros((n, n), np.float32)
+    for i in range(1, n):
+      a[(i - 1) // m * m if i % m else max(i - m, 0), i] = 1.0
+    adj[b, :n, :n, 0] = np.maximum(a, a.T)
+  nd = _t(ns.astype(np.int32))
+  L = ops.laplacian_l4(_t(adj), nd)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], nd, K)
+  A, Vd, Dd = L[:, :, :, 0].double(), V.double(), D.double()
+  eye = torch.eye(K, device=DEV, dtype=torch.float64)[None]
+  assert (Vd.transpose(1, 2) @ Vd - eye).abs().max().item() < 2e-6
+  assert (A @ Vd - Vd * Dd[:, None, :]).abs().max().item() < 2e-6
+  for b in range(0, B, 9):
+    n = int(ns[b])
+    lam = np.linalg.eigvalsh(A[b, :n, :n].cpu().numpy())
+    want = np.sort(lam[np.argsort(-np.abs(lam), kind='mergesort')][:K])
+    assert np.abs(np.sort(Dd[b].cpu().numpy()) - want).max() < 1e-6

@@ -3,9 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from lanczosnet_amd import ops
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
-for N in (100, 128, 136, 144, 152, 160, 176, 192):
-  rs = np.random.RandomState(N)
-  B = 48
+for N in [int(x) for x in os.environ.get('FOREST_N', '100,128,136,144,152,160,176,192').split(',')]:
+  rs = np.random.RandomState(N + int(os.environ.get('FOREST_SEED', '0')))
+  B = int(os.environ.get('FOREST_B', '48'))
   ns = rs.randint(max(33, N - 16), N + 1, size=B)
   adj = np.zeros((B, N, N, 1), np.float32)
   for b in range(B):
