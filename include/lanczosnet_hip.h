@@ -224,6 +224,13 @@ int lnz_lanczos_ritz_large_sym(const float* A, int64_t stride_b, int64_t stride_
 int64_t lnz_packed_rows_k8_size(int rows, int cols);
 int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, float* Wp,
                      lnz_stream_t stream);
+/* The same stream for the split-precision GEMM1 of the strip kernel (lnz_forward_args.gemm_mode =
+ * 2): same size (lnz_packed_rows_k8_size; cols a multiple of 32) and the same (rt, 16-k step, lane)
+ * indexing, but the two 16-byte slots a lane owns in a 32-k block b hold eight fp16 hi pieces, then
+ * the eight lo pieces (x = hi + lo to 22 bits) of W[32 rt + wj][32 b + 8 kq + 0..7] (lane slot
+ * 64 (kq >> 1) + 32 (kq & 1) + wj) — the B operands of v_mfma_f32_16x16x32_f16. */
+int lnz_pack_rows_k8_split(const float* W, int rows, int cols, int64_t ld, float* Wp,
+                           lnz_stream_t stream);
 /* W [rows, cols] -> fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order:
  *   out[rt][kb][piece][lane][e] (e = 0..7 halves, 16 B per lane) with
  *   x = W[32*rt + (lane&31)][16*kb + 8*(lane>>5) + e], piece 0 = half(x), piece 1 = half(x - piece0);
@@ -320,7 +327,12 @@ typedef struct lnz_forward_args {
    * operand precision, measured 6e-7 end-to-end vs fp64 (fp32 MFMA path: 2e-7).  Needs dhid == 128,
    * filter_kind == 0, K <= 20, din0 <= 128; packs from lnz_pack_rows_f16x2 with the layer-0 input
    * width zero-padded to 128 and 16 KiB of slack behind the last layer; G followed by 64 B of
-   * slack (gains are read as whole dwordx4 groups).  gemm_mode = 0 (default) is the exact fp32 path. */
+   * slack (gains are read as whole dwordx4 groups).  gemm_mode = 0 (default) is the exact fp32 path.
+   * gemm_mode = 2: the same split of GEMM1 on the STRIP plan (inference forward only; needs `strips`
+   * and everything the strip kernel needs: dhid 128, din0 64 or 128, diagonal gains or dense K x K
+   * filters) on v_mfma_f32_16x16x32_f16 — Wp = lnz_pack_rows_k8_split of the same matrices at the
+   * same offsets, the node state lives in LDS as fp16 hi | lo groups; Lp, the Laplacian products,
+   * the eigen-space arithmetic, the lift and the head stay exact fp32 (none of the *16 fields). */
   int32_t gemm_mode;
   const void* Wp16;           /* packed fp16 hi/lo conv weights: layer l at (char*)Wp16 + w16_off[l] */
   int64_t w16_off[16];        /* byte offsets                                                     */

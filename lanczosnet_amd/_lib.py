@@ -76,6 +76,7 @@ SIGNATURES = {
                                        _I, _I, _I, _P, _P, _P, _P]),
     'lnz_packed_rows_k8_size': (C.c_int64, [_I, _I]),
     'lnz_pack_rows_k8': (C.c_int, [_P, _I, _I, _L, _P, _P]),
+    'lnz_pack_rows_k8_split': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_packed_rows_f16x2_bytes': (C.c_int64, [_I, _I]),
     'lnz_pack_rows_f16x2': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_pack_bias_rows': (C.c_int, [_P, _I, _P, _P]),

@@ -1299,7 +1299,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
   LNZ_REQUIRE(a.mask && a.V && (a.Lp || (a.gemm_mode == 1 && a.Lp16)), LNZ_EINVAL,
               "%s: null tensor pointer", who);
   LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "%s: G missing", who);
-  LNZ_REQUIRE(a.gemm_mode == 0 || a.gemm_mode == 1, LNZ_EINVAL, "%s: gemm_mode %d", who,
+  LNZ_REQUIRE(a.gemm_mode >= 0 && a.gemm_mode <= 2, LNZ_EINVAL, "%s: gemm_mode %d", who,
               a.gemm_mode);
   LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL, "%s: filter_kind %d", who,
               a.filter_kind);
@@ -1317,6 +1317,13 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
     if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
+    if (a.gemm_mode == 2) {
+      LNZ_REQUIRE(lnz::strip_forward_eligible(a, 0), LNZ_ENOTSUP,
+                  "%s: gemm_mode 2 (split-precision GEMM1) runs on the strip plan only: strips, hidden "
+                  "width 128, input width 64 or 128, diagonal gains, <= 12 long and <= 32 channels in all",
+                  who);
+      return lnz::launch_strip_forward(a, 0, s);
+    }
     // (the training forward — act_out — has no 32 x 32-tile kernel any more: the switch that
     // selects those for A/B runs applies to inference launches only)
     const bool tiles16 = forward16_enabled() || a.act_out;

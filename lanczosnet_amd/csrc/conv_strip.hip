@@ -43,6 +43,69 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 
+// ---- split-precision node state (HALF, lnz_forward_args.gemm_mode 2): a row of the node-state
+// buffers keeps its P floats of LDS, but a 32-column block (128 B) holds the 32 fp16 hi pieces of
+// its columns, then the 32 lo pieces (x = hi + lo to 22 bits): lane (j, kq) of a wave reads the A
+// operand of v_mfma_f32_16x16x32_f16 for columns 32 b + 8 kq .. + 7 as ONE ds_read_b128 per piece,
+// at the same float offsets 32 b + 4 kq (hi) and + 16 (lo) as an fp32 fragment — the conflict-free
+// pattern of the pitch.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma32h(f32x4 a, f32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                c, 0, 0, 0);
+}
+__device__ __forceinline__ int half_at(int k) { return 64 * (k >> 5) + (k & 31); }  // hi piece; lo: + 32
+template <bool HALF>
+__device__ __forceinline__ void xs_put(float* rowp, int k, float x) {
+  if constexpr (HALF) {
+    _Float16* g = reinterpret_cast<_Float16*>(rowp) + half_at(k);
+    const _Float16 h = (_Float16)x;
+    g[0] = h;
+    g[32] = (_Float16)(x - (float)h);
+  } else {
+    rowp[k] = x;
+  }
+}
+template <bool HALF>
+__device__ __forceinline__ float xs_get(const float* rowp, int k) {
+  if constexpr (HALF) {
+    const _Float16* g = reinterpret_cast<const _Float16*>(rowp) + half_at(k);
+    return (float)g[0] + (float)g[32];
+  } else {
+    return rowp[k];
+  }
+}
+// four consecutive columns 4 c4 .. + 3
+template <bool HALF>
+__device__ __forceinline__ void xs_put4(float* rowp, int c4, float4 v) {
+  if constexpr (HALF) {
+    f16x4 h, l;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (_Float16)x[e];
+      l[e] = (_Float16)(x[e] - (float)h[e]);
+    }
+    _Float16* g = reinterpret_cast<_Float16*>(rowp) + half_at(4 * c4);
+    *reinterpret_cast<f16x4*>(g) = h;
+    *reinterpret_cast<f16x4*>(g + 32) = l;
+  } else {
+    *reinterpret_cast<float4*>(rowp + 4 * c4) = v;
+  }
+}
+template <bool HALF>
+__device__ __forceinline__ f32x4 xs_get4(const float* rowp, int c4) {
+  if constexpr (HALF) {
+    const _Float16* g = reinterpret_cast<const _Float16*>(rowp) + half_at(4 * c4);
+    const f16x4 h = *reinterpret_cast<const f16x4*>(g), l = *reinterpret_cast<const f16x4*>(g + 32);
+    return f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2],
+                 (float)h[3] + (float)l[3]};
+  } else {
+    return *reinterpret_cast<const f32x4*>(rowp + 4 * c4);
+  }
+}
+
 // LDS floats of a strip of S subtiles with nl long channels
 constexpr int strip_lds_floats(int S, int nl) {
   return 2 * S * 16 * P + S * 3 * 16 * VBP + 2 * nl * S * 16 + 3 * S * 16 + 3 * MAXMOL + 8;
@@ -51,13 +114,17 @@ constexpr int strip_lds_floats(int S, int nl) {
 
 // MODE 0 = forward (a.act_out: the training forward's activation store); MODE 1 = the
 // input-gradient pass; FK 0 = diagonal gains, 2 = dense K x K filters; SHORT = short-diffusion
-// channels — all as in conv_forward16.hip.
-template <int S, int MODE, int FK, bool SHORT>
+// channels — all as in conv_forward16.hip.  HALF: GEMM1 in split precision (x_hi w_hi + x_lo w_hi +
+// x_hi w_lo on v_mfma_f32_16x16x32_f16, fp32 accumulate: 3 x 16 cycles per 32-k block and subtile
+// instead of 8 x 32), node state in LDS as fp16 pieces (above), weights from lnz_pack_rows_k8_split;
+// everything behind GEMM1's accumulators is the exact-fp32 code.
+template <int S, int MODE, int FK, bool SHORT, bool HALF>
 __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restrict__ ent, float* lds,
                                               const int tid, const int wave) {
   constexpr int R = 16 * S;
   constexpr bool FWD = MODE == 0;
   constexpr bool DIAG = FK == 0;
+  static_assert(!HALF || FWD, "split precision: inference forward only");
 #ifdef LNZ_STRIP_PHASES  // per-wave clock64 stamps of the phases (tools/phase_probe16.py)
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_all = clock64(), _t0 = t_all;
 #define LNZ_PH(i) { const long long _t1 = clock64(); ph[i] += _t1 - _t0; _t0 = _t1; }
@@ -129,7 +196,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
           }
         }
       }
-      *reinterpret_cast<float4*>(&Xs[row * P + 4 * c4]) = v;
+      xs_put4<HALF>(&Xs[row * P], c4, v);
     }
   }
   // ---- Ritz blocks: Vb[Jn][d][nu][ro] = V[molecule][node][slot] when node row 16 Jn + nu and
@@ -278,27 +345,64 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
               if (J < 0 || J >= S) continue;
               const int nu = 4 * kq + r;
               Y[I] = mfma16(Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j],
-                            Xs[cur * R * P + (16 * J + nu) * P + 16 * wave + j], Y[I]);
+                            xs_get<HALF>(&Xs[cur * R * P + (16 * J + nu) * P], 16 * wave + j), Y[I]);
             }
 #pragma unroll
         for (int I = 0; I < S; ++I)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            Xs[nxt * R * P + (16 * I + 4 * kq + r) * P + 16 * wave + j] = Y[I][r];
+            xs_put<HALF>(&Xs[nxt * R * P + (16 * I + 4 * kq + r) * P], 16 * wave + j, Y[I][r]);
       }
       __syncthreads();
     }
 
     LNZ_PH(1)  // layer head: ring prime, gains loads, first-layer projection
     // ---------------- GEMM1 of one channel: Z[I] = A rows (X or Y) x W_c^T ----------------
-    f32x4 Z[S], acur[S];
+    f32x4 Z[S], acur[S], alow[HALF ? S : 1];
     auto load_first = [&](lds_cptr x0) {
 #pragma unroll
-      for (int I = 0; I < S; ++I) acur[I] = lds4(x0 + 16 * I * P);
+      for (int I = 0; I < S; ++I) {
+        acur[I] = lds4(x0 + 16 * I * P);
+        if constexpr (HALF) alow[I] = lds4(x0 + 16 * I * P + 16);
+      }
     };
     // four steps; `wrap`: the A prefetch of the last one fetches k = 0 again — the first fragments
     // of the NEXT channel (channels of a block read the same rows)
     auto steps4 = [&](lds_cptr xb, lds_cptr x0, auto wrap) {
+      if constexpr (HALF) {
+        // the same 64 columns as two 32-k blocks: ring slots 2 u (hi pieces of the block's weights)
+        // and 2 u + 1 (lo); a slot is reloaded right behind the last MFMA that reads it — one block
+        // (3 S MFMAs of this wave and as many of its partner) of prefetch distance
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (u == 0) ring[3] = wp[3 * 128];
+          f32x4 anext[S], lnext[S];
+          const lds_cptr xn = (decltype(wrap)::value && u == 1) ? x0 : xb + 32 * (u + 1);
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            anext[I] = lds4(xn + 16 * I * P);
+            lnext[I] = lds4(xn + 16 * I * P + 16);
+          }
+          const f32x4 bh = __builtin_bit_cast(f32x4, ring[2 * u]);
+          const f32x4 bl = __builtin_bit_cast(f32x4, ring[2 * u + 1]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma32h(acur[I], bl, Z[I]);
+          if (u == 0) ring[1] = wp[5 * 128];
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma32h(alow[I], bh, Z[I]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma32h(acur[I], bh, Z[I]);
+          if (u == 0) ring[0] = wp[4 * 128];
+          else ring[2] = wp[6 * 128];
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            acur[I] = anext[I];
+            alow[I] = lnext[I];
+          }
+        }
+        wp += 4 * 128;
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         ring[(u + 3) & 3] = wp[(u + 3) * 128];
@@ -512,7 +616,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         }
         out[I] = v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[nxt * R * P + (row0 + r) * P + col] = v[r];
+        for (int r = 0; r < 4; ++r) xs_put<HALF>(&Xs[nxt * R * P + (row0 + r) * P], col, v[r]);
       }
       if (nl > 0 && more) {
         f32x4 Y[S];
@@ -531,7 +635,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
 #pragma unroll
         for (int I = 0; I < S; ++I)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Xs[cur * R * P + (16 * I + 4 * kq + r) * P + col] = Y[I][r];
+          for (int r = 0; r < 4; ++r) xs_put<HALF>(&Xs[cur * R * P + (16 * I + 4 * kq + r) * P], col, Y[I][r]);
       }
       if (MODE == 1 && la > 0 && (a.dy_compact || a.dbias_part)) {
         // What the weight / bias gradients of conv layer la - 1 need: dY_{la-1} in the COMPACT row
@@ -576,7 +680,8 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       const int row = idx >> 7, col = idx & 127;
       const int own = rowinfo[row];
       if (own >= 0)
-        a.state_out[((int64_t)mid[own] * 32 + (row - mstart[own])) * 128 + col] = Xs[cur * R * P + row * P + col];
+        a.state_out[((int64_t)mid[own] * 32 + (row - mstart[own])) * 128 + col] =
+            xs_get<HALF>(&Xs[cur * R * P + row * P], col);
     }
   }
 
@@ -591,9 +696,10 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     f32x4 acc[2] = {splat4(a.bias_head[j]), splat4(a.bias_head[16 + j])};
     const float4* __restrict__ wh = reinterpret_cast<const float4*>(a.Wp_head) + 64 * (kq >> 1) + 32 * (kq & 1) + j;
     const lds_cptr xr = xlane + cur * R * P + 16 * I * P;
+    const float* xrow = Xs + cur * R * P + (16 * I + j) * P;
 #pragma unroll 2
     for (int q = 0; q < 8; ++q) {
-      const f32x4 av = lds4(xr + 16 * q);
+      const f32x4 av = HALF ? xs_get4<HALF>(xrow, 4 * q + kq) : lds4(xr + 16 * q);
       const float4 b0 = wh[q * 128], b1 = wh[q * 128 + 16];
       acc[0] = mfma16(av[0], b0.x, acc[0]);
       acc[1] = mfma16(av[0], b1.x, acc[1]);
@@ -859,7 +965,7 @@ __global__ __launch_bounds__(512) void lanczosnet_strip_gain_grad_kernel(const l
 }
 
 // One workgroup = 8 waves on one strip of the plan.
-template <int MODE, int FK, bool SHORT>
+template <int MODE, int FK, bool SHORT, bool HALF = false>
 __global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) float lds_strip[];
@@ -869,12 +975,12 @@ __global__ __launch_bounds__(512) void lanczosnet_strip_kernel(const lnz_forward
   const int32_t* ent = a.strips + (int64_t)blockIdx.x * LNZ_STRIP_INTS;
   const int sub = __builtin_amdgcn_readfirstlane(ent[1]);
   switch (sub) {
-    case 1: strip_forward<1, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
-    case 2: strip_forward<2, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
-    case 3: strip_forward<3, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
-    case 4: strip_forward<4, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
-    case 5: strip_forward<5, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
-    case 6: strip_forward<6, MODE, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 1: strip_forward<1, MODE, FK, SHORT, HALF>(a, ent, lds_strip, tid, wave); break;
+    case 2: strip_forward<2, MODE, FK, SHORT, HALF>(a, ent, lds_strip, tid, wave); break;
+    case 3: strip_forward<3, MODE, FK, SHORT, HALF>(a, ent, lds_strip, tid, wave); break;
+    case 4: strip_forward<4, MODE, FK, SHORT, HALF>(a, ent, lds_strip, tid, wave); break;
+    case 5: strip_forward<5, MODE, FK, SHORT, HALF>(a, ent, lds_strip, tid, wave); break;
+    case 6: strip_forward<6, MODE, FK, SHORT, HALF>(a, ent, lds_strip, tid, wave); break;
     default: break;
   }
 }
@@ -888,7 +994,9 @@ namespace lnz {
 bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   if (mode != 0 && mode != 1) return false;
   if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
-  if (a.gemm_mode != 0 || (a.filter_kind != 0 && a.filter_kind != 1)) return false;
+  if (a.filter_kind != 0 && a.filter_kind != 1) return false;
+  // gemm_mode 2 (split-precision GEMM1): the inference forward with diagonal gains
+  if (a.gemm_mode == 2 ? (mode != 0 || a.act_out || a.filter_kind != 0) : a.gemm_mode != 0) return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
   if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
   // dbias_part is sized by the TILE plan ([2 * plan_wg_cap] entries) and indexed by strip here: a
@@ -928,6 +1036,9 @@ int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
       (const void*)lanczosnet_strip_kernel<0, 2, true>,  (const void*)lanczosnet_strip_kernel<1, 2, true>};
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
+  if (a.gemm_mode == 2)
+    fn = a.n_short > 0 ? (const void*)lanczosnet_strip_kernel<0, 0, true, true>
+                       : (const void*)lanczosnet_strip_kernel<0, 0, false, true>;
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;

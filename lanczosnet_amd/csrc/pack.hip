@@ -57,6 +57,52 @@ extern "C" int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, 
   return lnz::check_launch("lnz_pack_rows_k8");
 }
 
+// The same weight stream for the split-precision GEMM1 of the strip kernel (gemm_mode 2,
+// conv_strip.hip): same size and the same (rt, 16-k step, lane slot) indexing as lnz_pack_rows_k8 —
+// the kernel's four-slot ring walks it unchanged —, but the two slots of a 32-k block hold that
+// block's fp16 hi pieces, then its lo pieces: slot (rt, 2 b + piece), lane slot t = 64 (kq >> 1) +
+// 32 (kq & 1) + wj  ->  eight halves of W[32 rt + wj][32 b + 8 kq + e], e = 0..7: the B operand of
+// v_mfma_f32_16x16x32_f16 for lane (j, kq).
+__global__ void pack_rows_k8_split_kernel(const float* __restrict__ W, int rows, int cols, int64_t ld,
+                                          int RT, int NB, uint4* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, b, piece, slot)
+  int64_t total = (int64_t)RT * NB * 256;
+  if (idx >= total) return;
+  const int t = (int)(idx & 127), piece = (int)((idx >> 7) & 1);
+  const int b = (int)((idx >> 8) % NB), rt = (int)((idx >> 8) / NB);
+  const int kq = 2 * (t >> 6) + ((t >> 5) & 1);
+  const int row = 32 * rt + (t & 31);
+  unsigned w[4];
+#pragma unroll
+  for (int e2 = 0; e2 < 4; ++e2) {
+    unsigned short h[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = 2 * e2 + u;
+      const int col = 32 * b + 8 * kq + e;
+      const float x = (row < rows && col < cols) ? W[(int64_t)row * ld + col] : 0.0f;
+      const _Float16 xh = (_Float16)x;
+      const _Float16 v = piece ? (_Float16)(x - (float)xh) : xh;
+      h[u] = __builtin_bit_cast(unsigned short, v);
+    }
+    w[e2] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+  }
+  out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+extern "C" int lnz_pack_rows_k8_split(const float* W, int rows, int cols, int64_t ld, float* Wp,
+                                      lnz_stream_t stream) {
+  LNZ_REQUIRE(W && Wp && rows > 0 && cols > 0 && cols % 32 == 0 && ld >= cols, LNZ_EINVAL,
+              "lnz_pack_rows_k8_split: bad arguments (rows=%d cols=%d ld=%lld; cols must be a "
+              "multiple of 32)", rows, cols, (long long)ld);
+  int RT = (rows + 31) / 32, NB = cols / 32;
+  int64_t total = (int64_t)RT * NB * 256;
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_rows_k8_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W,
+                     rows, cols, ld, RT, NB, (uint4*)Wp);
+  return lnz::check_launch("lnz_pack_rows_k8_split");
+}
+
 // fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order (see header)
 __global__ void pack_rows_f16x2_kernel(const float* __restrict__ W, int rows, int cols, int64_t ld,
                                        int RT, int KB, uint4* __restrict__ out) {

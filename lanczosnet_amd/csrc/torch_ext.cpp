@@ -299,15 +299,17 @@ Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
 }
 
 // ---- R7b + R9 + R10: the fused forward (exact-fp32 kernel) -------------------------------------
-// dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind]
+// dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind (, gemm_mode: 0, or 2 = split-
+// precision GEMM1 on strips with Wp from lnz_pack_rows_k8_split)]
 Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, const Tensor& Lp,
                const c10::optional<Tensor>& ident, const Tensor& V, const c10::optional<Tensor>& G,
                const Tensor& mask, const Tensor& Wp, const Tensor& bias, at::IntArrayRef w_off,
                at::IntArrayRef b_off, const Tensor& Wp_head, const Tensor& bias_head,
                const c10::optional<Tensor>& plan, int64_t plan_cap, at::IntArrayRef dims,
                at::IntArrayRef short_dist, const c10::optional<Tensor>& strips, int64_t strip_cap) {
-  TORCH_CHECK(dims.size() == 7, "lanczosnet::forward: dims = [num_layer, din0, dhid, dout, n_long, "
-                                "n_edge, filter_kind]");
+  TORCH_CHECK(dims.size() == 7 || dims.size() == 8,
+              "lanczosnet::forward: dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind(, gemm_mode)]");
+  TORCH_CHECK(dims.size() == 7 || dims[7] == 0 || dims[7] == 2, "lanczosnet::forward: gemm_mode 0 or 2");
   need(Lp, at::kFloat, "Lp");
   need(V, at::kFloat, "V");
   need(mask, at::kByte, "mask");
@@ -333,6 +335,7 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
   a.num_layer = dims[0], a.din0 = dims[1], a.dhid = dims[2], a.dout = dims[3];
   a.n_short = short_dist.size(), a.n_long = dims[4], a.n_edge = dims[5];
   a.filter_kind = dims[6];
+  a.gemm_mode = dims.size() > 7 ? (int32_t)dims[7] : 0;
   for (size_t i = 0; i < short_dist.size(); ++i) a.short_dist[i] = (int32_t)short_dist[i];
   if (node_feat.scalar_type() == at::kLong) {
     need(node_feat, at::kLong, "node_feat");

@@ -40,6 +40,9 @@ class _LanczosNetBase(nn.Module):
     # 'fp32' (default): exact fp32 MFMA.  'f16x3': opt-in split-precision GEMM1 (x_hi w_hi + x_hi w_lo
     # + x_lo w_hi on fp16 MFMA, fp32 accumulate; 6e-7 vs fp64, parity bar 1e-5) — see DESIGN.md §4.7
     gemm_mode = os.environ.get('LANCZOSNET_GEMM', 'fp32')
+    # 'f16x3': 'strips' = split-precision GEMM1 inside the strip kernel (everything else exact fp32);
+    # 'tiles' = the older one-molecule-per-tile kernel (GEMM2 split as well), kept for A/B runs
+    split_kernel = os.environ.get('LANCZOSNET_F16X3_KERNEL', 'strips')
     # graphs beyond 32 nodes, fp32-grade mode of the streamed kernels: 3 = three bf16 pieces per
     # operand (six products), 2 = two fp16 pieces (three products, 2/3 of the operand bytes)
     large_split_planes = int(os.environ.get('LANCZOSNET_LARGE_PLANES', '3'))
@@ -195,7 +198,7 @@ class _LanczosNetBase(nn.Module):
 
     # -- packed-parameter plan ------------------------------------------------------------
     def _param_signature(self):
-        return (self.gemm_mode,) + tuple((p.data_ptr(), p._version, str(p.device))
+        return (self.gemm_mode, self.split_kernel) + tuple((p.data_ptr(), p._version, str(p.device))
                                          for p in self.parameters())
 
     def _fused_supported(self):
@@ -237,13 +240,19 @@ class _LanczosNetBase(nn.Module):
         if din0p != din0:
             w = torch.nn.functional.pad(w.view(dhid, n_chan, din0), (0, din0p - din0))
             w = w.reshape(dhid, n_chan * din0p)
-        wp = ops.pack_rows_k8(w)
+        # gemm_mode 'f16x3' on the strip plan (csrc/conv_strip.hip, HALF): the same stream at the same
+        # offsets, fp16 hi / lo pieces of the weights; every other operand is the exact kernel's
+        split_strips = (self.gemm_mode == 'f16x3' and self.split_kernel == 'strips' and dhid == 128
+                        and self.filter_kind == 0 and self._tiles16_channels_ok()
+                        and self.output_dim <= 31)
+        pack_conv = ops.pack_rows_k8_split if split_strips else ops.pack_rows_k8
+        wp = pack_conv(w)
         packs.append(wp)
         w_off.append(0)
         woff = wp.numel()
         if self.num_layer > 1:
             stack = torch.cat([self._mix_weight(t) for t in range(1, self.num_layer)], dim=0)
-            wps = ops.pack_rows_k8(stack)
+            wps = pack_conv(stack)
             packs.append(wps)
             per = wps.numel() // (self.num_layer - 1)
             for t in range(1, self.num_layer):
@@ -275,7 +284,8 @@ class _LanczosNetBase(nn.Module):
                     bias_head=bias_head,
                     embedding=emb)
         plan['Wp16'] = None
-        if self.gemm_mode == 'f16x3':
+        plan['gemm_mode'] = 2 if split_strips else 0
+        if self.gemm_mode == 'f16x3' and not split_strips:
             if not (self.filter_kind == 0 and dhid == 128 and self.num_eig_vec <= 20):
                 raise NotImplementedError("gemm_mode='f16x3' is built for LanczosNet with hidden "
                                           "width 128 and num_eig_vec <= 20")
@@ -297,7 +307,7 @@ class _LanczosNetBase(nn.Module):
             plan['din0'] = din0  # this kernel pads columns itself
             if emb is not None:
                 plan['embedding'] = self.embedding.weight.detach().float().contiguous()
-        elif self.gemm_mode not in ('fp32', 'bf16'):
+        elif self.gemm_mode not in ('fp32', 'bf16', 'f16x3'):
             raise ValueError("gemm_mode must be 'fp32', 'f16x3' (N <= 32) or 'bf16' (N > 32)")
         if self._has_mlp() and self.filter_kind == 0:
             plan['mlp_pack'] = ops.pack_spectral_mlp_layers(

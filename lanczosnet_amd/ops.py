@@ -373,6 +373,19 @@ def pack_rows_k8(W):
   return out
 
 
+def pack_rows_k8_split(W):
+  """[rows, cols] (cols a multiple of 32) -> the weight stream of the split-precision strip kernel
+  (gemm_mode 2): fp16 hi / lo pieces at pack_rows_k8's size and offsets (include/lanczosnet_hip.h)."""
+  _need_cuda(W)
+  W = _f32c(W)
+  rows, cols = W.shape
+  out = torch.empty((_abi().packed_rows_k8_size(rows, cols),), dtype=torch.float32,
+                    device=W.device)
+  with torch.cuda.device(W.device):
+    _abi().pack_rows_k8_split(W, rows, cols, cols, out)
+  return out
+
+
 def pack_rows_f16x2(W):
   """[rows, cols] -> fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order (uint8 buffer)."""
   _need_cuda(W)
@@ -719,7 +732,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   ops_[_IN['G']] = G
   ops_[_IN['Wp']], ops_[_IN['bias']] = plan['Wp'], plan['bias']
   ops_[_IN['Wp_head']], ops_[_IN['bias_head']] = plan['Wp_head'], plan['bias_head']
-  gemm_mode = 1 if plan.get('Wp16') is not None else 0
+  gemm_mode = 1 if plan.get('Wp16') is not None else int(plan.get('gemm_mode', 0))
   dims[_DIM['gemm_mode']] = gemm_mode
   assert (gemm_mode == 1) == (Lp.dtype == torch.uint8), 'Lp pack does not match gemm_mode'
   w16_off = []
@@ -735,6 +748,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     tiles, cap = plan_tiles(mask_u8, allow_pairs=(tiling == 'auto' and pairing_supported(plan)))
   if tiling != 'none':
     _set_plan(ops_, dims, tiles, cap)
+  if gemm_mode == 2 and ops_[_IN['strips']] is None:   # this mode exists on the strip plan only
+    strips = plan_strips(mask_u8)
+    scap = (strips.numel() - 1) // STRIP_INTS
+    ops_[_IN['strips']], ops_[_IN['n_strips']] = strips, strips[scap * STRIP_INTS:]
+    dims[_DIM['strip_cap']] = scap
   score = torch.empty((B, plan['dout']), dtype=torch.float32, device=V.device)
   if act_out is not None:
     assert tuple(act_out.shape) == (plan['num_layer'], B, 32, plan['dhid']) and \
@@ -839,11 +857,14 @@ def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
     consts = plan['_ext_consts'] = (
         [int(x) for x in plan['w_off'][:plan['num_layer']]],
         [int(x) for x in plan['b_off'][:plan['num_layer']]],
-        [plan['num_layer'], plan['din0'], plan['dhid'], plan['dout'], plan['n_long'], plan['n_edge'], fk],
+        [plan['num_layer'], plan['din0'], plan['dhid'], plan['dout'], plan['n_long'], plan['n_edge'], fk,
+         int(plan.get('gemm_mode', 0))],
         [int(p) for p in plan['short']])
   w_off, b_off, dims, short = consts
   ident = getattr(Lp, 'ident', None) if use_ident else None
   strips = getattr(tiles, 'strips', None)
+  if strips is None and plan.get('gemm_mode', 0) == 2:
+    strips = plan_strips(mask_u8)   # the split-precision GEMM1 exists on the strip plan only
   scap = (strips.numel() - 1) // STRIP_INTS if strips is not None else 0
   return _ext().forward(nf, emb, Lp, ident, _f32c(V), G, mask_u8, plan['Wp'], plan['bias'], w_off,
                         b_off, plan['Wp_head'], plan['bias_head'], tiles, cap, dims, short,

@@ -1,0 +1,51 @@
+"""gemm_mode 'f16x3' on the strip plan against the exact kernel and the older tile kernel:
+deviation per molecule and forward launch time at the bench batch."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import oracle
+from lanczosnet_amd import ops, model
+from lanczosnet_amd.utils.arg_helper import make_model_config
+from lanczosnet_amd.synthetic import draw_batch
+
+DEV = 'cuda:0'
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+cfg = dict(oracle.DEFAULT_QM8_CFG)
+P = oracle.make_lanczosnet_params(cfg, 5)
+net = model.LanczosNet(make_model_config(cfg)).eval()
+net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+net = net.to(DEV)
+B = int(os.environ.get('B', '1024'))
+batch = draw_batch(B, seed=0)
+n = t(batch['n_nodes'])
+L = ops.laplacian_l4(t(batch['adjs']), n)
+D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+nf, mask = t(batch['node_feat']), t(batch['node_mask'])
+mask_u8 = mask.to(torch.uint8).contiguous()
+res = {}
+for name, gm, sk in (('fp32', 'fp32', 'strips'), ('split strips', 'f16x3', 'strips'), ('split tiles', 'f16x3', 'tiles')):
+  net.gemm_mode, net.split_kernel = gm, sk
+  plan = net._plan()
+  Lp = ops.pack_laplacian_for(plan, L)
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  tiles = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
+  with torch.no_grad():
+    for _ in range(3):
+      sc = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, tiling=tiles)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+      sc = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, tiling=tiles)
+    e1.record()
+    torch.cuda.synchronize()
+    sc2, st = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, return_state=True, tiling=tiles)
+  assert torch.equal(sc, sc2)
+  res[name] = (sc.double().cpu().numpy(), st.double().cpu().numpy(), e0.elapsed_time(e1) / 20)
+ref, rst, _ = res['fp32']
+for name, (sc, st, ms) in res.items():
+  dev = np.abs(sc - ref).max() / np.abs(ref).max()
+  per = (np.abs(sc - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+  real = batch['node_mask'].astype(bool)
+  sdev = np.abs(st[:, :real.shape[1]][real] - rst[:, :real.shape[1]][real]).max() / np.abs(rst).max()
+  print('%-13s forward %.4f ms  dev vs fp32 %.2e (per molecule %.2e)  state %.2e  finite %s'
+        % (name, ms, dev, per, sdev, np.isfinite(sc).all()))
