@@ -329,10 +329,13 @@ typedef struct lnz_forward_args {
    * width zero-padded to 128 and 16 KiB of slack behind the last layer; G followed by 64 B of
    * slack (gains are read as whole dwordx4 groups).  gemm_mode = 0 (default) is the exact fp32 path.
    * gemm_mode = 2: the same split of GEMM1 on the STRIP plan (inference forward only; needs `strips`
-   * and everything the strip kernel needs: dhid 128, din0 64 or 128, diagonal gains or dense K x K
-   * filters) on v_mfma_f32_16x16x32_f16 — Wp = lnz_pack_rows_k8_split of the same matrices at the
-   * same offsets, the node state lives in LDS as fp16 hi | lo groups; Lp, the Laplacian products,
-   * the eigen-space arithmetic, the lift and the head stay exact fp32 (none of the *16 fields). */
+   * and dhid 128, din0 128 — zero-pad narrower inputs and the layer-0 weight columns —, diagonal
+   * gains, no short-diffusion channels) on v_mfma_f32_16x16x32_f16: Wp = lnz_pack_rows_k8_split of the same matrices at the same
+   * offsets, followed by 32 KiB of slack (the weight ring over-reads 16 KiB); the node state lives in
+   * LDS as fp16 hi | lo blocks; the products with the Laplacian blocks and the Ritz blocks
+   * (projection, lift) run in the same three-product split, their operands split in the kernel
+   * (Lp and V are the exact kernel's); gains, biases, activations and the head are exact fp32.  None
+   * of the *16 fields below is used. */
   int32_t gemm_mode;
   const void* Wp16;           /* packed fp16 hi/lo conv weights: layer l at (char*)Wp16 + w16_off[l] */
   int64_t w16_off[16];        /* byte offsets                                                     */

@@ -1320,7 +1320,8 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
     if (a.gemm_mode == 2) {
       LNZ_REQUIRE(lnz::strip_forward_eligible(a, 0), LNZ_ENOTSUP,
                   "%s: gemm_mode 2 (split-precision GEMM1) runs on the strip plan only: strips, hidden "
-                  "width 128, input width 64 or 128, diagonal gains, <= 12 long and <= 32 channels in all",
+                  "width 128, input width 128, diagonal gains, no short-diffusion channels, <= 12 long and <= 32 "
+                  "channels in all",
                   who);
       return lnz::launch_strip_forward(a, 0, s);
     }

@@ -55,6 +55,18 @@ __device__ __forceinline__ f32x4 mfma32h(f32x4 a, f32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
                                                 c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// four values -> elements [4 q, 4 q + 4) of an operand's hi and lo pieces
+__device__ __forceinline__ void split_into(const f32x4 v, const int q, f16x8& h, f16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 x = (_Float16)v[e];
+    h[4 * q + e] = x;
+    l[4 * q + e] = (_Float16)(v[e] - (float)x);
+  }
+}
 __device__ __forceinline__ int half_at(int k) { return 64 * (k >> 5) + (k & 31); }  // hi piece; lo: + 32
 template <bool HALF>
 __device__ __forceinline__ void xs_put(float* rowp, int k, float x) {
@@ -107,8 +119,9 @@ __device__ __forceinline__ f32x4 xs_get4(const float* rowp, int c4) {
 }
 
 // LDS floats of a strip of S subtiles with nl long channels
-constexpr int strip_lds_floats(int S, int nl) {
-  return 2 * S * 16 * P + S * 3 * 16 * VBP + 2 * nl * S * 16 + 3 * S * 16 + 3 * MAXMOL + 8;
+constexpr int VH = 512;    // HALF: floats of a Ritz block's two split-precision operand fragments
+constexpr int strip_lds_floats(int S, int nl, bool half = false) {
+  return 2 * S * 16 * P + S * 3 * (half ? VH : 16 * VBP) + 2 * nl * S * 16 + 3 * S * 16 + 3 * MAXMOL + 8;
 }
 
 
@@ -124,7 +137,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   constexpr int R = 16 * S;
   constexpr bool FWD = MODE == 0;
   constexpr bool DIAG = FK == 0;
-  static_assert(!HALF || FWD, "split precision: inference forward only");
+  static_assert(!HALF || (FWD && DIAG && !SHORT), "split precision: inference forward, diagonal gains, no short channels");
 #ifdef LNZ_STRIP_PHASES  // per-wave clock64 stamps of the phases (tools/phase_probe16.py)
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_all = clock64(), _t0 = t_all;
 #define LNZ_PH(i) { const long long _t1 = clock64(); ph[i] += _t1 - _t0; _t0 = _t1; }
@@ -138,7 +151,11 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   const int C = ns + nl + ne;
   float* Xs = lds;                                   // [2][R][P]
   float* Vb = Xs + 2 * R * P;                        // [S node subtile][3 = slot subtile - node subtile + 1][16 node][VBP]
-  float* Gs = Vb + S * 3 * 16 * VBP;                 // [2][nl][R]
+  // HALF: Vb holds the A operands of the split-precision lift and projection instead — per block
+  // (I, d), J = I + d - 1, and lane (j, kq) 16 bytes (4 hi | 4 lo pieces) of V[node 16 I + j][slot
+  // 16 J + 4 kq + 0..3] (lift, first S * 3 * 64 entries) and of V[node 16 J + 4 kq + 0..3][slot 16 I
+  // + j] (projection onto slot subtile I)
+  float* Gs = Vb + S * 3 * (HALF ? VH : 16 * VBP);   // [2][nl][R]
   int* rowinfo = reinterpret_cast<int*>(Gs + 2 * nl * R);  // [R] molecule of the strip owning the row, or -1
   int* rowok = rowinfo + R;                          // [R] the row is a real (masked-in) node
   int* idI = rowok + R;                              // [S] identity-channel bits common to a subtile's molecules (+ pad to R)
@@ -202,6 +219,33 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   // ---- Ritz blocks: Vb[Jn][d][nu][ro] = V[molecule][node][slot] when node row 16 Jn + nu and
   //      slot row 16 (Jn + d - 1) + ro belong to the same molecule (slot k of a molecule rides on
   //      its k-th row), zero elsewhere
+  if constexpr (HALF) {
+    for (int idx = tid; idx < 2 * S * 3 * 64; idx += 512) {
+      const int proj = idx >= S * 3 * 64 ? 1 : 0;
+      const int i0 = idx - proj * S * 3 * 64;
+      const int I = i0 / 192, rem = i0 - I * 192;
+      const int d = rem >> 6, jj = rem & 15, kk = (rem >> 4) & 3;
+      const int J = I + d - 1;
+      f32x4 v = splat4(0.f);
+      if (J >= 0 && J < S) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nrow = proj ? 16 * J + 4 * kk + r : 16 * I + jj;
+          const int srow = proj ? 16 * I + jj : 16 * J + 4 * kk + r;
+          const int own = rowinfo[nrow];
+          if (own >= 0 && rowinfo[srow] == own) {
+            const int lnode = nrow - mstart[own], k = srow - mstart[own];
+            if (lnode < N && k < K) v[r] = finite_or_zero(a.V[((int64_t)mid[own] * N + lnode) * K + k]);
+          }
+        }
+      }
+      f16x8 h = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+      split_into(v, 0, h, l);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[4 + e] = l[e];
+      *reinterpret_cast<f16x8*>(Vb + 4 * idx) = h;
+    }
+  } else {
   for (int idx = tid; idx < S * 3 * 256; idx += 512) {
     const int Jn = idx / 768, rem = idx - Jn * 768;
     const int d = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
@@ -215,6 +259,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       }
     }
     Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = v;
+  }
   }
   // ---- spectral gains by slot row: Gs[l & 1][s][rho]; loads of layer l + 1 are issued at the
   //      start of layer l and go to LDS in front of the layer's last barrier
@@ -314,10 +359,13 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     // weight stream of this wave: contiguous over the layer's channels, 128 float4 per 16-k step,
     // 4-slot register ring (prefetch distance 3 steps = 12 S MFMAs)
     const float4* __restrict__ wp = Wl + (int64_t)rt * Gtot * 64 + wlane;
-    float4 ring[4];
+    // (HALF: every layer is 128 wide = four 32-k blocks per channel = eight slots; a slot is reloaded
+    // with the NEXT channel's block right behind its last use — a whole channel of prefetch distance:
+    // with GEMM1 at a fifth of its fp32 time, one block of distance left the loads exposed)
+    float4 ring[HALF ? 8 : 4];
     if (active) {
 #pragma unroll
-      for (int s3 = 0; s3 < 3; ++s3) ring[s3] = wp[s3 * 128];
+      for (int s3 = 0; s3 < (HALF ? 8 : 3); ++s3) ring[s3] = wp[s3 * 128];
     }
     // (behind the ring prime: vector loads return in order, the first steps must not wait for G)
     if (DIAG && nl > 0 && more) load_gains(lg);
@@ -344,8 +392,14 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
               const int J = I + d - 1;
               if (J < 0 || J >= S) continue;
               const int nu = 4 * kq + r;
-              Y[I] = mfma16(Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j],
-                            xs_get<HALF>(&Xs[cur * R * P + (16 * J + nu) * P], 16 * wave + j), Y[I]);
+              float vt;
+              if constexpr (HALF) {  // (once per launch: the fp32 product on the rebuilt operands)
+                const _Float16* f = reinterpret_cast<const _Float16*>(Vb + 4 * ((S * 3 + I * 3 + d) * 64 + lane));
+                vt = (float)f[r] + (float)f[4 + r];
+              } else {
+                vt = Vb[((J * 3 + (2 - d)) * 16 + nu) * VBP + j];
+              }
+              Y[I] = mfma16(vt, xs_get<HALF>(&Xs[cur * R * P + (16 * J + nu) * P], 16 * wave + j), Y[I]);
             }
 #pragma unroll
         for (int I = 0; I < S; ++I)
@@ -369,40 +423,6 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     // four steps; `wrap`: the A prefetch of the last one fetches k = 0 again — the first fragments
     // of the NEXT channel (channels of a block read the same rows)
     auto steps4 = [&](lds_cptr xb, lds_cptr x0, auto wrap) {
-      if constexpr (HALF) {
-        // the same 64 columns as two 32-k blocks: ring slots 2 u (hi pieces of the block's weights)
-        // and 2 u + 1 (lo); a slot is reloaded right behind the last MFMA that reads it — one block
-        // (3 S MFMAs of this wave and as many of its partner) of prefetch distance
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (u == 0) ring[3] = wp[3 * 128];
-          f32x4 anext[S], lnext[S];
-          const lds_cptr xn = (decltype(wrap)::value && u == 1) ? x0 : xb + 32 * (u + 1);
-#pragma unroll
-          for (int I = 0; I < S; ++I) {
-            anext[I] = lds4(xn + 16 * I * P);
-            lnext[I] = lds4(xn + 16 * I * P + 16);
-          }
-          const f32x4 bh = __builtin_bit_cast(f32x4, ring[2 * u]);
-          const f32x4 bl = __builtin_bit_cast(f32x4, ring[2 * u + 1]);
-#pragma unroll
-          for (int I = 0; I < S; ++I) Z[I] = mfma32h(acur[I], bl, Z[I]);
-          if (u == 0) ring[1] = wp[5 * 128];
-#pragma unroll
-          for (int I = 0; I < S; ++I) Z[I] = mfma32h(alow[I], bh, Z[I]);
-#pragma unroll
-          for (int I = 0; I < S; ++I) Z[I] = mfma32h(acur[I], bh, Z[I]);
-          if (u == 0) ring[0] = wp[4 * 128];
-          else ring[2] = wp[6 * 128];
-#pragma unroll
-          for (int I = 0; I < S; ++I) {
-            acur[I] = anext[I];
-            alow[I] = lnext[I];
-          }
-        }
-        wp += 4 * 128;
-        return;
-      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         ring[(u + 3) & 3] = wp[(u + 3) * 128];
@@ -433,6 +453,8 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       wp += 4 * 128;
     };
     auto gemm1 = [&](lds_cptr x0, auto&& before_last) {
+      // (HALF: a channel's GEMM1 is 12 S short MFMAs — the operator fragments are asked for at its
+      // start, not under its last four steps)
       // the two waves of a SIMD (w, w + 4) take turns at the head of the matrix pipe.  (A feedback
       // version — each wave publishes the channels it has started in LDS and the one behind its
       // partner raises its priority — evens the two out, 548 | 596 k cycles in the long block
@@ -442,6 +464,40 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       ++chan_total;
 #pragma unroll
       for (int I = 0; I < S; ++I) Z[I] = splat4(0.f);
+      if constexpr (HALF) {
+        before_last();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {  // 32-k block b: ring slots 2 b (hi pieces of the weights), 2 b + 1 (lo)
+          f32x4 anext[S], lnext[S];
+          const lds_cptr xn = b == 3 ? x0 : x0 + 32 * (b + 1);  // (wraps to the next channel's first block)
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            anext[I] = lds4(xn + 16 * I * P);
+            lnext[I] = lds4(xn + 16 * I * P + 16);
+          }
+          const f32x4 bh = __builtin_bit_cast(f32x4, ring[2 * b]);
+          const f32x4 bl = __builtin_bit_cast(f32x4, ring[2 * b + 1]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma32h(acur[I], bl, Z[I]);
+          ring[2 * b + 1] = wp[(8 + 2 * b + 1) * 128];
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma32h(alow[I], bh, Z[I]);
+#pragma unroll
+          for (int I = 0; I < S; ++I) Z[I] = mfma32h(acur[I], bh, Z[I]);
+          ring[2 * b] = wp[(8 + 2 * b) * 128];
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            acur[I] = anext[I];
+            alow[I] = lnext[I];
+          }
+          // (Issue order left to the compiler: it reads a block's fragments in one burst in front of
+          // the block and sinks a channel's eight reloads behind its last MFMA.  Forcing one fragment
+          // read behind each MFMA and each reload behind its slot's last sweep with
+          // sched_group_barrier costs 48 spilled registers and measures the same: 0.219 | 0.222 ms.)
+        }
+        wp += 8 * 128;
+        return;
+      }
       lds_cptr xb = x0;
 #pragma unroll 1
       for (int q0 = 4; q0 < Q16; q0 += 4) {
@@ -468,12 +524,71 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         }
       }
     };
+    // acc[I] += F[I][J] Zp[J] over the neighbouring blocks in split precision on
+    // v_mfma_f32_16x16x32_f16 (HALF); frag(I, d, q, ah, al) puts the hi / lo pieces of lane (j, kq)'s
+    // fragment of block (I, J = I + d - 1) into elements [4 q, 4 q + 4) of the A operands
+    auto apply_split = [&](f32x4 (&acc)[S], const f32x4 (&Zp)[S], auto&& frag) {
+      if constexpr (HALF) {
+        // the same products in split precision on v_mfma_f32_16x16x32_f16 (16 cycles, like the
+        // 16-k shape): K = 32 = the subtile pair (2 p, 2 p + 1) — lane (j, kq) supplies its own C/D
+        // rows 4 kq .. + 3 of both Z blocks as B operand and the two operator fragments it holds as
+        // A operand (a block the row subtile does not touch: zeros) — three products per pair, at
+        // most two pairs per row subtile: 27 MFMAs of 16 cycles for S = 5 instead of 52 of 32
+        constexpr int NP = (S + 1) / 2;
+        f16x8 zh[NP], zl[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          zh[p] = zl[p] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (2 * p + q < S) split_into(Zp[2 * p + q], q, zh[p], zl[p]);
+        }
+        f16x8 ah[S][2], al[S][2];
+#pragma unroll
+        for (int I = 0; I < S; ++I)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int p = ((I > 0 ? I - 1 : 0) >> 1) + t;
+            ah[I][t] = al[I][t] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int J = 2 * p + q, d = J - I + 1;
+              if (J < S && d >= 0 && d < 3) frag(I, d, q, ah[I][t], al[I][t]);
+            }
+          }
+#pragma unroll
+        for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int I = 0; I < S; ++I) {
+              const int p = ((I > 0 ? I - 1 : 0) >> 1) + t;
+              if (2 * p >= S || 2 * p > I + 1) continue;  // no block of this pair touches row subtile I
+              acc[I] = mfma32h(kind == 1 ? al[I][t] : ah[I][t], kind == 0 ? zl[p] : zh[p], acc[I]);
+            }
+      }
+    };
+    // a Ritz block's stored operand pieces (which = 0: lift, 1: projection)
+    auto ritz_frag = [&](int which) {
+      return [&, which](int I, int d, int q, f16x8& ah, f16x8& al) {
+        const f16x4* f = reinterpret_cast<const f16x4*>(Vb + 4 * ((which * S * 3 + I * 3 + d) * 64 + lane));
+        const f16x4 h = f[0], l = f[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ah[4 * q + e] = h[e], al[4 * q + e] = l[e];
+      };
+    };
     // acc[I] += M[I][J] Zp[J] over every neighbouring block (I, J): branch free — a block no
     // molecule touches has all-zero fragments (offsets beyond the buffer) — and ordered so that
     // consecutive MFMAs go to different accumulators.  (With the blocks masked by a wave-uniform
     // bit each, 8 % fewer MFMAs were issued in chains of four dependent ones behind a branch:
     // the block phases ran at 2 - 5 x their matrix time.)
     auto apply_all = [&](f32x4 (&acc)[S], const f32x4 (&Zp)[S]) {
+      if constexpr (HALF) {
+        apply_split(acc, Zp, [&](int I, int d, int q, f16x8& ah, f16x8& al) {
+          split_into(mop[I][d], q, ah, al);
+        });
+        return;
+      }
 #pragma unroll
       for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -538,24 +653,28 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       }
       LNZ_PH(2)  // long block
       // lift back: out[I] (node rows) += V[I][J] T[J] over the slot subtiles J the block mask names
-      f32x4 vl[S][3];
+      if constexpr (HALF) {
+        apply_split(out, T, ritz_frag(0));
+      } else {
+        f32x4 vl[S][3];
 #pragma unroll
-      for (int I = 0; I < S; ++I)
+        for (int I = 0; I < S; ++I)
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          if (I + d - 1 < 0 || I + d - 1 >= S) continue;
-          vl[I][d] = *reinterpret_cast<const f32x4*>(&Vb[((I * 3 + d) * 16 + j) * VBP + 4 * kq]);
-        }
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int I = 0; I < S; ++I) {
-            const int J = I + d - 1;
-            if (J < 0 || J >= S) continue;
-            out[I] = mfma16(vl[I][d][r], T[J][r], out[I]);
+          for (int d = 0; d < 3; ++d) {
+            if (I + d - 1 < 0 || I + d - 1 >= S) continue;
+            vl[I][d] = *reinterpret_cast<const f32x4*>(&Vb[((I * 3 + d) * 16 + j) * VBP + 4 * kq]);
           }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int I = 0; I < S; ++I) {
+              const int J = I + d - 1;
+              if (J < 0 || J >= S) continue;
+              out[I] = mfma16(vl[I][d][r], T[J][r], out[I]);
+            }
+      }
     }
 
     LNZ_PH(3)  // lift
@@ -622,16 +741,20 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
         f32x4 Y[S];
 #pragma unroll
         for (int I = 0; I < S; ++I) Y[I] = splat4(0.f);
+        if constexpr (HALF) {
+          apply_split(Y, out, ritz_frag(1));
+        } else {
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+          for (int d = 0; d < 3; ++d)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int I = 0; I < S; ++I) {  // slot subtile I, node subtile J
-              const int J = I + d - 1;
-              if (J < 0 || J >= S) continue;
-              Y[I] = mfma16(Vb[((J * 3 + (2 - d)) * 16 + 4 * kq + r) * VBP + j], out[J][r], Y[I]);
-            }
+              for (int I = 0; I < S; ++I) {  // slot subtile I, node subtile J
+                const int J = I + d - 1;
+                if (J < 0 || J >= S) continue;
+                Y[I] = mfma16(Vb[((J * 3 + (2 - d)) * 16 + 4 * kq + r) * VBP + j], out[J][r], Y[I]);
+              }
+        }
 #pragma unroll
         for (int I = 0; I < S; ++I)
 #pragma unroll
@@ -996,7 +1119,11 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
   if (a.filter_kind != 0 && a.filter_kind != 1) return false;
   // gemm_mode 2 (split-precision GEMM1): the inference forward with diagonal gains
-  if (a.gemm_mode == 2 ? (mode != 0 || a.act_out || a.filter_kind != 0) : a.gemm_mode != 0) return false;
+  // (no short-diffusion channels there: that instantiation spills 36 registers, and no configuration of
+  // the reference with diagonal gains has them)
+  if (a.gemm_mode == 2 ? (mode != 0 || a.act_out || a.filter_kind != 0 || a.din0 != 128 || a.n_short != 0)
+                       : a.gemm_mode != 0)
+    return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
   if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
   // dbias_part is sized by the TILE plan ([2 * plan_wg_cap] entries) and indexed by strip here: a
@@ -1007,7 +1134,7 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
   const int64_t per_slot = a.filter_kind == 1 ? (int64_t)a.K * a.K : a.K;
   if ((int64_t)a.num_layer * a.B * a.n_long * per_slot * 4 >= (1ll << 31)) return false;
-  return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float) <= 160 * 1024;
+  return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long, a.gemm_mode == 2) * sizeof(float) <= 160 * 1024;
 }
 
 // lnz_lanczosnet_gain_grad on strips (the arguments have passed that entry point's checks)
@@ -1028,7 +1155,7 @@ int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s) {
 }
 
 int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
-  const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float);
+  const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long, a.gemm_mode == 2) * sizeof(float);
   const void* fns[8] = {
       (const void*)lanczosnet_strip_kernel<0, 0, false>, (const void*)lanczosnet_strip_kernel<1, 0, false>,
       (const void*)lanczosnet_strip_kernel<0, 2, false>, (const void*)lanczosnet_strip_kernel<1, 2, false>,
@@ -1036,9 +1163,7 @@ int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
       (const void*)lanczosnet_strip_kernel<0, 2, true>,  (const void*)lanczosnet_strip_kernel<1, 2, true>};
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
-  if (a.gemm_mode == 2)
-    fn = a.n_short > 0 ? (const void*)lanczosnet_strip_kernel<0, 0, true, true>
-                       : (const void*)lanczosnet_strip_kernel<0, 0, false, true>;
+  if (a.gemm_mode == 2) fn = (const void*)lanczosnet_strip_kernel<0, 0, false, true>;
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;

@@ -230,7 +230,13 @@ class _LanczosNetBase(nn.Module):
         # ring rotation): zero-pad layer-0 weight columns (per message channel) and the embedding /
         # feature columns to match
         din0 = self.input_dim
-        group = 64 if dhid == 128 else 32
+        # gemm_mode 'f16x3' on the strip plan (csrc/conv_strip.hip, HALF): the same stream at the same
+        # offsets, fp16 hi / lo pieces of the weights; every other operand is the exact kernel's
+        split_strips = (self.gemm_mode == 'f16x3' and self.split_kernel == 'strips' and dhid == 128
+                        and din0 <= 128 and self.filter_kind == 0 and self._tiles16_channels_ok()
+                        and self.num_scale_short == 0 and self.output_dim <= 31)
+        # (that kernel's weight ring is built for 128 input columns in every layer)
+        group = 128 if split_strips else (64 if dhid == 128 else 32)
         din0p = (din0 + group - 1) // group * group
         n_chan = self.num_scale_short + self.num_scale_long + self.num_edgetype + 1
         # layer 0 has its own width; the other layers share a shape and are packed by one launch
@@ -240,11 +246,6 @@ class _LanczosNetBase(nn.Module):
         if din0p != din0:
             w = torch.nn.functional.pad(w.view(dhid, n_chan, din0), (0, din0p - din0))
             w = w.reshape(dhid, n_chan * din0p)
-        # gemm_mode 'f16x3' on the strip plan (csrc/conv_strip.hip, HALF): the same stream at the same
-        # offsets, fp16 hi / lo pieces of the weights; every other operand is the exact kernel's
-        split_strips = (self.gemm_mode == 'f16x3' and self.split_kernel == 'strips' and dhid == 128
-                        and self.filter_kind == 0 and self._tiles16_channels_ok()
-                        and self.output_dim <= 31)
         pack_conv = ops.pack_rows_k8_split if split_strips else ops.pack_rows_k8
         wp = pack_conv(w)
         packs.append(wp)
@@ -277,8 +278,10 @@ class _LanczosNetBase(nn.Module):
                     dout=P, filter_kind=self.filter_kind,
                     short=list(self.short_diffusion_dist), n_long=self.num_scale_long,
                     n_edge=self.num_edgetype + 1,
-                    # + slack: the kernel's weight prefetch ring over-reads up to 7 steps (7 KiB)
-                    Wp=torch.cat(packs + [torch.zeros(2048, dtype=torch.float32, device=dev)]),
+                    # + slack: the kernel's weight prefetch ring over-reads up to 7 steps (7 KiB; the
+                    # split-precision ring 8 slots per wave pair: 16 KiB)
+                    Wp=torch.cat(packs + [torch.zeros(8192 if split_strips else 2048, dtype=torch.float32,
+                                                      device=dev)]),
                     bias=torch.cat(biases).contiguous(),
                     w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
                     bias_head=bias_head,

@@ -255,3 +255,39 @@ def strip_mfma_issued(strips, cfg):
               mfma_in_touched_blocks=int(useful),
               subtiles=int(sum(t['sub'] for t in strips)),
               max_subtiles_per_strip=int(max(t['sub'] for t in strips)))
+
+
+FLOP_PER_MFMA16X32_F16 = 2 * 16 * 16 * 32
+
+
+def strip_split_mfma_issued(strips, cfg):
+  """lanczosnet_strip_kernel<.., HALF> (gemm_mode 2): v_mfma_f32_16x16x32_f16 instructions (16384 flop)
+  one launch issues — per layer and wave GEMM1 = channels x four 32-k blocks x three products x S
+  subtiles (every layer is 128 wide there), and each block-diagonal product (the edge types' GEMM2,
+  the lift, the next layer's projection) = three products per subtile PAIR a row subtile touches.
+  The first layer's projection and the head stay on v_mfma_f32_16x16x4_f32 (counted apart)."""
+  n_long = len(cfg['long_diffusion_dist'])
+  n_edge = cfg['num_bond_type'] + 1
+  C = n_long + n_edge
+  nl = cfg['num_layer']
+
+  def pairs(S):   # (2 p, 2 p + 1) pairs over the row subtiles' neighbourhoods {I - 1, I, I + 1}
+    n = 0
+    for I in range(S):
+      p0 = max(I - 1, 0) >> 1
+      n += 1
+      if 2 * (p0 + 1) < S and 2 * (p0 + 1) <= I + 1:
+        n += 1
+    return n
+
+  f16 = f32 = 0
+  for t in strips:
+    S = t['sub']
+    for l in range(nl):
+      prods = n_edge + (1 if n_long else 0) + (1 if (n_long and l + 1 < nl) else 0)
+      f16 += 8 * 3 * (C * 4 * S + prods * pairs(S))
+    if n_long:
+      f32 += 8 * 4 * (3 * S - 2)
+    f32 += S * 64
+  return dict(mfma_f16_issued=int(f16), mfma_f32_issued=int(f32),
+              flops_issued=int(f16) * FLOP_PER_MFMA16X32_F16 + int(f32) * FLOP_PER_MFMA16)

@@ -224,3 +224,141 @@ def test_strip_launches_from_two_threads_on_fresh_streams():
     assert len(out[i]) == len(want)
     for a, w in zip(out[i], want):
       assert torch.equal(a, w)
+
+
+# ---- gemm_mode 2: split-precision GEMM1 (and block products) inside the strip kernel -------------
+def _split_pack_mirror(W):
+  """lnz_pack_rows_k8_split in numpy: [rt][32-k block][piece][lane slot][8 halves] (header)."""
+  rows, cols = W.shape
+  RT, NB = (rows + 31) // 32, cols // 32
+  Wz = np.zeros((RT * 32, cols), np.float32)
+  Wz[:rows] = W
+  hi = Wz.astype(np.float16)
+  lo = (Wz - hi.astype(np.float32)).astype(np.float16)
+  out = np.zeros((RT, NB, 2, 128, 8), np.float16)
+  for t in range(128):
+    kq, wj = 2 * (t >> 6) + ((t >> 5) & 1), t & 31
+    for piece, src in enumerate((hi, lo)):
+      blk = src.reshape(RT, 32, NB, 32)[:, wj, :, 8 * kq:8 * kq + 8]   # [RT, NB, 8]
+      out[:, :, piece, t, :] = blk
+  return out.reshape(-1).view(np.float32)
+
+
+def test_split_weight_pack_layout():
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(0)
+  for rows, cols in ((128, 128), (128, 14 * 128), (96, 64), (33, 32)):
+    W = (rs.randn(rows, cols) * 10.0 ** rs.randint(-3, 3, size=(rows, 1))).astype(np.float32)
+    got = ops.pack_rows_k8_split(torch.from_numpy(W).to(DEV)).cpu().numpy()
+    want = _split_pack_mirror(W)
+    assert got.shape == want.shape and got.tobytes() == want.tobytes(), (rows, cols)
+  with pytest.raises(Exception):
+    ops.pack_rows_k8_split(torch.zeros((32, 48), device=DEV))   # cols not a multiple of 32
+
+
+def _split_net(cfg, seed, general=False):
+  from lanczosnet_amd.model import LanczosNet, LanczosNetGeneral
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  P = oracle.make_lanczosnet_params(cfg, seed, general=general)
+  net = (LanczosNetGeneral if general else LanczosNet)(make_model_config(cfg, general=general)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  return net.to(DEV), P
+
+
+@pytest.mark.parametrize('B,n_cu,nmin,nmax,K', [(1024, 256, 2, 26, 20), (96, 7, 2, 26, 20), (33, 256, 2, 26, 12),
+                                                (64, 256, 1, 32, 20), (1, 256, 5, 5, 20), (700, 16, 27, 32, 24)])
+def test_split_precision_strip_forward_meets_the_parity_bar(B, n_cu, nmin, nmax, K):
+  """gemm_mode = 'f16x3' on the strip plan: strips of 1..6 subtiles, single molecules, full tiles,
+  other K — scores and final node states against the float64 oracle at the exact kernel's 1e-5 bar
+  (measured 1e-6 .. 2e-6), next to the exact kernel's own deviation."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  cfg = dict(oracle.DEFAULT_QM8_CFG, num_eig_vec=K)
+  net, P = _split_net(cfg, 3)
+  b = draw_batch(B, seed=11, n_min=nmin, n_max=nmax)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, K)
+  nf, mk = t(b['node_feat']), t(b['node_mask'].astype(np.uint8))
+  tiles = ops.plan_tiles(mk, True, n_cu=n_cu)
+  out = {}
+  for mode in ('fp32', 'f16x3'):
+    net.gemm_mode = mode
+    plan = net._plan()
+    assert plan['gemm_mode'] == (2 if mode == 'f16x3' else 0) and plan['Wp16'] is None
+    Lp = ops.pack_laplacian_for(plan, L)
+    assert Lp.dtype == torch.float32
+    G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+    with torch.no_grad():
+      s, st = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles, return_state=True)
+      s_fast = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
+      s_own = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling='single')  # (makes its own strip plan)
+    assert torch.equal(s, s_fast)
+    out[mode] = (s.cpu().numpy(), st.cpu().numpy(), s_own.cpu().numpy())
+  ref, rst = oracle.lanczos_net_forward(P, cfg, b['node_feat'], L.cpu().numpy(), D.cpu().numpy(),
+                                        V.cpu().numpy(), b['node_mask'], dtype=np.float64, return_state=True)
+  real = np.arange(32)[None, :] < b['n_nodes'][:, None]
+  N = b['node_mask'].shape[1]
+  for mode, (s, st, s_own) in out.items():
+    e_s = np.abs(s - ref).max() / np.abs(ref).max()
+    e_st = np.abs(st[:, :N][real[:, :N]] - rst[real[:, :N]]).max() / np.abs(rst).max()
+    print('%s: scores %.2e, node states %.2e of the float64 oracle' % (mode, e_s, e_st))
+    assert e_s <= 1e-5 and e_st <= 1e-5, mode
+    assert np.abs(s_own - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_split_precision_strip_forward_float_features_and_no_long_scales():
+  """LanczosNetGeneral-style float features (input width 10, zero-padded to the kernel's 128 columns)
+  and a model without long-diffusion scales (no eigen-space block at all)."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  from graph_fixture import GRAPH_CFG
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  rs = np.random.RandomState(2)
+  for cfg, general in ((dict(GRAPH_CFG, input_dim=10), True),
+                       (dict(oracle.DEFAULT_QM8_CFG, long_diffusion_dist=[]), False)):
+    net, P = _split_net(cfg, 4, general=general)
+    net.gemm_mode = 'f16x3'
+    B = 50
+    b = draw_batch(B, seed=3, n_min=4, n_max=30, num_bond_type=cfg['num_bond_type'])
+    n = t(b['n_nodes'])
+    L = ops.laplacian_l4(t(b['adjs']), n)
+    K = cfg['num_eig_vec']
+    D, V = ops.lanczos_ritz(L[..., 0], n, K)
+    feat = rs.randn(B, b['node_mask'].shape[1], 10).astype(np.float32) if general else b['node_feat']
+    with torch.no_grad():
+      got = net(t(feat), L, D, V, mask=t(b['node_mask'])).cpu().numpy()
+    assert net._plan()['gemm_mode'] == 2 and net._plan()['din0'] == 128
+    ref = oracle.lanczos_net_forward(P, cfg, feat, L.cpu().numpy(), D.cpu().numpy(), V.cpu().numpy(),
+                                     b['node_mask'], dtype=np.float64, general=general)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), general
+
+
+def test_split_precision_needs_the_strip_plan_and_says_so():
+  """gemm_mode 2 through the raw entry point without a strip plan, and a model with short-diffusion
+  channels (which keeps the older tile kernel): errors, not silent fallbacks."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net, _ = _split_net(cfg, 3)
+  net.gemm_mode = 'f16x3'
+  plan = net._plan()
+  b = draw_batch(8, seed=1)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+  Lp = ops.pack_laplacian_for(plan, L)
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
+  ext = ops._ext()
+  consts = ([int(x) for x in plan['w_off'][:7]], [int(x) for x in plan['b_off'][:7]],
+            [7, plan['din0'], 128, plan['dout'], plan['n_long'], plan['n_edge'], 0, 2], [])
+  mk = t(b['node_mask'].astype(np.uint8))
+  with pytest.raises(RuntimeError, match='strip plan'):
+    ext.forward(t(b['node_feat']), plan['embedding'], Lp, None, V, G, mk, plan['Wp'], plan['bias'],
+                consts[0], consts[1], plan['Wp_head'], plan['bias_head'], None, 0, consts[2], consts[3], None, 0)
+  cfg_s = dict(cfg, short_diffusion_dist=[1, 2])
+  net_s, _ = _split_net(cfg_s, 3)
+  net_s.gemm_mode = 'f16x3'
+  assert net_s._plan()['gemm_mode'] == 0 and net_s._plan()['Wp16'] is not None   # the tile kernel's packs

@@ -23,7 +23,10 @@ D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
 nf, mask = t(batch['node_feat']), t(batch['node_mask'])
 mask_u8 = mask.to(torch.uint8).contiguous()
 res = {}
-for name, gm, sk in (('fp32', 'fp32', 'strips'), ('split strips', 'f16x3', 'strips'), ('split tiles', 'f16x3', 'tiles')):
+CASES = (('fp32', 'fp32', 'strips'), ('split strips', 'f16x3', 'strips'), ('split tiles', 'f16x3', 'tiles'))
+if os.environ.get('SPLIT_ONLY'):
+  CASES = CASES[:2]
+for name, gm, sk in CASES:
   net.gemm_mode, net.split_kernel = gm, sk
   plan = net._plan()
   Lp = ops.pack_laplacian_for(plan, L)
@@ -32,15 +35,18 @@ for name, gm, sk in (('fp32', 'fp32', 'strips'), ('split strips', 'f16x3', 'stri
   with torch.no_grad():
     for _ in range(3):
       sc = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, tiling=tiles)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-      sc = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, tiling=tiles)
-    e1.record()
-    torch.cuda.synchronize()
+    best = 1e9
+    for rep in range(6):   # (box-to-box and run-to-run spread is 3 %: the best of six runs of 50)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(50):
+        sc = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, tiling=tiles)
+      e1.record()
+      torch.cuda.synchronize()
+      best = min(best, e0.elapsed_time(e1) / 50)
     sc2, st = ops.lanczosnet_forward(plan, nf, Lp, V, G, mask_u8, return_state=True, tiling=tiles)
   assert torch.equal(sc, sc2)
-  res[name] = (sc.double().cpu().numpy(), st.double().cpu().numpy(), e0.elapsed_time(e1) / 20)
+  res[name] = (sc.double().cpu().numpy(), st.double().cpu().numpy(), best)
 ref, rst, _ = res['fp32']
 for name, (sc, st, ms) in res.items():
   dev = np.abs(sc - ref).max() / np.abs(ref).max()

@@ -13,6 +13,7 @@ cfg = dict(oracle.DEFAULT_QM8_CFG)
 P = oracle.make_lanczosnet_params(cfg, 1)
 net = LanczosNet(make_model_config(cfg)).eval()
 net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}); net = net.cuda()
+net.gemm_mode = os.environ.get('PROBE_GEMM', 'fp32')   # 'f16x3': the split-precision strip kernel
 B = int(os.environ.get('PROBE_B', '1024'))
 b = draw_batch(B, seed=0)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
@@ -36,3 +37,10 @@ print('B=%d  [block, wave] kcycles: %s' % (B, ' '.join(names)))
 for blk in range(2):
   for w in (0, 3, 7):
     print('   ', blk, w, ' '.join('%8.1f' % (x / 1e3) for x in rec[blk, w][:10]))
+# the strip plan of this batch: subtiles per strip (a launch lasts as long as its longest strip)
+if os.environ.get('PROBE_STRIPS'):
+  st = ops.plan_strips(t(b['node_mask']).to(torch.uint8).contiguous()).cpu().numpy()
+  nst = int(st[-1])
+  ent = st[:-1].reshape(-1, ops.STRIP_INTS)[:nst]
+  print('strips', nst, 'subtiles histogram', np.bincount(ent[:, 1], minlength=7).tolist(),
+        'first 8 strips (molecules, subtiles):', ent[:8, :2].tolist())
