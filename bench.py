@@ -875,38 +875,23 @@ def main():
     fwd2_ms = e0.elapsed_time(e1) / N_FWD
     dev_rel = float((s2 - ref_score).abs().max() / ref_score.abs().max())
     split_score = s2.clone()
-    on_strips = plan.get('gemm_mode', 0) == 2
-    if on_strips:
-      # matrix-pipe work of the split-precision launch on the strip plan (utils/flop_model.py):
-      # v_mfma_f32_16x16x32_f16 instructions of GEMM1 and of the block-diagonal products, three per
-      # fp32 product; the first projection and the head stay on the fp32 shape
-      from lanczosnet_amd.utils.flop_model import strips_from_plan, strip_split_mfma_issued
-      fm2 = strip_split_mfma_issued(strips_from_plan(tiles[0].strips.cpu().numpy(), None), cfg)
-      f16_flop = float(fm2['flops_issued'])
-      mode_txt = ('f16x3 on the strip plan (lanczosnet_strip_kernel<.., HALF>, gemm_mode 2): X W^T as x_hi w_hi '
-                  '+ x_lo w_hi + x_hi w_lo on v_mfma_f32_16x16x32_f16, fp32 accumulate, node state in LDS as '
-                  'fp16 hi | lo pieces; the Laplacian products, the lift and the projection in the same '
-                  'split (operands split in the kernel); gains, biases, activations, head exact fp32; the '
-                  'rest of the step is the exact path\'s (same pack, same plan, same Ritz pairs) — opt-in, '
-                  'parity-tested at the same 1e-5 bar')
-      roof_note = ('issued f16 matrix flops (16384 x the v_mfma_f32_16x16x32_f16 the strip plan issues: %d per '
-                   'launch, + %d v_mfma_f32_16x16x4_f32): three split products per fp32 product, so the '
-                   'fp32-equivalent rate is a third of `achieved`' % (fm2['mfma_f16_issued'], fm2['mfma_f32_issued']))
-      roof_kernel = 'lanczosnet_strip_kernel<0,0,false,true>'
-    else:
-      # the older tile kernel: every node tile is one molecule on 32 rows (B tiles), per layer C
-      # channels of GEMM1 [32 x 128 x din] and n_edge channels of GEMM2 [32 x 32 x 128], each as THREE
-      # f16 products; the eigen-space projection and lift stay exact fp32 and are not counted
-      n_chan = len(cfg['short_diffusion_dist']) + len(cfg['long_diffusion_dist']) + cfg['num_bond_type'] + 1
-      din0_pad = (cfg['input_dim'] + 31) // 32 * 32
-      f16_flop = 0.0
-      for l_ in range(cfg['num_layer']):
-        din_ = din0_pad if l_ == 0 else 128
-        f16_flop += 3.0 * 2.0 * B * (n_chan * 32 * 128 * din_ + (cfg['num_bond_type'] + 1) * 32 * 32 * 128)
-      mode_txt = ('f16x3 on 32-row tiles (lanczosnet_forward_f16x3_kernel): X W^T as x_hi w_hi + x_hi w_lo + x_lo '
-                  'w_hi on v_mfma_f32_32x32x16_f16, fp32 accumulate; edge-type GEMM2 in the same split')
-      roof_note = 'issued f16 matrix flops, one molecule per 32-row tile'
-      roof_kernel = 'lanczosnet_forward_f16x3_kernel'
+    # matrix-pipe work of the split-precision launch on the strip plan (utils/flop_model.py):
+    # v_mfma_f32_16x16x32_f16 instructions of GEMM1 and of the block-diagonal products, three per
+    # fp32 product; the first projection and the head stay on the fp32 shape
+    from lanczosnet_amd.utils.flop_model import strips_from_plan, strip_split_mfma_issued
+    assert plan.get('gemm_mode', 0) == 1
+    fm2 = strip_split_mfma_issued(strips_from_plan(tiles[0].strips.cpu().numpy(), None), cfg)
+    f16_flop = float(fm2['flops_issued'])
+    mode_txt = ('f16x3 on the strip plan (lanczosnet_strip_kernel<.., HALF>, gemm_mode 1): X W^T as x_hi w_hi '
+                '+ x_lo w_hi + x_hi w_lo on v_mfma_f32_16x16x32_f16, fp32 accumulate, node state in LDS as '
+                'fp16 hi | lo pieces; the Laplacian products, the lift and the projection in the same '
+                'split (operands split in the kernel); gains, biases, activations, head exact fp32; the '
+                'rest of the step is the exact path\'s (same pack, same plan, same Ritz pairs) — opt-in, '
+                'parity-tested at the same 1e-5 bar')
+    roof_note = ('issued f16 matrix flops (16384 x the v_mfma_f32_16x16x32_f16 the strip plan issues: %d per '
+                 'launch, + %d v_mfma_f32_16x16x4_f32): three split products per fp32 product, so the '
+                 'fp32-equivalent rate is a third of `achieved`' % (fm2['mfma_f16_issued'], fm2['mfma_f32_issued']))
+    roof_kernel = 'lanczosnet_strip_kernel<0,0,false,true>'
     split = {'mode': mode_txt,
              'value': round(B * args.steps / el2, 1), 'unit': 'molecules/s',
              'ms_per_step': round(1e3 * el2 / args.steps, 4),

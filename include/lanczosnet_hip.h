@@ -225,19 +225,12 @@ int64_t lnz_packed_rows_k8_size(int rows, int cols);
 int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, float* Wp,
                      lnz_stream_t stream);
 /* The same stream for the split-precision GEMM1 of the strip kernel (lnz_forward_args.gemm_mode =
- * 2): same size (lnz_packed_rows_k8_size; cols a multiple of 32) and the same (rt, 16-k step, lane)
+ * 1): same size (lnz_packed_rows_k8_size; cols a multiple of 32) and the same (rt, 16-k step, lane)
  * indexing, but the two 16-byte slots a lane owns in a 32-k block b hold eight fp16 hi pieces, then
  * the eight lo pieces (x = hi + lo to 22 bits) of W[32 rt + wj][32 b + 8 kq + 0..7] (lane slot
  * 64 (kq >> 1) + 32 (kq & 1) + wj) — the B operands of v_mfma_f32_16x16x32_f16. */
 int lnz_pack_rows_k8_split(const float* W, int rows, int cols, int64_t ld, float* Wp,
                            lnz_stream_t stream);
-/* W [rows, cols] -> fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order:
- *   out[rt][kb][piece][lane][e] (e = 0..7 halves, 16 B per lane) with
- *   x = W[32*rt + (lane&31)][16*kb + 8*(lane>>5) + e], piece 0 = half(x), piece 1 = half(x - piece0);
- * rows padded to 32, cols to 16.  lnz_packed_rows_f16x2_bytes(rows, cols) bytes. */
-int64_t lnz_packed_rows_f16x2_bytes(int rows, int cols);
-int lnz_pack_rows_f16x2(const float* W, int rows, int cols, int64_t ld, void* out,
-                        lnz_stream_t stream);
 /* bias [rows] -> bp[rt][lane][r] = bias[32*rt + (r&3) + 8*(r>>2) + 4*(lane>>5)] (the C/D
  * row of accumulator register r); holds 32*ceil(rows/32)*32 floats. */
 int lnz_pack_bias_rows(const float* bias, int rows, float* bp, lnz_stream_t stream);
@@ -253,12 +246,6 @@ int lnz_pack_laplacian(const float* L, int64_t stride_b, int64_t stride_r, int64
  * lnz_pack_laplacian_plan / lnz_prepare_batch[_gains] is the same array. */
 int lnz_pack_laplacian_ident(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                              int64_t stride_ch, int B, int N, int C, float* Lp, uint32_t* ident,
-                             lnz_stream_t stream);
-
-/* Same tile split into fp16 hi/lo pieces for the split-precision GEMM2 (gemm_mode = 1):
- * Lp16[b][c][blk][piece][lane][e] = L[b][lane&31][cd_row(8*blk+e, lane>>5)][c]; B*C*4096 bytes. */
-int lnz_pack_laplacian_f16x2(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
-                             int64_t stride_ch, int B, int N, int C, void* Lp16,
                              lnz_stream_t stream);
 
 /* ---- R7 (first half): per-eigenvalue spectral filter gains ----------------------------
@@ -322,25 +309,17 @@ typedef struct lnz_forward_args {
   const float* bias_head;     /* [32]: b_o (P), b_a, zeros                                   */
   float* score;               /* [B,dout]                                                    */
   float* state_out;           /* optional [B,32,dhid] final node state (debug/tests) or NULL */
-  /* ---- opt-in split-precision mode (gemm_mode = 1): X W_c^T evaluated as x_hi w_hi + x_hi w_lo +
-   * x_lo w_hi with fp16 pieces on v_mfma_f32_32x32x16_f16 (fp32 accumulate): 2^-22 relative
-   * operand precision, measured 6e-7 end-to-end vs fp64 (fp32 MFMA path: 2e-7).  Needs dhid == 128,
-   * filter_kind == 0, K <= 20, din0 <= 128; packs from lnz_pack_rows_f16x2 with the layer-0 input
-   * width zero-padded to 128 and 16 KiB of slack behind the last layer; G followed by 64 B of
-   * slack (gains are read as whole dwordx4 groups).  gemm_mode = 0 (default) is the exact fp32 path.
-   * gemm_mode = 2: the same split of GEMM1 on the STRIP plan (inference forward only; needs `strips`
-   * and dhid 128, din0 128 — zero-pad narrower inputs and the layer-0 weight columns —, diagonal
-   * gains, no short-diffusion channels) on v_mfma_f32_16x16x32_f16: Wp = lnz_pack_rows_k8_split of the same matrices at the same
-   * offsets, followed by 32 KiB of slack (the weight ring over-reads 16 KiB); the node state lives in
-   * LDS as fp16 hi | lo blocks; the products with the Laplacian blocks and the Ritz blocks
-   * (projection, lift) run in the same three-product split, their operands split in the kernel
-   * (Lp and V are the exact kernel's); gains, biases, activations and the head are exact fp32.  None
-   * of the *16 fields below is used. */
+  /* ---- gemm_mode = 0 (default): the exact fp32 path.  gemm_mode = 1: opt-in split precision on the
+   * STRIP plan (inference forward only; needs `strips`, dhid 128, din0 128 — zero-pad narrower inputs
+   * and the layer-0 weight columns —, diagonal gains, no short-diffusion channels): X W_c^T as x_hi
+   * w_hi + x_lo w_hi + x_hi w_lo with fp16 pieces (x = hi + lo to 22 bits) on
+   * v_mfma_f32_16x16x32_f16, fp32 accumulate; Wp = lnz_pack_rows_k8_split of the same matrices at the
+   * same offsets, followed by 32 KiB of slack (the weight ring over-reads 16 KiB); the node state
+   * lives in LDS as fp16 hi | lo blocks; the products with the Laplacian blocks and the Ritz blocks
+   * (projection, lift) run in the same three-product split, their operands split in the kernel (Lp
+   * and V are the exact kernel's); gains, biases, activations and the head are exact fp32.  Measured
+   * 1e-6 .. 2e-6 against float64 (exact path: 2e-7 .. 3e-7); parity bar 1e-5. */
   int32_t gemm_mode;
-  const void* Wp16;           /* packed fp16 hi/lo conv weights: layer l at (char*)Wp16 + w16_off[l] */
-  int64_t w16_off[16];        /* byte offsets                                                     */
-  const void* Wp16_head;      /* packed [32, 128] head                                            */
-  const void* Lp16;           /* lnz_pack_laplacian_f16x2 output (gemm_mode 1; replaces Lp there)  */
   const int32_t* plan;        /* optional tile plan (lnz_plan_tiles): [plan_wg_cap][4][3] int32, slot s
                                  of workgroup g = (molecule A, molecule B or -1, split row); NULL =
                                  one tile per molecule, 4 per workgroup, in batch order.  The plan

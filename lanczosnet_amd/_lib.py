@@ -40,8 +40,7 @@ class ForwardArgs(C.Structure):
       ('w_off', C.c_int64 * 16), ('b_off', C.c_int64 * 16),
       ('Wp_head', C.c_void_p), ('bias_head', C.c_void_p),
       ('score', C.c_void_p), ('state_out', C.c_void_p),
-      ('gemm_mode', C.c_int32), ('Wp16', C.c_void_p), ('w16_off', C.c_int64 * 16),
-      ('Wp16_head', C.c_void_p), ('Lp16', C.c_void_p), ('plan', C.c_void_p), ('n_wg', C.c_void_p), ('plan_wg_cap', C.c_int),
+      ('gemm_mode', C.c_int32), ('plan', C.c_void_p), ('n_wg', C.c_void_p), ('plan_wg_cap', C.c_int),
       ('act_out', C.c_void_p), ('act', C.c_void_p), ('dy', C.c_void_p), ('dx0', C.c_void_p),
       ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p), ('dgains', C.c_void_p),
       ('dy_compact', C.c_void_p), ('dy_compact_rows', C.c_int64), ('dbias_part', C.c_void_p),
@@ -77,8 +76,6 @@ SIGNATURES = {
     'lnz_packed_rows_k8_size': (C.c_int64, [_I, _I]),
     'lnz_pack_rows_k8': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_pack_rows_k8_split': (C.c_int, [_P, _I, _I, _L, _P, _P]),
-    'lnz_packed_rows_f16x2_bytes': (C.c_int64, [_I, _I]),
-    'lnz_pack_rows_f16x2': (C.c_int, [_P, _I, _I, _L, _P, _P]),
     'lnz_pack_bias_rows': (C.c_int, [_P, _I, _P, _P]),
     'lnz_pack_laplacian': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_collate_qm8': (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
@@ -91,7 +88,6 @@ SIGNATURES = {
     'lnz_plan_strips': (C.c_int, [_P, _I, _I, _I, _P, _P, _P]),
     'lnz_strip_cap': (C.c_int, [_I]),
     'lnz_plan_tiles': (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
-    'lnz_pack_laplacian_f16x2': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),
     'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),
     'lnz_pack_spectral_mlp_layers': (C.c_int, [_P, _I, _I, _P, _P]),

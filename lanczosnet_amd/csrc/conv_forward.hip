@@ -1255,7 +1255,6 @@ __global__ __launch_bounds__(128 * NWV) void lanczosnet_gain_grad_kernel(const l
 }  // namespace
 
 namespace lnz {
-int launch_forward_f16x3(const lnz_forward_args& a, hipStream_t s);  // conv_forward_f16.hip
 bool forward16_eligible(const lnz_forward_args& a, int mode);         // conv_forward16.hip
 int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s);
 bool strip_forward_eligible(const lnz_forward_args& a, int mode);     // conv_strip.hip
@@ -1296,10 +1295,10 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
   LNZ_REQUIRE(a.n_short >= 0 && a.n_short <= 8 && a.n_long >= 0 && a.n_edge >= 1 &&
                   a.n_short + a.n_long + a.n_edge <= LNZ_MAX_CHANNELS,
               LNZ_EINVAL, "%s: bad channel counts", who);
-  LNZ_REQUIRE(a.mask && a.V && (a.Lp || (a.gemm_mode == 1 && a.Lp16)), LNZ_EINVAL,
+  LNZ_REQUIRE(a.mask && a.V && a.Lp, LNZ_EINVAL,
               "%s: null tensor pointer", who);
   LNZ_REQUIRE(a.n_long == 0 || a.G, LNZ_EINVAL, "%s: G missing", who);
-  LNZ_REQUIRE(a.gemm_mode >= 0 && a.gemm_mode <= 2, LNZ_EINVAL, "%s: gemm_mode %d", who,
+  LNZ_REQUIRE(a.gemm_mode == 0 || a.gemm_mode == 1, LNZ_EINVAL, "%s: gemm_mode %d", who,
               a.gemm_mode);
   LNZ_REQUIRE(a.filter_kind == 0 || a.filter_kind == 1, LNZ_EINVAL, "%s: filter_kind %d", who,
               a.filter_kind);
@@ -1316,10 +1315,9 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
     LNZ_REQUIRE(!a.act_out || (a.gemm_mode == 0 && (a.filter_kind == 0 || dense_es)), LNZ_ENOTSUP,
                 "%s: act_out needs gemm_mode 0 and diagonal gains or dense filters in eigen space",
                 who);
-    if (a.gemm_mode == 1) return lnz::launch_forward_f16x3(a, s);
-    if (a.gemm_mode == 2) {
+    if (a.gemm_mode == 1) {
       LNZ_REQUIRE(lnz::strip_forward_eligible(a, 0), LNZ_ENOTSUP,
-                  "%s: gemm_mode 2 (split-precision GEMM1) runs on the strip plan only: strips, hidden "
+                  "%s: gemm_mode 1 (split-precision GEMM1) runs on the strip plan only: strips, hidden "
                   "width 128, input width 128, diagonal gains, no short-diffusion channels, <= 12 long and <= 32 "
                   "channels in all",
                   who);

@@ -43,7 +43,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 
-// ---- split-precision node state (HALF, lnz_forward_args.gemm_mode 2): a row of the node-state
+// ---- split-precision node state (HALF, lnz_forward_args.gemm_mode 1): a row of the node-state
 // buffers keeps its P floats of LDS, but a 32-column block (128 B) holds the 32 fp16 hi pieces of
 // its columns, then the 32 lo pieces (x = hi + lo to 22 bits): lane (j, kq) of a wave reads the A
 // operand of v_mfma_f32_16x16x32_f16 for columns 32 b + 8 kq .. + 7 as ONE ds_read_b128 per piece,
@@ -1118,10 +1118,10 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   if (mode != 0 && mode != 1) return false;
   if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
   if (a.filter_kind != 0 && a.filter_kind != 1) return false;
-  // gemm_mode 2 (split-precision GEMM1): the inference forward with diagonal gains
+  // gemm_mode 1 (split-precision GEMM1): the inference forward with diagonal gains
   // (no short-diffusion channels there: that instantiation spills 36 registers, and no configuration of
   // the reference with diagonal gains has them)
-  if (a.gemm_mode == 2 ? (mode != 0 || a.act_out || a.filter_kind != 0 || a.din0 != 128 || a.n_short != 0)
+  if (a.gemm_mode == 1 ? (mode != 0 || a.act_out || a.filter_kind != 0 || a.din0 != 128 || a.n_short != 0)
                        : a.gemm_mode != 0)
     return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
@@ -1134,7 +1134,7 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;
   const int64_t per_slot = a.filter_kind == 1 ? (int64_t)a.K * a.K : a.K;
   if ((int64_t)a.num_layer * a.B * a.n_long * per_slot * 4 >= (1ll << 31)) return false;
-  return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long, a.gemm_mode == 2) * sizeof(float) <= 160 * 1024;
+  return (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long, a.gemm_mode == 1) * sizeof(float) <= 160 * 1024;
 }
 
 // lnz_lanczosnet_gain_grad on strips (the arguments have passed that entry point's checks)
@@ -1155,7 +1155,7 @@ int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s) {
 }
 
 int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
-  const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long, a.gemm_mode == 2) * sizeof(float);
+  const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long, a.gemm_mode == 1) * sizeof(float);
   const void* fns[8] = {
       (const void*)lanczosnet_strip_kernel<0, 0, false>, (const void*)lanczosnet_strip_kernel<1, 0, false>,
       (const void*)lanczosnet_strip_kernel<0, 2, false>, (const void*)lanczosnet_strip_kernel<1, 2, false>,
@@ -1163,7 +1163,7 @@ int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
       (const void*)lanczosnet_strip_kernel<0, 2, true>,  (const void*)lanczosnet_strip_kernel<1, 2, true>};
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
-  if (a.gemm_mode == 2) fn = (const void*)lanczosnet_strip_kernel<0, 0, false, true>;
+  if (a.gemm_mode == 1) fn = (const void*)lanczosnet_strip_kernel<0, 0, false, true>;
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;

@@ -57,7 +57,7 @@ extern "C" int lnz_pack_rows_k8(const float* W, int rows, int cols, int64_t ld, 
   return lnz::check_launch("lnz_pack_rows_k8");
 }
 
-// The same weight stream for the split-precision GEMM1 of the strip kernel (gemm_mode 2,
+// The same weight stream for the split-precision GEMM1 of the strip kernel (gemm_mode 1,
 // conv_strip.hip): same size and the same (rt, 16-k step, lane slot) indexing as lnz_pack_rows_k8 —
 // the kernel's four-slot ring walks it unchanged —, but the two slots of a 32-k block hold that
 // block's fp16 hi pieces, then its lo pieces: slot (rt, 2 b + piece), lane slot t = 64 (kq >> 1) +
@@ -103,54 +103,6 @@ extern "C" int lnz_pack_rows_k8_split(const float* W, int rows, int cols, int64_
   return lnz::check_launch("lnz_pack_rows_k8_split");
 }
 
-// fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order (see header)
-__global__ void pack_rows_f16x2_kernel(const float* __restrict__ W, int rows, int cols, int64_t ld,
-                                       int RT, int KB, uint4* __restrict__ out) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (rt, kb, lane)
-  int64_t total = (int64_t)RT * KB * 64;
-  if (idx >= total) return;
-  int lane = (int)(idx & 63);
-  int kb = (int)((idx >> 6) % KB);
-  int rt = (int)((idx >> 6) / KB);
-  int row = 32 * rt + (lane & 31);
-  int col0 = 16 * kb + 8 * (lane >> 5);
-  unsigned hi[4], lo[4];
-#pragma unroll
-  for (int e2 = 0; e2 < 4; ++e2) {
-    unsigned short h[2], l[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int col = col0 + 2 * e2 + u;
-      float x = (row < rows && col < cols) ? W[(int64_t)row * ld + col] : 0.0f;
-      _Float16 xh = (_Float16)x;
-      _Float16 xl = (_Float16)(x - (float)xh);
-      h[u] = __builtin_bit_cast(unsigned short, xh);
-      l[u] = __builtin_bit_cast(unsigned short, xl);
-    }
-    hi[e2] = (unsigned)h[0] | ((unsigned)h[1] << 16);
-    lo[e2] = (unsigned)l[0] | ((unsigned)l[1] << 16);
-  }
-  int64_t base = ((int64_t)rt * KB + kb) * 2 * 64;
-  out[base + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-  out[base + 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-}
-
-extern "C" int64_t lnz_packed_rows_f16x2_bytes(int rows, int cols) {
-  int64_t RT = (rows + 31) / 32, KB = (cols + 15) / 16;
-  return RT * KB * 2 * 64 * 16;
-}
-
-extern "C" int lnz_pack_rows_f16x2(const float* W, int rows, int cols, int64_t ld, void* out,
-                                   lnz_stream_t stream) {
-  LNZ_REQUIRE(W && out && rows > 0 && cols > 0 && ld >= cols, LNZ_EINVAL,
-              "lnz_pack_rows_f16x2: bad arguments (rows=%d cols=%d)", rows, cols);
-  int RT = (rows + 31) / 32, KB = (cols + 15) / 16;
-  int64_t total = (int64_t)RT * KB * 64;
-  hipLaunchKernelGGL(pack_rows_f16x2_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, W, rows, cols, ld, RT, KB, (uint4*)out);
-  return lnz::check_launch("lnz_pack_rows_f16x2");
-}
-
 // bp[rt][lane][r] = bias[32 rt + cd_row(r, lane >> 5)]
 __global__ void pack_bias_rows_kernel(const float* __restrict__ bias, int rows, int RT,
                                       float* __restrict__ bp) {
@@ -177,63 +129,6 @@ __global__ __launch_bounds__(256) void pack_laplacian_kernel(
     float4* __restrict__ Lp, uint32_t* __restrict__ ident) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   pack_laplacian_body(L, sb, sr, sc, sch, N, C, Lp, tile, blockIdx.x, ident);
-}
-
-// Lp16[b][c][blk][piece][lane] (uint4 = 8 halves): element e = L[b][lane&31][cd_row(8 blk + e, lane>>5)][c]
-// split into fp16 hi / lo — the A operand of the split-precision GEMM2 (k-order = C/D register order).
-__global__ __launch_bounds__(256) void pack_laplacian_f16x2_kernel(
-    const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int N, int C,
-    uint4* __restrict__ Lp) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
-  const int b = blockIdx.x;
-  const float* Lb = L + (int64_t)b * sb;
-  const bool dense_cl = (sch == 1 && sc == C && sr == (int64_t)N * C);
-  const int total = N * N * C;
-  if (dense_cl) {
-    for (int i = threadIdx.x; i < total; i += blockDim.x) tile[i] = Lb[i];
-  } else {
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-      int c = i % C, m = (i / C) % N, r = i / (C * N);
-      tile[i] = Lb[r * sr + m * sc + c * sch];
-    }
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < C * 2 * 64; o += blockDim.x) {  // (c, blk, lane)
-    int lane = o & 63, blk = (o >> 6) & 1, c = o >> 7;
-    int row = lane & 31, hh = lane >> 5;
-    unsigned hi[4], lo[4];
-#pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) {
-      unsigned short h[2], l[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        int col = lnz::cd_row(8 * blk + 2 * e2 + u, hh);
-        float x = (row < N && col < N) ? tile[(row * N + col) * C + c] : 0.0f;
-        _Float16 xh = (_Float16)x;
-        _Float16 xl = (_Float16)(x - (float)xh);
-        h[u] = __builtin_bit_cast(unsigned short, xh);
-        l[u] = __builtin_bit_cast(unsigned short, xl);
-      }
-      hi[e2] = (unsigned)h[0] | ((unsigned)h[1] << 16);
-      lo[e2] = (unsigned)l[0] | ((unsigned)l[1] << 16);
-    }
-    int64_t base = (((int64_t)b * C + c) * 2 + blk) * 2 * 64;
-    Lp[base + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    Lp[base + 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-  }
-}
-
-extern "C" int lnz_pack_laplacian_f16x2(const float* L, int64_t stride_b, int64_t stride_r,
-                                        int64_t stride_c, int64_t stride_ch, int B, int N, int C,
-                                        void* Lp, lnz_stream_t stream) {
-  LNZ_REQUIRE(L && Lp && B > 0 && C > 0 && C <= LNZ_MAX_CHANNELS, LNZ_EINVAL,
-              "lnz_pack_laplacian_f16x2: bad arguments (B=%d C=%d)", B, C);
-  LNZ_REQUIRE(N > 0 && N <= LNZ_TILE, LNZ_ENOTSUP, "lnz_pack_laplacian_f16x2: N=%d > %d", N, LNZ_TILE);
-  size_t lds = (size_t)N * N * C * sizeof(float);
-  LNZ_REQUIRE(lds <= 64 * 1024, LNZ_ENOTSUP, "lnz_pack_laplacian_f16x2: tile too large");
-  hipLaunchKernelGGL(pack_laplacian_f16x2_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, L,
-                     stride_b, stride_r, stride_c, stride_ch, N, C, (uint4*)Lp);
-  return lnz::check_launch("lnz_pack_laplacian_f16x2");
 }
 
 extern "C" int lnz_pack_laplacian_ident(const float* L, int64_t stride_b, int64_t stride_r,

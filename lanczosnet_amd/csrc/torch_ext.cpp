@@ -73,12 +73,12 @@ const Tensor* first_defined(std::initializer_list<const Tensor*> ts) {
 // input_grad (1), messages (2), gain_grad (3).  `in` holds the read-only device operands in the
 // order of kIn below (None = NULL), `dims` the scalar fields in the order of kDim; the buffers a
 // launch writes are separate, alias-annotated arguments.
-enum { kNodeFeat, kNodeFeatF, kEmbedding, kMask, kLp, kV, kG, kWp, kBias, kWpHead, kBiasHead, kWp16,
-       kWp16Head, kLp16, kPlan, kNwg, kAct, kX0, kIdent, kRowOff, kStrips, kNStrips, kNumIn };
+enum { kNodeFeat, kNodeFeatF, kEmbedding, kMask, kLp, kV, kG, kWp, kBias, kWpHead, kBiasHead,
+       kPlan, kNwg, kAct, kX0, kIdent, kRowOff, kStrips, kNStrips, kNumIn };
 enum { dB, dN, dK, dNumLayer, dDin0, dDhid, dDout, dNLong, dNEdge, dNumAtom, dFilterKind, dGemmMode,
        dPlanCap, dBwdDin0, dMsgLayer, dDyCompactRows, dStripCap, kNumDim };
 void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at::IntArrayRef dims,
-                  at::IntArrayRef w_off, at::IntArrayRef b_off, at::IntArrayRef w16_off,
+                  at::IntArrayRef w_off, at::IntArrayRef b_off,
                   at::IntArrayRef short_dist, const c10::optional<Tensor>& score,
                   const c10::optional<Tensor>& state_out, const c10::optional<Tensor>& act_out,
                   const c10::optional<Tensor>& dy, const c10::optional<Tensor>& dx0,
@@ -86,7 +86,7 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
                   const c10::optional<Tensor>& dy_compact, const c10::optional<Tensor>& dbias_part) {
   TORCH_CHECK((int)in.size() == kNumIn && (int)dims.size() == kNumDim && which >= 0 && which <= 3,
               "lanczosnet::fused_launch: ", (int)kNumIn, " operands and ", (int)kNumDim, " dims expected");
-  TORCH_CHECK(w_off.size() <= 16 && b_off.size() <= 16 && w16_off.size() <= 16 && short_dist.size() <= 8);
+  TORCH_CHECK(w_off.size() <= 16 && b_off.size() <= 16 && short_dist.size() <= 8);
   auto opt = [&](int i) -> c10::optional<Tensor> { return in.get(i); };
   const c10::optional<Tensor> v = opt(kV);
   TORCH_CHECK(v.has_value() && v->dim() == 3, "lanczosnet::fused_launch: V [B,N,K] is required");
@@ -101,7 +101,6 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
   for (size_t i = 0; i < short_dist.size(); ++i) a.short_dist[i] = (int32_t)short_dist[i];
   for (size_t i = 0; i < w_off.size(); ++i) a.w_off[i] = w_off[i];
   for (size_t i = 0; i < b_off.size(); ++i) a.b_off[i] = b_off[i];
-  for (size_t i = 0; i < w16_off.size(); ++i) a.w16_off[i] = w16_off[i];
   a.node_feat = (const int64_t*)raw_ptr(opt(kNodeFeat), at::kLong, "node_feat");
   a.node_feat_f = (const float*)raw_ptr(opt(kNodeFeatF), at::kFloat, "node_feat_f");
   a.embedding = (const float*)raw_ptr(opt(kEmbedding), at::kFloat, "embedding");
@@ -113,9 +112,6 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
   a.bias = (const float*)raw_ptr(opt(kBias), at::kFloat, "bias");
   a.Wp_head = (const float*)raw_ptr(opt(kWpHead), at::kFloat, "Wp_head");
   a.bias_head = (const float*)raw_ptr(opt(kBiasHead), at::kFloat, "bias_head");
-  a.Wp16 = raw_any(opt(kWp16), "Wp16");
-  a.Wp16_head = raw_any(opt(kWp16Head), "Wp16_head");
-  a.Lp16 = raw_any(opt(kLp16), "Lp16");
   a.plan = (const int32_t*)raw_ptr(opt(kPlan), at::kInt, "plan");
   a.n_wg = (const int32_t*)raw_ptr(opt(kNwg), at::kInt, "n_wg");
   a.act = (const float*)raw_ptr(opt(kAct), at::kFloat, "act");
@@ -299,7 +295,7 @@ Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
 }
 
 // ---- R7b + R9 + R10: the fused forward (exact-fp32 kernel) -------------------------------------
-// dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind (, gemm_mode: 0, or 2 = split-
+// dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind (, gemm_mode: 0, or 1 = split-
 // precision GEMM1 on strips with Wp from lnz_pack_rows_k8_split)]
 Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, const Tensor& Lp,
                const c10::optional<Tensor>& ident, const Tensor& V, const c10::optional<Tensor>& G,
@@ -309,7 +305,7 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
                at::IntArrayRef short_dist, const c10::optional<Tensor>& strips, int64_t strip_cap) {
   TORCH_CHECK(dims.size() == 7 || dims.size() == 8,
               "lanczosnet::forward: dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind(, gemm_mode)]");
-  TORCH_CHECK(dims.size() == 7 || dims[7] == 0 || dims[7] == 2, "lanczosnet::forward: gemm_mode 0 or 2");
+  TORCH_CHECK(dims.size() == 7 || dims[7] == 0 || dims[7] == 1, "lanczosnet::forward: gemm_mode 0 or 1");
   need(Lp, at::kFloat, "Lp");
   need(V, at::kFloat, "V");
   need(mask, at::kByte, "mask");
@@ -432,7 +428,7 @@ TORCH_LIBRARY(lanczosnet, m) {
         "int strip_cap) -> Tensor");
   m.def("unsorted_segment_sum_forward(Tensor data, Tensor segment_ids, int num_segments) -> Tensor");
   m.def("unsorted_segment_sum_backward(Tensor grad_out, Tensor segment_ids, int dim1) -> Tensor");
-  m.def("fused_launch(int which, Tensor?[] operands, int[] dims, int[] w_off, int[] b_off, int[] w16_off, "
+  m.def("fused_launch(int which, Tensor?[] operands, int[] dims, int[] w_off, int[] b_off, "
         "int[] short_dist, Tensor(a!)? score, Tensor(b!)? state_out, Tensor(c!)? act_out, Tensor(d!)? dy, "
         "Tensor(e!)? dx0, Tensor(f!)? msg, Tensor(g!)? dgains, Tensor(h!)? dy_compact, Tensor(i!)? dbias_part) -> ()");
   LNZ_RAW_DEFS(m)

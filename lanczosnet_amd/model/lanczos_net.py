@@ -37,12 +37,10 @@ def _opt(node, key, default):
 class _LanczosNetBase(nn.Module):
     general = False
     filter_kind = 0                      # 0: diagonal gains on Ritz vectors, 1: dense (Ada)
-    # 'fp32' (default): exact fp32 MFMA.  'f16x3': opt-in split-precision GEMM1 (x_hi w_hi + x_hi w_lo
-    # + x_lo w_hi on fp16 MFMA, fp32 accumulate; 6e-7 vs fp64, parity bar 1e-5) — see DESIGN.md §4.7
+    # 'fp32' (default): exact fp32 MFMA.  'f16x3': opt-in split precision inside the strip kernel (x_hi
+    # w_hi + x_lo w_hi + x_hi w_lo on fp16 MFMA, fp32 accumulate, for GEMM1 and the block products;
+    # 1e-6 .. 2e-6 vs fp64, parity bar 1e-5) — see DESIGN.md §4.7
     gemm_mode = os.environ.get('LANCZOSNET_GEMM', 'fp32')
-    # 'f16x3': 'strips' = split-precision GEMM1 inside the strip kernel (everything else exact fp32);
-    # 'tiles' = the older one-molecule-per-tile kernel (GEMM2 split as well), kept for A/B runs
-    split_kernel = os.environ.get('LANCZOSNET_F16X3_KERNEL', 'strips')
     # graphs beyond 32 nodes, fp32-grade mode of the streamed kernels: 3 = three bf16 pieces per
     # operand (six products), 2 = two fp16 pieces (three products, 2/3 of the operand bytes)
     large_split_planes = int(os.environ.get('LANCZOSNET_LARGE_PLANES', '3'))
@@ -198,7 +196,7 @@ class _LanczosNetBase(nn.Module):
 
     # -- packed-parameter plan ------------------------------------------------------------
     def _param_signature(self):
-        return (self.gemm_mode, self.split_kernel) + tuple((p.data_ptr(), p._version, str(p.device))
+        return (self.gemm_mode,) + tuple((p.data_ptr(), p._version, str(p.device))
                                          for p in self.parameters())
 
     def _fused_supported(self):
@@ -232,7 +230,7 @@ class _LanczosNetBase(nn.Module):
         din0 = self.input_dim
         # gemm_mode 'f16x3' on the strip plan (csrc/conv_strip.hip, HALF): the same stream at the same
         # offsets, fp16 hi / lo pieces of the weights; every other operand is the exact kernel's
-        split_strips = (self.gemm_mode == 'f16x3' and self.split_kernel == 'strips' and dhid == 128
+        split_strips = (self.gemm_mode == 'f16x3' and dhid == 128
                         and din0 <= 128 and self.filter_kind == 0 and self._tiles16_channels_ok()
                         and self.num_scale_short == 0 and self.output_dim <= 31)
         # (that kernel's weight ring is built for 128 input columns in every layer)
@@ -286,31 +284,13 @@ class _LanczosNetBase(nn.Module):
                     w_off=w_off, b_off=b_off, Wp_head=ops.pack_rows_k8(head),
                     bias_head=bias_head,
                     embedding=emb)
-        plan['Wp16'] = None
-        plan['gemm_mode'] = 2 if split_strips else 0
+        plan['gemm_mode'] = 1 if split_strips else 0
         if self.gemm_mode == 'f16x3' and not split_strips:
-            if not (self.filter_kind == 0 and dhid == 128 and self.num_eig_vec <= 20):
-                raise NotImplementedError("gemm_mode='f16x3' is built for LanczosNet with hidden "
-                                          "width 128 and num_eig_vec <= 20")
-            packs16, w16_off, off = [], [], 0
-            for t in range(self.num_layer):
-                w = self._mix_weight(t)
-                d_in = w.shape[1] // n_chan
-                if d_in != 128:  # every layer consumes 128 input columns: zero-pad layer 0
-                    w = torch.nn.functional.pad(w.view(dhid, n_chan, d_in), (0, 128 - d_in))
-                    w = w.reshape(dhid, n_chan * 128)
-                pk = ops.pack_rows_f16x2(w)
-                packs16.append(pk)
-                w16_off.append(off)
-                off += pk.numel()
-            packs16.append(torch.zeros(16384, dtype=torch.uint8, device=dev))  # prefetch slack
-            plan['Wp16'] = torch.cat(packs16)
-            plan['w16_off'] = w16_off
-            plan['Wp16_head'] = ops.pack_rows_f16x2(head)
-            plan['din0'] = din0  # this kernel pads columns itself
-            if emb is not None:
-                plan['embedding'] = self.embedding.weight.detach().float().contiguous()
-        elif self.gemm_mode not in ('fp32', 'bf16', 'f16x3'):
+            raise NotImplementedError(
+                "gemm_mode='f16x3' runs inside the strip kernel: LanczosNet / LanczosNetGeneral with "
+                "hidden width 128, input width <= 128, no short-diffusion scales, <= 12 long scales, "
+                "<= 32 channels in all, output width <= 31")
+        if self.gemm_mode not in ('fp32', 'bf16', 'f16x3'):
             raise ValueError("gemm_mode must be 'fp32', 'f16x3' (N <= 32) or 'bf16' (N > 32)")
         if self._has_mlp() and self.filter_kind == 0:
             plan['mlp_pack'] = ops.pack_spectral_mlp_layers(

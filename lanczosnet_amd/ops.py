@@ -375,7 +375,7 @@ def pack_rows_k8(W):
 
 def pack_rows_k8_split(W):
   """[rows, cols] (cols a multiple of 32) -> the weight stream of the split-precision strip kernel
-  (gemm_mode 2): fp16 hi / lo pieces at pack_rows_k8's size and offsets (include/lanczosnet_hip.h)."""
+  (gemm_mode 1): fp16 hi / lo pieces at pack_rows_k8's size and offsets (include/lanczosnet_hip.h)."""
   _need_cuda(W)
   W = _f32c(W)
   rows, cols = W.shape
@@ -383,18 +383,6 @@ def pack_rows_k8_split(W):
                     device=W.device)
   with torch.cuda.device(W.device):
     _abi().pack_rows_k8_split(W, rows, cols, cols, out)
-  return out
-
-
-def pack_rows_f16x2(W):
-  """[rows, cols] -> fp16 hi/lo pieces in v_mfma_f32_32x32x16_f16 fragment order (uint8 buffer)."""
-  _need_cuda(W)
-  W = _f32c(W)
-  rows, cols = W.shape
-  out = torch.empty((_abi().packed_rows_f16x2_bytes(rows, cols),), dtype=torch.uint8,
-                    device=W.device)
-  with torch.cuda.device(W.device):
-    _abi().pack_rows_f16x2(W, rows, cols, cols, out)
   return out
 
 
@@ -423,32 +411,19 @@ def pack_laplacian(L):
   return Lp
 
 
-def pack_laplacian_f16x2(L):
-  """L [B,N,N,C] -> fp16 hi/lo A fragments of the split-precision GEMM2 (uint8 buffer)."""
-  _need_cuda(L)
-  assert L.dim() == 4 and L.dtype == torch.float32
-  B, N, _, Cn = L.shape
-  out = torch.empty((B * Cn * 4096,), dtype=torch.uint8, device=L.device)
-  sb, sr, sc, sch = L.stride()
-  with torch.cuda.device(L.device):
-    _abi().pack_laplacian_f16x2(L, sb, sr, sc, sch, B, N, Cn, out)
-  return out
-
-
 def pack_laplacian_for(plan, L):
-  """The Laplacian pack the fused forward expects for `plan` (fp32 fragments, or fp16 hi/lo
-  fragments when the plan was built with gemm_mode='f16x3')."""
+  """The Laplacian pack the fused forward expects for `plan` (fp32 fragments in both GEMM modes)."""
   Lf = L if L.dtype == torch.float32 else L.float()
-  return pack_laplacian_f16x2(Lf) if plan.get('Wp16') is not None else pack_laplacian(Lf)
+  return pack_laplacian(Lf)
 
 
 def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
   """Everything the fused forward needs besides (V, G), in the fewest launches: the Laplacian pack
-  for `plan`, the tile plan and the live-eigen-slot list.  Exact-fp32 plans use the single
-  lnz_pack_laplacian_plan launch (the planner runs under the packing); the split-precision pack
-  falls back to two launches.  Returns (Lp, tiles, rows) for lanczosnet_forward / spectral_gains."""
+  for `plan`, the tile plan and the live-eigen-slot list: the single lnz_pack_laplacian_plan launch
+  (the planner runs under the packing) while a molecule's block fits the pack workgroup's LDS.
+  Returns (Lp, tiles, rows) for lanczosnet_forward / spectral_gains."""
   Lf = L if L.dtype == torch.float32 else L.float()
-  if plan.get('Wp16') is not None or Lf.shape[1] * Lf.shape[1] * Lf.shape[3] * 4 > 48 * 1024:
+  if Lf.shape[1] * Lf.shape[1] * Lf.shape[3] * 4 > 48 * 1024:
     tiles, rows = plan_batch(mask_u8, pairing_supported(plan), K, n_cu)
     return pack_laplacian_for(plan, Lf), tiles, rows
   _need_cuda(Lf, mask_u8)
@@ -487,7 +462,7 @@ def prepare_batch(plan, L, mask_u8, n_nodes, K, n_cu=None, pack_stream=None):
   # several waves per SIMD they are throughput bound and the 64-thread standalone kernel, which
   # does not carry three idle waves and a pack tile per workgroup, is faster (B = 8192: 0.55 vs
   # 0.80 ms).
-  if plan.get('Wp16') is not None or N > 32 or N * N * Cn * 4 > 40 * 1024 or \
+  if N > 32 or N * N * Cn * 4 > 40 * 1024 or \
       B > 8 * (n_cu or _n_cu(Lf.device)):
     Lp, tiles, rows = pack_and_plan(plan, Lf, mask_u8, K, n_cu)
     D, V = lanczos_ritz(Lf[:, :, :, 0], n_nodes, K)
@@ -529,7 +504,7 @@ def prepare_batch_prev_gains(plan, L, mask_u8, n_nodes, K, prev, gains, n_cu=Non
   Lf = L if L.dtype == torch.float32 else L.float()
   B, N, _, Cn = Lf.shape
   _need_cuda(Lf, mask_u8, n_nodes, prev[0])
-  assert plan.get('Wp16') is None and N <= 32 and N * N * Cn * 4 <= 20480
+  assert N <= 32 and N * N * Cn * 4 <= 20480
   n_cu = n_cu or _n_cu(Lf.device)
   cap = _abi().plan_wg_cap(B, n_cu)
   dev = Lf.device
@@ -682,9 +657,9 @@ def plan_tiles(mask_u8, allow_pairs, n_cu=None):
 
 
 def pairing_supported(plan):
-  """Pair tiles exist in the exact-fp32 kernels, whose spectral channels run in eigen space:
-  diagonal gains (LanczosNet) and dense K x K filters (AdaLanczosNet)."""
-  return plan.get('Wp16') is None
+  """Pair tiles exist in every forward kernel there is (the spectral channels run in eigen space:
+  diagonal gains of LanczosNet, dense K x K filters of AdaLanczosNet); kept for the callers that ask."""
+  return True
 
 
 def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tiling='auto',
@@ -701,7 +676,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   ready = getattr(Lp, 'ready', None)   # a pack on a second stream (prepare_batch(pack_stream=...))
   if ready is not None:
     torch.cuda.current_stream(Lp.device).wait_event(ready)
-  if Lp.dtype == torch.float32 and plan.get('Wp16') is None and act_out is None and not return_state:
+  if act_out is None and not return_state:
     return _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident)
   ops_, dims = _fused_operands(plan, V)
   emb = None
@@ -717,13 +692,10 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     ops_[_IN['node_feat_f']] = nf.contiguous()
   mask_u8 = mask.to(torch.uint8).contiguous()
   ops_[_IN['mask']] = mask_u8
-  if Lp.dtype == torch.uint8:   # split-precision fragments (pack_laplacian_f16x2)
-    ops_[_IN['Lp16']] = Lp
-  else:
-    ops_[_IN['Lp']] = Lp
-    ident = getattr(Lp, 'ident', None)  # identity-channel bits written by the pack kernels
-    if ident is not None and use_ident:
-      ops_[_IN['ident']] = ident
+  ops_[_IN['Lp']] = Lp
+  ident = getattr(Lp, 'ident', None)  # identity-channel bits written by the pack kernels
+  if ident is not None and use_ident:
+    ops_[_IN['ident']] = ident
   fk = int(plan.get('filter_kind', 0))
   if G is not None:
     want = (plan['num_layer'], B, plan['n_long'], K) + ((K,) if fk == 1 else ())
@@ -732,13 +704,8 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   ops_[_IN['G']] = G
   ops_[_IN['Wp']], ops_[_IN['bias']] = plan['Wp'], plan['bias']
   ops_[_IN['Wp_head']], ops_[_IN['bias_head']] = plan['Wp_head'], plan['bias_head']
-  gemm_mode = 1 if plan.get('Wp16') is not None else int(plan.get('gemm_mode', 0))
+  gemm_mode = int(plan.get('gemm_mode', 0))
   dims[_DIM['gemm_mode']] = gemm_mode
-  assert (gemm_mode == 1) == (Lp.dtype == torch.uint8), 'Lp pack does not match gemm_mode'
-  w16_off = []
-  if gemm_mode == 1:
-    ops_[_IN['Wp16']], ops_[_IN['Wp16_head']] = plan['Wp16'], plan['Wp16_head']
-    w16_off = [int(x) for x in plan['w16_off'][:plan['num_layer']]]
   # Tile plan: small molecules share a 32-row tile and the tiles are dealt, balanced by cost, over
   # one workgroup per CU (the launch is a single round: it lasts as long as its busiest CU).
   if isinstance(tiling, tuple):
@@ -748,7 +715,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     tiles, cap = plan_tiles(mask_u8, allow_pairs=(tiling == 'auto' and pairing_supported(plan)))
   if tiling != 'none':
     _set_plan(ops_, dims, tiles, cap)
-  if gemm_mode == 2 and ops_[_IN['strips']] is None:   # this mode exists on the strip plan only
+  if gemm_mode == 1 and ops_[_IN['strips']] is None:   # this mode exists on the strip plan only
     strips = plan_strips(mask_u8)
     scap = (strips.numel() - 1) // STRIP_INTS
     ops_[_IN['strips']], ops_[_IN['n_strips']] = strips, strips[scap * STRIP_INTS:]
@@ -762,7 +729,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
     state = torch.zeros((B, 32, plan['dhid']), dtype=torch.float32, device=V.device)
   nl = plan['num_layer']
   _ext().fused_launch(0, ops_, dims, [int(x) for x in plan['w_off'][:nl]],
-                      [int(x) for x in plan['b_off'][:nl]], w16_off, [int(p) for p in plan['short']],
+                      [int(x) for x in plan['b_off'][:nl]], [int(p) for p in plan['short']],
                       score, state, act_out, None, None, None, None, None, None)
   return (score, state) if return_state else score
 
@@ -770,7 +737,7 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
 # operand / scalar slots of torch.ops.lanczosnet.fused_launch (csrc/torch_ext.cpp: kIn / kDim)
 _IN = {k: i for i, k in enumerate(
     ['node_feat', 'node_feat_f', 'embedding', 'mask', 'Lp', 'V', 'G', 'Wp', 'bias', 'Wp_head',
-     'bias_head', 'Wp16', 'Wp16_head', 'Lp16', 'plan', 'n_wg', 'act', 'x0', 'ident', 'row_off',
+     'bias_head', 'plan', 'n_wg', 'act', 'x0', 'ident', 'row_off',
      'strips', 'n_strips'])}
 _DIM = {k: i for i, k in enumerate(
     ['B', 'N', 'K', 'num_layer', 'din0', 'dhid', 'dout', 'n_long', 'n_edge', 'num_atom', 'filter_kind',
@@ -863,7 +830,7 @@ def _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident):
   w_off, b_off, dims, short = consts
   ident = getattr(Lp, 'ident', None) if use_ident else None
   strips = getattr(tiles, 'strips', None)
-  if strips is None and plan.get('gemm_mode', 0) == 2:
+  if strips is None and plan.get('gemm_mode', 0) == 1:
     strips = plan_strips(mask_u8)   # the split-precision GEMM1 exists on the strip plan only
   scap = (strips.numel() - 1) // STRIP_INTS if strips is not None else 0
   return _ext().forward(nf, emb, Lp, ident, _f32c(V), G, mask_u8, plan['Wp'], plan['bias'], w_off,
@@ -906,7 +873,7 @@ def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling, row_off
   assert tuple(dx0.shape) == (B, 32, plan['din0']) and dx0.is_contiguous()
   dims[_DIM['din0']], dims[_DIM['bwd_din0']] = dh, plan['din0']
   ops_[_IN['Wp']], ops_[_IN['act']] = plan['Wp_t'], act
-  _ext().fused_launch(1, ops_, dims, [int(x) for x in plan['wt_off'][:L]], [], [],
+  _ext().fused_launch(1, ops_, dims, [int(x) for x in plan['wt_off'][:L]], [],
                       [int(p) for p in plan['short']], None, None, None, dy, dx0, None, None, dy_compact, dbias_part)
 
 
@@ -928,7 +895,7 @@ def lanczosnet_messages(plan, Lp, V, G, mask_u8, act, x0, layer, msg, tiling, ro
   if row_off is not None:
     assert row_off.dtype == torch.int64 and row_off.is_contiguous() and row_off.numel() == B
     ops_[_IN['row_off']] = row_off
-  _ext().fused_launch(2, ops_, dims, [], [], [], [int(p) for p in plan['short']], None, None, None,
+  _ext().fused_launch(2, ops_, dims, [], [], [int(p) for p in plan['short']], None, None, None,
                       None, None, msg, None, None, None)
 
 
@@ -948,7 +915,7 @@ def lanczosnet_gain_grad(plan, Lp, V, G, mask_u8, act, x0, dy, tiling):
   # zero-initialised: eigen slots beyond a molecule's row block (k >= split of a shared tile) are
   # dead (k >= n) and are not written
   dG = torch.zeros((L, B, K, S), dtype=torch.float32, device=V.device)
-  _ext().fused_launch(3, ops_, dims, [int(x) for x in plan['w_off'][:L]], [], [],
+  _ext().fused_launch(3, ops_, dims, [int(x) for x in plan['w_off'][:L]], [],
                       [int(p) for p in plan['short']], None, None, None, dy, None, None, dG, None, None)
   return dG
 

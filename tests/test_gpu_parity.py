@@ -527,17 +527,15 @@ def test_training_gradients_match_reference_autograd(impl):
   assert torch.isfinite(s2).all() and not torch.equal(s2, score.detach())
 
 
-@pytest.mark.parametrize('split_kernel', ['strips', 'tiles'])
-def test_split_precision_f16x3_mode_meets_parity_bar(split_kernel):
-  """Opt-in gemm_mode='f16x3' (fp16 hi/lo split GEMM1: inside the strip kernel on
-  v_mfma_f32_16x16x32_f16, or the older one-molecule-per-tile kernel on v_mfma_f32_32x32x16_f16):
-  same 1e-5 bar against the reference fixture and the fp64 oracle; measured deviation is reported."""
+def test_split_precision_f16x3_mode_meets_parity_bar():
+  """Opt-in gemm_mode='f16x3' (fp16 hi/lo split products inside the strip kernel on
+  v_mfma_f32_16x16x32_f16): same 1e-5 bar against the reference fixture and the fp64 oracle; measured
+  deviation is reported."""
   g = load_golden('lanczosnet_full.npz')
   c = load_golden('collate_batch.npz')
   cfg = dict(oracle.DEFAULT_QM8_CFG)
   P = oracle.make_lanczosnet_params(cfg, int(g['param_seed']))
   net = _model(cfg, P)
-  net.split_kernel = split_kernel
   args = (_t(c['node_feat']), _t(c['L']), _t(c['D']), _t(c['V']))
   with torch.no_grad():
     exact = net(*args, mask=_t(c['node_mask'])).cpu().numpy()

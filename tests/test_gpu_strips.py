@@ -226,7 +226,7 @@ def test_strip_launches_from_two_threads_on_fresh_streams():
       assert torch.equal(a, w)
 
 
-# ---- gemm_mode 2: split-precision GEMM1 (and block products) inside the strip kernel -------------
+# ---- gemm_mode 1: split-precision GEMM1 (and block products) inside the strip kernel -------------
 def _split_pack_mirror(W):
   """lnz_pack_rows_k8_split in numpy: [rt][32-k block][piece][lane slot][8 halves] (header)."""
   rows, cols = W.shape
@@ -286,7 +286,7 @@ def test_split_precision_strip_forward_meets_the_parity_bar(B, n_cu, nmin, nmax,
   for mode in ('fp32', 'f16x3'):
     net.gemm_mode = mode
     plan = net._plan()
-    assert plan['gemm_mode'] == (2 if mode == 'f16x3' else 0) and plan['Wp16'] is None
+    assert plan['gemm_mode'] == (1 if mode == 'f16x3' else 0)
     Lp = ops.pack_laplacian_for(plan, L)
     assert Lp.dtype == torch.float32
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
@@ -329,15 +329,15 @@ def test_split_precision_strip_forward_float_features_and_no_long_scales():
     feat = rs.randn(B, b['node_mask'].shape[1], 10).astype(np.float32) if general else b['node_feat']
     with torch.no_grad():
       got = net(t(feat), L, D, V, mask=t(b['node_mask'])).cpu().numpy()
-    assert net._plan()['gemm_mode'] == 2 and net._plan()['din0'] == 128
+    assert net._plan()['gemm_mode'] == 1 and net._plan()['din0'] == 128
     ref = oracle.lanczos_net_forward(P, cfg, feat, L.cpu().numpy(), D.cpu().numpy(), V.cpu().numpy(),
                                      b['node_mask'], dtype=np.float64, general=general)
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), general
 
 
 def test_split_precision_needs_the_strip_plan_and_says_so():
-  """gemm_mode 2 through the raw entry point without a strip plan, and a model with short-diffusion
-  channels (which keeps the older tile kernel): errors, not silent fallbacks."""
+  """gemm_mode 1 through the raw entry point without a strip plan, and a model with short-diffusion
+  channels (the split-precision instantiation has none): errors, not silent fallbacks."""
   from lanczosnet_amd import ops
   from lanczosnet_amd.synthetic import draw_batch
   cfg = dict(oracle.DEFAULT_QM8_CFG)
@@ -353,7 +353,7 @@ def test_split_precision_needs_the_strip_plan_and_says_so():
   G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
   ext = ops._ext()
   consts = ([int(x) for x in plan['w_off'][:7]], [int(x) for x in plan['b_off'][:7]],
-            [7, plan['din0'], 128, plan['dout'], plan['n_long'], plan['n_edge'], 0, 2], [])
+            [7, plan['din0'], 128, plan['dout'], plan['n_long'], plan['n_edge'], 0, 1], [])
   mk = t(b['node_mask'].astype(np.uint8))
   with pytest.raises(RuntimeError, match='strip plan'):
     ext.forward(t(b['node_feat']), plan['embedding'], Lp, None, V, G, mk, plan['Wp'], plan['bias'],
@@ -361,4 +361,5 @@ def test_split_precision_needs_the_strip_plan_and_says_so():
   cfg_s = dict(cfg, short_diffusion_dist=[1, 2])
   net_s, _ = _split_net(cfg_s, 3)
   net_s.gemm_mode = 'f16x3'
-  assert net_s._plan()['gemm_mode'] == 0 and net_s._plan()['Wp16'] is not None   # the tile kernel's packs
+  with pytest.raises(NotImplementedError, match='strip kernel'):
+    net_s._plan()
