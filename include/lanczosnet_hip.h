@@ -274,6 +274,23 @@ int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_ho
                             int num_layer, int kind, const float* mlp_pack, const int32_t* rows,
                             const int32_t* n_rows, float* G, lnz_stream_t stream);
 
+/* Training: parameter gradients of the spectral-filter MLPs of ALL conv layers from dG (the output of
+ * lnz_lanczosnet_gain_grad viewed as [num_layer][B*K][S]) in one launch — replaces autograd through
+ * the `spectral_filter[l]` Sequentials (model/lanczos_net.py:95-123,146-149: Linear(S,128), ReLU,
+ * Linear(128,128), ReLU, Linear(128,128), ReLU, Linear(128,S)).  ptrs[l*8 + {0..7}] = W0, b0, W2, b2,
+ * W4, b4, W6, b6 of layer l as for lnz_pack_spectral_mlp_layers (raw row-major parameters; b6 is not
+ * read).  rows / n_rows: the live eigen rows of lnz_plan_batch (NULL, NULL = every row of D); rows
+ * of dG outside that list are not read.  Every one of the `parts` workgroups of a layer (parts <=
+ * lnz_spectral_mlp_grad_parts(rows upper bound, num_layer, n_cu)) writes one partial of each
+ * gradient; the gradient is the sum of a layer's partials over that index (any fixed order):
+ *   dW0 [L][parts][128][S], dW2, dW4 [L][parts][128][128], dW6 [L][parts][S][128],
+ *   db [L][parts][3][128] (b0, b2, b4), db6 [L][parts][S].      S <= 8; exact fp32. */
+int lnz_spectral_mlp_grad_parts(int n_rows_max, int num_layer, int n_cu);
+int lnz_spectral_mlp_grad(const float* D, int B, int K, const int32_t* dist_host, int S,
+                          int num_layer, const int32_t* rows, const int32_t* n_rows, const float* dG,
+                          const float* const* ptrs, int parts, float* dW0, float* dW2, float* dW4,
+                          float* dW6, float* db, float* db6, lnz_stream_t stream);
+
 /* ---- R7 (second half) + R9 + R10: fused LanczosNet forward ------------------------------
  * One workgroup per molecule runs the whole network on chip: embedding gather, then per conv
  * layer  X' = relu( sum_c M_c X W_c^T + b )  with M_c in message order
@@ -366,6 +383,10 @@ typedef struct lnz_forward_args {
                                  l) = column sums of dLoss/dY_l over the node tiles of half h of
                                  workgroup g, for l = 0 .. num_layer-2; their sum over the first
                                  index (any fixed order) is the bias gradient of conv layer l      */
+  int32_t dbias_part_cap;     /* entries (first index) of dbias_part; 0 = 2 * plan_wg_cap.  The pass
+                                 runs on the strip plan (one entry per strip) when strip_cap fits,
+                                 on 32-row tiles (two entries per workgroup) otherwise: size it
+                                 max(2 * plan_wg_cap, strip_cap) to get the strips                 */
   /* ---- forward, optional (ABI 5): strip plan of lnz_plan_strips.  With it the exact-fp32
    * inference forward of a diagonal-gain model without short-diffusion channels runs on strips of
    * 16-row subtiles (conv_strip.hip) instead of 32-row tiles; every other launch ignores it. */

@@ -44,6 +44,7 @@ class ForwardArgs(C.Structure):
       ('act_out', C.c_void_p), ('act', C.c_void_p), ('dy', C.c_void_p), ('dx0', C.c_void_p),
       ('bwd_din0', C.c_int32), ('x0', C.c_void_p), ('msg', C.c_void_p), ('msg_layer', C.c_int32), ('ident', C.c_void_p), ('row_off', C.c_void_p), ('dgains', C.c_void_p),
       ('dy_compact', C.c_void_p), ('dy_compact_rows', C.c_int64), ('dbias_part', C.c_void_p),
+      ('dbias_part_cap', C.c_int32),
       ('strips', C.c_void_p), ('n_strips', C.c_void_p), ('strip_cap', C.c_int),
   ]
 
@@ -91,6 +92,8 @@ SIGNATURES = {
     'lnz_spectral_mlp_pack_size': (C.c_int64, [_I]),
     'lnz_pack_spectral_mlp': (C.c_int, [_P] * 8 + [_I, _P, _P]),
     'lnz_pack_spectral_mlp_layers': (C.c_int, [_P, _I, _I, _P, _P]),
+    'lnz_spectral_mlp_grad_parts': (C.c_int, [_I, _I, _I]),
+    'lnz_spectral_mlp_grad': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     'lnz_spectral_gains': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P]),
     'lnz_spectral_gains_rows': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_lanczosnet_input_grad': (C.c_int, [C.POINTER(ForwardArgs), _P]),

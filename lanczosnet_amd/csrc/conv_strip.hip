@@ -782,7 +782,7 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
               if (lrow0 + r < nmol) dc[r * 128] = v[r];
           }
         }
-        if (a.dbias_part && (int)blockIdx.x < 2 * a.plan_wg_cap) {
+        if (a.dbias_part && (int)blockIdx.x < (a.dbias_part_cap > 0 ? a.dbias_part_cap : 2 * a.plan_wg_cap)) {
           colsum += __shfl_xor(colsum, 16, 64);
           colsum += __shfl_xor(colsum, 32, 64);
           if (kq == 0)
@@ -1126,9 +1126,12 @@ bool strip_forward_eligible(const lnz_forward_args& a, int mode) {
     return false;
   if (a.dhid != 128 || a.din0 % 64 != 0 || a.din0 > 128) return false;
   if (mode == 1 && (a.din0 != 128 || a.bwd_din0 % 16 != 0)) return false;
-  // dbias_part is sized by the TILE plan ([2 * plan_wg_cap] entries) and indexed by strip here: a
-  // strip beyond it would drop its bias-gradient partial, so such a launch stays on the tile kernel
-  if (mode == 1 && a.dbias_part && (!a.plan || a.strip_cap > 2 * a.plan_wg_cap)) return false;
+  // dbias_part is indexed by strip here: a strip beyond its entries (dbias_part_cap, or the tile
+  // plan's 2 * plan_wg_cap) would drop its bias-gradient partial, so such a launch stays on the tile
+  // kernel
+  if (mode == 1 && a.dbias_part &&
+      a.strip_cap > (a.dbias_part_cap > 0 ? a.dbias_part_cap : (a.plan ? 2 * a.plan_wg_cap : 0)))
+    return false;
   if (a.n_short + a.n_long + a.n_edge > 32 || a.n_edge < 1 || a.n_long > 12 || a.dout > 31) return false;
   if (a.filter_kind == 1 && a.K % 4 != 0) return false;
   if ((int64_t)a.B * a.n_edge * 4096 >= (1ll << 31)) return false;

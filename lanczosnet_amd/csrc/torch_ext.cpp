@@ -148,9 +148,11 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
   if (a.dy_compact)
     TORCH_CHECK(dy_compact->numel() >= (int64_t)a.num_layer * a.dy_compact_rows * a.dhid && a.row_off,
                 "lanczosnet::fused_launch: dy_compact needs [num_layer, rows, dhid] and row_off");
-  if (a.dbias_part)
+  if (a.dbias_part) {
     TORCH_CHECK(dbias_part->numel() >= 2 * (int64_t)(a.plan ? a.plan_wg_cap : (a.B + 3) / 4) * a.num_layer * a.dhid,
                 "lanczosnet::fused_launch: dbias_part shorter than [2 * workgroups, num_layer, dhid]");
+    a.dbias_part_cap = (int32_t)(dbias_part->numel() / ((int64_t)a.num_layer * a.dhid));
+  }
   const c10::DeviceGuard guard(v->device());
   int rc;
   switch (which) {

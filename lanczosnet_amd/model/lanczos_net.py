@@ -44,6 +44,9 @@ class _LanczosNetBase(nn.Module):
     # graphs beyond 32 nodes, fp32-grade mode of the streamed kernels: 3 = three bf16 pieces per
     # operand (six products), 2 = two fp16 pieces (three products, 2/3 of the operand bytes)
     large_split_planes = int(os.environ.get('LANCZOSNET_LARGE_PLANES', '3'))
+    # spectral-filter MLP gradients in the HIP backward: 'hip' = lnz_spectral_mlp_grad (one launch),
+    # 'torch' = autograd through batched library GEMMs (the oracle that kernel is tested against)
+    mlp_grad_impl = os.environ.get('LANCZOSNET_MLP_GRAD', 'hip')
     # 'hip' = HIP backward kernels where built (LanczosNet, width 128); 'torch' = autograd through
     # the torch recomputation everywhere (the gradient oracle the HIP backward is tested against)
     backward_impl = os.environ.get('LANCZOSNET_BACKWARD', 'hip')
@@ -850,7 +853,10 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     # (graph capture: rows past the real count are never written — zeros, they meet zero messages)
     dyc = (torch.zeros if static_rows else torch.empty)((Lnum, R_tot, dh), dtype=torch.float32,
                                                         device=dev)
-    dbp = torch.zeros((2 * tiles[1], Lnum, dh), dtype=torch.float32, device=dev)
+    # (one entry per strip when the plan carries strips: the pass then runs on them)
+    strips_ = getattr(tiles[0], 'strips', None)
+    n_part = max(2 * tiles[1], (strips_.numel() - 1) // ops.STRIP_INTS if strips_ is not None else 0)
+    dbp = torch.zeros((n_part, Lnum, dh), dtype=torch.float32, device=dev)
     ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles, row_off=row_off,
                               dy_compact=dyc, dbias_part=dbp)
 
@@ -995,7 +1001,25 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
                 R = torch.matmul(dYv[:, la], Wl.reshape(dh, S * d)).view(B, K, S, d)
                 dG.append((R * Xv.unsqueeze(2)).sum(dim=3))             # [B,K,S]
             dG = torch.stack(dG).reshape(Lnum, B * K, S)               # [L, B*K, S]
-        if S > 0 and m._has_mlp():
+        lin_idx = ([i for i, mod in enumerate(m.spectral_filter[0]) if isinstance(mod, nn.Linear)]
+                   if S > 0 and m._has_mlp() else [])
+        if (S > 0 and m._has_mlp() and m.mlp_grad_impl == 'hip' and S <= 8 and len(lin_idx) == 4
+                and dG.is_contiguous()):
+            # one launch for every layer's MLP (csrc/spectral_gains_grad.hip): forward recomputation,
+            # the chain of ReLU masks and all eight parameter gradients on chip, live rows only
+            layers = [[(m.spectral_filter[t][i].weight, m.spectral_filter[t][i].bias) for i in lin_idx]
+                      for t in range(Lnum)]
+            rows_max = B * K
+            if live_rows is not None and not ctx.static_rows:
+                rows_max = min(int(ctx.rtot[0]), B * K)   # (sum of node extents >= live eigen rows)
+            gl = ops.spectral_mlp_grad(D.float(), m.long_diffusion_dist, layers, dG,
+                                       rows=(live_rows, n_live) if live_rows is not None else None,
+                                       rows_max=rows_max)
+            for li, i in enumerate(lin_idx):
+                for t in range(Lnum):
+                    grads[id(m.spectral_filter[t][i].weight)] = gl[li][0][t]
+                    grads[id(m.spectral_filter[t][i].bias)] = gl[li][1][t]
+        elif S > 0 and m._has_mlp():
             pows = torch.stack([torch.pow(D.float(), p) for p in m.long_diffusion_dist],
                                dim=2).view(B * K, S)
             if live_rows is not None and not ctx.static_rows:
@@ -1010,7 +1034,6 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
                 pows = pows.index_select(0, idx)
                 dG = dG.index_select(1, idx) * keep.view(1, R_live, 1)
             pows = pows.unsqueeze(0).expand(Lnum, pows.shape[0], S)
-            lin_idx = [i for i, mod in enumerate(m.spectral_filter[0]) if isinstance(mod, nn.Linear)]
             with torch.enable_grad():
                 h = pows
                 for li, i in enumerate(lin_idx):

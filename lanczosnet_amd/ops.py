@@ -585,6 +585,38 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True)
                                bool(zero_fill))
 
 
+def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
+  """lnz_spectral_mlp_grad: parameter gradients of the spectral-filter MLPs of every conv layer from
+  dG [L, B*K, S] in one launch.  layers: per conv layer the 4 (weight, bias) pairs of its
+  `spectral_filter[l]` (raw parameters).  rows: (gain_rows, n_gain_rows) of plan_batch() or None;
+  rows_max: host-side upper bound of the live row count (sizes the grid; default B*K).  Returns
+  [(dW0, db0), (dW2, db2), (dW4, db4), (dW6, db6)], each stacked over the layers ([L, ...])."""
+  _need_cuda(D, dG)
+  D = _f32c(D)
+  B, K = D.shape
+  S, L = len(dist), len(layers)
+  assert dG.is_contiguous() and dG.dtype == torch.float32 and tuple(dG.shape) == (L, B * K, S)
+  keep = []
+  for lins in layers:
+    assert [tuple(w.shape) for (w, _) in lins] == [(128, S), (128, 128), (128, 128), (S, 128)], \
+        'lnz_spectral_mlp_grad is built for the reference\'s S-128-128-128-S filter MLP'
+    for (w, b) in lins:
+      keep += [_f32c(w.detach()), _f32c(b.detach())]
+  dev = D.device
+  parts = _abi().spectral_mlp_grad_parts(int(rows_max or B * K), L, _n_cu(dev))
+  f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+  dW0, dW2, dW4, dW6 = f(L, parts, 128, S), f(L, parts, 128, 128), f(L, parts, 128, 128), f(L, parts, S, 128)
+  db, db6 = f(L, parts, 3, 128), f(L, parts, S)
+  with torch.cuda.device(dev):
+    _abi().spectral_mlp_grad(D, B, K, [int(x) for x in dist], S, L,
+                             rows[0] if rows is not None else None,
+                             rows[1] if rows is not None else None, dG, keep, parts, dW0, dW2, dW4, dW6,
+                             db, db6)
+  dbs = db.sum(dim=1)   # the partials, added in a fixed order
+  return [(dW0.sum(dim=1), dbs[:, 0]), (dW2.sum(dim=1), dbs[:, 1]), (dW4.sum(dim=1), dbs[:, 2]),
+          (dW6.sum(dim=1), db6.sum(dim=1))]
+
+
 def collate_qm8(shard, ids, N, E, P):
   """lnz_collate_qm8: device arrays of a packed shard (dataset/packed.py) + molecule ids [B] ->
   padded batch dict (node_feat, node_mask, label, L [B,N,N,E+1], n_nodes)."""
@@ -853,7 +885,8 @@ def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling, row_off
   fills dy[0..num_layer-2] and dx0 [B,32,din0].  plan['Wp_t'] / plan['wt_off']: transposed packs in
   kernel-layer order (LanczosNet._plan_backward).  All buffers zero-initialised by the caller.
   Optional: dy_compact [num_layer, R, dhid] with row_off [B] int64 — slots 0 .. num_layer-2 receive
-  the same gradients in the compact row numbering of the message matrix; dbias_part [2 * cap,
+  the same gradients in the compact row numbering of the message matrix; dbias_part [>= 2 * cap (with
+  max(2 * cap, strip entries) the pass runs on the strip plan),
   num_layer, dhid] (zero-initialised) — per workgroup half the column sums of dY_l, l <= num_layer-2."""
   _need_cuda(Lp, V, G, mask_u8, act, dy, dx0, row_off, dy_compact, dbias_part)
   ops_, dims = _training_args(plan, Lp, V, G, mask_u8, tiling)
@@ -864,7 +897,8 @@ def lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiling, row_off
     ops_[_IN['row_off']] = row_off
     dims[_DIM['dy_compact_rows']] = int(dy_compact.shape[1])
   if dbias_part is not None:
-    assert tuple(dbias_part.shape) == (2 * tiling[1], plan['num_layer'], plan['dhid']) and \
+    assert dbias_part.shape[0] >= 2 * tiling[1] and \
+        tuple(dbias_part.shape[1:]) == (plan['num_layer'], plan['dhid']) and \
         dbias_part.is_contiguous() and dbias_part.dtype == torch.float32
   B = V.shape[0]
   L, dh = plan['num_layer'], plan['dhid']

@@ -1,0 +1,100 @@
+"""lnz_spectral_mlp_grad (csrc/spectral_gains_grad.hip): the parameter gradients of the spectral-filter
+MLPs of all conv layers from dG in one launch, against float64 autograd through the same
+nn.Sequential chain (the reference's own route: model/lanczos_net.py:95-123,146-149), on row lists
+with ragged tails, with and without the live-row list, for other S and layer counts; and the
+training step that uses it against the one that keeps autograd + library GEMMs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _mlps(rs, L, S):
+  return [[(torch.from_numpy(rs.randn(o, i).astype(np.float32) / np.sqrt(i)).to(DEV),
+            torch.from_numpy((0.1 * rs.randn(o)).astype(np.float32)).to(DEV))
+           for (o, i) in ((128, S), (128, 128), (128, 128), (S, 128))] for _ in range(L)]
+
+
+def _autograd64(D, dist, layers, dG, idx):
+  pows = torch.stack([torch.pow(D.double(), p) for p in dist], dim=2).view(-1, len(dist))
+  out = []
+  for l, lins in enumerate(layers):
+    ps = [(w.double().requires_grad_(True), b.double().requires_grad_(True)) for (w, b) in lins]
+    h = pows[idx]
+    for i, (w, b) in enumerate(ps):
+      h = h @ w.t() + b
+      if i < 3:
+        h = torch.relu(h)
+    g = torch.autograd.grad(h, [t for wb in ps for t in wb], dG[l].double()[idx])
+    out.append(g)
+  return out   # [layer][W0, b0, W2, b2, W4, b4, W6, b6]
+
+
+@pytest.mark.parametrize('B,K,S,L,live', [(1024, 20, 7, 7, True), (1024, 20, 7, 7, False), (37, 20, 7, 2, True),
+                                          (3, 8, 1, 1, False), (200, 12, 8, 16, True), (64, 20, 3, 5, True)])
+def test_mlp_grad_matches_float64_autograd(B, K, S, L, live):
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(B + S)
+  dist = [1, 2, 3, 5, 7, 10, 20, 30][:S]
+  D = torch.from_numpy((rs.rand(B, K) * 1.9 - 0.95).astype(np.float32)).to(DEV)   # |lambda(L4)| <= 1
+  layers = _mlps(rs, L, S)
+  dG = torch.from_numpy(rs.randn(L, B * K, S).astype(np.float32)).to(DEV)
+  rows = None
+  idx = torch.arange(B * K, device=DEV)
+  if live:   # a ragged subset in ascending order, as lnz_plan_batch lists the live eigen slots
+    n = rs.randint(1, K + 1, size=B)
+    keep = np.concatenate([b * K + np.arange(n[b]) for b in range(B)]).astype(np.int32)
+    buf = np.full(B * K, -7, np.int32)
+    buf[:len(keep)] = keep
+    rows = (torch.from_numpy(buf).to(DEV), torch.tensor([len(keep)], dtype=torch.int32, device=DEV))
+    idx = torch.from_numpy(keep.astype(np.int64)).to(DEV)
+  got = ops.spectral_mlp_grad(D, dist, layers, dG, rows=rows, rows_max=int(idx.numel()))
+  want = _autograd64(D, dist, layers, dG, idx)
+  worst = 0.0
+  for l in range(L):
+    for li in range(4):
+      for which in range(2):
+        g = got[li][which][l].double()
+        w = want[l][2 * li + which]
+        assert g.shape == w.shape
+        e = float((g - w).abs().max() / w.abs().max().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 2e-5, (l, li, which, e)
+  print('spectral MLP gradients vs float64 autograd: worst %.2e of max |g| (B=%d K=%d S=%d L=%d rows=%d)'
+        % (worst, B, K, S, L, int(idx.numel())))
+  # deterministic: partials are added in a fixed order
+  again = ops.spectral_mlp_grad(D, dist, layers, dG, rows=rows, rows_max=int(idx.numel()))
+  for a, b in zip(got, again):
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_training_step_with_the_mlp_grad_kernel_matches_the_autograd_route():
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNet
+  from lanczosnet_amd.synthetic import draw_batch
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net = LanczosNet(make_model_config(cfg)).train()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in oracle.make_lanczosnet_params(cfg, 9).items()})
+  net = net.to(DEV)
+  b = draw_batch(300, seed=2, n_min=2)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+  grads = {}
+  for impl in ('hip', 'torch'):
+    net.mlp_grad_impl = impl
+    net.zero_grad(set_to_none=True)
+    _, loss = net(t(b['node_feat']), L, D, V, label=t(b['label']), mask=t(b['node_mask']))
+    loss.backward()
+    grads[impl] = {k: p.grad.clone() for k, p in net.named_parameters()}
+  for k in grads['hip']:
+    a, w = grads['hip'][k].double(), grads['torch'][k].double()
+    assert float((a - w).abs().max()) <= 2e-5 * float(w.abs().max()) + 1e-12, k
+    if 'spectral_filter' not in k:
+      assert torch.equal(grads['hip'][k], grads['torch'][k]), k   # (everything else is the same code)
