@@ -22,12 +22,16 @@
 extern "C" {
 #endif
 
-/* 4: + lnz_large_pack_operators_fold, lnz_f32_linear_workspace_floats (stream-K inside
+/* 6: lnz_forward_args lost Wp16 / w16_off / Wp16_head / Lp16 (gemm_mode 1 is now the split precision
+ *    inside the strip kernel: lnz_pack_rows_k8_split; lnz_pack_rows_f16x2 and
+ *    lnz_pack_laplacian_f16x2 are gone) and gained dbias_part_cap; + lnz_midgraph_forward,
+ *    lnz_spectral_mlp_grad;  5: + the strip plan (lnz_plan_strips, strips / n_strips / strip_cap);
+ * 4: + lnz_large_pack_operators_fold, lnz_f32_linear_workspace_floats (stream-K inside
  *    lnz_f32_linear: the partials argument changed its size and gained a zero-on-entry tail);
  * 3: + lnz_f32_linear, lnz_laplacian, the fp64 training kernels of the AdaLanczosNet spectrum
  *    (lnz_ada_graph_laplacian_f64, lnz_ada_lanczos_layer_f64, lnz_ada_t_powers_f64 and their
  *    _backward);  2: + lnz_lanczos_ritz_ws / _workspace_bytes, lnz_f16x3_*. */
-#define LNZ_ABI_VERSION 5
+#define LNZ_ABI_VERSION 6
 #define LNZ_OK 0
 #define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
 #define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */
@@ -387,9 +391,10 @@ typedef struct lnz_forward_args {
                                  runs on the strip plan (one entry per strip) when strip_cap fits,
                                  on 32-row tiles (two entries per workgroup) otherwise: size it
                                  max(2 * plan_wg_cap, strip_cap) to get the strips                 */
-  /* ---- forward, optional (ABI 5): strip plan of lnz_plan_strips.  With it the exact-fp32
-   * inference forward of a diagonal-gain model without short-diffusion channels runs on strips of
-   * 16-row subtiles (conv_strip.hip) instead of 32-row tiles; every other launch ignores it. */
+  /* ---- optional (ABI 5): strip plan of lnz_plan_strips.  With it the width-128 launches run on
+   * strips of 16-row subtiles (conv_strip.hip) instead of 32-row tiles: the forward (inference and
+   * training, both GEMM modes; gemm_mode 1 exists on strips only), the input-gradient pass (see
+   * dbias_part_cap) and the gain-gradient pass.  lnz_lanczosnet_messages ignores it. */
   const int32_t* strips;      /* [strip_cap][LNZ_STRIP_INTS] int32                                   */
   const int32_t* n_strips;    /* device scalar: strips in use                                        */
   int strip_cap;              /* lnz_strip_cap(B): entries in `strips` (= grid size)                 */
