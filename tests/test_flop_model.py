@@ -105,3 +105,21 @@ def test_tile_masks_follow_row_group_mask():
   fm = forward_mfma_issued(t, QM8_CFG)
   assert fm['tiles'] == 3 and fm['mfma_issued'] < fm['mfma_unskipped']
   assert abs(fm['useful_row_frac'] - (26 + 7 + 20 + 16 + 9) / 96.0) < 1e-12
+
+
+def test_split_precision_strip_model_counts_subtile_pairs():
+  """strip_split_mfma_issued: a row subtile's block products run over the (2p, 2p+1) subtile pairs its
+  neighbourhood {I-1, I, I+1} meets — counted independently here; the launch total of the bench batch
+  equals the SQ_INSTS_VALU_MFMA_MOPS_F16 / _F32 counters (profiles/r05_split_strip_pmc.txt)."""
+  from lanczosnet_amd.utils.flop_model import strip_split_mfma_issued
+  cfg = QM8_CFG
+  for S in range(1, 7):
+    want_pairs = sum(len({J >> 1 for J in (I - 1, I, I + 1) if 0 <= J < S}) for I in range(S))
+    got = strip_split_mfma_issued([dict(sub=S)], cfg)
+    C, n_edge, nl = 15, 7, 7
+    f16 = sum(8 * 3 * (C * 4 * S + (n_edge + 1 + (1 if l + 1 < nl else 0)) * want_pairs) for l in range(nl))
+    assert got['mfma_f16_issued'] == f16, S
+    assert got['mfma_f32_issued'] == 8 * 4 * (3 * S - 2) + 64 * S, S
+  # the bench batch's plan: 243 strips of five subtiles and one of two
+  tot = strip_split_mfma_issued([dict(sub=5)] * 243 + [dict(sub=2)], cfg)
+  assert tot['mfma_f16_issued'] == 15524592 and tot['mfma_f32_issued'] == 179104
