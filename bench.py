@@ -753,7 +753,8 @@ def main():
     if events and all_stages:
       events[1].record()
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
-                           rows=rows, zero_fill=not ops.pairing_supported(plan))
+                           rows=rows, zero_fill=not ops.pairing_supported(plan),
+                           split_pack=Lp if plan.get('gemm_mode', 0) == 1 else None)
     if events and all_stages:
       events[2].record()
     if events:
@@ -860,6 +861,14 @@ def main():
         s2 = step()
       torch.cuda.synchronize()
       el2 = time.perf_counter() - t1
+      # the stages of this mode's step (the gains launch carries the pack's conversion along)
+      evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(min(args.steps, 20))]
+      for e_ in evs:
+        step(e_, all_stages=True)
+      torch.cuda.synchronize()
+      split_stage_ms = {'prepare_batch(plan+lanczos_ritz+pack)': round(float(np.mean([e_[0].elapsed_time(e_[1]) for e_ in evs])), 4),
+                        'spectral_gains(+pack conversion)': round(float(np.mean([e_[1].elapsed_time(e_[2]) for e_ in evs])), 4),
+                        'lanczosnet_forward': round(float(np.mean([e_[4].elapsed_time(e_[5]) for e_ in evs])), 4)}
       Lp = ops.pack_laplacian_for(plan, L)
       D, V = ops.lanczos_ritz(A, n_nodes, K)
       G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
@@ -885,8 +894,9 @@ def main():
     mode_txt = ('f16x3 on the strip plan (lanczosnet_strip_kernel<.., HALF>, gemm_mode 1): X W^T as x_hi w_hi '
                 '+ x_lo w_hi + x_hi w_lo on v_mfma_f32_16x16x32_f16, fp32 accumulate, node state in LDS as '
                 'fp16 hi | lo pieces; the Laplacian products, the lift and the projection in the same '
-                'split (operands split in the kernel); gains, biases, activations, head exact fp32; the '
-                'rest of the step is the exact path\'s (same pack, same plan, same Ritz pairs) — opt-in, '
+                'split (Ritz blocks split once per launch, the Laplacian pack converted in place by '
+                'workgroups that ride along with the gains launch); gains, biases, activations, head exact '
+                'fp32; the rest of the step is the exact path\'s (same plan, same Ritz pairs) — opt-in, '
                 'parity-tested at the same 1e-5 bar')
     roof_note = ('issued f16 matrix flops (16384 x the v_mfma_f32_16x16x32_f16 the strip plan issues: %d per '
                  'launch, + %d v_mfma_f32_16x16x4_f32): three split products per fp32 product, so the '
@@ -895,6 +905,7 @@ def main():
     split = {'mode': mode_txt,
              'value': round(B * args.steps / el2, 1), 'unit': 'molecules/s',
              'ms_per_step': round(1e3 * el2 / args.steps, 4),
+             'stage_ms': split_stage_ms,
              'forward_ms': round(fwd2_ms, 4),
              'forward_ms_note': 'mean of %d back-to-back launches behind 5 warm ones (HIP events)' % N_FWD,
              'max_rel_dev_vs_fp32_path': dev_rel,

@@ -295,6 +295,19 @@ int lnz_spectral_mlp_grad(const float* D, int B, int K, const int32_t* dist_host
                           const float* const* ptrs, int parts, float* dW0, float* dW2, float* dW4,
                           float* dW6, float* db, float* db6, lnz_stream_t stream);
 
+/* ... and, riding along with the MLP launch (kind 0), the conversion of the batch's packed Laplacian
+ * (lp_floats floats at Lp_split, e.g. B * C * 1024 of lnz_pack_laplacian*) into the form the
+ * split-precision forward reads (lnz_forward_args.gemm_mode = 1), IN PLACE: every fragment float4
+ * becomes 4 fp16 hi pieces | 4 lo pieces.  The launch sits between the pack and the forward anyway
+ * and is bound by the matrix pipe; the conversion's workgroups run behind the MLP's.  Lp_split NULL
+ * = lnz_spectral_gains_rows.  lnz_split_laplacian_pack is the same conversion as a launch of its
+ * own (models without spectral MLPs).  A converted pack is of no use to gemm_mode 0. */
+int lnz_spectral_gains_rows_split(const float* D, int B, int K, const int32_t* dist_host, int S,
+                                  int num_layer, int kind, const float* mlp_pack, const int32_t* rows,
+                                  const int32_t* n_rows, float* G, float* Lp_split, int64_t lp_floats,
+                                  lnz_stream_t stream);
+int lnz_split_laplacian_pack(float* Lp, int64_t n_floats, lnz_stream_t stream);
+
 /* ---- R7 (second half) + R9 + R10: fused LanczosNet forward ------------------------------
  * One workgroup per molecule runs the whole network on chip: embedding gather, then per conv
  * layer  X' = relu( sum_c M_c X W_c^T + b )  with M_c in message order
@@ -337,8 +350,9 @@ typedef struct lnz_forward_args {
    * v_mfma_f32_16x16x32_f16, fp32 accumulate; Wp = lnz_pack_rows_k8_split of the same matrices at the
    * same offsets, followed by 32 KiB of slack (the weight ring over-reads 16 KiB); the node state
    * lives in LDS as fp16 hi | lo blocks; the products with the Laplacian blocks and the Ritz blocks
-   * (projection, lift) run in the same three-product split, their operands split in the kernel (Lp
-   * and V are the exact kernel's); gains, biases, activations and the head are exact fp32.  Measured
+   * (projection, lift) run in the same three-product split: V is the exact kernel's (split once per
+   * launch), Lp is the exact kernel's pack converted in place by lnz_spectral_gains_rows_split /
+   * lnz_split_laplacian_pack; gains, biases, activations and the head are exact fp32.  Measured
    * 1e-6 .. 2e-6 against float64 (exact path: 2e-7 .. 3e-7); parity bar 1e-5. */
   int32_t gemm_mode;
   const int32_t* plan;        /* optional tile plan (lnz_plan_tiles): [plan_wg_cap][4][3] int32, slot s

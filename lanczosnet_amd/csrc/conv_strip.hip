@@ -585,7 +585,12 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
     auto apply_all = [&](f32x4 (&acc)[S], const f32x4 (&Zp)[S]) {
       if constexpr (HALF) {
         apply_split(acc, Zp, [&](int I, int d, int q, f16x8& ah, f16x8& al) {
-          split_into(mop[I][d], q, ah, al);
+          // the pack holds a fragment as 4 hi | 4 lo pieces (lnz_spectral_gains_rows_split /
+          // lnz_split_laplacian_pack): splitting the 3 S - 2 fragments of an edge type here, in every
+          // one of the eight waves and in every layer, was 11 % of the launch
+          const f16x8 f = __builtin_bit_cast(f16x8, mop[I][d]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ah[4 * q + e] = f[e], al[4 * q + e] = f[4 + e];
         });
         return;
       }

@@ -1,6 +1,7 @@
 // Operand packing into v_mfma_f32_32x32x2_f32 fragment order, error state, ABI version.
 #include "common.hpp"
 #include "prep.hpp"
+#include "split_pack.hpp"
 
 namespace lnz {
 static thread_local char g_err[512] = "";
@@ -101,6 +102,20 @@ extern "C" int lnz_pack_rows_k8_split(const float* W, int rows, int cols, int64_
   hipLaunchKernelGGL(pack_rows_k8_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W,
                      rows, cols, ld, RT, NB, (uint4*)Wp);
   return lnz::check_launch("lnz_pack_rows_k8_split");
+}
+
+__global__ __launch_bounds__(256) void split_laplacian_pack_kernel(float4* __restrict__ p, int64_t n4) {
+  lnz::split_pack_chunk<256>(p, n4, blockIdx.x, threadIdx.x);
+}
+
+extern "C" int lnz_split_laplacian_pack(float* Lp, int64_t n_floats, lnz_stream_t stream) {
+  LNZ_REQUIRE(Lp && n_floats > 0 && n_floats % 4 == 0, LNZ_EINVAL,
+              "lnz_split_laplacian_pack: bad arguments (n_floats=%lld)", (long long)n_floats);
+  const int64_t n4 = n_floats / 4, blocks = (n4 + lnz::kSplitChunk - 1) / lnz::kSplitChunk;
+  LNZ_REQUIRE(blocks < (1ll << 31), LNZ_ENOTSUP, "lnz_split_laplacian_pack: pack too large");
+  hipLaunchKernelGGL(split_laplacian_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (float4*)Lp, n4);
+  return lnz::check_launch("lnz_split_laplacian_pack");
 }
 
 // bp[rt][lane][r] = bias[32 rt + cd_row(r, lane >> 5)]

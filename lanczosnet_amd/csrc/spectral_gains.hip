@@ -12,6 +12,7 @@
 // per row.  grid = (row tiles, conv layers): B*K/32 * L workgroups (4480 for B=1024) >> 256 CUs.
 #include "common.hpp"
 #include "gains_body.hpp"
+#include "split_pack.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -27,14 +28,31 @@ __global__ void pack_w0_kernel(const float* __restrict__ W0, int S, float* __res
   out[idx] = f < S ? W0[(32 * ot + (lane & 31)) * S + f] : 0.0f;
 }
 
+// A byte mover that rides along (lnz_spectral_gains_rows_split): the workgroups behind the MLP's
+// (blockIdx.x >= main_x) turn the batch's packed Laplacian into the split-precision strip kernel's
+// form in place, one 16 KiB chunk each — the gains launch sits between the pack and the forward
+// anyway, is bound by the matrix pipe and touches no memory to speak of.
+struct SplitRide {
+  float4* pack;     // NULL: nothing rides along
+  int64_t n4;       // float4 words
+  int main_x;       // gridDim.x of the MLP part
+};
+__device__ __forceinline__ bool ride_along(const SplitRide& r, const int lane) {
+  if (!r.pack || (int)blockIdx.x < r.main_x) return false;
+  const int64_t chunk = (int64_t)(blockIdx.x - r.main_x) * gridDim.y + blockIdx.y;
+  if (chunk * lnz::kSplitChunk < r.n4) lnz::split_pack_chunk<64>(r.pack, r.n4, chunk, lane);
+  return true;
+}
+
 // rows / n_rows (optional): compact list of the (b*K + k) eigen slots that carry a Ritz pair
 // (k < min(n_b, K), lnz_plan_batch) — the slots of zero-padded eigen columns are skipped: their
 // gains never reach an output (the V column is zero, model/lanczos_net.py:114-117).
 __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
     const float* __restrict__ D, int R, int B, int K, DistArr dist, int S,
     const float* __restrict__ mlp_pack, const int32_t* __restrict__ rows,
-    const int32_t* __restrict__ n_rows, float* __restrict__ G) {
+    const int32_t* __restrict__ n_rows, float* __restrict__ G, const SplitRide ride) {
   const int lane = threadIdx.x;
+  if (ride_along(ride, lane)) return;
   if (rows) R = *n_rows;
   if ((int)blockIdx.x * 32 >= R) return;
   const int idx = blockIdx.x * 32 + (lane & 31);
@@ -49,8 +67,9 @@ __global__ __launch_bounds__(64) void spectral_gains_mlp_kernel(
 __global__ __launch_bounds__(64) void spectral_gains_mlp2_kernel(
     const float* __restrict__ D, int R, int B, int K, DistArr dist, int S,
     const float* __restrict__ mlp_pack, const int32_t* __restrict__ rows,
-    const int32_t* __restrict__ n_rows, float* __restrict__ G) {
+    const int32_t* __restrict__ n_rows, float* __restrict__ G, const SplitRide ride) {
   const int lane = threadIdx.x;
+  if (ride_along(ride, lane)) return;
   if (rows) R = *n_rows;
   if ((int)blockIdx.x * 64 >= R) return;
   int row[2];
@@ -171,11 +190,14 @@ extern "C" int lnz_pack_spectral_mlp_layers(const float* const* ptrs, int num_la
   return lnz::check_launch("lnz_pack_spectral_mlp_layers");
 }
 
-extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_host,
-                                       int S, int num_layer, int kind, const float* mlp_pack,
-                                       const int32_t* rows, const int32_t* n_rows, float* G,
-                                       lnz_stream_t stream) {
+extern "C" int lnz_spectral_gains_rows_split(const float* D, int B, int K, const int32_t* dist_host,
+                                             int S, int num_layer, int kind, const float* mlp_pack,
+                                             const int32_t* rows, const int32_t* n_rows, float* G,
+                                             float* Lp_split, int64_t lp_floats, lnz_stream_t stream) {
   LNZ_REQUIRE(!rows || n_rows, LNZ_EINVAL, "lnz_spectral_gains_rows: rows without n_rows");
+  LNZ_REQUIRE(!Lp_split || (kind == 0 && lp_floats > 0 && lp_floats % 4 == 0), LNZ_EINVAL,
+              "lnz_spectral_gains_rows_split: the pack rides along with the MLP launch only (kind 0), "
+              "lp_floats a positive multiple of 4");
   LNZ_REQUIRE(D && dist_host && G && B > 0 && K > 0 && num_layer > 0, LNZ_EINVAL,
               "lnz_spectral_gains: bad arguments (B=%d K=%d L=%d)", B, K, num_layer);
   LNZ_REQUIRE(S >= 1 && S <= SMAX, LNZ_ENOTSUP, "lnz_spectral_gains: S=%d not in 1..%d", S, SMAX);
@@ -192,14 +214,17 @@ extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32
       return e ? atoi(e) : 0;
     }();
     const bool two = forced ? forced == 2 : (int64_t)((R + 31) / 32) * num_layer >= 2048;
+    SplitRide ride = {reinterpret_cast<float4*>(Lp_split), lp_floats / 4, (R + (two ? 63 : 31)) / (two ? 64 : 32)};
+    const int64_t chunks = Lp_split ? (ride.n4 + lnz::kSplitChunk - 1) / lnz::kSplitChunk : 0;
+    const int64_t extra_x = (chunks + num_layer - 1) / num_layer;
+    LNZ_REQUIRE(ride.main_x + extra_x < (1ll << 31), LNZ_ENOTSUP, "lnz_spectral_gains_rows_split: pack too large");
+    dim3 grid((unsigned)(ride.main_x + extra_x), num_layer);
     if (two) {
-      dim3 grid((R + 63) / 64, num_layer);
       hipLaunchKernelGGL(spectral_gains_mlp2_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
-                         mlp_pack, rows, n_rows, G);
+                         mlp_pack, rows, n_rows, G, ride);
     } else {
-      dim3 grid((R + 31) / 32, num_layer);
       hipLaunchKernelGGL(spectral_gains_mlp_kernel, grid, dim3(64), 0, s, D, R, B, K, dist, S,
-                         mlp_pack, rows, n_rows, G);
+                         mlp_pack, rows, n_rows, G, ride);
     }
   } else {
     int64_t total = (int64_t)num_layer * B * S * K;
@@ -207,6 +232,14 @@ extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32
                        s, D, B, K, dist, S, num_layer, G);
   }
   return lnz::check_launch("lnz_spectral_gains");
+}
+
+extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_host,
+                                       int S, int num_layer, int kind, const float* mlp_pack,
+                                       const int32_t* rows, const int32_t* n_rows, float* G,
+                                       lnz_stream_t stream) {
+  return lnz_spectral_gains_rows_split(D, B, K, dist_host, S, num_layer, kind, mlp_pack, rows, n_rows, G,
+                                       nullptr, 0, stream);
 }
 
 extern "C" int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,

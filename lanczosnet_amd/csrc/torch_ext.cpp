@@ -271,8 +271,16 @@ std::tuple<Tensor, Tensor, Tensor> plan_ritz(const Tensor& L, const Tensor& mask
 // ---- R7a: spectral gains ---------------------------------------------------------------------
 Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
                       const c10::optional<Tensor>& mlp_pack, const c10::optional<Tensor>& rows,
-                      const c10::optional<Tensor>& n_rows, bool zero_fill) {
+                      const c10::optional<Tensor>& n_rows, bool zero_fill,
+                      const c10::optional<Tensor>& split_pack) {
   need(D, at::kFloat, "D");
+  // split_pack: the batch's packed Laplacian, converted IN PLACE to the split-precision forward's form
+  // by workgroups that ride along with the MLP launch (lnz_spectral_gains_rows_split)
+  if (split_pack.has_value()) {
+    need(*split_pack, at::kFloat, "split_pack");
+    TORCH_CHECK(mlp_pack.has_value() && split_pack->numel() % 4 == 0,
+                "lanczosnet::spectral_gains: split_pack rides along with the MLP launch only");
+  }
   TORCH_CHECK(D.dim() == 2 && !dist.empty());
   if (mlp_pack.has_value()) need(*mlp_pack, at::kFloat, "mlp_pack");
   const bool use_rows = rows.has_value() && n_rows.has_value() && mlp_pack.has_value();
@@ -287,11 +295,12 @@ Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
   Tensor buf = (use_rows && zero_fill) ? at::zeros({n + 16}, D.options()) : at::empty({n + 16}, D.options());
   Tensor G = buf.narrow(0, 0, n).view({num_layer, B, S, K});
   std::vector<int32_t> d32(dist.begin(), dist.end());
-  check(lnz_spectral_gains_rows(D.data_ptr<float>(), B, K, d32.data(), S, (int)num_layer,
-                                mlp_pack.has_value() ? 0 : 1, (const float*)optr(mlp_pack),
-                                use_rows ? rows->data_ptr<int32_t>() : nullptr,
-                                use_rows ? n_rows->data_ptr<int32_t>() : nullptr, G.data_ptr<float>(),
-                                cur_stream()),
+  check(lnz_spectral_gains_rows_split(D.data_ptr<float>(), B, K, d32.data(), S, (int)num_layer,
+                                      mlp_pack.has_value() ? 0 : 1, (const float*)optr(mlp_pack),
+                                      use_rows ? rows->data_ptr<int32_t>() : nullptr,
+                                      use_rows ? n_rows->data_ptr<int32_t>() : nullptr, G.data_ptr<float>(),
+                                      split_pack.has_value() ? split_pack->data_ptr<float>() : nullptr,
+                                      split_pack.has_value() ? split_pack->numel() : 0, cur_stream()),
         "spectral_gains");
   return G;
 }
@@ -423,7 +432,7 @@ TORCH_LIBRARY(lanczosnet, m) {
   m.def("plan_ritz(Tensor L, Tensor mask, Tensor n_nodes, int K, int n_cu, bool allow_pairs) -> "
         "(Tensor, Tensor, Tensor)");
   m.def("spectral_gains(Tensor D, int[] dist, int num_layer, Tensor? mlp_pack, Tensor? rows, "
-        "Tensor? n_rows, bool zero_fill) -> Tensor");
+        "Tensor? n_rows, bool zero_fill, Tensor(a!)? split_pack) -> Tensor");
   m.def("forward(Tensor node_feat, Tensor? embedding, Tensor Lp, Tensor? ident, Tensor V, Tensor? G, "
         "Tensor mask, Tensor Wp, Tensor bias, int[] w_off, int[] b_off, Tensor Wp_head, "
         "Tensor bias_head, Tensor? plan, int plan_cap, int[] dims, int[] short_dist, Tensor? strips, "

@@ -412,9 +412,11 @@ def pack_laplacian(L):
 
 
 def pack_laplacian_for(plan, L):
-  """The Laplacian pack the fused forward expects for `plan` (fp32 fragments in both GEMM modes)."""
+  """The Laplacian pack the fused forward expects for `plan`: fp32 fragments, converted in place to
+  fp16 hi | lo pieces for a split-precision plan (gemm_mode 1)."""
   Lf = L if L.dtype == torch.float32 else L.float()
-  return pack_laplacian(Lf)
+  Lp = pack_laplacian(Lf)
+  return split_laplacian_pack(Lp) if plan.get('gemm_mode', 0) == 1 else Lp
 
 
 def pack_and_plan(plan, L, mask_u8, K, n_cu=None):
@@ -569,20 +571,51 @@ def pack_spectral_mlp_layers(layers, S):
 
 
 # ------------------------------------------------------------------------------------------ R7
-def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True):
+def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True, split_pack=None):
   """D [B,K] -> G [num_layer,B,S,K].  mlp_pack=None selects the plain-power branch.
   rows: optional (gain_rows, n_gain_rows) int32 device tensors from plan_batch(): the MLP runs
   only on the eigen slots that carry a Ritz pair, every other entry of G is zero — or left
   uninitialised with zero_fill=False, which is what the exact-fp32 forward kernel needs (it never
-  reads the slots k >= n))."""
-  _need_cuda(D, mlp_pack)
+  reads the slots k >= n)).  split_pack: the batch's packed Laplacian of a gemm_mode-1 plan —
+  converted in place to the split-precision forward's form by workgroups that ride along with the
+  MLP launch (split_laplacian_pack() as part of this launch)."""
+  _need_cuda(D, mlp_pack, split_pack)
   D = _f32c(D)
   B, K = D.shape
   S = len(dist)
   use_rows = rows is not None and mlp_pack is not None
-  return _ext().spectral_gains(D, [int(x) for x in dist], num_layer, mlp_pack,
-                               rows[0] if use_rows else None, rows[1] if use_rows else None,
-                               bool(zero_fill))
+  ride = None
+  if split_pack is not None and not getattr(split_pack, 'fp16_pieces', False):
+    if mlp_pack is None:
+      split_laplacian_pack(split_pack)
+    else:
+      assert split_pack.dtype == torch.float32 and split_pack.is_contiguous()
+      ready = getattr(split_pack, 'ready', None)   # a pack on a second stream
+      if ready is not None:
+        torch.cuda.current_stream(split_pack.device).wait_event(ready)
+      ride = split_pack
+  G = _ext().spectral_gains(D, [int(x) for x in dist], num_layer, mlp_pack,
+                            rows[0] if use_rows else None, rows[1] if use_rows else None,
+                            bool(zero_fill), ride)
+  if ride is not None:
+    ride.fp16_pieces = True
+  return G
+
+
+def split_laplacian_pack(Lp):
+  """lnz_split_laplacian_pack: the fp32 Laplacian pack -> the split-precision forward's form (every
+  fragment float4 = 4 fp16 hi pieces | 4 lo pieces), IN PLACE; marks the tensor (`Lp.fp16_pieces`)."""
+  _need_cuda(Lp)
+  if getattr(Lp, 'fp16_pieces', False):
+    return Lp
+  assert Lp.dtype == torch.float32 and Lp.is_contiguous()
+  ready = getattr(Lp, 'ready', None)
+  if ready is not None:
+    torch.cuda.current_stream(Lp.device).wait_event(ready)
+  with torch.cuda.device(Lp.device):
+    _abi().split_laplacian_pack(Lp, Lp.numel())
+  Lp.fp16_pieces = True
+  return Lp
 
 
 def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
@@ -708,6 +741,11 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   ready = getattr(Lp, 'ready', None)   # a pack on a second stream (prepare_batch(pack_stream=...))
   if ready is not None:
     torch.cuda.current_stream(Lp.device).wait_event(ready)
+  if plan.get('gemm_mode', 0) == 1:
+    split_laplacian_pack(Lp)   # (no-op when spectral_gains(split_pack=Lp) converted it on the way)
+  elif getattr(Lp, 'fp16_pieces', False):
+    raise RuntimeError('this Laplacian pack was converted for a split-precision plan (gemm_mode 1): '
+                       'pack again for the exact kernel')
   if act_out is None and not return_state:
     return _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident)
   ops_, dims = _fused_operands(plan, V)
