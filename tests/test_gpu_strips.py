@@ -363,3 +363,34 @@ def test_split_precision_needs_the_strip_plan_and_says_so():
   net_s.gemm_mode = 'f16x3'
   with pytest.raises(NotImplementedError, match='strip kernel'):
     net_s._plan()
+
+
+def test_laplacian_pack_conversion_alone_and_under_the_gains_launch():
+  """lnz_split_laplacian_pack (in place: every fragment float4 -> 4 fp16 hi | 4 lo pieces) against
+  numpy, and the same conversion riding along with the gains launch (lnz_spectral_gains_rows_split):
+  same bytes, the gains untouched; an exact-fp32 plan refuses a converted pack."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net, _ = _split_net(cfg, 3)
+  b = draw_batch(77, seed=4)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  D, V = ops.lanczos_ritz(L[..., 0], n, 20)
+  Lp = ops.pack_laplacian(L)
+  raw = Lp.cpu().numpy().reshape(-1, 4)
+  hi = raw.astype(np.float16)
+  lo = (raw - hi.astype(np.float32)).astype(np.float16)
+  want = np.concatenate([hi, lo], axis=1).reshape(-1).view(np.float32)
+  alone = ops.split_laplacian_pack(Lp.clone())
+  assert alone.cpu().numpy().reshape(-1).tobytes() == want.tobytes()
+  assert ops.split_laplacian_pack(alone) is alone      # (marked: not converted twice)
+  plan32 = net._plan()
+  G0 = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan32['mlp_pack'])
+  ride = Lp.clone()
+  G1 = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan32['mlp_pack'], split_pack=ride)
+  assert torch.equal(G0, G1)
+  assert ride.cpu().numpy().reshape(-1).tobytes() == want.tobytes() and ride.fp16_pieces
+  with pytest.raises(RuntimeError, match='converted'):
+    ops.lanczosnet_forward(plan32, t(b['node_feat']), ride, V, G0, t(b['node_mask'].astype(np.uint8)))
