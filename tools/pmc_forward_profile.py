@@ -61,7 +61,9 @@ def main():
   res = {c: run_pass(c, outdir, extra) for c in
          ('SQ_INSTS_VALU_MFMA_MOPS_F32', 'FETCH_SIZE', 'WRITE_SIZE')}
   fwd = [k for k in res['SQ_INSTS_VALU_MFMA_MOPS_F32'] if k.startswith('lanczosnet_forward') or k.startswith('lanczosnet_strip')]
-  fwd = max(fwd, key=lambda k: res['SQ_INSTS_VALU_MFMA_MOPS_F32'][k]['launches'])
+  # (the exact-fp32 forward of the step: the opt-in split-precision leg of the same bench run launches
+  # its own instantiation more often, but issues 0.5 % of the fp32 matrix instructions)
+  fwd = max(fwd, key=lambda k: res['SQ_INSTS_VALU_MFMA_MOPS_F32'][k]['per_launch'])
   mops = res['SQ_INSTS_VALU_MFMA_MOPS_F32'][fwd]
   fetch, write = res['FETCH_SIZE'][fwd], res['WRITE_SIZE'][fwd]
   out = {
