@@ -285,15 +285,25 @@ int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_ho
  * W4, b4, W6, b6 of layer l as for lnz_pack_spectral_mlp_layers (raw row-major parameters; b6 is not
  * read).  rows / n_rows: the live eigen rows of lnz_plan_batch (NULL, NULL = every row of D); rows
  * of dG outside that list are not read.  Every one of the `parts` workgroups of a layer (parts <=
- * lnz_spectral_mlp_grad_parts(rows upper bound, num_layer, n_cu)) writes one partial of each
- * gradient; the gradient is the sum of a layer's partials over that index (any fixed order):
- *   dW0 [L][parts][128][S], dW2, dW4 [L][parts][128][128], dW6 [L][parts][S][128],
- *   db [L][parts][3][128] (b0, b2, b4), db6 [L][parts][S].      S <= 8; exact fp32. */
+ * lnz_spectral_mlp_grad_parts(rows upper bound, num_layer, n_cu)) writes ONE partial of T =
+ * lnz_spectral_mlp_grad_floats(S) floats into partials [L][parts][T]:
+ *   dW0 [128][S] | dW2 [128][128] | dW4 [128][128] | dW6 [S][128] | db0, db2, db4 [3][128] | db6 [S] | pad
+ * and the gradients are the sum of a layer's partials over the `parts` index (any fixed order: one
+ * reduction for all eight).  S <= 8; exact fp32. */
+int lnz_spectral_mlp_grad_floats(int S);
 int lnz_spectral_mlp_grad_parts(int n_rows_max, int num_layer, int n_cu);
 int lnz_spectral_mlp_grad(const float* D, int B, int K, const int32_t* dist_host, int S,
                           int num_layer, const int32_t* rows, const int32_t* n_rows, const float* dG,
-                          const float* const* ptrs, int parts, float* dW0, float* dW2, float* dW4,
-                          float* dW6, float* db, float* db6, lnz_stream_t stream);
+                          const float* const* ptrs, int parts, float* partials, lnz_stream_t stream);
+
+/* Training: the embedding table's gradient dE[a][c] = sum over the node rows (b, i) with ids[b][i] == a
+ * (clamped to [0, num_atom) as the forward clamps) of dx[b * mol_stride + i * row_stride + c], c <
+ * width — autograd's embedding backward (model/lanczos_net.py:154), without atomics: workgroup
+ * (a, chunk) writes partials[chunk][a][width], the gradient is their sum over `chunks` (any fixed
+ * order).  ids [B, N] int64; width in {16, 32, 64, 128}; strides in floats, multiples of 4. */
+int lnz_embedding_grad(const int64_t* ids, int B, int N, const float* dx, int64_t mol_stride,
+                       int64_t row_stride, int width, int num_atom, int chunks, float* partials,
+                       lnz_stream_t stream);
 
 /* ... and, riding along with the MLP launch (kind 0), the conversion of the batch's packed Laplacian
  * (lp_floats floats at Lp_split, e.g. B * C * 1024 of lnz_pack_laplacian*) into the form the

@@ -95,7 +95,9 @@ SIGNATURES = {
     'lnz_spectral_mlp_grad_parts': (C.c_int, [_I, _I, _I]),
     'lnz_spectral_gains_rows_split': (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
     'lnz_split_laplacian_pack': (C.c_int, [_P, _L, _P]),
-    'lnz_spectral_mlp_grad': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'lnz_spectral_mlp_grad_floats': (C.c_int, [_I]),
+    'lnz_embedding_grad': (C.c_int, [_P, _I, _I, _P, _L, _L, _I, _I, _I, _P, _P]),
+    'lnz_spectral_mlp_grad': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     'lnz_spectral_gains': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P]),
     'lnz_spectral_gains_rows': (C.c_int, [_P, _I, _I, C.POINTER(C.c_int32), _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_lanczosnet_input_grad': (C.c_int, [C.POINTER(ForwardArgs), _P]),

@@ -346,3 +346,73 @@ extern "C" int lnz_unsorted_segment_sum_backward(const float* grad_out, const in
                        segment_ids, rows, dim1, dim2, num_segments, grad_data);
   return lnz::check_launch("lnz_unsorted_segment_sum_backward");
 }
+
+// ---------------------------------------------------------------------------------------
+// Training: the embedding table's gradient (model/lanczos_net.py:154: node_feat -> nn.Embedding)
+//   dE[a][c] = sum over the node rows (b, i) with id[b][i] == a of dX0[b][i][c]
+// The reference gets it from autograd's embedding backward (atomics); as one-hot^T dX0 it was a
+// library GEMM with K = B N rows for a 70 x 64 output plus the one-hot matrix itself (0.13 ms of the
+// step).  Here workgroup (a, chunk) scans a slice of the rows — lane = row, ids read coalesced — and
+// adds the matching rows into registers; lanes meet in a fixed-order shuffle tree, waves in LDS:
+// one partial per (chunk, a), summed by the caller in a fixed order.  No atomics.
+// ---------------------------------------------------------------------------------------
+template <int W4>   // row width in float4
+__global__ __launch_bounds__(256) void embedding_grad_kernel(
+    const int64_t* __restrict__ ids, const float* __restrict__ dx, int64_t rows, int N, int64_t mol_stride,
+    int64_t row_stride, int num_atom, float* __restrict__ part) {
+  __shared__ float red[4][W4 * 4];
+  const int a = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+  const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+  const int64_t lo = chunk * per, hi = lo + per < rows ? lo + per : rows;
+  float4 acc[W4];
+#pragma unroll
+  for (int c = 0; c < W4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t r = lo + tid; r < hi; r += 256) {
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= num_atom ? num_atom - 1 : id);   // (the forward's clamp)
+    if (id == a) {
+      const int64_t b = r / N, i = r - b * N;
+      const float4* __restrict__ src = reinterpret_cast<const float4*>(dx + b * mol_stride + i * row_stride);
+#pragma unroll
+      for (int c = 0; c < W4; ++c) {
+        const float4 v = src[c];
+        acc[c].x += v.x, acc[c].y += v.y, acc[c].z += v.z, acc[c].w += v.w;
+      }
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int c = 0; c < W4; ++c) {
+    float v[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v[e] += __shfl_xor(v[e], off, 64);
+      if (lane == 0) red[wave][4 * c + e] = v[e];
+    }
+  }
+  __syncthreads();
+  if (tid < W4 * 4)
+    part[((int64_t)chunk * num_atom + a) * (W4 * 4) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+extern "C" int lnz_embedding_grad(const int64_t* ids, int B, int N, const float* dx, int64_t mol_stride,
+                                  int64_t row_stride, int width, int num_atom, int chunks, float* partials,
+                                  lnz_stream_t stream) {
+  LNZ_REQUIRE(ids && dx && partials && B > 0 && N > 0 && num_atom > 0 && chunks > 0 && chunks <= 65535,
+              LNZ_EINVAL, "lnz_embedding_grad: bad arguments (B=%d N=%d atoms=%d chunks=%d)", B, N, num_atom, chunks);
+  LNZ_REQUIRE((width == 16 || width == 32 || width == 64 || width == 128) && mol_stride % 4 == 0 &&
+                  row_stride % 4 == 0 && ((uintptr_t)dx & 15) == 0,
+              LNZ_ENOTSUP, "lnz_embedding_grad: width %d not in {16, 32, 64, 128} or rows not 16-byte aligned", width);
+  const dim3 grid(num_atom, chunks);
+  const int64_t rows = (int64_t)B * N;
+  hipStream_t s = (hipStream_t)stream;
+#define LNZ_EG(W4) hipLaunchKernelGGL(embedding_grad_kernel<W4>, grid, dim3(256), 0, s, ids, dx, rows, N, \
+                                      mol_stride, row_stride, num_atom, partials)
+  if (width == 16) LNZ_EG(4);
+  else if (width == 32) LNZ_EG(8);
+  else if (width == 64) LNZ_EG(16);
+  else LNZ_EG(32);
+#undef LNZ_EG
+  return lnz::check_launch("lnz_embedding_grad");
+}

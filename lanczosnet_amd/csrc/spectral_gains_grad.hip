@@ -100,13 +100,9 @@ struct GradArgs {
   const int32_t* n_rows;
   const float* dG;      // [L][B K][S]
   const float* p[16][8];  // [layer][W0 [128][S], b0, W2 [128][128], b2, W4, b4, W6 [S][128], b6 (unused)]
-  float* dW0;           // [L][parts][128][S]
-  float* dW2;           // [L][parts][128][128]
-  float* dW4;
-  float* dW6;           // [L][parts][S][128]
-  float* db;            // [L][parts][3][128]   (b0, b2, b4)
-  float* db6;           // [L][parts][S]
-  int BK, S, parts;
+  float* out;           // [L][parts][T]: dW0 [128][S] | dW2 [128][128] | dW4 | dW6 [S][128] | db0, db2, db4
+                        // [3][128] | db6 [S] | pad to a multiple of four
+  int BK, S, parts, T;
   DistArr dist;
 };
 
@@ -263,30 +259,39 @@ __global__ __launch_bounds__(512) void spectral_mlp_grad_kernel(const GradArgs a
   }
 
   // ---- this workgroup's partials
-  const int64_t lp = (int64_t)l * a.parts + part;
+  float* __restrict__ o0 = a.out + ((int64_t)l * a.parts + part) * a.T;   // dW0
+  float* __restrict__ o2 = o0 + 128 * S;                                   // dW2
+  float* __restrict__ o4 = o2 + 16384;                                     // dW4
+  float* __restrict__ o6 = o4 + 16384;                                     // dW6
+  float* __restrict__ ob = o6 + S * 128;                                   // db0 | db2 | db4 | db6
 #pragma unroll
   for (int ib = 0; ib < 8; ++ib)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t at = (lp * 128 + 16 * wave + 4 * kq + q) * 128 + 16 * ib + j;
-      a.dW2[at] = acc2[ib][q];
-      a.dW4[at] = acc4[ib][q];
+      const int at = (16 * wave + 4 * kq + q) * 128 + 16 * ib + j;
+      o2[at] = acc2[ib][q];
+      o4[at] = acc4[ib][q];
     }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int e = tid + 512 * u;
     const int s6 = e >> 7, c6 = e & 127;
-    if (s6 < S) a.dW6[(lp * S + s6) * 128 + c6] = g6[u];
+    if (s6 < S) o6[s6 * 128 + c6] = g6[u];
     const int o = e / SX, s = e - o * SX;
-    if (s < S) a.dW0[(lp * 128 + o) * S + s] = g0[u];
+    if (s < S) o0[o * S + s] = g0[u];
   }
-  if (tid < 384) a.db[(lp * 3 + (tid >> 7)) * 128 + (tid & 127)] = gb;
-  else if (tid < 384 + SX && tid - 384 < S) a.db6[lp * S + (tid - 384)] = gb;
+  if (tid < 384) ob[tid] = gb;
+  else if (tid < 384 + SX && tid - 384 < S) ob[tid] = gb;
 }
 
 constexpr size_t kGradLds = (size_t)(4 * TR * P + 2 * TR * SX + 2 * 128 * SX + 3 * 128) * sizeof(float);
 
 }  // namespace
+
+extern "C" int lnz_spectral_mlp_grad_floats(int S) {   // floats of one partial (layout: header)
+  if (S < 1 || S > SX) return 0;
+  return (128 * S + 2 * 16384 + S * 128 + 384 + S + 3) & ~3;
+}
 
 extern "C" int lnz_spectral_mlp_grad_parts(int n_rows_max, int num_layer, int n_cu) {
   if (n_rows_max <= 0 || num_layer <= 0 || n_cu <= 0) return 0;
@@ -299,23 +304,21 @@ extern "C" int lnz_spectral_mlp_grad_parts(int n_rows_max, int num_layer, int n_
 extern "C" int lnz_spectral_mlp_grad(const float* D, int B, int K, const int32_t* dist_host, int S,
                                      int num_layer, const int32_t* rows, const int32_t* n_rows,
                                      const float* dG, const float* const* ptrs, int parts,
-                                     float* dW0, float* dW2, float* dW4, float* dW6, float* db,
-                                     float* db6, lnz_stream_t stream) {
-  LNZ_REQUIRE(D && dist_host && dG && ptrs && dW0 && dW2 && dW4 && dW6 && db && db6, LNZ_EINVAL,
-              "lnz_spectral_mlp_grad: null pointer");
+                                     float* partials, lnz_stream_t stream) {
+  LNZ_REQUIRE(D && dist_host && dG && ptrs && partials, LNZ_EINVAL, "lnz_spectral_mlp_grad: null pointer");
   LNZ_REQUIRE(B > 0 && K > 0 && num_layer > 0 && num_layer <= 16 && parts > 0 && parts <= 65535,
               LNZ_EINVAL, "lnz_spectral_mlp_grad: bad sizes (B=%d K=%d L=%d parts=%d)", B, K, num_layer, parts);
   LNZ_REQUIRE(S >= 1 && S <= SX, LNZ_ENOTSUP, "lnz_spectral_mlp_grad: S=%d not in 1..%d", S, SX);
   LNZ_REQUIRE(!rows == !n_rows, LNZ_EINVAL, "lnz_spectral_mlp_grad: rows and n_rows come together");
   GradArgs a;
   a.D = D, a.rows = rows, a.n_rows = n_rows, a.dG = dG;
-  a.dW0 = dW0, a.dW2 = dW2, a.dW4 = dW4, a.dW6 = dW6, a.db = db, a.db6 = db6;
+  a.out = partials;
   for (int l = 0; l < num_layer; ++l)
     for (int i = 0; i < 8; ++i) {
       LNZ_REQUIRE(ptrs[l * 8 + i] || i == 7, LNZ_EINVAL, "lnz_spectral_mlp_grad: null parameter pointer");
       a.p[l][i] = ptrs[l * 8 + i];
     }
-  a.BK = B * K, a.S = S, a.parts = parts;
+  a.BK = B * K, a.S = S, a.parts = parts, a.T = lnz_spectral_mlp_grad_floats(S);
   for (int s = 0; s < lnz_gains::SMAX; ++s) a.dist.v[s] = s < S ? dist_host[s] : 0;
   // per launch: the attribute is per device, and a process may drive several
   (void)hipFuncSetAttribute((const void*)spectral_mlp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1051,8 +1051,11 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
 
         # ---- embedding rows: one-hot^T dX_0 as a GEMM (index_add's atomics are 10x slower here)
         if not m.general:
-            onehot = torch.nn.functional.one_hot(node_feat.reshape(-1), m.num_atom).to(torch.float32)
-            grads[id(m.embedding.weight)] = onehot.t() @ dx0[:, :N, :din0].reshape(-1, din0)
+            if din0 in (16, 32, 64, 128):   # (lnz_embedding_grad: rows of dX_0 added by atom id, no atomics)
+                grads[id(m.embedding.weight)] = ops.embedding_grad(node_feat.contiguous(), dx0, din0, m.num_atom)
+            else:
+                onehot = torch.nn.functional.one_hot(node_feat.reshape(-1), m.num_atom).to(torch.float32)
+                grads[id(m.embedding.weight)] = onehot.t() @ dx0[:, :N, :din0].reshape(-1, din0)
 
         out = [grads.get(id(p_)) if p_.requires_grad else None for p_ in m.parameters()]
         return (None, None, None, None, None, None) + tuple(out)
@@ -1673,8 +1676,12 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         dT = ops.ada_t_powers_f64_backward(pow_saved, dtcat)
         dLe = ops.ada_lanczos_layer_f64_backward(Le, lws, dT, dQ.double())
         dstate = dx0[:, :N, :din0] + ops.ada_graph_laplacian_f64_backward(lap_saved, dLe).float()
-        onehot = torch.nn.functional.one_hot(node_feat.reshape(-1), m.num_atom).to(torch.float32)
-        grads[id(m.embedding.weight)] = onehot.t() @ dstate.reshape(-1, din0)
+        if din0 in (16, 32, 64, 128):
+            grads[id(m.embedding.weight)] = ops.embedding_grad(node_feat.contiguous(), dstate.contiguous(), din0,
+                                                               m.num_atom)
+        else:
+            onehot = torch.nn.functional.one_hot(node_feat.reshape(-1), m.num_atom).to(torch.float32)
+            grads[id(m.embedding.weight)] = onehot.t() @ dstate.reshape(-1, din0)
         mark('spectrum')
         if dbg:
             m._dbg['marks'] = marks

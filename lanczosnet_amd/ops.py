@@ -637,17 +637,32 @@ def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
       keep += [_f32c(w.detach()), _f32c(b.detach())]
   dev = D.device
   parts = _abi().spectral_mlp_grad_parts(int(rows_max or B * K), L, _n_cu(dev))
-  f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-  dW0, dW2, dW4, dW6 = f(L, parts, 128, S), f(L, parts, 128, 128), f(L, parts, 128, 128), f(L, parts, S, 128)
-  db, db6 = f(L, parts, 3, 128), f(L, parts, S)
+  T = _abi().spectral_mlp_grad_floats(S)
+  partials = torch.empty((L, parts, T), dtype=torch.float32, device=dev)
   with torch.cuda.device(dev):
     _abi().spectral_mlp_grad(D, B, K, [int(x) for x in dist], S, L,
                              rows[0] if rows is not None else None,
-                             rows[1] if rows is not None else None, dG, keep, parts, dW0, dW2, dW4, dW6,
-                             db, db6)
-  dbs = db.sum(dim=1)   # the partials, added in a fixed order
-  return [(dW0.sum(dim=1), dbs[:, 0]), (dW2.sum(dim=1), dbs[:, 1]), (dW4.sum(dim=1), dbs[:, 2]),
-          (dW6.sum(dim=1), db6.sum(dim=1))]
+                             rows[1] if rows is not None else None, dG, keep, parts, partials)
+  g = partials.sum(dim=1)   # [L, T]: the partials, added in a fixed order — one reduction for all eight
+  o2, o4, o6, ob = 128 * S, 128 * S + 16384, 128 * S + 32768, 128 * S + 32768 + S * 128
+  return [(g[:, :o2].view(L, 128, S), g[:, ob:ob + 128]),
+          (g[:, o2:o4].view(L, 128, 128), g[:, ob + 128:ob + 256]),
+          (g[:, o4:o6].view(L, 128, 128), g[:, ob + 256:ob + 384]),
+          (g[:, o6:ob].view(L, S, 128), g[:, ob + 384:ob + 384 + S])]
+
+
+def embedding_grad(ids, dx, width, num_atom, chunks=32):
+  """lnz_embedding_grad: dE [num_atom, width] = sum of the rows dx[b, i, :width] by atom id ids[b, i]
+  (ids [B, N] int64; dx [B, >= N, >= width] fp32 with a contiguous last dimension) — the embedding
+  table's gradient without atomics (partials per row chunk, added in a fixed order)."""
+  _need_cuda(ids, dx)
+  B, N = ids.shape
+  assert ids.dtype == torch.int64 and ids.is_contiguous() and dx.dtype == torch.float32
+  assert dx.dim() == 3 and dx.shape[0] == B and dx.shape[1] >= N and dx.shape[2] >= width and dx.stride(2) == 1
+  part = torch.empty((chunks, num_atom, width), dtype=torch.float32, device=dx.device)
+  with torch.cuda.device(dx.device):
+    _abi().embedding_grad(ids, B, N, dx, dx.stride(0), dx.stride(1), width, num_atom, chunks, part)
+  return part.sum(dim=0)
 
 
 def collate_qm8(shard, ids, N, E, P):

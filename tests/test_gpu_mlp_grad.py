@@ -98,3 +98,19 @@ def test_training_step_with_the_mlp_grad_kernel_matches_the_autograd_route():
     assert float((a - w).abs().max()) <= 2e-5 * float(w.abs().max()) + 1e-12, k
     if 'spectral_filter' not in k:
       assert torch.equal(grads['hip'][k], grads['torch'][k]), k   # (everything else is the same code)
+
+
+@pytest.mark.parametrize('B,N,width,atoms,chunks', [(1024, 26, 64, 70, 32), (3, 5, 16, 4, 7), (200, 32, 128, 9, 1),
+                                                   (77, 19, 32, 70, 5)])
+def test_embedding_grad_matches_index_add_in_float64(B, N, width, atoms, chunks):
+  """lnz_embedding_grad against index_add in float64 (out-of-range ids clamp as in the forward), on a
+  strided dX_0 block ([B, 32, width] rows, N of them used); repeats are bit-identical."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(B)
+  ids = rs.randint(-1, atoms + 1, size=(B, N)).astype(np.int64)
+  dx = torch.from_numpy(rs.randn(B, 32, width).astype(np.float32)).to(DEV)
+  got = ops.embedding_grad(torch.from_numpy(ids).to(DEV), dx, width, atoms, chunks=chunks)
+  want = torch.zeros((atoms, width), dtype=torch.float64, device=DEV)
+  want.index_add_(0, torch.from_numpy(np.clip(ids, 0, atoms - 1)).to(DEV).reshape(-1), dx[:, :N].double().reshape(-1, width))
+  assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+  assert torch.equal(got, ops.embedding_grad(torch.from_numpy(ids).to(DEV), dx, width, atoms, chunks=chunks))
