@@ -1259,6 +1259,8 @@ bool forward16_eligible(const lnz_forward_args& a, int mode);         // conv_fo
 int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s);
 bool strip_forward_eligible(const lnz_forward_args& a, int mode);     // conv_strip.hip
 int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s);
+bool strip_messages_eligible(const lnz_forward_args& a);
+int launch_strip_messages(const lnz_forward_args& a, hipStream_t s);
 bool strip_gain_grad_eligible(const lnz_forward_args& a);
 int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s);
 }
@@ -1359,6 +1361,8 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
       LNZ_REQUIRE(a.msg && a.msg_layer >= 0 && a.msg_layer < a.num_layer &&
                       (a.msg_layer > 0 || a.x0),
                   LNZ_EINVAL, "%s: need msg, msg_layer in range, x0 for layer 0", who);
+      LNZ_REQUIRE(a.msg_layer == 0 || a.act, LNZ_EINVAL, "%s: act missing", who);
+      if (strips_enabled() && lnz::strip_messages_eligible(a)) return lnz::launch_strip_messages(a, s);
     }
   }
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;  // upper bound of the workgroup count

@@ -1073,6 +1073,250 @@ __device__ __forceinline__ void strip_gain_grad(KArgs& a, const int32_t* __restr
   }
 }
 
+// -----------------------------------------------------------------------------------------
+// The message pass on strips (training, lnz_lanczosnet_messages; conv_forward.hip's MODE 2 on the
+// tile plan): every channel's M_c X_l of ONE conv layer, written in the compact row numbering of the
+// message matrix — the reference's cat(msg) (model/lanczos_net.py:164-180), from which dW_l =
+// dY_l^T msg_l is one GEMM.  No GEMM1 and no node-state buffers: wave w loads its 16 columns of X_l
+// straight into C/D order (register q of subtile I = row 16 I + 4 kq + q), projects once (Y = V^T X),
+// and per channel either scales Y by the gains and lifts it (long scales) or multiplies with the
+// Laplacian blocks (edge types); the products are the forward's block loops.  Diagonal gains, no
+// short-diffusion channels.
+template <int S>
+__device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restrict__ ent, float* lds,
+                                               const int tid, const int wave) {
+  constexpr int R = 16 * S;
+  constexpr unsigned OOB = 0x80000000u;
+  const int lane = tid & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int N = a.N, K = a.K, B = a.B;
+  const int nl = a.n_long, ne = a.n_edge, C = nl + ne;
+  const int la = a.msg_layer;
+  const int d = la == 0 ? a.din0 : 128;
+  const float* __restrict__ src = la == 0 ? a.x0 : a.act + (int64_t)(la - 1) * B * 32 * 128;
+  float* Vb = lds;                                   // [S][3][16][VBP]
+  float* Gs = Vb + S * 3 * 16 * VBP;                 // [nl][R]
+  int* rowinfo = reinterpret_cast<int*>(Gs + nl * R);
+  int* mstart = rowinfo + R;
+  int* mext = mstart + MAXMOL;
+  int* mid = mext + MAXMOL;
+  int* drow = mid + MAXMOL + 8;                      // [R]
+  constexpr int OP = 132;                            // row pitch of the staged channel tile
+  float* Os = reinterpret_cast<float*>(drow + R);    // [2][R][OP]
+  const int nm = ent[0];
+  if (tid < MAXMOL) {
+    const bool in = tid < nm;
+    mid[tid] = in ? ent[2 + 3 * tid] : -1;
+    mstart[tid] = in ? ent[3 + 3 * tid] : 0;
+    mext[tid] = in ? ent[4 + 3 * tid] : 0;
+  }
+  __syncthreads();
+  if (tid < R) {
+    int own = -1;
+    for (int i = 0; i < nm; ++i) {
+      const int n = mext[i];
+      const int rows = n <= 4 ? 4 : (n + 3) & ~3;
+      if (tid >= mstart[i] && tid < mstart[i] + rows) own = i;
+    }
+    rowinfo[tid] = own;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < S * 3 * 256; idx += 512) {
+    const int Jn = idx / 768, rem = idx - Jn * 768;
+    const int dd = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
+    const int nrow = 16 * Jn + nu, srow = 16 * (Jn + dd - 1) + ro;
+    float v = 0.0f;
+    if (srow >= 0 && srow < R) {
+      const int own = rowinfo[nrow];
+      if (own >= 0 && rowinfo[srow] == own) {
+        const int lnode = nrow - mstart[own], k = srow - mstart[own];
+        if (lnode < N && k < K) v = finite_or_zero(a.V[((int64_t)mid[own] * N + lnode) * K + k]);
+      }
+    }
+    Vb[((Jn * 3 + dd) * 16 + nu) * VBP + ro] = v;
+  }
+  for (int idx = tid; idx < nl * R; idx += 512) {   // this layer's gains by slot row
+    const int sc = idx / R, rho = idx - sc * R;
+    const int own = rowinfo[rho];
+    float g = 0.0f;
+    if (own >= 0) {
+      const int k = rho - mstart[own];
+      if (k < K && k < mext[own]) g = a.G[(((int64_t)la * B + mid[own]) * nl + sc) * K + k];
+    }
+    Gs[idx] = g;
+  }
+  // per-lane addressing of the packed Laplacian (as in the forward)
+  unsigned loff[S][3];
+  const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.Lp), 0, B * ne * 4096, 0x00020000);
+#pragma unroll
+  for (int I = 0; I < S; ++I) {
+    const int row = 16 * I + j;
+    const int own = rowinfo[row];
+    const int st = own >= 0 ? mstart[own] : 0;
+    const int mol = own >= 0 ? mid[own] : 0;
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd) {
+      const int J = I + dd - 1;
+      unsigned off = OOB;
+      if (J >= 0 && J < S) {
+        const int cg = 16 * J + 4 * kq;
+        const int c = cg - st;
+        if (own >= 0 && rowinfo[cg] == own)
+          off = (unsigned)((mol * ne * 256 + (c >> 3) * 64 + ((c >> 2) & 1) * 32 + (row - st)) * 16);
+      }
+      loff[I][dd] = off;
+    }
+  }
+  // this wave's 16 columns of X_l in C/D order
+  const int col = 16 * wave + j;
+  const bool active = 16 * wave < d;
+  f32x4 Xc[S];
+#pragma unroll
+  for (int I = 0; I < S; ++I) {
+    const int row0 = 16 * I + 4 * kq;
+    const int own = rowinfo[row0];
+    Xc[I] = splat4(0.f);
+    if (own >= 0 && active) {
+      const float* p = src + ((int64_t)mid[own] * 32 + (row0 - mstart[own])) * d + col;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xc[I][q] = p[q * d];
+    }
+  }
+  // where a strip row's message goes: its row of the (compact) message matrix, or -1
+  if (tid < R) {
+    const int own = rowinfo[tid];
+    int dst = -1;
+    if (own >= 0) {
+      const int lrow = tid - mstart[own];
+      if (lrow < (a.row_off ? mext[own] : 32))
+        dst = a.row_off ? (int)a.row_off[mid[own]] + lrow : mid[own] * 32 + lrow;
+    }
+    drow[tid] = dst;
+  }
+  __syncthreads();
+  const int64_t ld = (int64_t)C * d;
+  // A channel leaves through LDS: a wave holds 16 columns of a row (64 bytes) — written from the
+  // registers, half cache lines of a 124 MB stream arrive at different times (measured: the message
+  // pass 3.5 x slower than the tile kernel's 128-byte rows) — so the tile is staged (two buffers, one
+  // barrier per channel) and leaves as whole rows, 16 bytes per lane.
+  int chan = 0;
+  auto emit = [&](const f32x4 (&out)[S], bool have) {
+    float* os = Os + (chan & 1) * R * OP;
+    if (have) {
+#pragma unroll
+      for (int I = 0; I < S; ++I)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) os[(16 * I + 4 * kq + q) * OP + col] = out[I][q];
+    }
+    __syncthreads();   // (also: every thread is through with the stores out of the other buffer's previous use)
+    const int d4 = d >> 2;
+    for (int idx = tid; idx < R * d4; idx += 512) {
+      const int r = idx / d4, c4 = idx - r * d4;
+      const int dst = drow[r];
+      if (dst >= 0)
+        *reinterpret_cast<float4*>(a.msg + (int64_t)dst * ld + (int64_t)chan * d + 4 * c4) =
+            *reinterpret_cast<const float4*>(os + r * OP + 4 * c4);
+    }
+    ++chan;
+  };
+  // ---- long scales: V diag(g_s) V^T X_l
+  if (nl > 0) {
+    f32x4 Y[S];
+#pragma unroll
+    for (int I = 0; I < S; ++I) Y[I] = splat4(0.f);
+    f32x4 vl[S][3];
+    if (active) {
+#pragma unroll
+      for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int I = 0; I < S; ++I) {  // slot subtile I, node subtile J
+            const int J = I + dd - 1;
+            if (J < 0 || J >= S) continue;
+            Y[I] = mfma16(Vb[((J * 3 + (2 - dd)) * 16 + 4 * kq + r) * VBP + j], Xc[J][r], Y[I]);
+          }
+#pragma unroll
+      for (int I = 0; I < S; ++I)
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) {
+          if (I + dd - 1 < 0 || I + dd - 1 >= S) continue;
+          vl[I][dd] = *reinterpret_cast<const f32x4*>(&Vb[((I * 3 + dd) * 16 + j) * VBP + 4 * kq]);
+        }
+    }
+    for (int s = 0; s < nl; ++s) {
+      f32x4 out[S];
+      if (active) {
+        f32x4 T[S];
+#pragma unroll
+        for (int I = 0; I < S; ++I) {
+          T[I] = *reinterpret_cast<const f32x4*>(Gs + s * R + 16 * I + 4 * kq) * Y[I];
+          out[I] = splat4(0.f);
+        }
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int I = 0; I < S; ++I) {
+              const int J = I + dd - 1;
+              if (J < 0 || J >= S) continue;
+              out[I] = mfma16(vl[I][dd][r], T[J][r], out[I]);
+            }
+      }
+      emit(out, active);
+    }
+  }
+  // ---- edge types: M_e X_l
+  for (int e = 0; e < ne; ++e) {
+    f32x4 out[S];
+    if (active) {
+      f32x4 mop[S][3];
+#pragma unroll
+      for (int I = 0; I < S; ++I) {
+        out[I] = splat4(0.f);
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) {
+          if (I + dd - 1 < 0 || I + dd - 1 >= S) continue;
+          mop[I][dd] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[I][dd], e * 4096, 0));
+        }
+      }
+#pragma unroll
+      for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            const int J = I + dd - 1;
+            if (J < 0 || J >= S) continue;
+            out[I] = mfma16(mop[I][dd][r], Xc[J][r], out[I]);
+          }
+    }
+    emit(out, active);
+  }
+}
+
+__global__ __launch_bounds__(512) void lanczosnet_strip_messages_kernel(const lnz_forward_args) {
+  KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  extern __shared__ __attribute__((aligned(16))) float lds_strip[];
+  if ((int)blockIdx.x >= *a.n_strips) return;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int32_t* ent = a.strips + (int64_t)blockIdx.x * LNZ_STRIP_INTS;
+  const int sub = __builtin_amdgcn_readfirstlane(ent[1]);
+  switch (sub) {
+    case 1: strip_messages<1>(a, ent, lds_strip, tid, wave); break;
+    case 2: strip_messages<2>(a, ent, lds_strip, tid, wave); break;
+    case 3: strip_messages<3>(a, ent, lds_strip, tid, wave); break;
+    case 4: strip_messages<4>(a, ent, lds_strip, tid, wave); break;
+    case 5: strip_messages<5>(a, ent, lds_strip, tid, wave); break;
+    case 6: strip_messages<6>(a, ent, lds_strip, tid, wave); break;
+    default: break;
+  }
+}
+
 __global__ __launch_bounds__(512) void lanczosnet_strip_gain_grad_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) float lds_strip[];
@@ -1151,6 +1395,24 @@ bool strip_gain_grad_eligible(const lnz_forward_args& a) {
   if (a.din0 % 64 != 0 || a.n_long < 1 || a.n_long > 12) return false;
   // the eight waves' partial sums of a strip fit in its dY buffer
   return 8 * a.n_long <= P;
+}
+
+// lnz_lanczosnet_messages on strips (the arguments have passed that entry point's checks)
+bool strip_messages_eligible(const lnz_forward_args& a) {
+  if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
+  if (a.gemm_mode != 0 || a.filter_kind != 0 || a.dhid != 128 || a.n_short != 0) return false;
+  if (a.din0 % 16 != 0 || a.din0 > 128 || a.n_edge < 1 || a.n_long > 16) return false;
+  return (int64_t)a.B * a.n_edge * 4096 < (1ll << 31);
+}
+
+int launch_strip_messages(const lnz_forward_args& a, hipStream_t s) {
+  const size_t bytes = (size_t)(LNZ_STRIP_SUB * 3 * 16 * VBP + a.n_long * 16 * LNZ_STRIP_SUB +
+                                2 * 16 * LNZ_STRIP_SUB + 3 * MAXMOL + 8 + 2 * 16 * LNZ_STRIP_SUB * 132) * sizeof(float);
+  // per launch: the attribute is per device, and a process may drive several (DataParallel)
+  (void)hipFuncSetAttribute((const void*)lanczosnet_strip_messages_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(lanczosnet_strip_messages_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
+  return check_launch("lnz_lanczosnet_messages (strips)");
 }
 
 int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s) {

@@ -352,48 +352,58 @@ extern "C" int lnz_unsorted_segment_sum_backward(const float* grad_out, const in
 //   dE[a][c] = sum over the node rows (b, i) with id[b][i] == a of dX0[b][i][c]
 // The reference gets it from autograd's embedding backward (atomics); as one-hot^T dX0 it was a
 // library GEMM with K = B N rows for a 70 x 64 output plus the one-hot matrix itself (0.13 ms of the
-// step).  Here workgroup (a, chunk) scans a slice of the rows — lane = row, ids read coalesced — and
-// adds the matching rows into registers; lanes meet in a fixed-order shuffle tree, waves in LDS:
-// one partial per (chunk, a), summed by the caller in a fixed order.  No atomics.
+// step).  Here workgroup (a, chunk) scans a slice of the rows: a wave reads 64 ids at a time (lane =
+// row, coalesced), then visits the matching rows one by one with lane = column and adds them in row
+// order; the four waves meet in LDS: one partial per (chunk, a), summed by the caller in a fixed
+// order.  No atomics, no shuffles.  (A first form — lane = row, 64 accumulators per lane, a shuffle
+// tree at the end — spent 51 us in 384 ds_bpermutes per wave.)
 // ---------------------------------------------------------------------------------------
-template <int W4>   // row width in float4
+template <int CPL>   // columns per lane: width = 64 CPL (CPL = 1: widths up to 64, lanes beyond it idle)
 __global__ __launch_bounds__(256) void embedding_grad_kernel(
     const int64_t* __restrict__ ids, const float* __restrict__ dx, int64_t rows, int N, int64_t mol_stride,
-    int64_t row_stride, int num_atom, float* __restrict__ part) {
-  __shared__ float red[4][W4 * 4];
+    int64_t row_stride, int width, int num_atom, float* __restrict__ part) {
+  __shared__ float red[4][64 * CPL];
   const int a = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
   const int64_t lo = chunk * per, hi = lo + per < rows ? lo + per : rows;
-  float4 acc[W4];
+  float acc[CPL];
 #pragma unroll
-  for (int c = 0; c < W4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t r = lo + tid; r < hi; r += 256) {
-    int64_t id = ids[r];
-    id = id < 0 ? 0 : (id >= num_atom ? num_atom - 1 : id);   // (the forward's clamp)
-    if (id == a) {
-      const int64_t b = r / N, i = r - b * N;
-      const float4* __restrict__ src = reinterpret_cast<const float4*>(dx + b * mol_stride + i * row_stride);
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  const bool mine = lane * CPL < width;
+  // 64 ids per wave and step (lane = row, coalesced); the matching rows are then visited one by one
+  // with lane = column(s): no cross-lane reduction at the end
+  for (int64_t r0 = lo + 64 * wave; r0 < hi; r0 += 256) {
+    const int64_t r = r0 + lane;
+    int64_t id = r < hi ? ids[r] : -1;
+    const bool hit = r < hi && (id < 0 ? 0 : (id >= num_atom ? num_atom - 1 : id)) == a;   // (the forward's clamp)
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      // up to eight matching rows in flight (padding rows carry id 0: a third of all rows for that
+      // atom — one dependent load after the other made its workgroups the launch's long pole);
+      // added in row order, a missing one adds 0.0
+      float v[8][CPL];
 #pragma unroll
-      for (int c = 0; c < W4; ++c) {
-        const float4 v = src[c];
-        acc[c].x += v.x, acc[c].y += v.y, acc[c].z += v.z, acc[c].w += v.w;
+      for (int u = 0; u < 8; ++u) {
+        const bool have = m != 0;
+        const int k = have ? __builtin_ctzll(m) : 0;
+        m &= m - 1;
+        const int64_t rr = r0 + k, b = rr / N, i = rr - b * N;
+        const float* __restrict__ src = dx + b * mol_stride + i * row_stride + lane * CPL;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) v[u][c] = (have && mine) ? src[c] : 0.0f;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) acc[c] += v[u][c];
     }
   }
-  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-  for (int c = 0; c < W4; ++c) {
-    float v[4] = {acc[c].x, acc[c].y, acc[c].z, acc[c].w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v[e] += __shfl_xor(v[e], off, 64);
-      if (lane == 0) red[wave][4 * c + e] = v[e];
-    }
-  }
+  for (int c = 0; c < CPL; ++c) red[wave][lane * CPL + c] = acc[c];
   __syncthreads();
-  if (tid < W4 * 4)
-    part[((int64_t)chunk * num_atom + a) * (W4 * 4) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid < width)
+    part[((int64_t)chunk * num_atom + a) * width + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 extern "C" int lnz_embedding_grad(const int64_t* ids, int B, int N, const float* dx, int64_t mol_stride,
@@ -407,12 +417,10 @@ extern "C" int lnz_embedding_grad(const int64_t* ids, int B, int N, const float*
   const dim3 grid(num_atom, chunks);
   const int64_t rows = (int64_t)B * N;
   hipStream_t s = (hipStream_t)stream;
-#define LNZ_EG(W4) hipLaunchKernelGGL(embedding_grad_kernel<W4>, grid, dim3(256), 0, s, ids, dx, rows, N, \
-                                      mol_stride, row_stride, num_atom, partials)
-  if (width == 16) LNZ_EG(4);
-  else if (width == 32) LNZ_EG(8);
-  else if (width == 64) LNZ_EG(16);
-  else LNZ_EG(32);
+#define LNZ_EG(CPL) hipLaunchKernelGGL(embedding_grad_kernel<CPL>, grid, dim3(256), 0, s, ids, dx, rows, N, \
+                                       mol_stride, row_stride, width, num_atom, partials)
+  if (width <= 64) LNZ_EG(1);
+  else LNZ_EG(2);
 #undef LNZ_EG
   return lnz::check_launch("lnz_embedding_grad");
 }

@@ -651,7 +651,7 @@ def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
           (g[:, o6:ob].view(L, S, 128), g[:, ob + 384:ob + 384 + S])]
 
 
-def embedding_grad(ids, dx, width, num_atom, chunks=32):
+def embedding_grad(ids, dx, width, num_atom, chunks=64):
   """lnz_embedding_grad: dE [num_atom, width] = sum of the rows dx[b, i, :width] by atom id ids[b, i]
   (ids [B, N] int64; dx [B, >= N, >= width] fp32 with a contiguous last dimension) — the embedding
   table's gradient without atomics (partials per row chunk, added in a fixed order)."""

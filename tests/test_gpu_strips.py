@@ -394,3 +394,62 @@ def test_laplacian_pack_conversion_alone_and_under_the_gains_launch():
   assert ride.cpu().numpy().reshape(-1).tobytes() == want.tobytes() and ride.fp16_pieces
   with pytest.raises(RuntimeError, match='converted'):
     ops.lanczosnet_forward(plan32, t(b['node_feat']), ride, V, G0, t(b['node_mask'].astype(np.uint8)))
+
+
+@pytest.mark.parametrize('B,nmin,nmax', [(1024, 8, 26), (37, 1, 32), (5, 3, 9)])
+def test_message_pass_on_strips_matches_the_tile_kernel_and_the_definition(B, nmin, nmax, monkeypatch):
+  """lnz_lanczosnet_messages on the strip plan (csrc/conv_strip.hip strip_messages) against the
+  32-row-tile kernel and against the definition msg[:, c] = M_c X_l in float64 (long scales: V diag(g)
+  V^T), layer 0 (input width 64) and a hidden layer, compact and padded row numbering."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.synthetic import draw_batch
+  cfg = dict(oracle.DEFAULT_QM8_CFG)
+  net, _ = _split_net(cfg, 6)
+  b = draw_batch(B, seed=9, n_min=nmin, n_max=nmax)
+  t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+  n = t(b['n_nodes'])
+  L = ops.laplacian_l4(t(b['adjs']), n)
+  K = 20
+  D, V = ops.lanczos_ritz(L[..., 0], n, K)
+  plan = net._plan()
+  mk = t(b['node_mask'].astype(np.uint8))
+  Lp, tiles, rows = ops.pack_and_plan(plan, L, mk, K)
+  assert getattr(tiles[0], 'strips', None) is not None
+  G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'], rows=rows)
+  Lnum, N = cfg['num_layer'], b['node_mask'].shape[1]
+  act = torch.zeros((Lnum, B, 32, 128), device=DEV)
+  with torch.no_grad():
+    ops.lanczosnet_forward(plan, t(b['node_feat']), Lp, V, G, mk, tiling=tiles, act_out=act)
+  x0 = torch.zeros((B, 32, plan['din0']), device=DEV)
+  x0[:, :N, :cfg['input_dim']] = net.embedding.weight.detach()[t(b['node_feat'])]
+  n_mol = n.long()
+  row_off = (torch.cumsum(n_mol, 0) - n_mol).contiguous()
+  R_tot = int(n_mol.sum())
+  Cn = plan['n_long'] + plan['n_edge']
+  Ld, Vd, Gd = L.double(), V.double(), G.double()
+  for layer in (0, 3):
+    d = plan['din0'] if layer == 0 else 128
+    X = (x0 if layer == 0 else act[layer - 1])[:, :N].double()                    # [B, N, d]
+    want = []
+    for s in range(plan['n_long']):
+      want.append(Vd @ (Gd[layer, :, s, :, None] * (Vd.transpose(1, 2) @ X)))
+    for e in range(plan['n_edge']):
+      want.append(Ld[:, :, :, e] @ X)
+    want = torch.stack(want, dim=2)                                                # [B, N, C, d]
+    real = torch.arange(N, device=DEV)[None, :] < n[:, None]
+    out = {}
+    for strips in ('1', '0'):
+      monkeypatch.setenv('LNZ_STRIPS', strips)
+      msg_c = torch.full((R_tot, Cn * d), float('nan'), device=DEV)
+      ops.lanczosnet_messages(plan, Lp, V, G, mk, act, x0, layer, msg_c, tiles, row_off=row_off)
+      msg_p = torch.zeros((B * 32, Cn * d), device=DEV)
+      ops.lanczosnet_messages(plan, Lp, V, G, mk, act, x0, layer, msg_p, tiles)
+      out[strips] = (msg_c, msg_p)
+      assert torch.isfinite(msg_c).all()          # every compact row is written
+      got = msg_c.double().view(R_tot, Cn, d)
+      ref = want[real]                             # rows in (molecule, node) order = the compact numbering
+      assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (layer, strips)
+      padded = msg_p.view(B, 32, Cn, d)[:, :N][real].double()
+      assert float((padded - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (layer, strips)
+    scale = float(out['0'][0].abs().max())
+    assert float((out['1'][0] - out['0'][0]).abs().max()) <= 2e-6 * scale
