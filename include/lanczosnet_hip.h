@@ -418,7 +418,8 @@ typedef struct lnz_forward_args {
   /* ---- optional (ABI 5): strip plan of lnz_plan_strips.  With it the width-128 launches run on
    * strips of 16-row subtiles (conv_strip.hip) instead of 32-row tiles: the forward (inference and
    * training, both GEMM modes; gemm_mode 1 exists on strips only), the input-gradient pass (see
-   * dbias_part_cap) and the gain-gradient pass.  lnz_lanczosnet_messages ignores it. */
+   * dbias_part_cap), the message pass (diagonal gains, no short-diffusion channels) and the
+   * gain-gradient pass. */
   const int32_t* strips;      /* [strip_cap][LNZ_STRIP_INTS] int32                                   */
   const int32_t* n_strips;    /* device scalar: strips in use                                        */
   int strip_cap;              /* lnz_strip_cap(B): entries in `strips` (= grid size)                 */
