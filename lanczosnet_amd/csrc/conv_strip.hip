@@ -130,7 +130,9 @@ constexpr int strip_lds_floats(int S, int nl, bool half = false) {
 // channels — all as in conv_forward16.hip.  HALF: GEMM1 in split precision (x_hi w_hi + x_lo w_hi +
 // x_hi w_lo on v_mfma_f32_16x16x32_f16, fp32 accumulate: 3 x 16 cycles per 32-k block and subtile
 // instead of 8 x 32), node state in LDS as fp16 pieces (above), weights from lnz_pack_rows_k8_split;
-// everything behind GEMM1's accumulators is the exact-fp32 code.
+// the block products (Laplacian blocks from a pack converted by lnz_split_laplacian_pack, Ritz blocks
+// pre-split in LDS; lift and projection) run in the same split on subtile pairs (apply_split below);
+// gains, biases, ReLU, the head and all accumulation are the exact-fp32 code.
 template <int S, int MODE, int FK, bool SHORT, bool HALF>
 __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restrict__ ent, float* lds,
                                               const int tid, const int wave) {

@@ -261,7 +261,7 @@ FLOP_PER_MFMA16X32_F16 = 2 * 16 * 16 * 32
 
 
 def strip_split_mfma_issued(strips, cfg):
-  """lanczosnet_strip_kernel<.., HALF> (gemm_mode 2): v_mfma_f32_16x16x32_f16 instructions (16384 flop)
+  """lanczosnet_strip_kernel<.., HALF> (gemm_mode 1): v_mfma_f32_16x16x32_f16 instructions (16384 flop)
   one launch issues — per layer and wave GEMM1 = channels x four 32-k blocks x three products x S
   subtiles (every layer is 128 wide there), and each block-diagonal product (the edge types' GEMM2,
   the lift, the next layer's projection) = three products per subtile PAIR a row subtile touches.
