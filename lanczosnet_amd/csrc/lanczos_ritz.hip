@@ -992,7 +992,12 @@ __device__ __forceinline__ void lanczos_ritz32_body(
 #endif
 }
 
-__global__ __launch_bounds__(64) void lanczos_ritz32_kernel(
+#ifdef LNZ_RITZ_VGPR160   // (probe: a wave that fits next to two 176-register forward waves on a SIMD)
+#define LNZ_RITZ32_ATTR __attribute__((amdgpu_num_vgpr(80)))
+#else
+#define LNZ_RITZ32_ATTR
+#endif
+__global__ __launch_bounds__(64) LNZ_RITZ32_ATTR void lanczos_ritz32_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int64_t sc,
     const int32_t* __restrict__ n_nodes, int N, int K, float* __restrict__ D,
     float* __restrict__ V, int32_t* __restrict__ info) {
