@@ -581,8 +581,6 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True,
   MLP launch (split_laplacian_pack() as part of this launch)."""
   _need_cuda(D, mlp_pack, split_pack)
   D = _f32c(D)
-  B, K = D.shape
-  S = len(dist)
   use_rows = rows is not None and mlp_pack is not None
   ride = None
   if split_pack is not None and not getattr(split_pack, 'fp16_pieces', False):
