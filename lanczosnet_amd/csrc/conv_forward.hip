@@ -1362,7 +1362,12 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
                       (a.msg_layer > 0 || a.x0),
                   LNZ_EINVAL, "%s: need msg, msg_layer in range, x0 for layer 0", who);
       LNZ_REQUIRE(a.msg_layer == 0 || a.act, LNZ_EINVAL, "%s: act missing", who);
-      if (strips_enabled() && lnz::strip_messages_eligible(a)) return lnz::launch_strip_messages(a, s);
+      // (the 32-row-tile instantiations of this pass — 204 and 598 spilled scalars, 21 spilled vector
+      // registers — went in r05: every training batch carries a strip plan)
+      LNZ_REQUIRE(lnz::strip_messages_eligible(a), LNZ_ENOTSUP,
+                  "%s: built on the strip plan: strips, hidden width 128, input width %% 16 == 0 and <= 128, "
+                  "<= 16 long scales, K %% 4 == 0 for dense filters", who);
+      return lnz::launch_strip_messages(a, s);
     }
   }
   const int grid = a.plan ? a.plan_wg_cap : (a.B + 3) / 4;  // upper bound of the workgroup count
@@ -1386,10 +1391,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
   // model with an input width that is a multiple of 64 takes the 8-slot ring in the forward
   // modes; the backward modes always take the 4-slot ring.
   const bool all_deep = a.dhid == 128 && a.din0 % 64 == 0;
-  if (mode == 2) {
-    if (a.filter_kind == 0) LNZ_LAUNCH_D(4, 10, 0, 2, 0);
-    else LNZ_LAUNCH_D(4, 10, 2, 2, 0);
-  } else if (a.filter_kind == 0) {
+  if (a.filter_kind == 0) {
     if (all_deep) LNZ_LAUNCH_D(4, 10, 0, 0, 1);
     else if (a.dhid == 128) LNZ_LAUNCH(4, 10, 0, 0);
     else LNZ_LAUNCH(2, 10, 0, 0);

@@ -1082,9 +1082,10 @@ __device__ __forceinline__ void strip_gain_grad(KArgs& a, const int32_t* __restr
 // dY_l^T msg_l is one GEMM.  No GEMM1 and no node-state buffers: wave w loads its 16 columns of X_l
 // straight into C/D order (register q of subtile I = row 16 I + 4 kq + q), projects once (Y = V^T X),
 // and per channel either scales Y by the gains and lifts it (long scales) or multiplies with the
-// Laplacian blocks (edge types); the products are the forward's block loops.  Diagonal gains, no
-// short-diffusion channels.
-template <int S>
+// Laplacian blocks (edge types); the products are the forward's block loops.  FK 0: diagonal gains;
+// FK 2: dense K x K filters in eigen space (AdaLanczosNet: V DD_s V^T X).  SHORT: short-diffusion
+// channels L_0^p X in front (channel order [short][long][edge], as everywhere).
+template <int S, int FK, bool SHORT>
 __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restrict__ ent, float* lds,
                                                const int tid, const int wave) {
   constexpr int R = 16 * S;
@@ -1092,7 +1093,8 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
   const int lane = tid & 63;
   const int j = lane & 15, kq = lane >> 4;
   const int N = a.N, K = a.K, B = a.B;
-  const int nl = a.n_long, ne = a.n_edge, C = nl + ne;
+  constexpr bool DIAG = FK == 0;
+  const int ns = SHORT ? a.n_short : 0, nl = a.n_long, ne = a.n_edge, C = ns + nl + ne;
   const int la = a.msg_layer;
   const int d = la == 0 ? a.din0 : 128;
   const float* __restrict__ src = la == 0 ? a.x0 : a.act + (int64_t)(la - 1) * B * 32 * 128;
@@ -1137,7 +1139,7 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
     }
     Vb[((Jn * 3 + dd) * 16 + nu) * VBP + ro] = v;
   }
-  for (int idx = tid; idx < nl * R; idx += 512) {   // this layer's gains by slot row
+  for (int idx = tid; idx < (DIAG ? nl * R : 0); idx += 512) {   // this layer's gains by slot row
     const int sc = idx / R, rho = idx - sc * R;
     const int own = rowinfo[rho];
     float g = 0.0f;
@@ -1149,8 +1151,11 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
   }
   // per-lane addressing of the packed Laplacian (as in the forward)
   unsigned loff[S][3];
+  unsigned doff[DIAG ? 1 : S][3];  // FK 2: fragment (I, J) of a dense filter (as in the forward)
   const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.Lp), 0, B * ne * 4096, 0x00020000);
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.G), 0, (!DIAG && nl > 0) ? a.num_layer * B * nl * K * K * 4 : 0, 0x00020000);
 #pragma unroll
   for (int I = 0; I < S; ++I) {
     const int row = 16 * I + j;
@@ -1160,14 +1165,17 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
 #pragma unroll
     for (int dd = 0; dd < 3; ++dd) {
       const int J = I + dd - 1;
-      unsigned off = OOB;
+      unsigned off = OOB, dof = OOB;
       if (J >= 0 && J < S) {
         const int cg = 16 * J + 4 * kq;
         const int c = cg - st;
-        if (own >= 0 && rowinfo[cg] == own)
+        if (own >= 0 && rowinfo[cg] == own) {
           off = (unsigned)((mol * ne * 256 + (c >> 3) * 64 + ((c >> 2) & 1) * 32 + (row - st)) * 16);
+          if (row - st < K && c < K) dof = (unsigned)((((mol * nl) * K + (row - st)) * K + c) * 4);
+        }
       }
       loff[I][dd] = off;
+      if constexpr (!DIAG) doff[I][dd] = dof;
     }
   }
   // this wave's 16 columns of X_l in C/D order
@@ -1222,7 +1230,46 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
     }
     ++chan;
   };
-  // ---- long scales: V diag(g_s) V^T X_l
+  // ---- short-diffusion channels: L_0^p X_l
+  if constexpr (SHORT) {
+    f32x4 mop[S][3];
+    if (active) {
+#pragma unroll
+      for (int I = 0; I < S; ++I)
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd) {
+          if (I + dd - 1 < 0 || I + dd - 1 >= S) continue;
+          mop[I][dd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(l_rsrc, loff[I][dd], 0, 0));
+        }
+    }
+    for (int c = 0; c < ns; ++c) {
+      f32x4 Zc[S];
+#pragma unroll
+      for (int I = 0; I < S; ++I) Zc[I] = Xc[I];
+      const int p = a.short_dist[c];
+      if (active) {
+        for (int rep = 0; rep < p; ++rep) {
+          f32x4 Zn[S];
+#pragma unroll
+          for (int I = 0; I < S; ++I) Zn[I] = splat4(0.f);
+#pragma unroll
+          for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int I = 0; I < S; ++I) {
+                const int J = I + dd - 1;
+                if (J < 0 || J >= S) continue;
+                Zn[I] = mfma16(mop[I][dd][r], Zc[J][r], Zn[I]);
+              }
+#pragma unroll
+          for (int I = 0; I < S; ++I) Zc[I] = Zn[I];
+        }
+      }
+      emit(Zc, active);
+    }
+  }
+  // ---- long scales: V diag(g_s) V^T X_l  (FK 2: V DD_s V^T X_l)
   if (nl > 0) {
     f32x4 Y[S];
 #pragma unroll
@@ -1251,11 +1298,35 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
       f32x4 out[S];
       if (active) {
         f32x4 T[S];
+        if constexpr (DIAG) {
 #pragma unroll
-        for (int I = 0; I < S; ++I) {
-          T[I] = *reinterpret_cast<const f32x4*>(Gs + s * R + 16 * I + 4 * kq) * Y[I];
-          out[I] = splat4(0.f);
+          for (int I = 0; I < S; ++I) T[I] = *reinterpret_cast<const f32x4*>(Gs + s * R + 16 * I + 4 * kq) * Y[I];
+        } else {
+          f32x4 dd_[S][3];
+#pragma unroll
+          for (int I = 0; I < S; ++I) {
+            T[I] = splat4(0.f);
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+              if (I + dd - 1 < 0 || I + dd - 1 >= S) continue;
+              dd_[I][dd] = __builtin_bit_cast(
+                  f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, doff[DIAG ? 0 : I][dd],
+                                                               (la * B * nl + s) * K * K * 4, 0));
+            }
+          }
+#pragma unroll
+          for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int I = 0; I < S; ++I) {
+                const int J = I + dd - 1;
+                if (J < 0 || J >= S) continue;
+                T[I] = mfma16(dd_[I][dd][r], Y[J][r], T[I]);
+              }
         }
+#pragma unroll
+        for (int I = 0; I < S; ++I) out[I] = splat4(0.f);
 #pragma unroll
         for (int dd = 0; dd < 3; ++dd)
 #pragma unroll
@@ -1300,6 +1371,7 @@ __device__ __forceinline__ void strip_messages(KArgs& a, const int32_t* __restri
   }
 }
 
+template <int FK, bool SHORT>
 __global__ __launch_bounds__(512) void lanczosnet_strip_messages_kernel(const lnz_forward_args) {
   KArgs& a = *(KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) float lds_strip[];
@@ -1309,12 +1381,12 @@ __global__ __launch_bounds__(512) void lanczosnet_strip_messages_kernel(const ln
   const int32_t* ent = a.strips + (int64_t)blockIdx.x * LNZ_STRIP_INTS;
   const int sub = __builtin_amdgcn_readfirstlane(ent[1]);
   switch (sub) {
-    case 1: strip_messages<1>(a, ent, lds_strip, tid, wave); break;
-    case 2: strip_messages<2>(a, ent, lds_strip, tid, wave); break;
-    case 3: strip_messages<3>(a, ent, lds_strip, tid, wave); break;
-    case 4: strip_messages<4>(a, ent, lds_strip, tid, wave); break;
-    case 5: strip_messages<5>(a, ent, lds_strip, tid, wave); break;
-    case 6: strip_messages<6>(a, ent, lds_strip, tid, wave); break;
+    case 1: strip_messages<1, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 2: strip_messages<2, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 3: strip_messages<3, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 4: strip_messages<4, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 5: strip_messages<5, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
+    case 6: strip_messages<6, FK, SHORT>(a, ent, lds_strip, tid, wave); break;
     default: break;
   }
 }
@@ -1402,8 +1474,11 @@ bool strip_gain_grad_eligible(const lnz_forward_args& a) {
 // lnz_lanczosnet_messages on strips (the arguments have passed that entry point's checks)
 bool strip_messages_eligible(const lnz_forward_args& a) {
   if (!a.strips || !a.n_strips || a.strip_cap <= 0) return false;
-  if (a.gemm_mode != 0 || a.filter_kind != 0 || a.dhid != 128 || a.n_short != 0) return false;
+  if (a.gemm_mode != 0 || (a.filter_kind != 0 && a.filter_kind != 1) || a.dhid != 128) return false;
   if (a.din0 % 16 != 0 || a.din0 > 128 || a.n_edge < 1 || a.n_long > 16) return false;
+  if (a.filter_kind == 1 && a.K % 4 != 0) return false;
+  const int64_t per_slot = a.filter_kind == 1 ? (int64_t)a.K * a.K : a.K;
+  if ((int64_t)a.num_layer * a.B * a.n_long * per_slot * 4 >= (1ll << 31)) return false;
   return (int64_t)a.B * a.n_edge * 4096 < (1ll << 31);
 }
 
@@ -1411,9 +1486,15 @@ int launch_strip_messages(const lnz_forward_args& a, hipStream_t s) {
   const size_t bytes = (size_t)(LNZ_STRIP_SUB * 3 * 16 * VBP + a.n_long * 16 * LNZ_STRIP_SUB +
                                 2 * 16 * LNZ_STRIP_SUB + 3 * MAXMOL + 8 + 2 * 16 * LNZ_STRIP_SUB * 132) * sizeof(float);
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
-  (void)hipFuncSetAttribute((const void*)lanczosnet_strip_messages_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(lanczosnet_strip_messages_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
+  const void* fns[4] = {(const void*)lanczosnet_strip_messages_kernel<0, false>,
+                        (const void*)lanczosnet_strip_messages_kernel<0, true>,
+                        (const void*)lanczosnet_strip_messages_kernel<2, false>,
+                        (const void*)lanczosnet_strip_messages_kernel<2, true>};
+  const void* fn = fns[(a.filter_kind == 0 ? 0 : 2) + (a.n_short > 0 ? 1 : 0)];
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  lnz_forward_args args = a;
+  void* params[] = {&args};
+  (void)hipLaunchKernel(fn, dim3(a.strip_cap), dim3(512), params, bytes, s);
   return check_launch("lnz_lanczosnet_messages (strips)");
 }
 

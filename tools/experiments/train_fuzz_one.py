@@ -1,4 +1,5 @@
-"""One configuration of train_fuzz.py three ways: HIP backward on strips, on 32-row tiles, torch."""
+"""One configuration of train_fuzz.py three ways: HIP backward on strips, on 32-row tiles, torch.
+(Ran at the commit before the tile form of the message pass was retired; LNZ_STRIPS=0 now refuses it.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
