@@ -194,53 +194,93 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
   __syncthreads();
 
   // ---- embedding gather / float features (model/lanczos_net.py:154, lanczos_net_general.py:156)
+  //      Three entries per thread at a time, every load unconditional (a row nobody owns reads
+  //      element 0 and stores zeros): the ids of all three are in flight together, then the three
+  //      rows — one load after the other, each waited for, was 2 x 2.5 global round trips of the
+  //      prologue's 8.7 us
   {
-    const int d4 = a.din0 >> 2;
-    for (int idx = tid; idx < R * d4; idx += 512) {
-      const int row = idx / d4, c4 = idx - row * d4;
-      const int own = rowinfo[row];
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (own >= 0 && !FWD) {  // the incoming gradient dY of the last conv layer
-        v = reinterpret_cast<const float4*>(
-            a.dy + (((int64_t)(a.num_layer - 1) * B + mid[own]) * 32 + (row - mstart[own])) * 128)[c4];
-      } else if (own >= 0) {
-        const int mol = mid[own], lrow = row - mstart[own];
-        if (lrow < N) {
-          if (a.node_feat) {
-            int64_t id = a.node_feat[(int64_t)mol * N + lrow];
-            id = id < 0 ? 0 : (id >= a.num_atom ? a.num_atom - 1 : id);
-            v = reinterpret_cast<const float4*>(a.embedding + id * a.din0)[c4];
-          } else {
-            v = reinterpret_cast<const float4*>(a.node_feat_f + ((int64_t)mol * N + lrow) * a.din0)[c4];
-          }
-        }
+    const int d4 = a.din0 >> 2, total = R * d4;
+    constexpr int UN = 3;
+    for (int base = tid; base < total; base += 512 * UN) {
+      int row[UN], c4[UN];
+      bool in[UN], valid[UN];
+      int64_t at[UN];   // element offset of the source row (or the id's position)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + 512 * u;
+        in[u] = idx < total;
+        row[u] = in[u] ? idx / d4 : 0;
+        c4[u] = in[u] ? idx - row[u] * d4 : 0;
+        const int own = rowinfo[row[u]];
+        const int mol = own >= 0 ? mid[own] : 0, lrow = own >= 0 ? row[u] - mstart[own] : 0;
+        valid[u] = in[u] && own >= 0 && (!FWD || lrow < N);
+        at[u] = !valid[u] ? 0
+                : !FWD   ? (((int64_t)(a.num_layer - 1) * B + mol) * 32 + lrow) * 128
+                         : (int64_t)mol * N + lrow;
       }
-      xs_put4<HALF>(&Xs[row * P], c4, v);
+      if (FWD && a.node_feat) {
+        int64_t id[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) id[u] = a.node_feat[at[u]];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int64_t c = id[u] < 0 ? 0 : (id[u] >= a.num_atom ? a.num_atom - 1 : id[u]);
+          at[u] = valid[u] ? c * a.din0 : 0;
+        }
+      } else if (FWD) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) at[u] *= a.din0;
+      }
+      const float* __restrict__ srcb = !FWD ? a.dy : (a.node_feat ? a.embedding : a.node_feat_f);
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) v[u] = reinterpret_cast<const float4*>(srcb + at[u])[c4[u]];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (in[u]) xs_put4<HALF>(&Xs[row[u] * P], c4[u], valid[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
   // ---- Ritz blocks: Vb[Jn][d][nu][ro] = V[molecule][node][slot] when node row 16 Jn + nu and
   //      slot row 16 (Jn + d - 1) + ro belong to the same molecule (slot k of a molecule rides on
   //      its k-th row), zero elsewhere
+  //      (every load of a thread unconditional and in flight before the first store: element 0 where
+  //      the entry is zero)
   if constexpr (HALF) {
-    for (int idx = tid; idx < 2 * S * 3 * 64; idx += 512) {
+    constexpr int NV = (2 * S * 3 * 64 + 511) / 512;
+    float vv[NV][4];
+    bool ok[NV][4];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + 512 * u;
+      const bool in = idx < 2 * S * 3 * 64;
       const int proj = idx >= S * 3 * 64 ? 1 : 0;
-      const int i0 = idx - proj * S * 3 * 64;
+      const int i0 = in ? idx - proj * S * 3 * 64 : 0;
       const int I = i0 / 192, rem = i0 - I * 192;
       const int d = rem >> 6, jj = rem & 15, kk = (rem >> 4) & 3;
       const int J = I + d - 1;
-      f32x4 v = splat4(0.f);
-      if (J >= 0 && J < S) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nrow = proj ? 16 * J + 4 * kk + r : 16 * I + jj;
-          const int srow = proj ? 16 * I + jj : 16 * J + 4 * kk + r;
+      for (int r = 0; r < 4; ++r) {
+        const int nrow = proj ? 16 * J + 4 * kk + r : 16 * I + jj;
+        const int srow = proj ? 16 * I + jj : 16 * J + 4 * kk + r;
+        int64_t at = 0;
+        ok[u][r] = false;
+        if (in && J >= 0 && J < S) {
           const int own = rowinfo[nrow];
           if (own >= 0 && rowinfo[srow] == own) {
             const int lnode = nrow - mstart[own], k = srow - mstart[own];
-            if (lnode < N && k < K) v[r] = finite_or_zero(a.V[((int64_t)mid[own] * N + lnode) * K + k]);
+            if (lnode < N && k < K) ok[u][r] = true, at = ((int64_t)mid[own] * N + lnode) * K + k;
           }
         }
+        vv[u][r] = a.V[at];
       }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + 512 * u;
+      if (idx >= 2 * S * 3 * 64) continue;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = ok[u][r] ? finite_or_zero(vv[u][r]) : 0.0f;
       f16x8 h = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, l = h;
       split_into(v, 0, h, l);
 #pragma unroll
@@ -248,20 +288,35 @@ __device__ __forceinline__ void strip_forward(KArgs& a, const int32_t* __restric
       *reinterpret_cast<f16x8*>(Vb + 4 * idx) = h;
     }
   } else {
-  for (int idx = tid; idx < S * 3 * 256; idx += 512) {
-    const int Jn = idx / 768, rem = idx - Jn * 768;
-    const int d = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
-    const int nrow = 16 * Jn + nu, srow = 16 * (Jn + d - 1) + ro;
-    float v = 0.0f;
-    if (srow >= 0 && srow < R) {
-      const int own = rowinfo[nrow];
-      if (own >= 0 && rowinfo[srow] == own) {
-        const int lnode = nrow - mstart[own], k = srow - mstart[own];
-        if (lnode < N && k < K) v = finite_or_zero(a.V[((int64_t)mid[own] * N + lnode) * K + k]);
+    constexpr int NV = (S * 3 * 256 + 511) / 512;
+    float vv[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + 512 * u;
+      const bool in = idx < S * 3 * 256;
+      const int Jn = idx / 768, rem = idx - Jn * 768;
+      const int d = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
+      const int nrow = 16 * Jn + nu, srow = 16 * (Jn + d - 1) + ro;
+      int64_t at = 0;
+      ok[u] = false;
+      if (in && srow >= 0 && srow < R) {
+        const int own = rowinfo[nrow];
+        if (own >= 0 && rowinfo[srow] == own) {
+          const int lnode = nrow - mstart[own], k = srow - mstart[own];
+          if (lnode < N && k < K) ok[u] = true, at = ((int64_t)mid[own] * N + lnode) * K + k;
+        }
       }
+      vv[u] = a.V[at];
     }
-    Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = v;
-  }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + 512 * u;
+      if (idx >= S * 3 * 256) continue;
+      const int Jn = idx / 768, rem = idx - Jn * 768;
+      const int d = rem >> 8, nu = (rem >> 4) & 15, ro = rem & 15;
+      Vb[((Jn * 3 + d) * 16 + nu) * VBP + ro] = ok[u] ? finite_or_zero(vv[u]) : 0.0f;
+    }
   }
   // ---- spectral gains by slot row: Gs[l & 1][s][rho]; loads of layer l + 1 are issued at the
   //      start of layer l and go to LDS in front of the layer's last barrier
