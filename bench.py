@@ -653,6 +653,61 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
           'parity': parity, 'finite': finite}
 
 
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher around it: re-run this command line as N ranks
+  under torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a free port) and hand
+  back its exit status.  The children see RANK / WORLD_SIZE and take the ordinary path."""
+  import socket
+  import subprocess
+  rc = 1
+  for attempt in range(3):  # a port taken between the probe and the rendezvous: try another
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               LNZ_BENCH_SELF_SPAWNED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)]
+    p = subprocess.run(cmd + sys.argv[1:], env=env, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(p.stderr)
+    rc = p.returncode
+    if rc == 0 or 'ddress already in use' not in p.stderr:
+      break
+  return rc
+
+
+def shard_parity(cfg, params, batch, score, n_check):
+  """This rank's own shard against the oracle on a bounded sample (the first n_check molecules of
+  the shard it timed): the same figure as `parity_rel_err`, normalised by the sample's largest
+  reference score, degenerate top-K cuts excluded by the same rule.  Every rank runs it, so that an
+  N-rank line verifies N shards and not only seed 0."""
+  import oracle
+  n_check = min(n_check, batch['node_mask'].shape[0])
+  N = batch['node_mask'].shape[1]
+  K = cfg['num_eig_vec']
+  L = np.zeros((n_check, N, N, 7), np.float32)
+  Dl, Vl = [], []
+  ambiguous = np.zeros(n_check, bool)
+  for b in range(n_check):
+    nb = int(batch['n_nodes'][b])
+    L[b, :nb, :nb] = oracle.laplacian_multi_l4(batch['adjs'][b, :nb, :nb])
+    e, V, _ = oracle.graph_laplacian_eigs(batch['adjs'][b, :nb, :nb].sum(axis=2),
+                                          graph_laplacian_type='L4')
+    Dl.append(e)
+    Vl.append(V)
+    ambiguous[b] = oracle.degenerate_cut(e, K)
+  D, V = oracle.collate_eigs(Dl, Vl, N, K)
+  ref = oracle.lanczos_net_forward_torch(params, cfg, batch['node_feat'][:n_check], L, D, V,
+                                         batch['node_mask'][:n_check]).astype(np.float64)
+  got = score[:n_check].cpu().numpy().astype(np.float64)
+  keep = ~ambiguous
+  dev = np.abs(got - ref).max(axis=1) / np.abs(ref).max()
+  return float(dev[keep].max()) if keep.any() else 0.0, int(keep.sum())
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -664,6 +719,8 @@ def main():
                   help='software pipeline over the stream of batches: one launch prepares batch k+1 '
                        'and computes the spectral gains of batch k')
   ap.add_argument('--cpu-reps', type=int, default=5)
+  ap.add_argument('--shard-parity', type=int, default=64,
+                  help='N > 1: molecules of its own shard every rank checks against the oracle')
   ap.add_argument('--no-secondary', action='store_true',
                   help='skip the secondary legs (large-graph Lanczos, AdaLanczosNet)')
   ap.add_argument('--sweep', action='store_true',
@@ -682,15 +739,31 @@ def main():
                   help='diagnostic only (power/DVFS probe): all-zero weights; never reported')
   args = ap.parse_args()
 
+  one_dev = os.environ.get('LNZ_BENCH_ONE_DEVICE', '0') == '1'
+  launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+  if args.gpus < 1:
+    raise SystemExit('bench.py: --gpus must be >= 1')
+  # the N ranks need N devices (runner/qm8_runner.py:62 hands nn.DataParallel its `gpus` list the
+  # same way): fewer visible is an error, not a silently smaller job
+  n_dev = torch.cuda.device_count()
+  if not one_dev and n_dev < args.gpus:
+    raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) visible; nothing measured '
+                     '(LNZ_BENCH_ONE_DEVICE=1 runs the N-rank path on one device over gloo as a '
+                     'functional test)' % (args.gpus, n_dev))
+  if not launched and args.gpus > 1:
+    # plain `python bench.py --gpus N`: become the launcher — N ranks, one per GPU, under
+    # torch.distributed.run on the loopback rendezvous; rank 0's JSON line is this process's stdout
+    raise SystemExit(spawn_ranks(args.gpus))
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d inside a %d-rank launch (WORLD_SIZE): the two must agree'
+                     % (args.gpus, world))
   dist = None
   # LNZ_BENCH_ONE_DEVICE=1 (functional test of the N > 1 path on a box with ONE GPU): every rank
   # uses cuda:0 and the exchange runs on gloo — RCCL refuses two ranks on one device.  Not a
   # measurement mode.
-  one_dev = os.environ.get('LNZ_BENCH_ONE_DEVICE', '0') == '1'
   if one_dev:
     local_rank = 0
   if world > 1:
@@ -825,6 +898,18 @@ def main():
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
   timed_score = score.clone()
+  shard_check = None
+  if dist and not args.zero_params:
+    # every rank verifies ITS shard (seed = rank) on a bounded sample, after the clock has stopped
+    err_r, n_r = shard_parity(cfg, params, batch, timed_score, args.shard_parity)
+    mine = {'rank': rank, 'seed': rank, 'device': '%s:%d' % (torch.cuda.get_device_name(dev), dev.index),
+            'parity_rel_err': err_r, 'molecules_checked': n_r}
+    shard_check = [None] * world
+    dist.all_gather_object(shard_check, mine)
+    # the ranks the backend really formed: a sum of ones over the group
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    ranks_formed = int(ones.item())
   # the last step's gathered scores carry this rank's shard unchanged
   gather_ok = bool(torch.equal(gather.result(gather.issued - 1)[rank * B:(rank + 1) * B],
                                timed_score)) if gather else None
@@ -1080,12 +1165,22 @@ def main():
     if dist:
       out['config']['exchange'] = {
           'backend': dist.get_backend(), 'world': world,
+          'ranks_formed': ranks_formed if shard_check is not None else dist.get_world_size(),
+          'launcher': ('bench.py --gpus %d re-ran itself under torch.distributed.run' % world
+                       if os.environ.get('LNZ_BENCH_SELF_SPAWNED') == '1' else 'torch.distributed.run (external)'),
+          'devices_visible_per_rank': n_dev,
           'collective': 'all_gather_into_tensor of the [%d,%d] f32 shard scores, every step, async '
                         '(AsyncScoreGather)' % (B, cfg['output_dim']),
           'gathered_equals_local': gather_ok,
           'ms_per_step_per_rank': per_rank_ms,
           'note': 'ms_per_step (top level) = max over the ranks; every rank times its own %d steps '
                   'between the two barriers' % args.steps}
+    if shard_check is not None:
+      out['config']['exchange']['shards'] = shard_check
+      out['config']['exchange']['shards_note'] = (
+          'every rank checks the scores of the shard it timed (draw_batch seed = rank) against the '
+          'oracle on its first %d molecules; bar 1e-5, the run fails above it' % args.shard_parity)
+      out['parity_rel_err'] = max(s_['parity_rel_err'] for s_ in shard_check)
     if split is not None:
       out['config']['split_precision_mode'] = split
     if pipe is not None:
@@ -1162,7 +1257,9 @@ def main():
     print(json.dumps(out))
     if max(out.get('parity_rel_err', 0.0), out.get('parity_rel_err_per_molecule', 0.0)) > 1e-5:
       raise SystemExit('bench.py: parity_rel_err %.3e / per molecule %.3e exceeds 1e-5'
-                       % (out['parity_rel_err'], out['parity_rel_err_per_molecule']))
+                       % (out['parity_rel_err'], out.get('parity_rel_err_per_molecule', 0.0)))
+    if dist and shard_check is not None and ranks_formed != world:
+      raise SystemExit('bench.py: the backend formed %d ranks, %d asked' % (ranks_formed, world))
   if dist:
     dist.destroy_process_group()
 
