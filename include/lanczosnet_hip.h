@@ -220,6 +220,32 @@ int lnz_lanczos_ritz_large_sym(const float* A, int64_t stride_b, int64_t stride_
                                int M, int K, void* workspace, float* D, float* V, int32_t* info,
                                lnz_stream_t stream);
 
+/* The K-step entry of the product surface: what get_graph_laplacian_eigs computes with
+ * use_eigen_decomp=False (utils/data_helper.py:205-208: `eigsh(L, k, which='LM')`, a K-dimensional
+ * Krylov method instead of the full decomposition) for graphs beyond the 192 nodes
+ * lnz_lanczos_ritz serves, ragged batches included: n_nodes [B] (optional; NULL = every graph has
+ * N nodes) are the real node counts of zero-padded matrices (dataset/graph_data.py:222-260); the
+ * Krylov vectors stay zero on the padding and the recurrence stops after n_b steps by itself.
+ * flags:
+ *   LNZ_KSTEP_SYMMETRIC  the dense stream reads only the upper 256 x 256 chunk blocks
+ *                        (= lnz_lanczos_ritz_large_sym; otherwise = lnz_lanczos_ritz_large);
+ *   LNZ_KSTEP_COMPACT    A is read from HBM ONCE: a first launch gathers the nonzeros of every
+ *                        64-row slab into a sliced-ELL image in the workspace (row_cap entries per
+ *                        row at most, a multiple of 8), and the M steps multiply by that image —
+ *                        the Laplacian of a G(n, 0.01) graph is 99 %% zeros and skipping an exact
+ *                        zero changes no sum.  A graph with a longer row is computed by the dense
+ *                        stream in the same call (dense_fallback [B], optional output: 1 for such
+ *                        a graph).  The FULL matrix is read (no UPLO convention in this mode).
+ * Same algorithm, arithmetic and outputs as lnz_lanczos_ritz_large; the three SpMV variants differ
+ * in the order of their fp64 additions only.  Deterministic. */
+#define LNZ_KSTEP_SYMMETRIC 1
+#define LNZ_KSTEP_COMPACT 2
+int64_t lnz_lanczos_ritz_kstep_workspace_bytes(int B, int N, int flags, int row_cap);
+int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r,
+                           const int32_t* n_nodes, int B, int N, int M, int K, int flags,
+                           int row_cap, void* workspace, int64_t workspace_bytes, float* D, float* V,
+                           int32_t* info, int32_t* dense_fallback, lnz_stream_t stream);
+
 /* ---- operand packing (MFMA fragment order) -------------------------------------------
  * W [rows, cols] (leading dimension ld) -> Wp[rt][q][lane][u] =
  *   W[32*rt + (lane&31)][8*q + 4*(lane>>5) + u], zero padded to rows%32==0, cols%8==0.

@@ -337,6 +337,95 @@ __device__ __forceinline__ void cgs_pass(LargeSmem& sm, const double* __restrict
   __syncthreads();
 }
 
+// ---- sliced-ELL image of a sparse dense-stored A (K-step entry, LNZ_KSTEP_COMPACT) ---------------
+// The normalised Laplacian of a G(n, p = 0.01) graph (BASELINE config 5) is 99 % zeros, and the
+// K-step recurrence multiplies by it K times.  The dense matrix is therefore read from HBM ONCE, by
+// ell_compact_kernel, which gathers the nonzeros of every 64-row slab g into
+//   vals[b][g][k][i], cols[b][g][k][i] : entry k of row 64 g + i  (k < cap; zero padded up to
+//   widths[b][g] = the slab's longest row rounded up to ELL_UNROLL)
+// — 0.4 MB per graph at n = 2048, p = 0.01 instead of 16.8 MB — and the Lanczos steps run on that
+// image (MODE 2 below).  A graph with a row of more than `cap` nonzeros raises over[b]; it is left
+// to the dense symmetric stream, launched behind (gate).  Skipping an exact zero changes no sum, so
+// the result is the dense kernels' up to the order of the fp64 additions.
+constexpr int ELL_UNROLL = 8;
+struct EllImage {
+  const float* vals;
+  const uint16_t* cols;
+  const int32_t* widths;
+  int cap;
+};
+
+// One wave per slab: rows 64 g .. 64 g + 63, each one fully coalesced 8 KiB read (lane l holds
+// columns 256 s + 4 l .. + 3 of chunk s, like the full-stream SpMV), the next row in flight while
+// the ballots of this one place its nonzeros.
+__global__ __launch_bounds__(TPB) void ell_compact_kernel(
+    const float* __restrict__ A, int64_t sb, int64_t sr, int N, int cap, float* __restrict__ vals,
+    uint16_t* __restrict__ cols, int32_t* __restrict__ widths, int32_t* __restrict__ over) {
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nslab = (N + 63) >> 6;
+  const int g = blockIdx.x * NWAVE + wave;
+  if (g >= nslab) return;
+  const float* Ab = A + (int64_t)b * sb;
+  const int64_t base = (((int64_t)b * nslab + g) * cap) * 64;
+  float* vs = vals + base;
+  uint16_t* cs = cols + base;
+  const int r0 = 64 * g, nrow = min(64, N - r0);
+  auto load_row = [&](int r, float4 (&a)[NCH]) {
+    const float* row = Ab + (int64_t)r * sr;
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      const int c0 = 256 * s + 4 * lane;
+      a[s] = (c0 < N) ? lnz_stream_f4(row + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int cnt = 0;       // lane i: entries of row r0 + i
+  int longest = 0;   // (wave-uniform)
+  auto place_row = [&](int i, const float4 (&a)[NCH]) {
+    int k = 0;  // wave-uniform running count of this row
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      const float e[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
+      const unsigned long long any = __ballot(e[0] != 0.f || e[1] != 0.f || e[2] != 0.f || e[3] != 0.f);
+      if (any == 0ull) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool nz = e[c] != 0.f;
+        const unsigned long long m = __ballot(nz);
+        if (m == 0ull) continue;
+        const int pos = k + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (nz && pos < cap) {
+          vs[(int64_t)pos * 64 + i] = e[c];
+          cs[(int64_t)pos * 64 + i] = (uint16_t)(256 * s + 4 * lane + c);
+        }
+        k += __popcll(m);
+      }
+    }
+    if (lane == i) cnt = k;
+    longest = max(longest, k);
+  };
+  {
+    float4 a0[NCH], a1[NCH];
+    if (nrow > 0) load_row(r0, a0);
+    for (int i = 0; i < nrow; i += 2) {
+      if (i + 1 < nrow) load_row(r0 + i + 1, a1);
+      place_row(i, a0);
+      if (i + 2 < nrow) load_row(r0 + i + 2, a0);
+      if (i + 1 < nrow) place_row(i + 1, a1);
+    }
+  }
+  if (longest > cap) {
+    if (lane == 0) over[b] = 1;   // (every writer stores the same value)
+    longest = cap;
+  }
+  const int w = (longest + ELL_UNROLL - 1) / ELL_UNROLL * ELL_UNROLL;  // (cap is a multiple of ELL_UNROLL)
+  for (int k = min(cnt, cap); k < w; ++k) {  // this lane's row: zero entries up to the slab's width
+    vs[(int64_t)k * 64 + lane] = 0.f;
+    cs[(int64_t)k * 64 + lane] = 0;
+  }
+  if (lane == 0) widths[(int64_t)b * nslab + g] = w;
+}
+
 #ifdef LNZ_LARGE_PROBE
 __device__ unsigned long long g_large_probe[16];
 #define LNZ_PROBE(k)                                                  \
@@ -351,14 +440,27 @@ __device__ unsigned long long g_large_probe[16];
 #define LNZ_PROBE(k)
 #endif
 
-template <bool SYM>
+// MODE 0: full stream; 1: symmetric stream (upper chunk blocks); 2: the sliced-ELL image of A that
+// ell_compact_kernel gathered (A itself is not read at all).  `gate` (optional): the per-graph
+// "row capacity exceeded" flags of the compaction — the workgroup of graph b runs only when
+// (gate[b] != 0) == gate_want, so that the ELL launch and the dense fallback launch behind it
+// split a batch between them without a host round trip.
+template <int MODE>
 __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int N, int M, int K,
     double* __restrict__ work, float* __restrict__ D,
-    float* __restrict__ V, int32_t* __restrict__ info) {
+    float* __restrict__ V, int32_t* __restrict__ info, const int32_t* __restrict__ n_nodes,
+    const int32_t* __restrict__ gate, int gate_want, EllImage ell) {
+  constexpr bool SYM = MODE == 1;
+  constexpr bool ELL = MODE == 2;
   __shared__ __attribute__((aligned(16))) LargeSmem sm;
   __shared__ SymSched sched;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (gate && (gate[b] != 0) != (gate_want != 0)) return;
+  // ragged batch: graph b has n_b <= N nodes, rows / columns >= n_b of its matrix are zero padding
+  // (dataset/graph_data.py:222-260).  Only the start vector has to know: a Krylov vector that is
+  // zero on the padding stays zero there, and the recurrence stops by itself after n_b steps.
+  const int n_b = n_nodes ? min(max(n_nodes[b], 0), N) : N;
   const int wave = tid >> 6, lane = tid & 63;
   const float* Ab = A + (int64_t)b * sb;
   double* Qg = work + (int64_t)b * MMAX * N;
@@ -374,7 +476,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
   double part = 0.0;
   for (int r = tid; r < NCH * 256; r += TPB) {
     double w = 0.0;
-    if (r < N) {
+    if (r < n_b) {
       unsigned hsh = (unsigned)(r + 1) * 2654435761u;
       w = 1.0 + (double)((hsh >> 8) & 0xffff) * (1.0 / 65536.0);
     }
@@ -391,7 +493,8 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
   int steps = 0;
   for (int j = 0; j < M; ++j) {
     const double nrm = sqrt(nrm2);
-    if (j > 0 && nrm <= kTol) break;  // invariant subspace reached: stop (slots stay zero)
+    // invariant subspace reached: stop (slots stay zero); an empty graph takes no step at all
+    if ((j > 0 || n_b == 0) && nrm <= kTol) break;
     if (j > 0 && tid == 0) sm.ee[j - 1] = nrm;
     const double ninv = 1.0 / nrm;
     for (int r = tid; r < NCH * 256; r += TPB) {
@@ -546,6 +649,56 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
         sm.ws[r] = acc;
         part = fma(acc, acc, part);  // |w|^2 on the way (rows past N are zeros)
       }
+    } else if constexpr (ELL) {
+      // ---- SpMV on the sliced-ELL image: lane i of the wave that owns slab g forms row 64 g + i,
+      //      entry k of the slab's rows is one coalesced 256-byte (values) + 128-byte (columns)
+      //      read; q is gathered from LDS.  Entries in the order the compaction met them
+      //      (fixed), padded with zeros to the slab's width (a multiple of ELL_UNROLL).
+      const int nslab = (N + 63) >> 6;
+      part = 0.0;
+      for (int g = wave; g < nslab; g += NWAVE) {
+        const int w = __builtin_amdgcn_readfirstlane(ell.widths[(int64_t)b * nslab + g]);
+        const int64_t base = (((int64_t)b * nslab + g) * ell.cap) * 64 + lane;
+        const float* vp = ell.vals + base;
+        const uint16_t* cp = ell.cols + base;
+        double acc0 = 0.0, acc1 = 0.0;
+        float vb[ELL_UNROLL];
+        uint16_t cb[ELL_UNROLL];
+        if (w > 0) {
+#pragma unroll
+          for (int i = 0; i < ELL_UNROLL; ++i) {
+            vb[i] = vp[i * 64];
+            cb[i] = cp[i * 64];
+          }
+        }
+        for (int k0 = 0; k0 < w; k0 += ELL_UNROLL) {
+          float vn[ELL_UNROLL];
+          uint16_t cn[ELL_UNROLL];
+          const bool more_k = k0 + ELL_UNROLL < w;  // (wave-uniform)
+          if (more_k) {
+#pragma unroll
+            for (int i = 0; i < ELL_UNROLL; ++i) {
+              vn[i] = vp[(k0 + ELL_UNROLL + i) * 64];
+              cn[i] = cp[(k0 + ELL_UNROLL + i) * 64];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < ELL_UNROLL; i += 2) {
+            acc0 = fma((double)vb[i], sm.qs[cb[i]], acc0);
+            acc1 = fma((double)vb[i + 1], sm.qs[cb[i + 1]], acc1);
+          }
+          if (more_k) {
+#pragma unroll
+            for (int i = 0; i < ELL_UNROLL; ++i) {
+              vb[i] = vn[i];
+              cb[i] = cn[i];
+            }
+          }
+        }
+        const double acc = acc0 + acc1;
+        sm.ws[64 * g + lane] = acc;   // (rows in [N, 64 nslab) have no entries: zeros)
+        part = fma(acc, acc, part);
+      }
     } else {
     // ---- SpMV: w = A q; q slice in registers, A streamed once ------------------------------
       double qreg[NCH][4];
@@ -603,7 +756,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
     //      fp32 outputs; near an invariant subspace |w1| collapses and the second pass runs).
     //      oracle/lanczos_kstep.py states the same rule.
     double coef = 0.0;
-    if constexpr (!SYM) {
+    if constexpr (MODE == 0) {
       part = 0.0;
       for (int r = tid; r < N; r += TPB) part = fma(sm.ws[r], sm.ws[r], part);
     }
@@ -616,7 +769,7 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
         nrm2 = block_sum(sm, part, tid);
         if (nrm2 >= kReorth * nrm2_before) break;
       }
-      if constexpr (SYM) {
+      if constexpr (MODE != 0) {
         cgs_pass(sm, Qg, N, j, wave, lane);
       } else {
         // full-stream kernel (its SpMV holds q in 64 registers; the single-read pass spills
@@ -743,7 +896,8 @@ extern "C" int64_t lnz_lanczos_ritz_large_workspace_bytes(int B, int N) {
 
 static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int B, int N, int M,
                         int K, void* workspace, float* D, float* V, int32_t* info,
-                        lnz_stream_t stream, bool sym, const char* who) {
+                        lnz_stream_t stream, bool sym, const char* who,
+                        const int32_t* n_nodes = nullptr, const int32_t* gate = nullptr) {
   LNZ_REQUIRE(A && workspace && D && V && B > 0 && N > 0 && M > 0 && K > 0, LNZ_EINVAL,
               "%s: bad arguments (B=%d N=%d M=%d K=%d)", who, B, N, M, K);
   LNZ_REQUIRE(N <= NCH * 256 && M <= MMAX && K <= M, LNZ_ENOTSUP,
@@ -756,13 +910,98 @@ static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int 
               LNZ_ENOTSUP, "%s: one graph must span less than 4 GiB (row stride %lld)", who,
               (long long)stride_r);
   double* basis = (double*)workspace;
+  const EllImage none = {nullptr, nullptr, nullptr, 0};
   if (sym)
-    hipLaunchKernelGGL(lanczos_ritz_large_kernel<true>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, D, V, info);
+    hipLaunchKernelGGL(lanczos_ritz_large_kernel<1>, dim3(B), dim3(TPB), 0, (hipStream_t)stream, A,
+                       stride_b, stride_r, N, M, K, basis, D, V, info, n_nodes, gate, 1, none);
   else
-    hipLaunchKernelGGL(lanczos_ritz_large_kernel<false>, dim3(B), dim3(TPB), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, N, M, K, basis, D, V, info);
+    hipLaunchKernelGGL(lanczos_ritz_large_kernel<0>, dim3(B), dim3(TPB), 0, (hipStream_t)stream, A,
+                       stride_b, stride_r, N, M, K, basis, D, V, info, n_nodes, gate, 1, none);
   return lnz::check_launch(who);
+}
+
+// ---- the K-step entry: the reference's `eigsh` branch for graphs beyond one workgroup's reach ------
+static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+struct KstepLayout {
+  int64_t basis, over, widths, vals, cols, total;
+};
+static KstepLayout kstep_layout(int B, int N, int flags, int row_cap) {
+  KstepLayout L;
+  const int64_t nslab = (N + 63) / 64;
+  L.basis = 0;
+  int64_t at = align256((int64_t)B * MMAX * N * (int64_t)sizeof(double));
+  L.over = L.widths = L.vals = L.cols = at;
+  if (flags & LNZ_KSTEP_COMPACT) {
+    L.over = at;
+    at = align256(at + (int64_t)B * 4);
+    L.widths = at;
+    at = align256(at + (int64_t)B * nslab * 4);
+    L.vals = at;
+    at = align256(at + (int64_t)B * nslab * row_cap * 64 * 4);
+    L.cols = at;
+    at = align256(at + (int64_t)B * nslab * row_cap * 64 * 2);
+  }
+  L.total = at;
+  return L;
+}
+
+extern "C" int64_t lnz_lanczos_ritz_kstep_workspace_bytes(int B, int N, int flags, int row_cap) {
+  if (B <= 0 || N <= 0 || row_cap < 0) return 0;
+  return kstep_layout(B, N, flags, row_cap).total;
+}
+
+extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r,
+                                      const int32_t* n_nodes, int B, int N, int M, int K, int flags,
+                                      int row_cap, void* workspace, int64_t workspace_bytes, float* D,
+                                      float* V, int32_t* info, int32_t* dense_fallback,
+                                      lnz_stream_t stream) {
+  const char* who = "lnz_lanczos_ritz_kstep";
+  const bool sym = (flags & LNZ_KSTEP_SYMMETRIC) != 0;
+  if (!(flags & LNZ_KSTEP_COMPACT)) {
+    LNZ_REQUIRE(workspace_bytes >= kstep_layout(B, N, flags, 0).total, LNZ_EINVAL,
+                "%s: workspace of %lld bytes, %lld needed", who, (long long)workspace_bytes,
+                (long long)kstep_layout(B, N, flags, 0).total);
+    LNZ_REQUIRE(!dense_fallback, LNZ_EINVAL, "%s: dense_fallback is an output of LNZ_KSTEP_COMPACT", who);
+    return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, sym, who, n_nodes);
+  }
+  LNZ_REQUIRE(row_cap >= ELL_UNROLL && row_cap % ELL_UNROLL == 0 && row_cap <= 1024, LNZ_EINVAL,
+              "%s: row_cap=%d must be a multiple of %d in [%d, 1024]", who, row_cap, ELL_UNROLL, ELL_UNROLL);
+  LNZ_REQUIRE(A && workspace && B > 0 && N > 0, LNZ_EINVAL, "%s: bad arguments", who);
+  const KstepLayout L = kstep_layout(B, N, flags, row_cap);
+  LNZ_REQUIRE(workspace_bytes >= L.total, LNZ_EINVAL, "%s: workspace of %lld bytes, %lld needed", who,
+              (long long)workspace_bytes, (long long)L.total);
+  LNZ_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, LNZ_EINVAL, "%s: workspace alignment", who);
+  char* ws = (char*)workspace;
+  int32_t* over = dense_fallback ? dense_fallback : (int32_t*)(ws + L.over);
+  int32_t* widths = (int32_t*)(ws + L.widths);
+  float* vals = (float*)(ws + L.vals);
+  uint16_t* cols = (uint16_t*)(ws + L.cols);
+  // the dense launcher's argument checks first (nothing is launched when they fail)
+  LNZ_REQUIRE(D && V && M > 0 && K > 0, LNZ_EINVAL, "%s: bad arguments (B=%d N=%d M=%d K=%d)", who, B, N, M, K);
+  LNZ_REQUIRE(N <= NCH * 256 && M <= MMAX && K <= M, LNZ_ENOTSUP,
+              "%s: N=%d <= 2048, K=%d <= M=%d <= 64 required", who, N, K, M);
+  LNZ_REQUIRE(N % 4 == 0 && stride_r % 4 == 0 && stride_b % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(A) & 15) == 0,
+              LNZ_ENOTSUP, "%s: rows must be contiguous, 16-byte aligned, N %% 4 == 0", who);
+  LNZ_REQUIRE(M <= N, LNZ_EINVAL, "%s: M=%d > N=%d", who, M, N);
+  if (hipMemsetAsync(over, 0, (size_t)B * 4, (hipStream_t)stream) != hipSuccess) {
+    lnz::set_error("%s: hipMemsetAsync failed", who);
+    return LNZ_ELAUNCH;
+  }
+  const int nslab = (N + 63) / 64;
+  hipLaunchKernelGGL(ell_compact_kernel, dim3((nslab + NWAVE - 1) / NWAVE, B), dim3(TPB), 0,
+                     (hipStream_t)stream, A, stride_b, stride_r, N, row_cap, vals, cols, widths, over);
+  int rc = lnz::check_launch(who);
+  if (rc != LNZ_OK) return rc;
+  const EllImage img = {vals, cols, widths, row_cap};
+  hipLaunchKernelGGL(lanczos_ritz_large_kernel<2>, dim3(B), dim3(TPB), 0, (hipStream_t)stream, A,
+                     stride_b, stride_r, N, M, K, (double*)workspace, D, V, info, n_nodes,
+                     (const int32_t*)over, 0, img);
+  rc = lnz::check_launch(who);
+  if (rc != LNZ_OK) return rc;
+  // graphs the image could not hold: the dense stream (its workgroups leave at once otherwise)
+  return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, sym, who, n_nodes,
+                      (const int32_t*)over);
 }
 
 extern "C" int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B,

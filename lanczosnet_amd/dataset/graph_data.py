@@ -12,7 +12,9 @@ graph-level label `Y [1, graph_emb_dim]`; the model is `LanczosNetGeneral`.  Sam
   `node_feat [n,D]`, `label [1,P]`); the Laplacians (`lnz_laplacian_l4`, replacing
   get_graph_data.py:61-72) and the Ritz pairs (`lnz_lanczos_ritz`, workgroup-per-graph kernel for
   N > 32, replacing utils/data_helper.py:197-223 and the pad / cut of graph_data.py:262-287) are
-  computed ON THE DEVICE.
+  computed ON THE DEVICE.  Batches padded beyond 192 nodes (BASELINE config 5: 2048) get the
+  pairs of the K-step recurrence instead (`lnz_lanczos_ritz_kstep`: the reference's
+  use_eigen_decomp=False branch, utils/data_helper.py:205-208; announced by a UserWarning).
 
 `GraphData(config, split)` is the class the runner instantiates with
 `eval(config.dataset.loader_name)(config, split=...)` (runner/graph_runner.py:38-40).

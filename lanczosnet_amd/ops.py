@@ -143,6 +143,13 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
                     'workgroup_p2', 'workgroup_p4')
   B, N, _ = A.shape
   n_nodes = n_nodes.to(torch.int32).contiguous()
+  if kernel == 'auto' and N > RITZ_FULL_MAX_N:
+    # beyond one workgroup's reach the full-length decomposition is not offered: the K-step Krylov
+    # method — the reference's OTHER branch, use_eigen_decomp=False (utils/data_helper.py:205-208)
+    _warn_once('lanczos_ritz: %d > %d nodes — Ritz pairs of the K-step Lanczos recurrence (the '
+               'reference\'s use_eigen_decomp=False / eigsh branch, utils/data_helper.py:205-208), not of '
+               'the full decomposition; converged leading pairs agree' % (N, RITZ_FULL_MAX_N))
+    return lanczos_ritz_kstep(A, n_nodes, K, K, return_info=return_info)
   if kernel == 'auto':
     D, V, info = _ext().lanczos_ritz(A, n_nodes, K)
     return (D, V, info) if return_info else (D, V)
@@ -163,6 +170,70 @@ def lanczos_ritz(A, n_nodes, K, return_info=False, kernel='auto'):
       _abi().lanczos_ritz_ws(A, sb, sr, sc, n_nodes, B, N, K, D,
                                          V, info, ws, need, flags)
   return (D, V, info) if return_info else (D, V)
+
+
+RITZ_FULL_MAX_N = 192     # lnz_lanczos_ritz: one wavefront (N <= 32) / one workgroup per graph
+
+
+
+def kstep_row_cap(N):
+  """Default sliced-ELL row capacity of the compacted K-step path: N / 8 entries per row, between
+  64 and 256 (a multiple of 8).  The capacity only sizes the workspace (6 bytes x N x capacity per
+  graph: 3 MB at N = 2048) — a step reads the slabs' real widths; a graph with a longer row takes
+  the dense stream."""
+  return max(64, min(256, (N // 8 + 7) // 8 * 8))
+_WARNED = set()
+
+
+def _warn_once(msg):
+  if msg not in _WARNED:
+    _WARNED.add(msg)
+    import warnings
+    warnings.warn(msg, UserWarning, stacklevel=3)
+
+
+def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=None,
+                       workspace=None, return_info=False, return_fallback=False):
+  """lnz_lanczos_ritz_kstep: M-step Lanczos Ritz pairs (top K by |theta|) of a ragged batch of
+  large dense-stored graphs — the reference's `eigsh` branch (utils/data_helper.py:205-208).
+  A [B,N,N] float32 (rows contiguous; any N <= 2048: a width that is not a multiple of 4 or rows
+  that are not 16-byte aligned are copied into an aligned buffer first), n_nodes [B] or None.
+  compact: read A once and run the steps on its sliced-ELL image (graphs with a row of more than
+  row_cap nonzeros take the dense stream in the same call); symmetric: the dense stream reads the
+  upper chunk blocks only.  Returns D [B,K], V [B,N,K] (+ info [B] = steps taken) (+ fallback [B])."""
+  _need_cuda(A, n_nodes, workspace)
+  assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
+  B, N, _ = A.shape
+  Np = (N + 3) // 4 * 4
+  if Np != N or A.stride(2) != 1 or A.stride(1) % 4 or A.stride(0) % 4 or A.data_ptr() % 16:
+    Ap = torch.zeros((B, Np, Np), dtype=torch.float32, device=A.device)
+    Ap[:, :N, :N] = A
+    if n_nodes is None:
+      n_nodes = torch.full((B,), N, dtype=torch.int32, device=A.device)
+    A = Ap
+  if n_nodes is not None:
+    n_nodes = n_nodes.to(torch.int32).contiguous()
+  assert 0 < K <= M <= min(Np, 64), 'K <= M <= 64 Lanczos steps'
+  flags = (1 if symmetric else 0) | (2 if compact else 0)
+  cap = int(row_cap if row_cap is not None else kstep_row_cap(Np)) if compact else 0
+  need = _abi().lanczos_ritz_kstep_workspace_bytes(B, Np, flags, cap)
+  if workspace is None or workspace.numel() * workspace.element_size() < need:
+    workspace = torch.empty((need,), dtype=torch.uint8, device=A.device)
+  D = torch.empty((B, K), dtype=torch.float32, device=A.device)
+  V = torch.empty((B, Np, K), dtype=torch.float32, device=A.device)
+  info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
+  fb = torch.empty((B,), dtype=torch.int32, device=A.device) if (return_fallback and compact) else None
+  with torch.cuda.device(A.device):
+    _abi().lanczos_ritz_kstep(A, A.stride(0), A.stride(1), n_nodes, B, Np, M, K, flags, cap,
+                              workspace, workspace.numel() * workspace.element_size(), D, V, info, fb)
+  if Np != N:
+    V = V[:, :N, :].contiguous()
+  out = (D, V)
+  if return_info:
+    out += (info,)
+  if return_fallback:
+    out += (fb,)
+  return out
 
 
 def tridiag_eigh(diag, offdiag):

@@ -6,15 +6,23 @@ import numpy as np
 import oracle
 
 
-def graphs(B, N, p, seed):
-  """B dense symmetric L4 Laplacians of G(N, p) graphs, float32 [B,N,N]."""
+def adjacency(B, N, p, seed):
+  """The B symmetric 0/1 adjacency matrices of G(N, p) graphs behind `graphs`, float64 [B,N,N]."""
   rs = np.random.RandomState(seed)
-  A = np.zeros((B, N, N), np.float32)
+  out = np.zeros((B, N, N), np.float64)
   for b in range(B):
     a = (rs.rand(N, N) < p).astype(np.float64)
     a = np.triu(a, 1)
-    a = a + a.T
-    A[b] = oracle.laplacian_l4(a)
+    out[b] = a + a.T
+  return out
+
+
+def graphs(B, N, p, seed):
+  """B dense symmetric L4 Laplacians of G(N, p) graphs, float32 [B,N,N]."""
+  adj = adjacency(B, N, p, seed)
+  A = np.zeros((B, N, N), np.float32)
+  for b in range(B):
+    A[b] = oracle.laplacian_l4(adj[b])
   return A
 
 

@@ -219,11 +219,38 @@ def test_workgroup_ritz_kernel_small_graphs_and_edge_cases():
   assert np.abs(Dw.cpu().numpy() - D).max() < 1e-6
 
 
-def test_lanczos_ritz_rejects_graphs_beyond_one_workgroup():
+def test_graphs_beyond_one_workgroup_take_the_kstep_branch_and_say_so():
+  """Beyond 192 nodes the full-length decomposition is not offered: the workgroup kernel and
+  use_eigen_decomp=True refuse, the default entry answers with the reference's OTHER branch
+  (use_eigen_decomp=False: a K-dimensional Krylov method, utils/data_helper.py:205-208) and warns.
+  For a graph whose Krylov space from the start vector is smaller than K the two branches coincide:
+  the pairs are exact eigenpairs."""
   from lanczosnet_amd import ops, _lib
-  A = torch.zeros((1, 200, 200), device=DEV)
+  from lanczosnet_amd.utils.data_helper import get_graph_laplacian_eigs_batched
+  n = 200
+  a = np.zeros((n, n))
+  a[0, 1:] = a[1:, 0] = 1.0                     # a star: L4 has three distinct eigenvalues
+  A = torch.from_numpy(oracle.laplacian_l4(a)[None].astype(np.float32)).to(DEV)
+  nn = torch.tensor([n], dtype=torch.int32, device=DEV)
   with pytest.raises(_lib.NotSupported):
-    ops.lanczos_ritz(A, torch.tensor([200], dtype=torch.int32, device=DEV), 20)
+    ops.lanczos_ritz(A, nn, 20, kernel='workgroup')
+  with pytest.raises(_lib.NotSupported):
+    get_graph_laplacian_eigs_batched(A, nn, 20, use_eigen_decomp=True)
+  ops._WARNED.clear()
+  with pytest.warns(UserWarning, match='use_eigen_decomp=False'):
+    D, V = get_graph_laplacian_eigs_batched(A, nn, 20)
+  D2, V2 = get_graph_laplacian_eigs_batched(A, nn, 20, use_eigen_decomp=False)
+  assert torch.equal(D, D2) and torch.equal(V, V2)
+  lam = np.linalg.eigvalsh(A[0].double().cpu().numpy())
+  # the start vector is not orthogonal to the lambda = 1 and the two star eigenvectors; of the
+  # (n - 2)-fold eigenvalue it meets one direction: four Ritz values, all exact
+  got = D[0].cpu().numpy()
+  live = got[np.abs(got) > 0]
+  assert 3 <= len(live) <= 4
+  assert all(np.abs(lam - x).min() < 1e-6 for x in live) and abs(live[0] - 1.0) < 1e-6
+  Vd = V[0].double().cpu().numpy()[:, :len(live)]
+  Ad = A[0].double().cpu().numpy()
+  assert np.abs(Ad @ Vd - Vd * live).max() < 1e-6
 
 
 def _structured_graphs():

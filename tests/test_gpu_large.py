@@ -130,6 +130,114 @@ def test_large_lanczos_early_stop_on_invariant_subspace():
   assert (V.cpu().numpy()[0][:, 1:] == 0).all()
 
 
+def _projector_gap(Va, Vb):
+  Pa = Va.double() @ Va.double().transpose(1, 2)
+  Pb = Vb.double() @ Vb.double().transpose(1, 2)
+  return float((Pa - Pb).abs().max())
+
+
+@pytest.mark.parametrize('N,M,B,p', [(512, 32, 3, 0.02), (2048, 64, 2, 0.01), (1412, 40, 2, 0.006), (300, 24, 4, 0.05)])
+def test_kstep_entry_compacted_image_matches_the_dense_streams_and_the_restatement(N, M, B, p):
+  """lnz_lanczos_ritz_kstep: the steps on the sliced-ELL image of A (read once) give the Ritz pairs
+  of the dense streams (full / symmetric) — skipping exact zeros changes no sum, only the order of
+  the fp64 additions — and of the fp64 restatement; no graph fell back; two calls agree bitwise."""
+  from lanczosnet_amd import ops
+  A = _graphs(B, N, p, seed=N + 1)
+  Ad = torch.from_numpy(A).to(DEV)
+  Dc, Vc, info, fb = ops.lanczos_ritz_kstep(Ad, None, M, M, return_info=True, return_fallback=True)
+  Dc2, Vc2 = ops.lanczos_ritz_kstep(Ad, None, M, M)
+  assert torch.equal(Dc, Dc2) and torch.equal(Vc, Vc2)
+  assert (fb == 0).all() and (info == M).all()
+  for sym in (False, True):
+    Dd, Vd = ops.lanczos_ritz_kstep(Ad, None, M, M, symmetric=sym, compact=False)
+    Dl, Vl = ops.lanczos_ritz_large(Ad, M, M, symmetric=sym)
+    assert torch.equal(Dd, Dl) and torch.equal(Vd, Vl)        # the dense modes ARE the large entries
+    assert (Dc - Dd).abs().max() < 1e-6
+    assert _projector_gap(Vc, Vd) < 1e-5
+  for b in range(B):
+    Dr, Vr, _ = oracle.lanczos_kstep_fp64(A[b], M, M)
+    assert np.abs(Dc[b].cpu().numpy() - Dr).max() < 1e-6
+    Vg = Vc[b].cpu().numpy().astype(np.float64)
+    assert np.abs(Vg @ Vg.T - Vr @ Vr.T).max() < 1e-5
+
+
+def test_kstep_entry_ragged_batch_and_unaligned_width():
+  """Real node counts below the padded width (dataset/graph_data.py:222-260), a width that is not a
+  multiple of 4: every graph's pairs are those of its own n_b x n_b matrix, V is zero on the padding."""
+  from lanczosnet_amd import ops
+  N, K = 333, 24
+  sizes = [333, 250, 201, 16]
+  A = np.zeros((len(sizes), N, N), np.float32)
+  for b, n in enumerate(sizes):
+    A[b, :n, :n] = _graphs(1, n, 6.0 / n, seed=40 + b)[0]
+  nn = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+  for compact in (True, False):
+    D, V, info = ops.lanczos_ritz_kstep(torch.from_numpy(A).to(DEV), nn, K, K, compact=compact,
+                                        return_info=True)
+    assert V.shape == (len(sizes), N, K)
+    for b, n in enumerate(sizes):
+      Dr, Vr, (_, _, kk, _) = oracle.lanczos_kstep_fp64(A[b, :n, :n], K, K)
+      assert int(info[b]) == kk and kk <= min(K, n)
+      assert np.abs(D[b].cpu().numpy() - Dr).max() < 1e-6 and (D[b, kk:] == 0).all()
+      Vg = V[b].cpu().numpy().astype(np.float64)
+      assert (Vg[n:] == 0).all() and (Vg[:, kk:] == 0).all()
+      assert np.abs(Vg[:n] @ Vg[:n].T - Vr @ Vr.T).max() < 1e-5
+
+
+def test_kstep_entry_dense_rows_fall_back_to_the_stream_in_the_same_call():
+  """A graph with a row beyond the image's capacity is computed by the dense stream (flagged), its
+  sparse neighbours in the batch by the image; both equal the all-dense call."""
+  from lanczosnet_amd import ops
+  N, M = 512, 32
+  A = _graphs(3, N, 0.01, seed=77)
+  A[1] = _graphs(1, N, 0.3, seed=78)[0]           # ~150 entries per row: over the capacity of 64
+  hub = np.zeros((N, N))                           # one hub node: ONE long row (and column)
+  hub[0, 1:200] = hub[1:200, 0] = 1.0
+  A[2] = oracle.laplacian_l4(hub)
+  Ad = torch.from_numpy(A).to(DEV)
+  D, V, fb = ops.lanczos_ritz_kstep(Ad, None, M, M, return_fallback=True)
+  assert fb.cpu().tolist() == [0, 1, 1]
+  Dd, Vd = ops.lanczos_ritz_kstep(Ad, None, M, M, compact=False)
+  assert torch.equal(D[1:], Dd[1:]) and torch.equal(V[1:], Vd[1:])     # the same kernel ran them
+  assert (D[0] - Dd[0]).abs().max() < 1e-6 and _projector_gap(V[:1], Vd[:1]) < 1e-5
+  D8, V8, fb8 = ops.lanczos_ritz_kstep(Ad, None, M, M, row_cap=256, return_fallback=True)
+  assert fb8.cpu().tolist() == [0, 0, 0]                                # a roomier image holds all three
+  assert (D8 - Dd).abs().max() < 1e-6 and _projector_gap(V8, Vd) < 1e-5
+
+
+def test_config5_from_raw_adjacency_through_the_dataset_mirror():
+  """BASELINE config 5 end to end on the product surface, no hand-called kernel: raw adjacency ->
+  `collate_graph_adjacency` (device L4; `ops.lanczos_ritz` routes 2048 nodes to the K-step entry,
+  the reference's use_eigen_decomp=False branch, utils/data_helper.py:205-208) ->
+  `LanczosNetGeneral.forward`, against the scores the unmodified reference class produced on these
+  inputs (tests/golden/config5_full.npz)."""
+  import warnings
+  from large_fixture import adjacency
+  from lanczosnet_amd.dataset.graph_data import collate_graph_adjacency
+  g = load_golden('config5_full.npz')
+  B, N, K = int(g['B']), int(g['N']), int(g['K'])
+  cfg, P, net, X, L, mask = _general_setup(B, N, K, int(g['num_layer']), int(g['seed']),
+                                           float(g['p_edge']))
+  adj = adjacency(B, N, float(g['p_edge']), int(g['seed']))
+  items = [dict(adjs=adj[b][:, :, None].astype(np.float32), node_feat=X[b], label=np.zeros((1, 2)))
+           for b in range(B)]
+  with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    from lanczosnet_amd import ops
+    ops._WARNED.clear()
+    batch = collate_graph_adjacency(items, K, device=DEV)
+  assert any('use_eigen_decomp=False' in str(x.message) for x in w)      # the branch is announced
+  assert (batch['L'].cpu().numpy() - L).__abs__().max() < 1e-7
+  assert np.abs(batch['D'].cpu().numpy() - g['D']).max() < 1e-6
+  with torch.no_grad():
+    score = net(batch['node_feat'], batch['L'], batch['D'], batch['V'],
+                mask=torch.from_numpy(mask).to(DEV))    # (the fixture masks the tail of graph 1)
+  ref = g['score']
+  err = (np.abs(score.cpu().numpy() - ref).max(axis=1) / np.abs(ref).max(axis=1)).max()
+  print('config 5 from the raw adjacency vs REFERENCE: %.2e' % err)
+  assert err < 1e-4
+
+
 def _bf16_round(x):
   return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
 
