@@ -545,6 +545,7 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
       Lp = ops.pack_laplacian(L)
       ev[5].record()
       score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask_u8)
+      conv_kernel_ran = ops.last_kernel()
       ev[6].record()
       torch.cuda.synchronize()
       if it >= 2:
@@ -698,11 +699,8 @@ def ada_leg(dev, L, node_feat, mask_u8, reps=5):
                                         'folded into the first / last weights)' % (n_in, n_out),
                               'note': 'achieved prices the flops executed; stage time includes '
                                       'the input gather and the 7 output scatters'},
-          'conv_kernel': ('lanczosnet_forward16_kernel<0,2,true> (16 x 16 MFMA tiles, eight waves on every '
-                          'node tile of a workgroup; input width zero-padded 70 -> 128)'
-                          if os.environ.get('LNZ_FORWARD16', '1') != '0' else
-                          'lanczosnet_forward_kernel<4,10,2,0,0> (32 x 32 tiles)') +
-                         ': dense K x K filters in eigen space (Q [sum_s DD_s (Q^T X W_s^T)]), pair tiles',
+          'conv_kernel': conv_kernel_ran + ' (lnz_last_kernel(): what the launcher selected for this '
+                         'run): dense K x K filters in eigen space (Q [sum_s DD_s (Q^T X W_s^T)])',
           'library_filter_gemm_mode': library, 'split_precision_mode': split, 'train_step': train,
           'parity': parity, 'finite': finite}
 
@@ -952,6 +950,7 @@ def main():
     elapsed = float(tt.item())
   assert torch.isfinite(score).all()
   timed_score = score.clone()
+  kernel_ran = ops.last_kernel()   # what the launcher selected for the timed forwards
   shard_check = None
   if dist and not args.zero_params:
     # every rank verifies ITS shard (seed = rank) on a bounded sample, after the clock has stopped
@@ -1128,6 +1127,9 @@ def main():
       fm = forward16_mfma_issued(tile_list, cfg) if f16 else forward_mfma_issued(tile_list, cfg)
     roof_kernel = ('lanczosnet_strip_kernel' if strip else 'lanczosnet_forward16_kernel' if f16
                    else 'lanczosnet_forward_kernel<4,10,0,0>')
+    # the flop model above follows the launcher's rule; the name in the line is the launcher's own
+    assert kernel_ran.startswith(roof_kernel.split('<')[0]), (kernel_ran, roof_kernel)
+    roof_kernel = kernel_ran
     roof_insn = ('2048 flop x the v_mfma_f32_16x16x4_f32' if f16 else
                  '4096 flop x the v_mfma_f32_32x32x2_f32')
     n_tiles = fm['tiles']

@@ -49,6 +49,10 @@ typedef void* lnz_stream_t;
 
 int lnz_abi_version(void);
 const char* lnz_last_error(void);
+/* The kernel (name with template arguments) the calling thread's last lnz_lanczosnet_forward /
+ * _input_grad launch selected — the launchers choose between the strip, 16 x 16-tile and 32 x 32-tile
+ * kernels by shape and plan; measurements name what ran instead of restating the rule. */
+const char* lnz_last_kernel(void);
 
 /* ---- R1: graph Laplacian ------------------------------------------------------------
  * L4 = D^-1/2 (I + A) D^-1/2 for the simple graph (channel 0, A = sum_e A_e) and for every
@@ -508,7 +512,11 @@ int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips
  * layer of model/lanczos_net_general.py:157-182 (model/lanczos_net.py:157-182), the head and the
  * gated masked mean (:185-194) in ONE launch, exact fp32 (v_mfma_f32_16x16x4_f32).  A graph is
  * spread over four workgroups by output columns (32 each); the layer's state goes through Xwork
- * behind a counter in `sync` the four spin on (csrc/conv_mid.hip).
+ * behind a counter in `sync` the four spin on (csrc/conv_mid.hip).  The four must be resident
+ * together: a batch larger than the device holds at once (occupancy x compute units; 64 graphs on
+ * an idle MI355X) is issued as consecutive launches.  Whether the four share one L2 is read from
+ * the hardware at run time (fence-free exchange only then, agent-scope release / acquire
+ * otherwise); every spin is bounded and ends in a trap, i.e. a failed launch, not a hang.
  *   X0     [B,N,din0] fp32   layer-0 state (node features / embedding rows), din0 a multiple of
  *                            16 (zero-padded columns), <= 128
  *   L      [B,N,N,C] fp32    by element strides; C = edge types + 1 channels, 1..2
@@ -518,7 +526,7 @@ int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips
  *                            edge types (no short-diffusion channels) —, the layers behind each other
  *   bias   [num_layer,128];  Whead [dout + 1,128], bhead [dout + 1]: head rows, then the gate row
  *   Xwork  [lnz_midgraph_workspace_floats(B, N, num_layer)] fp32 scratch
- *   sync   [B * num_layer] int32, ZERO on entry
+ *   sync   [B * (num_layer + 1)] int32, ZERO on entry (arrival counters, then placement words)
  *   score  [B,dout]
  * N <= 128, K <= 32, S <= 16, dout <= 31, hidden width 128. */
 int64_t lnz_midgraph_workspace_floats(int B, int N, int num_layer);

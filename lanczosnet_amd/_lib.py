@@ -54,6 +54,7 @@ _P, _I, _L = C.c_void_p, C.c_int, C.c_int64
 SIGNATURES = {
     'lnz_abi_version': (C.c_int, []),
     'lnz_last_error': (C.c_char_p, []),
+    'lnz_last_kernel': (C.c_char_p, []),
     'lnz_laplacian_l4': (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     'lnz_laplacian': (C.c_int, [_P, _P, _I, _I, _I, _I, C.c_double, _P, _P]),
     'lnz_lanczos_ritz': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P]),

@@ -14,6 +14,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace lnz {
 
 void set_error(const char* fmt, ...);
+// the kernel (with its template arguments) a lnz_lanczosnet_* launcher selected, for lnz_last_kernel()
+void note_kernel(const char* fmt, ...);
 
 #define LNZ_REQUIRE(cond, code, ...)      \
   do {                                    \

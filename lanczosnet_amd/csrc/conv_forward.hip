@@ -1379,6 +1379,7 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
 #define LNZ_LAUNCH_D(NWV_, KHT_, FK_, MODE_, DEEPK_)                                             \
   do {                                                                                           \
     auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_, MODE_, DEEPK_>;                        \
+    lnz::note_kernel("lanczosnet_forward_kernel<%d,%d,%d,%d,%d>", NWV_, KHT_, FK_, MODE_, DEEPK_); \
     if (gs_bytes)                                                                                \
       (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 (int)gs_bytes);                                                  \

@@ -811,6 +811,8 @@ int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s) {
       (const void*)lanczosnet_forward16_kernel<0, 2, true>,  (const void*)lanczosnet_forward16_kernel<1, 2, true>};
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
+  note_kernel("lanczosnet_forward16_kernel<%d,%d,%s>", mode, a.filter_kind == 0 ? 0 : 2,
+              a.n_short > 0 ? "true" : "false");
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;

@@ -11,7 +11,17 @@
 // product of a layer needs the full input state but only its own column slice of the weights, so
 // the only exchange is one [n, 32]-column slice per workgroup and layer through global memory (L2)
 // behind a counter the four workgroups of a graph spin on.  The four are given block indices that
-// are equal modulo 8 — the same XCD, the same L2.
+// are equal modulo 8 — on MI355X in SPX mode the same XCD, the same L2 — which HIP does not promise:
+//   * placement is CHECKED, not assumed: every workgroup posts its HW_REG_XCC_ID in the graph's
+//     placement word at kernel start; four equal ids = one L2, and only then is the exchange fence
+//     free (write-through stores + sc1 loads).  Otherwise (CU masks, other partition modes, another
+//     part) the publisher releases and the consumer acquires at agent scope — correct under any
+//     placement, a few microseconds slower per layer;
+//   * forward progress needs the four workgroups of a graph resident together: the launcher sizes
+//     every launch to what the device holds at once (occupancy query x compute units, whole groups
+//     of 8 graphs = 32 blocks) and issues larger batches as consecutive launches;
+//   * every spin is bounded: a peer that never arrives ends in a trap (a failed launch the host
+//     sees), never in a hang.
 //
 // Per layer, with X [n, d] the state in LDS (row pitch 132), V [n, K] the Ritz vectors, g_s [K] the
 // spectral gains of long scale s, L_c the edge-type Laplacians, W_c [128, d] the channel blocks of
@@ -58,10 +68,25 @@ struct MidArgs {
   const float* Whead;   // [dout + 1, 128]: head rows, then the gate row
   const float* bhead;   // [dout + 1]
   float* Xwork;         // [num_layer, B, NR, 128] exchange buffer
-  int32_t* sync;        // [B * num_layer] zero-initialised
+  int32_t* sync;        // [B * (num_layer + 1)] zero-initialised: per (graph, layer) arrival counters,
+                        // then the graphs' placement words
   float* score;         // [B, dout]
   int B, N, K, C, S, num_layer, din0, dout, R;
+  int b0, b1;           // this launch's graphs [b0, b1)
+  int force_fenced;     // LNZ_MID_FENCED=1: take the release / acquire exchange whatever the placement (tests)
 };
+
+constexpr int kSpinLimit = 1 << 24;   // x s_sleep(1) (64 clocks): about half a second
+
+// tid 0 of a workgroup: wait until the low byte of *word reaches 4; returns the word
+__device__ __forceinline__ int spin_until_four(const int32_t* word) {
+  int v, spins = 0;
+  while (((v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xff) < 4) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > kSpinLimit) __builtin_trap();   // a peer workgroup never arrived
+  }
+  return v;
+}
 
 constexpr int mid_lds_floats(int R) {
   return 16 * R * XP + 32 * TP + 32 * XP + 2 * 32 * TP + 32 * AP + 16 * 32;
@@ -107,8 +132,15 @@ __global__ __launch_bounds__(512) void midgraph_forward_kernel(MidArgs a) {
   // blocks 32 g .. 32 g + 31 = graphs 8 g .. 8 g + 7, four column quarters each; the quarters of a
   // graph are 8 apart (equal modulo 8: one XCD)
   const int idx32 = blockIdx.x & 31;
-  const int b = 8 * (blockIdx.x >> 5) + (idx32 & 7), q = idx32 >> 3;
-  if (b >= a.B) return;
+  const int b = a.b0 + 8 * (blockIdx.x >> 5) + (idx32 & 7), q = idx32 >> 3;
+  if (b >= a.b1) return;
+  __shared__ int one_l2;   // the four workgroups of this graph run on one XCD (checked below)
+  int32_t* place = a.sync + (int64_t)a.B * a.num_layer + b;
+  if (tid == 0) {
+    // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this workgroup runs on
+    const int xcc = (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15;
+    __hip_atomic_fetch_add(place, 1 | ((xcc + 1) << (8 + 4 * q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const int N = a.N, K = a.K, S = a.S, R = a.R, NR = 16 * R, B = a.B;
   float* Xs = lds;                    // [NR][XP]
   float* Vt = Xs + NR * XP;           // [32 slots][TP]   Vt[k][node]
@@ -363,19 +395,28 @@ __global__ __launch_bounds__(512) void midgraph_forward_kernel(MidArgs a) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (l == 0 && tid == 0) {
+      // placement: all four posted at kernel start, long ago; equal ids = one L2
+      const int pw = spin_until_four(place);
+      const int mine = (pw >> (8 + 4 * q)) & 15;
+      one_l2 = ((pw >> 8) & 15) == mine && ((pw >> 12) & 15) == mine && ((pw >> 16) & 15) == mine &&
+               ((pw >> 20) & 15) == mine && !a.force_fenced;
+    }
     __syncthreads();
     LNZ_PH(5)  // epilogue + publish
     const bool last = l == a.num_layer - 1;
     Wl += (int64_t)128 * nch * din;
     if (!last) fetch_layer<C>(a, l + 1, Wl, b, q, tid, wave, j, kq, bw, we, gnext);
+    const bool fenced = !one_l2;   // (workgroup-uniform)
     if (tid == 0) {
+      // different L2s: the slice has to leave this one before the counter says it is there
+      if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_fetch_add(&a.sync[b * a.num_layer + l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!last || q == 0)
-        while (__hip_atomic_load(&a.sync[b * a.num_layer + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 4)
-          __builtin_amdgcn_s_sleep(1);
+      if (!last || q == 0) (void)spin_until_four(&a.sync[b * a.num_layer + l]);
     }
     if (last && q != 0) return;  // the head is workgroup (b, 0)'s
     __syncthreads();
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ... and stale lines of this L2 dropped
     LNZ_PH(6)  // wait for the other three
     {
       // the three other workgroups' slices by sc1 loads, the own one from its staging copy
@@ -440,7 +481,7 @@ __global__ __launch_bounds__(512) void midgraph_forward_kernel(MidArgs a) {
   LNZ_PH(8)  // head
 #ifdef LNZ_MID_PHASES
   if (blockIdx.x == 0 && tid == 0)
-    for (int i = 0; i < 9; ++i) a.sync[a.B * a.num_layer + i] = (int32_t)(ph[i] >> 4);
+    for (int i = 0; i < 9; ++i) a.sync[a.B * (a.num_layer + 1) + i] = (int32_t)(ph[i] >> 4);
 #endif
 }
 
@@ -473,11 +514,33 @@ extern "C" int lnz_midgraph_forward(const float* X0, const float* L, int64_t str
   a.B = B, a.N = N, a.K = K, a.C = C, a.S = S, a.num_layer = num_layer, a.din0 = din0, a.dout = dout;
   a.R = (N + 15) / 16;
   const size_t bytes = (size_t)mid_lds_floats(a.R) * sizeof(float);
-  const int grid = ((B + 7) / 8) * 32;
   const void* fn = C == 1 ? (const void*)midgraph_forward_kernel<1> : (const void*)midgraph_forward_kernel<2>;
   // per launch: the attribute is per device
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  void* params[] = {&a};
-  (void)hipLaunchKernel(fn, dim3(grid), dim3(512), params, bytes, (hipStream_t)stream);
-  return lnz::check_launch("lnz_midgraph_forward");
+  LNZ_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess,
+              LNZ_ENOTSUP, "lnz_midgraph_forward: %zu bytes of LDS per workgroup are not available on this device",
+              bytes);
+  // The four workgroups of a graph wait for each other: a launch holds only as many blocks as the
+  // device keeps resident at once (whole groups of 32 blocks = 8 graphs); a larger batch goes out
+  // as consecutive launches on the stream.
+  int dev = 0, n_cu = 0, per_cu = 0;
+  LNZ_REQUIRE(hipGetDevice(&dev) == hipSuccess &&
+                  hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, bytes) == hipSuccess,
+              LNZ_ELAUNCH, "lnz_midgraph_forward: occupancy query failed");
+  const int groups = (int)(((int64_t)n_cu * per_cu) / 32);
+  LNZ_REQUIRE(groups >= 1, LNZ_ENOTSUP,
+              "lnz_midgraph_forward: the device holds %d x %d workgroups at once, 32 (eight graphs) are needed",
+              n_cu, per_cu);
+  const char* ff = getenv("LNZ_MID_FENCED");
+  a.force_fenced = ff && ff[0] == '1';
+  for (int b0 = 0; b0 < B; b0 += 8 * groups) {
+    a.b0 = b0;
+    a.b1 = b0 + 8 * groups < B ? b0 + 8 * groups : B;
+    const int grid = ((a.b1 - a.b0 + 7) / 8) * 32;
+    void* params[] = {&a};
+    (void)hipLaunchKernel(fn, dim3(grid), dim3(512), params, bytes, (hipStream_t)stream);
+    const int rc = lnz::check_launch("lnz_midgraph_forward");
+    if (rc != LNZ_OK) return rc;
+  }
+  return LNZ_OK;
 }

@@ -1572,6 +1572,8 @@ int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
   const int which = (a.n_short > 0 ? 4 : 0) + (a.filter_kind == 0 ? 0 : 2) + mode;
   const void* fn = fns[which];
   if (a.gemm_mode == 1) fn = (const void*)lanczosnet_strip_kernel<0, 0, false, true>;
+  note_kernel("lanczosnet_strip_kernel<%d,%d,%s,%s>", mode, a.filter_kind == 0 ? 0 : 2,
+              a.n_short > 0 && a.gemm_mode != 1 ? "true" : "false", a.gemm_mode == 1 ? "true" : "false");
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   lnz_forward_args args = a;

@@ -11,10 +11,18 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+static thread_local char g_kernel[160] = "";
+void note_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
 }  // namespace lnz
 
 extern "C" int lnz_abi_version(void) { return LNZ_ABI_VERSION; }
 extern "C" const char* lnz_last_error(void) { return lnz::g_err; }
+extern "C" const char* lnz_last_kernel(void) { return lnz::g_kernel; }
 
 // ---------------------------------------------------------------------------------------
 // Wp[rt][q][lane][u] = W[32 rt + (lane & 31)][8 q + 4 (lane >> 5) + u]

@@ -425,6 +425,7 @@ Tensor segment_sum_backward(const Tensor& grad_out, const Tensor& segment_ids, i
 
 TORCH_LIBRARY(lanczosnet, m) {
   m.def("abi_version() -> int", []() -> int64_t { return lnz_abi_version(); });
+  m.def("last_kernel() -> str", []() -> std::string { return std::string(lnz_last_kernel()); });
   m.def("laplacian_l4(Tensor adjs, Tensor n_nodes) -> Tensor");
   m.def("lanczos_ritz(Tensor A, Tensor n_nodes, int K) -> (Tensor, Tensor, Tensor)");
   m.def("prepare_batch(Tensor L, Tensor mask, Tensor n_nodes, int K, int n_cu, bool allow_pairs) -> "

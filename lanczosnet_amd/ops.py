@@ -78,6 +78,12 @@ def _abi():
   return _RAW_NS
 
 
+def last_kernel():
+  """lnz_last_kernel(): the kernel (with template arguments) the calling thread's last fused
+  forward / input-gradient launch selected."""
+  return torch.ops.lanczosnet.last_kernel()
+
+
 def _need_cuda(*tensors):
   for t in tensors:
     if t is None:
@@ -409,7 +415,7 @@ def midgraph_forward(X0, L, V, G, mask_u8, W, bias, Whead, bhead, num_layer):
   dout = Whead.shape[0] - 1
   dev = X0.device
   Xwork = torch.empty((int(_abi().midgraph_workspace_floats(B, N, num_layer)),), dtype=torch.float32, device=dev)
-  sync = torch.zeros((B * num_layer + 16,), dtype=torch.int32, device=dev)   # (+ 16: phase stamps of profiling builds)
+  sync = torch.zeros((B * (num_layer + 1) + 16,), dtype=torch.int32, device=dev)   # (+ 16: phase stamps of profiling builds)
   midgraph_forward.last_sync = sync
   score = torch.empty((B, dout), dtype=torch.float32, device=dev)
   sb, sr, sc, sch = L.stride()

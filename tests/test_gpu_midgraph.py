@@ -157,3 +157,58 @@ def test_midgraph_hand_off_is_stable_under_load():
       bad += int(not torch.equal(got, want[it & 1]))
     torch.cuda.synchronize()
   assert bad == 0, bad
+
+
+def test_midgraph_batch_of_1024_graphs_goes_out_in_resident_chunks():
+  """Forward progress: the four workgroups of a graph wait for each other, so a launch may hold
+  only as many blocks as the device keeps resident (lnz_midgraph_forward sizes its launches by the
+  occupancy query).  1024 graphs = 4096 workgroups, sixteen times the chip: every graph's score
+  must equal the score the same graph gets in a batch of 64 (same kernel, same arithmetic: bitwise)."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(31)
+  cfg = dict(GRAPH_CFG, hidden_dim=[128] * 3, num_layer=3)
+  net, _ = _net(cfg, 9)
+  B, N = 1024, 48
+  ns, adj, mask = _graphs(rs, B, N, 33, 0.2)
+  n = _t(ns)
+  L = ops.laplacian_l4(_t(adj), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+  X = _t(rs.randn(B, N, 10).astype(np.float32) * mask[:, :, None])
+  mk = _t(mask)
+  with torch.no_grad():
+    big = net(X, L, D, V, mask=mk)
+    torch.cuda.synchronize()
+    assert torch.isfinite(big).all()
+    for lo in (0, 448, 960):
+      part = net(X[lo:lo + 64], L[lo:lo + 64], D[lo:lo + 64], V[lo:lo + 64], mask=mk[lo:lo + 64])
+      assert torch.equal(part, big[lo:lo + 64]), lo
+
+
+def test_midgraph_fenced_exchange_gives_the_same_bits(monkeypatch):
+  """The exchange is fence free only when the hardware says the four workgroups of a graph share an
+  L2 (HW_REG_XCC_ID, posted in the placement word); otherwise the publisher releases and the consumer
+  acquires at agent scope.  LNZ_MID_FENCED=1 takes that path on this box too: same scores, bit for
+  bit, and the placement words show what the check saw — four arrivals, four equal XCD ids."""
+  from lanczosnet_amd import ops
+  rs = np.random.RandomState(41)
+  cfg = dict(GRAPH_CFG)
+  net, _ = _net(cfg, 7)
+  B, N = 64, 100
+  ns, adj, mask = _graphs(rs, B, N, 20, 0.5)
+  n = _t(ns)
+  L = ops.laplacian_l4(_t(adj), n)
+  D, V = ops.lanczos_ritz(L[:, :, :, 0], n, 20)
+  X, mk = _t(rs.randn(B, N, 10).astype(np.float32)), _t(mask)
+  with torch.no_grad():
+    free = net(X, L, D, V, mask=mk).clone()
+    place = ops.midgraph_forward.last_sync[B * 7:B * 8].cpu().numpy()
+    monkeypatch.setenv('LNZ_MID_FENCED', '1')
+    fenced = [net(X, L, D, V, mask=mk).clone() for _ in range(20)]
+  assert all(torch.equal(f, free) for f in fenced)
+  assert ((place & 0xff) == 4).all()
+  ids = np.stack([(place >> (8 + 4 * q)) & 15 for q in range(4)], axis=1)
+  assert (ids >= 1).all() and (ids <= 8).all()
+  same = (ids == ids[:, :1]).all(axis=1)
+  print('graphs whose four workgroups shared an XCD: %d of %d' % (same.sum(), B))
+  # (observed on MI355X in SPX mode: all of them — block b runs on XCD b % 8; HIP does not promise
+  # it, which is why the kernel checks: a graph outside `same` simply took the fenced exchange)

@@ -282,7 +282,9 @@ def test_forward_with_device_ritz_pairs_end_to_end():
     nb = int(c['n_nodes'][b])
     keep[b] = not oracle.degenerate_cut(c['D_full'][b][:nb], 20)
   assert keep.sum() >= len(score) - 3
-  assert rel_err(score[keep], g['score'][keep]) < 2e-5
+  err = rel_err(score[keep], g["score"][keep])
+  print("adjacency -> device Ritz pairs -> forward vs reference golden: %.2e (%d of %d molecules)" % (err, keep.sum(), len(keep)))
+  assert err < 1e-5     # north_star's bar
 
 
 def test_forward_widths_outside_fused_kernel_use_library_path_with_warning():
