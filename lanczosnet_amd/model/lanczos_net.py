@@ -1144,9 +1144,8 @@ class AdaLanczosNet(_LanczosNetBase):
             cfg, 'use_reorthogonalization') else True
         self.use_power_iteration_cap = cfg.model.use_power_iteration_cap if hasattr(
             cfg, 'use_power_iteration_cap') else True
-        if not self.use_reorthogonalization:
-            raise NotImplementedError('HIP Lanczos layer is built with re-orthogonalisation on '
-                                      '(the reference never turns it off, SURVEY.md F7)')
+        # (re-orthogonalisation off — reachable only through a TOP-LEVEL config attribute, F7 — runs
+        # on the device-side restatement: the HIP Lanczos layer is built with it on)
         self.input_dim = self.num_atom  # model/ada_lanczos_net.py:40
         # The reference collects T^ii in ASCENDING ii whatever the order of the list
         # (model/ada_lanczos_net.py:262-270), and a repeated entry gives it fewer T blocks than its
@@ -1165,15 +1164,24 @@ class AdaLanczosNet(_LanczosNetBase):
         dev = self._guard_forward(L, mask)
         t = self._to_module_device(dev, node_feat=node_feat, L=L, label=label, mask=mask)
         node_feat, L, label, mask = (t[k] for k in ('node_feat', 'L', 'label', 'mask'))
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError('AdaLanczosNet: dropout > 0 in training mode is not built')
-        if self.num_scale_long == 0:
-            raise NotImplementedError('AdaLanczosNet without long-diffusion scales is not built')
-        if not self._fused_supported() or L.shape[1] > 32:
-            raise NotImplementedError('AdaLanczosNet HIP path needs hidden width 64/128 and N <= 32')
         B, N = node_feat.shape[0], node_feat.shape[1]
-        q1 = self._draw_q1(B, N, L.device)
-        if self._needs_grad():
+        # the start vector is drawn only when there is a Lanczos layer to run (:308-315)
+        q1 = self._draw_q1(B, N, L.device) if self.num_scale_long > 0 else None
+        drop = self.training and self.dropout > 0.0
+        off = self._off_nominal(L.shape[1], drop)
+        if off:
+            # every configuration the reference class accepts runs: outside what the fused kernels
+            # are built for, on the device-side restatement of the same operator sequence
+            if off not in self.__dict__.setdefault('_warned_off_nominal', set()):
+                self._warned_off_nominal.add(off)
+                warnings.warn('lanczosnet_amd: AdaLanczosNet with %s is outside the HIP kernels (built '
+                              'for re-orthogonalisation on, MLP filters over >= 1 long scale, hidden '
+                              'width 64 / 128, N <= 32, no training dropout): using the device-side '
+                              'torch restatement of model/ada_lanczos_net.py:289-368, which is slower'
+                              % off)
+            with torch.set_grad_enabled(self._needs_grad()):
+                score = self._torch_forward_ada(node_feat, L, mask, q1, dropout=drop)
+        elif self._needs_grad():
             # forward = HIP kernels; backward = HIP conv-stack backward + library GEMMs for the
             # filter MLPs + autograd through the fp64 Lanczos layer (_AdaLanczosNetFusedFunction)
             # where built, else autograd through the whole torch restatement
@@ -1185,6 +1193,23 @@ class AdaLanczosNet(_LanczosNetBase):
         if label is not None:
             return score, self.loss_func(score, label)
         return score
+
+    def _off_nominal(self, N, drop):
+        """'' when the HIP kernels serve this call, else the reasons they do not (one string)."""
+        why = []
+        if not self.use_reorthogonalization and self.num_scale_long > 0:
+            why.append('use_reorthogonalization=False')
+        if drop:
+            why.append('dropout=%r in training' % self.dropout)
+        if self.num_scale_long == 0:
+            why.append('no long-diffusion scales')
+        elif self.spectral_filter_kind != 'MLP':
+            why.append('spectral_filter_kind=%r' % (self.spectral_filter_kind,))
+        if not self._fused_supported():
+            why.append('hidden_dim=%r' % (self.hidden_dim,))
+        if N > 32:
+            why.append('%d > 32 nodes' % N)
+        return ', '.join(why)
 
     # set by lanczosnet_amd.train.GraphedTrainStep: a device buffer [B, N, 1] that the step object
     # refills from the CPU generator before every replay (nothing may touch the host inside a HIP
@@ -1379,14 +1404,17 @@ class AdaLanczosNet(_LanczosNetBase):
             Lp = ops.pack_laplacian(Lf)
             return ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask)
 
-    def _torch_forward_ada(self, node_feat, L, mask, q1):
+    def _torch_forward_ada(self, node_feat, L, mask, q1, dropout=False):
         """Differentiable torch restatement (device tensors, batched, no Python loops over the
-        batch) of model/ada_lanczos_net.py:101-368 incl. the quirks of `_lanczos_layer` — used ONLY
-        inside backward; forward values always come from the HIP kernels.  Three stages:
+        batch) of model/ada_lanczos_net.py:101-368 incl. the quirks of `_lanczos_layer` — used
+        inside backward (forward values of the nominal configuration always come from the HIP
+        kernels) and as the forward of the configurations `_off_nominal` names.  Three stages:
         `_torch_ada_spectrum` (learned Laplacian, Lanczos layer, T powers), `_torch_ada_filters`
         (the filter MLPs) and `_torch_ada_conv` (conv stack + readout)."""
+        if self.num_scale_long == 0:   # no Lanczos layer, no filters (:308,324)
+            return self._torch_ada_conv(self.embedding(node_feat), L, None, None, mask, dropout=dropout)
         state, tcat, Q = self._torch_ada_spectrum(node_feat, L, mask, q1)
-        return self._torch_ada_conv(state, L, Q, self._torch_ada_filters(tcat), mask)
+        return self._torch_ada_conv(state, L, Q, self._torch_ada_filters(tcat), mask, dropout=dropout)
 
     def _torch_ada_spectrum(self, node_feat, L, mask, q1):
         """model/ada_lanczos_net.py:101-270 -> (embedded node state [B,N,D], cat of the T powers
@@ -1439,7 +1467,7 @@ class AdaLanczosNet(_LanczosNetBase):
             z = torch.bmm(Le, Qs[ii])
             alpha = (Qs[ii] * z).sum(dim=1, keepdim=True)
             z = z - alpha * Qs[ii] - betas[ii - 1] * Qs[ii - 1]
-            if ii > 1:
+            if ii > 1 and self.use_reorthogonalization:   # (:177)
                 qp = Qs[ii - 1]
                 Pj = eye - torch.bmm(qp, qp.transpose(1, 2)) / (
                     (qp * qp).sum(dim=1, keepdim=True) + eps)
@@ -1481,21 +1509,27 @@ class AdaLanczosNet(_LanczosNetBase):
         """model/ada_lanczos_net.py:271-278: the symmetrised dense filters [B, K, K, S] of every
         conv layer."""
         B, K, S = tcat.shape[0], self.num_eig_vec, self.num_scale_long
+        if self.spectral_filter_kind != 'MLP':
+            # :282-284: the T powers themselves, L_s = Q T^p Q^T (cat(T_list, dim=2) is [B, K, S K])
+            DD = tcat.view(B, K, S, K).permute(0, 1, 3, 2)
+            return [DD] * self.num_layer
         out = []
         for t in range(self.num_layer):
             DD = self.spectral_filter[t](tcat).view(B, K, K, S)
             out.append((DD + DD.transpose(1, 2)) * 0.5)
         return out
 
-    def _torch_ada_conv(self, state, L, Q, DDs, mask):
-        """model/ada_lanczos_net.py:289-368: conv stack on given filters + readout."""
+    def _torch_ada_conv(self, state, L, Q, DDs, mask, dropout=False):
+        """model/ada_lanczos_net.py:289-368: conv stack on given filters + readout.  dropout=True:
+        `F.dropout(state, p)` after every conv layer where the reference applies it (:347) — same
+        call, same shape, same order."""
         B, N = state.shape[0], state.shape[1]
         S = self.num_scale_long
         Lc = L.float().permute(0, 3, 1, 2).contiguous()
-        Qt = Q.transpose(1, 2)
+        Qt = Q.transpose(1, 2) if S > 0 else None
         m = (mask != 0).float().unsqueeze(2)
         for t in range(self.num_layer):
-            DD = DDs[t]
+            DD = DDs[t] if S > 0 else None
             W, bias = self._mix_weight(t), self.filter[t].bias
             d_in = state.shape[2]
             Wc = W.view(W.shape[0], -1, d_in)
@@ -1515,6 +1549,8 @@ class AdaLanczosNet(_LanczosNetBase):
                 out = out + torch.bmm(Lc[:, e], Z[c])
                 c += 1
             state = torch.relu(out)
+            if dropout:
+                state = torch.nn.functional.dropout(state, self.dropout, training=True)
         y = self.filter[-1](state) * self.att_func(state)
         return (y * m).sum(dim=1) / m.sum(dim=1)
 
