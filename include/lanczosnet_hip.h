@@ -507,6 +507,23 @@ int lnz_plan_batch(const uint8_t* mask, int B, int N, int n_cu, int allow_pairs,
 int lnz_strip_cap(int B);
 int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips,
                     int32_t* n_strips, lnz_stream_t stream);
+/* ---- R10 backward: the readout head (model/lanczos_net.py:185-194 under loss.backward(),
+ * runner/qm8_runner.py:247).  y = (W_o x + b_o) * sigmoid(w_g x + b_g), score = masked mean of y.
+ *   X_last     [B,32,dhid]  the stored last conv state (post ReLU; lnz_lanczosnet_forward act_out)
+ *   mask       [B,N] uint8;  grad_score [B,P] = dL/dscore
+ *   Whead      [P+1,dhid], bhead [P+1]: output rows, then the gate row
+ *   row_off    [B] int64 (optional): first row of molecule b in the compact numbering of dY_compact
+ * ->
+ *   dY         [B,32,dhid]  dL/d(pre-activation of the last conv layer) (zero on padding / masked rows)
+ *   dY_compact [R,dhid]     (optional) the rows below a molecule's node extent, compact
+ *   dWhead     [P+1,dhid], dbhead [P+1], dbias_last [dhid] (column sums of dY)
+ * workspace: lnz_head_backward_workspace_floats(P, n_wg) floats; n_wg workgroups walk the molecules
+ * (the partial sums are added in workgroup order: deterministic).  dhid = 128, N <= 32, P <= 31. */
+int64_t lnz_head_backward_workspace_floats(int P, int n_wg);
+int lnz_head_backward(const float* X_last, const uint8_t* mask, const float* grad_score,
+                      const float* Whead, const float* bhead, const int64_t* row_off, int B, int N,
+                      int P, int dhid, int n_wg, float* workspace, float* dY, float* dY_compact,
+                      float* dWhead, float* dbhead, float* dbias_last, lnz_stream_t stream);
 /* ---- R9 + R10 + R11 for graphs of 33..128 nodes: the reference's own graph configuration
  * (config/graph_lanczos_net.yaml, dataset/get_graph_data.py:15-49: n in [20, 100]) — every conv
  * layer of model/lanczos_net_general.py:157-182 (model/lanczos_net.py:157-182), the head and the

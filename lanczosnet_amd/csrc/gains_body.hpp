@@ -83,7 +83,11 @@ __device__ inline void dense_tile(const float4* __restrict__ wstream, float4 (&r
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     constexpr int D = LNZ_GAINS_DIST;
+#ifdef LNZ_GAINS_PROBE_NOLOAD   // probe: the MLP without its weight stream (what do the loads cost?)
+    ring[(F0 + q + D) % RING] = make_float4(0.5f, 0.25f, 0.125f, 1.0f);
+#else
     ring[(F0 + q + D) % RING] = wstream[(F0 + q + D) * 64];  // over-read lands in the slack
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const float4 a = ring[(F0 + q) % RING];
     const int ti = q >> 2, g = q & 3;
@@ -119,6 +123,10 @@ __device__ __forceinline__ void gains_mlp_tiles(const float* __restrict__ D, con
                                                 float* __restrict__ G) {
   const int hh = lane >> 5;
   const float* pk = mlp_pack + (int64_t)l * PACK_SIZE;
+#ifdef LNZ_GAINS_PROBE_STAGGER   // probe: de-phase the waves that stream the same weights in lockstep
+  for (int i = 0; i < (int)((blockIdx.x & (LNZ_GAINS_PROBE_STAGGER_N - 1)) * LNZ_GAINS_PROBE_STAGGER); ++i)
+    __builtin_amdgcn_s_sleep(16);   // 16 x 64 clocks
+#endif
 
   // start the 128-wide weight stream right away: it is independent of the first layer
   const float4* __restrict__ wstream = reinterpret_cast<const float4*>(pk + OFF_W2) + lane;
@@ -142,8 +150,13 @@ __device__ __forceinline__ void gains_mlp_tiles(const float* __restrict__ D, con
       float feat[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
+#ifdef LNZ_GAINS_PROBE_NOPOW    // probe: the features without the fp64 power loops
+        float lo = t < S ? dval : 0.0f;
+        float hi = (8 + t) < S ? dval : 0.0f;
+#else
         float lo = t < S ? powi(dval, dist.v[t]) : 0.0f;
         float hi = (8 + t) < S ? powi(dval, dist.v[8 + t]) : 0.0f;
+#endif
         feat[t] = hh ? hi : lo;
       }
       // Linear(S -> 128) + ReLU

@@ -47,6 +47,9 @@ class _LanczosNetBase(nn.Module):
     # spectral-filter MLP gradients in the HIP backward: 'hip' = lnz_spectral_mlp_grad (one launch),
     # 'torch' = autograd through batched library GEMMs (the oracle that kernel is tested against)
     mlp_grad_impl = os.environ.get('LANCZOSNET_MLP_GRAD', 'hip')
+    # readout-head gradients in the HIP backward: 'hip' = lnz_head_backward (one launch), 'torch' =
+    # autograd on the stored last state (the oracle that kernel is tested against)
+    head_grad_impl = os.environ.get('LANCZOSNET_HEAD_GRAD', 'hip')
     # 'hip' = HIP backward kernels where built (LanczosNet, width 128); 'torch' = autograd through
     # the torch recomputation everywhere (the gradient oracle the HIP backward is tested against)
     backward_impl = os.environ.get('LANCZOSNET_BACKWARD', 'hip')
@@ -824,23 +827,29 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     n_chan = n_short + S + m.num_edgetype + 1
     dev = V.device
     grads = {}
-    # ---- head (model/lanczos_net.py:185-194) on the stored last state
+    # ---- head (model/lanczos_net.py:185-194) on the stored last state: lnz_head_backward (one
+    #      launch; below, once the compact row numbering exists) or torch autograd
+    P_out = m.filter[-1].weight.shape[0]
+    hip_head = (m.head_grad_impl == 'hip' and dh == 128 and N <= 32 and P_out <= 31 and
+                mask_u8.shape[1] == N)
     head_params = list(m.filter[-1].parameters()) + list(m.att_func.parameters())
+    hg = None
     with torch.enable_grad():
-        XL = act[Lnum - 1][:, :N].detach().requires_grad_(True)
-        # output Linear and gate Linear as ONE product (three library GEMMs forward + backward instead
-        # of six thin ones; every output column is the same dot product either way)
-        P_out = m.filter[-1].weight.shape[0]
-        Z = torch.nn.functional.linear(XL, torch.cat([m.filter[-1].weight, m.att_func[0].weight], dim=0),
-                                       torch.cat([m.filter[-1].bias, m.att_func[0].bias], dim=0))
-        y = Z[..., :P_out] * torch.sigmoid(Z[..., P_out:])
-        mk = (mask_u8 != 0).float().unsqueeze(2)
-        score = (y * mk).sum(dim=1) / mk.sum(dim=1)
-        hg = torch.autograd.grad(score, [XL] + head_params, grad_score.contiguous())
-    for p_, g_ in zip(head_params, hg[1:]):
-        grads[id(p_)] = g_
+        if not hip_head:
+            XL = act[Lnum - 1][:, :N].detach().requires_grad_(True)
+            # output Linear and gate Linear as ONE product (three library GEMMs forward + backward instead
+            # of six thin ones; every output column is the same dot product either way)
+            Z = torch.nn.functional.linear(XL, torch.cat([m.filter[-1].weight, m.att_func[0].weight], dim=0),
+                                           torch.cat([m.filter[-1].bias, m.att_func[0].bias], dim=0))
+            y = Z[..., :P_out] * torch.sigmoid(Z[..., P_out:])
+            mk = (mask_u8 != 0).float().unsqueeze(2)
+            score = (y * mk).sum(dim=1) / mk.sum(dim=1)
+            hg = torch.autograd.grad(score, [XL] + head_params, grad_score.contiguous())
     dy = torch.zeros((Lnum, B, 32, dh), dtype=torch.float32, device=dev)
-    dy[Lnum - 1][:, :N] = hg[0] * (XL > 0).float()
+    if hg is not None:
+        for p_, g_ in zip(head_params, hg[1:]):
+            grads[id(p_)] = g_
+        dy[Lnum - 1][:, :N] = hg[0] * (XL > 0).float()
     dx0 = torch.zeros((B, 32, din0p), dtype=torch.float32, device=dev)
 
     # ---- compact row numbering (real nodes only: half of the padded rows are empty) — the row
@@ -863,6 +872,14 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     strips_ = getattr(tiles[0], 'strips', None)
     n_part = max(2 * tiles[1], (strips_.numel() - 1) // ops.STRIP_INTS if strips_ is not None else 0)
     dbp = torch.zeros((n_part, Lnum, dh), dtype=torch.float32, device=dev)
+    db_last = None
+    if hip_head:
+        Wh = torch.cat([m.filter[-1].weight.detach(), m.att_func[0].weight.detach()], dim=0)
+        bh = torch.cat([m.filter[-1].bias.detach(), m.att_func[0].bias.detach()], dim=0)
+        dWh, dbh, db_last = ops.head_backward(act[Lnum - 1], mask_u8, grad_score, Wh, bh, N, dy[Lnum - 1],
+                                              row_off=row_off, dY_compact=dyc[Lnum - 1])
+        grads[id(m.filter[-1].weight)], grads[id(m.filter[-1].bias)] = dWh[:P_out], dbh[:P_out]
+        grads[id(m.att_func[0].weight)], grads[id(m.att_func[0].bias)] = dWh[P_out:], dbh[P_out:]
     ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles, row_off=row_off,
                               dy_compact=dyc, dbias_part=dbp)
 
@@ -875,25 +892,27 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
 
     # ---- conv weights / biases: dW_l = dY_l^T cat_c(M_c X_l), db_l = column sums of dY_l, over
     #      the REAL node rows only
-    valid = None
-    r = torch.arange(R_tot, device=dev)
     if static_rows:
-        # rows past the real count are never written by the kernels: zero-filled here, and the
-        # incoming gradient's rows are masked
-        valid = (r < row_end[-1]).to(torch.float32).unsqueeze(1)
-        mol_of_r = torch.searchsorted(row_end, r, right=True).clamp_(max=B - 1)
-        real = mol_of_r * 32 + (r - row_off[mol_of_r]).clamp_(min=0, max=31)
+        # rows past the real count are never written by the kernels: zero-filled here
         msg_buf = torch.zeros((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
         msg_buf0 = msg_buf if din0p == dh else \
             torch.zeros((R_tot * n_chan * din0p,), dtype=torch.float32, device=dev)
     else:
-        # compact row r -> padded row (molecule * 32 + node), without a data-dependent shape
-        mol_of_r = torch.searchsorted(row_end, r, right=True)
-        real = mol_of_r * 32 + (r - row_off[mol_of_r])
         msg_buf = msg_buf0 = torch.empty((R_tot * n_chan * dh,), dtype=torch.float32, device=dev)
-    # the incoming gradient (slot L - 1) is the one layer the kernel does not write compactly
-    last = dy[Lnum - 1].view(B * 32, dh).index_select(0, real)
-    dyc[Lnum - 1] = last if valid is None else last * valid
+    if not hip_head:
+        # the incoming gradient (slot L - 1) is the one layer the input-gradient kernel does not write
+        # compactly (lnz_head_backward does): compact row r -> padded row (molecule * 32 + node),
+        # without a data-dependent shape; under graph capture the rows past the real count are masked
+        r = torch.arange(R_tot, device=dev)
+        if static_rows:
+            valid = (r < row_end[-1]).to(torch.float32).unsqueeze(1)
+            mol_of_r = torch.searchsorted(row_end, r, right=True).clamp_(max=B - 1)
+            real = mol_of_r * 32 + (r - row_off[mol_of_r]).clamp_(min=0, max=31)
+            dyc[Lnum - 1] = dy[Lnum - 1].view(B * 32, dh).index_select(0, real) * valid
+        else:
+            mol_of_r = torch.searchsorted(row_end, r, right=True)
+            real = mol_of_r * 32 + (r - row_off[mol_of_r])
+            dyc[Lnum - 1] = dy[Lnum - 1].view(B * 32, dh).index_select(0, real)
     for la in range(Lnum):
         d = din0p if la == 0 else dh
         msg = (msg_buf0 if la == 0 else msg_buf)[:R_tot * n_chan * d].view(R_tot, n_chan * d)
@@ -907,7 +926,7 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     # reduction over [2 * workgroups, L, dh] instead of one over the [L, B * 32, dh] block);
     # the last layer's from the incoming gradient
     db_all = dbp.sum(dim=0)
-    db_all[Lnum - 1] = dy[Lnum - 1].view(B * 32, dh).sum(dim=0)
+    db_all[Lnum - 1] = db_last if db_last is not None else dy[Lnum - 1].view(B * 32, dh).sum(dim=0)
     for la in range(Lnum):
         grads[id(m.filter[la].bias)] = db_all[la]
     return grads, dy, dx0, x0

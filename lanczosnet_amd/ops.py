@@ -726,6 +726,27 @@ def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
           (g[:, o6:ob].view(L, S, 128), g[:, ob + 384:ob + 384 + S])]
 
 
+def head_backward(X_last, mask_u8, grad_score, Whead, bhead, N, dY, row_off=None, dY_compact=None, n_wg=256):
+  """lnz_head_backward: the readout head's backward in one launch (+ a tiny fixed-order reduction).
+  X_last [B,32,128] (last conv state), mask [B,N] uint8, grad_score [B,P], Whead [P+1,128] / bhead
+  [P+1] (output rows, then the gate row); dY [B,32,128] is written in place (and dY_compact [R,128]
+  at row_off[b] + r for the rows below the node extent).  Returns dWhead [P+1,128], dbhead [P+1],
+  dbias_last [128] (column sums of dY)."""
+  _need_cuda(X_last, mask_u8, grad_score, Whead, bhead, dY, row_off, dY_compact)
+  B, P = grad_score.shape
+  assert X_last.shape == (B, 32, 128) and X_last.is_contiguous() and dY.shape == (B, 32, 128) and dY.is_contiguous()
+  assert Whead.shape == (P + 1, 128) and Whead.is_contiguous() and mask_u8.dtype == torch.uint8
+  dev = X_last.device
+  ws = torch.empty((int(_abi().head_backward_workspace_floats(P, n_wg)),), dtype=torch.float32, device=dev)
+  dW = torch.empty((P + 1, 128), dtype=torch.float32, device=dev)
+  db = torch.empty((P + 1,), dtype=torch.float32, device=dev)
+  dbl = torch.empty((128,), dtype=torch.float32, device=dev)
+  with torch.cuda.device(dev):
+    _abi().head_backward(X_last, mask_u8.contiguous(), grad_score.float().contiguous(), Whead, bhead.contiguous(),
+                         row_off, B, N, P, 128, n_wg, ws, dY, dY_compact, dW, db, dbl)
+  return dW, db, dbl
+
+
 def embedding_grad(ids, dx, width, num_atom, chunks=64):
   """lnz_embedding_grad: dE [num_atom, width] = sum of the rows dx[b, i, :width] by atom id ids[b, i]
   (ids [B, N] int64; dx [B, >= N, >= width] fp32 with a contiguous last dimension) — the embedding
