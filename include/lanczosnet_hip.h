@@ -511,7 +511,9 @@ int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips
  * runner/qm8_runner.py:247).  y = (W_o x + b_o) * sigmoid(w_g x + b_g), score = masked mean of y.
  *   X_last     [B,32,dhid]  the stored last conv state (post ReLU; lnz_lanczosnet_forward act_out)
  *   mask       [B,N] uint8;  grad_score [B,P] = dL/dscore
- *   Whead      [P+1,dhid], bhead [P+1]: output rows, then the gate row
+ *   Whead      [P+1,dhid], bhead [P+1]: output rows, then the gate row — or [P,dhid], [P] with the
+ *              gate row given on its own as Wgate [1,dhid], bgate [1] (the module keeps them in two
+ *              Linears, model/lanczos_net.py:57,61)
  *   row_off    [B] int64 (optional): first row of molecule b in the compact numbering of dY_compact
  * ->
  *   dY         [B,32,dhid]  dL/d(pre-activation of the last conv layer) (zero on padding / masked rows)
@@ -520,8 +522,15 @@ int lnz_plan_strips(const uint8_t* mask, int B, int N, int n_cu, int32_t* strips
  * workspace: lnz_head_backward_workspace_floats(P, n_wg) floats; n_wg workgroups walk the molecules
  * (the partial sums are added in workgroup order: deterministic).  dhid = 128, N <= 32, P <= 31. */
 int64_t lnz_head_backward_workspace_floats(int P, int n_wg);
+/* Node extents (last real node + 1; the training kernels size a molecule by it), their exclusive
+ * prefix sums (first row of a molecule in the compact numbering of the message matrix,
+ * lnz_lanczosnet_messages row_off) and their total, from mask [B,N] uint8: extent, row_off [B] int64,
+ * total [1] int64.  One launch. */
+int lnz_node_extents(const uint8_t* mask, int B, int N, int64_t* extent, int64_t* row_off,
+                     int64_t* total, lnz_stream_t stream);
 int lnz_head_backward(const float* X_last, const uint8_t* mask, const float* grad_score,
-                      const float* Whead, const float* bhead, const int64_t* row_off, int B, int N,
+                      const float* Whead, const float* bhead, const float* Wgate, const float* bgate,
+                      const int64_t* row_off, int B, int N,
                       int P, int dhid, int n_wg, float* workspace, float* dY, float* dY_compact,
                       float* dWhead, float* dbhead, float* dbias_last, lnz_stream_t stream);
 /* ---- R9 + R10 + R11 for graphs of 33..128 nodes: the reference's own graph configuration

@@ -24,8 +24,10 @@ struct HeadArgs {
   const float* X;           // [B,32,128]
   const uint8_t* mask;      // [B,N]
   const float* gscore;      // [B,P]
-  const float* W;           // [P+1,128]
-  const float* bias;        // [P+1]
+  const float* W;           // [P,128] output rows (+ the gate row behind them when Wgate is NULL)
+  const float* bias;        // [P] (+ 1)
+  const float* Wgate;       // [1,128] or NULL
+  const float* bgate;       // [1] or NULL
   const int64_t* row_off;   // [B] or NULL
   float* dY;                // [B,32,128]
   float* dYc;               // [R,128] or NULL
@@ -50,9 +52,10 @@ __global__ __launch_bounds__(256, 2) void head_backward_kernel(HeadArgs a) {
   const int c = tid & 127, rh = tid >> 7;
   for (int i = tid; i < P1 * 32; i += 256) {
     const int o = i >> 5, k4 = i & 31;
-    *reinterpret_cast<float4*>(&Ws[o * XP + 4 * k4]) = *reinterpret_cast<const float4*>(a.W + o * DH + 4 * k4);
+    const float* src = (a.Wgate && o == P) ? a.Wgate : a.W + o * DH;
+    *reinterpret_cast<float4*>(&Ws[o * XP + 4 * k4]) = *reinterpret_cast<const float4*>(src + 4 * k4);
   }
-  if (tid < P1) bs[tid] = a.bias[tid];
+  if (tid < P1) bs[tid] = (a.bgate && tid == P) ? a.bgate[0] : a.bias[tid];
   for (int i = tid; i < 32 * ZP; i += 256) dzs[i] = 0.0f;   // (the columns past P + 1 stay zero)
   // this thread's parameter-gradient partials: dW[o][c] for its half's head rows
   float dw[NDW];
@@ -207,7 +210,54 @@ __global__ void head_backward_reduce_kernel(const float* __restrict__ part, int 
   else dbias[i - P1 * DH - 32] = s;
 }
 
+// Node extents (last real node + 1) of a batch, their exclusive prefix sums (the compact row
+// numbering of the message matrix) and their total: one workgroup, one launch.
+__global__ __launch_bounds__(1024) void node_extents_kernel(const uint8_t* __restrict__ mask, int B, int N,
+                                                            int64_t* __restrict__ extent,
+                                                            int64_t* __restrict__ row_off,
+                                                            int64_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    int e = 0;
+    if (b < B)
+      for (int j = 0; j < N; ++j)
+        if (mask[(int64_t)b * N + j]) e = j + 1;
+    int incl = e;   // inclusive scan over the wave, then over the waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (b < B) {
+      extent[b] = e;
+      row_off[b] = before + incl - e;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) total[0] = carry_s;
+}
+
 }  // namespace
+
+extern "C" int lnz_node_extents(const uint8_t* mask, int B, int N, int64_t* extent, int64_t* row_off,
+                                int64_t* total, lnz_stream_t stream) {
+  LNZ_REQUIRE(mask && extent && row_off && total && B > 0 && N > 0, LNZ_EINVAL,
+              "lnz_node_extents: bad arguments (B=%d N=%d)", B, N);
+  hipLaunchKernelGGL(node_extents_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, B, N, extent,
+                     row_off, total);
+  return lnz::check_launch("lnz_node_extents");
+}
 
 extern "C" int64_t lnz_head_backward_workspace_floats(int P, int n_wg) {
   if (P < 1 || P > PMAX || n_wg < 1) return 0;
@@ -215,7 +265,8 @@ extern "C" int64_t lnz_head_backward_workspace_floats(int P, int n_wg) {
 }
 
 extern "C" int lnz_head_backward(const float* X_last, const uint8_t* mask, const float* grad_score,
-                                 const float* Whead, const float* bhead, const int64_t* row_off, int B,
+                                 const float* Whead, const float* bhead, const float* Wgate,
+                                 const float* bgate, const int64_t* row_off, int B,
                                  int N, int P, int dhid, int n_wg, float* workspace, float* dY,
                                  float* dY_compact, float* dWhead, float* dbhead, float* dbias_last,
                                  lnz_stream_t stream) {
@@ -227,8 +278,10 @@ extern "C" int lnz_head_backward(const float* X_last, const uint8_t* mask, const
               dhid, N, P);
   LNZ_REQUIRE(n_wg >= 1 && n_wg <= 4096, LNZ_EINVAL, "lnz_head_backward: n_wg=%d", n_wg);
   LNZ_REQUIRE(!dY_compact || row_off, LNZ_EINVAL, "lnz_head_backward: dY_compact without row_off");
+  LNZ_REQUIRE(!Wgate == !bgate, LNZ_EINVAL, "lnz_head_backward: Wgate and bgate come together");
   HeadArgs a;
   a.X = X_last, a.mask = mask, a.gscore = grad_score, a.W = Whead, a.bias = bhead, a.row_off = row_off;
+  a.Wgate = Wgate, a.bgate = bgate;
   a.dY = dY, a.dYc = dY_compact, a.part = workspace;
   a.B = B, a.N = N, a.P = P, a.n_wg = n_wg < B ? n_wg : B;
   if (P + 1 == 17)

@@ -855,8 +855,8 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     # ---- compact row numbering (real nodes only: half of the padded rows are empty) — the row
     #      order of the message matrix; node extent (last real node + 1) is what the kernels size
     #      a molecule by
-    row_end = torch.cumsum(n_mol, 0)
-    row_off = (row_end - n_mol).contiguous()                                 # int64 [B]
+    # (n_mol: the block lnz_node_extents wrote in the forward — extents | row offsets | total)
+    n_mol, row_off, row_total = n_mol[:B], n_mol[B:2 * B], n_mol[2 * B:]
     if static_rows:
         R_tot = B * N   # graph capture: no host round trip; rows past the real count are masked
     else:
@@ -874,10 +874,10 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
     dbp = torch.zeros((n_part, Lnum, dh), dtype=torch.float32, device=dev)
     db_last = None
     if hip_head:
-        Wh = torch.cat([m.filter[-1].weight.detach(), m.att_func[0].weight.detach()], dim=0)
-        bh = torch.cat([m.filter[-1].bias.detach(), m.att_func[0].bias.detach()], dim=0)
-        dWh, dbh, db_last = ops.head_backward(act[Lnum - 1], mask_u8, grad_score, Wh, bh, N, dy[Lnum - 1],
-                                              row_off=row_off, dY_compact=dyc[Lnum - 1])
+        dWh, dbh, db_last = ops.head_backward(act[Lnum - 1], mask_u8, grad_score, m.filter[-1].weight.detach(),
+                                              m.filter[-1].bias.detach(), N, dy[Lnum - 1], row_off=row_off,
+                                              dY_compact=dyc[Lnum - 1], Wgate=m.att_func[0].weight.detach(),
+                                              bgate=m.att_func[0].bias.detach())
         grads[id(m.filter[-1].weight)], grads[id(m.filter[-1].bias)] = dWh[:P_out], dbh[:P_out]
         grads[id(m.att_func[0].weight)], grads[id(m.att_func[0].bias)] = dWh[P_out:], dbh[P_out:]
     ops.lanczosnet_input_grad(plan, Lp, V, G, mask_u8, act, dy, dx0, tiles, row_off=row_off,
@@ -905,12 +905,13 @@ def _fused_conv_backward(m, plan, grad_score, node_feat, V, G, mask_u8, Lp, act,
         # without a data-dependent shape; under graph capture the rows past the real count are masked
         r = torch.arange(R_tot, device=dev)
         if static_rows:
-            valid = (r < row_end[-1]).to(torch.float32).unsqueeze(1)
+            row_end = row_off + n_mol
+            valid = (r < row_total).to(torch.float32).unsqueeze(1)
             mol_of_r = torch.searchsorted(row_end, r, right=True).clamp_(max=B - 1)
             real = mol_of_r * 32 + (r - row_off[mol_of_r]).clamp_(min=0, max=31)
             dyc[Lnum - 1] = dy[Lnum - 1].view(B * 32, dh).index_select(0, real) * valid
         else:
-            mol_of_r = torch.searchsorted(row_end, r, right=True)
+            mol_of_r = torch.searchsorted(row_off + n_mol, r, right=True)
             real = mol_of_r * 32 + (r - row_off[mol_of_r])
             dyc[Lnum - 1] = dy[Lnum - 1].view(B * 32, dh).index_select(0, real)
     for la in range(Lnum):
@@ -960,8 +961,8 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         # number of real node rows.  The count travels to the host asynchronously, under the
         # forward kernel, so the backward never has to drain the GPU to learn a shape.
         N = Vc.shape[1]
-        n_mol = ((mask_u8 != 0).long() *
-                 torch.arange(1, N + 1, device=Vc.device).view(1, N)).amax(dim=1)
+        # (one launch: extents, their exclusive prefix sums = the compact row numbering, the total)
+        n_mol = ops.node_extents_block(mask_u8)
         # Under HIP-graph capture (train.GraphedTrainStep) nothing may touch the host: the backward
         # then sizes its message matrix by the padded row count B * N and masks the tail on the
         # device instead of reading the real row count.
@@ -970,7 +971,7 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
         rtot = ev = None
         if not ctx.static_rows:
             rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
-            rtot.copy_(n_mol.sum().view(1), non_blocking=True)
+            rtot.copy_(n_mol[-1:], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         score = ops.lanczosnet_forward(plan, node_feat, Lp, Vc, G, mask_u8, tiling=tiles,
@@ -1619,8 +1620,8 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         Lp = ops.pack_laplacian(Lf)
         tiles = ops.plan_tiles(mask_u8, allow_pairs=ops.pairing_supported(plan))
         act = torch.zeros((m.num_layer, B, 32, plan['dhid']), dtype=torch.float32, device=Q.device)
-        n_mol = ((mask_u8 != 0).long() *
-                 torch.arange(1, N + 1, device=Q.device).view(1, N)).amax(dim=1)
+        # (one launch: extents, their exclusive prefix sums = the compact row numbering, the total)
+        n_mol = ops.node_extents_block(mask_u8)
         # (as _LanczosNetFusedFunction: under HIP-graph capture nothing may touch the host, the
         # backward then sizes its message matrix by the padded row count)
         ctx.static_rows = (torch.cuda.is_current_stream_capturing()
@@ -1628,7 +1629,7 @@ class _AdaLanczosNetFusedFunction(torch.autograd.Function):
         rtot = ev = None
         if not ctx.static_rows:
             rtot = torch.empty((1,), dtype=torch.int64, pin_memory=True)
-            rtot.copy_(n_mol.sum().view(1), non_blocking=True)
+            rtot.copy_(n_mol[-1:], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
         score = ops.lanczosnet_forward(plan, node_feat, Lp, Q, DDp, mask_u8, tiling=tiles,

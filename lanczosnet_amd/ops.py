@@ -726,16 +726,37 @@ def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
           (g[:, o6:ob].view(L, S, 128), g[:, ob + 384:ob + 384 + S])]
 
 
-def head_backward(X_last, mask_u8, grad_score, Whead, bhead, N, dY, row_off=None, dY_compact=None, n_wg=256):
+def node_extents_block(mask_u8):
+  """lnz_node_extents: mask [B,N] uint8 -> ONE int64 tensor [2 B + 1]: extents | row offsets (their
+  exclusive prefix sums) | total.  One launch."""
+  _need_cuda(mask_u8)
+  B, N = mask_u8.shape
+  out = torch.empty((2 * B + 1,), dtype=torch.int64, device=mask_u8.device)
+  with torch.cuda.device(mask_u8.device):
+    _abi().node_extents(mask_u8.contiguous(), B, N, out[:B], out[B:2 * B], out[2 * B:])
+  return out
+
+
+def node_extents(mask_u8):
+  """(extent [B], row_off [B], total [1]) views of node_extents_block."""
+  B = mask_u8.shape[0]
+  out = node_extents_block(mask_u8)
+  return out[:B], out[B:2 * B], out[2 * B:]
+
+
+def head_backward(X_last, mask_u8, grad_score, Whead, bhead, N, dY, row_off=None, dY_compact=None, n_wg=256,
+                  Wgate=None, bgate=None):
   """lnz_head_backward: the readout head's backward in one launch (+ a tiny fixed-order reduction).
   X_last [B,32,128] (last conv state), mask [B,N] uint8, grad_score [B,P], Whead [P+1,128] / bhead
   [P+1] (output rows, then the gate row); dY [B,32,128] is written in place (and dY_compact [R,128]
-  at row_off[b] + r for the rows below the node extent).  Returns dWhead [P+1,128], dbhead [P+1],
+  at row_off[b] + r for the rows below the node extent).  Wgate / bgate: the gate row on its own
+  (Whead then holds the P output rows only).  Returns dWhead [P+1,128], dbhead [P+1],
   dbias_last [128] (column sums of dY)."""
   _need_cuda(X_last, mask_u8, grad_score, Whead, bhead, dY, row_off, dY_compact)
   B, P = grad_score.shape
   assert X_last.shape == (B, 32, 128) and X_last.is_contiguous() and dY.shape == (B, 32, 128) and dY.is_contiguous()
-  assert Whead.shape == (P + 1, 128) and Whead.is_contiguous() and mask_u8.dtype == torch.uint8
+  assert Whead.shape == (P + (Wgate is None), 128) and Whead.is_contiguous() and mask_u8.dtype == torch.uint8
+  assert Wgate is None or (Wgate.shape == (1, 128) and Wgate.is_contiguous())
   dev = X_last.device
   ws = torch.empty((int(_abi().head_backward_workspace_floats(P, n_wg)),), dtype=torch.float32, device=dev)
   dW = torch.empty((P + 1, 128), dtype=torch.float32, device=dev)
@@ -743,7 +764,7 @@ def head_backward(X_last, mask_u8, grad_score, Whead, bhead, N, dY, row_off=None
   dbl = torch.empty((128,), dtype=torch.float32, device=dev)
   with torch.cuda.device(dev):
     _abi().head_backward(X_last, mask_u8.contiguous(), grad_score.float().contiguous(), Whead, bhead.contiguous(),
-                         row_off, B, N, P, 128, n_wg, ws, dY, dY_compact, dW, db, dbl)
+                         Wgate, bgate, row_off, B, N, P, 128, n_wg, ws, dY, dY_compact, dW, db, dbl)
   return dW, db, dbl
 
 

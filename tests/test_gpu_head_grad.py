@@ -86,3 +86,18 @@ def test_training_gradients_with_the_head_kernel_equal_the_autograd_head():
               for k in grads['torch'])
   print('worst relative gradient deviation, head kernel vs autograd head: %.2e' % worst)
   assert worst < 5e-6
+
+
+@pytest.mark.parametrize('B,N', [(1024, 26), (3000, 32), (1, 5), (70, 100)])
+def test_node_extents_one_launch(B, N):
+  """lnz_node_extents: extents (last real node + 1, holes in the mask included), their exclusive prefix
+  sums and the total — the compact row numbering the training kernels share."""
+  from lanczosnet_amd import ops
+  g = torch.Generator(device=DEV)
+  g.manual_seed(B)
+  mask = (torch.rand((B, N), generator=g, device=DEV) < 0.6).to(torch.uint8)
+  mask[0] = 0
+  ext, off, tot = ops.node_extents(mask)
+  want = (mask.long() * torch.arange(1, N + 1, device=DEV)).amax(dim=1)
+  assert torch.equal(ext, want)
+  assert torch.equal(off, torch.cumsum(want, 0) - want) and int(tot) == int(want.sum())
