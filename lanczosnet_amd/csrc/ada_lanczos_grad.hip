@@ -533,8 +533,7 @@ extern "C" int lnz_ada_graph_laplacian_f64(const float* X, int D, const float* L
               "lnz_ada_graph_laplacian_f64: bad arguments (B=%d N=%d D=%d)", B, N, D);
   const size_t lds = ((size_t)N * D + (size_t)N * N + N) * sizeof(double);
   LNZ_REQUIRE(lds <= 96 * 1024, LNZ_ENOTSUP, "lnz_ada_graph_laplacian_f64: N=%d, D=%d too large", N, D);
-  (void)hipFuncSetAttribute((const void*)ada_laplacian_f64_forward_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  LNZ_DYNAMIC_LDS(ada_laplacian_f64_forward_kernel, lds, "ada_lanczos_grad.hip");
   hipLaunchKernelGGL(ada_laplacian_f64_forward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, X, D,
                      L0, stride_b, stride_r, stride_c, N, Le, state);
   return lnz::check_launch("lnz_ada_graph_laplacian_f64");
@@ -548,8 +547,7 @@ extern "C" int lnz_ada_graph_laplacian_f64_backward(const float* X, int D, int B
   const size_t lds = ((size_t)N * D + 2 * (size_t)N * N + 2 * N) * sizeof(double);
   LNZ_REQUIRE(lds <= 96 * 1024, LNZ_ENOTSUP, "lnz_ada_graph_laplacian_f64_backward: N=%d, D=%d too large",
               N, D);
-  (void)hipFuncSetAttribute((const void*)ada_laplacian_f64_backward_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  LNZ_DYNAMIC_LDS(ada_laplacian_f64_backward_kernel, lds, "ada_lanczos_grad.hip");
   hipLaunchKernelGGL(ada_laplacian_f64_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, X, D,
                      N, state, dLe, dX);
   return lnz::check_launch("lnz_ada_graph_laplacian_f64_backward");
@@ -564,8 +562,7 @@ extern "C" int lnz_ada_t_powers_f64(const double* T, int B, int K, const int32_t
   const int pmax = pow_args(dist_host, S, &d);
   LNZ_REQUIRE(pmax >= 1 && pmax <= 4096, LNZ_EINVAL, "lnz_ada_t_powers_f64: bad exponents");
   const size_t lds = (size_t)3 * K * K * sizeof(double);
-  (void)hipFuncSetAttribute((const void*)ada_t_powers_f64_forward_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  LNZ_DYNAMIC_LDS(ada_t_powers_f64_forward_kernel, lds, "ada_lanczos_grad.hip");
   hipLaunchKernelGGL(ada_t_powers_f64_forward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, K, d,
                      S, pmax, Tcat, P);
   return lnz::check_launch("lnz_ada_t_powers_f64");
@@ -581,8 +578,7 @@ extern "C" int lnz_ada_t_powers_f64_backward(const double* T, int B, int K, cons
   const int pmax = pow_args(dist_host, S, &d);
   LNZ_REQUIRE(pmax >= 1 && pmax <= 4096, LNZ_EINVAL, "lnz_ada_t_powers_f64_backward: bad exponents");
   const size_t lds = (size_t)5 * K * K * sizeof(double);
-  (void)hipFuncSetAttribute((const void*)ada_t_powers_f64_backward_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  LNZ_DYNAMIC_LDS(ada_t_powers_f64_backward_kernel, lds, "ada_lanczos_grad.hip");
   hipLaunchKernelGGL(ada_t_powers_f64_backward_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, T, K, d,
                      S, pmax, dTcat, P, dT);
   return lnz::check_launch("lnz_ada_t_powers_f64_backward");

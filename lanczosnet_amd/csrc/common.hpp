@@ -34,6 +34,26 @@ inline int check_launch(const char* what) {
   return LNZ_OK;
 }
 
+// Dynamic LDS beyond the 64 KiB default has to be granted per function AND per device (a process may
+// drive several): asked for at every launch.  A part that cannot grant it (less than 160 KiB of LDS per
+// workgroup) answers LNZ_ENOTSUP with a message — the callers' cue to take another path — instead of
+// an opaque launch failure.
+inline int set_dynamic_lds(const void* fn, size_t bytes, const char* what) {
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: %zu bytes of dynamic LDS per workgroup are not available on this device (%s)", what,
+              bytes, hipGetErrorString(e));
+    return LNZ_ENOTSUP;
+  }
+  return LNZ_OK;
+}
+#define LNZ_DYNAMIC_LDS(fn, bytes, what)                                       \
+  do {                                                                         \
+    const int rc_lds_ = lnz::set_dynamic_lds((const void*)(fn), (bytes), what); \
+    if (rc_lds_ != LNZ_OK) return rc_lds_;                                     \
+  } while (0)
+
 // C/D row of accumulator register r for the lane half hh (= lane >> 5):
 //   row = (r & 3) + 8 * (r >> 2) + 4 * hh          (v_mfma_f32_32x32x2_f32, col = lane & 31)
 __host__ __device__ inline int cd_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }

@@ -1381,8 +1381,8 @@ static int launch_conv(const lnz_forward_args& a, int mode, hipStream_t s, const
     auto kfn = lanczosnet_forward_kernel<NWV_, KHT_, FK_, MODE_, DEEPK_>;                        \
     lnz::note_kernel("lanczosnet_forward_kernel<%d,%d,%d,%d,%d>", NWV_, KHT_, FK_, MODE_, DEEPK_); \
     if (gs_bytes)                                                                                \
-      (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                (int)gs_bytes);                                                  \
+      LNZ_DYNAMIC_LDS(kfn, \
+      gs_bytes, "conv_forward.hip");                                                  \
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(128 * NWV_), gs_bytes, s, a);                       \
   } while (0)
 #define LNZ_LAUNCH(NWV_, KHT_, FK_, MODE_) LNZ_LAUNCH_D(NWV_, KHT_, FK_, MODE_, -1)

@@ -814,7 +814,7 @@ int launch_forward16(const lnz_forward_args& a, int mode, hipStream_t s) {
   note_kernel("lanczosnet_forward16_kernel<%d,%d,%s>", mode, a.filter_kind == 0 ? 0 : 2,
               a.n_short > 0 ? "true" : "false");
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  LNZ_DYNAMIC_LDS(fn, 160 * 1024, "conv_forward16.hip");
   lnz_forward_args args = a;
   void* params[] = {&args};
   (void)hipLaunchKernel(fn, dim3(grid), dim3(512), params, bytes, s);

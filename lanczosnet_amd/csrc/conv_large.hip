@@ -931,8 +931,8 @@ extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t*
   // nn.DataParallel, runner/qm8_runner.py:62): set on the current device at every launch
 #define LNZ_LAUNCH_GEMM1(PP)                                                                        \
   do {                                                                                              \
-    (void)hipFuncSetAttribute((const void*)large_gemm1_kernel<PP>,                                  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+    LNZ_DYNAMIC_LDS(large_gemm1_kernel<PP>, \
+      lds, "conv_large.hip");                \
     hipLaunchKernelGGL(large_gemm1_kernel<PP>, grid, dim3(256), lds, (hipStream_t)stream, X, ldx,   \
                        din, dinp, Wf, B, N, Nk, C, Zt);                                             \
   } while (0)
@@ -999,8 +999,7 @@ extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint
   // (the dynamic-LDS limit is a per-device attribute: set on the current device at every launch)
 #define LNZ_LAUNCH_CONV(PP, WW)                                                                     \
   do {                                                                                              \
-    (void)hipFuncSetAttribute((const void*)large_conv_kernel<PP, WW>,                               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+    LNZ_DYNAMIC_LDS((large_conv_kernel<PP, WW>), lds, "conv_large.hip");                            \
     hipLaunchKernelGGL((large_conv_kernel<PP, WW>), dim3(grid), dim3(64 * WW), lds,                 \
                        (hipStream_t)stream, Lb, Vb, Zt, Tt, bias, B, N, Nk, C, tiles, relu, Xout);  \
   } while (0)

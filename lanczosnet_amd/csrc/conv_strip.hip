@@ -1546,7 +1546,7 @@ int launch_strip_messages(const lnz_forward_args& a, hipStream_t s) {
                         (const void*)lanczosnet_strip_messages_kernel<2, false>,
                         (const void*)lanczosnet_strip_messages_kernel<2, true>};
   const void* fn = fns[(a.filter_kind == 0 ? 0 : 2) + (a.n_short > 0 ? 1 : 0)];
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  LNZ_DYNAMIC_LDS(fn, 160 * 1024, "conv_strip.hip");
   lnz_forward_args args = a;
   void* params[] = {&args};
   (void)hipLaunchKernel(fn, dim3(a.strip_cap), dim3(512), params, bytes, s);
@@ -1556,8 +1556,7 @@ int launch_strip_messages(const lnz_forward_args& a, hipStream_t s) {
 int launch_strip_gain_grad(const lnz_forward_args& a, hipStream_t s) {
   const size_t bytes = (size_t)strip_lds_floats(LNZ_STRIP_SUB, a.n_long) * sizeof(float);
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
-  (void)hipFuncSetAttribute((const void*)lanczosnet_strip_gain_grad_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  LNZ_DYNAMIC_LDS(lanczosnet_strip_gain_grad_kernel, 160 * 1024, "conv_strip.hip");
   hipLaunchKernelGGL(lanczosnet_strip_gain_grad_kernel, dim3(a.strip_cap), dim3(512), bytes, s, a);
   return check_launch("lnz_lanczosnet_gain_grad (strips)");
 }
@@ -1575,7 +1574,7 @@ int launch_strip_forward(const lnz_forward_args& a, int mode, hipStream_t s) {
   note_kernel("lanczosnet_strip_kernel<%d,%d,%s,%s>", mode, a.filter_kind == 0 ? 0 : 2,
               a.n_short > 0 && a.gemm_mode != 1 ? "true" : "false", a.gemm_mode == 1 ? "true" : "false");
   // per launch: the attribute is per device, and a process may drive several (DataParallel)
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  LNZ_DYNAMIC_LDS(fn, 160 * 1024, "conv_strip.hip");
   lnz_forward_args args = a;
   void* params[] = {&args};
   (void)hipLaunchKernel(fn, dim3(a.strip_cap), dim3(512), params, bytes, s);

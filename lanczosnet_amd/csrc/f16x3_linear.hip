@@ -393,8 +393,8 @@ extern "C" int lnz_f16x3_linear(const uint16_t* x_hi, const uint16_t* x_lo, int 
 #define LNZ_F16X3_LAUNCH(SO_, WN_, PIPE_, OH_, OL_, OF_)                                             \
   do {                                                                                               \
     auto kfn = f16x3_linear_kernel<SO_, WN_, PIPE_>;                                                 \
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                              (int)kLds);                                                            \
+    LNZ_DYNAMIC_LDS(kfn, \
+      kLds, "f16x3_linear.hip");                                                            \
     hipLaunchKernelGGL(kfn, g2, dim3(128 * WN_), kLds, s, x_hi, x_lo, ldx, w_hi, w_lo, ldw, bias,    \
                        alpha, relu, M, N, K, tiles_n, bh, OH_, OL_, OF_, ldo, partials);             \
   } while (0)

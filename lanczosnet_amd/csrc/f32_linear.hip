@@ -397,8 +397,14 @@ __global__ __launch_bounds__(128 * WN) void f32_linear_kernel(
     };
     if (!whole && owner) {
       if (tid == 0) {
-        while (__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gB - gA)
+        // bounded: the producers are earlier workgroups of this launch (every workgroup is resident:
+        // grid <= compute units), so the count arrives within microseconds — a workspace that is
+        // not zero on entry (or a lost producer) ends in a trap, a failed launch, not in a hang
+        int spins = 0;
+        while (__hip_atomic_load(flags + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gB - gA) {
           __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 22)) __builtin_trap();   // 4 M x 512 clocks: about a second
+        }
         flags[tile] = 0;   // ready for the next launch (nobody else touches it before then)
       }
       __syncthreads();
@@ -553,7 +559,7 @@ extern "C" int lnz_f32_linear(const float* x, int ldx, const float* w, int ldw, 
   hipStream_t s = (hipStream_t)stream;
   int* flags = sk_per ? reinterpret_cast<int*>(partials + (int64_t)grid * BM * BN) : nullptr;
   auto kfn = f32_linear_kernel<LNZ_F32LIN_WN, LNZ_F32LIN_MI, (LNZ_F32LIN_WN == 4 ? LNZ_F32LIN_PP : 0)>;
-  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+  LNZ_DYNAMIC_LDS(kfn, kLds, "f32_linear.hip");
   hipLaunchKernelGGL(kfn, dim3(grid), dim3(128 * LNZ_F32LIN_WN), kLds, s, x, ldx, w, ldw, bias,
                      relu, M, N, K, tiles_n, bh, out, ldo, sk_per ? partials : nullptr, flags, sk_per);
   return lnz::check_launch("lnz_f32_linear");

@@ -1569,8 +1569,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
                   (long long)workspace_bytes, (long long)need);
     }
     auto kfn = lanczos_ritz_wg_kernel<true>;
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    LNZ_DYNAMIC_LDS(kfn, lds, "lanczos_ritz_wg.hip");
     hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N,
                        K, D, V, info, (double*)workspace, (flags >> 1) & 15, (int)a_bytes);
     const int rc = lnz::check_launch("lnz_lanczos_ritz");
@@ -1578,7 +1577,7 @@ int lnz_launch_ritz_wg(const float* A, int64_t stride_b, int64_t stride_r, int64
     return rc;
   }
   auto kfn = lanczos_ritz_wg_kernel<false>;
-  (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  LNZ_DYNAMIC_LDS(kfn, lds, "lanczos_ritz_wg.hip");
   hipLaunchKernelGGL(kfn, dim3(B), dim3(kNT), lds, s, A, stride_b, stride_r, stride_c, n_nodes, N, K,
                      D, V, info, (double*)nullptr, (flags >> 1) & 15, (int)a_bytes);
   return lnz::check_launch("lnz_lanczos_ritz");

@@ -321,8 +321,7 @@ extern "C" int lnz_spectral_mlp_grad(const float* D, int B, int K, const int32_t
   a.BK = B * K, a.S = S, a.parts = parts, a.T = lnz_spectral_mlp_grad_floats(S);
   for (int s = 0; s < lnz_gains::SMAX; ++s) a.dist.v[s] = s < S ? dist_host[s] : 0;
   // per launch: the attribute is per device, and a process may drive several
-  (void)hipFuncSetAttribute((const void*)spectral_mlp_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kGradLds);
+  LNZ_DYNAMIC_LDS(spectral_mlp_grad_kernel, kGradLds, "spectral_gains_grad.hip");
   hipLaunchKernelGGL(spectral_mlp_grad_kernel, dim3(parts, num_layer), dim3(512), kGradLds,
                      (hipStream_t)stream, a);
   return lnz::check_launch("lnz_spectral_mlp_grad");

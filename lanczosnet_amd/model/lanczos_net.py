@@ -1038,14 +1038,20 @@ class _LanczosNetFusedFunction(torch.autograd.Function):
             rows_max = B * K
             if live_rows is not None and not ctx.static_rows:
                 rows_max = min(int(ctx.rtot[0]), B * K)   # (sum of node extents >= live eigen rows)
-            gl = ops.spectral_mlp_grad(D.float(), m.long_diffusion_dist, layers, dG,
-                                       rows=(live_rows, n_live) if live_rows is not None else None,
-                                       rows_max=rows_max)
-            for li, i in enumerate(lin_idx):
+            try:
+                gl = ops.spectral_mlp_grad(D.float(), m.long_diffusion_dist, layers, dG,
+                                           rows=(live_rows, n_live) if live_rows is not None else None,
+                                           rows_max=rows_max)
+            except ops.NotSupported:
+                # (a part without 160 KiB of LDS per workgroup: lnz::set_dynamic_lds says so) —
+                # the library-GEMM branch below serves it from now on
+                gl = None
+                m.mlp_grad_impl = 'torch'
+            for li, i in enumerate(lin_idx if gl is not None else ()):
                 for t in range(Lnum):
                     grads[id(m.spectral_filter[t][i].weight)] = gl[li][0][t]
                     grads[id(m.spectral_filter[t][i].bias)] = gl[li][1][t]
-        elif S > 0 and m._has_mlp():
+        if S > 0 and m._has_mlp() and id(m.spectral_filter[0][lin_idx[0]].weight) not in grads:
             pows = torch.stack([torch.pow(D.float(), p) for p in m.long_diffusion_dist],
                                dim=2).view(B * K, S)
             if live_rows is not None and not ctx.static_rows:

@@ -78,6 +78,10 @@ def _abi():
   return _RAW_NS
 
 
+NotSupported = _lib.NotSupported
+LnzError = _lib.LnzError
+
+
 def last_kernel():
   """lnz_last_kernel(): the kernel (with template arguments) the calling thread's last fused
   forward / input-gradient launch selected."""
@@ -1398,23 +1402,36 @@ def f32_linear(x, w, bias=None, relu=False, out=None):
   return out
 
 
-_F32_LINEAR_WS = {}
+import collections
+
+_F32_LINEAR_WS = collections.OrderedDict()   # (device, stream, size) -> zero-initialised buffer
+_F32_LINEAR_WS_PINNED = {}                    # id -> buffer a captured HIP graph holds the address of
+_F32_LINEAR_WS_ENTRIES = 32                   # entries kept; the least recently used goes
 
 
 def _f32_linear_workspace(M, N, K, device):
   """Stream-K workspace of lnz_f32_linear (None for shapes that run one workgroup per tile): the
-  partial tiles + the tile counters, which have to be zero on entry and are zero again on return —
-  so ONE zero-initialised buffer per (device, stream, size) serves every call (no fill launch per
-  Linear).  Kernels on one stream run in order; another stream gets its own buffer."""
+  partial tiles + the tile counters.  The counters have to be zero on entry and are zero again on
+  return, the partial tiles are not — so a buffer serves ONE layout only: the key carries the size
+  (a buffer shared between two shapes would hand the second one the first one's partial tiles as
+  counters, and a stream-K workgroup spins on its counter).  One zero-initialised buffer per
+  (device, stream, size), no fill launch per Linear; kernels on one stream run in order, another
+  stream gets its own buffer.  Bounded: the 32 most recently used entries are kept (a few MB each);
+  buffers handed out under HIP-graph capture (train.GraphedTrainStep) are pinned for the life of the
+  process — the graph holds their addresses."""
   need = int(_abi().f32_linear_workspace_floats(M, N, K))
   if need == 0:
     return None
   key = (device.index, torch.cuda.current_stream(device).cuda_stream, need)
   ws = _F32_LINEAR_WS.get(key)
   if ws is None:
-    # never evicted: a captured HIP graph (train.GraphedTrainStep) holds these addresses — partial
-    # tiles and tile counters — for its lifetime; one entry per (device, stream, size), a few MB each
-    ws = _F32_LINEAR_WS[key] = torch.zeros((need,), dtype=torch.float32, device=device)
+    ws = torch.zeros((need,), dtype=torch.float32, device=device)
+  _F32_LINEAR_WS[key] = ws
+  _F32_LINEAR_WS.move_to_end(key)
+  if torch.cuda.is_current_stream_capturing():
+    _F32_LINEAR_WS_PINNED[id(ws)] = ws
+  while len(_F32_LINEAR_WS) > _F32_LINEAR_WS_ENTRIES:
+    _F32_LINEAR_WS.popitem(last=False)
   return ws
 
 

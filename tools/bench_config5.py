@@ -16,6 +16,7 @@ ap.add_argument('--nodes', type=int, default=2048)
 ap.add_argument('--reps', type=int, default=3)
 ap.add_argument('--library', action='store_true', help='also time the hipBLASLt path')
 ap.add_argument('--full-stream', action='store_true', help='Lanczos on the whole A (lnz_lanczos_ritz_large) instead of the upper chunk blocks (lnz_lanczos_ritz_large_sym)')
+ap.add_argument('--dense-stream', action='store_true', help='the dense streams (A re-read every step) instead of the product entry (ops.lanczos_ritz -> lnz_lanczos_ritz_kstep: A read once into a sliced-ELL image)')
 args = ap.parse_args()
 B, N, K = args.batch, args.nodes, 64
 cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
@@ -35,18 +36,22 @@ for b in range(B):
 X = torch.randn((B, N, 10), generator=g, device='cuda')
 mask = torch.ones((B, N), dtype=torch.uint8, device='cuda')
 A0 = L[:, :, :, 0].contiguous()
-ws = torch.empty((ops._abi().lanczos_ritz_large_workspace_bytes(B, N),), dtype=torch.uint8, device='cuda')
+ws = torch.empty((ops._abi().lanczos_ritz_kstep_workspace_bytes(B, N, 3, ops.kstep_row_cap(N)),), dtype=torch.uint8, device='cuda')
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 res = {}
 modes = [('hip_bf16', 1), ('hip_split3', 3), ('hip_f16x2', 2)] + ([('library_fp32', None)] if args.library else [])
 SYM = not args.full_stream
-D, V = ops.lanczos_ritz_large(A0, K, K, workspace=ws, symmetric=SYM)
+if args.dense_stream:
+  ritz = lambda: ops.lanczos_ritz_large(A0, K, K, workspace=ws, symmetric=SYM)
+else:
+  ritz = lambda: ops.lanczos_ritz_kstep(A0, None, K, K, workspace=ws)
+D, V = ritz()
 ref = None
 for name, planes in modes:
   best = None
   for it in range(args.reps + 1):
     ev[0].record()
-    D, V = ops.lanczos_ritz_large(A0, K, K, workspace=ws, symmetric=SYM)
+    D, V = ritz()
     ev[1].record()
     with torch.no_grad():
       if planes is None:
@@ -99,4 +104,5 @@ def stages(classes):
 res['bf16_stages_folded'] = stages((0, 0))
 res['bf16_stages_every_channel'] = stages((0, 1))
 print(json.dumps({'workload': 'LanczosNetGeneral N=%d K=%d batch=%d' % (N, K, B),
-                  'lanczos': 'lnz_lanczos_ritz_large' + ('_sym' if SYM else ''), **res}))
+                  'lanczos': ('lnz_lanczos_ritz_large' + ('_sym' if SYM else '')) if args.dense_stream else
+                             'lnz_lanczos_ritz_kstep (compacted image; the product entry)', **res}))
