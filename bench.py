@@ -1149,7 +1149,7 @@ def main():
     # process, so `traffic` cites the committed counter run of the SAME command and workload
     # (tools/pmc_forward_profile.py -> profiles/), never a number measured in this run
     traffic, traffic_source = None, None
-    for name in (('r05_strip_pmc.json', 'r04_strip_pmc.json') if strip else ('r04_forward16_pmc.json',) if f16 else
+    for name in (('r06_strip_pmc.json', 'r05_strip_pmc.json', 'r04_strip_pmc.json') if strip else ('r04_forward16_pmc.json',) if f16 else
                  ('r03_forward_pmc.json', 'pmc_forward_hbm_bytes.json')):
       prof = os.path.join(ROOT, 'profiles', name)
       if os.path.exists(prof) and B == 1024:
