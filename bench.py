@@ -954,6 +954,8 @@ def main():
   shard_check = None
   if dist and not args.zero_params:
     # every rank verifies ITS shard (seed = rank) on a bounded sample, after the clock has stopped
+    # (N ranks share the host: a few intra-op threads each, not one pool of all cores per rank)
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // world)))
     err_r, n_r = shard_parity(cfg, params, batch, timed_score, args.shard_parity)
     mine = {'rank': rank, 'seed': rank, 'device': '%s:%d' % (torch.cuda.get_device_name(dev), dev.index),
             'parity_rel_err': err_r, 'molecules_checked': n_r}
