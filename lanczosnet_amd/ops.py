@@ -223,7 +223,9 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
     A = Ap
   if n_nodes is not None:
     n_nodes = n_nodes.to(torch.int32).contiguous()
-  assert 0 < K <= M <= min(Np, 64), 'K <= M <= 64 Lanczos steps'
+  if not (0 < K <= M <= min(Np, 64)):
+    raise _lib.NotSupported(_lib.LNZ_ENOTSUP, 'lanczos_ritz_kstep: K=%d <= M=%d <= 64 Lanczos steps (and M <= N=%d) '
+                            'required: the K-step branch serves up to 64 Ritz pairs' % (K, M, N))
   flags = (1 if symmetric else 0) | (2 if compact else 0)
   cap = int(row_cap if row_cap is not None else kstep_row_cap(Np)) if compact else 0
   need = _abi().lanczos_ritz_kstep_workspace_bytes(B, Np, flags, cap)
