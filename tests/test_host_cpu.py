@@ -279,3 +279,12 @@ def test_no_process_wide_mutable_state_in_the_kernels_sources():
   tl = [l for f in os.listdir(csrc) if f.endswith(('.hip', '.hpp', '.cpp'))
         for l in open(os.path.join(csrc, f)) if 'thread_local' in l.split('//')[0]]
   assert len(tl) == 2 and 'g_err' in tl[0] + tl[1] and 'g_kernel' in tl[0] + tl[1], tl
+
+
+def test_package_alias_resolves_to_the_same_modules():
+  """`lanczosnetwork_amd` (the name of the build brief) is an alias of `lanczosnet_amd`, not a copy."""
+  import lanczosnetwork_amd.model as m1
+  import lanczosnet_amd.model as m2
+  import lanczosnetwork_amd.ops as o1
+  import lanczosnet_amd.ops as o2
+  assert m1 is m2 and o1 is o2 and m1.LanczosNet is m2.LanczosNet
