@@ -357,7 +357,8 @@ struct EllImage {
 
 // One wave per slab: rows 64 g .. 64 g + 63, each one fully coalesced 8 KiB read (lane l holds
 // columns 256 s + 4 l .. + 3 of chunk s, like the full-stream SpMV), the next row in flight while
-// the ballots of this one place its nonzeros.
+// the ballots of this one place its nonzeros.  1.02 ms for B = 256, N = 2048 (4.2 TB/s); with the
+// placement compiled out the same stream takes 0.87 ms — the ballots are not what it waits for.
 __global__ __launch_bounds__(TPB) void ell_compact_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int N, int cap, float* __restrict__ vals,
     uint16_t* __restrict__ cols, int32_t* __restrict__ widths, int32_t* __restrict__ over) {
@@ -863,25 +864,49 @@ __global__ __launch_bounds__(TPB) void lanczos_ritz_large_kernel(
 
   // ---- D [K], V [N, K] = Q S -------------------------------------------------------------------
   for (int k = tid; k < K; k += TPB) D[(int64_t)b * K + k] = k < kk ? (float)sm.dd[sm.perm[k]] : 0.0f;
+  // V = Q S on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): wave w forms the 16-row tiles w, w + 8,
+  // ... of V for all (<= 64) Ritz vectors — A = 16 basis entries of 4 Krylov vectors straight from
+  // the workspace (the basis is read ONCE, 128-byte runs), B = the selected, signed Ritz coefficients
+  // St[i][k] staged in the slot region (dead by now; pitch 80: the four k rows of a fragment fall on
+  // disjoint banks).  The r05 form read one LDS coefficient per FMA: 67 MB of LDS reads per graph,
+  // 0.31 ms of the compacted path's 4.5 ms.
+  constexpr int SP = 80;
+  double* St = &sm.cslot[0][0];   // [MMAX][SP]
+  for (int idx = tid; idx < MMAX * MMAX; idx += TPB) {
+    const int i = idx / MMAX, k = idx - i * MMAX;
+    St[i * SP + k] = (k < kk && i < n) ? (double)sm.sgn[k] * sm.Zt[sm.perm[k] * ZLD + i] : 0.0;
+  }
+  __syncthreads();
+  typedef double d4v __attribute__((ext_vector_type(4)));
   float* Vb = V + (int64_t)b * N * K;
-  for (int r = tid; r < N; r += TPB) {
-    double qcol[MMAX];
+  const int j16 = lane & 15, k4 = lane >> 4;
+  const int ntile = (N + 15) >> 4, nblk = (K + 15) >> 4;
+  for (int t = wave; t < ntile; t += NWAVE) {
+    const int row = 16 * t + j16;
+    double a[MMAX / 4];
 #pragma unroll
-    for (int i = 0; i < MMAX; ++i) qcol[i] = i < n ? Qg[(int64_t)i * N + r] : 0.0;
-    for (int k = 0; k < K; ++k) {
-      float out = 0.0f;
-      if (k < kk) {
-        const double* s = &sm.Zt[sm.perm[k] * ZLD];
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < MMAX; i += 2) {
-          a0 = fma(qcol[i], s[i], a0);
-          a1 = fma(qcol[i + 1], s[i + 1], a1);
-        }
-        out = sm.sgn[k] * (float)(a0 + a1);
-      }
-      Vb[(int64_t)r * K + k] = out;
+    for (int s4 = 0; s4 < MMAX / 4; ++s4) {
+      const int i = 4 * s4 + k4;
+      a[s4] = (i < n && row < N) ? Qg[(int64_t)i * N + row] : 0.0;
     }
+    d4v acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < MMAX / 4; ++s4) {
+      const double* sp = &St[(4 * s4 + k4) * SP + j16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nblk) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s4], sp[16 * c], acc[c], 0, 0, 0);
+    }
+    // C/D of the f64 form: register g holds row k4 + 4 g, column j16
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * t + k4 + 4 * g, k = 16 * c + j16;
+        if (r < N && k < K) Vb[(int64_t)r * K + k] = (float)acc[c][g];
+      }
   }
   LNZ_PROBE(9);
   if (info && tid == 0) info[b] = steps;
