@@ -193,23 +193,35 @@ __device__ inline void tql2_wave(LargeSmem& sm, const int n, const int lane) {
         double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
         const double el1 = lane_f64(e, l + 1);
         double carry = sm.Zt[m * ZLD + lane];
-        double znext = sm.Zt[(m - 1) * ZLD + lane];  // (m > l >= 0)
+        double z0 = sm.Zt[(m - 1) * ZLD + lane];  // (m > l >= 0)
+        double ei = lane_f64(e, m - 1), di = lane_f64(d, m - 1);
         for (int i = m - 1; i >= l; --i) {
-          const double z0 = znext;
-          if (i > l) znext = sm.Zt[(i - 1) * ZLD + lane];  // the next rotation's row, ahead of time
+          // the next rotation's inputs ahead of time: none of them is written by this rotation
+          const int ip = i > l ? i - 1 : l;
+          const double znext = sm.Zt[ip * ZLD + lane];
+          const double ei_n = lane_f64(e, ip), di_n = lane_f64(d, ip);
           c3 = c2;
           c2 = c;
           s2 = s;
-          const double ei = lane_f64(e, i), di = lane_f64(d, i);
           g = c * ei;
           const double hp = c * p;
           const double tt = fma(p, p, ei * ei);
-          const double rinv = rsqrt(tt);
-          const double rad = tt * rinv;
+          const double num = fma(p, di, -(ei * g));  // (p d_i - e_i g): off the rsqrt chain
+          // 1 / sqrt(tt): hardware seed (~2^-26) + two Newton steps (tt is a normal double here:
+          // |e_i| > eps * tst1 for l <= i < m) — 7 dependent instructions on the rotation-to-rotation
+          // chain instead of the library rsqrt's scaling and special cases
+          double y = __builtin_amdgcn_rsq(tt);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const double hy = 0.5 * y;
+            const double er = fma(-(tt * y), hy, 0.5);
+            y = fma(y, er, y);
+          }
+          const double rad = tt * y;
           const double e_next = s * rad;
-          s = ei * rinv;
-          c = p * rinv;
-          p = c * di - s * g;
+          s = ei * y;
+          c = p * y;
+          p = y * num;  // = c d_i - s g
           const double d_next = hp + s * (c * g + s * di);
           if (lane == i + 1) {
             e = e_next;
@@ -217,6 +229,9 @@ __device__ inline void tql2_wave(LargeSmem& sm, const int n, const int lane) {
           }
           sm.Zt[(i + 1) * ZLD + lane] = s * z0 + c * carry;
           carry = c * z0 - s * carry;
+          z0 = znext;
+          ei = ei_n;
+          di = di_n;
         }
         sm.Zt[l * ZLD + lane] = carry;
         p = -s * s2 * c3 * el1 * lane_f64(e, l) / dl1;
