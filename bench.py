@@ -880,6 +880,8 @@ def main():
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'],
                            rows=rows, zero_fill=not ops.pairing_supported(plan),
                            split_pack=Lp if plan.get('gemm_mode', 0) == 1 else None)
+    if plan.get('gemm_mode', 0) == 1:
+      G, Lp = G   # (split-precision mode: the pack's float16 form is written under the gains launch)
     if events and all_stages:
       events[2].record()
     if events:

@@ -347,6 +347,16 @@ int lnz_spectral_gains_rows_split(const float* D, int B, int K, const int32_t* d
                                   const int32_t* n_rows, float* G, float* Lp_split, int64_t lp_floats,
                                   lnz_stream_t stream);
 int lnz_split_laplacian_pack(float* Lp, int64_t n_floats, lnz_stream_t stream);
+/* The same two conversions OUT OF PLACE, into `dst` (lp_floats * 4 bytes; the same bytes are moved):
+ * the fp32 pack stays what it was, and a host that types `dst` as 2-byte elements carries the format
+ * in the data's type instead of in a flag beside it (what lanczosnet_amd/ops.py does since r06).
+ * dst == Lp is the in-place form above. */
+int lnz_spectral_gains_rows_split_to(const float* D, int B, int K, const int32_t* dist_host, int S,
+                                     int num_layer, int kind, const float* mlp_pack,
+                                     const int32_t* rows, const int32_t* n_rows, float* G,
+                                     const float* Lp_split, uint16_t* Lp_dst, int64_t lp_floats,
+                                     lnz_stream_t stream);
+int lnz_split_laplacian_pack_to(const float* Lp, int64_t n_floats, uint16_t* dst, lnz_stream_t stream);
 
 /* ---- R7 (second half) + R9 + R10: fused LanczosNet forward ------------------------------
  * One workgroup per molecule runs the whole network on chip: embedding gather, then per conv

@@ -100,7 +100,9 @@ SIGNATURES = {
     'lnz_pack_spectral_mlp_layers': (C.c_int, [_P, _I, _I, _P, _P]),
     'lnz_spectral_mlp_grad_parts': (C.c_int, [_I, _I, _I]),
     'lnz_spectral_gains_rows_split': (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P]),
+    'lnz_spectral_gains_rows_split_to': (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
     'lnz_split_laplacian_pack': (C.c_int, [_P, _L, _P]),
+    'lnz_split_laplacian_pack_to': (C.c_int, [_P, _L, _P, _P]),
     'lnz_spectral_mlp_grad_floats': (C.c_int, [_I]),
     'lnz_embedding_grad': (C.c_int, [_P, _I, _I, _P, _L, _L, _I, _I, _I, _P, _P]),
     'lnz_spectral_mlp_grad': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

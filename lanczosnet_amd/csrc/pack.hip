@@ -112,18 +112,25 @@ extern "C" int lnz_pack_rows_k8_split(const float* W, int rows, int cols, int64_
   return lnz::check_launch("lnz_pack_rows_k8_split");
 }
 
-__global__ __launch_bounds__(256) void split_laplacian_pack_kernel(float4* __restrict__ p, int64_t n4) {
-  lnz::split_pack_chunk<256>(p, n4, blockIdx.x, threadIdx.x);
+__global__ __launch_bounds__(256) void split_laplacian_pack_kernel(const float4* p, float4* dst, int64_t n4) {
+  lnz::split_pack_chunk<256>(p, dst, n4, blockIdx.x, threadIdx.x);
 }
 
-extern "C" int lnz_split_laplacian_pack(float* Lp, int64_t n_floats, lnz_stream_t stream) {
-  LNZ_REQUIRE(Lp && n_floats > 0 && n_floats % 4 == 0, LNZ_EINVAL,
+extern "C" int lnz_split_laplacian_pack_to(const float* Lp, int64_t n_floats, uint16_t* dst,
+                                           lnz_stream_t stream) {
+  LNZ_REQUIRE(Lp && dst && n_floats > 0 && n_floats % 4 == 0, LNZ_EINVAL,
               "lnz_split_laplacian_pack: bad arguments (n_floats=%lld)", (long long)n_floats);
+  LNZ_REQUIRE(((reinterpret_cast<uintptr_t>(Lp) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, LNZ_EINVAL,
+              "lnz_split_laplacian_pack: 16-byte aligned buffers required");
   const int64_t n4 = n_floats / 4, blocks = (n4 + lnz::kSplitChunk - 1) / lnz::kSplitChunk;
   LNZ_REQUIRE(blocks < (1ll << 31), LNZ_ENOTSUP, "lnz_split_laplacian_pack: pack too large");
   hipLaunchKernelGGL(split_laplacian_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (float4*)Lp, n4);
+                     (const float4*)Lp, (float4*)dst, n4);
   return lnz::check_launch("lnz_split_laplacian_pack");
+}
+
+extern "C" int lnz_split_laplacian_pack(float* Lp, int64_t n_floats, lnz_stream_t stream) {
+  return lnz_split_laplacian_pack_to(Lp, n_floats, reinterpret_cast<uint16_t*>(Lp), stream);
 }
 
 // bp[rt][lane][r] = bias[32 rt + cd_row(r, lane >> 5)]

@@ -30,17 +30,18 @@ __global__ void pack_w0_kernel(const float* __restrict__ W0, int S, float* __res
 
 // A byte mover that rides along (lnz_spectral_gains_rows_split): the workgroups behind the MLP's
 // (blockIdx.x >= main_x) turn the batch's packed Laplacian into the split-precision strip kernel's
-// form in place, one 16 KiB chunk each — the gains launch sits between the pack and the forward
+// form (into `dst`: another buffer, or the pack itself), one 16 KiB chunk each — the gains launch sits between the pack and the forward
 // anyway, is bound by the matrix pipe and touches no memory to speak of.
 struct SplitRide {
-  float4* pack;     // NULL: nothing rides along
+  const float4* pack;  // NULL: nothing rides along
+  float4* dst;
   int64_t n4;       // float4 words
   int main_x;       // gridDim.x of the MLP part
 };
 __device__ __forceinline__ bool ride_along(const SplitRide& r, const int lane) {
   if (!r.pack || (int)blockIdx.x < r.main_x) return false;
   const int64_t chunk = (int64_t)(blockIdx.x - r.main_x) * gridDim.y + blockIdx.y;
-  if (chunk * lnz::kSplitChunk < r.n4) lnz::split_pack_chunk<64>(r.pack, r.n4, chunk, lane);
+  if (chunk * lnz::kSplitChunk < r.n4) lnz::split_pack_chunk<64>(r.pack, r.dst, r.n4, chunk, lane);
   return true;
 }
 
@@ -190,10 +191,12 @@ extern "C" int lnz_pack_spectral_mlp_layers(const float* const* ptrs, int num_la
   return lnz::check_launch("lnz_pack_spectral_mlp_layers");
 }
 
-extern "C" int lnz_spectral_gains_rows_split(const float* D, int B, int K, const int32_t* dist_host,
-                                             int S, int num_layer, int kind, const float* mlp_pack,
-                                             const int32_t* rows, const int32_t* n_rows, float* G,
-                                             float* Lp_split, int64_t lp_floats, lnz_stream_t stream) {
+extern "C" int lnz_spectral_gains_rows_split_to(const float* D, int B, int K, const int32_t* dist_host,
+                                                int S, int num_layer, int kind, const float* mlp_pack,
+                                                const int32_t* rows, const int32_t* n_rows, float* G,
+                                                const float* Lp_split, uint16_t* Lp_dst, int64_t lp_floats,
+                                                lnz_stream_t stream) {
+  LNZ_REQUIRE(!Lp_split == !Lp_dst, LNZ_EINVAL, "lnz_spectral_gains_rows_split_to: pack and destination come together");
   LNZ_REQUIRE(!rows || n_rows, LNZ_EINVAL, "lnz_spectral_gains_rows: rows without n_rows");
   LNZ_REQUIRE(!Lp_split || (kind == 0 && lp_floats > 0 && lp_floats % 4 == 0), LNZ_EINVAL,
               "lnz_spectral_gains_rows_split: the pack rides along with the MLP launch only (kind 0), "
@@ -214,7 +217,8 @@ extern "C" int lnz_spectral_gains_rows_split(const float* D, int B, int K, const
       return e ? atoi(e) : 0;
     }();
     const bool two = forced ? forced == 2 : (int64_t)((R + 31) / 32) * num_layer >= 2048;
-    SplitRide ride = {reinterpret_cast<float4*>(Lp_split), lp_floats / 4, (R + (two ? 63 : 31)) / (two ? 64 : 32)};
+    SplitRide ride = {reinterpret_cast<const float4*>(Lp_split), reinterpret_cast<float4*>(Lp_dst), lp_floats / 4,
+                      (R + (two ? 63 : 31)) / (two ? 64 : 32)};
     const int64_t chunks = Lp_split ? (ride.n4 + lnz::kSplitChunk - 1) / lnz::kSplitChunk : 0;
     const int64_t extra_x = (chunks + num_layer - 1) / num_layer;
     LNZ_REQUIRE(ride.main_x + extra_x < (1ll << 31), LNZ_ENOTSUP, "lnz_spectral_gains_rows_split: pack too large");
@@ -234,12 +238,20 @@ extern "C" int lnz_spectral_gains_rows_split(const float* D, int B, int K, const
   return lnz::check_launch("lnz_spectral_gains");
 }
 
+extern "C" int lnz_spectral_gains_rows_split(const float* D, int B, int K, const int32_t* dist_host,
+                                             int S, int num_layer, int kind, const float* mlp_pack,
+                                             const int32_t* rows, const int32_t* n_rows, float* G,
+                                             float* Lp_split, int64_t lp_floats, lnz_stream_t stream) {
+  return lnz_spectral_gains_rows_split_to(D, B, K, dist_host, S, num_layer, kind, mlp_pack, rows, n_rows, G,
+                                          Lp_split, reinterpret_cast<uint16_t*>(Lp_split), lp_floats, stream);
+}
+
 extern "C" int lnz_spectral_gains_rows(const float* D, int B, int K, const int32_t* dist_host,
                                        int S, int num_layer, int kind, const float* mlp_pack,
                                        const int32_t* rows, const int32_t* n_rows, float* G,
                                        lnz_stream_t stream) {
-  return lnz_spectral_gains_rows_split(D, B, K, dist_host, S, num_layer, kind, mlp_pack, rows, n_rows, G,
-                                       nullptr, 0, stream);
+  return lnz_spectral_gains_rows_split_to(D, B, K, dist_host, S, num_layer, kind, mlp_pack, rows, n_rows, G,
+                                          nullptr, nullptr, 0, stream);
 }
 
 extern "C" int lnz_spectral_gains(const float* D, int B, int K, const int32_t* dist_host, int S,

@@ -1,7 +1,10 @@
 // The packed Laplacian in the form the split-precision strip kernel reads (lnz_forward_args.gemm_mode
 // 1): a fragment float4 — four consecutive columns of one row — becomes 4 fp16 hi pieces | 4 lo pieces
-// (x = hi + lo to 22 bits) in the same 16 bytes, IN PLACE.  Shared by the standalone launch
-// (pack.hip) and the gains launch that carries the conversion along (spectral_gains.hip).
+// (x = hi + lo to 22 bits) in 16 bytes at the same position of the destination — another buffer (the
+// product path: the result is a float16-typed tensor, its format travels with its type) or the source
+// itself (in place: a thread reads all of its fragments before it writes any).  Shared by the
+// standalone launch (pack.hip) and the gains launch that carries the conversion along
+// (spectral_gains.hip).
 #pragma once
 #include "common.hpp"
 
@@ -10,7 +13,7 @@ namespace lnz {
 constexpr int kSplitChunk = 1024;  // float4 per block
 
 template <int NT>
-__device__ __forceinline__ void split_pack_chunk(float4* __restrict__ p, const int64_t n4,
+__device__ __forceinline__ void split_pack_chunk(const float4* p, float4* dst, const int64_t n4,
                                                  const int64_t chunk, const int tid) {
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   constexpr int PER = kSplitChunk / NT;
@@ -30,7 +33,7 @@ __device__ __forceinline__ void split_pack_chunk(float4* __restrict__ p, const i
       o[e] = h;
       o[4 + e] = (_Float16)(x[e] - (float)h);
     }
-    if (base + u * NT < n4) p[base + u * NT] = __builtin_bit_cast(float4, o);
+    if (base + u * NT < n4) dst[base + u * NT] = __builtin_bit_cast(float4, o);
   }
 }
 

@@ -105,7 +105,8 @@ void fused_launch(int64_t which, const c10::List<c10::optional<Tensor>>& in, at:
   a.node_feat_f = (const float*)raw_ptr(opt(kNodeFeatF), at::kFloat, "node_feat_f");
   a.embedding = (const float*)raw_ptr(opt(kEmbedding), at::kFloat, "embedding");
   a.mask = (const uint8_t*)raw_ptr(opt(kMask), at::kByte, "mask");
-  a.Lp = (const float*)raw_ptr(opt(kLp), at::kFloat, "Lp");
+  a.Lp = (const float*)(dims[dGemmMode] == 1 ? raw_2byte(opt(kLp), "Lp (float16 split pack, gemm_mode 1)")
+                                              : raw_ptr(opt(kLp), at::kFloat, "Lp"));
   a.V = (const float*)raw_ptr(v, at::kFloat, "V");
   a.G = (const float*)raw_ptr(opt(kG), at::kFloat, "G");
   a.Wp = (const float*)raw_ptr(opt(kWp), at::kFloat, "Wp");
@@ -272,12 +273,18 @@ std::tuple<Tensor, Tensor, Tensor> plan_ritz(const Tensor& L, const Tensor& mask
 Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
                       const c10::optional<Tensor>& mlp_pack, const c10::optional<Tensor>& rows,
                       const c10::optional<Tensor>& n_rows, bool zero_fill,
-                      const c10::optional<Tensor>& split_pack) {
+                      const c10::optional<Tensor>& split_pack, const c10::optional<Tensor>& split_dst) {
   need(D, at::kFloat, "D");
-  // split_pack: the batch's packed Laplacian, converted IN PLACE to the split-precision forward's form
-  // by workgroups that ride along with the MLP launch (lnz_spectral_gains_rows_split)
+  // split_pack: the batch's packed Laplacian (fp32), converted INTO split_dst (2-byte elements, the
+  // same number of bytes) — the split-precision forward's form — by workgroups that ride along with
+  // the MLP launch (lnz_spectral_gains_rows_split_to)
+  TORCH_CHECK(split_pack.has_value() == split_dst.has_value(),
+              "lanczosnet::spectral_gains: split_pack and split_dst come together");
   if (split_pack.has_value()) {
     need(*split_pack, at::kFloat, "split_pack");
+    TORCH_CHECK(split_dst->is_cuda() && split_dst->is_contiguous() && split_dst->element_size() == 2 &&
+                    split_dst->numel() == 2 * split_pack->numel(),
+                "lanczosnet::spectral_gains: split_dst must be a contiguous 2-byte tensor of twice the pack's elements");
     TORCH_CHECK(mlp_pack.has_value() && split_pack->numel() % 4 == 0,
                 "lanczosnet::spectral_gains: split_pack rides along with the MLP launch only");
   }
@@ -295,12 +302,13 @@ Tensor spectral_gains(const Tensor& D, at::IntArrayRef dist, int64_t num_layer,
   Tensor buf = (use_rows && zero_fill) ? at::zeros({n + 16}, D.options()) : at::empty({n + 16}, D.options());
   Tensor G = buf.narrow(0, 0, n).view({num_layer, B, S, K});
   std::vector<int32_t> d32(dist.begin(), dist.end());
-  check(lnz_spectral_gains_rows_split(D.data_ptr<float>(), B, K, d32.data(), S, (int)num_layer,
-                                      mlp_pack.has_value() ? 0 : 1, (const float*)optr(mlp_pack),
-                                      use_rows ? rows->data_ptr<int32_t>() : nullptr,
-                                      use_rows ? n_rows->data_ptr<int32_t>() : nullptr, G.data_ptr<float>(),
-                                      split_pack.has_value() ? split_pack->data_ptr<float>() : nullptr,
-                                      split_pack.has_value() ? split_pack->numel() : 0, cur_stream()),
+  check(lnz_spectral_gains_rows_split_to(D.data_ptr<float>(), B, K, d32.data(), S, (int)num_layer,
+                                         mlp_pack.has_value() ? 0 : 1, (const float*)optr(mlp_pack),
+                                         use_rows ? rows->data_ptr<int32_t>() : nullptr,
+                                         use_rows ? n_rows->data_ptr<int32_t>() : nullptr, G.data_ptr<float>(),
+                                         split_pack.has_value() ? split_pack->data_ptr<float>() : nullptr,
+                                         split_dst.has_value() ? (uint16_t*)split_dst->data_ptr() : nullptr,
+                                         split_pack.has_value() ? split_pack->numel() : 0, cur_stream()),
         "spectral_gains");
   return G;
 }
@@ -317,7 +325,14 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
   TORCH_CHECK(dims.size() == 7 || dims.size() == 8,
               "lanczosnet::forward: dims = [num_layer, din0, dhid, dout, n_long, n_edge, filter_kind(, gemm_mode)]");
   TORCH_CHECK(dims.size() == 7 || dims[7] == 0 || dims[7] == 1, "lanczosnet::forward: gemm_mode 0 or 1");
-  need(Lp, at::kFloat, "Lp");
+  // the pack's element type carries its format: fp32 fragments for the exact kernel, fp16 hi | lo
+  // pieces (lnz_split_laplacian_pack_to) for gemm_mode 1
+  if (dims.size() > 7 && dims[7] == 1) {
+    TORCH_CHECK(Lp.is_cuda() && Lp.is_contiguous() && Lp.scalar_type() == at::kHalf,
+                "lanczosnet::forward: gemm_mode 1 reads a float16 (split) Laplacian pack, got ", Lp.scalar_type());
+  } else {
+    need(Lp, at::kFloat, "Lp");
+  }
   need(V, at::kFloat, "V");
   need(mask, at::kByte, "mask");
   need(Wp, at::kFloat, "Wp");
@@ -359,7 +374,7 @@ Tensor forward(const Tensor& node_feat, const c10::optional<Tensor>& embedding, 
   }
   a.mask = mask.data_ptr<uint8_t>();
   a.V = V.data_ptr<float>();
-  a.Lp = Lp.data_ptr<float>();
+  a.Lp = (const float*)Lp.data_ptr();
   if (ident.has_value()) {
     need(*ident, at::kInt, "ident");
     a.ident = (const uint32_t*)ident->data_ptr<int32_t>();
@@ -433,7 +448,7 @@ TORCH_LIBRARY(lanczosnet, m) {
   m.def("plan_ritz(Tensor L, Tensor mask, Tensor n_nodes, int K, int n_cu, bool allow_pairs) -> "
         "(Tensor, Tensor, Tensor)");
   m.def("spectral_gains(Tensor D, int[] dist, int num_layer, Tensor? mlp_pack, Tensor? rows, "
-        "Tensor? n_rows, bool zero_fill, Tensor(a!)? split_pack) -> Tensor");
+        "Tensor? n_rows, bool zero_fill, Tensor? split_pack, Tensor(a!)? split_dst) -> Tensor");
   m.def("forward(Tensor node_feat, Tensor? embedding, Tensor Lp, Tensor? ident, Tensor V, Tensor? G, "
         "Tensor mask, Tensor Wp, Tensor bias, int[] w_off, int[] b_off, Tensor Wp_head, "
         "Tensor bias_head, Tensor? plan, int plan_cap, int[] dims, int[] short_dist, Tensor? strips, "

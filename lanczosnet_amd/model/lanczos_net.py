@@ -318,6 +318,8 @@ class _LanczosNetBase(nn.Module):
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer, plan['mlp_pack'],
                                    rows=rows, zero_fill=not ops.pairing_supported(plan),
                                    split_pack=Lp if plan['gemm_mode'] == 1 else None)
+            if plan['gemm_mode'] == 1:
+                G, Lp = G   # (the gains and the pack's float16 form, written under the same launch)
         return ops.lanczosnet_forward(plan, node_feat, Lp, V, G, mask_u8, tiling=tiles)
 
     @torch.no_grad()

@@ -495,8 +495,8 @@ def pack_laplacian(L):
 
 
 def pack_laplacian_for(plan, L):
-  """The Laplacian pack the fused forward expects for `plan`: fp32 fragments, converted in place to
-  fp16 hi | lo pieces for a split-precision plan (gemm_mode 1)."""
+  """The Laplacian pack the fused forward expects for `plan`: fp32 fragments, or their fp16 hi | lo
+  pieces as a float16 tensor for a split-precision plan (gemm_mode 1)."""
   Lf = L if L.dtype == torch.float32 else L.float()
   Lp = pack_laplacian(Lf)
   return split_laplacian_pack(Lp) if plan.get('gemm_mode', 0) == 1 else Lp
@@ -659,44 +659,55 @@ def spectral_gains(D, dist, num_layer, mlp_pack=None, rows=None, zero_fill=True,
   rows: optional (gain_rows, n_gain_rows) int32 device tensors from plan_batch(): the MLP runs
   only on the eigen slots that carry a Ritz pair, every other entry of G is zero — or left
   uninitialised with zero_fill=False, which is what the exact-fp32 forward kernel needs (it never
-  reads the slots k >= n)).  split_pack: the batch's packed Laplacian of a gemm_mode-1 plan —
-  converted in place to the split-precision forward's form by workgroups that ride along with the
-  MLP launch (split_laplacian_pack() as part of this launch)."""
+  reads the slots k >= n)).  split_pack: the batch's packed Laplacian (fp32) of a gemm_mode-1 plan —
+  the call then returns (G, Lh), Lh the pack in the split-precision forward's form: a NEW float16
+  tensor written by workgroups that ride along with the MLP launch (split_laplacian_pack() as part
+  of this launch; the fp32 pack is left as it was)."""
   _need_cuda(D, mlp_pack, split_pack)
   D = _f32c(D)
   use_rows = rows is not None and mlp_pack is not None
-  ride = None
-  if split_pack is not None and not getattr(split_pack, 'fp16_pieces', False):
-    if mlp_pack is None:
-      split_laplacian_pack(split_pack)
+  ride = dst = None
+  if split_pack is not None:
+    if split_pack.dtype == torch.float16 or mlp_pack is None:
+      dst = split_laplacian_pack(split_pack)   # (already converted, or no MLP launch to ride along with)
     else:
       assert split_pack.dtype == torch.float32 and split_pack.is_contiguous()
       ready = getattr(split_pack, 'ready', None)   # a pack on a second stream
       if ready is not None:
         torch.cuda.current_stream(split_pack.device).wait_event(ready)
-      ride = split_pack
+      ride, dst = split_pack, _split_pack_like(split_pack)
   G = _ext().spectral_gains(D, [int(x) for x in dist], num_layer, mlp_pack,
                             rows[0] if use_rows else None, rows[1] if use_rows else None,
-                            bool(zero_fill), ride)
-  if ride is not None:
-    ride.fp16_pieces = True
-  return G
+                            bool(zero_fill), ride, dst if ride is not None else None)
+  return G if split_pack is None else (G, dst)
+
+
+def _split_pack_like(Lp):
+  """The destination of a pack's split-precision form: float16, the same bytes ([..., 2 x last]); the
+  identity-channel bits of the pack go along."""
+  Lh = torch.empty(tuple(Lp.shape[:-1]) + (2 * Lp.shape[-1],), dtype=torch.float16, device=Lp.device)
+  ident = getattr(Lp, 'ident', None)
+  if ident is not None:
+    Lh.ident = ident
+  return Lh
 
 
 def split_laplacian_pack(Lp):
-  """lnz_split_laplacian_pack: the fp32 Laplacian pack -> the split-precision forward's form (every
-  fragment float4 = 4 fp16 hi pieces | 4 lo pieces), IN PLACE; marks the tensor (`Lp.fp16_pieces`)."""
+  """lnz_split_laplacian_pack_to: the fp32 Laplacian pack -> its split-precision form (every fragment
+  float4 = 4 fp16 hi pieces | 4 lo pieces) as a NEW float16 tensor; the fp32 pack is not touched.  The
+  element type IS the format: the exact kernels take float32 packs only, the gemm_mode-1 forward
+  float16 ones — a clone, view or detach keeps it.  A float16 pack is returned as it is."""
   _need_cuda(Lp)
-  if getattr(Lp, 'fp16_pieces', False):
+  if Lp.dtype == torch.float16:
     return Lp
   assert Lp.dtype == torch.float32 and Lp.is_contiguous()
   ready = getattr(Lp, 'ready', None)
   if ready is not None:
     torch.cuda.current_stream(Lp.device).wait_event(ready)
+  Lh = _split_pack_like(Lp)
   with torch.cuda.device(Lp.device):
-    _abi().split_laplacian_pack(Lp, Lp.numel())
-  Lp.fp16_pieces = True
-  return Lp
+    _abi().split_laplacian_pack_to(Lp, Lp.numel(), Lh)
+  return Lh
 
 
 def spectral_mlp_grad(D, dist, layers, dG, rows=None, rows_max=None):
@@ -880,10 +891,10 @@ def lanczosnet_forward(plan, node_feat, Lp, V, G, mask, return_state=False, tili
   if ready is not None:
     torch.cuda.current_stream(Lp.device).wait_event(ready)
   if plan.get('gemm_mode', 0) == 1:
-    split_laplacian_pack(Lp)   # (no-op when spectral_gains(split_pack=Lp) converted it on the way)
-  elif getattr(Lp, 'fp16_pieces', False):
-    raise RuntimeError('this Laplacian pack was converted for a split-precision plan (gemm_mode 1): '
-                       'pack again for the exact kernel')
+    Lp = split_laplacian_pack(Lp)   # (a float16 pack — spectral_gains(split_pack=...) made it on the way — passes)
+  elif Lp.dtype != torch.float32:
+    raise RuntimeError('this Laplacian pack is the float16 form of a split-precision plan (gemm_mode 1): '
+                       'the exact kernels read the fp32 pack')
   if act_out is None and not return_state:
     return _forward_ext(plan, node_feat, Lp, V, G, mask, tiling, use_ident)
   ops_, dims = _fused_operands(plan, V)

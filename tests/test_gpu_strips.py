@@ -288,7 +288,7 @@ def test_split_precision_strip_forward_meets_the_parity_bar(B, n_cu, nmin, nmax,
     plan = net._plan()
     assert plan['gemm_mode'] == (1 if mode == 'f16x3' else 0)
     Lp = ops.pack_laplacian_for(plan, L)
-    assert Lp.dtype == torch.float32
+    assert Lp.dtype == (torch.float16 if mode == 'f16x3' else torch.float32)   # the type is the format
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'])
     with torch.no_grad():
       s, st = ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles, return_state=True)
@@ -366,9 +366,11 @@ def test_split_precision_needs_the_strip_plan_and_says_so():
 
 
 def test_laplacian_pack_conversion_alone_and_under_the_gains_launch():
-  """lnz_split_laplacian_pack (in place: every fragment float4 -> 4 fp16 hi | 4 lo pieces) against
-  numpy, and the same conversion riding along with the gains launch (lnz_spectral_gains_rows_split):
-  same bytes, the gains untouched; an exact-fp32 plan refuses a converted pack."""
+  """lnz_split_laplacian_pack_to (every fragment float4 -> 4 fp16 hi | 4 lo pieces, into a NEW float16
+  tensor: the element type carries the format) against numpy, and the same conversion riding along
+  with the gains launch (lnz_spectral_gains_rows_split_to): same bytes, the gains and the fp32 pack
+  untouched; a clone / view of the float16 pack is still refused by an exact-fp32 plan, an fp32 pack
+  handed to the split plan is converted on the way; the in-place C entry gives the same bytes."""
   from lanczosnet_amd import ops
   from lanczosnet_amd.synthetic import draw_batch
   cfg = dict(oracle.DEFAULT_QM8_CFG)
@@ -379,21 +381,39 @@ def test_laplacian_pack_conversion_alone_and_under_the_gains_launch():
   L = ops.laplacian_l4(t(b['adjs']), n)
   D, V = ops.lanczos_ritz(L[..., 0], n, 20)
   Lp = ops.pack_laplacian(L)
+  before = Lp.clone()
   raw = Lp.cpu().numpy().reshape(-1, 4)
   hi = raw.astype(np.float16)
   lo = (raw - hi.astype(np.float32)).astype(np.float16)
-  want = np.concatenate([hi, lo], axis=1).reshape(-1).view(np.float32)
-  alone = ops.split_laplacian_pack(Lp.clone())
+  want = np.concatenate([hi, lo], axis=1).reshape(-1)
+  alone = ops.split_laplacian_pack(Lp)
+  assert alone.dtype == torch.float16 and alone.numel() == 2 * Lp.numel() and alone.data_ptr() != Lp.data_ptr()
   assert alone.cpu().numpy().reshape(-1).tobytes() == want.tobytes()
-  assert ops.split_laplacian_pack(alone) is alone      # (marked: not converted twice)
+  assert torch.equal(Lp, before)                         # the fp32 pack is what it was
+  assert ops.split_laplacian_pack(alone) is alone        # a float16 pack is already converted
   plan32 = net._plan()
   G0 = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan32['mlp_pack'])
-  ride = Lp.clone()
-  G1 = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan32['mlp_pack'], split_pack=ride)
-  assert torch.equal(G0, G1)
-  assert ride.cpu().numpy().reshape(-1).tobytes() == want.tobytes() and ride.fp16_pieces
-  with pytest.raises(RuntimeError, match='converted'):
-    ops.lanczosnet_forward(plan32, t(b['node_feat']), ride, V, G0, t(b['node_mask'].astype(np.uint8)))
+  G1, ride = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan32['mlp_pack'], split_pack=Lp)
+  assert torch.equal(G0, G1) and torch.equal(Lp, before)
+  assert ride.dtype == torch.float16 and ride.cpu().numpy().reshape(-1).tobytes() == want.tobytes()
+  assert torch.equal(ride.ident, Lp.ident)
+  nf, mk = t(b['node_feat']), t(b['node_mask'].astype(np.uint8))
+  for converted in (ride, ride.clone(), ride.detach().view(-1).view(ride.shape)):   # the format is in the type
+    with pytest.raises(RuntimeError, match='float16 form'):
+      ops.lanczosnet_forward(plan32, nf, converted, V, G0, mk)
+  net.gemm_mode = 'f16x3'
+  plan16 = net._plan()
+  s_typed = ops.lanczosnet_forward(plan16, nf, ride, V, G0, mk)
+  s_onfly = ops.lanczosnet_forward(plan16, nf, Lp, V, G0, mk)   # an fp32 pack: converted on the way, not in place
+  assert torch.equal(s_typed, s_onfly) and torch.equal(Lp, before)
+  # a clone keeps the format (its type) and loses only the identity-channel bits: every channel then
+  # goes through its fragments — the same scores to rounding
+  s_clone = ops.lanczosnet_forward(plan16, nf, ride.clone(), V, G0, mk)
+  assert float((s_clone - s_typed).abs().max()) <= 1e-5 * float(s_typed.abs().max())
+  # the C ABI's in-place entry (a C host that keeps its own books): the same bytes
+  inplace = Lp.clone()
+  ops._abi().split_laplacian_pack(inplace, inplace.numel())
+  assert inplace.view(torch.float16).cpu().numpy().reshape(-1).tobytes() == want.tobytes()
 
 
 @pytest.mark.parametrize('B,nmin,nmax', [(1024, 8, 26), (37, 1, 32), (5, 3, 9)])

@@ -22,6 +22,8 @@ for mode in ('fp32', 'f16x3'):
     Lp, tiles, rows, D, V = ops.prepare_batch(plan, L, mk, n, K)
     G = ops.spectral_gains(D, cfg['long_diffusion_dist'], cfg['num_layer'], plan['mlp_pack'], rows=rows, zero_fill=False,
                            split_pack=Lp if plan['gemm_mode'] == 1 else None)
+    if plan['gemm_mode'] == 1:
+      G, Lp = G
     return ops.lanczosnet_forward(plan, nf, Lp, V, G, mk, tiling=tiles)
   def timed(f, steps=200):
     for _ in range(20): f()
