@@ -288,3 +288,32 @@ def test_package_alias_resolves_to_the_same_modules():
   import lanczosnetwork_amd.ops as o1
   import lanczosnet_amd.ops as o2
   assert m1 is m2 and o1 is o2 and m1.LanczosNet is m2.LanczosNet
+
+
+def test_round6_host_side_queries_and_argument_checks_without_gpu():
+  """Host-side size queries and argument validation of the r06 entries (no launch happens): the K-step
+  workspace layout, the image capacity rule, the head-backward workspace, and the refusals."""
+  import torch
+  from lanczosnet_amd import _lib, _torch_ext, ops
+  _torch_ext.load()
+  ns = torch.ops.lanczosnet
+  B, N = 256, 2048
+  basis = B * 64 * N * 8
+  assert ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 0, 0) == basis
+  assert ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 1, 0) == basis            # symmetric: same workspace
+  img = ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 3, 64) - basis
+  assert img >= B * (N // 64) * 64 * 64 * 6 and img < B * (N // 64) * 64 * 64 * 6 + B * (N // 64) * 4 + B * 4 + 4 * 256
+  assert ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 3, 256) > ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 3, 64)
+  assert [ops.kstep_row_cap(n) for n in (200, 512, 1024, 2048)] == [64, 64, 128, 256]
+  assert ns.raw_head_backward_workspace_floats(16, 256) == 256 * (17 * 128 + 32 + 128)
+  assert ns.raw_head_backward_workspace_floats(32, 256) == 0                         # head width <= 31
+  lib = _lib.load()
+  null = C.c_void_p(None)
+  # the K-step entry refuses before it launches: missing pointers, a capacity that is not a multiple of 8
+  rc = lib.lnz_lanczos_ritz_kstep(null, 0, 0, null, 1, 256, 8, 8, 2, 12, null, 0, null, null, null, null, null)
+  assert rc == _lib.LNZ_EINVAL
+  assert b'row_cap' in lib.lnz_last_error()
+  assert lib.lnz_head_backward(null, null, null, null, null, null, null, null, 4, 20, 16, 128, 256,
+                               null, null, null, null, null, null, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_node_extents(null, 4, 20, null, null, null, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_last_kernel() is not None
