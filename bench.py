@@ -971,6 +971,24 @@ def main():
   gather_ok = bool(torch.equal(gather.result(gather.issued - 1)[rank * B:(rank + 1) * B],
                                timed_score)) if gather else None
 
+  # secondary measurement (N = 1 only, never `value`): the same sequential step once the device has
+  # been under this load for a while.  The first ~25 steps after start-up run at ramping matrix clocks
+  # (forward launch 0.605 against 0.588 ms): a short run (the driver's --steps 20 --warmup 5) reads
+  # about 3 % slower than a long one for that reason alone, on the same box.
+  sustained = None
+  if world == 1 and not args.zero_params and not args.pipeline:
+    with torch.no_grad():
+      for _ in range(60):
+        step()
+      torch.cuda.synchronize()
+      t1 = time.perf_counter()
+      for _ in range(50):
+        step()
+      torch.cuda.synchronize()
+      sustained = {'ms_per_step': round(1e3 * (time.perf_counter() - t1) / 50, 4),
+                   'note': '50 steps timed behind %d + 60 untimed ones (the timed region of `value` sits behind %d)'
+                           % (args.warmup + args.steps, args.warmup)}
+
   # secondary measurement (N = 1 only, never `value`): software pipeline over the stream of batches
   pipe = None
   if world == 1 and args.gemm == 'fp32' and not args.zero_params and not args.pipeline:
@@ -1243,6 +1261,8 @@ def main():
       out['parity_rel_err'] = max(s_['parity_rel_err'] for s_ in shard_check)
     if split is not None:
       out['config']['split_precision_mode'] = split
+    if sustained is not None:
+      out['config']['sustained_clock_mode'] = sustained
     if pipe is not None:
       out['config']['pipelined_stream_mode'] = pipe
     if sweep is not None:
