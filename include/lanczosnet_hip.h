@@ -193,6 +193,38 @@ int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt, c
                    const float* bias, int B, int N, int C, int planes, int relu, float* Xout,
                    lnz_stream_t stream);
 
+/* ---- the same layer on the NONZEROS of the Laplacian (csrc/conv_sparse.hip) --------------------
+ * The normalised Laplacian of a large sparse graph (config 5: G(n = 2048, p = 0.01), 99 % zeros) is
+ * read from HBM once per batch instead of once per layer; planes = 1 (bf16 operands, fp32
+ * accumulate: the streamed form's products without the zeros), one operator class (every channel
+ * of L equal to channel 0: the reference's single-edge-type collate, dataset/graph_data.py:225-262).
+ * A layer = gemm1_rows + spectral + conv(C = 0, relu = 0) + sparse_conv(relu).
+ *   lnz_large_sparse_image   L [B,N,N,C] fp32 by element strides -> entries [B][N][row_cap] u32 =
+ *                            bf16(value) << 16 | column (rounded to nearest even, as
+ *                            lnz_large_pack_operators rounds), counts [B][N] i32: the nonzeros of
+ *                            channel 0 row by row (fixed order; zero padded to a multiple of 8 per
+ *                            row).  flags (one device int32, cleared by the call): bit 0 = a
+ *                            channel differs from channel 0 somewhere, bit 1 = a row holds more
+ *                            than row_cap nonzeros (row_cap a multiple of 8, >= 32; N <= 65536).
+ *                            A non-zero flag means the image must NOT be used: the caller reads it
+ *                            back and takes lnz_large_pack_operators / lnz_large_conv instead.
+ *   lnz_large_pack_vectors   Vb alone, exactly as lnz_large_pack_operators writes it.
+ *   lnz_large_gemm1_rows     Z [B][N][128] bf16 = X W^T, row major (Wf: the C = 1, planes = 1 form
+ *                            of lnz_large_gemm1's fragments, the class's weight blocks summed).
+ *   lnz_large_conv, C = 0    the lift alone: Xout = act( Vb Tt^T + bias ) (Lb, Zt may be NULL).
+ *   lnz_large_sparse_conv    X [B,N,128] in place: X[r] = act( X[r] + sum_k value[r][k] Z[column[r][k]] ),
+ *                            accumulated in fp32 in entry order.  An exact zero of L contributes
+ *                            nothing (the streamed kernels multiply it: 0 x inf = NaN there). */
+int lnz_large_sparse_image(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
+                           int64_t stride_ch, int B, int N, int C, int row_cap, uint32_t* entries,
+                           int32_t* counts, int32_t* flags, lnz_stream_t stream);
+int lnz_large_pack_vectors(const float* V, int B, int N, int K, int planes, uint16_t* Vb,
+                           lnz_stream_t stream);
+int lnz_large_gemm1_rows(const float* X, int ldx, int din, const uint16_t* Wf, int B, int N,
+                         uint16_t* Z, lnz_stream_t stream);
+int lnz_large_sparse_conv(const uint32_t* entries, const int32_t* counts, int row_cap,
+                          const uint16_t* Z, int B, int N, int relu, float* X, lnz_stream_t stream);
+
 /* ---- R6 standalone: batched symmetric tridiagonal eigensolver --------------------------------
  * The step the reference leaves to LAPACK (inside np.linalg.eigh, utils/data_helper.py:201) /
  * ARPACK (:208).  diag [B,M], offdiag [B,M-1] (fp64) -> R [B,M] ascending, Bm [B,M,M] with

@@ -276,6 +276,30 @@ __global__ __launch_bounds__(256) void large_pack_kernel(
   }
 }
 
+// The Ritz vectors alone (the sparse conv has no packed Laplacian): Vb exactly as large_pack_kernel
+// writes it.
+template <int P>
+__global__ __launch_bounds__(256) void large_pack_vectors_kernel(const float* __restrict__ V, int B,
+                                                                 int N, int K, u16* __restrict__ Vb) {
+  const int rg = blockIdx.x, b = blockIdx.y, RT = gridDim.x;
+  const int row32 = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const int r = 32 * rg + row32;
+  const int64_t plane_v = (int64_t)B * RT * 2048;
+  bf16x8 out[P];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = 8 * j + u;
+    const float x = (r < N && k < K) ? V[((int64_t)b * N + r) * K + k] : 0.0f;
+    u16 p[P];
+    split_pieces<P>(x * ElemTraits<P>::kAScale, p);
+#pragma unroll
+    for (int i = 0; i < P; ++i) out[i][u] = __builtin_bit_cast(__bf16, p[i]);
+  }
+  const int64_t o = ((int64_t)b * RT + rg) * 2048 + (int64_t)frag_slot(row32, j) * 8;
+#pragma unroll
+  for (int i = 0; i < P; ++i) *reinterpret_cast<bf16x8*>(Vb + i * plane_v + o) = out[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // GEMM1: Zt[c][o][n] = sum_i W_c[o][i] X[n][i]   (= (X W_c^T)^T, the conv kernel's B image)
 // Workgroup = 128 node rows; the X tile is read ONCE, coalesced, converted (split) to bf16 and
@@ -284,7 +308,10 @@ __global__ __launch_bounds__(256) void large_pack_kernel(
 // channel (Wf is stored in fragment order: one 1 KiB wave load per fragment); the 128 x 128
 // output tile of a channel goes through LDS so that Zt rows are written as 256 B runs.
 // ------------------------------------------------------------------------------------------
-template <int P>
+// ROWS (P = 1, one channel; the sparse conv of csrc/conv_sparse.hip): the product is written ROW
+// major instead, Z [B][N][128] bf16 — a node's 128 features are the 256 contiguous bytes the
+// gather of lnz_large_sparse_conv reads per nonzero.
+template <int P, bool ROWS = false>
 __global__ __launch_bounds__(256) void large_gemm1_kernel(
     const float* __restrict__ X, int ldx, int din, int dinp, const u16* __restrict__ Wf,
     int B, int N, int Nk, int C, u16* __restrict__ Zt) {
@@ -385,6 +412,24 @@ __global__ __launch_bounds__(256) void large_gemm1_kernel(
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] *= ElemTraits<P>::kAInv;
+    }
+    if constexpr (ROWS) {
+      // acc[nt][4 q .. 4 q + 3] = features 32 w + 8 q + 4 h .. + 3 of node n0 + 32 nt + l31: 8 B stores
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 32 * nt + l31;
+        if (n < N) {
+          u16* dst = Zt + ((int64_t)b * N + n) * DH + 32 * w + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint2 v;
+            v.x = (unsigned)to_piece<P>(acc[nt][4 * q]) | ((unsigned)to_piece<P>(acc[nt][4 * q + 1]) << 16);
+            v.y = (unsigned)to_piece<P>(acc[nt][4 * q + 2]) | ((unsigned)to_piece<P>(acc[nt][4 * q + 3]) << 16);
+            *reinterpret_cast<uint2*>(dst + 8 * q) = v;
+          }
+        }
+      }
+      continue;
     }
     // ---- output, plane by plane through LDS: Zs[o][n] <- piece p of the tile, then 256 B runs
 #pragma unroll
@@ -943,6 +988,19 @@ extern "C" int lnz_large_gemm1(const float* X, int ldx, int din, const uint16_t*
   return lnz::check_launch("lnz_large_gemm1");
 }
 
+extern "C" int lnz_large_gemm1_rows(const float* X, int ldx, int din, const uint16_t* Wf, int B,
+                                    int N, uint16_t* Z, lnz_stream_t stream) {
+  LNZ_REQUIRE(X && Wf && Z && B > 0 && N > 0 && din > 0 && ldx >= din, LNZ_EINVAL,
+              "lnz_large_gemm1_rows: bad arguments");
+  const int dinp = (din + 15) / 16 * 16;
+  LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_gemm1_rows: input width %d > 128", din);
+  const size_t lds = ((size_t)128 * (dinp + 8) + 128 * 136) * sizeof(uint16_t);
+  LNZ_DYNAMIC_LDS((large_gemm1_kernel<1, true>), lds, "conv_large.hip");
+  hipLaunchKernelGGL((large_gemm1_kernel<1, true>), dim3((N + 127) / 128, B), dim3(256), lds,
+                     (hipStream_t)stream, X, ldx, din, dinp, Wf, B, N, 0, 1, Z);
+  return lnz::check_launch("lnz_large_gemm1_rows");
+}
+
 extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float* V, const float* G,
                                   const float* Wt, int B, int N, int K, int S, int planes,
                                   float* Ybuf, uint16_t* Tt, lnz_stream_t stream) {
@@ -978,11 +1036,29 @@ extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float*
   return lnz::check_launch("lnz_large_spectral");
 }
 
+extern "C" int lnz_large_pack_vectors(const float* V, int B, int N, int K, int planes, uint16_t* Vb,
+                                      lnz_stream_t stream) {
+  LNZ_REQUIRE(V && Vb && B > 0 && N > 0 && K > 0, LNZ_EINVAL, "lnz_large_pack_vectors: bad arguments");
+  LNZ_REQUIRE(K <= 64, LNZ_ENOTSUP, "lnz_large_pack_vectors: K=%d > 64", K);
+  LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_pack_vectors: planes must be 1, 2 or 3");
+  dim3 grid((N + 31) / 32, B);
+  if (planes == 1)
+    hipLaunchKernelGGL(large_pack_vectors_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, V, B, N, K, Vb);
+  else if (planes == 2)
+    hipLaunchKernelGGL(large_pack_vectors_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, V, B, N, K, Vb);
+  else
+    hipLaunchKernelGGL(large_pack_vectors_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, V, B, N, K, Vb);
+  return lnz::check_launch("lnz_large_pack_vectors");
+}
+
 extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt,
                               const uint16_t* Tt, const float* bias, int B, int N, int C, int planes,
                               int relu, float* Xout, lnz_stream_t stream) {
-  LNZ_REQUIRE(Lb && Vb && Zt && Tt && bias && Xout && B > 0 && N > 0 && C > 0, LNZ_EINVAL,
+  // C == 0: no node-space channel — the launch is the lift V T (+ bias, activation) alone, the
+  // form the sparse conv (csrc/conv_sparse.hip) adds its gathered products to; Lb / Zt unused
+  LNZ_REQUIRE(Vb && Tt && bias && Xout && B > 0 && N > 0 && C >= 0 && (C == 0 || (Lb && Zt)), LNZ_EINVAL,
               "lnz_large_conv: bad arguments");
+  if (C == 0) Lb = Vb, Zt = Tt;   // (the streams start on their lift block; never dereferenced as operators)
   LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_conv: planes must be 1, 2 or 3");
   const int Nk = (int)lnz_large_nk(N);
   const size_t lds = (size_t)2 * planes * DH * BP * sizeof(uint16_t);

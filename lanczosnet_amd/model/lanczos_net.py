@@ -586,6 +586,53 @@ class _LanczosNetBase(nn.Module):
             return ok
         return Lb, Vb, classes, verify
 
+    # -- the node-space term on the nonzeros of L (csrc/conv_sparse.hip) -------------------------
+    # bf16 mode only (planes = 1).  The image kernel reads L once, keeps the nonzeros of channel 0
+    # and reports (a) whether any other channel differs from channel 0 (the fold claim of
+    # `_large_pack`, checked here for all channels at once) and (b) whether a row is too dense for
+    # the gather to beat the stream.  The flags come back through pinned memory behind the layer
+    # launches; a raised flag discards the result, the batch takes the streamed kernels, and the
+    # next `large_sparse_backoff` calls on this device do not try again.
+    large_sparse = os.environ.get('LANCZOSNET_LARGE_SPARSE', '1') != '0'
+    large_sparse_backoff = 32
+
+    def _large_sparse_layers(self, node_feat, Lf, Vf, G):
+        """-> the last conv layer's state [B,N,128], or None when the batch has to take the
+        streamed kernels (disabled, capturing, N beyond 16-bit columns, or a raised image flag)."""
+        B, N, _, Cn = Lf.shape
+        if not self.large_sparse or N > 65536 or torch.cuda.is_current_stream_capturing():
+            return None
+        st = self.__dict__.setdefault('_large_sparse_state', {}).setdefault(Lf.device.index, {})
+        if st.get('skip', 0) > 0:
+            st['skip'] -= 1
+            return None
+        img = ops.large_sparse_image(Lf)
+        host = st.get('host')
+        if host is None:
+            host = st['host'] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        host.copy_(img.flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        Vb = ops.large_pack_vectors(Vf, 1)
+        classes = (0,) * Cn
+        plan = self._plan_large(1, classes)
+        work = ops.large_sparse_work_buffers(B, N, Lf.device)
+        state = node_feat.float().contiguous() if self.general else \
+            self.embedding(node_feat).float().contiguous()
+        bufs = [None, None]
+        for t, lay in enumerate(plan['conv'][(1, classes)]):
+            state = ops.large_sparse_conv_layer(state, lay['din'], img, Vb, Vf, lay['Wb'], lay['Wt'],
+                                                G[t] if G is not None else None, lay['bias'], work,
+                                                relu=True, out=bufs[t & 1])
+            bufs[t & 1] = state
+        ev.synchronize()   # the image launch: long finished
+        flags = int(host.item())
+        st['last_flags'] = flags
+        if flags:
+            st['skip'] = self.large_sparse_backoff
+            return None
+        return state
+
     @torch.no_grad()
     def _large_graph_forward_hip(self, node_feat, L, D, V, mask, planes=3):
         """Graphs beyond the 32-node MFMA tile on the hand-written streaming kernels
@@ -601,7 +648,8 @@ class _LanczosNetBase(nn.Module):
         if S > 0:
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer,
                                    self._plan_large()['mlp_pack'])
-        for attempt in range(2):
+        state = self._large_sparse_layers(node_feat, Lf, Vf, G) if planes == 1 else None
+        for attempt in range(2 if state is None else 0):
             Lb, Vb, classes, verify = self._large_pack(Lf, Vf, planes)
             plan = self._plan_large(planes, classes)
             work = ops.large_work_buffers(Lb)

@@ -443,6 +443,89 @@ def large_work_buffers(Lb):
   return Zt, Tt, Ybuf
 
 
+# ---- the same layer on the nonzeros of the Laplacian (csrc/conv_sparse.hip) ----------------------
+class LargeSparseImage:
+  """Row-by-row nonzeros of channel 0 of L [B,N,N,C] (lnz_large_sparse_image): entries [B,N,cap]
+  int32 = bf16(value) << 16 | column, counts [B,N], flags (one int32 on the device: bit 0 = a
+  channel differs from channel 0, bit 1 = a row overflowed `cap`; non-zero = the image must not be
+  used)."""
+  __slots__ = ('entries', 'counts', 'flags', 'cap', 'B', 'N')
+
+  def __init__(self, entries, counts, flags, cap):
+    self.entries, self.counts, self.flags, self.cap = entries, counts, flags, cap
+    self.B, self.N = counts.shape
+
+
+def large_sparse_row_cap(N):
+  """Entries kept per row of the sparse image: N / 32, at least 32, at most 256, a multiple of 8.
+  The gather costs ~0.28 ms per layer at 21 entries per row (B = 256, N = 2048) against the streamed
+  form's 0.47 ms whatever the density: beyond ~30 entries per row the streamed form is the faster
+  one, so a graph with a row twice that long is sent there (flags bit 1)."""
+  return int(min(256, max(32, (N // 32 + 7) // 8 * 8)))
+
+
+def large_sparse_image(L, row_cap=None):
+  """lnz_large_sparse_image on the current stream.  L [B,N,N,C] fp32 (any strides)."""
+  _need_cuda(L)
+  assert L.dim() == 4 and L.dtype == torch.float32
+  B, N, _, Cn = L.shape
+  cap = large_sparse_row_cap(N) if row_cap is None else int(row_cap)
+  dev = L.device
+  entries = torch.empty((B, N, cap), dtype=torch.int32, device=dev)
+  counts = torch.empty((B, N), dtype=torch.int32, device=dev)
+  flags = torch.empty((1,), dtype=torch.int32, device=dev)
+  sb, sr, sc, sch = L.stride()
+  with torch.cuda.device(dev):
+    _abi().large_sparse_image(L, sb, sr, sc, sch, B, N, Cn, cap, entries, counts, flags)
+  return LargeSparseImage(entries, counts, flags, cap)
+
+
+def large_pack_vectors(V, planes=1):
+  """lnz_large_pack_vectors: V [B,N,K] fp32 -> Vb [planes,B,RT,4,64,8] (see large_pack_operators)."""
+  _need_cuda(V)
+  V = _f32c(V)
+  B, N, K = V.shape
+  Vb = torch.empty((planes, B, (N + 31) // 32, 4, 64, 8), dtype=large_plane_dtype(planes), device=V.device)
+  with torch.cuda.device(V.device):
+    _abi().large_pack_vectors(V, B, N, K, planes, Vb)
+  return Vb
+
+
+def large_sparse_work_buffers(B, N, device):
+  """(Z, Tt, Ybuf) of large_sparse_conv_layer: Z [B,N,128] bf16, Tt [1,B,128,64] bf16 (zero: stays
+  zero without long scales), Ybuf [B,64,128] fp32 (zero; the spectral kernels keep it zero)."""
+  Z = torch.empty((B, N, 128), dtype=torch.bfloat16, device=device)
+  Tt = torch.zeros((1, B, 128, 64), dtype=torch.bfloat16, device=device)
+  Ybuf = torch.zeros((B, 64, 128), dtype=torch.float32, device=device)
+  return Z, Tt, Ybuf
+
+
+def large_sparse_conv_layer(X, din, img, Vb, V, Wf, Wt, G, bias, work, relu=True, out=None):
+  """One conv layer with the node-space term on the sparse image: lnz_large_gemm1_rows +
+  lnz_large_spectral + lnz_large_conv (C = 0: the lift + bias) + lnz_large_sparse_conv.  X [B,N,ldx]
+  fp32 (first `din` columns are the layer input); Vb = large_pack_vectors(V); V [B,N,K] fp32; Wf: the
+  one-channel, one-plane fragments of the summed weight blocks (large_weight_fragments); Wt / G as
+  large_conv_layer; work from large_sparse_work_buffers().  Returns X' [B,N,128]."""
+  Z, Tt, Ybuf = work
+  _need_cuda(X, img.entries, Vb, Wf, bias, Z, Tt)
+  B, N = img.B, img.N
+  assert X.dtype == torch.float32 and X.is_contiguous() and X.shape[0] == B and X.shape[1] == N
+  assert Vb.shape[0] == 1 and Wf.shape[0] == 1 and Wf.shape[1] == 1
+  if out is None:
+    out = torch.empty((B, N, 128), dtype=torch.float32, device=X.device)
+  with torch.cuda.device(X.device):
+    abi = _abi()
+    abi.large_gemm1_rows(X, X.shape[2], din, Wf, B, N, Z)
+    if G is not None:
+      K, S = V.shape[2], G.shape[1]
+      assert V.dtype == torch.float32 and V.is_contiguous()
+      assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
+      abi.large_spectral(X, X.shape[2], din, V, G, Wt, B, N, K, S, 1, Ybuf, Tt)
+    abi.large_conv(None, Vb, None, Tt, bias, B, N, 0, 1, 0, out)
+    abi.large_sparse_conv(img.entries, img.counts, img.cap, Z, B, N, int(bool(relu)), out)
+  return out
+
+
 # ------------------------------------------------------------------------------------- packing
 def pack_rows_k8(W):
   """[rows, cols] -> MFMA fragment order (see include/lanczosnet_hip.h)."""
