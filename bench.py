@@ -404,7 +404,11 @@ def large_graph_leg(dev, A, D, V, reps=3):
   MATERIALISED [B,N,N,2] tensor of the reference's collate; `forward_expanded_view_ms` the same
   batch handed over as a zero-channel-stride view (what a device-side collate can emit: equality
   is then structural, the pack reads one channel); `forward_unfolded_ms` with folding off.
-  The dominant kernel (lnz_large_conv) is HBM bound on the packed-operator stream: algorithmic
+  [r06] `forward_ms` is the module's default in this mode: the node-space term on the NONZEROS of L
+  (csrc/conv_sparse.hip: L read once into a row-by-row image, per layer a gather of Z's rows) —
+  `sparse_path` prices its launches; `forward_streamed_ms` is the streamed form (the in-call
+  fallback for dense graphs or differing channels), whose numbers follow.
+  The dominant kernel of the streamed form (lnz_large_conv) is HBM bound on the packed-operator stream: algorithmic
   bytes per launch = B * (Cd N Nk + N 64 + Cd 128 Nk + 128 64) * 2 (bf16 Lb, Vb, Zt, Tt read once)
   + B N 128 * 4 (X' written), Cd = distinct operators streamed (1); SURVEY 8(d)'s accounting
   counts every channel of L (C = 2) whether or not the kernel has to read it: reported beside it,
@@ -437,11 +441,15 @@ def large_graph_leg(dev, A, D, V, reps=3):
       ts.append(e[0].elapsed_time(e[1]))
     return float(np.mean(ts)), r
   with torch.no_grad():
+    net.large_sparse = False
     net._large_graph_forward_hip(X, L, D, V, mask, planes=1)   # first batch: learns the fold
-    for name, planes, Lin, fold in (('bf16', 1, L, True), ('bf16_view', 1, Lx, True),
-                                    ('split3', 3, L, True), ('bf16_unfolded', 1, L, False)):
-      net.large_fold = fold
+    for name, planes, Lin, fold, sparse in (('bf16', 1, L, True, False), ('bf16_view', 1, Lx, True, False),
+                                            ('split3', 3, L, True, False), ('bf16_unfolded', 1, L, False, False),
+                                            ('sparse', 1, L, True, True), ('sparse_view', 1, Lx, True, True)):
+      net.large_fold, net.large_sparse = fold, sparse
       out[name] = timed(lambda: net._large_graph_forward_hip(X, Lin, D, V, mask, planes=planes))
+    sparse_flags = net._large_sparse_state[dev.index if dev.index is not None else 0]['last_flags']
+    sparse_kernel = ops.last_kernel()
     net.large_fold = True
     classes = net._large_fold_classes(L)[0]
     folded = len(set(classes)) == 1
@@ -470,6 +478,29 @@ def large_graph_leg(dev, A, D, V, reps=3):
     e[1].record()
     torch.cuda.synchronize()
     conv_ms = e[0].elapsed_time(e[1]) / 7
+    # the sparse path's launches on the same layer
+    img_ms, img = timed(lambda: ops.large_sparse_image(L))
+    img_view_ms, _ = timed(lambda: ops.large_sparse_image(Lx))
+    swork = ops.large_sparse_work_buffers(B, N, dev)
+    abi = ops._abi()
+    folded_plan = net._plan_large(1, (0, 0))['conv'][(1, (0, 0))][1]
+
+    def per_launch(fn, n=7):
+      fn()
+      e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+      e[0].record()
+      for _ in range(n):
+        fn()
+      e[1].record()
+      torch.cuda.synchronize()
+      return e[0].elapsed_time(e[1]) / n
+    sp_gemm1 = per_launch(lambda: abi.large_gemm1_rows(state, 128, 128, folded_plan['Wb'], B, N, swork[0]))
+    sp_spec = per_launch(lambda: abi.large_spectral(state, 128, 128, V, Gs[1], folded_plan['Wt'], B, N, K, 8, 1,
+                                                    swork[2], swork[1]))
+    sp_lift = per_launch(lambda: abi.large_conv(None, Vb, None, swork[1], lay['bias'], B, N, 0, 1, 0, buf))
+    sp_conv = per_launch(lambda: abi.large_sparse_conv(img.entries, img.counts, img.cap, swork[0], B, N, 1, buf))
+    cnt = img.counts.float()
+    slots = float(((img.counts + 7) // 8 * 8).sum().item())
   Nk = Lb.dims[1]
   Cd = Lb.shape[2]
   alg_of = lambda c: B * (c * N * Nk + N * 64 + c * 128 * Nk + 128 * 64) * 2 + B * N * 128 * 4  # noqa: E731
@@ -479,10 +510,28 @@ def large_graph_leg(dev, A, D, V, reps=3):
   fold_rel = float((out['bf16'][1] - out['bf16_unfolded'][1]).abs().max() / out['bf16_unfolded'][1].abs().max())
   res = {'workload': 'LanczosNetGeneral conv stack on the graphs of lanczos_large_mode: B=%d, N=%d, '
                      'K=%d, E+1=2, S=8, 10 -> 7 x 128 -> 2, bf16 operands / fp32 accumulate '
-                     '(pack + 7 x [gemm1, eigen-space block, streamed conv] + head)' % (B, N, K),
-         'forward_ms': round(out['bf16'][0], 3),
-         'graphs_per_s_forward': round(B / out['bf16'][0] * 1e3, 1),
-         'forward_expanded_view_ms': round(out['bf16_view'][0], 3),
+                     '(sparse image of L + 7 x [gemm1, eigen-space block, lift, gather] + head; streamed form: pack + 7 x '
+                     '[gemm1, eigen-space block, streamed conv] + head)' % (B, N, K),
+         'forward_ms': round(out['sparse'][0], 3),
+         'graphs_per_s_forward': round(B / out['sparse'][0] * 1e3, 1),
+         'forward_path': 'sparse image of L (csrc/conv_sparse.hip; the module\'s default in this mode, '
+                         'streamed kernels as the in-call fallback); last dominant kernel: %s' % sparse_kernel,
+         'forward_expanded_view_ms': round(out['sparse_view'][0], 3),
+         'sparse_vs_streamed_rel': float((out['sparse'][1] - out['bf16'][1]).abs().max() / out['bf16'][1].abs().max()),
+         'sparse_path': {
+             'image_flags': int(sparse_flags), 'row_cap': int(img.cap),
+             'entries_per_row_mean': round(float(cnt.mean().item()), 2), 'entries_per_row_max': int(cnt.max().item()),
+             'image_ms': {'materialised_[B,N,N,2]': round(img_ms, 3),
+                          'GBps': round(B * 2 * N * N * 4 / img_ms / 1e6, 1),
+                          'zero_channel_stride_view': round(img_view_ms, 3),
+                          'view_GBps': round(B * N * N * 4 / img_view_ms / 1e6, 1)},
+             'layer_ms': {'gemm1_rows': round(sp_gemm1, 4), 'eigen_space_block': round(sp_spec, 4),
+                          'lift_launch': round(sp_lift, 4), 'sparse_conv': round(sp_conv, 4)},
+             'gather': {'kernel': 'sparse_conv_kernel', 'bound': 'L2 -> L1 path (256 B per nonzero)',
+                        'bytes_per_launch': int(slots * 256),
+                        'GBps': round(slots * 256 / sp_conv / 1e6, 1)}},
+         'forward_streamed_ms': round(out['bf16'][0], 3),
+         'forward_streamed_expanded_view_ms': round(out['bf16_view'][0], 3),
          'forward_unfolded_ms': round(out['bf16_unfolded'][0], 3),
          'split_precision_forward_ms': round(out['split3'][0], 3),
          'bf16_vs_split_precision_rel': dev_rel,
@@ -507,7 +556,7 @@ def large_graph_leg(dev, A, D, V, reps=3):
                                   'bytes it actually moves)'}}}
   if not folded:
     res['channel_fold']['note'] = 'fold not taken'
-  del net, L, Lb, Vb, work
+  del net, L, Lb, Vb, work, img, swork
   torch.cuda.empty_cache()
   return res
 

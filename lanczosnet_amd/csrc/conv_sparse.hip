@@ -46,10 +46,11 @@ __device__ inline int lane_rank(unsigned long long m) {  // set bits of m below 
 }
 
 // ---- image: one wavefront per row ---------------------------------------------------------------
-// PAIR: channels-last pair of channels (sc == 2, sch == 1, rows 16-byte aligned): a float4 is two
-// columns x two channels, 1 KiB contiguous per wave load, eight loads in flight.  Otherwise: 4-byte
-// loads at the given strides (coalesced when sc == 1: channel-major tensors, expanded views).
-template <bool PAIR>
+// FORM 2: channels-last pair of channels (sc == 2, sch == 1, rows 16-byte aligned): a float4 is two
+// columns x two channels, 1 KiB contiguous per wave load, eight loads in flight.  FORM 1: one
+// operator in contiguous rows (sc == 1 and a single channel or a zero channel stride — an expanded
+// view): a float4 is four columns.  FORM 0: 4-byte loads at the given strides.
+template <int FORM>
 __global__ __launch_bounds__(256) void sparse_image_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int B, int N, int C,
     int cap, unsigned* __restrict__ ent, int32_t* __restrict__ counts,
@@ -70,7 +71,26 @@ __global__ __launch_bounds__(256) void sparse_image_kernel(
     if (nz && pos < cap) oe[pos] = pack_entry(v, col);
     k += __popcll(m);
   };
-  if constexpr (PAIR) {
+  if constexpr (FORM == 1) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(Lr);
+    const int nq = N >> 2;   // (N is a multiple of 4 in this form)
+    for (int q0 = 0; q0 < nq; q0 += 64 * 8) {
+      f32x4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + 64 * u + lane;
+        x[u] = q < nq ? __builtin_nontemporal_load(src + q) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + 64 * u + lane;
+        if (__ballot((x[u][0] != 0.0f) | (x[u][1] != 0.0f) | (x[u][2] != 0.0f) | (x[u][3] != 0.0f)) == 0ull)
+          continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) place(x[u][c], 4 * q + c);
+      }
+    }
+  } else if constexpr (FORM == 2) {
     const f32x4* src = reinterpret_cast<const f32x4*>(Lr);
     const int nq = N >> 1;   // float4 = columns 2 q, 2 q + 1 (N is even in this form)
     for (int q0 = 0; q0 < nq; q0 += 64 * 8) {
@@ -216,16 +236,20 @@ extern "C" int lnz_large_sparse_image(const float* L, int64_t stride_b, int64_t 
   hipStream_t s = (hipStream_t)stream;
   LNZ_REQUIRE(hipMemsetAsync(flags, 0, sizeof(int32_t), s) == hipSuccess, LNZ_ELAUNCH,
               "lnz_large_sparse_image: hipMemsetAsync failed");
-  const bool pair = C == 2 && stride_c == 2 && stride_ch == 1 && N % 2 == 0 &&
-                    (((uintptr_t)L) & 15) == 0 && stride_b % 4 == 0 && stride_r % 4 == 0;
+  const bool aligned = (((uintptr_t)L) & 15) == 0 && stride_b % 4 == 0 && stride_r % 4 == 0;
+  const bool pair = aligned && C == 2 && stride_c == 2 && stride_ch == 1 && N % 2 == 0;
+  const bool rows1 = aligned && stride_c == 1 && (C == 1 || stride_ch == 0) && N % 4 == 0;
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (pair)
-    hipLaunchKernelGGL(sparse_image_kernel<true>, grid, dim3(256), 0, s, L, stride_b, stride_r,
+    hipLaunchKernelGGL(sparse_image_kernel<2>, grid, dim3(256), 0, s, L, stride_b, stride_r,
+                       stride_c, stride_ch, B, N, C, row_cap, entries, counts, flags);
+  else if (rows1)
+    hipLaunchKernelGGL(sparse_image_kernel<1>, grid, dim3(256), 0, s, L, stride_b, stride_r,
                        stride_c, stride_ch, B, N, C, row_cap, entries, counts, flags);
   else
-    hipLaunchKernelGGL(sparse_image_kernel<false>, grid, dim3(256), 0, s, L, stride_b, stride_r,
+    hipLaunchKernelGGL(sparse_image_kernel<0>, grid, dim3(256), 0, s, L, stride_b, stride_r,
                        stride_c, stride_ch, B, N, C, row_cap, entries, counts, flags);
-  lnz::note_kernel("sparse_image_kernel<%s>", pair ? "pair" : "strided");
+  lnz::note_kernel("sparse_image_kernel<%s>", pair ? "pair" : rows1 ? "rows" : "strided");
   return lnz::check_launch("lnz_large_sparse_image");
 }
 

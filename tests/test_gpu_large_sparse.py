@@ -35,7 +35,7 @@ def _sparse_L(B, N, C, p, seed, layout):
 
 @pytest.mark.parametrize('B,N,C,p,layout', [
     (3, 256, 2, 0.03, 'channels_last'), (2, 301, 2, 0.02, 'channels_last'), (2, 200, 1, 0.05, 'channels_last'),
-    (2, 264, 3, 0.03, 'channels_last'), (2, 256, 2, 0.03, 'channel_major'), (2, 256, 2, 0.03, 'expanded'),
+    (2, 264, 3, 0.03, 'channels_last'), (2, 256, 2, 0.03, 'channel_major'), (2, 256, 2, 0.03, 'expanded'), (2, 301, 2, 0.02, 'expanded'),
     (2, 256, 2, 0.03, 'padded_parent'), (1, 2048, 2, 0.01, 'channels_last')])
 def test_sparse_image_holds_exactly_the_nonzeros(B, N, C, p, layout):
   """entries = bf16(value) << 16 | column for every nonzero of channel 0, each row's set complete
