@@ -1012,11 +1012,13 @@ extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float*
   LNZ_REQUIRE(planes >= 1 && planes <= 3, LNZ_EINVAL, "lnz_large_spectral: planes must be 1, 2 or 3");
   const int dinp = (din + 15) / 16 * 16;
   LNZ_REQUIRE(dinp <= 128, LNZ_ENOTSUP, "lnz_large_spectral: input width %d > 128", din);
-  // row chunks: enough workgroups to fill the chip, at least 128 rows each (multiple of 16)
+  // row chunks: one workgroup per compute unit, at least 128 rows each (multiple of 16).  (A
+  // workgroup's first tile is an exposed HBM round trip and its partial tile ends in 8 K atomics:
+  // B = 256, N = 2048 by the number of workgroups: 4096 0.178 ms, 2048 0.155, 512 0.131, 256 0.128.)
   static const int target_wgs = [] {  // read once (thread-safe static initialisation)
     const char* e = getenv("LNZ_LARGE_PROJECT_WGS");
-    const int v = e ? atoi(e) : 2048;
-    return v < 1 ? 2048 : v;
+    const int v = e ? atoi(e) : 256;
+    return v < 1 ? 256 : v;
   }();
   int chunks = (target_wgs + B - 1) / B;
   int rows = ((N + chunks - 1) / chunks + 63) / 64 * 64;
