@@ -32,7 +32,13 @@ namespace {
 typedef unsigned short u16;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int DH = 128;
-constexpr int ROWS_PER_WAVE = 16, WAVES = 4, TILE_ROWS = ROWS_PER_WAVE * WAVES;
+#ifndef LNZ_SPARSE_ROWS_PER_WAVE   // (tools/experiments/build_variant.sh sweeps)
+#define LNZ_SPARSE_ROWS_PER_WAVE 8
+#endif
+#ifndef LNZ_SPARSE_WAVES
+#define LNZ_SPARSE_WAVES 4
+#endif
+constexpr int ROWS_PER_WAVE = LNZ_SPARSE_ROWS_PER_WAVE, WAVES = LNZ_SPARSE_WAVES, TILE_ROWS = ROWS_PER_WAVE * WAVES;
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // bf16(value) << 16 | column; round to nearest even (v_cvt_pk_bf16_f32), as conv_large.hip's pack
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(256) void sparse_image_kernel(
 }
 
 // ---- conv: X[r][:] = act( X[r][:] + sum_k value[r][k] Z[column[r][k]][:] ) ---------------------
-// Workgroup = 64 rows of one graph (4 waves x 16 rows); blockIdx -> (graph, tile) deals the tiles
+// Workgroup = 32 rows of one graph (4 waves x 8 rows: 0.276 ms; x 16: 0.288, x 32: 0.340 — fewer
+// graphs share an L2 at a time); blockIdx -> (graph, tile) deals the tiles
 // of a graph to ONE XCD (workgroup i runs on XCD i % 8), whose L2 then holds the graph's Z (512
 // KiB).  One row at a time per wave, lanes along the 128 features (one dword = two bf16 features per
 // lane and entry: every gather is the 256 contiguous bytes of one node, its offset in an SGPR of a
