@@ -265,19 +265,24 @@ int lnz_lanczos_ritz_large_sym(const float* A, int64_t stride_b, int64_t stride_
  * flags:
  *   LNZ_KSTEP_SYMMETRIC  the dense stream reads only the upper 256 x 256 chunk blocks
  *                        (= lnz_lanczos_ritz_large_sym; otherwise = lnz_lanczos_ritz_large);
- *   LNZ_KSTEP_COMPACT    A is read from HBM ONCE: a first launch gathers the nonzeros of every
- *                        64-row slab into a sliced-ELL image in the workspace (row_cap entries per
+ *   LNZ_KSTEP_COMPACT    A is read from HBM ONCE: a first launch (one wavefront per row) gathers the
+ *                        nonzeros of every 64-row slab into a sliced-ELL image in the workspace (row_cap entries per
  *                        row at most, a multiple of 8), and the M steps multiply by that image —
  *                        the Laplacian of a G(n, 0.01) graph is 99 %% zeros and skipping an exact
  *                        zero changes no sum.  A graph with a longer row is computed by the dense
  *                        stream in the same call (dense_fallback [B], optional output: 1 for such
  *                        a graph).  The FULL matrix is read (no UPLO convention in this mode).
+ * stride_c (elements between the columns of a row): 1, or — with LNZ_KSTEP_COMPACT and a
+ * dense_fallback output — 2: A is channel 0 of a channels-last [N][N][2] block, the collated
+ * `L[..., 0]` of dataset/graph_data.py:225-262 read in place (N even; one float4 = two columns x
+ * two channels).  The dense streams need contiguous rows: with stride_c = 2 a graph flagged in
+ * dense_fallback is NOT computed — the caller copies such a batch and calls again.
  * Same algorithm, arithmetic and outputs as lnz_lanczos_ritz_large; the three SpMV variants differ
  * in the order of their fp64 additions only.  Deterministic. */
 #define LNZ_KSTEP_SYMMETRIC 1
 #define LNZ_KSTEP_COMPACT 2
 int64_t lnz_lanczos_ritz_kstep_workspace_bytes(int B, int N, int flags, int row_cap);
-int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r,
+int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                            const int32_t* n_nodes, int B, int N, int M, int K, int flags,
                            int row_cap, void* workspace, int64_t workspace_bytes, float* D, float* V,
                            int32_t* info, int32_t* dense_fallback, lnz_stream_t stream);

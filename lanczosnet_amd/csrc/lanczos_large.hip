@@ -355,7 +355,7 @@ __device__ __forceinline__ void cgs_pass(LargeSmem& sm, const double* __restrict
 // ---- sliced-ELL image of a sparse dense-stored A (K-step entry, LNZ_KSTEP_COMPACT) ---------------
 // The normalised Laplacian of a G(n, p = 0.01) graph (BASELINE config 5) is 99 % zeros, and the
 // K-step recurrence multiplies by it K times.  The dense matrix is therefore read from HBM ONCE, by
-// ell_compact_kernel, which gathers the nonzeros of every 64-row slab g into
+// ell_compact_rows_kernel, which gathers the nonzeros of every 64-row slab g into
 //   vals[b][g][k][i], cols[b][g][k][i] : entry k of row 64 g + i  (k < cap; zero padded up to
 //   widths[b][g] = the slab's longest row rounded up to ELL_UNROLL)
 // — 0.4 MB per graph at n = 2048, p = 0.01 instead of 16.8 MB — and the Lanczos steps run on that
@@ -370,76 +370,90 @@ struct EllImage {
   int cap;
 };
 
-// One wave per slab: rows 64 g .. 64 g + 63, each one fully coalesced 8 KiB read (lane l holds
-// columns 256 s + 4 l .. + 3 of chunk s, like the full-stream SpMV), the next row in flight while
-// the ballots of this one place its nonzeros.  1.02 ms for B = 256, N = 2048 (4.2 TB/s); with the
-// placement compiled out the same stream takes 0.87 ms — the ballots are not what it waits for.
-__global__ __launch_bounds__(TPB) void ell_compact_kernel(
-    const float* __restrict__ A, int64_t sb, int64_t sr, int N, int cap, float* __restrict__ vals,
-    uint16_t* __restrict__ cols, int32_t* __restrict__ widths, int32_t* __restrict__ over) {
-  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nslab = (N + 63) >> 6;
-  const int g = blockIdx.x * NWAVE + wave;
-  if (g >= nslab) return;
-  const float* Ab = A + (int64_t)b * sb;
-  const int64_t base = (((int64_t)b * nslab + g) * cap) * 64;
+// One wave per ROW (four rows per workgroup), the whole row requested before the first ballot: lane
+// l holds float4 64 u + l of the row, u < 8 — four columns each (PAIR = false), or two columns of
+// the two channels of a channels-last [N][N][2] block whose channel 0 is A (PAIR = true: the
+// product's collate layout is read in place, its .x / .z are the entries).  Entry k of row 64 g + i
+// goes to vals / cols [(g * cap + k) * 64 + i]; the rows of a slab are written by 64 different
+// waves, so the slab's width is an atomic max (widths zeroed by the caller) and the zero entries
+// up to it are written by ell_pad_kernel behind this launch.  4.3 GB in 0.67 ms (6.4 TB/s); the
+// r06 form with one wave per SLAB (a row's ballots behind the previous row's) ran at 4.2 TB/s.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void ell_compact_rows_kernel(
+    const float* __restrict__ A, int64_t sb, int64_t sr, int B, int N, int cap,
+    float* __restrict__ vals, uint16_t* __restrict__ cols, int32_t* __restrict__ widths,
+    int32_t* __restrict__ rowcnt, int32_t* __restrict__ over) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (rid >= (int64_t)B * N) return;
+  const int b = (int)(rid / N), r = (int)(rid - (int64_t)b * N);
+  const int nslab = (N + 63) >> 6, g = r >> 6, i = r & 63;
+  const float4* src = reinterpret_cast<const float4*>(A + (int64_t)b * sb + (int64_t)r * sr);
+  const int64_t base = (((int64_t)b * nslab + g) * cap) * 64 + i;
   float* vs = vals + base;
   uint16_t* cs = cols + base;
-  const int r0 = 64 * g, nrow = min(64, N - r0);
-  auto load_row = [&](int r, float4 (&a)[NCH]) {
-    const float* row = Ab + (int64_t)r * sr;
-#pragma unroll
-    for (int s = 0; s < NCH; ++s) {
-      const int c0 = 256 * s + 4 * lane;
-      a[s] = (c0 < N) ? lnz_stream_f4(row + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;   // entries of this row so far (wave-uniform)
+  auto place = [&](const float v, const int col) {
+    const bool nz = v != 0.f;
+    const unsigned long long m = __ballot(nz);
+    if (m == 0ull) return;
+    const int pos = k + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (nz && pos < cap) {
+      vs[(int64_t)pos * 64] = v;
+      cs[(int64_t)pos * 64] = (uint16_t)col;
     }
+    k += __popcll(m);
   };
-  int cnt = 0;       // lane i: entries of row r0 + i
-  int longest = 0;   // (wave-uniform)
-  auto place_row = [&](int i, const float4 (&a)[NCH]) {
-    int k = 0;  // wave-uniform running count of this row
+  const int nq = PAIR ? N >> 1 : N >> 2;   // float4s per row
+  for (int q0 = 0; q0 < nq; q0 += 64 * 8) {
+    float4 x[8];
 #pragma unroll
-    for (int s = 0; s < NCH; ++s) {
-      const float e[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
-      const unsigned long long any = __ballot(e[0] != 0.f || e[1] != 0.f || e[2] != 0.f || e[3] != 0.f);
-      if (any == 0ull) continue;
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + 64 * u + lane;
+      x[u] = q < nq ? lnz_stream_f4(reinterpret_cast<const float*>(src + q)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bool nz = e[c] != 0.f;
-        const unsigned long long m = __ballot(nz);
-        if (m == 0ull) continue;
-        const int pos = k + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (nz && pos < cap) {
-          vs[(int64_t)pos * 64 + i] = e[c];
-          cs[(int64_t)pos * 64 + i] = (uint16_t)(256 * s + 4 * lane + c);
-        }
-        k += __popcll(m);
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + 64 * u + lane;
+      if (PAIR) {
+        if (__ballot(x[u].x != 0.f || x[u].z != 0.f) == 0ull) continue;
+        place(x[u].x, 2 * q);
+        place(x[u].z, 2 * q + 1);
+      } else {
+        if (__ballot(x[u].x != 0.f || x[u].y != 0.f || x[u].z != 0.f || x[u].w != 0.f) == 0ull) continue;
+        place(x[u].x, 4 * q);
+        place(x[u].y, 4 * q + 1);
+        place(x[u].z, 4 * q + 2);
+        place(x[u].w, 4 * q + 3);
       }
     }
-    if (lane == i) cnt = k;
-    longest = max(longest, k);
-  };
-  {
-    float4 a0[NCH], a1[NCH];
-    if (nrow > 0) load_row(r0, a0);
-    for (int i = 0; i < nrow; i += 2) {
-      if (i + 1 < nrow) load_row(r0 + i + 1, a1);
-      place_row(i, a0);
-      if (i + 2 < nrow) load_row(r0 + i + 2, a0);
-      if (i + 1 < nrow) place_row(i + 1, a1);
-    }
   }
-  if (longest > cap) {
-    if (lane == 0) over[b] = 1;   // (every writer stores the same value)
-    longest = cap;
+  if (lane == 0) {
+    if (k > cap) over[b] = 1;   // (every writer stores the same value)
+    const int c = k < cap ? k : cap;
+    rowcnt[rid] = c;
+    atomicMax(widths + (int64_t)b * nslab + g, (c + ELL_UNROLL - 1) / ELL_UNROLL * ELL_UNROLL);
   }
-  const int w = (longest + ELL_UNROLL - 1) / ELL_UNROLL * ELL_UNROLL;  // (cap is a multiple of ELL_UNROLL)
-  for (int k = min(cnt, cap); k < w; ++k) {  // this lane's row: zero entries up to the slab's width
-    vs[(int64_t)k * 64 + lane] = 0.f;
-    cs[(int64_t)k * 64 + lane] = 0;
+}
+
+// zero entries from a row's count up to its slab's width (one wave per slab, lane = row)
+__global__ __launch_bounds__(256) void ell_pad_kernel(int B, int N, int cap, float* __restrict__ vals,
+                                                      uint16_t* __restrict__ cols,
+                                                      const int32_t* __restrict__ widths,
+                                                      const int32_t* __restrict__ rowcnt) {
+  const int lane = threadIdx.x & 63;
+  const int nslab = (N + 63) >> 6;
+  const int64_t sid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sid >= (int64_t)B * nslab) return;
+  const int b = (int)(sid / nslab), g = (int)(sid - (int64_t)b * nslab);
+  const int row = 64 * g + lane;
+  const int w = widths[sid];
+  const int c = row < N ? rowcnt[(int64_t)b * N + row] : 0;
+  const int64_t base = sid * cap * 64 + lane;
+  for (int k = c; k < w; ++k) {
+    vals[base + (int64_t)k * 64] = 0.f;
+    cols[base + (int64_t)k * 64] = 0;
   }
-  if (lane == 0) widths[(int64_t)b * nslab + g] = w;
 }
 
 #ifdef LNZ_LARGE_PROBE
@@ -457,7 +471,7 @@ __device__ unsigned long long g_large_probe[16];
 #endif
 
 // MODE 0: full stream; 1: symmetric stream (upper chunk blocks); 2: the sliced-ELL image of A that
-// ell_compact_kernel gathered (A itself is not read at all).  `gate` (optional): the per-graph
+// ell_compact_rows_kernel gathered (A itself is not read at all).  `gate` (optional): the per-graph
 // "row capacity exceeded" flags of the compaction — the workgroup of graph b runs only when
 // (gate[b] != 0) == gate_want, so that the ELL launch and the dense fallback launch behind it
 // split a batch between them without a host round trip.
@@ -963,14 +977,14 @@ static int launch_large(const float* A, int64_t stride_b, int64_t stride_r, int 
 // ---- the K-step entry: the reference's `eigsh` branch for graphs beyond one workgroup's reach ------
 static inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 struct KstepLayout {
-  int64_t basis, over, widths, vals, cols, total;
+  int64_t basis, over, widths, vals, cols, rowcnt, total;
 };
 static KstepLayout kstep_layout(int B, int N, int flags, int row_cap) {
   KstepLayout L;
   const int64_t nslab = (N + 63) / 64;
   L.basis = 0;
   int64_t at = align256((int64_t)B * MMAX * N * (int64_t)sizeof(double));
-  L.over = L.widths = L.vals = L.cols = at;
+  L.over = L.widths = L.vals = L.cols = L.rowcnt = at;
   if (flags & LNZ_KSTEP_COMPACT) {
     L.over = at;
     at = align256(at + (int64_t)B * 4);
@@ -980,6 +994,8 @@ static KstepLayout kstep_layout(int B, int N, int flags, int row_cap) {
     at = align256(at + (int64_t)B * nslab * row_cap * 64 * 4);
     L.cols = at;
     at = align256(at + (int64_t)B * nslab * row_cap * 64 * 2);
+    L.rowcnt = at;
+    at = align256(at + (int64_t)B * N * 4);
   }
   L.total = at;
   return L;
@@ -991,12 +1007,17 @@ extern "C" int64_t lnz_lanczos_ritz_kstep_workspace_bytes(int B, int N, int flag
 }
 
 extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r,
-                                      const int32_t* n_nodes, int B, int N, int M, int K, int flags,
+                                      int64_t stride_c, const int32_t* n_nodes, int B, int N, int M,
+                                      int K, int flags,
                                       int row_cap, void* workspace, int64_t workspace_bytes, float* D,
                                       float* V, int32_t* info, int32_t* dense_fallback,
                                       lnz_stream_t stream) {
   const char* who = "lnz_lanczos_ritz_kstep";
   const bool sym = (flags & LNZ_KSTEP_SYMMETRIC) != 0;
+  LNZ_REQUIRE(stride_c == 1 || (stride_c == 2 && (flags & LNZ_KSTEP_COMPACT) && dense_fallback),
+              LNZ_ENOTSUP,
+              "%s: stride_c=%lld: columns are contiguous, or (LNZ_KSTEP_COMPACT with dense_fallback) A is "
+              "channel 0 of a channels-last [N][N][2] block", who, (long long)stride_c);
   if (!(flags & LNZ_KSTEP_COMPACT)) {
     LNZ_REQUIRE(workspace_bytes >= kstep_layout(B, N, flags, 0).total, LNZ_EINVAL,
                 "%s: workspace of %lld bytes, %lld needed", who, (long long)workspace_bytes,
@@ -1024,14 +1045,27 @@ extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t 
                   (reinterpret_cast<uintptr_t>(A) & 15) == 0,
               LNZ_ENOTSUP, "%s: rows must be contiguous, 16-byte aligned, N %% 4 == 0", who);
   LNZ_REQUIRE(M <= N, LNZ_EINVAL, "%s: M=%d > N=%d", who, M, N);
-  if (hipMemsetAsync(over, 0, (size_t)B * 4, (hipStream_t)stream) != hipSuccess) {
+  int32_t* rowcnt = (int32_t*)(ws + L.rowcnt);
+  const int nslab = (N + 63) / 64;
+  // (over and widths are neighbours in the workspace unless the caller keeps `over`: two memsets)
+  if (hipMemsetAsync(over, 0, (size_t)B * 4, (hipStream_t)stream) != hipSuccess ||
+      hipMemsetAsync(widths, 0, (size_t)B * nslab * 4, (hipStream_t)stream) != hipSuccess) {
     lnz::set_error("%s: hipMemsetAsync failed", who);
     return LNZ_ELAUNCH;
   }
-  const int nslab = (N + 63) / 64;
-  hipLaunchKernelGGL(ell_compact_kernel, dim3((nslab + NWAVE - 1) / NWAVE, B), dim3(TPB), 0,
-                     (hipStream_t)stream, A, stride_b, stride_r, N, row_cap, vals, cols, widths, over);
+  const int64_t rows = (int64_t)B * N;
+  LNZ_REQUIRE(stride_c == 1 || N % 2 == 0, LNZ_ENOTSUP, "%s: stride_c = 2 needs an even N", who);
+  if (stride_c == 2)
+    hipLaunchKernelGGL(ell_compact_rows_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, A, stride_b, stride_r, B, N, row_cap, vals, cols, widths, rowcnt, over);
+  else
+    hipLaunchKernelGGL(ell_compact_rows_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, A, stride_b, stride_r, B, N, row_cap, vals, cols, widths, rowcnt, over);
   int rc = lnz::check_launch(who);
+  if (rc != LNZ_OK) return rc;
+  hipLaunchKernelGGL(ell_pad_kernel, dim3((unsigned)(((int64_t)B * nslab + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, B, N, row_cap, vals, cols, widths, rowcnt);
+  rc = lnz::check_launch(who);
   if (rc != LNZ_OK) return rc;
   const EllImage img = {vals, cols, widths, row_cap};
   hipLaunchKernelGGL(lanczos_ritz_large_kernel<2>, dim3(B), dim3(TPB), 0, (hipStream_t)stream, A,
@@ -1039,7 +1073,9 @@ extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t 
                      (const int32_t*)over, 0, img);
   rc = lnz::check_launch(who);
   if (rc != LNZ_OK) return rc;
-  // graphs the image could not hold: the dense stream (its workgroups leave at once otherwise)
+  // graphs the image could not hold: the dense stream (its workgroups leave at once otherwise).
+  // The streams read contiguous rows: with stride_c = 2 the caller looks at dense_fallback instead.
+  if (stride_c != 1) return LNZ_OK;
   return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, sym, who, n_nodes,
                       (const int32_t*)over);
 }

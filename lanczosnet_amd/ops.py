@@ -206,16 +206,20 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
                        workspace=None, return_info=False, return_fallback=False):
   """lnz_lanczos_ritz_kstep: M-step Lanczos Ritz pairs (top K by |theta|) of a ragged batch of
   large dense-stored graphs — the reference's `eigsh` branch (utils/data_helper.py:205-208).
-  A [B,N,N] float32 (rows contiguous; any N <= 2048: a width that is not a multiple of 4 or rows
-  that are not 16-byte aligned are copied into an aligned buffer first), n_nodes [B] or None.
+  A [B,N,N] float32, any N <= 2048, n_nodes [B] or None.  Read in place: contiguous rows, or (compact)
+  channel 0 of a channels-last pair — `L[..., 0]` of the collated [B,N,N,2] — with 16-byte aligned
+  rows and N a multiple of 4; anything else is copied into an aligned buffer first.
   compact: read A once and run the steps on its sliced-ELL image (graphs with a row of more than
-  row_cap nonzeros take the dense stream in the same call); symmetric: the dense stream reads the
-  upper chunk blocks only.  Returns D [B,K], V [B,N,K] (+ info [B] = steps taken) (+ fallback [B])."""
+  row_cap nonzeros take the dense stream in the same call — for the channels-last view after a look
+  at the fallback flags and a copy); symmetric: the dense stream reads the upper chunk blocks only.
+  Returns D [B,K], V [B,N,K] (+ info [B] = steps taken) (+ fallback [B])."""
   _need_cuda(A, n_nodes, workspace)
   assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
   B, N, _ = A.shape
   Np = (N + 3) // 4 * 4
-  if Np != N or A.stride(2) != 1 or A.stride(1) % 4 or A.stride(0) % 4 or A.data_ptr() % 16:
+  aligned = Np == N and A.stride(1) % 4 == 0 and A.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0
+  in_place = aligned and (A.stride(2) == 1 or (compact and A.stride(2) == 2))
+  if not in_place:
     Ap = torch.zeros((B, Np, Np), dtype=torch.float32, device=A.device)
     Ap[:, :N, :N] = A
     if n_nodes is None:
@@ -234,10 +238,17 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
   D = torch.empty((B, K), dtype=torch.float32, device=A.device)
   V = torch.empty((B, Np, K), dtype=torch.float32, device=A.device)
   info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
-  fb = torch.empty((B,), dtype=torch.int32, device=A.device) if (return_fallback and compact) else None
+  strided = A.stride(2) != 1
+  fb = torch.empty((B,), dtype=torch.int32, device=A.device) if ((return_fallback or strided) and compact) else None
   with torch.cuda.device(A.device):
-    _abi().lanczos_ritz_kstep(A, A.stride(0), A.stride(1), n_nodes, B, Np, M, K, flags, cap,
+    _abi().lanczos_ritz_kstep(A, A.stride(0), A.stride(1), A.stride(2), n_nodes, B, Np, M, K, flags, cap,
                               workspace, workspace.numel() * workspace.element_size(), D, V, info, fb)
+  if strided and bool(fb.any()):
+    # the dense streams read contiguous rows: a batch with a graph beyond the image's row capacity
+    # is copied after all (the flags are the only host read of this path)
+    return lanczos_ritz_kstep(A.contiguous(), n_nodes, M, K, symmetric=symmetric, compact=compact,
+                              row_cap=row_cap, workspace=workspace, return_info=return_info,
+                              return_fallback=return_fallback)
   if Np != N:
     V = V[:, :N, :].contiguous()
   out = (D, V)

@@ -205,6 +205,58 @@ def test_kstep_entry_dense_rows_fall_back_to_the_stream_in_the_same_call():
   assert (D8 - Dd).abs().max() < 1e-6 and _projector_gap(V8, Vd) < 1e-5
 
 
+def test_kstep_entry_reads_channel_0_of_the_collated_laplacian_in_place():
+  """`L[..., 0]` of the channels-last [B,N,N,2] tensor of the collate (column stride 2) goes to the
+  image kernel as it lies — no copy, spied on — and gives the pairs of the contiguous matrix (the
+  entries of a row are placed in another order: fp64 sums in another order); a batch with a graph
+  beyond the row capacity is copied after the look at the fallback flags and equals the dense call;
+  an unaligned width still takes the copy."""
+  from lanczosnet_amd import ops
+  N, M, B = 512, 32, 3
+  A = _graphs(B, N, 0.02, seed=5)
+  Ad = torch.from_numpy(A).to(DEV)
+  L = torch.stack([Ad, Ad * 0.5], dim=3)                     # channel 1 must not matter
+  copies = []
+  orig = torch.zeros
+
+  def spy(*a, **kw):
+    if len(a) and isinstance(a[0], tuple) and len(a[0]) == 3:
+      copies.append(a[0])
+    return orig(*a, **kw)
+  torch.zeros = spy
+  try:
+    Dv, Vv, info, fb = ops.lanczos_ritz_kstep(L[..., 0], None, M, M, return_info=True, return_fallback=True)
+    assert not copies and (fb == 0).all() and (info == M).all()
+    Dc, Vc = ops.lanczos_ritz_kstep(Ad, None, M, M)
+    assert not copies
+    assert (Dv - Dc).abs().max() < 1e-6 and _projector_gap(Vv, Vc) < 1e-5
+    nn = torch.tensor([N, 300, 77], dtype=torch.int32, device=DEV)       # ragged, in place
+    Ar = Ad.clone()
+    for b in range(B):
+      Ar[b, int(nn[b]):, :] = 0
+      Ar[b, :, int(nn[b]):] = 0
+    Lr = torch.stack([Ar, Ar], dim=3)
+    Dr, Vr = ops.lanczos_ritz_kstep(Lr[..., 0], nn, M, M)
+    Dr2, Vr2 = ops.lanczos_ritz_kstep(Ar, nn, M, M)
+    assert not copies and (Dr - Dr2).abs().max() < 1e-6 and _projector_gap(Vr, Vr2) < 1e-5
+    L2 = L.clone()
+    L2[1, 7, :200, 0] = 0.01                                   # a row beyond the capacity of 64
+    L2[1, :200, 7, 0] = 0.01
+    Df, Vf, fbf = ops.lanczos_ritz_kstep(L2[..., 0], None, M, M, return_fallback=True)
+    assert fbf.cpu().tolist() == [0, 1, 0]
+    Dd, Vd = ops.lanczos_ritz_kstep(L2[..., 0].contiguous(), None, M, M, compact=False)
+    assert torch.equal(Df[1], Dd[1]) and torch.equal(Vf[1], Vd[1])
+    assert (Df - Dd).abs().max() < 1e-6 and _projector_gap(Vf, Vd) < 1e-5
+    del copies[:]
+    Lo = torch.stack([Ad[:, :510, :510], Ad[:, :510, :510]], dim=3)      # N = 510: not a multiple of 4
+    Do, Vo = ops.lanczos_ritz_kstep(Lo[..., 0], None, M, M)
+    assert copies and Vo.shape == (B, 510, M)
+    Do2, Vo2 = ops.lanczos_ritz_kstep(Ad[:, :510, :510].contiguous(), None, M, M)
+    assert (Do - Do2).abs().max() < 1e-6 and _projector_gap(Vo, Vo2) < 1e-5
+  finally:
+    torch.zeros = orig
+
+
 def test_config5_from_raw_adjacency_through_the_dataset_mirror():
   """BASELINE config 5 end to end on the product surface, no hand-called kernel: raw adjacency ->
   `collate_graph_adjacency` (device L4; `ops.lanczos_ritz` routes 2048 nodes to the K-step entry,

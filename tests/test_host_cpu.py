@@ -310,7 +310,7 @@ def test_round6_host_side_queries_and_argument_checks_without_gpu():
   lib = _lib.load()
   null = C.c_void_p(None)
   # the K-step entry refuses before it launches: missing pointers, a capacity that is not a multiple of 8
-  rc = lib.lnz_lanczos_ritz_kstep(null, 0, 0, null, 1, 256, 8, 8, 2, 12, null, 0, null, null, null, null, null)
+  rc = lib.lnz_lanczos_ritz_kstep(null, 0, 0, 1, null, 1, 256, 8, 8, 2, 12, null, 0, null, null, null, null, null)
   assert rc == _lib.LNZ_EINVAL
   assert b'row_cap' in lib.lnz_last_error()
   assert lib.lnz_head_backward(null, null, null, null, null, null, null, null, 4, 20, 16, 128, 256,
