@@ -302,7 +302,8 @@ def test_round6_host_side_queries_and_argument_checks_without_gpu():
   assert ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 0, 0) == basis
   assert ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 1, 0) == basis            # symmetric: same workspace
   img = ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 3, 64) - basis
-  assert img >= B * (N // 64) * 64 * 64 * 6 and img < B * (N // 64) * 64 * 64 * 6 + B * (N // 64) * 4 + B * 4 + 4 * 256
+  # (image values + columns, slab widths, per-graph flags, per-row counts; 256-byte aligned regions)
+  assert img >= B * (N // 64) * 64 * 64 * 6 and img < B * (N // 64) * 64 * 64 * 6 + B * (N // 64) * 4 + B * 4 + B * N * 4 + 5 * 256
   assert ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 3, 256) > ns.raw_lanczos_ritz_kstep_workspace_bytes(B, N, 3, 64)
   assert [ops.kstep_row_cap(n) for n in (200, 512, 1024, 2048)] == [64, 64, 128, 256]
   assert ns.raw_head_backward_workspace_floats(16, 256) == 256 * (17 * 128 + 32 + 128)
