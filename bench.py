@@ -450,6 +450,15 @@ def large_graph_leg(dev, A, D, V, reps=3):
       out[name] = timed(lambda: net._large_graph_forward_hip(X, Lin, D, V, mask, planes=planes))
     sparse_flags = net._large_sparse_state[dev.index if dev.index is not None else 0]['last_flags']
     sparse_kernel = ops.last_kernel()
+    # the product surface: ONE pass over the collated L for the Ritz pairs and the conv image
+    # (dataset/graph_data.py collate_graph_adjacency -> ops.lanczos_ritz_collated), then the forward
+    import warnings
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      collated_ms, (Dc, Vc) = timed(lambda: ops.lanczos_ritz_collated(L, None, K))
+    fwd_img_ms, s_img = timed(lambda: net._large_graph_forward_hip(X, L, Dc, Vc, mask, planes=1))
+    image_from = net._large_sparse_state[dev.index if dev.index is not None else 0]['image_from']
+    del L._lnz_sparse_image
     net.large_fold = True
     classes = net._large_fold_classes(L)[0]
     folded = len(set(classes)) == 1
@@ -530,6 +539,13 @@ def large_graph_leg(dev, A, D, V, reps=3):
              'gather': {'kernel': 'sparse_conv_kernel', 'bound': 'L2 -> L1 path (256 B per nonzero)',
                         'bytes_per_launch': int(slots * 256),
                         'GBps': round(slots * 256 / sp_conv / 1e6, 1)}},
+         'product_surface': {
+             'what': 'ops.lanczos_ritz_collated(L) [lnz_lanczos_ritz_kstep_image: L[..., 0] of the collated '
+                     '[B,N,N,2] tensor read in place, ONCE, for the Ritz pairs and the conv image] + forward',
+             'ritz_pairs_and_image_ms': round(collated_ms, 3), 'forward_ms': round(fwd_img_ms, 3),
+             'image_from': image_from, 'end_to_end_ms': round(collated_ms + fwd_img_ms, 3),
+             'graphs_per_s': round(B / (collated_ms + fwd_img_ms) * 1e3, 1),
+             'vs_forward_with_own_image_rel': float((s_img - out['sparse'][1]).abs().max() / out['sparse'][1].abs().max())},
          'forward_streamed_ms': round(out['bf16'][0], 3),
          'forward_streamed_expanded_view_ms': round(out['bf16_view'][0], 3),
          'forward_unfolded_ms': round(out['bf16_unfolded'][0], 3),

@@ -287,6 +287,20 @@ int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r, i
                            int row_cap, void* workspace, int64_t workspace_bytes, float* D, float* V,
                            int32_t* info, int32_t* dense_fallback, lnz_stream_t stream);
 
+/* The same call leaving the image of lnz_large_sparse_image behind (csrc/conv_sparse.hip): the
+ * compaction pass has every entry of the row in hand (and, with stride_c = 2, the second channel of
+ * the collated pair), so conv_entries [B][N][conv_row_cap] / conv_counts [B][N] / conv_flags (one
+ * int32: bit 0 = the two channels differ somewhere — stride_c = 2 only; with stride_c = 1 the
+ * caller vouches for a single operator —, bit 1 = a row beyond conv_row_cap) cost no second read of
+ * L: one pass over the collated Laplacian per batch serves the Ritz pairs and all conv layers.
+ * LNZ_KSTEP_COMPACT required; conv_row_cap a multiple of 8, at least 32. */
+int lnz_lanczos_ritz_kstep_image(const float* A, int64_t stride_b, int64_t stride_r,
+                                 int64_t stride_c, const int32_t* n_nodes, int B, int N, int M, int K,
+                                 int flags, int row_cap, void* workspace, int64_t workspace_bytes,
+                                 float* D, float* V, int32_t* info, int32_t* dense_fallback,
+                                 uint32_t* conv_entries, int32_t* conv_counts, int conv_row_cap,
+                                 int32_t* conv_flags, lnz_stream_t stream);
+
 /* ---- operand packing (MFMA fragment order) -------------------------------------------
  * W [rows, cols] (leading dimension ld) -> Wp[rt][q][lane][u] =
  *   W[32*rt + (lane&31)][8*q + 4*(lane>>5) + u], zero padded to rows%32==0, cols%8==0.

@@ -378,11 +378,29 @@ struct EllImage {
 // waves, so the slab's width is an atomic max (widths zeroed by the caller) and the zero entries
 // up to it are written by ell_pad_kernel behind this launch.  4.3 GB in 0.67 ms (6.4 TB/s); the
 // r06 form with one wave per SLAB (a row's ballots behind the previous row's) ran at 4.2 TB/s.
+// The same pass can leave the image the large-graph conv gathers from (csrc/conv_sparse.hip,
+// lnz_large_sparse_image's format: entries [B][N][ccap] = bf16(value) << 16 | column in the SAME
+// entry order, counts, flag bits 0 = the two channels differ somewhere (PAIR only: both are in the
+// float4 anyway), 1 = a row beyond ccap) — the collated L is then read from HBM once per batch for
+// the Ritz pairs AND the seven conv layers.
+struct ConvImageOut {
+  unsigned* ent;      // NULL: not wanted
+  int32_t* counts;
+  int32_t* flags;
+  int cap;
+};
+typedef __bf16 lnz_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float lnz_f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline unsigned conv_entry(float v, int col) {   // (= conv_sparse.hip pack_entry: round to nearest even)
+  const lnz_bf16x2 p = __builtin_convertvector(lnz_f32x2{v, 0.0f}, lnz_bf16x2);
+  return ((unsigned)__builtin_bit_cast(unsigned short, p[0]) << 16) | (unsigned)col;
+}
+
 template <bool PAIR>
 __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
     const float* __restrict__ A, int64_t sb, int64_t sr, int B, int N, int cap,
     float* __restrict__ vals, uint16_t* __restrict__ cols, int32_t* __restrict__ widths,
-    int32_t* __restrict__ rowcnt, int32_t* __restrict__ over) {
+    int32_t* __restrict__ rowcnt, int32_t* __restrict__ over, ConvImageOut cv) {
   const int lane = threadIdx.x & 63;
   const int64_t rid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (rid >= (int64_t)B * N) return;
@@ -393,6 +411,8 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
   float* vs = vals + base;
   uint16_t* cs = cols + base;
   int k = 0;   // entries of this row so far (wave-uniform)
+  unsigned* ce = cv.ent ? cv.ent + rid * cv.cap : nullptr;
+  bool differ = false;
   auto place = [&](const float v, const int col) {
     const bool nz = v != 0.f;
     const unsigned long long m = __ballot(nz);
@@ -402,6 +422,7 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
       vs[(int64_t)pos * 64] = v;
       cs[(int64_t)pos * 64] = (uint16_t)col;
     }
+    if (ce && nz && pos < cv.cap) ce[pos] = conv_entry(v, col);
     k += __popcll(m);
   };
   const int nq = PAIR ? N >> 1 : N >> 2;   // float4s per row
@@ -416,6 +437,7 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
     for (int u = 0; u < 8; ++u) {
       const int q = q0 + 64 * u + lane;
       if (PAIR) {
+        differ |= (x[u].x != x[u].y) | (x[u].z != x[u].w);
         if (__ballot(x[u].x != 0.f || x[u].z != 0.f) == 0ull) continue;
         place(x[u].x, 2 * q);
         place(x[u].z, 2 * q + 1);
@@ -426,6 +448,16 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
         place(x[u].z, 4 * q + 2);
         place(x[u].w, 4 * q + 3);
       }
+    }
+  }
+  if (ce) {
+    const int c = k < cv.cap ? k : cv.cap;
+    if (c + lane < ((c + 7) & ~7)) ce[c + lane] = 0u;   // (the conv walks whole groups of eight)
+    const bool any_differ = __ballot(differ) != 0ull;
+    if (lane == 0) {
+      cv.counts[rid] = c;
+      const int f = (any_differ ? 1 : 0) | (k > cv.cap ? 2 : 0);
+      if (f) atomicOr(cv.flags, f);
     }
   }
   if (lane == 0) {
@@ -1006,13 +1038,10 @@ extern "C" int64_t lnz_lanczos_ritz_kstep_workspace_bytes(int B, int N, int flag
   return kstep_layout(B, N, flags, row_cap).total;
 }
 
-extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r,
-                                      int64_t stride_c, const int32_t* n_nodes, int B, int N, int M,
-                                      int K, int flags,
-                                      int row_cap, void* workspace, int64_t workspace_bytes, float* D,
-                                      float* V, int32_t* info, int32_t* dense_fallback,
-                                      lnz_stream_t stream) {
-  const char* who = "lnz_lanczos_ritz_kstep";
+static int kstep_launch(const char* who, const float* A, int64_t stride_b, int64_t stride_r,
+                        int64_t stride_c, const int32_t* n_nodes, int B, int N, int M, int K, int flags,
+                        int row_cap, void* workspace, int64_t workspace_bytes, float* D, float* V,
+                        int32_t* info, int32_t* dense_fallback, ConvImageOut cv, lnz_stream_t stream) {
   const bool sym = (flags & LNZ_KSTEP_SYMMETRIC) != 0;
   LNZ_REQUIRE(stride_c == 1 || (stride_c == 2 && (flags & LNZ_KSTEP_COMPACT) && dense_fallback),
               LNZ_ENOTSUP,
@@ -1049,7 +1078,8 @@ extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t 
   const int nslab = (N + 63) / 64;
   // (over and widths are neighbours in the workspace unless the caller keeps `over`: two memsets)
   if (hipMemsetAsync(over, 0, (size_t)B * 4, (hipStream_t)stream) != hipSuccess ||
-      hipMemsetAsync(widths, 0, (size_t)B * nslab * 4, (hipStream_t)stream) != hipSuccess) {
+      hipMemsetAsync(widths, 0, (size_t)B * nslab * 4, (hipStream_t)stream) != hipSuccess ||
+      (cv.ent && hipMemsetAsync(cv.flags, 0, 4, (hipStream_t)stream) != hipSuccess)) {
     lnz::set_error("%s: hipMemsetAsync failed", who);
     return LNZ_ELAUNCH;
   }
@@ -1057,10 +1087,10 @@ extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t 
   LNZ_REQUIRE(stride_c == 1 || N % 2 == 0, LNZ_ENOTSUP, "%s: stride_c = 2 needs an even N", who);
   if (stride_c == 2)
     hipLaunchKernelGGL(ell_compact_rows_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, B, N, row_cap, vals, cols, widths, rowcnt, over);
+                       (hipStream_t)stream, A, stride_b, stride_r, B, N, row_cap, vals, cols, widths, rowcnt, over, cv);
   else
     hipLaunchKernelGGL(ell_compact_rows_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, A, stride_b, stride_r, B, N, row_cap, vals, cols, widths, rowcnt, over);
+                       (hipStream_t)stream, A, stride_b, stride_r, B, N, row_cap, vals, cols, widths, rowcnt, over, cv);
   int rc = lnz::check_launch(who);
   if (rc != LNZ_OK) return rc;
   hipLaunchKernelGGL(ell_pad_kernel, dim3((unsigned)(((int64_t)B * nslab + 3) / 4)), dim3(256), 0,
@@ -1078,6 +1108,32 @@ extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t 
   if (stride_c != 1) return LNZ_OK;
   return launch_large(A, stride_b, stride_r, B, N, M, K, workspace, D, V, info, stream, sym, who, n_nodes,
                       (const int32_t*)over);
+}
+
+extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r,
+                                      int64_t stride_c, const int32_t* n_nodes, int B, int N, int M,
+                                      int K, int flags, int row_cap, void* workspace,
+                                      int64_t workspace_bytes, float* D, float* V, int32_t* info,
+                                      int32_t* dense_fallback, lnz_stream_t stream) {
+  return kstep_launch("lnz_lanczos_ritz_kstep", A, stride_b, stride_r, stride_c, n_nodes, B, N, M, K,
+                      flags, row_cap, workspace, workspace_bytes, D, V, info, dense_fallback,
+                      ConvImageOut{nullptr, nullptr, nullptr, 0}, stream);
+}
+
+extern "C" int lnz_lanczos_ritz_kstep_image(const float* A, int64_t stride_b, int64_t stride_r,
+                                            int64_t stride_c, const int32_t* n_nodes, int B, int N,
+                                            int M, int K, int flags, int row_cap, void* workspace,
+                                            int64_t workspace_bytes, float* D, float* V,
+                                            int32_t* info, int32_t* dense_fallback,
+                                            uint32_t* conv_entries, int32_t* conv_counts,
+                                            int conv_row_cap, int32_t* conv_flags, lnz_stream_t stream) {
+  const char* who = "lnz_lanczos_ritz_kstep_image";
+  LNZ_REQUIRE(flags & LNZ_KSTEP_COMPACT, LNZ_EINVAL, "%s: needs LNZ_KSTEP_COMPACT", who);
+  LNZ_REQUIRE(conv_entries && conv_counts && conv_flags && conv_row_cap >= 32 && conv_row_cap % 8 == 0,
+              LNZ_EINVAL, "%s: conv image outputs (row capacity a multiple of 8, at least 32)", who);
+  return kstep_launch(who, A, stride_b, stride_r, stride_c, n_nodes, B, N, M, K, flags, row_cap,
+                      workspace, workspace_bytes, D, V, info, dense_fallback,
+                      ConvImageOut{conv_entries, conv_counts, conv_flags, conv_row_cap}, stream);
 }
 
 extern "C" int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B,

@@ -83,7 +83,8 @@ def collate_graph_adjacency(items, num_eigs, device='cuda', model_name='LanczosN
                n_nodes=n_nodes)
     if num_eigs:
         # (the Ritz pairs are those of the L4 simple graph in every branch, graph_data.py:262-287)
-        out['D'], out['V'] = ops.lanczos_ritz(L[:, :, :, 0], n_nodes, num_eigs)
+        # (beyond 192 nodes the same pass over L also leaves the conv's sparse image riding on it)
+        out['D'], out['V'] = ops.lanczos_ritz_collated(L, n_nodes, num_eigs)
     if model_name == 'DCNN':
         L[:, :, :, 0] = ops.laplacian(adjs_d, n_nodes, 'L7')[:, :, :, 0]
     elif model_name == 'ChebyNet':

@@ -590,7 +590,9 @@ class _LanczosNetBase(nn.Module):
     # bf16 mode only (planes = 1).  The image kernel reads L once, keeps the nonzeros of channel 0
     # and reports (a) whether any other channel differs from channel 0 (the fold claim of
     # `_large_pack`, checked here for all channels at once) and (b) whether a row is too dense for
-    # the gather to beat the stream.  The flags come back through pinned memory behind the layer
+    # the gather to beat the stream (when the batch comes from `collate_graph_adjacency`, its K-step
+    # Lanczos pass over L has left that image riding on the tensor: L is read once per batch).
+    # The flags come back through pinned memory behind the layer
     # launches; a raised flag discards the result, the batch takes the streamed kernels, and the
     # next `large_sparse_backoff` calls on this device do not try again.
     large_sparse = os.environ.get('LANCZOSNET_LARGE_SPARSE', '1') != '0'
@@ -606,7 +608,10 @@ class _LanczosNetBase(nn.Module):
         if st.get('skip', 0) > 0:
             st['skip'] -= 1
             return None
-        img = ops.large_sparse_image(Lf)
+        img = ops.attached_sparse_image(Lf)   # left by the collate's Lanczos pass over this very tensor
+        st['image_from'] = 'collate' if img is not None else 'forward'
+        if img is None:
+            img = ops.large_sparse_image(Lf)
         host = st.get('host')
         if host is None:
             host = st['host'] = torch.zeros((1,), dtype=torch.int32).pin_memory()

@@ -203,7 +203,7 @@ def _warn_once(msg):
 
 
 def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=None,
-                       workspace=None, return_info=False, return_fallback=False):
+                       workspace=None, return_info=False, return_fallback=False, conv_image=None):
   """lnz_lanczos_ritz_kstep: M-step Lanczos Ritz pairs (top K by |theta|) of a ragged batch of
   large dense-stored graphs — the reference's `eigsh` branch (utils/data_helper.py:205-208).
   A [B,N,N] float32, any N <= 2048, n_nodes [B] or None.  Read in place: contiguous rows, or (compact)
@@ -212,7 +212,11 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
   compact: read A once and run the steps on its sliced-ELL image (graphs with a row of more than
   row_cap nonzeros take the dense stream in the same call — for the channels-last view after a look
   at the fallback flags and a copy); symmetric: the dense stream reads the upper chunk blocks only.
-  Returns D [B,K], V [B,N,K] (+ info [B] = steps taken) (+ fallback [B])."""
+  conv_image: None, or the row capacity of a LargeSparseImage to leave behind (lnz_lanczos_ritz_kstep_image:
+  the conv layers' image from the SAME pass over A; only when A is read in place — with a
+  contiguous A the caller vouches that A is the batch's one operator).  The image is appended to
+  the result (None when A had to be copied or the batch fell back to the dense stream).
+  Returns D [B,K], V [B,N,K] (+ info [B] = steps taken) (+ fallback [B]) (+ image)."""
   _need_cuda(A, n_nodes, workspace)
   assert A.dim() == 3 and A.shape[1] == A.shape[2] and A.dtype == torch.float32
   B, N, _ = A.shape
@@ -240,15 +244,25 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
   info = torch.empty((B,), dtype=torch.int32, device=A.device) if return_info else None
   strided = A.stride(2) != 1
   fb = torch.empty((B,), dtype=torch.int32, device=A.device) if ((return_fallback or strided) and compact) else None
+  img = None
   with torch.cuda.device(A.device):
-    _abi().lanczos_ritz_kstep(A, A.stride(0), A.stride(1), A.stride(2), n_nodes, B, Np, M, K, flags, cap,
-                              workspace, workspace.numel() * workspace.element_size(), D, V, info, fb)
+    if conv_image is not None and compact and in_place:
+      ccap = int(conv_image)
+      img = LargeSparseImage(torch.empty((B, N, ccap), dtype=torch.int32, device=A.device),
+                             torch.empty((B, N), dtype=torch.int32, device=A.device),
+                             torch.empty((1,), dtype=torch.int32, device=A.device), ccap)
+      _abi().lanczos_ritz_kstep_image(A, A.stride(0), A.stride(1), A.stride(2), n_nodes, B, Np, M, K, flags,
+                                      cap, workspace, workspace.numel() * workspace.element_size(), D, V,
+                                      info, fb, img.entries, img.counts, ccap, img.flags)
+    else:
+      _abi().lanczos_ritz_kstep(A, A.stride(0), A.stride(1), A.stride(2), n_nodes, B, Np, M, K, flags, cap,
+                                workspace, workspace.numel() * workspace.element_size(), D, V, info, fb)
   if strided and bool(fb.any()):
     # the dense streams read contiguous rows: a batch with a graph beyond the image's row capacity
     # is copied after all (the flags are the only host read of this path)
     return lanczos_ritz_kstep(A.contiguous(), n_nodes, M, K, symmetric=symmetric, compact=compact,
                               row_cap=row_cap, workspace=workspace, return_info=return_info,
-                              return_fallback=return_fallback)
+                              return_fallback=return_fallback) + ((None,) if conv_image is not None else ())
   if Np != N:
     V = V[:, :N, :].contiguous()
   out = (D, V)
@@ -256,6 +270,8 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
     out += (info,)
   if return_fallback:
     out += (fb,)
+  if conv_image is not None:
+    out += (img,)
   return out
 
 
@@ -460,11 +476,51 @@ class LargeSparseImage:
   int32 = bf16(value) << 16 | column, counts [B,N], flags (one int32 on the device: bit 0 = a
   channel differs from channel 0, bit 1 = a row overflowed `cap`; non-zero = the image must not be
   used)."""
-  __slots__ = ('entries', 'counts', 'flags', 'cap', 'B', 'N')
+  __slots__ = ('entries', 'counts', 'flags', 'cap', 'B', 'N', 'version')
 
   def __init__(self, entries, counts, flags, cap):
     self.entries, self.counts, self.flags, self.cap = entries, counts, flags, cap
     self.B, self.N = counts.shape
+    self.version = None   # the source tensor's version counter when the image rides on it (attach_sparse_image)
+
+
+def attach_sparse_image(L, img):
+  """Let the image ride on the tensor it was built from: `L._lnz_sparse_image`, stamped with L's
+  version counter — an in-place write to L (or any of its views) afterwards invalidates it, a copy
+  of L (`.to()`, `.clone()`, a DataParallel scatter) does not carry it."""
+  img.version = L._version
+  L._lnz_sparse_image = img
+
+
+def attached_sparse_image(L):
+  """The image riding on L (attach_sparse_image), or None when there is none or L changed since."""
+  img = getattr(L, '_lnz_sparse_image', None)
+  if img is None or img.version != L._version or (img.B, img.N) != tuple(L.shape[:2]) or \
+      img.entries.device != L.device:
+    return None
+  return img
+
+
+def lanczos_ritz_collated(L, n_nodes, K):
+  """The Ritz pairs of the collate: lanczos_ritz(L[:, :, :, 0], n_nodes, K) on the collated
+  L [B,N,N,C] (dataset/graph_data.py:262-287).  Beyond RITZ_FULL_MAX_N nodes the K-step entry reads
+  channel 0 in place, and where the layout allows (the channels-last pair of a single-edge-type
+  collate, or one operator in contiguous rows) the SAME pass over L leaves the large-graph conv's
+  image riding on L (attach_sparse_image): L is then read from HBM once per batch."""
+  B, N, _, Cn = L.shape
+  A = L[:, :, :, 0]
+  pair = Cn == 2 and L.stride(3) == 1 and L.stride(2) == 2
+  single = L.stride(2) == 1 and (Cn == 1 or L.stride(3) == 0)
+  if N <= RITZ_FULL_MAX_N or L.dtype != torch.float32 or not (pair or single) or N > 2048:
+    return lanczos_ritz(A, n_nodes, K)
+  _warn_once('lanczos_ritz: %d > %d nodes — Ritz pairs of the K-step Lanczos recurrence (the '
+             'reference\'s use_eigen_decomp=False / eigsh branch, utils/data_helper.py:205-208), not of '
+             'the full decomposition; converged leading pairs agree' % (N, RITZ_FULL_MAX_N))
+  D, V, img = lanczos_ritz_kstep(A, n_nodes.to(torch.int32).contiguous() if n_nodes is not None else None,
+                                 K, K, conv_image=large_sparse_row_cap(N))
+  if img is not None:
+    attach_sparse_image(L, img)
+  return D, V
 
 
 def large_sparse_row_cap(N):

@@ -251,3 +251,88 @@ def test_config5_shape_sparse_and_streamed_scores_agree():
   assert torch.isfinite(ss).all()
   assert (ss - sd).abs().max().item() <= 2e-3 * den
   assert (ss - sl).abs().max().item() <= 2e-2 * den
+
+
+def test_kstep_pass_leaves_the_conv_image_behind():
+  """lnz_lanczos_ritz_kstep_image: the compaction pass of the K-step entry writes the conv's image
+  too — bit for bit lnz_large_sparse_image's (same entry order), for the channels-last pair read
+  in place (channel difference and row overflow flagged alike) and for one operator in contiguous
+  rows; the Ritz pairs are those of the plain entry."""
+  from lanczosnet_amd import ops
+  B, N, K = 3, 512, 32
+  A, L = _sparse_L(B, N, 2, 0.02, 21, 'channels_last')
+  for b in range(B):                                         # (a Laplacian-like diagonal: no empty Krylov start)
+    L[b, range(N), range(N), :] += 1.0
+  D0, V0 = ops.lanczos_ritz_kstep(L[..., 0], None, K, K)
+  D1, V1, img = ops.lanczos_ritz_kstep(L[..., 0], None, K, K, conv_image=64)
+  assert torch.equal(D0, D1) and torch.equal(V0, V1)
+  ref = ops.large_sparse_image(L, 64)
+  assert int(img.flags.item()) == 0 and int(ref.flags.item()) == 0
+  assert torch.equal(img.counts, ref.counts)
+  keep = (torch.arange(64, device=DEV)[None, None, :] < ((ref.counts + 7) // 8 * 8)[:, :, None])
+  assert torch.equal(img.entries[keep], ref.entries[keep])
+  L2 = L.clone()
+  L2[1, 9, 11, 1] += 0.5
+  _, _, img2 = ops.lanczos_ritz_kstep(L2[..., 0], None, K, K, conv_image=64)
+  assert int(img2.flags.item()) == 1
+  _, _, img3 = ops.lanczos_ritz_kstep(L[..., 0], None, K, K, conv_image=32)
+  assert int(img3.flags.item()) == int(ops.large_sparse_image(L, 32).flags.item())
+  Ac = L[..., 0].contiguous()                                # one operator, contiguous rows
+  D4, V4, img4 = ops.lanczos_ritz_kstep(Ac, None, K, K, conv_image=64)
+  ref4 = ops.large_sparse_image(Ac.unsqueeze(3), 64)
+  assert int(img4.flags.item()) == 0 and torch.equal(img4.counts, ref4.counts)
+  assert torch.equal(img4.entries[keep], ref4.entries[keep])
+  assert (D4 - D0).abs().max() < 1e-6
+  Lo = L[:, :510, :510]                                      # not read in place: no image
+  assert ops.lanczos_ritz_kstep(Lo[..., 0], None, K, K, conv_image=64)[2] is None
+
+
+def test_collate_leaves_the_image_on_L_and_the_module_uses_it():
+  """`collate_graph_adjacency` on graphs beyond 192 nodes: ONE pass over L gives the Ritz pairs and
+  leaves the conv's image riding on the tensor; the module (bf16 mode) finds it — no image launch of
+  its own — and scores as with its own image; an in-place write to L afterwards invalidates it."""
+  import warnings
+  from large_fixture import adjacency
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.dataset.graph_data import collate_graph_adjacency
+  from lanczosnet_amd.model import LanczosNetGeneral
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  B, N, K = 3, 256, 32
+  cfg, P, X, L, mask = general_inputs(B, N, K, 3, 7, 8.0 / N)
+  adj = adjacency(B, N, 8.0 / N, 7)
+  items = [dict(adjs=adj[b][:, :, None].astype(np.float32), node_feat=X[b], label=np.zeros((1, 2)))
+           for b in range(B)]
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    batch = collate_graph_adjacency(items, K, device=DEV)
+  Ld = batch['L']
+  img = ops.attached_sparse_image(Ld)
+  assert img is not None and int(img.flags.item()) == 0 and img.cap == ops.large_sparse_row_cap(N)
+  own = ops.large_sparse_image(Ld)
+  assert torch.equal(img.counts, own.counts)
+  net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval()
+  net.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+  net = net.to(DEV)
+  net.gemm_mode = 'bf16'
+  md = torch.from_numpy(mask).to(DEV)
+  calls = []
+  orig = ops.large_sparse_image
+
+  def spy(*a, **kw):
+    calls.append(1)
+    return orig(*a, **kw)
+  ops.large_sparse_image = spy
+  try:
+    with torch.no_grad():
+      s1 = net(batch['node_feat'], Ld, batch['D'], batch['V'], mask=md)
+      st = net._large_sparse_state[Ld.device.index]
+      assert not calls and st['image_from'] == 'collate' and st['last_flags'] == 0
+      s2 = net(batch['node_feat'], Ld.clone(), batch['D'], batch['V'], mask=md)    # a copy does not carry it
+      assert len(calls) == 1 and st['image_from'] == 'forward'
+      assert (s1 - s2).abs().max() <= 2e-3 * s2.abs().max()
+      Ld[0, 0, 0, :] += 0.0                                   # an in-place write: the version moves on
+      assert ops.attached_sparse_image(Ld) is None
+      net(batch['node_feat'], Ld, batch['D'], batch['V'], mask=md)
+      assert len(calls) == 2 and st['image_from'] == 'forward'
+  finally:
+    ops.large_sparse_image = orig
