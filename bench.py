@@ -362,6 +362,64 @@ def graph_config_leg(dev, B=64, reps=5):
                           'note': 'issued matrix instructions x 2048 flop / launch time; about 40 % of the launch '
                                   'is the per-layer exchange between the four workgroups of a graph (DESIGN.md 4.5c)'},
              'streamed_large_graph_kernels_ms': round(streamed_ms, 4)}
+  # The stream mode: the Ritz launch keeps 64 of 256 compute units busy for 0.45 ms and the forward
+  # needs its result — but the NEXT batch's does not.  Two streams: Laplacian + Ritz pairs of batch
+  # k + 1 beside the forward of batch k (each half a captured HIP graph, double-buffered outputs,
+  # events both ways), on DISJOINT compute units (hipExtStreamCreateWithCUMask: sharing them
+  # stretches the Ritz chain to 0.60 ms and the overlap buys nothing).  A secondary line: per-batch
+  # time of a stream of batches, not the latency of one.
+  pipelined = None
+  try:
+    from lanczosnet_amd.utils.streams import cu_masked_stream
+    with torch.no_grad():
+      cu_split = 64
+      s_prep, s_fwd = cu_masked_stream(0, cu_split, dev), cu_masked_stream(cu_split, 256, dev)
+      torch.cuda.synchronize()
+      slots = []
+      for i in range(2):
+        sl = {'gp': torch.cuda.CUDAGraph(), 'gf': torch.cuda.CUDAGraph()}
+        with torch.cuda.stream(s_prep):
+          with torch.cuda.graph(sl['gp'], stream=s_prep):
+            sl['L'] = ops.laplacian_l4(ad, nd)
+            sl['D'], sl['V'] = ops.lanczos_ritz(sl['L'][:, :, :, 0], nd, K)
+        with torch.cuda.stream(s_fwd):
+          with torch.cuda.graph(sl['gf'], stream=s_fwd):
+            sl['score'] = net(Xd, sl['L'], sl['D'], sl['V'], mask=md)
+        slots.append(sl)
+      torch.cuda.synchronize()
+
+      def prep(sl):
+        with torch.cuda.stream(s_prep):
+          if 'done' in sl:
+            s_prep.wait_event(sl['done'])
+          sl['gp'].replay()
+          sl['ready'] = torch.cuda.Event()
+          sl['ready'].record(s_prep)
+
+      def fwd_(sl):
+        with torch.cuda.stream(s_fwd):
+          s_fwd.wait_event(sl['ready'])
+          sl['gf'].replay()
+          sl['done'] = torch.cuda.Event()
+          sl['done'].record(s_fwd)
+      nb = 100
+      for warm in (True, False):
+        prep(slots[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(nb):
+          prep(slots[(k + 1) & 1])
+          fwd_(slots[k & 1])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nb * 1e3
+      pipelined = {'ms_per_batch': round(dt, 4), 'graphs_per_s': round(B / dt * 1e3, 1), 'batches': nb,
+                   'how': 'two HIP streams on disjoint compute units (%d for L4 + Ritz pairs of batch k+1, %d for '
+                          'the forward of batch k), each half a captured HIP graph; wall clock over %d batches'
+                          % (cu_split, 256 - cu_split, nb),
+                   'scores_equal_sequential': bool(torch.equal(slots[(nb - 1) & 1]['score'], score))}
+      del slots
+  except Exception as e:   # (a secondary line: the leg's numbers above do not depend on it)
+    pipelined = {'error': repr(e)[:200]}
   t0 = time.perf_counter()
   Ln = L[:16, :, :, 0].cpu().numpy().astype(np.float64)
   worst = 0.0
@@ -388,6 +446,7 @@ def graph_config_leg(dev, B=64, reps=5):
                    'max_abs_dD_vs_numpy_eigh_16_graphs': worst,
                    'host_numpy_eigh_ms_per_graph': round(eigh_ms, 4)},
           'forward': fwd,
+          'stream_of_batches_two_streams': pipelined,
           'finite': bool(torch.isfinite(score).all())}
 
 

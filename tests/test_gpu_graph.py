@@ -389,3 +389,80 @@ def test_workgroup_ritz_kernel_on_forests_of_equal_stars(N):
     lam = np.linalg.eigvalsh(A[b, :n, :n].cpu().numpy())
     want = np.sort(lam[np.argsort(-np.abs(lam), kind='mergesort')][:K])
     assert np.abs(np.sort(Dd[b].cpu().numpy()) - want).max() < 1e-6
+
+
+def test_two_stage_stream_of_batches_on_disjoint_compute_units():
+  """utils/streams.cu_masked_stream: the graph configuration as a stream of batches — L4 + Ritz pairs
+  of batch k+1 on 64 compute units beside the forward of batch k on the other 192, each half a
+  captured HIP graph — gives the scores of the sequential step bitwise."""
+  from lanczosnet_amd import ops
+  from lanczosnet_amd.model import LanczosNetGeneral
+  from lanczosnet_amd.utils.arg_helper import make_model_config
+  from lanczosnet_amd.utils.streams import cu_masked_stream
+  dev = torch.device(DEV)
+  B, K = 16, 20
+  cfg = dict(num_bond_type=1, short_diffusion_dist=[], long_diffusion_dist=[1, 2, 3, 5, 7, 10, 20, 30],
+             num_eig_vec=K, spectral_filter_kind='MLP', input_dim=10, hidden_dim=[128] * 7,
+             output_dim=2, num_layer=7, num_atom=0)
+  rs = np.random.RandomState(5)
+  ns = rs.randint(20, 101, size=B).astype(np.int32)
+  N = int(ns.max())
+  torch.manual_seed(3)
+  net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval().to(dev)
+  batches = []
+  for _ in range(3):
+    adjs = np.zeros((B, N, N, 1), np.float32)
+    for b in range(B):
+      a = np.triu((rs.rand(ns[b], ns[b]) < 0.5).astype(np.float32), 1)
+      adjs[b, :ns[b], :ns[b], 0] = a + a.T
+    batches.append(torch.from_numpy(adjs).to(dev))
+  nd = torch.from_numpy(ns).to(dev)
+  Xd = torch.from_numpy(rs.randn(B, N, 10).astype(np.float32)).to(dev)
+  md = torch.from_numpy((np.arange(N)[None, :] < ns[:, None]).astype(np.uint8)).to(dev)
+  with torch.no_grad():
+    refs = []
+    for ad in batches:
+      L = ops.laplacian_l4(ad, nd)
+      D, V = ops.lanczos_ritz(L[:, :, :, 0], nd, K)
+      refs.append(net(Xd, L, D, V, mask=md))
+    torch.cuda.synchronize()
+    s_prep, s_fwd = cu_masked_stream(0, 64, dev), cu_masked_stream(64, 256, dev)
+    ad_in = batches[0].clone()
+    slots = []
+    for i in range(2):
+      sl = {'gp': torch.cuda.CUDAGraph(), 'gf': torch.cuda.CUDAGraph()}
+      with torch.cuda.stream(s_prep):
+        with torch.cuda.graph(sl['gp'], stream=s_prep):
+          sl['L'] = ops.laplacian_l4(ad_in, nd)
+          sl['D'], sl['V'] = ops.lanczos_ritz(sl['L'][:, :, :, 0], nd, K)
+      with torch.cuda.stream(s_fwd):
+        with torch.cuda.graph(sl['gf'], stream=s_fwd):
+          sl['score'] = net(Xd, sl['L'], sl['D'], sl['V'], mask=md)
+      slots.append(sl)
+    torch.cuda.synchronize()
+    got = []
+
+    def prep(sl, ad):
+      with torch.cuda.stream(s_prep):
+        if 'done' in sl:
+          s_prep.wait_event(sl['done'])
+        ad_in.copy_(ad)
+        sl['gp'].replay()
+        sl['ready'] = torch.cuda.Event()
+        sl['ready'].record(s_prep)
+
+    def fwd(sl):
+      with torch.cuda.stream(s_fwd):
+        s_fwd.wait_event(sl['ready'])
+        sl['gf'].replay()
+        got.append(sl['score'].clone())
+        sl['done'] = torch.cuda.Event()
+        sl['done'].record(s_fwd)
+    prep(slots[0], batches[0])
+    for k in range(3):
+      if k + 1 < 3:
+        prep(slots[(k + 1) & 1], batches[k + 1])
+      fwd(slots[k & 1])
+    torch.cuda.synchronize()
+  for k in range(3):
+    assert torch.equal(got[k], refs[k])
