@@ -119,4 +119,28 @@ with torch.no_grad():
     dt = (time.perf_counter() - t0) / nb * 1e3
   res['two_streams_graphs_ms_per_batch'] = dt
   res['two_streams_equal'] = bool(torch.equal(slots[(nb - 1) & 1]['score'], ref))
+  # the Ritz launch is one latency chain per graph: 256 graphs take as long as 64 (0.46 ms) — a
+  # loader that collates four batches ahead shares ONE Laplacian + Ritz launch among them
+  ad4, nd4 = torch.cat([ad] * 4), torch.cat([nd] * 4)
+  g4 = torch.cuda.CUDAGraph()
+  s4 = torch.cuda.Stream()
+  s4.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(s4):
+    def four():
+      L4 = ops.laplacian_l4(ad4, nd4)
+      D4, V4 = ops.lanczos_ritz(L4[:, :, :, 0], nd4, K)
+      return [net(Xd, L4[B * i:B * (i + 1)], D4[B * i:B * (i + 1)], V4[B * i:B * (i + 1)], mask=md) for i in range(4)]
+    four()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g4, stream=s4):
+      outs = four()
+  torch.cuda.current_stream().wait_stream(s4)
+  g4.replay()
+  torch.cuda.synchronize()
+  res['four_batches_one_ritz_launch_equal'] = bool(all(torch.equal(o, ref) for o in outs))
+  t0 = time.perf_counter()
+  for _ in range(25):
+    g4.replay()
+  torch.cuda.synchronize()
+  res['four_batches_one_ritz_launch_ms_per_batch'] = (time.perf_counter() - t0) / 100 * 1e3
 print(json.dumps(res))
