@@ -25,6 +25,8 @@
 //   lnz_large_sparse_conv    X[r][:] = act( X[r][:] + sum_k value[r][k] Z[column[r][k]][:] )
 //
 // — the streamed form's products (bf16 x bf16, fp32 accumulate) without the zeros, in entry order.
+// (The same image falls out of the K-step Lanczos entry's own pass over L: lnz_lanczos_ritz_kstep_image,
+// csrc/lanczos_large.hip — the collated Laplacian is then read from HBM once per batch.)
 #include "common.hpp"
 
 namespace {
