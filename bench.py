@@ -533,6 +533,7 @@ def large_graph_leg(dev, A, D, V, reps=3):
     net._large_graph_forward_hip(X, L, D, V, mask, planes=1)   # first batch: learns the fold
     for name, planes, Lin, fold, sparse in (('bf16', 1, L, True, False), ('bf16_view', 1, Lx, True, False),
                                             ('split3', 3, L, True, False), ('bf16_unfolded', 1, L, False, False),
+                                            ('split3_sparse', 3, L, True, True),
                                             ('sparse', 1, L, True, True), ('sparse_view', 1, Lx, True, True)):
       net.large_fold, net.large_sparse = fold, sparse
       out[name] = timed(lambda: net._large_graph_forward_hip(X, Lin, D, V, mask, planes=planes))
@@ -637,7 +638,12 @@ def large_graph_leg(dev, A, D, V, reps=3):
          'forward_streamed_ms': round(out['bf16'][0], 3),
          'forward_streamed_expanded_view_ms': round(out['bf16_view'][0], 3),
          'forward_unfolded_ms': round(out['bf16_unfolded'][0], 3),
-         'split_precision_forward_ms': round(out['split3'][0], 3),
+         'split_precision_forward_ms': round(out['split3_sparse'][0], 3),
+         'split_precision_path': 'the module\'s default in the fp32 modes: sparse image with fp32 values, node-space '
+                                 'term in EXACT fp32 (lnz_f32_linear + lnz_large_sparse_conv_f32), lift from 3 bf16 pieces',
+         'split_precision_streamed_forward_ms': round(out['split3'][0], 3),
+         'split_precision_sparse_vs_streamed_rel': float((out['split3_sparse'][1] - out['split3'][1]).abs().max() /
+                                                         out['split3'][1].abs().max()),
          'bf16_vs_split_precision_rel': dev_rel,
          'channel_fold': {'classes': list(classes), 'operators_streamed': Cd, 'of_channels': 2,
                           'folded_vs_unfolded_rel': fold_rel,

@@ -203,7 +203,8 @@ int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt, c
  *                            bf16(value) << 16 | column (rounded to nearest even, as
  *                            lnz_large_pack_operators rounds), counts [B][N] i32: the nonzeros of
  *                            channel 0 row by row (fixed order; zero padded to a multiple of 8 per
- *                            row).  flags (one device int32, cleared by the call): bit 0 = a
+ *                            row); values (optional, NULL to skip): the same entries' fp32
+ *                            values [B][N][row_cap].  flags (one device int32, cleared by the call): bit 0 = a
  *                            channel differs from channel 0 somewhere, bit 1 = a row holds more
  *                            than row_cap nonzeros (row_cap a multiple of 8, >= 32; N <= 65536).
  *                            A non-zero flag means the image must NOT be used: the caller reads it
@@ -217,13 +218,21 @@ int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt, c
  *                            nothing (the streamed kernels multiply it: 0 x inf = NaN there). */
 int lnz_large_sparse_image(const float* L, int64_t stride_b, int64_t stride_r, int64_t stride_c,
                            int64_t stride_ch, int B, int N, int C, int row_cap, uint32_t* entries,
-                           int32_t* counts, int32_t* flags, lnz_stream_t stream);
+                           float* values, int32_t* counts, int32_t* flags, lnz_stream_t stream);
 int lnz_large_pack_vectors(const float* V, int B, int N, int K, int planes, uint16_t* Vb,
                            lnz_stream_t stream);
 int lnz_large_gemm1_rows(const float* X, int ldx, int din, const uint16_t* Wf, int B, int N,
                          uint16_t* Z, lnz_stream_t stream);
 int lnz_large_sparse_conv(const uint32_t* entries, const int32_t* counts, int row_cap,
                           const uint16_t* Z, int B, int N, int relu, float* X, lnz_stream_t stream);
+/* The node-space term of the split-precision modes (planes = 2, 3) in EXACT fp32 on the same image:
+ * values [B][N][row_cap] fp32 (lnz_large_sparse_image's optional output: the unrounded entries, in
+ * the entries' order), Zf [B][N][128] fp32 = X W^T (lnz_f32_linear on the [B N, din] states):
+ * X[r] = act( X[r] + sum_k values[r][k] Zf[column[r][k]] ), fp32 fma in entry order.  A layer =
+ * lnz_f32_linear + lnz_large_spectral(planes) + lnz_large_conv(C = 0, planes) + this. */
+int lnz_large_sparse_conv_f32(const uint32_t* entries, const float* values, const int32_t* counts,
+                              int row_cap, const float* Zf, int B, int N, int relu, float* X,
+                              lnz_stream_t stream);
 
 /* ---- R6 standalone: batched symmetric tridiagonal eigensolver --------------------------------
  * The step the reference leaves to LAPACK (inside np.linalg.eigh, utils/data_helper.py:201) /
@@ -300,6 +309,15 @@ int lnz_lanczos_ritz_kstep_image(const float* A, int64_t stride_b, int64_t strid
                                  float* D, float* V, int32_t* info, int32_t* dense_fallback,
                                  uint32_t* conv_entries, int32_t* conv_counts, int conv_row_cap,
                                  int32_t* conv_flags, lnz_stream_t stream);
+
+/* A HIP stream whose kernels run on compute units [first_cu, end_cu) of the current device only
+ * (hipExtStreamCreateWithCUMask).  For latency-chain launches that fill a fraction of the chip —
+ * the workgroup-per-graph Ritz launch of the reference's graph configuration keeps 64 of 256
+ * compute units busy for 0.45 ms — next to the previous batch's forward: on shared compute units
+ * the forward's waves stretch the chain to 0.60 ms and the overlap buys nothing; on disjoint ones a
+ * batch of the stream takes 0.50 instead of 0.67 ms.  The stream is the caller's
+ * (hipStreamDestroy). */
+int lnz_stream_create_cu_masked(int first_cu, int end_cu, lnz_stream_t* stream);
 
 /* ---- operand packing (MFMA fragment order) -------------------------------------------
  * W [rows, cols] (leading dimension ld) -> Wp[rt][q][lane][u] =

@@ -67,6 +67,7 @@ SIGNATURES = {
     'lnz_lanczos_ritz_kstep_workspace_bytes': (C.c_int64, [_I, _I, _I, _I]),
     'lnz_lanczos_ritz_kstep': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P]),
     'lnz_lanczos_ritz_kstep_image': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'lnz_stream_create_cu_masked': (C.c_int, [_I, _I, _P]),
     'lnz_head_backward_workspace_floats': (C.c_int64, [_I, _I]),
     'lnz_head_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'lnz_node_extents': (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
@@ -78,7 +79,8 @@ SIGNATURES = {
     'lnz_large_gemm1': (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
     'lnz_large_spectral': (C.c_int, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'lnz_large_conv': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    'lnz_large_sparse_image': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'lnz_large_sparse_image': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'lnz_large_sparse_conv_f32': (C.c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
     'lnz_large_pack_vectors': (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     'lnz_large_gemm1_rows': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _P]),
     'lnz_large_sparse_conv': (C.c_int, [_P, _P, _I, _P, _I, _I, _I, _P, _P]),

@@ -61,7 +61,7 @@ __device__ inline int lane_rank(unsigned long long m) {  // set bits of m below 
 template <int FORM>
 __global__ __launch_bounds__(256) void sparse_image_kernel(
     const float* __restrict__ L, int64_t sb, int64_t sr, int64_t sc, int64_t sch, int B, int N, int C,
-    int cap, unsigned* __restrict__ ent, int32_t* __restrict__ counts,
+    int cap, unsigned* __restrict__ ent, float* __restrict__ vals, int32_t* __restrict__ counts,
     int32_t* __restrict__ flags) {
   const int lane = threadIdx.x & 63;
   const int64_t rid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void sparse_image_kernel(
   const int b = (int)(rid / N), r = (int)(rid - (int64_t)b * N);
   const float* Lr = L + (int64_t)b * sb + (int64_t)r * sr;
   unsigned* oe = ent + rid * cap;
+  float* ov = vals ? vals + rid * cap : nullptr;   // (the exact-fp32 form's values, optional)
   int k = 0;            // entries of this row so far (wave-uniform)
   bool differ = false;  // a channel differs from channel 0 in this lane's columns
   auto place = [&](const float v, const int col) {
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(256) void sparse_image_kernel(
     const unsigned long long m = __ballot(nz);
     if (m == 0ull) return;
     const int pos = k + lane_rank(m);
-    if (nz && pos < cap) oe[pos] = pack_entry(v, col);
+    if (nz && pos < cap) {
+      oe[pos] = pack_entry(v, col);
+      if (ov) ov[pos] = v;
+    }
     k += __popcll(m);
   };
   if constexpr (FORM == 1) {
@@ -140,7 +144,10 @@ __global__ __launch_bounds__(256) void sparse_image_kernel(
   }
   const int cnt = k < cap ? k : cap;
   const int cnt8 = (cnt + 7) & ~7;   // (cap is a multiple of 8) the conv walks whole groups of eight
-  if (cnt + lane < cnt8) oe[cnt + lane] = 0u;
+  if (cnt + lane < cnt8) {
+    oe[cnt + lane] = 0u;
+    if (ov) ov[cnt + lane] = 0.0f;
+  }
   const bool any_differ = __ballot(differ) != 0ull;
   if (lane == 0) {
     counts[rid] = cnt;
@@ -229,12 +236,87 @@ __global__ __launch_bounds__(64 * WAVES) void sparse_conv_kernel(
   }
 }
 
+// ---- the same in exact fp32 (the split-precision modes' node-space term): fp32 values x fp32
+// features, Zf [B][N][128] fp32 (= lnz_f32_linear's X W^T), a lane's dwordx2 = features 2 lane,
+// 2 lane + 1: 512 B through the L2 -> L1 path per nonzero (twice the bf16 form's), no unpacking.
+__global__ __launch_bounds__(64 * WAVES) void sparse_conv_f32_kernel(
+    const unsigned* __restrict__ ent, const float* __restrict__ vals, const int32_t* __restrict__ counts,
+    int cap, const float* __restrict__ Zf, int B, int N, int tiles, int relu, float* __restrict__ X) {
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int b = xcd + 8 * (seq / tiles), tile = seq % tiles;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r0 = tile * TILE_ROWS + wave * ROWS_PER_WAVE;
+  if (r0 >= N) return;
+  const int nr = min(ROWS_PER_WAVE, N - r0);
+  const int64_t row0 = (int64_t)b * N + r0;
+  const int cv = lane < nr ? counts[row0 + lane] : 0;
+  const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(Zf + (int64_t)b * N * DH), 0, (unsigned)N * DH * 4, 0x00020000);
+  const unsigned zoff = 8u * lane;
+  auto entries = [&](const int rr, const int k0, const int cnt8, unsigned& e, float& v) {
+    const bool in = k0 + lane < cnt8;
+    const int64_t o = (row0 + rr) * cap + k0 + lane;
+    e = in ? ent[o] : 0u;
+    v = in ? vals[o] : 0.0f;
+  };
+  int cnt8n = (__builtin_amdgcn_readlane(cv, 0) + 7) & ~7;
+  unsigned en;
+  float vn;
+  entries(0, 0, cnt8n, en, vn);
+  for (int rr = 0; rr < nr; ++rr) {
+    const int cnt8 = cnt8n;
+    unsigned e = en;
+    float v = vn;
+    float* xr = X + (row0 + rr) * DH + 2 * lane;
+    f32x2 acc = *reinterpret_cast<const f32x2*>(xr);
+    if (rr + 1 < nr) {   // (uniform) the next row's entries
+      cnt8n = (__builtin_amdgcn_readlane(cv, rr + 1) + 7) & ~7;
+      entries(rr + 1, 0, cnt8n, en, vn);
+    }
+    for (int k0 = 0; k0 < cnt8; k0 += 64) {
+      if (k0 > 0) entries(rr, k0, cnt8, e, v);   // (rows of more than 64 entries)
+      const int m = min(64, cnt8 - k0);
+      for (int k = 0; k < m; k += 16) {
+        f32x2 z[2][8];
+        float s[2][8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (k + 8 * g < m) {   // (uniform)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const unsigned col = (unsigned)__builtin_amdgcn_readlane((int)e, k + 8 * g + u) & 0xffffu;
+              s[g][u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k + 8 * g + u));
+              z[g][u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, zoff, col * (DH * 4), 0));
+            }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (k + 8 * g < m) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              acc[0] = fmaf(s[g][u], z[g][u][0], acc[0]);
+              acc[1] = fmaf(s[g][u], z[g][u][1], acc[1]);
+            }
+          }
+        }
+      }
+    }
+    if (relu) {
+      acc[0] = acc[0] > 0.0f ? acc[0] : 0.0f;
+      acc[1] = acc[1] > 0.0f ? acc[1] : 0.0f;
+    }
+    *reinterpret_cast<f32x2*>(xr) = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int lnz_large_sparse_image(const float* L, int64_t stride_b, int64_t stride_r,
                                       int64_t stride_c, int64_t stride_ch, int B, int N, int C,
-                                      int row_cap, uint32_t* entries, int32_t* counts,
-                                      int32_t* flags, lnz_stream_t stream) {
+                                      int row_cap, uint32_t* entries, float* values,
+                                      int32_t* counts, int32_t* flags, lnz_stream_t stream) {
   LNZ_REQUIRE(L && entries && counts && flags && B > 0 && N > 0 && C > 0, LNZ_EINVAL,
               "lnz_large_sparse_image: bad arguments (B=%d N=%d C=%d)", B, N, C);
   LNZ_REQUIRE(N <= 65536, LNZ_ENOTSUP, "lnz_large_sparse_image: N=%d > 65536 (16-bit columns)", N);
@@ -251,13 +333,13 @@ extern "C" int lnz_large_sparse_image(const float* L, int64_t stride_b, int64_t 
   const dim3 grid((unsigned)((rows + 3) / 4));
   if (pair)
     hipLaunchKernelGGL(sparse_image_kernel<2>, grid, dim3(256), 0, s, L, stride_b, stride_r,
-                       stride_c, stride_ch, B, N, C, row_cap, entries, counts, flags);
+                       stride_c, stride_ch, B, N, C, row_cap, entries, values, counts, flags);
   else if (rows1)
     hipLaunchKernelGGL(sparse_image_kernel<1>, grid, dim3(256), 0, s, L, stride_b, stride_r,
-                       stride_c, stride_ch, B, N, C, row_cap, entries, counts, flags);
+                       stride_c, stride_ch, B, N, C, row_cap, entries, values, counts, flags);
   else
     hipLaunchKernelGGL(sparse_image_kernel<0>, grid, dim3(256), 0, s, L, stride_b, stride_r,
-                       stride_c, stride_ch, B, N, C, row_cap, entries, counts, flags);
+                       stride_c, stride_ch, B, N, C, row_cap, entries, values, counts, flags);
   lnz::note_kernel("sparse_image_kernel<%s>", pair ? "pair" : rows1 ? "rows" : "strided");
   return lnz::check_launch("lnz_large_sparse_image");
 }
@@ -277,4 +359,23 @@ extern "C" int lnz_large_sparse_conv(const uint32_t* entries, const int32_t* cou
                      (hipStream_t)stream, entries, counts, row_cap, Z, B, N, tiles, relu, X);
   lnz::note_kernel("sparse_conv_kernel");
   return lnz::check_launch("lnz_large_sparse_conv");
+}
+
+extern "C" int lnz_large_sparse_conv_f32(const uint32_t* entries, const float* values,
+                                         const int32_t* counts, int row_cap, const float* Zf, int B,
+                                         int N, int relu, float* X, lnz_stream_t stream) {
+  LNZ_REQUIRE(entries && values && counts && Zf && X && B > 0 && N > 0, LNZ_EINVAL,
+              "lnz_large_sparse_conv_f32: bad arguments");
+  LNZ_REQUIRE(row_cap >= 32 && row_cap % 8 == 0, LNZ_EINVAL,
+              "lnz_large_sparse_conv_f32: row_cap=%d must be a multiple of 8, at least 32", row_cap);
+  LNZ_REQUIRE((((uintptr_t)X) & 7) == 0 && (((uintptr_t)Zf) & 7) == 0, LNZ_EINVAL,
+              "lnz_large_sparse_conv_f32: X / Zf must be 8-byte aligned");
+  LNZ_REQUIRE((int64_t)N * DH * 4 <= 0x7fffffffll, LNZ_ENOTSUP, "lnz_large_sparse_conv_f32: N too large");
+  const int tiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+  const int64_t grid = (int64_t)8 * tiles * ((B + 7) / 8);
+  LNZ_REQUIRE(grid <= 0x7fffffffll, LNZ_ENOTSUP, "lnz_large_sparse_conv_f32: B x N too large");
+  hipLaunchKernelGGL(sparse_conv_f32_kernel, dim3((unsigned)grid), dim3(64 * WAVES), 0,
+                     (hipStream_t)stream, entries, values, counts, row_cap, Zf, B, N, tiles, relu, X);
+  lnz::note_kernel("sparse_conv_f32_kernel");
+  return lnz::check_launch("lnz_large_sparse_conv_f32");
 }

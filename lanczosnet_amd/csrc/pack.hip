@@ -291,3 +291,23 @@ extern "C" int lnz_plan_tiles(const uint8_t* mask, int B, int N, int n_cu, int a
   return lnz_plan_batch(mask, B, N, n_cu, allow_pairs, plan, n_wg, 0, nullptr, nullptr, nullptr,
                         nullptr, stream);
 }
+
+// A HIP stream confined to compute units [first_cu, end_cu) of the current device (see the header).
+extern "C" int lnz_stream_create_cu_masked(int first_cu, int end_cu, lnz_stream_t* stream) {
+  LNZ_REQUIRE(stream, LNZ_EINVAL, "lnz_stream_create_cu_masked: stream is NULL");
+  int dev = 0, n_cu = 0;
+  LNZ_REQUIRE(hipGetDevice(&dev) == hipSuccess &&
+                  hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
+              LNZ_ELAUNCH, "lnz_stream_create_cu_masked: no device");
+  LNZ_REQUIRE(0 <= first_cu && first_cu < end_cu && end_cu <= n_cu, LNZ_EINVAL,
+              "lnz_stream_create_cu_masked: compute units [%d, %d) of %d", first_cu, end_cu, n_cu);
+  uint32_t words[16] = {0};
+  const int n_words = (n_cu + 31) / 32;
+  LNZ_REQUIRE(n_words <= 16, LNZ_ENOTSUP, "lnz_stream_create_cu_masked: %d compute units", n_cu);
+  for (int cu = first_cu; cu < end_cu; ++cu) words[cu / 32] |= 1u << (cu % 32);
+  hipStream_t s = nullptr;
+  LNZ_REQUIRE(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, words) == hipSuccess, LNZ_ELAUNCH,
+              "lnz_stream_create_cu_masked: hipExtStreamCreateWithCUMask failed");
+  *stream = (lnz_stream_t)s;
+  return LNZ_OK;
+}

@@ -441,6 +441,16 @@ Tensor segment_sum_backward(const Tensor& grad_out, const Tensor& segment_ids, i
 TORCH_LIBRARY(lanczosnet, m) {
   m.def("abi_version() -> int", []() -> int64_t { return lnz_abi_version(); });
   m.def("last_kernel() -> str", []() -> std::string { return std::string(lnz_last_kernel()); });
+  // a HIP stream confined to compute units [first_cu, end_cu) of `device`: its handle, for
+  // torch.cuda.ExternalStream (lanczosnet_amd/utils/streams.py)
+  m.def("cu_masked_stream(int first_cu, int end_cu, int device) -> int",
+        [](int64_t first_cu, int64_t end_cu, int64_t device) -> int64_t {
+          c10::DeviceGuard guard(c10::Device(c10::DeviceType::CUDA, (c10::DeviceIndex)device));
+          lnz_stream_t st = nullptr;
+          const int rc = lnz_stream_create_cu_masked((int)first_cu, (int)end_cu, &st);
+          TORCH_CHECK(rc == 0, "lanczosnet_hip error ", rc, ": ", lnz_last_error());
+          return (int64_t)reinterpret_cast<intptr_t>(st);
+        });
   m.def("laplacian_l4(Tensor adjs, Tensor n_nodes) -> Tensor");
   m.def("lanczos_ritz(Tensor A, Tensor n_nodes, int K) -> (Tensor, Tensor, Tensor)");
   m.def("prepare_batch(Tensor L, Tensor mask, Tensor n_nodes, int K, int n_cu, bool allow_pairs) -> "

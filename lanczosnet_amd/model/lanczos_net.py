@@ -421,8 +421,13 @@ class _LanczosNetBase(nn.Module):
                 Wb = ops.large_weight_fragments(ops.split_bf16_planes(
                     Wn.permute(1, 0, 2).reshape(len(reps) * dout, dinp), planes))
                 Wt = ops.pack_rows_k8(Wc[:, :S].reshape(dout, S * dinp).contiguous()) if S else None
+                # one operator class: its summed fp32 block, columns padded to a multiple of 32
+                # (lnz_f32_linear's K) — the exact-fp32 sparse form of the split-precision modes
+                d32 = (d_in + 31) // 32 * 32
+                Wn32 = torch.nn.functional.pad(Wn[:, 0, :d_in], (0, d32 - d_in)).contiguous() \
+                    if len(reps) == 1 else None
                 layers.append(dict(Wb=Wb, Wt=Wt, bias=self.filter[t].bias.detach().float().contiguous(),
-                                   din=d_in))
+                                   din=d_in, Wn32=Wn32))
             cache['conv'][key] = layers
         return cache
 
@@ -587,7 +592,7 @@ class _LanczosNetBase(nn.Module):
         return Lb, Vb, classes, verify
 
     # -- the node-space term on the nonzeros of L (csrc/conv_sparse.hip) -------------------------
-    # bf16 mode only (planes = 1).  The image kernel reads L once, keeps the nonzeros of channel 0
+    # The image kernel reads L once, keeps the nonzeros of channel 0
     # and reports (a) whether any other channel differs from channel 0 (the fold claim of
     # `_large_pack`, checked here for all channels at once) and (b) whether a row is too dense for
     # the gather to beat the stream (when the batch comes from `collate_graph_adjacency`, its K-step
@@ -598,9 +603,12 @@ class _LanczosNetBase(nn.Module):
     large_sparse = os.environ.get('LANCZOSNET_LARGE_SPARSE', '1') != '0'
     large_sparse_backoff = 32
 
-    def _large_sparse_layers(self, node_feat, Lf, Vf, G):
+    def _large_sparse_layers(self, node_feat, Lf, Vf, G, planes=1):
         """-> the last conv layer's state [B,N,128], or None when the batch has to take the
-        streamed kernels (disabled, capturing, N beyond 16-bit columns, or a raised image flag)."""
+        streamed kernels (disabled, capturing, N beyond 16-bit columns, or a raised image flag).
+        planes = 1: bf16 values x bf16 features (the streamed bf16 form's products); planes = 2, 3
+        (the split-precision modes): the node-space term in EXACT fp32 — fp32 values x fp32
+        features of lnz_f32_linear — and the lift from `planes` pieces as in the streamed form."""
         B, N, _, Cn = Lf.shape
         if not self.large_sparse or N > 65536 or torch.cuda.is_current_stream_capturing():
             return None
@@ -608,28 +616,45 @@ class _LanczosNetBase(nn.Module):
         if st.get('skip', 0) > 0:
             st['skip'] -= 1
             return None
+        exact = planes != 1
         img = ops.attached_sparse_image(Lf)   # left by the collate's Lanczos pass over this very tensor
+        if img is not None and exact and img.values is None:
+            img = None                        # (that pass keeps the bf16 entries only)
         st['image_from'] = 'collate' if img is not None else 'forward'
         if img is None:
-            img = ops.large_sparse_image(Lf)
+            img = ops.large_sparse_image(Lf, values=exact)
         host = st.get('host')
         if host is None:
             host = st['host'] = torch.zeros((1,), dtype=torch.int32).pin_memory()
         host.copy_(img.flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        Vb = ops.large_pack_vectors(Vf, 1)
+        Vb = ops.large_pack_vectors(Vf, planes)
         classes = (0,) * Cn
-        plan = self._plan_large(1, classes)
-        work = ops.large_sparse_work_buffers(B, N, Lf.device)
+        plan = self._plan_large(planes, classes)
         state = node_feat.float().contiguous() if self.general else \
             self.embedding(node_feat).float().contiguous()
         bufs = [None, None]
-        for t, lay in enumerate(plan['conv'][(1, classes)]):
-            state = ops.large_sparse_conv_layer(state, lay['din'], img, Vb, Vf, lay['Wb'], lay['Wt'],
-                                                G[t] if G is not None else None, lay['bias'], work,
-                                                relu=True, out=bufs[t & 1])
-            bufs[t & 1] = state
+        if not exact:
+            work = ops.large_sparse_work_buffers(B, N, Lf.device)
+            for t, lay in enumerate(plan['conv'][(1, classes)]):
+                state = ops.large_sparse_conv_layer(state, lay['din'], img, Vb, Vf, lay['Wb'], lay['Wt'],
+                                                    G[t] if G is not None else None, lay['bias'], work,
+                                                    relu=True, out=bufs[t & 1])
+                bufs[t & 1] = state
+        else:
+            dev = Lf.device
+            work = (torch.empty((B, N, 128), dtype=torch.float32, device=dev),
+                    torch.zeros((planes, B, 128, 64), dtype=ops.large_plane_dtype(planes), device=dev),
+                    torch.zeros((B, 64, 128), dtype=torch.float32, device=dev))
+            d0 = state.shape[2]
+            if d0 % 32:
+                state = torch.nn.functional.pad(state, (0, (d0 + 31) // 32 * 32 - d0)).contiguous()
+            for t, lay in enumerate(plan['conv'][(planes, classes)]):
+                state = ops.large_sparse_conv_layer_f32(state, lay['din'], img, Vb, Vf, lay['Wn32'], lay['Wt'],
+                                                        G[t] if G is not None else None, lay['bias'], work,
+                                                        planes, relu=True, out=bufs[t & 1])
+                bufs[t & 1] = state
         ev.synchronize()   # the image launch: long finished
         flags = int(host.item())
         st['last_flags'] = flags
@@ -653,7 +678,7 @@ class _LanczosNetBase(nn.Module):
         if S > 0:
             G = ops.spectral_gains(D, self.long_diffusion_dist, self.num_layer,
                                    self._plan_large()['mlp_pack'])
-        state = self._large_sparse_layers(node_feat, Lf, Vf, G) if planes == 1 else None
+        state = self._large_sparse_layers(node_feat, Lf, Vf, G, planes)
         for attempt in range(2 if state is None else 0):
             Lb, Vb, classes, verify = self._large_pack(Lf, Vf, planes)
             plan = self._plan_large(planes, classes)

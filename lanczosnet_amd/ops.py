@@ -476,10 +476,11 @@ class LargeSparseImage:
   int32 = bf16(value) << 16 | column, counts [B,N], flags (one int32 on the device: bit 0 = a
   channel differs from channel 0, bit 1 = a row overflowed `cap`; non-zero = the image must not be
   used)."""
-  __slots__ = ('entries', 'counts', 'flags', 'cap', 'B', 'N', 'version')
+  __slots__ = ('entries', 'counts', 'flags', 'cap', 'B', 'N', 'version', 'values')
 
-  def __init__(self, entries, counts, flags, cap):
+  def __init__(self, entries, counts, flags, cap, values=None):
     self.entries, self.counts, self.flags, self.cap = entries, counts, flags, cap
+    self.values = values   # [B,N,cap] fp32: the unrounded entries (the exact-fp32 form), or None
     self.B, self.N = counts.shape
     self.version = None   # the source tensor's version counter when the image rides on it (attach_sparse_image)
 
@@ -531,20 +532,22 @@ def large_sparse_row_cap(N):
   return int(min(256, max(32, (N // 32 + 7) // 8 * 8)))
 
 
-def large_sparse_image(L, row_cap=None):
-  """lnz_large_sparse_image on the current stream.  L [B,N,N,C] fp32 (any strides)."""
+def large_sparse_image(L, row_cap=None, values=False):
+  """lnz_large_sparse_image on the current stream.  L [B,N,N,C] fp32 (any strides).  values: also
+  the entries' unrounded fp32 values (the exact-fp32 form of the gather)."""
   _need_cuda(L)
   assert L.dim() == 4 and L.dtype == torch.float32
   B, N, _, Cn = L.shape
   cap = large_sparse_row_cap(N) if row_cap is None else int(row_cap)
   dev = L.device
   entries = torch.empty((B, N, cap), dtype=torch.int32, device=dev)
+  vals = torch.empty((B, N, cap), dtype=torch.float32, device=dev) if values else None
   counts = torch.empty((B, N), dtype=torch.int32, device=dev)
   flags = torch.empty((1,), dtype=torch.int32, device=dev)
   sb, sr, sc, sch = L.stride()
   with torch.cuda.device(dev):
-    _abi().large_sparse_image(L, sb, sr, sc, sch, B, N, Cn, cap, entries, counts, flags)
-  return LargeSparseImage(entries, counts, flags, cap)
+    _abi().large_sparse_image(L, sb, sr, sc, sch, B, N, Cn, cap, entries, vals, counts, flags)
+  return LargeSparseImage(entries, counts, flags, cap, vals)
 
 
 def large_pack_vectors(V, planes=1):
@@ -590,6 +593,34 @@ def large_sparse_conv_layer(X, din, img, Vb, V, Wf, Wt, G, bias, work, relu=True
       abi.large_spectral(X, X.shape[2], din, V, G, Wt, B, N, K, S, 1, Ybuf, Tt)
     abi.large_conv(None, Vb, None, Tt, bias, B, N, 0, 1, 0, out)
     abi.large_sparse_conv(img.entries, img.counts, img.cap, Z, B, N, int(bool(relu)), out)
+  return out
+
+
+def large_sparse_conv_layer_f32(X, din, img, Vb, V, Wn, Wt, G, bias, work, planes, relu=True, out=None):
+  """The split-precision modes' layer with the node-space term in EXACT fp32 on the sparse image:
+  lnz_f32_linear (Zf = X Wn^T) + lnz_large_spectral + lnz_large_conv (C = 0: the lift, `planes`
+  pieces) + lnz_large_sparse_conv_f32.  X [B,N,ldx] fp32 with ldx a multiple of 32 (columns >= din
+  zero); Wn [128, ldx] fp32 (the class's summed weight blocks, zero padded); Vb =
+  large_pack_vectors(V, planes); img with `values`; work = (Zf [B,N,128] fp32, Tt [planes,B,128,64],
+  Ybuf)."""
+  Zf, Tt, Ybuf = work
+  _need_cuda(X, img.entries, img.values, Vb, Wn, bias, Zf, Tt)
+  B, N = img.B, img.N
+  ldx = X.shape[2]
+  assert X.dtype == torch.float32 and X.is_contiguous() and X.shape[0] == B and X.shape[1] == N
+  assert ldx % 32 == 0 and tuple(Wn.shape) == (128, ldx) and Vb.shape[0] == planes == Tt.shape[0]
+  if out is None:
+    out = torch.empty((B, N, 128), dtype=torch.float32, device=X.device)
+  f32_linear(X.view(B * N, ldx), Wn, out=Zf.view(B * N, 128))
+  with torch.cuda.device(X.device):
+    abi = _abi()
+    if G is not None:
+      K, S = V.shape[2], G.shape[1]
+      assert V.dtype == torch.float32 and V.is_contiguous()
+      assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
+      abi.large_spectral(X, ldx, din, V, G, Wt, B, N, K, S, planes, Ybuf, Tt)
+    abi.large_conv(None, Vb, None, Tt, bias, B, N, 0, planes, 0, out)
+    abi.large_sparse_conv_f32(img.entries, img.values, img.counts, img.cap, Zf, B, N, int(bool(relu)), out)
   return out
 
 

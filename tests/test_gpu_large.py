@@ -448,6 +448,7 @@ def test_large_forward_folds_equal_channels_and_survives_a_wrong_guess():
   cfg, P, net, X, L, mask = _general_setup(B, N, K, 3, 7, 8.0 / N)
   _, _, plain, _, _, _ = _general_setup(B, N, K, 3, 7, 8.0 / N)
   plain.large_fold = False
+  net.large_sparse = plain.large_sparse = False   # (the streamed kernels: the sparse image has its own tests)
   Ld = torch.from_numpy(L).to(DEV)
   Xd, md = torch.from_numpy(X).to(DEV), torch.from_numpy(mask).to(DEV)
   D, V = ops.lanczos_ritz_large(Ld[:, :, :, 0].contiguous(), K, K)
@@ -486,7 +487,6 @@ def test_large_forward_folds_equal_channels_and_survives_a_wrong_guess():
       s7 = net(Xd, Ld[:, :, :, :1].expand(B, N, N, 2), D, V, mask=md)   # zero channel stride
       assert seen == [1] and close(s7, s2)
       net.gemm_mode = 'bf16'                     # config 5's mode folds the same way
-      net.large_sparse = plain.large_sparse = False   # (the streamed kernels: the sparse image has its own tests)
       plain.gemm_mode = 'bf16'
       sb = net(Xd, Ld, D, V, mask=md)
       rb = plain(Xd, Ld, D, V, mask=md)

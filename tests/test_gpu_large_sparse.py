@@ -149,7 +149,8 @@ def test_module_takes_the_sparse_image_in_bf16_mode_and_falls_back_when_it_must(
   operator pack at all) with the streamed kernels' scores; channels that differ, or a graph too
   dense for the row capacity, raise the image's flag — the batch is recomputed on the streamed
   kernels (equal to a module with the sparse path off) and the next calls do not try again until
-  the back-off has run out; the split-precision modes never take it."""
+  the back-off has run out; the split-precision modes take the image too, with the node-space
+  term in exact fp32 (1e-5 against their streamed kernels)."""
   from lanczosnet_amd import ops
   from lanczosnet_amd.model import LanczosNetGeneral
   from lanczosnet_amd.utils.arg_helper import make_model_config
@@ -214,10 +215,15 @@ def test_module_takes_the_sparse_image_in_bf16_mode_and_falls_back_when_it_must(
       # of X W_c^T, against `plain`'s one — the bf16 mode's own tolerance)
       assert st['last_flags'] == 2 and close(s4, ref3, 2e-2)
       st['skip'] = 0
-      n_img = len(images)
-      net.gemm_mode = 'fp32'                                   # split-precision modes: never
-      net(Xd, Ld, D, V, mask=md)
-      assert len(images) == n_img
+      n_img, n_pack = len(images), len(packs)
+      net.gemm_mode = plain.gemm_mode = 'fp32'                 # split-precision modes: the exact-fp32 gather
+      s5 = net(Xd, Ld, D, V, mask=md)
+      assert len(images) == n_img + 1 and len(packs) == n_pack and st['last_flags'] == 0
+      assert ops.last_kernel() == 'sparse_conv_f32_kernel'
+      assert close(s5, plain(Xd, Ld, D, V, mask=md), 1e-5)     # against the streamed three-piece kernels
+      for planes in (2, 3):
+        net.large_split_planes = plain.large_split_planes = planes
+        assert close(net(Xd, Ld, D, V, mask=md), plain(Xd, Ld, D, V, mask=md), 1e-5)
   finally:
     ops.large_pack_operators, ops.large_sparse_image = orig_pack, orig_img
 

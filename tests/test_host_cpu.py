@@ -241,10 +241,11 @@ def test_torch_extension_registers_every_entry_point_and_is_the_only_binding_of_
   struct_launches = {'lnz_lanczosnet_forward', 'lnz_lanczosnet_input_grad', 'lnz_lanczosnet_messages',
                      'lnz_lanczosnet_gain_grad'}
   for sym in _header_symbols():
-    if sym in ('lnz_abi_version', 'lnz_last_error', 'lnz_last_kernel') or sym in struct_launches:
+    if sym in ('lnz_abi_version', 'lnz_last_error', 'lnz_last_kernel', 'lnz_stream_create_cu_masked') or \
+        sym in struct_launches:
       continue
     assert hasattr(torch.ops.lanczosnet, 'raw_' + sym[4:]), sym
-  assert hasattr(torch.ops.lanczosnet, 'fused_launch')
+  assert hasattr(torch.ops.lanczosnet, 'fused_launch') and hasattr(torch.ops.lanczosnet, 'cu_masked_stream')
   assert torch.ops.lanczosnet.raw_large_nk(100) == 128
   assert torch.ops.lanczosnet.raw_lanczos_ritz_workspace_bytes(3, 192) == 3 * 192 * 193 * 8
   assert torch.ops.lanczosnet.raw_f32_linear_splits(1024, 4096, 4096) == 1

@@ -22,7 +22,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, 'include', 'lanczosnet_hip.h')
 OUT = os.path.join(ROOT, 'lanczosnet_amd', 'csrc', 'torch_ext_abi.inc')
-SKIP = {'lnz_abi_version', 'lnz_last_error', 'lnz_last_kernel'}
+SKIP = {'lnz_abi_version', 'lnz_last_error', 'lnz_last_kernel', 'lnz_stream_create_cu_masked'}
 DTYPE = {'float': 'at::kFloat', 'double': 'at::kDouble', 'int32_t': 'at::kInt', 'uint32_t': 'at::kInt',
          'int64_t': 'at::kLong', 'uint8_t': 'at::kByte', 'unsigned long long': 'at::kLong'}
 
