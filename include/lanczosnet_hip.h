@@ -298,7 +298,8 @@ int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t stride_r, i
 
 /* The same call leaving the image of lnz_large_sparse_image behind (csrc/conv_sparse.hip): the
  * compaction pass has every entry of the row in hand (and, with stride_c = 2, the second channel of
- * the collated pair), so conv_entries [B][N][conv_row_cap] / conv_counts [B][N] / conv_flags (one
+ * the collated pair), so conv_entries [B][N][conv_row_cap] (+ conv_values, optional: the unrounded
+ * fp32 values of the exact form) / conv_counts [B][N] / conv_flags (one
  * int32: bit 0 = the two channels differ somewhere — stride_c = 2 only; with stride_c = 1 the
  * caller vouches for a single operator —, bit 1 = a row beyond conv_row_cap) cost no second read of
  * L: one pass over the collated Laplacian per batch serves the Ritz pairs and all conv layers.
@@ -307,8 +308,8 @@ int lnz_lanczos_ritz_kstep_image(const float* A, int64_t stride_b, int64_t strid
                                  int64_t stride_c, const int32_t* n_nodes, int B, int N, int M, int K,
                                  int flags, int row_cap, void* workspace, int64_t workspace_bytes,
                                  float* D, float* V, int32_t* info, int32_t* dense_fallback,
-                                 uint32_t* conv_entries, int32_t* conv_counts, int conv_row_cap,
-                                 int32_t* conv_flags, lnz_stream_t stream);
+                                 uint32_t* conv_entries, float* conv_values, int32_t* conv_counts,
+                                 int conv_row_cap, int32_t* conv_flags, lnz_stream_t stream);
 
 /* A HIP stream whose kernels run on compute units [first_cu, end_cu) of the current device only
  * (hipExtStreamCreateWithCUMask).  For latency-chain launches that fill a fraction of the chip —

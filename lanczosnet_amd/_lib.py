@@ -66,7 +66,7 @@ SIGNATURES = {
     'lnz_lanczos_ritz_large_sym': (C.c_int, [_P, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_lanczos_ritz_kstep_workspace_bytes': (C.c_int64, [_I, _I, _I, _I]),
     'lnz_lanczos_ritz_kstep': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P]),
-    'lnz_lanczos_ritz_kstep_image': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'lnz_lanczos_ritz_kstep_image': (C.c_int, [_P, _L, _L, _L, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'lnz_stream_create_cu_masked': (C.c_int, [_I, _I, _P]),
     'lnz_head_backward_workspace_floats': (C.c_int64, [_I, _I]),
     'lnz_head_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

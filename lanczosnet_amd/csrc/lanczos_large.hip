@@ -385,6 +385,7 @@ struct EllImage {
 // the Ritz pairs AND the seven conv layers.
 struct ConvImageOut {
   unsigned* ent;      // NULL: not wanted
+  float* vals;        // NULL: not wanted (the exact-fp32 form's unrounded values)
   int32_t* counts;
   int32_t* flags;
   int cap;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
   uint16_t* cs = cols + base;
   int k = 0;   // entries of this row so far (wave-uniform)
   unsigned* ce = cv.ent ? cv.ent + rid * cv.cap : nullptr;
+  float* cvv = (cv.ent && cv.vals) ? cv.vals + rid * cv.cap : nullptr;
   bool differ = false;
   auto place = [&](const float v, const int col) {
     const bool nz = v != 0.f;
@@ -422,7 +424,10 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
       vs[(int64_t)pos * 64] = v;
       cs[(int64_t)pos * 64] = (uint16_t)col;
     }
-    if (ce && nz && pos < cv.cap) ce[pos] = conv_entry(v, col);
+    if (ce && nz && pos < cv.cap) {
+      ce[pos] = conv_entry(v, col);
+      if (cvv) cvv[pos] = v;
+    }
     k += __popcll(m);
   };
   const int nq = PAIR ? N >> 1 : N >> 2;   // float4s per row
@@ -452,7 +457,10 @@ __global__ __launch_bounds__(256) void ell_compact_rows_kernel(
   }
   if (ce) {
     const int c = k < cv.cap ? k : cv.cap;
-    if (c + lane < ((c + 7) & ~7)) ce[c + lane] = 0u;   // (the conv walks whole groups of eight)
+    if (c + lane < ((c + 7) & ~7)) {   // (the conv walks whole groups of eight)
+      ce[c + lane] = 0u;
+      if (cvv) cvv[c + lane] = 0.f;
+    }
     const bool any_differ = __ballot(differ) != 0ull;
     if (lane == 0) {
       cv.counts[rid] = c;
@@ -1117,7 +1125,7 @@ extern "C" int lnz_lanczos_ritz_kstep(const float* A, int64_t stride_b, int64_t 
                                       int32_t* dense_fallback, lnz_stream_t stream) {
   return kstep_launch("lnz_lanczos_ritz_kstep", A, stride_b, stride_r, stride_c, n_nodes, B, N, M, K,
                       flags, row_cap, workspace, workspace_bytes, D, V, info, dense_fallback,
-                      ConvImageOut{nullptr, nullptr, nullptr, 0}, stream);
+                      ConvImageOut{nullptr, nullptr, nullptr, nullptr, 0}, stream);
 }
 
 extern "C" int lnz_lanczos_ritz_kstep_image(const float* A, int64_t stride_b, int64_t stride_r,
@@ -1125,15 +1133,16 @@ extern "C" int lnz_lanczos_ritz_kstep_image(const float* A, int64_t stride_b, in
                                             int M, int K, int flags, int row_cap, void* workspace,
                                             int64_t workspace_bytes, float* D, float* V,
                                             int32_t* info, int32_t* dense_fallback,
-                                            uint32_t* conv_entries, int32_t* conv_counts,
-                                            int conv_row_cap, int32_t* conv_flags, lnz_stream_t stream) {
+                                            uint32_t* conv_entries, float* conv_values,
+                                            int32_t* conv_counts, int conv_row_cap,
+                                            int32_t* conv_flags, lnz_stream_t stream) {
   const char* who = "lnz_lanczos_ritz_kstep_image";
   LNZ_REQUIRE(flags & LNZ_KSTEP_COMPACT, LNZ_EINVAL, "%s: needs LNZ_KSTEP_COMPACT", who);
   LNZ_REQUIRE(conv_entries && conv_counts && conv_flags && conv_row_cap >= 32 && conv_row_cap % 8 == 0,
               LNZ_EINVAL, "%s: conv image outputs (row capacity a multiple of 8, at least 32)", who);
   return kstep_launch(who, A, stride_b, stride_r, stride_c, n_nodes, B, N, M, K, flags, row_cap,
                       workspace, workspace_bytes, D, V, info, dense_fallback,
-                      ConvImageOut{conv_entries, conv_counts, conv_flags, conv_row_cap}, stream);
+                      ConvImageOut{conv_entries, conv_values, conv_counts, conv_flags, conv_row_cap}, stream);
 }
 
 extern "C" int lnz_lanczos_ritz_large(const float* A, int64_t stride_b, int64_t stride_r, int B,

@@ -619,7 +619,7 @@ class _LanczosNetBase(nn.Module):
         exact = planes != 1
         img = ops.attached_sparse_image(Lf)   # left by the collate's Lanczos pass over this very tensor
         if img is not None and exact and img.values is None:
-            img = None                        # (that pass keeps the bf16 entries only)
+            img = None                        # (an image without the unrounded values)
         st['image_from'] = 'collate' if img is not None else 'forward'
         if img is None:
             img = ops.large_sparse_image(Lf, values=exact)

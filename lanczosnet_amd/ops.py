@@ -250,10 +250,11 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
       ccap = int(conv_image)
       img = LargeSparseImage(torch.empty((B, N, ccap), dtype=torch.int32, device=A.device),
                              torch.empty((B, N), dtype=torch.int32, device=A.device),
-                             torch.empty((1,), dtype=torch.int32, device=A.device), ccap)
+                             torch.empty((1,), dtype=torch.int32, device=A.device), ccap,
+                             torch.empty((B, N, ccap), dtype=torch.float32, device=A.device))
       _abi().lanczos_ritz_kstep_image(A, A.stride(0), A.stride(1), A.stride(2), n_nodes, B, Np, M, K, flags,
                                       cap, workspace, workspace.numel() * workspace.element_size(), D, V,
-                                      info, fb, img.entries, img.counts, ccap, img.flags)
+                                      info, fb, img.entries, img.values, img.counts, ccap, img.flags)
     else:
       _abi().lanczos_ritz_kstep(A, A.stride(0), A.stride(1), A.stride(2), n_nodes, B, Np, M, K, flags, cap,
                                 workspace, workspace.numel() * workspace.element_size(), D, V, info, fb)

@@ -277,6 +277,12 @@ def test_kstep_pass_leaves_the_conv_image_behind():
   assert torch.equal(img.counts, ref.counts)
   keep = (torch.arange(64, device=DEV)[None, None, :] < ((ref.counts + 7) // 8 * 8)[:, :, None])
   assert torch.equal(img.entries[keep], ref.entries[keep])
+  refv = ops.large_sparse_image(L, 64, values=True)         # the exact form's unrounded values ride along
+  assert torch.equal(img.values[keep], refv.values[keep]) and torch.equal(refv.entries[keep], ref.entries[keep])
+  live = torch.arange(64, device=DEV)[None, None, :] < ref.counts[:, :, None]
+  cols = (refv.entries[live].long() & 0xffff)
+  bi, ri, _ = torch.nonzero(live, as_tuple=True)
+  assert torch.equal(refv.values[live], L[bi, ri, cols, 0])
   L2 = L.clone()
   L2[1, 9, 11, 1] += 0.5
   _, _, img2 = ops.lanczos_ritz_kstep(L2[..., 0], None, K, K, conv_image=64)
@@ -333,6 +339,11 @@ def test_collate_leaves_the_image_on_L_and_the_module_uses_it():
       s1 = net(batch['node_feat'], Ld, batch['D'], batch['V'], mask=md)
       st = net._large_sparse_state[Ld.device.index]
       assert not calls and st['image_from'] == 'collate' and st['last_flags'] == 0
+      net.gemm_mode = 'fp32'                                  # the fp32 modes find it too (its fp32 values)
+      s1f = net(batch['node_feat'], Ld, batch['D'], batch['V'], mask=md)
+      assert not calls and st['image_from'] == 'collate' and ops.last_kernel() == 'sparse_conv_f32_kernel'
+      assert (s1f - s1).abs().max() <= 2e-2 * s1f.abs().max()
+      net.gemm_mode = 'bf16'
       s2 = net(batch['node_feat'], Ld.clone(), batch['D'], batch['V'], mask=md)    # a copy does not carry it
       assert len(calls) == 1 and st['image_from'] == 'forward'
       assert (s1 - s2).abs().max() <= 2e-3 * s2.abs().max()
