@@ -599,7 +599,8 @@ class _LanczosNetBase(nn.Module):
     # Lanczos pass over L has left that image riding on the tensor: L is read once per batch).
     # The flags come back through pinned memory behind the layer
     # launches; a raised flag discards the result, the batch takes the streamed kernels, and the
-    # next `large_sparse_backoff` calls on this device do not try again.
+    # next `large_sparse_backoff` calls on this device do not try again (twice as many after every
+    # further failure in a row, up to 32 x).
     large_sparse = os.environ.get('LANCZOSNET_LARGE_SPARSE', '1') != '0'
     large_sparse_backoff = 32
 
@@ -659,8 +660,11 @@ class _LanczosNetBase(nn.Module):
         flags = int(host.item())
         st['last_flags'] = flags
         if flags:
-            st['skip'] = self.large_sparse_backoff
+            # (a data set of dense graphs raises it every time: the pause doubles, up to 32 x)
+            st['streak'] = min(st.get('streak', 0) + 1, 6)
+            st['skip'] = self.large_sparse_backoff << (st['streak'] - 1)
             return None
+        st['streak'] = 0
         return state
 
     @torch.no_grad()

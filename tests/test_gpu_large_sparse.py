@@ -214,6 +214,10 @@ def test_module_takes_the_sparse_image_in_bf16_mode_and_falls_back_when_it_must(
       # (this module's streamed path has not learned the fold yet: two operators, two bf16 roundings
       # of X W_c^T, against `plain`'s one — the bf16 mode's own tolerance)
       assert st['last_flags'] == 2 and close(s4, ref3, 2e-2)
+      assert st['skip'] == 2
+      st['skip'] = 0
+      net(Xd, L3, D, V, mask=md)                               # again: the pause doubles
+      assert st['last_flags'] == 2 and st['skip'] == 4
       st['skip'] = 0
       n_img, n_pack = len(images), len(packs)
       net.gemm_mode = plain.gemm_mode = 'fp32'                 # split-precision modes: the exact-fp32 gather
