@@ -22,7 +22,14 @@
 extern "C" {
 #endif
 
-/* 6: lnz_forward_args lost Wp16 / w16_off / Wp16_head / Lp16 (gemm_mode 1 is now the split precision
+/* 7: lnz_midgraph_forward's `sync` grew to B * (num_layer + 1) words (placement words behind the
+ *    arrival counters) and its launch is chunked to the resident workgroups; + the K-step entry
+ *    (lnz_lanczos_ritz_kstep[_image], _workspace_bytes), the sparse large-graph conv
+ *    (lnz_large_sparse_image, lnz_large_pack_vectors, lnz_large_gemm1_rows, lnz_large_sparse_conv[_f32];
+ *    lnz_large_conv accepts C = 0), lnz_head_backward, lnz_node_extents, the out-of-place split-pack
+ *    entries (lnz_split_laplacian_pack_to, lnz_spectral_gains_rows_split_to), lnz_last_kernel,
+ *    lnz_stream_create_cu_masked;
+ * 6: lnz_forward_args lost Wp16 / w16_off / Wp16_head / Lp16 (gemm_mode 1 is now the split precision
  *    inside the strip kernel: lnz_pack_rows_k8_split; lnz_pack_rows_f16x2 and
  *    lnz_pack_laplacian_f16x2 are gone) and gained dbias_part_cap; + lnz_midgraph_forward,
  *    lnz_spectral_mlp_grad;  5: + the strip plan (lnz_plan_strips, strips / n_strips / strip_cap);
@@ -31,7 +38,7 @@ extern "C" {
  * 3: + lnz_f32_linear, lnz_laplacian, the fp64 training kernels of the AdaLanczosNet spectrum
  *    (lnz_ada_graph_laplacian_f64, lnz_ada_lanczos_layer_f64, lnz_ada_t_powers_f64 and their
  *    _backward);  2: + lnz_lanczos_ritz_ws / _workspace_bytes, lnz_f16x3_*. */
-#define LNZ_ABI_VERSION 6
+#define LNZ_ABI_VERSION 7
 #define LNZ_OK 0
 #define LNZ_EINVAL (-1)   /* bad argument (shape/limit)            */
 #define LNZ_ELAUNCH (-2)  /* HIP launch / runtime error            */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LANCZOSNET_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liblanczosnet_hip.so')
 
 LNZ_OK, LNZ_EINVAL, LNZ_ELAUNCH, LNZ_ENOTSUP = 0, -1, -2, -3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class LnzError(RuntimeError):

@@ -34,7 +34,7 @@ def _model(cfg, params, general=False):
 def test_library_loaded_in_tree():
   from lanczosnet_amd import _lib
   lib = _lib.load()
-  assert lib.lnz_abi_version() == _lib.ABI_VERSION == 6
+  assert lib.lnz_abi_version() == _lib.ABI_VERSION == 7
   assert _lib.LIB_PATH.endswith('lanczosnet_amd/csrc/liblanczosnet_hip.so')
 
 
