@@ -62,16 +62,7 @@ with torch.no_grad():
   # two halves, two slots, two streams — optionally on disjoint sets of compute units
   # (hipExtStreamCreateWithCUMask: the Ritz launch is a latency chain per workgroup, and forward
   # waves sharing its compute units stretch it from 0.45 to 0.60 ms)
-  def masked_stream(lo, hi):
-    import ctypes
-    hip = ctypes.CDLL('libamdhip64.so')
-    words = (ctypes.c_uint32 * 8)(*([0] * 8))
-    for cu in range(lo, hi):
-      words[cu // 32] |= 1 << (cu % 32)
-    st = ctypes.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-    assert rc == 0, rc
-    return torch.cuda.ExternalStream(st.value)
+  from lanczosnet_amd.utils.streams import cu_masked_stream as masked_stream
   split = int(os.environ.get('LNZ_GRAPH_STREAMS_CU_SPLIT', '0'))
   if split:
     s_prep, s_fwd = masked_stream(0, split), masked_stream(split, 256)
