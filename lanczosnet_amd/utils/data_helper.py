@@ -27,19 +27,62 @@ def get_graph_laplacian_eigs_batched(L_simple, n_nodes, k, use_eigen_decomp=None
 
     use_eigen_decomp (the reference's switch, :173,199-208):
       True   the pairs of the FULL decomposition (`np.linalg.eigh`, :201) — full-length Lanczos +
-             tridiagonal eigensolver, `lnz_lanczos_ritz`, graphs of up to 192 nodes; larger ones
-             raise (the reference itself calls this branch "computationally heavy for large size adj");
+             tridiagonal eigensolver, `lnz_lanczos_ritz`, graphs of up to 192 nodes; larger ones go
+             to the vendor eigensolver on the device (`torch.linalg.eigh`, fp64) with a UserWarning
+             (the reference itself calls this branch "computationally heavy for large size adj");
       False  the k-dimensional Krylov method (`eigsh(L, k, which='LM')`, :208) — the k-step
              Lanczos of `lnz_lanczos_ritz_kstep`, any N <= 2048, ragged batches;
       None   (default) True up to 192 nodes, False beyond, with a UserWarning naming the branch."""
-    from .. import ops, _lib
+    from .. import ops
     N = L_simple.shape[1]
     if use_eigen_decomp is None:
         return ops.lanczos_ritz(L_simple, n_nodes, k)
     if use_eigen_decomp:
         if N > ops.RITZ_FULL_MAX_N:
-            raise _lib.NotSupported(_lib.LNZ_ENOTSUP,
-                                    'use_eigen_decomp=True serves graphs of up to %d nodes (got %d); '
-                                    'use_eigen_decomp=False is the k-step branch' % (ops.RITZ_FULL_MAX_N, N))
+            return _full_decomposition_library(L_simple, n_nodes, k)
         return ops.lanczos_ritz(L_simple, n_nodes, k)
     return ops.lanczos_ritz_kstep(L_simple, n_nodes, min(k, 64), k)
+
+
+def _full_decomposition_library(L_simple, n_nodes, k):
+    """use_eigen_decomp=True beyond the hand-written kernels' 192 nodes: the reference's branch has no
+    size limit (`np.linalg.eigh`, :199-201).  Served — with a UserWarning, like every path outside
+    the kernels — by the vendor's symmetric eigensolver on the device (`torch.linalg.eigh`, fp64):
+    per graph the n_b x n_b block (the reference decomposes the unpadded matrix), |eigenvalue| order
+    with the reference's stable tie rule, the kernels' sign convention (largest-magnitude component
+    positive), zero padding to [B,k] / [B,N,k] (dataset/graph_data.py:262-287).  Graphs of one size
+    share a batched call."""
+    import warnings
+
+    import torch
+    from .. import ops
+    ops._need_cuda(L_simple, n_nodes)
+    warnings.warn('get_graph_laplacian_eigs_batched(use_eigen_decomp=True) beyond %d nodes: the full '
+                  'decomposition runs on the vendor eigensolver (torch.linalg.eigh, fp64), not on a hand-written '
+                  'kernel; use_eigen_decomp=False is the k-step branch (lnz_lanczos_ritz_kstep)'
+                  % ops.RITZ_FULL_MAX_N, UserWarning, stacklevel=3)
+    B, N = L_simple.shape[0], L_simple.shape[1]
+    sizes = [N] * B if n_nodes is None else [int(x) for x in n_nodes.cpu().tolist()]
+    D = torch.zeros((B, k), dtype=torch.float32, device=L_simple.device)
+    V = torch.zeros((B, N, k), dtype=torch.float32, device=L_simple.device)
+    for n in sorted(set(sizes)):
+        if n <= 0:
+            continue
+        idx = torch.tensor([b for b, s in enumerate(sizes) if s == n], device=L_simple.device)
+        A = L_simple.index_select(0, idx)[:, :n, :n].to(torch.float64)
+        w, U = torch.linalg.eigh(A)                                   # ascending
+        # stable sort by descending |w| (np.argsort(-|w|, kind='mergesort'), :218-220)
+        order = torch.sort(-w.abs(), dim=1, stable=True).indices
+        kk = min(k, n)
+        order = order[:, :kk]
+        wk = torch.gather(w, 1, order)
+        Uk = torch.gather(U, 2, order.unsqueeze(1).expand(-1, n, -1))
+        big = Uk.abs().argmax(dim=1, keepdim=True)                    # first of the largest magnitudes
+        sg = torch.sign(torch.gather(Uk, 1, big))
+        sg = torch.where(sg == 0, torch.ones_like(sg), sg)
+        Uk = Uk * sg
+        D[idx, :kk] = wk.to(torch.float32)
+        Vn = torch.zeros((idx.numel(), N, k), dtype=torch.float32, device=L_simple.device)
+        Vn[:, :n, :kk] = Uk.to(torch.float32)
+        V[idx] = Vn
+    return D, V

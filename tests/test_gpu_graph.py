@@ -220,8 +220,9 @@ def test_workgroup_ritz_kernel_small_graphs_and_edge_cases():
 
 
 def test_graphs_beyond_one_workgroup_take_the_kstep_branch_and_say_so():
-  """Beyond 192 nodes the full-length decomposition is not offered: the workgroup kernel and
-  use_eigen_decomp=True refuse, the default entry answers with the reference's OTHER branch
+  """Beyond 192 nodes the hand-written full-length decomposition is not offered: the workgroup kernel
+  refuses (use_eigen_decomp=True goes to the vendor eigensolver, next test), the default entry answers
+  with the reference's OTHER branch
   (use_eigen_decomp=False: a K-dimensional Krylov method, utils/data_helper.py:205-208) and warns.
   For a graph whose Krylov space from the start vector is smaller than K the two branches coincide:
   the pairs are exact eigenpairs."""
@@ -234,8 +235,6 @@ def test_graphs_beyond_one_workgroup_take_the_kstep_branch_and_say_so():
   nn = torch.tensor([n], dtype=torch.int32, device=DEV)
   with pytest.raises(_lib.NotSupported):
     ops.lanczos_ritz(A, nn, 20, kernel='workgroup')
-  with pytest.raises(_lib.NotSupported):
-    get_graph_laplacian_eigs_batched(A, nn, 20, use_eigen_decomp=True)
   ops._WARNED.clear()
   with pytest.warns(UserWarning, match='use_eigen_decomp=False'):
     D, V = get_graph_laplacian_eigs_batched(A, nn, 20)
@@ -251,6 +250,42 @@ def test_graphs_beyond_one_workgroup_take_the_kstep_branch_and_say_so():
   Vd = V[0].double().cpu().numpy()[:, :len(live)]
   Ad = A[0].double().cpu().numpy()
   assert np.abs(Ad @ Vd - Vd * live).max() < 1e-6
+
+
+def test_full_decomposition_beyond_192_nodes_runs_on_the_vendor_eigensolver_and_says_so():
+  """use_eigen_decomp=True has no size limit in the reference (np.linalg.eigh, utils/data_helper.py:
+  199-201).  Beyond the kernels' 192 nodes it is served by torch.linalg.eigh (fp64, device) with a
+  UserWarning: ragged batch, the reference's |eigenvalue| order / pad / cut (oracle.graph_eigs =
+  numpy on the unpadded blocks), eigenvalues to 1e-6, the selected invariant subspaces to 1e-5 where
+  the cut does not fall inside a cluster; V zero on the padding, D / V zero beyond n."""
+  from lanczosnet_amd.utils.data_helper import get_graph_laplacian_eigs_batched
+  rs = np.random.RandomState(3)
+  N, K = 300, 40
+  sizes = [300, 257, 257, 30]
+  A = np.zeros((len(sizes), N, N), np.float32)
+  for b, n in enumerate(sizes):
+    a = np.triu((rs.rand(n, n) < 0.05).astype(np.float64), 1)
+    A[b, :n, :n] = oracle.laplacian_l4(a + a.T)
+  nn = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+  with pytest.warns(UserWarning, match='vendor eigensolver'):
+    D, V = get_graph_laplacian_eigs_batched(torch.from_numpy(A).to(DEV), nn, K, use_eigen_decomp=True)
+  D, V = D.cpu().numpy(), V.double().cpu().numpy()
+  assert D.shape == (len(sizes), K) and V.shape == (len(sizes), N, K)
+  for b, n in enumerate(sizes):
+    w, U = np.linalg.eigh(A[b, :n, :n].astype(np.float64))
+    idx = np.argsort(-np.abs(w), kind='mergesort')
+    kk = min(K, n)
+    assert np.abs(D[b, :kk] - w[idx[:kk]]).max() < 1e-6 and (D[b, kk:] == 0).all()
+    assert (V[b, n:] == 0).all() and (V[b, :, kk:] == 0).all()
+    Vb = V[b, :n, :kk]
+    assert np.abs(Vb.T @ Vb - np.eye(kk)).max() < 1e-5
+    assert np.abs(A[b, :n, :n].astype(np.float64) @ Vb - Vb * D[b, :kk]).max() < 1e-5      # eigenpairs
+    big = np.abs(Vb).argmax(axis=0)
+    assert (Vb[big, np.arange(kk)] > 0).all()                                            # the kernels' sign rule
+    mags = np.abs(w[idx])
+    if kk == n or mags[kk - 1] - mags[kk] > 1e-6:                                          # cut outside a cluster
+      Ur = U[:, idx[:kk]]
+      assert np.abs(Vb @ Vb.T - Ur @ Ur.T).max() < 1e-5
 
 
 def _structured_graphs():
