@@ -595,6 +595,9 @@ def large_graph_leg(dev, A, D, V, reps=3):
     sp_gemm1 = per_launch(lambda: abi.large_gemm1_rows(state, 128, 128, folded_plan['Wb'], B, N, swork[0]))
     sp_spec = per_launch(lambda: abi.large_spectral(state, 128, 128, V, Gs[1], folded_plan['Wt'], B, N, K, 8, 1,
                                                     swork[2], swork[1]))
+    sp_fused = per_launch(lambda: abi.large_spectral_gemm1_rows(state, 128, 128, V, Gs[1], folded_plan['Wt'],
+                                                                folded_plan['Wb'], B, N, K, 8, swork[2], swork[1],
+                                                                swork[0]))
     sp_lift = per_launch(lambda: abi.large_conv(None, Vb, None, swork[1], lay['bias'], B, N, 0, 1, 0, buf))
     sp_conv = per_launch(lambda: abi.large_sparse_conv(img.entries, img.counts, img.cap, swork[0], B, N, 1, buf))
     cnt = img.counts.float()
@@ -623,7 +626,8 @@ def large_graph_leg(dev, A, D, V, reps=3):
                           'GBps': round(B * 2 * N * N * 4 / img_ms / 1e6, 1),
                           'zero_channel_stride_view': round(img_view_ms, 3),
                           'view_GBps': round(B * N * N * 4 / img_view_ms / 1e6, 1)},
-             'layer_ms': {'gemm1_rows': round(sp_gemm1, 4), 'eigen_space_block': round(sp_spec, 4),
+             'layer_ms': {'eigen_space_block+gemm1_rows_in_one_pass_over_X': round(sp_fused, 4),
+                          'gemm1_rows_alone': round(sp_gemm1, 4), 'eigen_space_block_alone': round(sp_spec, 4),
                           'lift_launch': round(sp_lift, 4), 'sparse_conv': round(sp_conv, 4)},
              'gather': {'kernel': 'sparse_conv_kernel', 'bound': 'L2 -> L1 path (256 B per nonzero)',
                         'bytes_per_launch': int(slots * 256),

@@ -232,6 +232,11 @@ int lnz_large_gemm1_rows(const float* X, int ldx, int din, const uint16_t* Wf, i
                          uint16_t* Z, lnz_stream_t stream);
 int lnz_large_sparse_conv(const uint32_t* entries, const int32_t* counts, int row_cap,
                           const uint16_t* Z, int B, int N, int relu, float* X, lnz_stream_t stream);
+/* lnz_large_spectral (planes = 1) and lnz_large_gemm1_rows in one pass over X: the projection's
+ * X tile in LDS also yields Z (the same bits as lnz_large_gemm1_rows). */
+int lnz_large_spectral_gemm1_rows(const float* X, int ldx, int din, const float* V, const float* G,
+                                  const float* Wt, const uint16_t* Wf, int B, int N, int K, int S,
+                                  float* Ybuf, uint16_t* Tt, uint16_t* Z, lnz_stream_t stream);
 /* The node-space term of the split-precision modes (planes = 2, 3) in EXACT fp32 on the same image:
  * values [B][N][row_cap] fp32 (lnz_large_sparse_image's optional output: the unrounded entries, in
  * the entries' order), Zf [B][N][128] fp32 = X W^T (lnz_f32_linear on the [B N, din] states):

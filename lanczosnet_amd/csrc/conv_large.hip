@@ -475,9 +475,15 @@ __global__ __launch_bounds__(256) void large_gemm1_kernel(
 // each zero padded to dinp columns): [4][S * dinp / 8][64][4] fp32.
 // Output Tt [P][B][128][64] bf16 (the B image of the conv kernel's lift block).
 // ------------------------------------------------------------------------------------------
+// WITHZ (the sparse conv's layer, planes = 1): the X tile in LDS also gives Z = bf16(X) bf16(W)^T
+// for its 64 rows — large_gemm1_kernel<1, rows>'s products bit for bit (same fragments, same k
+// order) — so the layer reads X once instead of twice: wave (kt, qt) = rows 32 kt .. + 31 of the
+// step x features 32 qt .. + 31, its weight fragments in registers for the whole launch.
+template <bool WITHZ>
 __global__ __launch_bounds__(512) void large_project_kernel(
     const float* __restrict__ X, int ldx, int din, int dinp, const float* __restrict__ V, int N,
-    int K, int rows_per_wg, float* __restrict__ Ybuf) {
+    int K, int rows_per_wg, float* __restrict__ Ybuf, const u16* __restrict__ Wf,
+    u16* __restrict__ Z) {
   // 64-row steps: the V [64 x 64] and X [64 x 128] pieces are read once per workgroup with
   // coalesced 16 B loads into LDS (double buffered) and feed all eight wave tiles from there —
   // straight from global, every wave re-read its 128 B column slice of every row (2 x 4 B loads
@@ -534,6 +540,14 @@ __global__ __launch_bounds__(512) void large_project_kernel(
     }
   };
   f32x16 acc = lnz::splat16(0.0f);
+  const int nks = dinp / 16;
+  bf16x8 af[WITHZ ? 8 : 1];
+  if constexpr (WITHZ) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      af[ks] = ks < nks ? *reinterpret_cast<const bf16x8*>(Wf + ((int64_t)qt * nks + ks) * 512 + lane * 8)
+                        : bf16x8{};
+  }
   fetch(nbeg);
   stash(0);
   __syncthreads();
@@ -541,6 +555,32 @@ __global__ __launch_bounds__(512) void large_project_kernel(
   for (int n0 = nbeg; n0 < nend; n0 += 64) {
     const bool more = n0 + 64 < nend;
     if (more) fetch(n0 + 64);
+    if constexpr (WITHZ) {
+      f32x16 z = lnz::splat16(0.0f);
+      const float* xr = &Xs[buf][32 * kt + l31][8 * h];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < nks) {   // (uniform)
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr + 16 * ks);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(xr + 16 * ks + 4);
+          bf16x8 bx;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bx[u] = to_bf16(x0[u]), bx[4 + u] = to_bf16(x1[u]);
+          z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bx, z, 0, 0, 0);
+        }
+      }
+      const int n = n0 + 32 * kt + l31;
+      if (n < nend) {
+        u16* dst = Z + ((int64_t)b * N + n) * DH + 32 * qt + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint2 v;
+          v.x = (unsigned)bits(to_bf16(z[4 * q])) | ((unsigned)bits(to_bf16(z[4 * q + 1])) << 16);
+          v.y = (unsigned)bits(to_bf16(z[4 * q + 2])) | ((unsigned)bits(to_bf16(z[4 * q + 3])) << 16);
+          *reinterpret_cast<uint2*>(dst + 8 * q) = v;
+        }
+      }
+    }
     if (work) {
 #pragma unroll 4
       for (int u = 0; u < 32; u += 8) {
@@ -1001,9 +1041,10 @@ extern "C" int lnz_large_gemm1_rows(const float* X, int ldx, int din, const uint
   return lnz::check_launch("lnz_large_gemm1_rows");
 }
 
-extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float* V, const float* G,
-                                  const float* Wt, int B, int N, int K, int S, int planes,
-                                  float* Ybuf, uint16_t* Tt, lnz_stream_t stream) {
+static int large_spectral_launch(const float* X, int ldx, int din, const float* V, const float* G,
+                                 const float* Wt, int B, int N, int K, int S, int planes,
+                                 float* Ybuf, uint16_t* Tt, const uint16_t* Wf_rows, uint16_t* Z_rows,
+                                 lnz_stream_t stream) {
   LNZ_REQUIRE(X && V && G && Wt && Ybuf && Tt && B > 0 && N > 0 && K > 0 && S > 0 && din > 0 &&
                   ldx >= din,
               LNZ_EINVAL, "lnz_large_spectral: bad arguments");
@@ -1024,8 +1065,12 @@ extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float*
   int rows = ((N + chunks - 1) / chunks + 63) / 64 * 64;
   if (rows < 128) rows = 128;
   chunks = (N + rows - 1) / rows;
-  hipLaunchKernelGGL(large_project_kernel, dim3(chunks, B), dim3(512), 0, (hipStream_t)stream, X,
-                     ldx, din, dinp, V, N, K, rows, Ybuf);
+  if (Wf_rows)
+    hipLaunchKernelGGL(large_project_kernel<true>, dim3(chunks, B), dim3(512), 0, (hipStream_t)stream, X,
+                       ldx, din, dinp, V, N, K, rows, Ybuf, Wf_rows, Z_rows);
+  else
+    hipLaunchKernelGGL(large_project_kernel<false>, dim3(chunks, B), dim3(512), 0, (hipStream_t)stream, X,
+                       ldx, din, dinp, V, N, K, rows, Ybuf, (const u16*)nullptr, (u16*)nullptr);
   if (planes == 1)
     hipLaunchKernelGGL(large_spectral_kernel<1>, dim3(B), dim3(512), 0, (hipStream_t)stream, dinp,
                        Ybuf, G, Wt, B, K, S, Tt);
@@ -1051,6 +1096,20 @@ extern "C" int lnz_large_pack_vectors(const float* V, int B, int N, int K, int p
   else
     hipLaunchKernelGGL(large_pack_vectors_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, V, B, N, K, Vb);
   return lnz::check_launch("lnz_large_pack_vectors");
+}
+
+extern "C" int lnz_large_spectral(const float* X, int ldx, int din, const float* V, const float* G,
+                                  const float* Wt, int B, int N, int K, int S, int planes,
+                                  float* Ybuf, uint16_t* Tt, lnz_stream_t stream) {
+  return large_spectral_launch(X, ldx, din, V, G, Wt, B, N, K, S, planes, Ybuf, Tt, nullptr, nullptr, stream);
+}
+
+extern "C" int lnz_large_spectral_gemm1_rows(const float* X, int ldx, int din, const float* V,
+                                             const float* G, const float* Wt, const uint16_t* Wf,
+                                             int B, int N, int K, int S, float* Ybuf, uint16_t* Tt,
+                                             uint16_t* Z, lnz_stream_t stream) {
+  LNZ_REQUIRE(Wf && Z, LNZ_EINVAL, "lnz_large_spectral_gemm1_rows: bad arguments");
+  return large_spectral_launch(X, ldx, din, V, G, Wt, B, N, K, S, 1, Ybuf, Tt, Wf, Z, stream);
 }
 
 extern "C" int lnz_large_conv(const uint16_t* Lb, const uint16_t* Vb, const uint16_t* Zt,

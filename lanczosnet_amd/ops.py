@@ -562,6 +562,9 @@ def large_pack_vectors(V, planes=1):
   return Vb
 
 
+_FUSED_PROJECT_GEMM1 = os.environ.get('LNZ_FUSED_PROJECT_GEMM1', '1') != '0'
+
+
 def large_sparse_work_buffers(B, N, device):
   """(Z, Tt, Ybuf) of large_sparse_conv_layer: Z [B,N,128] bf16, Tt [1,B,128,64] bf16 (zero: stays
   zero without long scales), Ybuf [B,64,128] fp32 (zero; the spectral kernels keep it zero)."""
@@ -586,12 +589,17 @@ def large_sparse_conv_layer(X, din, img, Vb, V, Wf, Wt, G, bias, work, relu=True
     out = torch.empty((B, N, 128), dtype=torch.float32, device=X.device)
   with torch.cuda.device(X.device):
     abi = _abi()
-    abi.large_gemm1_rows(X, X.shape[2], din, Wf, B, N, Z)
     if G is not None:
       K, S = V.shape[2], G.shape[1]
       assert V.dtype == torch.float32 and V.is_contiguous()
       assert G.is_contiguous() and G.dtype == torch.float32 and tuple(G.shape) == (B, S, K)
-      abi.large_spectral(X, X.shape[2], din, V, G, Wt, B, N, K, S, 1, Ybuf, Tt)
+      if _FUSED_PROJECT_GEMM1:
+        abi.large_spectral_gemm1_rows(X, X.shape[2], din, V, G, Wt, Wf, B, N, K, S, Ybuf, Tt, Z)
+      else:
+        abi.large_gemm1_rows(X, X.shape[2], din, Wf, B, N, Z)
+        abi.large_spectral(X, X.shape[2], din, V, G, Wt, B, N, K, S, 1, Ybuf, Tt)
+    else:
+      abi.large_gemm1_rows(X, X.shape[2], din, Wf, B, N, Z)
     abi.large_conv(None, Vb, None, Tt, bias, B, N, 0, 1, 0, out)
     abi.large_sparse_conv(img.entries, img.counts, img.cap, Z, B, N, int(bool(relu)), out)
   return out

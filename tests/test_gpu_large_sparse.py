@@ -130,9 +130,13 @@ def test_sparse_layer_matches_the_streamed_layer_and_fp64(B, N, K, din, S, p):
   Y = np.einsum('bnk,bnd->bkd', V.astype(np.float64), X.astype(np.float64))
   T = sum(G[:, s, :, None] * np.einsum('bkd,od->bko', Y, W[:, s].astype(np.float64)) for s in range(S))
   ref = np.maximum(ref + np.einsum('bnk,bko->bno', V.astype(np.float64), T), 0.0)
-  sparse = ops.large_sparse_conv_layer(Xd, din, img, Vb2, Vd, Wf, Wt, Gd, bd,
-                                       ops.large_sparse_work_buffers(B, N, DEV))
+  wfull = ops.large_sparse_work_buffers(B, N, DEV)
+  sparse = ops.large_sparse_conv_layer(Xd, din, img, Vb2, Vd, Wf, Wt, Gd, bd, wfull)
   assert np.abs(sparse.cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max()
+  # the projection launch also wrote Z (one pass over X): lnz_large_gemm1_rows's bits
+  Zsep = torch.empty_like(wfull[0])
+  ops._abi().large_gemm1_rows(Xd, din, din, Wf, B, N, Zsep)
+  assert torch.equal(wfull[0].view(torch.int16), Zsep.view(torch.int16))
   # without long scales: Tt stays zero, the lift adds the bias alone
   # (against the launch's OWN Z — a product near a bf16 rounding tie may round the other way in the
   # fp64 restatement — only the fp32 accumulation order is left: 1e-5)
