@@ -232,6 +232,12 @@ int lnz_large_gemm1_rows(const float* X, int ldx, int din, const uint16_t* Wf, i
                          uint16_t* Z, lnz_stream_t stream);
 int lnz_large_sparse_conv(const uint32_t* entries, const int32_t* counts, int row_cap,
                           const uint16_t* Z, int B, int N, int relu, float* X, lnz_stream_t stream);
+/* The readout on the last large-graph conv state (model/lanczos_net_general.py:185-201 /
+ * model/lanczos_net.py:185-194): score [B,P] = mean over the real nodes (mask [B,N] != 0) of
+ * (W_h x + b_h) * sigmoid(w_g x + b_g); X [B,N,128] fp32, Whead [P + 1][128] = the output Linear's
+ * rows then the gate's, bhead [P + 1]; P <= 16.  One pass over X, deterministic. */
+int lnz_large_head(const float* X, const uint8_t* mask, const float* Whead, const float* bhead, int B,
+                   int N, int P, float* score, lnz_stream_t stream);
 /* lnz_large_spectral (planes = 1) and lnz_large_gemm1_rows in one pass over X: the projection's
  * X tile in LDS also yields Z (the same bits as lnz_large_gemm1_rows). */
 int lnz_large_spectral_gemm1_rows(const float* X, int ldx, int din, const float* V, const float* G,

@@ -81,6 +81,7 @@ SIGNATURES = {
     'lnz_large_conv': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'lnz_large_sparse_image': (C.c_int, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'lnz_large_spectral_gemm1_rows': (C.c_int, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'lnz_large_head': (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
     'lnz_large_sparse_conv_f32': (C.c_int, [_P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
     'lnz_large_pack_vectors': (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     'lnz_large_gemm1_rows': (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _P]),

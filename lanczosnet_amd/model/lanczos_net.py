@@ -602,6 +602,7 @@ class _LanczosNetBase(nn.Module):
     # next `large_sparse_backoff` calls on this device do not try again (twice as many after every
     # further failure in a row, up to 32 x).
     large_sparse = os.environ.get('LANCZOSNET_LARGE_SPARSE', '1') != '0'
+    large_head_kernel = os.environ.get('LANCZOSNET_LARGE_HEAD', '1') != '0'
     large_sparse_backoff = 32
 
     def _large_sparse_layers(self, node_feat, Lf, Vf, G, planes=1):
@@ -698,6 +699,11 @@ class _LanczosNetBase(nn.Module):
             if verify is None or verify():
                 break
             # a folded channel differed in this batch: the guess is dropped, pack every channel
+        if self.large_head_kernel and self.output_dim <= 16 and state.shape[2] == 128:
+            # the readout in one pass over the state (csrc/head_large.hip)
+            Wh = torch.cat([self.filter[-1].weight.detach().float(), self.att_func[0].weight.detach().float()])
+            bh = torch.cat([self.filter[-1].bias.detach().float(), self.att_func[0].bias.detach().float()])
+            return ops.large_head(state, mask, Wh, bh)
         y = self.filter[-1](state) * self.att_func(state)
         m = (mask != 0).float().unsqueeze(2)
         return (y * m).sum(dim=1) / m.sum(dim=1)

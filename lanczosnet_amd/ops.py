@@ -562,6 +562,19 @@ def large_pack_vectors(V, planes=1):
   return Vb
 
 
+def large_head(X, mask_u8, Whead, bhead):
+  """lnz_large_head: score [B,P] = masked mean of (W_h x + b_h) * sigmoid(w_g x + b_g) over the
+  last conv state X [B,N,128]; Whead [P + 1,128] (the gate's row last), bhead [P + 1]."""
+  _need_cuda(X, mask_u8, Whead, bhead)
+  assert X.dtype == torch.float32 and X.is_contiguous() and X.shape[2] == 128
+  B, N, _ = X.shape
+  P = Whead.shape[0] - 1
+  score = torch.empty((B, P), dtype=torch.float32, device=X.device)
+  with torch.cuda.device(X.device):
+    _abi().large_head(X, mask_u8.to(torch.uint8).contiguous(), _f32c(Whead), _f32c(bhead), B, N, P, score)
+  return score
+
+
 _FUSED_PROJECT_GEMM1 = os.environ.get('LNZ_FUSED_PROJECT_GEMM1', '1') != '0'
 
 

@@ -361,3 +361,24 @@ def test_collate_leaves_the_image_on_L_and_the_module_uses_it():
       assert len(calls) == 2 and st['image_from'] == 'forward'
   finally:
     ops.large_sparse_image = orig
+
+
+@pytest.mark.parametrize('B,N,P', [(3, 300, 2), (2, 2048, 2), (5, 77, 5), (2, 130, 16), (1, 33, 1)])
+def test_large_head_matches_the_torch_readout(B, N, P):
+  """lnz_large_head = (W_h x + b_h) * sigmoid(w_g x + b_g), mean over the real nodes (ragged masks,
+  holes in the mask), against the fp64 torch form at 1e-6; deterministic."""
+  from lanczosnet_amd import ops
+  g = torch.Generator(device=DEV).manual_seed(N + P)
+  X = torch.randn((B, N, 128), device=DEV, generator=g)
+  Wh = torch.randn((P + 1, 128), device=DEV, generator=g) / 11.0
+  bh = torch.randn((P + 1,), device=DEV, generator=g)
+  mask = (torch.rand((B, N), device=DEV, generator=g) < 0.8).to(torch.uint8)
+  mask[0, N // 2:] = 0
+  mask[0, 0] = 1
+  got = ops.large_head(X, mask, Wh, bh)
+  assert torch.equal(got, ops.large_head(X, mask, Wh, bh))
+  Xd, Wd, bd = X.double(), Wh.double(), bh.double()
+  y = (Xd @ Wd[:P].T + bd[:P]) * torch.sigmoid(Xd @ Wd[P:].T + bd[P:])
+  m = (mask != 0).double().unsqueeze(2)
+  ref = (y * m).sum(1) / m.sum(1)
+  assert (got.double() - ref).abs().max() <= 1e-6 * ref.abs().max()
