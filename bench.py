@@ -403,6 +403,9 @@ def graph_config_leg(dev, B=64, reps=5):
           sl['done'] = torch.cuda.Event()
           sl['done'].record(s_fwd)
       nb = 100
+      import gc
+      gc.collect()
+      gc.disable()   # (wall-clock windows: no ~75 ms collection pause inside, see main())
       for warm in (True, False):
         prep(slots[0])
         torch.cuda.synchronize()
@@ -449,6 +452,9 @@ def graph_config_leg(dev, B=64, reps=5):
       del g4, outs4
   except Exception as e:   # (a secondary line: the leg's numbers above do not depend on it)
     pipelined = {'error': repr(e)[:200]}
+  finally:
+    import gc
+    gc.enable()
   t0 = time.perf_counter()
   Ln = L[:16, :, :, 0].cpu().numpy().astype(np.float64)
   worst = 0.0
@@ -1080,6 +1086,13 @@ def main():
       Lp, tiles, rows, D, V = nLp, ntiles, nrows, nD, nV
     return score
 
+  # The interpreter's cyclic collector is kept out of the timed region: a full collection over the
+  # process's objects is a ~75 ms pause (seen as ONE 3x slower step in tools/bench_train_step.py when
+  # an unrelated change moved its schedule) — a hundred steps of this loop.  Collected now, off until
+  # the clock stops.
+  import gc
+  gc.collect()
+  gc.disable()
   with torch.no_grad():
     if args.pipeline:
       score = run_pipelined(args.warmup)
@@ -1103,6 +1116,7 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+  gc.enable()
   per_rank_ms = None
   if dist:
     # every rank's own clock (a SCALE run explains itself: which rank was the slow one), then the

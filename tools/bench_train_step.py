@@ -31,9 +31,14 @@ def step():
 
 for _ in range(3):
   step()
+# (a full cyclic collection is a ~75 ms pause: with ten timed steps one of them inside the window
+# reads as a 3x slower step — collected here, frozen, and the window is thirty steps)
+import gc
+gc.collect()
+gc.freeze()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-K = 10
+K = 30
 for _ in range(K):
   loss = step()
 torch.cuda.synchronize()

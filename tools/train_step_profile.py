@@ -38,6 +38,9 @@ else:
 for _ in range(4):
   step()
 torch.cuda.synchronize()
+import gc
+gc.collect()
+gc.freeze()
 t0 = time.perf_counter()
 for _ in range(K):
   loss = step()
