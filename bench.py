@@ -1158,10 +1158,13 @@ def main():
       for _ in range(60):
         step()
       torch.cuda.synchronize()
+      gc.collect()
+      gc.disable()
       t1 = time.perf_counter()
       for _ in range(50):
         step()
       torch.cuda.synchronize()
+      gc.enable()
       sustained = {'ms_per_step': round(1e3 * (time.perf_counter() - t1) / 50, 4),
                    'note': '50 steps timed behind %d + 60 untimed ones (the timed region of `value` sits behind %d)'
                            % (args.warmup + args.steps, args.warmup)}
@@ -1172,10 +1175,13 @@ def main():
     with torch.no_grad():
       run_pipelined(args.warmup)
       torch.cuda.synchronize()
+      gc.collect()
+      gc.disable()
       t1 = time.perf_counter()
       sp = run_pipelined(args.steps)
       torch.cuda.synchronize()
       elp = time.perf_counter() - t1
+      gc.enable()
     pipe = {'mode': 'one launch prepares batch k+1 (plan + Lanczos/eigensolve + pack) and computes the '
                     'spectral gains of batch k; then forward of batch k (lnz_prepare_batch_prev_gains)',
             'value': round(B * args.steps / elp, 1), 'unit': 'molecules/s',
@@ -1193,11 +1199,14 @@ def main():
         s2 = step()
       torch.cuda.synchronize()
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      gc.collect()
+      gc.disable()
       t1 = time.perf_counter()
       for i in range(args.steps):
         s2 = step()
       torch.cuda.synchronize()
       el2 = time.perf_counter() - t1
+      gc.enable()
       # the stages of this mode's step (the gains launch carries the pack's conversion along)
       evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(min(args.steps, 20))]
       for e_ in evs:
