@@ -29,6 +29,9 @@ net = LanczosNetGeneral(make_model_config(cfg, general=True)).eval().to(dev)
 t = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
 ad, nd, Xd, md = t(adjs), t(ns), t(X), t(mask)
 res = {}
+import gc
+gc.collect()
+gc.disable()   # (wall-clock windows below: no collection pause inside)
 with torch.no_grad():
   def step():
     L = ops.laplacian_l4(ad, nd)
