@@ -319,3 +319,37 @@ def test_round6_host_side_queries_and_argument_checks_without_gpu():
                                null, null, null, null, null, null, null) == _lib.LNZ_EINVAL
   assert lib.lnz_node_extents(null, 4, 20, null, null, null, null) == _lib.LNZ_EINVAL
   assert lib.lnz_last_kernel() is not None
+
+
+def test_sparse_large_graph_entries_refuse_before_they_launch():
+  """The round's large-graph additions answer bad requests on the host (no GPU needed): missing
+  pointers, row capacities that are not multiples of 8 / below 32, too many readout columns, a
+  column stride the K-step entry cannot read, an image request without the compact mode; and the
+  row-capacity rule of the Python side."""
+  import torch
+  from lanczosnet_amd import _lib, ops
+  lib = _lib.load()
+  null = C.c_void_p(None)
+  one = C.c_void_p(16)   # (a non-NULL, aligned "pointer": every call below fails before anything is touched)
+  assert lib.lnz_large_sparse_image(null, 0, 0, 0, 0, 1, 64, 2, 64, null, null, null, null, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_large_sparse_image(one, 0, 0, 0, 0, 1, 64, 2, 20, one, null, one, one, null) == _lib.LNZ_EINVAL
+  assert b'row_cap' in lib.lnz_last_error()
+  assert lib.lnz_large_sparse_image(one, 0, 0, 0, 0, 1, 70000, 2, 64, one, null, one, one, null) == _lib.LNZ_ENOTSUP
+  assert lib.lnz_large_sparse_conv(one, one, 24, one, 1, 64, 1, one, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_large_sparse_conv(null, one, 64, one, 1, 64, 1, one, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_large_sparse_conv_f32(one, null, one, 64, one, 1, 64, 1, one, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_large_gemm1_rows(one, 8, 10, one, 1, 64, one, null) == _lib.LNZ_EINVAL      # ldx < din
+  assert lib.lnz_large_gemm1_rows(one, 200, 200, one, 1, 64, one, null) == _lib.LNZ_ENOTSUP   # width > 128
+  assert lib.lnz_large_pack_vectors(one, 1, 64, 65, 1, one, null) == _lib.LNZ_ENOTSUP         # K > 64
+  assert lib.lnz_large_head(one, one, one, one, 1, 64, 17, one, null) == _lib.LNZ_ENOTSUP
+  assert lib.lnz_large_head(null, one, one, one, 1, 64, 2, one, null) == _lib.LNZ_EINVAL
+  assert lib.lnz_stream_create_cu_masked(0, 64, null) == _lib.LNZ_EINVAL
+  # column stride 3; stride 2 without the compact image / without the fallback flags
+  args = lambda sc, flags, fb: (one, 0, 0, sc, null, 1, 256, 8, 8, flags, 64, one, 1 << 40, one, one, null, fb, null)  # noqa: E731
+  assert lib.lnz_lanczos_ritz_kstep(*args(3, 2, one)) == _lib.LNZ_ENOTSUP
+  assert lib.lnz_lanczos_ritz_kstep(*args(2, 1, one)) == _lib.LNZ_ENOTSUP
+  assert lib.lnz_lanczos_ritz_kstep(*args(2, 2, null)) == _lib.LNZ_ENOTSUP
+  rc = lib.lnz_lanczos_ritz_kstep_image(one, 0, 0, 1, null, 1, 256, 8, 8, 1, 64, one, 1 << 40, one, one, null, null,
+                                        one, null, one, 64, one, null)
+  assert rc == _lib.LNZ_EINVAL and b'COMPACT' in lib.lnz_last_error()
+  assert [ops.large_sparse_row_cap(n) for n in (100, 256, 1024, 2048, 8192, 65536)] == [32, 32, 32, 64, 256, 256]
