@@ -223,6 +223,11 @@ def lanczos_ritz_kstep(A, n_nodes, M, K, symmetric=True, compact=True, row_cap=N
   Np = (N + 3) // 4 * 4
   aligned = Np == N and A.stride(1) % 4 == 0 and A.stride(0) % 4 == 0 and A.data_ptr() % 16 == 0
   in_place = aligned and (A.stride(2) == 1 or (compact and A.stride(2) == 2))
+  if in_place and A.stride(2) == 2:
+    # the pair form reads float4s: the last one of a row ends one element behind the row's last
+    # entry — inside the storage for channel 0 of a [.., N, 2] block, not for every stride-2 view
+    last = A.storage_offset() + (B - 1) * A.stride(0) + (N - 1) * A.stride(1) + 2 * N
+    in_place = last * 4 <= A.untyped_storage().nbytes()
   if not in_place:
     Ap = torch.zeros((B, Np, Np), dtype=torch.float32, device=A.device)
     Ap[:, :N, :N] = A

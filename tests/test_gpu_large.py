@@ -648,3 +648,28 @@ def test_qm8_schema_molecules_beyond_the_32_node_tile():
   ref = oracle.lanczos_net_forward(P, cfg, b['node_feat'], Lo, Do, Vo, b['node_mask'], dtype=np.float64)
   per = np.abs(score - ref).max(axis=1) / np.abs(ref).max()
   assert per.max() < 1e-5, per
+
+
+def test_kstep_entry_stride_2_view_without_room_behind_its_last_row_is_copied():
+  """The in-place pair form reads float4s; a stride-2 view whose last row ends at the end of its
+  storage (every other column of a [B,N,2N-1] tensor) has no element behind its last entry: it takes
+  the copy, and gives the pairs of the contiguous matrix."""
+  from lanczosnet_amd import ops
+  N, M, B = 256, 16, 2
+  A = torch.from_numpy(_graphs(B, N, 0.03, seed=9)).to(DEV)
+  wide = torch.zeros((B, N, 2 * N - 1), device=DEV)
+  wide[:, :, ::2] = A
+  view = wide[:, :, ::2]
+  assert view.stride(2) == 2 and view.stride(1) % 4 != 0      # (odd row pitch: not aligned either)
+  Dv, Vv = ops.lanczos_ritz_kstep(view, None, M, M)
+  Dc, Vc = ops.lanczos_ritz_kstep(A, None, M, M)
+  assert (Dv - Dc).abs().max() < 1e-6 and _projector_gap(Vv, Vc) < 1e-5
+  wide2 = torch.zeros((B, N, 2 * N), device=DEV)               # aligned rows, room behind: in place
+  wide2[:, :, ::2] = A
+  Dw, Vw = ops.lanczos_ritz_kstep(wide2[:, :, ::2], None, M, M)
+  assert (Dw - Dc).abs().max() < 1e-6 and _projector_gap(Vw, Vc) < 1e-5
+  flat = torch.zeros((B * N * 2 * N + 0,), device=DEV)        # exactly [B,N,N,2] minus nothing: the collate case
+  L = flat.view(B, N, N, 2)
+  L[..., 0] = A
+  Dl, Vl = ops.lanczos_ritz_kstep(L[..., 0], None, M, M)
+  assert (Dl - Dc).abs().max() < 1e-6 and _projector_gap(Vl, Vc) < 1e-5
