@@ -29,6 +29,8 @@
 // csrc/lanczos_large.hip — the collated Laplacian is then read from HBM once per batch.)
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace {
 
 typedef unsigned short u16;
@@ -43,12 +45,13 @@ constexpr int DH = 128;
 #ifndef LNZ_SPARSE_GS
 #define LNZ_SPARSE_GS 8
 #endif
-// Gathers go out in groups of GS entries behind one uniform test each (a row's count rounded up to
-// GS; the image pads rows with zero entries up to a multiple of 8).  B = 256, N = 2048, 21.5 entries
-// per row: GS = 8 0.275 ms; 4 0.311, 2 0.449, 1 0.700 (every test is a point the loads behind it wait
-// at); 16 0.288, 32 0.347 (padding gathers).
+// A row's count is rounded up to GS (the image pads rows with zero entries up to a multiple of 8) and
+// a turn of the gather is ONE uniform decision followed by a straight line of GS .. 32 loads and their
+// FMAs.  With a uniform test in front of every group of GS instead (B = 256, N = 2048, 21.5 entries
+// per row): GS = 8 0.275 ms; 4 0.311, 2 0.449, 1 0.700 — every test is a point the loads behind it
+// wait at —; 16 0.288, 32 0.347 (padding gathers).  Straight-line turns: GS = 8 0.264, GS = 4 0.265.
 constexpr int GS = LNZ_SPARSE_GS;
-static_assert(GS == 1 || GS == 2 || GS == 4 || GS == 8, "the image pads rows to multiples of 8");
+static_assert(GS == 4 || GS == 8, "the image pads rows to multiples of 8; a turn is at most 8 groups");
 constexpr int ROWS_PER_WAVE = LNZ_SPARSE_ROWS_PER_WAVE, WAVES = LNZ_SPARSE_WAVES, TILE_ROWS = ROWS_PER_WAVE * WAVES;
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -212,28 +215,29 @@ __global__ __launch_bounds__(64 * WAVES) void sparse_conv_kernel(
       if (k0 > 0) e = entries(rr, k0, cnt8);   // (rows of more than 64 entries)
       const int m = min(64, cnt8 - k0);
       for (int k = 0; k < m; k += 32) {
-        unsigned z[32 / GS][GS];
-        float s[32 / GS][GS];
+        // ONE uniform decision per turn, then a straight line of 8, 16, 24 or 32 gathers and their
+        // FMAs (a test per group of eight was a point the loads behind it waited at)
+        auto turn = [&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          unsigned z[n];
+          float s[n];
 #pragma unroll
-        for (int g = 0; g < 32 / GS; ++g) {
-          if (k + GS * g < m) {   // (uniform)
-#pragma unroll
-            for (int u = 0; u < GS; ++u) {
-              const unsigned se = (unsigned)__builtin_amdgcn_readlane((int)e, k + GS * g + u);
-              s[g][u] = __uint_as_float(se & 0xffff0000u);
-              z[g][u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(z_rsrc, zoff, (se & 0xffffu) * (DH * 2), 0);
-            }
+          for (int u = 0; u < n; ++u) {
+            const unsigned se = (unsigned)__builtin_amdgcn_readlane((int)e, k + u);
+            s[u] = __uint_as_float(se & 0xffff0000u);
+            z[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(z_rsrc, zoff, (se & 0xffffu) * (DH * 2), 0);
           }
-        }
 #pragma unroll
-        for (int g = 0; g < 32 / GS; ++g) {
-          if (k + GS * g < m) {
-#pragma unroll
-            for (int u = 0; u < GS; ++u) {
-              acc[0] = fmaf(s[g][u], __uint_as_float(z[g][u] << 16), acc[0]);
-              acc[1] = fmaf(s[g][u], __uint_as_float(z[g][u] & 0xffff0000u), acc[1]);
-            }
+          for (int u = 0; u < n; ++u) {
+            acc[0] = fmaf(s[u], __uint_as_float(z[u] << 16), acc[0]);
+            acc[1] = fmaf(s[u], __uint_as_float(z[u] & 0xffff0000u), acc[1]);
           }
+        };
+        switch (min(32, m - k) / GS) {   // (m - k is a multiple of GS)
+#define LNZ_TURN(q) case q: if constexpr (q * GS <= 32) turn(std::integral_constant<int, (q * GS <= 32 ? q * GS : 32)>{}); break;
+          LNZ_TURN(1) LNZ_TURN(2) LNZ_TURN(3) LNZ_TURN(4) LNZ_TURN(5) LNZ_TURN(6) LNZ_TURN(7) LNZ_TURN(8)
+#undef LNZ_TURN
+          default: break;
         }
       }
     }
@@ -287,29 +291,24 @@ __global__ __launch_bounds__(64 * WAVES) void sparse_conv_f32_kernel(
       if (k0 > 0) entries(rr, k0, cnt8, e, v);   // (rows of more than 64 entries)
       const int m = min(64, cnt8 - k0);
       for (int k = 0; k < m; k += 16) {
-        f32x2 z[2][8];
-        float s[2][8];
+        auto turn = [&](auto nc) {   // (one uniform decision, then a straight line: see the bf16 form)
+          constexpr int n = decltype(nc)::value;
+          f32x2 z[n];
+          float s[n];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if (k + 8 * g < m) {   // (uniform)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const unsigned col = (unsigned)__builtin_amdgcn_readlane((int)e, k + 8 * g + u) & 0xffffu;
-              s[g][u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k + 8 * g + u));
-              z[g][u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, zoff, col * (DH * 4), 0));
-            }
+          for (int u = 0; u < n; ++u) {
+            const unsigned col = (unsigned)__builtin_amdgcn_readlane((int)e, k + u) & 0xffffu;
+            s[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k + u));
+            z[u] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, zoff, col * (DH * 4), 0));
           }
-        }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if (k + 8 * g < m) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              acc[0] = fmaf(s[g][u], z[g][u][0], acc[0]);
-              acc[1] = fmaf(s[g][u], z[g][u][1], acc[1]);
-            }
+          for (int u = 0; u < n; ++u) {
+            acc[0] = fmaf(s[u], z[u][0], acc[0]);
+            acc[1] = fmaf(s[u], z[u][1], acc[1]);
           }
-        }
+        };
+        if (m - k > 8) turn(std::integral_constant<int, 16>{});
+        else turn(std::integral_constant<int, 8>{});
       }
     }
     if (relu) {
